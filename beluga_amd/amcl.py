@@ -1,0 +1,292 @@
+"""Host-side mirror of the reference's filter interface, backed by the HIP library.
+
+`Amcl` has the surface of `beluga::Amcl` (beluga/include/beluga/algorithm/amcl_core.hpp:81-233) /
+`beluga_ros::Amcl` (beluga_ros/include/beluga_ros/amcl.hpp:102-282): same constructor ingredients
+(map, motion model params, sensor model params, AmclParams), `particles()`, `initialize(pose, covariance)`,
+`update_map(map)`, `update(control_action, measurement)` returning `None` where the reference returns
+`std::nullopt`, and `force_update()`.  Parameter classes carry the reference's field names and defaults.
+All per-particle work happens in libbeluga_mcl.so on the GPU; this module only marshals arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class AmclParams:
+    """beluga::AmclParams (amcl_core.hpp:34-55) + beluga_ros spatial resolutions (beluga_ros/amcl.hpp:90-97)."""
+    update_min_d: float = 0.25
+    update_min_a: float = 0.2
+    resample_interval: int = 1
+    selective_resampling: bool = False
+    min_particles: int = 500
+    max_particles: int = 2000
+    alpha_slow: float = 0.001
+    alpha_fast: float = 0.1
+    kld_epsilon: float = 0.05
+    kld_z: float = 3.0
+    spatial_resolution_x: float = 0.5
+    spatial_resolution_y: float = 0.5
+    spatial_resolution_theta: float = 10.0 * math.pi / 180.0
+
+
+@dataclass
+class DifferentialDriveModelParam:
+    """motion/differential_drive_model.hpp:40-68."""
+    rotation_noise_from_rotation: float
+    rotation_noise_from_translation: float
+    translation_noise_from_translation: float
+    translation_noise_from_rotation: float
+    distance_threshold: float = 0.01
+
+
+@dataclass
+class LikelihoodFieldModelParam:
+    """sensor/likelihood_field_model_base.hpp:42-64."""
+    max_obstacle_distance: float = 100.0
+    max_laser_distance: float = 2.0
+    z_hit: float = 0.5
+    z_random: float = 0.5
+    sigma_hit: float = 0.2
+    model_unknown_space: bool = False
+    only_obstacle_boundaries: bool = False
+
+
+@dataclass
+class BeamModelParam:
+    """sensor/beam_model.hpp:43-58."""
+    z_hit: float = 0.5
+    z_short: float = 0.5
+    z_max: float = 0.05
+    z_rand: float = 0.05
+    sigma_hit: float = 0.2
+    lambda_short: float = 0.1
+    beam_max_range: float = 60.0
+
+
+@dataclass
+class OccupancyGrid:
+    """An OccupancyGrid2 (sensor/data/occupancy_grid.hpp:39-75): row-major int8 cells, resolution, origin, value traits."""
+    cells: np.ndarray  # (H, W) int8
+    resolution: float
+    origin: Sequence[float] = (1.0, 0.0, 0.0, 0.0)  # SE2 as (cos, sin, x, y)
+    value_traits: Tuple[int, int, int] = (0, -1, 100)  # free, unknown, occupied
+
+
+def se2_from_xytheta(x: float, y: float, theta: float) -> np.ndarray:
+    return np.array([math.cos(theta), math.sin(theta), x, y], dtype=np.float64)
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(capi.c_double_p)
+
+
+class Amcl:
+    def __init__(self, grid: OccupancyGrid, motion: DifferentialDriveModelParam, sensor, params: AmclParams = AmclParams(), *,
+                 seed: int = 0, device: int = 0, shard_offset: int = 0, shard_capacity: int = 0, hip_stream: int = 0):
+        self._lib = capi.load()
+        cfg = capi.Config()
+        self._lib.mcl_default_config(C.byref(cfg))
+        cfg.device_id = device
+        cfg.seed = seed
+        for k in ("update_min_d", "update_min_a", "resample_interval", "min_particles", "max_particles", "alpha_slow",
+                  "alpha_fast", "kld_epsilon", "kld_z", "spatial_resolution_x", "spatial_resolution_y", "spatial_resolution_theta"):
+            setattr(cfg.amcl, k, getattr(params, k))
+        cfg.amcl.selective_resampling = int(params.selective_resampling)
+        for k in ("rotation_noise_from_rotation", "rotation_noise_from_translation", "translation_noise_from_translation",
+                  "translation_noise_from_rotation", "distance_threshold"):
+            setattr(cfg.motion, k, getattr(motion, k))
+        if isinstance(sensor, LikelihoodFieldModelParam):
+            cfg.sensor_kind = capi.MCL_SENSOR_LIKELIHOOD_FIELD
+            for k in ("max_obstacle_distance", "max_laser_distance", "z_hit", "z_random", "sigma_hit"):
+                setattr(cfg.lf, k, getattr(sensor, k))
+            cfg.lf.model_unknown_space = int(sensor.model_unknown_space)
+            cfg.lf.only_obstacle_boundaries = int(sensor.only_obstacle_boundaries)
+        elif isinstance(sensor, BeamModelParam):
+            cfg.sensor_kind = capi.MCL_SENSOR_BEAM
+            for k in ("z_hit", "z_short", "z_max", "z_rand", "sigma_hit", "lambda_short", "beam_max_range"):
+                setattr(cfg.beam, k, getattr(sensor, k))
+        else:
+            raise ValueError("sensor must be LikelihoodFieldModelParam or BeamModelParam")
+        cfg.shard_offset = shard_offset
+        cfg.shard_capacity = shard_capacity
+        cfg.hip_stream = hip_stream or None
+        self.params = params
+        self._cfg = cfg
+        self._ctx = capi._ctx()
+        st = self._lib.mcl_create(C.byref(cfg), C.byref(self._ctx))
+        if st != capi.MCL_OK:
+            msg = self._lib.mcl_last_error(None).decode()
+            self._ctx = None
+            raise capi.MclError(st, msg)
+        self._shape = None
+        self.last_info = None
+        self.update_map(grid)
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.mcl_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != capi.MCL_OK:
+            raise capi.MclError(st, self._lib.mcl_last_error(self._ctx).decode())
+
+    # -- reference surface -------------------------------------------------------------------------
+    def update_map(self, grid: OccupancyGrid):
+        """Amcl::update_map (amcl_core.hpp:150)."""
+        cells = np.ascontiguousarray(grid.cells, dtype=np.int8)
+        H, W = cells.shape
+        origin = np.ascontiguousarray(grid.origin, dtype=np.float64)
+        traits = (C.c_int8 * 3)(*grid.value_traits)
+        self._check(self._lib.mcl_set_map(self._ctx, cells.ctypes.data_as(capi.c_i8_p), W, H, float(grid.resolution), _dp(origin),
+                                          traits))
+        self._shape = (H, W)
+
+    def likelihood_field(self) -> np.ndarray:
+        """LikelihoodFieldModelBase::likelihood_field() (likelihood_field_model_base.hpp:102)."""
+        out = np.zeros(self._shape, dtype=np.float32)
+        self._check(self._lib.mcl_get_likelihood_field(self._ctx, out.ctypes.data_as(capi.c_float_p)))
+        return out
+
+    def set_likelihood_field(self, field: np.ndarray):
+        field = np.ascontiguousarray(field, dtype=np.float32)
+        assert field.shape == self._shape
+        self._check(self._lib.mcl_set_likelihood_field(self._ctx, field.ctypes.data_as(capi.c_float_p)))
+
+    def initialize(self, pose_xytheta, covariance):
+        """Amcl::initialize(pose, covariance) (amcl_core.hpp:145-147). Raises RuntimeError on a bad covariance."""
+        m = np.ascontiguousarray(pose_xytheta, dtype=np.float64)
+        cv = np.ascontiguousarray(covariance, dtype=np.float64).reshape(9)
+        st = self._lib.mcl_initialize_normal(self._ctx, _dp(m), _dp(cv))
+        if st == capi.MCL_ERR_BAD_COVARIANCE:
+            raise RuntimeError("Invalid covariance matrix")  # multivariate_normal_distribution.hpp:114-124
+        self._check(st)
+
+    def set_particles(self, states, weights):
+        """Amcl::initialize(distribution) with caller-drawn states (amcl_core.hpp:131-137)."""
+        s = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 4)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        assert len(s) == len(w)
+        self._check(self._lib.mcl_set_particles(self._ctx, _dp(s), _dp(w), len(w)))
+
+    def num_particles(self) -> int:
+        n = C.c_uint64(0)
+        self._check(self._lib.mcl_num_particles(self._ctx, C.byref(n)))
+        return n.value
+
+    def particles(self):
+        """Amcl::particles() (amcl_core.hpp:127): (states[n,4] as (cos,sin,x,y), weights[n])."""
+        n = self.num_particles()
+        s, w = np.zeros((n, 4)), np.zeros(n)
+        got = C.c_uint64(0)
+        self._check(self._lib.mcl_get_particles(self._ctx, _dp(s), _dp(w), n, C.byref(got)))
+        return s, w
+
+    def force_update(self):
+        """Amcl::force_update() (amcl_core.hpp:204)."""
+        self._check(self._lib.mcl_force_update(self._ctx))
+
+    def update(self, control_action, measurement) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        """Amcl::update (amcl_core.hpp:165-201). Returns (pose (cos,sin,x,y), covariance 3x3) or None."""
+        ctrl = np.ascontiguousarray(control_action, dtype=np.float64)
+        pts = np.ascontiguousarray(measurement, dtype=np.float64).reshape(-1, 2)
+        est, info = capi.Estimate(), capi.UpdateInfo()
+        self._check(self._lib.mcl_update(self._ctx, _dp(ctrl), _dp(pts), len(pts), C.byref(est), C.byref(info)))
+        self.last_info = {
+            "updated": bool(info.updated), "resampled": bool(info.resampled), "num_particles": info.num_particles,
+            "weight_sum": info.weight_sum, "ess": info.effective_sample_size,
+            "random_state_probability": info.random_state_probability,
+        }
+        if not info.updated:
+            return None
+        return np.array(est.pose), np.array(est.covariance).reshape(3, 3)
+
+    # -- stage-level entry points (parity tests, multi-GPU driver) ------------------------------------
+    def propagate(self, pose, previous_pose, step: int):
+        a = np.ascontiguousarray(pose, dtype=np.float64)
+        b = np.ascontiguousarray(previous_pose, dtype=np.float64)
+        self._check(self._lib.mcl_propagate(self._ctx, _dp(a), _dp(b), step))
+
+    def reweight(self, measurement):
+        pts = np.ascontiguousarray(measurement, dtype=np.float64).reshape(-1, 2)
+        self._check(self._lib.mcl_reweight(self._ctx, _dp(pts), len(pts)))
+
+    def weight_sum(self) -> float:
+        v = C.c_double(0)
+        self._check(self._lib.mcl_weight_sum(self._ctx, C.byref(v)))
+        return v.value
+
+    def normalize(self, factor: float = float("nan")):
+        st = capi.WeightStats()
+        self._check(self._lib.mcl_normalize(self._ctx, factor, C.byref(st)))
+        return {"sum": st.sum, "norm_sum": st.norm_sum, "norm_sumsq": st.norm_sumsq}
+
+    def resample(self, random_state_probability: float, step: int) -> int:
+        n = C.c_uint64(0)
+        self._check(self._lib.mcl_resample(self._ctx, random_state_probability, step, C.byref(n)))
+        return n.value
+
+    def estimate_sums(self, pivot=(0.0, 0.0)) -> np.ndarray:
+        p = np.ascontiguousarray(pivot, dtype=np.float64)
+        out = np.zeros(12)
+        self._check(self._lib.mcl_estimate_sums(self._ctx, _dp(p), _dp(out)))
+        return out
+
+    def estimate(self):
+        est = capi.Estimate()
+        self._check(self._lib.mcl_estimate_pose(self._ctx, C.byref(est)))
+        return np.array(est.pose), np.array(est.covariance).reshape(3, 3)
+
+    def build_cdf(self) -> float:
+        t = C.c_double(0)
+        self._check(self._lib.mcl_build_cdf(self._ctx, C.byref(t)))
+        return t.value
+
+    def device_view(self) -> capi.DeviceView:
+        v = capi.DeviceView()
+        self._check(self._lib.mcl_get_device_view(self._ctx, C.byref(v)))
+        return v
+
+    def set_num_particles(self, n: int):
+        self._check(self._lib.mcl_set_num_particles(self._ctx, n))
+
+    def gather_by_cdf(self, d_targets: int, m: int, d_x: int, d_y: int, d_c: int, d_s: int):
+        self._check(self._lib.mcl_gather_by_cdf(self._ctx, d_targets, m, d_x, d_y, d_c, d_s))
+
+    def sync(self):
+        self._check(self._lib.mcl_sync(self._ctx))
+
+    # -- measurement hooks ---------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._check(self._lib.mcl_profile_enable(self._ctx, int(on)))
+
+    def profile_read(self, reset: bool = True):
+        ms = (C.c_double * 5)()
+        cnt = (C.c_uint64 * 5)()
+        self._check(self._lib.mcl_profile_read(self._ctx, ms, cnt, int(reset)))
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(capi.STAGES)}
+
+
+def estimate_from_sums(sums: np.ndarray):
+    lib = capi.load()
+    s = np.ascontiguousarray(sums, dtype=np.float64)
+    est = capi.Estimate()
+    st = lib.mcl_estimate_from_sums(_dp(s), C.byref(est))
+    if st != capi.MCL_OK:
+        raise capi.MclError(st, "mcl_estimate_from_sums")
+    return np.array(est.pose), np.array(est.covariance).reshape(3, 3)

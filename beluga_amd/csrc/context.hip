@@ -1,0 +1,934 @@
+// context.hip — mcl_ctx and the C ABI of include/beluga_mcl.h.
+//
+// Host-side control flow of beluga::Amcl::update (amcl_core.hpp:165-201): the policies, the 2-deep
+// control window and the recovery estimator run on the host exactly as in the reference and consume
+// device-computed sums; everything that touches N particles is a kernel launch on the context's
+// stream (kernels.hip).  There is no CPU fallback for any per-particle stage.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "beluga_mcl.h"
+#include "kernels.h"
+#include "map_build.h"
+
+namespace {
+
+using namespace mcl;
+
+thread_local std::string g_create_error;
+
+// algorithm/exponential_filter.hpp:32-44
+struct ExponentialFilter {
+  double alpha{0.}, output{0.};
+  void reset() { output = 0.; }
+  double operator()(double input) {
+    output += (output == 0.) ? input : alpha * (input - output);
+    return output;
+  }
+};
+
+template <class T>
+struct DeviceBuffer {
+  T* ptr{nullptr};
+  size_t count{0};
+  hipError_t ensure(size_t n) {
+    if (n <= count) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
+    if (e == hipSuccess) count = n;
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+  }
+};
+
+struct ParticleSet {
+  DeviceBuffer<double> x, y, c, s, w;
+  hipError_t ensure(size_t n) {
+    hipError_t e;
+    if ((e = x.ensure(n)) != hipSuccess) return e;
+    if ((e = y.ensure(n)) != hipSuccess) return e;
+    if ((e = c.ensure(n)) != hipSuccess) return e;
+    if ((e = s.ensure(n)) != hipSuccess) return e;
+    return w.ensure(n);
+  }
+  void release() {
+    x.release();
+    y.release();
+    c.release();
+    s.release();
+    w.release();
+  }
+  ParticleSoA view() const { return ParticleSoA{x.ptr, y.ptr, c.ptr, s.ptr, w.ptr}; }
+};
+
+Pose2 pose_from(const double p[4]) { return Pose2{Rot2{p[0], p[1]}, p[2], p[3]}; }
+
+// motion/differential_drive_model.hpp:129-154,167-173
+double rotation_variance(const Rot2& r) {
+  const Rot2 flipped = rot_mul(r, rot_exp(kPi));
+  const double delta = std::min(std::abs(rot_log(r)), std::abs(rot_log(flipped)));
+  return delta * delta;
+}
+DiffDriveSampler make_sampler(const Pose2& pose, const Pose2& prev, const mcl_diffdrive_params& a) {
+  const double tx = pose.x - prev.x, ty = pose.y - prev.y;
+  const double distance = std::sqrt(tx * tx + ty * ty);
+  const double distance_variance = distance * distance;
+  const Rot2 heading = rot_exp(std::atan2(ty, tx));
+  const Rot2 first = distance > a.distance_threshold ? rot_mul(heading, rot_inverse(prev.r)) : Rot2{1.0, 0.0};
+  const Rot2 second = rot_mul(rot_mul(pose.r, rot_inverse(prev.r)), rot_inverse(first));
+  DiffDriveSampler s;
+  s.m1 = rot_log(first);
+  s.s1 = std::sqrt(a.rotation_noise_from_rotation * rotation_variance(first) + a.rotation_noise_from_translation * distance_variance);
+  s.mt = distance;
+  s.st = std::sqrt(a.translation_noise_from_translation * distance_variance +
+                   a.translation_noise_from_rotation * (rotation_variance(first) + rotation_variance(second)));
+  s.m2 = rot_log(second);
+  s.s2 = std::sqrt(a.rotation_noise_from_rotation * rotation_variance(second) + a.rotation_noise_from_translation * distance_variance);
+  return s;
+}
+
+// Symmetric 3x3 eigen-decomposition (cyclic Jacobi): T = V sqrt(L)  (multivariate_normal_distribution.hpp:109-126).
+bool covariance_to_transform(const double cov[9], double T[9]) {
+  double a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) a[i][j] = cov[3 * i + j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = i + 1; j < 3; ++j) {
+      const double scale = std::max(std::abs(a[i][j]), std::abs(a[j][i]));
+      if (std::abs(a[i][j] - a[j][i]) > 1e-12 * scale) return false;  // "not symmetric"
+      if (!std::isfinite(a[i][j])) return false;
+    }
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (a[p][q] == 0.0) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::abs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) {
+          const double akp = a[k][p], akq = a[k][q];
+          a[k][p] = c * akp - s * akq;
+          a[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double apk = a[p][k], aqk = a[q][k];
+          a[p][k] = c * apk - s * aqk;
+          a[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double vkp = v[k][p], vkq = v[k][q];
+          v[k][p] = c * vkp - s * vkq;
+          v[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int j = 0; j < 3; ++j) {
+    if (!std::isfinite(a[j][j])) return false;
+    if (a[j][j] < 0.0) {
+      if (a[j][j] > -1e-14) a[j][j] = 0.0;
+      else return false;  // "negative eigenvalues"
+    }
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) T[3 * i + j] = v[i][j] * std::sqrt(a[j][j]);
+  return true;
+}
+
+}  // namespace
+
+struct mcl_ctx {
+  mcl_config cfg;
+  std::string error;
+  int device{0};
+  hipStream_t stream{nullptr};
+  bool own_stream{false};
+
+  uint64_t capacity{0};
+  uint64_t n{0};
+  ParticleSet sets[2];
+  int live{0};
+
+  // map
+  bool have_map{false};
+  uint32_t W{0}, H{0};
+  double resolution{0};
+  Pose2 origin{}, origin_inverse{};
+  OccupancyTraits traits{0, -1, 100};
+  DeviceBuffer<float> d_field;
+  DeviceBuffer<int8_t> d_cells;
+  DeviceBuffer<uint32_t> d_free;
+  uint64_t n_free{0};
+  std::vector<float> h_field;
+
+  // scan
+  DeviceBuffer<double> d_points;
+  double* h_points{nullptr};  // pinned
+  size_t h_points_cap{0};
+
+  // reductions / scans
+  DeviceBuffer<double> d_chunk;      // [12][stride]
+  uint32_t chunk_stride{0};
+  DeviceBuffer<double> d_scalars;    // 32 doubles
+  double* h_scalars{nullptr};        // pinned, 32 doubles
+  DeviceBuffer<double> d_cdf;
+  DeviceBuffer<double> d_aos;        // host<->device AoS staging (cap*4)
+
+  // KLD
+  DeviceBuffer<unsigned long long> d_hashes;
+  DeviceBuffer<unsigned long long> d_table_keys;
+  DeviceBuffer<unsigned int> d_table_first;
+  uint64_t table_capacity{0};
+  DeviceBuffer<uint32_t> d_flags, d_uchunk;  // flags[cap]; uchunk[2][stride]
+  DeviceBuffer<unsigned long long> d_kld_scalars;  // [0]=first_fail, [1]=beam steps; as u32 view: k words at [4..]
+  unsigned long long* h_kld_scalars{nullptr};      // pinned, 8 words
+
+  // host-side filter state (amcl_core.hpp:206-232)
+  ExponentialFilter slow, fast;
+  bool have_latest{false};
+  Pose2 latest{};
+  uint64_t every_n_current{0};
+  bool force_update{true};
+  bool have_window{false};
+  Pose2 window0{}, window1{};
+  uint32_t step{0};
+  bool have_pivot{false};
+  double pivot[2]{0, 0};
+  int lf_variant{kLfWavePerParticle};
+
+  // profiling
+  bool profile{false};
+  hipEvent_t ev[MCL_NUM_STAGES][2]{};
+  bool ev_pending[MCL_NUM_STAGES]{};
+  double prof_ms[MCL_NUM_STAGES]{};
+  uint64_t prof_count[MCL_NUM_STAGES]{};
+
+  ParticleSoA cur() const { return sets[live].view(); }
+  ParticleSoA other() const { return sets[live ^ 1].view(); }
+  double* chunk_row(int k) { return d_chunk.ptr + static_cast<size_t>(k) * chunk_stride; }
+  FieldView field_view() const {
+    return FieldView{d_field.ptr, W, H, 1. / resolution, origin_inverse, static_cast<float>(1. / cfg.lf.max_laser_distance)};
+  }
+  GridView grid_view() const { return GridView{d_cells.ptr, W, H, resolution, origin, origin_inverse, traits.free_value}; }
+};
+
+namespace {
+
+mcl_status fail(mcl_ctx* ctx, mcl_status code, const std::string& msg) {
+  if (ctx) ctx->error = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define MCL_HIP(ctx, expr)                                                                               \
+  do {                                                                                                   \
+    const hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) {                                                                              \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? MCL_ERR_OUT_OF_MEMORY : MCL_ERR_HIP,                  \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                    \
+    }                                                                                                    \
+  } while (0)
+
+#define MCL_REQUIRE(ctx, cond, msg) \
+  do {                              \
+    if (!(cond)) return fail(ctx, MCL_ERR_INVALID_ARGUMENT, msg); \
+  } while (0)
+
+mcl_status bind_device(mcl_ctx* ctx) {
+  MCL_HIP(ctx, hipSetDevice(ctx->device));
+  return MCL_OK;
+}
+
+void stage_begin(mcl_ctx* ctx, int stage) {
+  if (!ctx->profile) return;
+  (void)hipEventRecord(ctx->ev[stage][0], ctx->stream);
+}
+void stage_end(mcl_ctx* ctx, int stage) {
+  if (!ctx->profile) return;
+  (void)hipEventRecord(ctx->ev[stage][1], ctx->stream);
+  ctx->ev_pending[stage] = true;
+}
+// Call after the stream has been synchronised.
+void stage_collect(mcl_ctx* ctx) {
+  if (!ctx->profile) return;
+  for (int s = 0; s < MCL_NUM_STAGES; ++s) {
+    if (!ctx->ev_pending[s]) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev[s][0], ctx->ev[s][1]) == hipSuccess) {
+      ctx->prof_ms[s] += ms;
+      ctx->prof_count[s] += 1;
+    }
+    ctx->ev_pending[s] = false;
+  }
+}
+
+mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
+  for (auto& set : ctx->sets) MCL_HIP(ctx, set.ensure(cap));
+  const uint32_t chunks = num_chunks(cap) + 1;
+  ctx->chunk_stride = chunks;
+  MCL_HIP(ctx, ctx->d_chunk.ensure(static_cast<size_t>(12) * chunks));
+  MCL_HIP(ctx, ctx->d_cdf.ensure(cap));
+  MCL_HIP(ctx, ctx->d_aos.ensure(cap * 4));
+  ctx->capacity = cap;
+  return MCL_OK;
+}
+
+mcl_status ensure_kld(mcl_ctx* ctx) {
+  const uint64_t cap = ctx->capacity;
+  MCL_HIP(ctx, ctx->d_hashes.ensure(cap));
+  MCL_HIP(ctx, ctx->d_flags.ensure(cap));
+  MCL_HIP(ctx, ctx->d_uchunk.ensure(static_cast<size_t>(2) * ctx->chunk_stride));
+  uint64_t tc = 1024;
+  while (tc < 2 * cap) tc <<= 1;
+  MCL_HIP(ctx, ctx->d_table_keys.ensure(tc));
+  MCL_HIP(ctx, ctx->d_table_first.ensure(tc));
+  ctx->table_capacity = tc;
+  return MCL_OK;
+}
+
+mcl_status upload_points(mcl_ctx* ctx, const double* pts, uint64_t B) {
+  if (B == 0) return MCL_OK;
+  MCL_HIP(ctx, ctx->d_points.ensure(2 * B));
+  if (ctx->h_points_cap < 2 * B) {
+    if (ctx->h_points) (void)hipHostFree(ctx->h_points);
+    ctx->h_points = nullptr;
+    MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_points), 2 * B * sizeof(double)));
+    ctx->h_points_cap = 2 * B;
+  }
+  // The pinned staging copy lets the H2D run asynchronously; the previous cycle's copy has
+  // completed because every update ends with a stream synchronisation.
+  std::memcpy(ctx->h_points, pts, 2 * B * sizeof(double));
+  MCL_HIP(ctx, hipMemcpyAsync(ctx->d_points.ptr, ctx->h_points, 2 * B * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  return MCL_OK;
+}
+
+mcl_status do_propagate(mcl_ctx* ctx, const Pose2& pose, const Pose2& prev, uint32_t step) {
+  stage_begin(ctx, MCL_STAGE_PROPAGATE);
+  launch_propagate(ctx->stream, ctx->cur(), ctx->n, make_sampler(pose, prev, ctx->cfg.motion), ctx->cfg.seed, step,
+                   ctx->cfg.shard_offset);
+  stage_end(ctx, MCL_STAGE_PROPAGATE);
+  MCL_HIP(ctx, hipGetLastError());
+  return MCL_OK;
+}
+
+mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B) {
+  if (!ctx->have_map) return fail(ctx, MCL_ERR_NOT_READY, "mcl_reweight: no map set");
+  MCL_REQUIRE(ctx, B <= 0xFFFFFFFFull, "too many points");
+  if (const mcl_status s = upload_points(ctx, pts, B)) return s;
+  stage_begin(ctx, MCL_STAGE_REWEIGHT);
+  if (ctx->cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD) {
+    MCL_REQUIRE(ctx, B * sizeof(double2) <= 160 * 1024 || ctx->lf_variant == kLfLanePerParticle, "scan too large for LDS staging");
+    launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B),
+                       ctx->lf_variant);
+  } else {
+    const mcl_beam_params& b = ctx->cfg.beam;
+    launch_reweight_beam(ctx->stream, ctx->cur(), ctx->n, ctx->grid_view(),
+                         BeamModel{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range},
+                         ctx->d_points.ptr, static_cast<uint32_t>(B), ctx->d_kld_scalars.ptr + 1);
+  }
+  stage_end(ctx, MCL_STAGE_REWEIGHT);
+  MCL_HIP(ctx, hipGetLastError());
+  return MCL_OK;
+}
+
+// d_scalars layout: [0] weight sum, [1] norm_sum, [2] norm_sumsq, [3] factor override, [4] cdf total, [8..16] estimate sums
+mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats) {
+  stage_begin(ctx, MCL_STAGE_NORMALIZE);
+  launch_weight_sum(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->d_scalars.ptr + 0);
+  const double* d_factor = ctx->d_scalars.ptr + 0;
+  if (!std::isnan(factor)) {
+    ctx->h_scalars[3] = factor;
+    MCL_HIP(ctx, hipMemcpyAsync(ctx->d_scalars.ptr + 3, ctx->h_scalars + 3, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    d_factor = ctx->d_scalars.ptr + 3;
+  }
+  launch_normalize(ctx->stream, ctx->cur().w, ctx->n, d_factor, ctx->chunk_row(1), ctx->chunk_row(2), ctx->d_scalars.ptr + 1);
+  MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars.ptr, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  stage_end(ctx, MCL_STAGE_NORMALIZE);
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  stage_collect(ctx);
+  if (stats) {
+    stats->sum = ctx->h_scalars[0];
+    stats->norm_sum = ctx->h_scalars[1];
+    stats->norm_sumsq = ctx->h_scalars[2];
+  }
+  return MCL_OK;
+}
+
+mcl_status do_build_cdf(mcl_ctx* ctx) {
+  launch_cdf(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(3), ctx->chunk_row(4), ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4);
+  MCL_HIP(ctx, hipGetLastError());
+  return MCL_OK;
+}
+
+mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t step, uint64_t* n_out) {
+  const mcl_amcl_params& a = ctx->cfg.amcl;
+  MCL_REQUIRE(ctx, ctx->n > 0, "mcl_resample: empty particle set");
+  const uint64_t max_p = std::min<uint64_t>(a.max_particles, ctx->capacity);
+  stage_begin(ctx, MCL_STAGE_RESAMPLE);
+  if (const mcl_status s = do_build_cdf(ctx)) return s;
+  ResampleArgs ra{};
+  ra.seed = ctx->cfg.seed;
+  ra.step = step;
+  ra.random_state_probability = random_state_probability;
+  ra.n_in = ctx->n;
+  const FreeCells fc{ctx->d_free.ptr, ctx->have_map ? ctx->n_free : 0};
+  const HashParams hp{a.spatial_resolution_x, a.spatial_resolution_y, a.spatial_resolution_theta};
+  const GridView gv = ctx->grid_view();
+  uint64_t result = max_p;
+  if (a.min_particles >= max_p) {
+    // count <= min holds for every candidate (take_while_kld.hpp:86): plain take(max).
+    ra.first_candidate = 0;
+    ra.count = max_p;
+    ra.out_offset = 0;
+    launch_resample_draw(ctx->stream, ctx->cur(), ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp, nullptr);
+    MCL_HIP(ctx, hipGetLastError());
+  } else {
+    if (ctx->table_capacity == 0) {
+      if (const mcl_status s = ensure_kld(ctx)) return s;
+    }
+    MCL_REQUIRE(ctx, max_p < 0xFFFFFFFFull, "max_particles too large for KLD resampling");
+    MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_keys.ptr, 0xFF, ctx->table_capacity * sizeof(unsigned long long), ctx->stream));
+    MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_first.ptr, 0xFF, ctx->table_capacity * sizeof(unsigned int), ctx->stream));
+    MCL_HIP(ctx, hipMemsetAsync(ctx->d_kld_scalars.ptr, 0xFF, sizeof(unsigned long long), ctx->stream));  // first_fail = ~0
+    uint32_t* kwords = reinterpret_cast<uint32_t*>(ctx->d_kld_scalars.ptr + 4);                          // [0]=k_base,[1]=k_total
+    MCL_HIP(ctx, hipMemsetAsync(kwords, 0, 2 * sizeof(uint32_t), ctx->stream));
+    const KldTable table{ctx->d_table_keys.ptr, ctx->d_table_first.ptr, ctx->table_capacity};
+    uint64_t pos = 0;
+    uint64_t chunk = std::max<uint64_t>(a.min_particles + 1, 1ull << 16);
+    int flip = 0;
+    while (pos < max_p) {
+      const uint64_t cnt = std::min(chunk, max_p - pos);
+      ra.first_candidate = pos;
+      ra.count = cnt;
+      ra.out_offset = pos;
+      launch_resample_draw(ctx->stream, ctx->cur(), ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp,
+                           ctx->d_hashes.ptr);
+      launch_kld_insert(ctx->stream, ctx->d_hashes.ptr, pos, cnt, table);
+      launch_kld_scan(ctx->stream, ctx->d_hashes.ptr, pos, cnt, table, ctx->d_flags.ptr, ctx->d_uchunk.ptr,
+                      ctx->d_uchunk.ptr + ctx->chunk_stride, kwords + flip, kwords + (flip ^ 1), a.min_particles, a.kld_epsilon,
+                      a.kld_z, ctx->d_kld_scalars.ptr);
+      MCL_HIP(ctx, hipGetLastError());
+      MCL_HIP(ctx, hipMemcpyAsync(ctx->h_kld_scalars, ctx->d_kld_scalars.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                  ctx->stream));
+      MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->h_kld_scalars[0] != ~0ull) {
+        result = ctx->h_kld_scalars[0];  // the first element failing the predicate is dropped (take_while)
+        break;
+      }
+      pos += cnt;
+      flip ^= 1;
+      chunk *= 2;
+    }
+    result = std::min(result, max_p);  // | take(max)
+  }
+  stage_end(ctx, MCL_STAGE_RESAMPLE);
+  ctx->live ^= 1;
+  ctx->n = result;
+  if (n_out) *n_out = result;
+  return MCL_OK;
+}
+
+mcl_status do_estimate_sums(mcl_ctx* ctx, const double pivot[2], double sums[12]) {
+  stage_begin(ctx, MCL_STAGE_ESTIMATE);
+  launch_estimate_sums(ctx->stream, ctx->cur(), ctx->n, pivot[0], pivot[1], ctx->chunk_row(0), ctx->d_scalars.ptr + 8);
+  MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, ctx->d_scalars.ptr + 8, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  stage_end(ctx, MCL_STAGE_ESTIMATE);
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  stage_collect(ctx);
+  for (int k = 0; k < 9; ++k) sums[k] = ctx->h_scalars[8 + k];
+  sums[9] = pivot[0];
+  sums[10] = pivot[1];
+  sums[11] = 0.0;
+  return MCL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mcl_version(void) { return "beluga_mcl 0.1 (gfx950)"; }
+
+void mcl_default_config(mcl_config* cfg) {
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->sensor_kind = MCL_SENSOR_LIKELIHOOD_FIELD;
+  cfg->amcl.update_min_d = 0.25;
+  cfg->amcl.update_min_a = 0.2;
+  cfg->amcl.resample_interval = 1;
+  cfg->amcl.selective_resampling = 0;
+  cfg->amcl.min_particles = 500;
+  cfg->amcl.max_particles = 2000;
+  cfg->amcl.alpha_slow = 0.001;
+  cfg->amcl.alpha_fast = 0.1;
+  cfg->amcl.kld_epsilon = 0.05;
+  cfg->amcl.kld_z = 3.0;
+  cfg->amcl.spatial_resolution_x = 0.5;
+  cfg->amcl.spatial_resolution_y = 0.5;
+  cfg->amcl.spatial_resolution_theta = 10.0 * kPi / 180.0;
+  cfg->motion.distance_threshold = 0.01;
+  cfg->lf = mcl_lf_params{100.0, 2.0, 0.5, 0.5, 0.2, 0, 0};
+  cfg->beam = mcl_beam_params{0.5, 0.5, 0.05, 0.05, 0.2, 0.1, 60.0};
+}
+
+const char* mcl_last_error(const mcl_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, MCL_ERR_INVALID_ARGUMENT, "mcl_create: null argument");
+  *out = nullptr;
+  if (cfg->amcl.max_particles == 0 || cfg->amcl.resample_interval == 0)
+    return fail(nullptr, MCL_ERR_INVALID_ARGUMENT, "mcl_create: max_particles and resample_interval must be > 0");
+  if (cfg->sensor_kind != MCL_SENSOR_LIKELIHOOD_FIELD && cfg->sensor_kind != MCL_SENSOR_BEAM)
+    return fail(nullptr, MCL_ERR_INVALID_ARGUMENT, "mcl_create: unknown sensor_kind");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    return fail(nullptr, MCL_ERR_NO_DEVICE, "mcl_create: no HIP device (this library has no CPU fallback)");
+  if (cfg->device_id < 0 || cfg->device_id >= count) return fail(nullptr, MCL_ERR_INVALID_ARGUMENT, "mcl_create: bad device_id");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device_id) != hipSuccess) return fail(nullptr, MCL_ERR_HIP, "hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, MCL_ERR_NO_DEVICE, std::string("mcl_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+
+  mcl_ctx* ctx = new (std::nothrow) mcl_ctx();
+  if (!ctx) return fail(nullptr, MCL_ERR_OUT_OF_MEMORY, "mcl_create: host allocation failed");
+  ctx->cfg = *cfg;
+  ctx->device = cfg->device_id;
+  ctx->slow.alpha = cfg->amcl.alpha_slow;
+  ctx->fast.alpha = cfg->amcl.alpha_fast;
+  mcl_status st = MCL_OK;
+  auto init = [&]() -> mcl_status {
+    MCL_HIP(ctx, hipSetDevice(ctx->device));
+    if (cfg->hip_stream) {
+      ctx->stream = static_cast<hipStream_t>(cfg->hip_stream);
+    } else {
+      MCL_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = true;
+    }
+    const uint64_t cap = cfg->shard_capacity ? cfg->shard_capacity : cfg->amcl.max_particles;
+    if (const mcl_status s = ensure_capacity(ctx, cap)) return s;
+    MCL_HIP(ctx, ctx->d_scalars.ensure(32));
+    MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalars), 32 * sizeof(double)));
+    MCL_HIP(ctx, ctx->d_kld_scalars.ensure(8));
+    MCL_HIP(ctx, hipMemsetAsync(ctx->d_kld_scalars.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_kld_scalars), 8 * sizeof(unsigned long long)));
+    for (auto& pair : ctx->ev)
+      for (auto& e : pair) MCL_HIP(ctx, hipEventCreate(&e));
+    if (const char* v = std::getenv("BELUGA_MCL_LF_VARIANT")) ctx->lf_variant = std::atoi(v) == 1 ? kLfLanePerParticle : kLfWavePerParticle;
+    return MCL_OK;
+  };
+  st = init();
+  if (st != MCL_OK) {
+    g_create_error = ctx->error;
+    mcl_destroy(ctx);
+    return st;
+  }
+  *out = ctx;
+  return MCL_OK;
+}
+
+void mcl_destroy(mcl_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& set : ctx->sets) set.release();
+  ctx->d_field.release();
+  ctx->d_cells.release();
+  ctx->d_free.release();
+  ctx->d_points.release();
+  ctx->d_chunk.release();
+  ctx->d_scalars.release();
+  ctx->d_cdf.release();
+  ctx->d_aos.release();
+  ctx->d_hashes.release();
+  ctx->d_table_keys.release();
+  ctx->d_table_first.release();
+  ctx->d_flags.release();
+  ctx->d_uchunk.release();
+  ctx->d_kld_scalars.release();
+  if (ctx->h_points) (void)hipHostFree(ctx->h_points);
+  if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+  if (ctx->h_kld_scalars) (void)hipHostFree(ctx->h_kld_scalars);
+  for (auto& pair : ctx->ev)
+    for (auto& e : pair)
+      if (e) (void)hipEventDestroy(e);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32_t height, double resolution,
+                       const double origin[4], const int8_t value_traits[3]) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, cells && origin && value_traits && width > 0 && height > 0 && resolution > 0, "mcl_set_map: bad argument");
+  MCL_REQUIRE(ctx, static_cast<uint64_t>(width) * height < 0xFFFFFFFFull, "mcl_set_map: grid too large");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  const size_t n = static_cast<size_t>(width) * height;
+  ctx->W = width;
+  ctx->H = height;
+  ctx->resolution = resolution;
+  ctx->origin = pose_from(origin);
+  ctx->origin_inverse = pose_inverse(ctx->origin);  // likelihood_field_model_base.hpp:99 ; raycasting.hpp:69
+  ctx->traits = OccupancyTraits{value_traits[0], value_traits[1], value_traits[2]};
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MCL_HIP(ctx, ctx->d_cells.ensure(n));
+  MCL_HIP(ctx, hipMemcpy(ctx->d_cells.ptr, cells, n, hipMemcpyHostToDevice));
+  std::vector<uint32_t> free_cells;
+  collect_free_cells(cells, width, height, ctx->traits, free_cells);
+  ctx->n_free = free_cells.size();
+  MCL_HIP(ctx, ctx->d_free.ensure(std::max<size_t>(free_cells.size(), 1)));
+  if (!free_cells.empty())
+    MCL_HIP(ctx, hipMemcpy(ctx->d_free.ptr, free_cells.data(), free_cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (ctx->cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD) {
+    build_likelihood_field(cells, width, height, resolution, ctx->traits, ctx->cfg.lf, ctx->h_field);
+    MCL_HIP(ctx, ctx->d_field.ensure(n));
+    MCL_HIP(ctx, hipMemcpy(ctx->d_field.ptr, ctx->h_field.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  ctx->have_map = true;
+  return MCL_OK;
+}
+
+mcl_status mcl_get_likelihood_field(mcl_ctx* ctx, float* out) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, out, "null output");
+  if (!ctx->have_map || !ctx->d_field.ptr) return fail(ctx, MCL_ERR_NOT_READY, "no likelihood field");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MCL_HIP(ctx, hipMemcpy(out, ctx->d_field.ptr, static_cast<size_t>(ctx->W) * ctx->H * sizeof(float), hipMemcpyDeviceToHost));
+  return MCL_OK;
+}
+
+mcl_status mcl_set_likelihood_field(mcl_ctx* ctx, const float* field) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, field, "null field");
+  if (!ctx->have_map) return fail(ctx, MCL_ERR_NOT_READY, "set the map first");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  const size_t n = static_cast<size_t>(ctx->W) * ctx->H;
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MCL_HIP(ctx, ctx->d_field.ensure(n));
+  MCL_HIP(ctx, hipMemcpy(ctx->d_field.ptr, field, n * sizeof(float), hipMemcpyHostToDevice));
+  return MCL_OK;
+}
+
+mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], const double cov[9]) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, mean_xytheta && cov, "null argument");
+  double T[9];
+  if (!covariance_to_transform(cov, T)) return fail(ctx, MCL_ERR_BAD_COVARIANCE, "Invalid covariance matrix");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  const uint64_t n = std::min<uint64_t>(ctx->cfg.amcl.max_particles, ctx->capacity);  // take_exactly(max_particles)
+  launch_init_normal(ctx->stream, ctx->cur(), n, mean_xytheta, T, ctx->cfg.seed, ctx->cfg.shard_offset);
+  MCL_HIP(ctx, hipGetLastError());
+  ctx->n = n;
+  ctx->force_update = true;  // amcl_core.hpp:136
+  return MCL_OK;
+}
+
+mcl_status mcl_set_particles(mcl_ctx* ctx, const double* states, const double* weights, uint64_t n) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, n == 0 || (states && weights), "null argument");
+  MCL_REQUIRE(ctx, n <= ctx->capacity, "mcl_set_particles: n exceeds capacity");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  if (n) {
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MCL_HIP(ctx, hipMemcpy(ctx->d_aos.ptr, states, n * 4 * sizeof(double), hipMemcpyHostToDevice));
+    MCL_HIP(ctx, hipMemcpy(ctx->cur().w, weights, n * sizeof(double), hipMemcpyHostToDevice));
+    launch_aos_to_soa(ctx->stream, ctx->d_aos.ptr, ctx->cur(), n);
+    MCL_HIP(ctx, hipGetLastError());
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ctx->n = n;
+  ctx->force_update = true;
+  return MCL_OK;
+}
+
+mcl_status mcl_num_particles(mcl_ctx* ctx, uint64_t* n) {
+  if (!ctx || !n) return MCL_ERR_INVALID_ARGUMENT;
+  *n = ctx->n;
+  return MCL_OK;
+}
+
+mcl_status mcl_get_particles(mcl_ctx* ctx, double* states, double* weights, uint64_t capacity, uint64_t* n) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, capacity >= ctx->n, "mcl_get_particles: output too small");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  if (ctx->n) {
+    launch_soa_to_aos(ctx->stream, ctx->cur(), ctx->d_aos.ptr, ctx->n);
+    MCL_HIP(ctx, hipGetLastError());
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (states) MCL_HIP(ctx, hipMemcpy(states, ctx->d_aos.ptr, ctx->n * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    if (weights) MCL_HIP(ctx, hipMemcpy(weights, ctx->cur().w, ctx->n * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (n) *n = ctx->n;
+  return MCL_OK;
+}
+
+mcl_status mcl_force_update(mcl_ctx* ctx) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  ctx->force_update = true;
+  return MCL_OK;
+}
+
+mcl_status mcl_propagate(mcl_ctx* ctx, const double pose[4], const double previous_pose[4], uint32_t step) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, pose && previous_pose, "null argument");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  return do_propagate(ctx, pose_from(pose), pose_from(previous_pose), step);
+}
+
+mcl_status mcl_reweight(mcl_ctx* ctx, const double* points_xy, uint64_t num_points) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, num_points == 0 || points_xy, "null points");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  return do_reweight(ctx, points_xy, num_points);
+}
+
+mcl_status mcl_weight_sum(mcl_ctx* ctx, double* sum) {
+  if (!ctx || !sum) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  launch_weight_sum(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->d_scalars.ptr + 0);
+  MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars.ptr, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *sum = ctx->h_scalars[0];
+  return MCL_OK;
+}
+
+mcl_status mcl_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  return do_normalize(ctx, factor, stats);
+}
+
+mcl_status mcl_resample(mcl_ctx* ctx, double random_state_probability, uint32_t step, uint64_t* n_out) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  const mcl_status s = do_resample(ctx, random_state_probability, step, n_out);
+  if (s == MCL_OK) {
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    stage_collect(ctx);
+  }
+  return s;
+}
+
+mcl_status mcl_estimate_sums(mcl_ctx* ctx, const double pivot_xy[2], double sums[12]) {
+  if (!ctx || !sums) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  const double zero[2] = {0, 0};
+  return do_estimate_sums(ctx, pivot_xy ? pivot_xy : zero, sums);
+}
+
+// algorithm/estimation.hpp:436-475 from the single-pass sufficient statistics.
+mcl_status mcl_estimate_from_sums(const double sums[12], mcl_estimate* out) {
+  if (!sums || !out) return MCL_ERR_INVALID_ARGUMENT;
+  const double sw = sums[0], sw2 = sums[1];
+  const double mc = sums[2] / sw, ms = sums[3] / sw;
+  const double mdx = sums[4] / sw, mdy = sums[5] / sw;
+  const double sq = sw2 / (sw * sw);  // sum of squared normalised weights
+  const double corr = 1.0 - sq;       // estimation.hpp:270
+  const double cxx = (sums[6] / sw - mdx * mdx) / corr;
+  const double cxy = (sums[7] / sw - mdx * mdy) / corr;
+  const double cyy = (sums[8] / sw - mdy * mdy) / corr;
+  for (double& v : out->covariance) v = 0.0;
+  out->covariance[0] = cxx;
+  out->covariance[1] = cxy;
+  out->covariance[3] = cxy;
+  out->covariance[4] = cyy;
+  out->pose[2] = sums[9] + mdx;
+  out->pose[3] = sums[10] + mdy;
+  const double norm = std::sqrt(mc * mc + ms * ms);
+  if (norm < std::numeric_limits<double>::epsilon()) {  // estimation.hpp:460-466
+    out->covariance[8] = std::numeric_limits<double>::infinity();
+    const Rot2 zero = rot_exp(0.0);
+    out->pose[0] = zero.c;
+    out->pose[1] = zero.s;
+  } else {
+    out->covariance[8] = -2.0 * std::log(norm);
+    const Rot2 r = rot_from_complex(mc, ms);
+    out->pose[0] = r.c;
+    out->pose[1] = r.s;
+  }
+  return MCL_OK;
+}
+
+mcl_status mcl_estimate_pose(mcl_ctx* ctx, mcl_estimate* out) {
+  if (!ctx || !out) return MCL_ERR_INVALID_ARGUMENT;
+  if (ctx->n == 0) return fail(ctx, MCL_ERR_NOT_READY, "no particles");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  double sums[12];
+  if (const mcl_status s = do_estimate_sums(ctx, ctx->pivot, sums)) return s;
+  const mcl_status s = mcl_estimate_from_sums(sums, out);
+  if (s == MCL_OK && std::isfinite(out->pose[2]) && std::isfinite(out->pose[3])) {
+    ctx->pivot[0] = out->pose[2];
+    ctx->pivot[1] = out->pose[3];
+  }
+  return s;
+}
+
+mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* points_xy, uint64_t num_points,
+                      mcl_estimate* estimate, mcl_update_info* info) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, control_pose && (num_points == 0 || points_xy), "null argument");
+  if (info) {
+    std::memset(info, 0, sizeof(*info));
+    info->effective_sample_size = -1.0;
+    info->num_particles = ctx->n;
+  }
+  if (ctx->n == 0) return MCL_OK;  // amcl_core.hpp:166-168 -> nullopt
+  const Pose2 pose = pose_from(control_pose);
+  // update_policy_ = on_motion (policies/on_motion.hpp:63-67,121-133); evaluated even when forced (:170)
+  bool moved;
+  if (!ctx->have_latest) {
+    ctx->latest = pose;
+    ctx->have_latest = true;
+    moved = true;
+  } else {
+    const Pose2 delta = pose_mul(pose_inverse(ctx->latest), pose);
+    moved = std::sqrt(delta.x * delta.x + delta.y * delta.y) > ctx->cfg.amcl.update_min_d ||
+            std::abs(rot_log(delta.r)) > ctx->cfg.amcl.update_min_a;
+    if (moved) ctx->latest = pose;
+  }
+  if (!moved && !ctx->force_update) return MCL_OK;
+  if (const mcl_status s = bind_device(ctx)) return s;
+
+  // control_action_window_ << control (RollingWindow<SE2,2>: newest first, extrapolates when short)
+  if (!ctx->have_window) {
+    ctx->window0 = ctx->window1 = pose;
+    ctx->have_window = true;
+  } else {
+    ctx->window1 = ctx->window0;
+    ctx->window0 = pose;
+  }
+  ctx->step += 1;
+
+  if (const mcl_status s = do_propagate(ctx, ctx->window0, ctx->window1, ctx->step)) return s;  // :174-175
+  if (const mcl_status s = do_reweight(ctx, points_xy, num_points)) return s;                    // :176
+  mcl_weight_stats stats{};
+  if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), &stats)) return s;  // :177
+
+  // :179 ThrunRecoveryProbabilityEstimator on the NORMALISED weights (thrun_..._estimator.hpp:69-89)
+  double random_state_probability = 0.0;
+  {
+    const double average = stats.norm_sum / static_cast<double>(ctx->n);
+    const double fast_average = ctx->fast(average);
+    const double slow_average = ctx->slow(average);
+    if (std::abs(slow_average) >= std::numeric_limits<double>::epsilon())
+      random_state_probability = std::clamp(1.0 - fast_average / slow_average, 0.0, 1.0);
+  }
+  // :181 every_n [&& on_effective_size_drop] (every_n.hpp:47-50, on_effective_size_drop.hpp:45-49)
+  ctx->every_n_current = (ctx->every_n_current + 1) % ctx->cfg.amcl.resample_interval;
+  bool do_resampling = ctx->every_n_current == 0;
+  double ess = -1.0;
+  if (do_resampling && ctx->cfg.amcl.selective_resampling) {
+    ess = stats.norm_sum == 0.0 ? 0.0 : (stats.norm_sum * stats.norm_sum) / stats.norm_sumsq;  // effective_sample_size.hpp:46-59
+    do_resampling = ess < static_cast<double>(ctx->n) * 0.5;
+  }
+  if (do_resampling) {
+    if (random_state_probability > 0.0) {  // :184-186
+      ctx->slow.reset();
+      ctx->fast.reset();
+    }
+    if (const mcl_status s = do_resample(ctx, random_state_probability, ctx->step, nullptr)) return s;  // :188-196
+  }
+  ctx->force_update = false;  // :199
+  mcl_estimate est{};
+  if (const mcl_status s = mcl_estimate_pose(ctx, &est)) return s;  // :200
+  if (estimate) *estimate = est;
+  if (info) {
+    info->updated = 1;
+    info->resampled = do_resampling ? 1 : 0;
+    info->num_particles = ctx->n;
+    info->weight_sum = stats.sum;
+    info->effective_sample_size = ess;
+    info->random_state_probability = random_state_probability;
+  }
+  return MCL_OK;
+}
+
+mcl_status mcl_get_device_view(mcl_ctx* ctx, mcl_device_view* view) {
+  if (!ctx || !view) return MCL_ERR_INVALID_ARGUMENT;
+  const ParticleSoA p = ctx->cur();
+  view->x = p.x;
+  view->y = p.y;
+  view->c = p.c;
+  view->s = p.s;
+  view->w = p.w;
+  view->cdf = ctx->d_cdf.ptr;
+  view->n = ctx->n;
+  view->capacity = ctx->capacity;
+  view->hip_stream = ctx->stream;
+  return MCL_OK;
+}
+
+mcl_status mcl_set_num_particles(mcl_ctx* ctx, uint64_t n) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, n <= ctx->capacity, "n exceeds capacity");
+  ctx->n = n;
+  return MCL_OK;
+}
+
+mcl_status mcl_build_cdf(mcl_ctx* ctx, double* total) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  if (ctx->n == 0) {
+    if (total) *total = 0.0;
+    return MCL_OK;
+  }
+  if (const mcl_status s = do_build_cdf(ctx)) return s;
+  if (total) {
+    MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 4, ctx->d_scalars.ptr + 4, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *total = ctx->h_scalars[4];
+  }
+  return MCL_OK;
+}
+
+mcl_status mcl_gather_by_cdf(mcl_ctx* ctx, const double* d_targets, uint64_t m, double* d_out_x, double* d_out_y, double* d_out_c,
+                             double* d_out_s) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, m == 0 || (d_targets && d_out_x && d_out_y && d_out_c && d_out_s), "null argument");
+  MCL_REQUIRE(ctx, m == 0 || ctx->n > 0, "empty shard cannot serve draws");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  launch_gather_by_cdf(ctx->stream, ctx->cur(), ctx->d_cdf.ptr, ctx->n, d_targets, m, d_out_x, d_out_y, d_out_c, d_out_s);
+  MCL_HIP(ctx, hipGetLastError());
+  return MCL_OK;
+}
+
+mcl_status mcl_sync(mcl_ctx* ctx) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  stage_collect(ctx);
+  return MCL_OK;
+}
+
+mcl_status mcl_profile_enable(mcl_ctx* ctx, int32_t on) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  ctx->profile = on != 0;
+  return MCL_OK;
+}
+
+mcl_status mcl_profile_read(mcl_ctx* ctx, double ms[MCL_NUM_STAGES], uint64_t counts[MCL_NUM_STAGES], int32_t reset) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  for (int s = 0; s < MCL_NUM_STAGES; ++s) {
+    if (ms) ms[s] = ctx->prof_ms[s];
+    if (counts) counts[s] = ctx->prof_count[s];
+    if (reset) {
+      ctx->prof_ms[s] = 0;
+      ctx->prof_count[s] = 0;
+    }
+  }
+  return MCL_OK;
+}
+
+}  // extern "C"

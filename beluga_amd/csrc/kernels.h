@@ -1,0 +1,122 @@
+// kernels.h — launchers of the gfx950 kernels behind the C ABI (include/beluga_mcl.h).
+// Data layout in HBM (all owned by mcl_ctx):
+//   particles : structure of arrays, f64:  x[cap] y[cap] c[cap] s[cap] w[cap]   (two state sets: live + resample target)
+//   field     : f32 row-major H x W likelihood field (likelihood_field_model_base.hpp:120), 64 MB at 4000^2
+//   cells     : int8 row-major H x W occupancy grid (beam model + free-space sampling), 16 MB at 4000^2
+//   points    : f64 (x,y) pairs of the current scan, 17 KB at 1080 beams
+//   cdf       : f64 inclusive scan of the normalised weights
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "se2.h"
+
+namespace mcl {
+
+struct ParticleSoA {
+  double* x;
+  double* y;
+  double* c;
+  double* s;
+  double* w;
+};
+
+struct FieldView {
+  const float* data;
+  uint32_t W, H;
+  double inv_resolution;  // 1. / resolution (regular_grid.hpp:76)
+  Pose2 world_to_field;   // grid.origin().inverse() (likelihood_field_model_base.hpp:99)
+  float unknown_value;    // float(1 / max_laser_distance) (likelihood_field_model.hpp:75)
+};
+
+struct GridView {
+  const int8_t* cells;
+  uint32_t W, H;
+  double resolution;
+  Pose2 origin;          // grid frame in the world
+  Pose2 origin_inverse;  // world -> grid
+  int8_t free_value;
+};
+
+struct BeamModel {
+  double z_hit, z_short, z_max, z_rand, sigma_hit, lambda_short, beam_max_range;
+};
+
+struct DiffDriveSampler {  // three (mean, stddev) pairs: first rotation, translation, second rotation
+  double m1, s1, mt, st, m2, s2;
+};
+
+struct FreeCells {
+  const uint32_t* index;  // linear indices of free cells
+  uint64_t count;
+};
+
+struct HashParams {
+  double res_x, res_y, res_theta;
+};
+
+struct ResampleArgs {
+  uint64_t seed;
+  uint32_t step;
+  double random_state_probability;
+  uint64_t n_in;            // live particles of the source set
+  uint64_t first_candidate; // global index of candidate 0 of this launch
+  uint64_t count;           // candidates in this launch
+  uint64_t out_offset;      // where candidate `first_candidate` lands in the output set
+};
+
+enum LfVariant : int { kLfWavePerParticle = 0, kLfLanePerParticle = 1 };
+
+// K1  actions/propagate.hpp:57-79 + differential_drive_model.hpp:156-163
+void launch_propagate(hipStream_t st, ParticleSoA p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
+                      uint64_t index_offset);
+// K2  actions/reweight.hpp:53-60 + likelihood_field_model.hpp:68-91
+void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant);
+// K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
+void launch_reweight_beam(hipStream_t st, ParticleSoA p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
+                          unsigned long long* d_steps);
+
+// Deterministic chunked reductions / scans.  Chunk = 2048 consecutive elements per workgroup.
+constexpr uint32_t kChunk = 2048;
+inline uint32_t num_chunks(uint64_t n) { return static_cast<uint32_t>((n + kChunk - 1) / kChunk); }
+
+// K3a: partial[b] = sum of w over chunk b ; then d_out[0] = sum of partials (fixed order).
+void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_partials, double* d_out);
+// K3b: w[i] /= *d_factor unless |factor-1| < eps (normalize.hpp:73-82); chunk sums of the new w and w^2;
+//      d_out[0] = total of new w, d_out[1] = total of squares.
+void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_factor, double* d_chunk_sum, double* d_chunk_sumsq,
+                      double* d_out);
+// K5: cdf[i] = inclusive scan of w; d_chunk_sum is recomputed; d_total[0] = cdf[n-1].
+void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
+                double* d_total);
+// K6: one thread per candidate (views/sample.hpp:102,133-135; random_intersperse.hpp:90-115; particle_traits.hpp:105).
+void launch_resample_draw(hipStream_t st, ParticleSoA src, const double* cdf, const double* d_total, ParticleSoA dst,
+                          ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes);
+// Sharded variant: targets given, no RNG (mcl_gather_by_cdf).
+void launch_gather_by_cdf(hipStream_t st, ParticleSoA src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
+                          double* ox, double* oy, double* oc, double* os);
+// K7: exact parallel take_while_kld (take_while_kld.hpp:72-88).
+struct KldTable {
+  unsigned long long* keys;  // 0 = empty (hash 0 is remapped)
+  unsigned int* first;       // smallest candidate index that produced the key
+  uint64_t capacity;         // power of two
+};
+void launch_kld_insert(hipStream_t st, const unsigned long long* d_hashes, uint64_t first, uint64_t count, KldTable t);
+// flags[j] = 1 if candidate j is the first with its hash; inclusive scan -> d_k[j]; then the first j
+// violating (j+1 <= min || j+1 <= target(k_base + k[j])) is atomically minimised into *d_first_fail.
+void launch_kld_scan(hipStream_t st, const unsigned long long* d_hashes, uint64_t first, uint64_t count, KldTable t,
+                     uint32_t* d_flags_scan, uint32_t* d_chunk_sum, uint32_t* d_chunk_offset, const uint32_t* d_k_base,
+                     uint32_t* d_k_total, uint64_t min_particles, double epsilon, double z, unsigned long long* d_first_fail);
+// K8: estimation.hpp:436-475 sufficient statistics; d_out[9].
+void launch_estimate_sums(hipStream_t st, ParticleSoA p, uint64_t n, double pivot_x, double pivot_y, double* d_partials,
+                          double* d_out);
+// init: multivariate_normal_distribution.hpp:96-126 with T = V sqrt(L)
+void launch_init_normal(hipStream_t st, ParticleSoA p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
+                        uint64_t index_offset);
+void launch_fill(hipStream_t st, double* p, uint64_t n, double v);
+// AoS (c,s,x,y) host layout <-> SoA device layout
+void launch_aos_to_soa(hipStream_t st, const double* aos, ParticleSoA p, uint64_t n);
+void launch_soa_to_aos(hipStream_t st, ParticleSoA p, double* aos, uint64_t n);
+
+}  // namespace mcl

@@ -1,0 +1,767 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the MCL update cycle.
+//
+// No MFMA anywhere: the cycle is gather + streaming work.  What matters here is
+// coalesced SoA access, keeping the scan in LDS / SGPRs, enough waves in flight to hide gather
+// latency, and deterministic (fixed-order) f64 reductions so runs are reproducible.
+//
+// Built with -ffp-contract=off: the reference (and the oracle) evaluate `p*cos - q*sin + t` with
+// separate roundings (likelihood_field_model.hpp:82-83); a contracted FMA would move a handful of
+// beam end-points across a cell boundary of `floor(x / resolution)` (regular_grid.hpp:75-78).
+#include "kernels.h"
+
+#include <cfloat>
+#include <climits>
+
+#include "rng.h"
+
+namespace mcl {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+
+__device__ __forceinline__ Pose2 load_pose(const ParticleSoA& p, uint64_t i) { return Pose2{Rot2{p.c[i], p.s[i]}, p.x[i], p.y[i]}; }
+__device__ __forceinline__ void store_pose(const ParticleSoA& p, uint64_t i, const Pose2& v) {
+  p.c[i] = v.r.c;
+  p.s[i] = v.r.s;
+  p.x[i] = v.x;
+  p.y[i] = v.y;
+}
+
+// ---- cross-lane helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane must be wave-uniform -> v_readlane_b32 x2 (SGPRs)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+template <int kCtrl>
+__device__ __forceinline__ double dpp_f64(double v) {  // row-local DPP permutation of a 64-bit value
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// Sum over the 64 lanes, fixed association: quads, octets, rows of 16 (DPP), then the four rows in order.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror
+  const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+  return (r0 + r1) + (r2 + r3);
+}
+
+// Deterministic block reduction of K doubles per thread.  Result valid in thread 0.
+template <int K>
+__device__ __forceinline__ void block_reduce(double (&v)[K], double* s_scratch /* [kBlock/64][K] */) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum_f64(v[k]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) s_scratch[wave * K + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double acc = s_scratch[k];
+      for (int w = 1; w < kBlock / 64; ++w) acc += s_scratch[w * K + k];
+      v[k] = acc;
+    }
+  }
+  __syncthreads();
+}
+
+// ---- K1 propagate ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_propagate(ParticleSoA p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
+                                                      uint64_t index_offset) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const RngWords a = rng_draw(seed, step, kRngPropagateA, index_offset + i);
+  const RngWords b = rng_draw(seed, step, kRngPropagateB, index_offset + i);
+  double z0, z1, z2, z3;
+  rng_box_muller(rng_uniform53(a.w[0], a.w[1]), rng_uniform53(a.w[2], a.w[3]), z0, z1);
+  rng_box_muller(rng_uniform53(b.w[0], b.w[1]), rng_uniform53(b.w[2], b.w[3]), z2, z3);
+  const double r1 = z0 * smp.s1 + smp.m1;
+  const double t = z1 * smp.st + smp.mt;
+  const double r2 = z2 * smp.s2 + smp.m2;
+  const Pose2 first{rot_exp(r1), 0.0, 0.0};
+  const Pose2 second{rot_exp(r2), t, 0.0};
+  store_pose(p, i, pose_mul(pose_mul(load_pose(p, i), first), second));
+}
+
+// ---- K2 likelihood-field reweight ------------------------------------------------------------------
+// One beam end-point -> pz^3.  likelihood_field_model.hpp:82-88, dense_grid.hpp:92-96,127-129,
+// regular_grid.hpp:75-78, linear_grid.hpp:73-75.
+template <bool kIdx32>
+__device__ __forceinline__ double lf_beam(const FieldView& f, double px, double py, double ct, double st, double xt, double yt) {
+  const double x = px * ct - py * st + xt;
+  const double y = px * st + py * ct + yt;
+  const int xi = static_cast<int>(floor(x * f.inv_resolution));
+  const int yi = static_cast<int>(floor(y * f.inv_resolution));
+  // Branch-free: out-of-grid lanes read cell 0 and discard it, so the gathers of an unrolled group
+  // of beams can all be in flight together instead of sitting behind one exec-mask branch each.
+  const bool inside = static_cast<unsigned>(xi) < f.W && static_cast<unsigned>(yi) < f.H;
+  float v;
+  if (kIdx32) {
+    const unsigned idx = inside ? static_cast<unsigned>(yi) * f.W + static_cast<unsigned>(xi) : 0u;
+    v = f.data[idx];
+  } else {
+    const size_t idx = inside ? static_cast<size_t>(yi) * f.W + static_cast<size_t>(xi) : size_t{0};
+    v = f.data[idx];
+  }
+  v = inside ? v : f.unknown_value;
+  const double pz = static_cast<double>(v);
+  return pz * pz * pz;
+}
+
+// Variant A — one wavefront per particle, lanes stride over the beams, scan staged in LDS.
+// A wave owns a tile of 64 particles: the 64 world->field transforms are computed lane-parallel, then
+// broadcast one at a time through SGPRs (v_readlane), so the per-beam math has scalar pose operands.
+template <bool kIdx32>
+__global__ __launch_bounds__(kBlock) void k_reweight_lf_wave(ParticleSoA p, uint64_t n, FieldView f, const double2* __restrict__ pts,
+                                                             uint32_t B) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double2* s_pts = reinterpret_cast<double2*>(smem);
+  for (uint32_t i = threadIdx.x; i < B; i += kBlock) s_pts[i] = pts[i];
+  __syncthreads();
+
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t tile = static_cast<uint64_t>(blockIdx.x) * (kBlock / kWave) + (threadIdx.x >> 6);
+  const uint64_t base = tile * kWave;
+  if (base >= n) return;
+  const uint64_t i = base + lane;
+  Pose2 state = pose_identity();
+  if (i < n) state = load_pose(p, i);
+  const Pose2 T = pose_mul(f.world_to_field, state);
+  const uint32_t cnt = static_cast<uint32_t>(n - base < kWave ? n - base : kWave);
+  double mine = 0.0;
+  for (uint32_t q = 0; q < cnt; ++q) {
+    const double ct = readlane_f64(T.r.c, q), st = readlane_f64(T.r.s, q);
+    const double xt = readlane_f64(T.x, q), yt = readlane_f64(T.y, q);
+    double acc = 0.0;
+#pragma unroll 4
+    for (uint32_t b = lane; b < B; b += kWave) {
+      const double2 pt = s_pts[b];
+      acc += lf_beam<kIdx32>(f, pt.x, pt.y, ct, st, xt, yt);
+    }
+    const double total = wave_sum_f64(acc);
+    if (lane == q) mine = total;
+  }
+  if (i < n) p.w[i] = p.w[i] * (1.0 + mine);
+}
+
+// Variant B — one lane per particle, every lane walks the scan in order; the scan is read with scalar
+// loads (wave-uniform address), the sum is the reference's sequential `1 + sum pz^3` bit for bit.
+template <bool kIdx32>
+__global__ __launch_bounds__(kBlock) void k_reweight_lf_lane(ParticleSoA p, uint64_t n, FieldView f, const double* __restrict__ pts,
+                                                             uint32_t B) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  Pose2 state = pose_identity();
+  if (i < n) state = load_pose(p, i);
+  const Pose2 T = pose_mul(f.world_to_field, state);
+  double acc = 1.0;
+#pragma unroll 8
+  for (uint32_t b = 0; b < B; ++b) {
+    const double px = pts[2 * b], py = pts[2 * b + 1];
+    acc += lf_beam<kIdx32>(f, px, py, T.r.c, T.r.s, T.x, T.y);
+  }
+  if (i < n) p.w[i] = p.w[i] * acc;
+}
+
+// ---- K2' beam model ---------------------------------------------------------------------------------
+// One wavefront per particle, one lane per beam; each lane walks its own Bresenham line on the int8 grid.
+__device__ __forceinline__ void cell_near(const GridView& g, double px, double py, int& xi, int& yi) {
+  const double inv = 1. / g.resolution;
+  xi = static_cast<int>(floor(px * inv));
+  yi = static_cast<int>(floor(py * inv));
+}
+
+__global__ __launch_bounds__(kBlock) void k_reweight_beam(ParticleSoA p, uint64_t n, GridView g, BeamModel m,
+                                                          const double2* __restrict__ pts, uint32_t B, unsigned long long* d_steps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double2* s_pts = reinterpret_cast<double2*>(smem);
+  for (uint32_t i = threadIdx.x; i < B; i += kBlock) s_pts[i] = pts[i];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (i >= n) return;
+  // Ray2d ctor: raycasting.hpp:62-70
+  const Pose2 src = pose_mul(g.origin_inverse, load_pose(p, i));
+  int sx, sy;
+  cell_near(g, src.x, src.y, sx, sy);
+  const double norm_hit = 1. / (sqrt(2. * kPi) * m.sigma_hit);
+  double acc = 0.0;
+  unsigned long long steps = 0;
+  for (uint32_t b = lane; b < B; b += kWave) {
+    const double2 pt = s_pts[b];
+    const double z = sqrt(pt.x * pt.x + pt.y * pt.y);
+    const double bc = pt.x / z, bs = pt.y / z;
+    // trace(): raycasting.hpp:78-88
+    double ex, ey;
+    rot_apply(src.r, bc * m.beam_max_range, bs * m.beam_max_range, ex, ey);
+    ex += src.x;
+    ey += src.y;
+    int fx, fy;
+    cell_near(g, ex, ey, fx, fy);
+    // Bresenham2i standard variant: bresenham.hpp:84-160
+    int x_ = sx, y_ = sy;
+    int xspan = fx - sx, xstep = 1;
+    if (xspan < 0) {
+      xspan = -xspan;
+      xstep = -1;
+    }
+    int yspan = fy - sy, ystep = 1;
+    if (yspan < 0) {
+      yspan = -yspan;
+      ystep = -1;
+    }
+    bool reversed = false;
+    if (xspan < yspan) {
+      int t = x_; x_ = y_; y_ = t;
+      t = xspan; xspan = yspan; yspan = t;
+      t = xstep; xstep = ystep; ystep = t;
+      reversed = true;
+    }
+    const int dxspan = 2 * xspan, dyspan = 2 * yspan;
+    int error = xspan, step = 0;
+    int cx = sx, cy = sy;
+    double z_mean = m.beam_max_range;  // cast(...).value_or(max_range)
+    while (true) {
+      if (!(static_cast<unsigned>(cx) < g.W && static_cast<unsigned>(cy) < g.H)) break;  // take_while(contains)
+      ++steps;
+      if (g.cells[static_cast<size_t>(cy) * g.W + static_cast<size_t>(cx)] != g.free_value) {  // cast(): raycasting.hpp:97-107
+        const double ax = (static_cast<double>(sx) + 0.5) * g.resolution, ay = (static_cast<double>(sy) + 0.5) * g.resolution;
+        const double bx = (static_cast<double>(cx) + 0.5) * g.resolution, by = (static_cast<double>(cy) + 0.5) * g.resolution;
+        const double dx = bx - ax, dy = by - ay;
+        z_mean = fmin(sqrt(dx * dx + dy * dy), m.beam_max_range);
+        break;
+      }
+      if (++step > xspan) break;
+      x_ += xstep;
+      error += dyspan;
+      if (error > dxspan) {
+        y_ += ystep;
+        error -= dxspan;
+      }
+      cx = reversed ? y_ : x_;
+      cy = reversed ? x_ : y_;
+    }
+    // mixture: beam_model.hpp:124-147
+    const double eta_hit = 2. / (erf((m.beam_max_range - z_mean) / (sqrt(2.) * m.sigma_hit)) - erf(-z_mean / (sqrt(2.) * m.sigma_hit)));
+    const double d = (z - z_mean) / m.sigma_hit;
+    double pz = m.z_hit * eta_hit * norm_hit * exp(-(d * d) / 2.);
+    if (z < z_mean) {
+      const double eta_short = 1. / (1. - exp(-m.lambda_short * z_mean));
+      pz += m.z_short * m.lambda_short * eta_short * exp(-m.lambda_short * z);
+    }
+    if (z < m.beam_max_range) {
+      pz += m.z_rand / m.beam_max_range;
+    } else {
+      pz += m.z_max;
+    }
+    acc += pz * pz * pz;
+  }
+  const double total = wave_sum_f64(acc);
+  if (d_steps) {
+    for (int o = 32; o > 0; o >>= 1) steps += __shfl_down(steps, o);
+    if (lane == 0) atomicAdd(d_steps, steps);
+  }
+  if (lane == 0) p.w[i] = p.w[i] * total;
+}
+
+// ---- K3 weight sums / normalize ----------------------------------------------------------------------
+// Each workgroup owns chunk b = [b*kChunk, (b+1)*kChunk): thread t holds elements t*8 .. t*8+7.
+constexpr int kItems = kChunk / kBlock;  // 8
+
+__global__ __launch_bounds__(kBlock) void k_chunk_sum(const double* __restrict__ w, uint64_t n, double* __restrict__ partials) {
+  __shared__ double scratch[kBlock / 64];
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
+  double v[1] = {0.0};
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint64_t i = base + k;
+    if (i < n) v[0] += w[i];
+  }
+  block_reduce<1>(v, scratch);
+  if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+}
+
+// out[k] = sum_b partials[k][b] for k < K (partials laid out [K][stride]); single workgroup, fixed order.
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_final_sum(const double* __restrict__ partials, uint32_t count, uint32_t stride,
+                                                      double* __restrict__ out) {
+  __shared__ double scratch[(kBlock / 64) * K];
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = 0.0;
+  for (uint32_t b = threadIdx.x; b < count; b += kBlock) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += partials[static_cast<size_t>(k) * stride + b];
+  }
+  block_reduce<K>(v, scratch);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = v[k];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_normalize(double* __restrict__ w, uint64_t n, const double* __restrict__ d_factor,
+                                                      double* __restrict__ chunk_sum, double* __restrict__ chunk_sumsq) {
+  __shared__ double scratch[(kBlock / 64) * 2];
+  const double factor = *d_factor;
+  const bool skip = fabs(factor - 1.0) < DBL_EPSILON;  // normalize.hpp:73
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
+  double v[2] = {0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint64_t i = base + k;
+    if (i < n) {
+      double x = w[i];
+      if (!skip) {
+        x = x / factor;
+        w[i] = x;
+      }
+      v[0] += x;
+      v[1] += x * x;
+    }
+  }
+  block_reduce<2>(v, scratch);
+  if (threadIdx.x == 0) {
+    chunk_sum[blockIdx.x] = v[0];
+    chunk_sumsq[blockIdx.x] = v[1];
+  }
+}
+
+// ---- K5 CDF -------------------------------------------------------------------------------------------
+// Exclusive scan of `count` chunk sums by one workgroup (sequential carry across 256-wide tiles);
+// total[0] = grand total.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scan_chunks(const T* __restrict__ chunk_sum, uint32_t count, T* __restrict__ chunk_offset,
+                                                        T* __restrict__ total, const T* __restrict__ base_value) {
+  __shared__ T s_wave[kBlock / 64];
+  __shared__ T s_carry;
+  if (threadIdx.x == 0) s_carry = base_value ? *base_value : T(0);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t start = 0; start < count; start += kBlock) {
+    const uint32_t i = start + threadIdx.x;
+    const T v = i < count ? chunk_sum[i] : T(0);
+    T incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const T up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    T wave_prefix = T(0);
+    for (int q = 0; q < wave; ++q) wave_prefix += s_wave[q];
+    const T carry = s_carry;
+    if (i < count) chunk_offset[i] = carry + wave_prefix + (incl - v);
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) s_carry = carry + wave_prefix + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total) *total = s_carry;
+}
+
+__global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, uint64_t n, const double* __restrict__ chunk_offset,
+                                                double* __restrict__ cdf, double* __restrict__ total) {
+  __shared__ double s_wave[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
+  double loc[kItems];
+  double run = 0.0;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint64_t i = base + k;
+    run += (i < n) ? w[i] : 0.0;
+    loc[k] = run;
+  }
+  double incl = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  double prefix = chunk_offset[blockIdx.x];
+  for (int q = 0; q < wave; ++q) prefix += s_wave[q];
+  prefix += incl - run;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint64_t i = base + k;
+    if (i < n) {
+      const double v = prefix + loc[k];
+      cdf[i] = v;
+      if (i == n - 1) *total = v;
+    }
+  }
+}
+
+// ---- K6 resample draw -----------------------------------------------------------------------------------
+// spatial_hash.hpp:45-75,87-94,190-193
+__device__ __forceinline__ unsigned long long floor_and_fibo_hash(double value, unsigned shift) {
+  const long long sv = static_cast<long long>(floor(value));
+  const unsigned long long h = 11400714819323198485ull * static_cast<unsigned long long>(sv);
+  return shift ? ((h << shift) | (h >> (64 - shift))) : h;
+}
+__device__ __forceinline__ unsigned long long spatial_hash(const Pose2& s, const HashParams& hp) {
+  return floor_and_fibo_hash(s.x / hp.res_x, 0) ^ floor_and_fibo_hash(s.y / hp.res_y, 21) ^
+         floor_and_fibo_hash(rot_log(s.r) / hp.res_theta, 42);
+}
+
+// std::lower_bound over cdf[0..n): first index with cdf[i] >= target, clamped to n-1
+// (discrete_distribution forces the last cumulative probability to one).
+__device__ __forceinline__ uint64_t cdf_lower_bound(const double* __restrict__ cdf, uint64_t n, double target) {
+  uint64_t lo = 0, len = n;
+  while (len > 0) {
+    const uint64_t half = len >> 1;
+    if (cdf[lo + half] < target) {
+      lo += half + 1;
+      len -= half + 1;
+    } else {
+      len = half;
+    }
+  }
+  return lo < n ? lo : n - 1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_resample_draw(ParticleSoA src, const double* __restrict__ cdf, const double* __restrict__ d_total,
+                                                          ParticleSoA dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
+                                                          unsigned long long* __restrict__ hashes) {
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= a.count) return;
+  const uint64_t j = a.first_candidate + t;
+  const RngWords r = rng_draw(a.seed, a.step, kRngResample, j);
+  Pose2 s;
+  // random_intersperse.hpp:90-100: never before the first element; Bernoulli(p) afterwards.
+  const bool intersperse =
+      j > 0 && a.random_state_probability > 0.0 && rng_uniform32(r.w[2]) < a.random_state_probability && fc.count > 0;
+  if (intersperse) {
+    // multivariate_uniform_distribution.hpp:145-147: uniform heading, centre of a uniformly chosen free cell (global frame)
+    const RngWords q = rng_draw(a.seed, a.step, kRngRandomState, j);
+    uint64_t cell = static_cast<uint64_t>(rng_uniform53(q.w[0], q.w[1]) * static_cast<double>(fc.count));
+    if (cell >= fc.count) cell = fc.count - 1;
+    const double theta = -kPi + 2.0 * kPi * rng_uniform53(q.w[2], q.w[3]);
+    const uint32_t idx = fc.index[cell];
+    const double lx = (static_cast<double>(static_cast<int>(idx % g.W)) + 0.5) * g.resolution;
+    const double ly = (static_cast<double>(static_cast<int>(idx / g.W)) + 0.5) * g.resolution;
+    double gx, gy;
+    rot_apply(g.origin.r, lx, ly, gx, gy);
+    s.r = rot_exp(theta);
+    s.x = gx + g.origin.x;
+    s.y = gy + g.origin.y;
+  } else {
+    uint64_t idx = 0;
+    if (a.n_in >= 2) {
+      const double u = rng_uniform53(r.w[0], r.w[1]);
+      idx = cdf_lower_bound(cdf, a.n_in, u * (*d_total));
+    }
+    s = load_pose(src, idx);
+  }
+  const uint64_t o = a.out_offset + t;
+  store_pose(dst, o, s);
+  dst.w[o] = 1.0;  // particle_traits.hpp:105
+  if (hashes) hashes[o] = spatial_hash(s, hp);
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_by_cdf(ParticleSoA src, const double* __restrict__ cdf, uint64_t n,
+                                                          const double* __restrict__ targets, uint64_t m, double* ox, double* oy,
+                                                          double* oc, double* os) {
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= m) return;
+  const uint64_t idx = cdf_lower_bound(cdf, n, targets[t]);
+  ox[t] = src.x[idx];
+  oy[t] = src.y[idx];
+  oc[t] = src.c[idx];
+  os[t] = src.s[idx];
+}
+
+// ---- K7 KLD ---------------------------------------------------------------------------------------------
+constexpr unsigned long long kEmptyKey = ~0ull;
+__device__ __forceinline__ unsigned long long kld_key(unsigned long long h) { return h == kEmptyKey ? h - 1 : h; }
+__device__ __forceinline__ uint64_t kld_slot(unsigned long long key, uint64_t mask) { return (key ^ (key >> 29) ^ (key >> 47)) & mask; }
+
+__global__ __launch_bounds__(kBlock) void k_kld_insert(const unsigned long long* __restrict__ hashes, uint64_t first, uint64_t count,
+                                                       KldTable t) {
+  const uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (q >= count) return;
+  const uint64_t j = first + q;
+  const unsigned long long key = kld_key(hashes[j]);
+  const uint64_t mask = t.capacity - 1;
+  uint64_t slot = kld_slot(key, mask);
+  while (true) {
+    const unsigned long long prev = atomicCAS(&t.keys[slot], kEmptyKey, key);
+    if (prev == kEmptyKey || prev == key) {
+      atomicMin(&t.first[slot], static_cast<unsigned int>(j));
+      return;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+// take_while_kld.hpp:73-81
+__device__ __forceinline__ unsigned long long kld_target_size(unsigned long long k, double two_epsilon, double z) {
+  if (k <= 2ull) return ULLONG_MAX;
+  const double common = 2. / static_cast<double>(9 * (k - 1));
+  const double base = 1. - common + sqrt(common) * z;
+  const double result = (static_cast<double>(k - 1) / two_epsilon) * base * base * base;
+  return static_cast<unsigned long long>(ceil(result));
+}
+
+__global__ __launch_bounds__(kBlock) void k_kld_flags(const unsigned long long* __restrict__ hashes, uint64_t first, uint64_t count,
+                                                      KldTable t, uint32_t* __restrict__ flags, uint32_t* __restrict__ chunk_sum) {
+  __shared__ uint32_t s_wave[kBlock / 64];
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
+  const uint64_t mask = t.capacity - 1;
+  uint32_t local = 0;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint64_t q = base + k;
+    if (q < count) {
+      const uint64_t j = first + q;
+      const unsigned long long key = kld_key(hashes[j]);
+      uint64_t slot = kld_slot(key, mask);
+      while (t.keys[slot] != key) slot = (slot + 1) & mask;
+      const uint32_t f = t.first[slot] == static_cast<unsigned int>(j) ? 1u : 0u;
+      flags[q] = f;
+      local += f;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_sum[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+__global__ __launch_bounds__(kBlock) void k_kld_check(uint64_t first, uint64_t count, const uint32_t* __restrict__ flags,
+                                                      const uint32_t* __restrict__ chunk_offset, uint64_t min_particles,
+                                                      double two_epsilon, double z, unsigned long long* __restrict__ first_fail) {
+  __shared__ uint32_t s_wave[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
+  uint32_t loc[kItems];
+  uint32_t run = 0;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint64_t q = base + k;
+    run += q < count ? flags[q] : 0u;
+    loc[k] = run;
+  }
+  uint32_t incl = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t prefix = chunk_offset[blockIdx.x];  // includes k_base
+  for (int q = 0; q < wave; ++q) prefix += s_wave[q];
+  prefix += incl - run;
+  unsigned long long fail = ULLONG_MAX;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint64_t q = base + k;
+    if (q < count) {
+      const unsigned long long cnt = first + q + 1;  // kld_condition's count after this element
+      const unsigned long long buckets = prefix + loc[k];
+      const bool keep = cnt <= min_particles || cnt <= kld_target_size(buckets, two_epsilon, z);
+      if (!keep && fail == ULLONG_MAX) fail = first + q;
+    }
+  }
+  if (fail != ULLONG_MAX) atomicMin(first_fail, fail);
+}
+
+// ---- K8 estimate -------------------------------------------------------------------------------------------
+constexpr int kEstK = 9;
+__global__ __launch_bounds__(kBlock) void k_estimate_partials(ParticleSoA p, uint64_t n, double pivot_x, double pivot_y,
+                                                              double* __restrict__ partials, uint32_t stride) {
+  __shared__ double scratch[(kBlock / 64) * kEstK];
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
+  double v[kEstK];
+#pragma unroll
+  for (int k = 0; k < kEstK; ++k) v[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint64_t i = base + k;
+    if (i < n) {
+      const double w = p.w[i];
+      const double dx = p.x[i] - pivot_x, dy = p.y[i] - pivot_y;
+      v[0] += w;
+      v[1] += w * w;
+      v[2] += w * p.c[i];
+      v[3] += w * p.s[i];
+      v[4] += w * dx;
+      v[5] += w * dy;
+      v[6] += w * dx * dx;
+      v[7] += w * dx * dy;
+      v[8] += w * dy * dy;
+    }
+  }
+  block_reduce<kEstK>(v, scratch);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < kEstK; ++k) partials[static_cast<size_t>(k) * stride + blockIdx.x] = v[k];
+  }
+}
+
+// ---- misc -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_init_normal(ParticleSoA p, uint64_t n, double m0, double m1, double m2, double t00,
+                                                        double t01, double t02, double t10, double t11, double t12, double t20,
+                                                        double t21, double t22, uint64_t seed, uint64_t index_offset) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const RngWords a = rng_draw(seed, 0, kRngInitA, index_offset + i);
+  const RngWords b = rng_draw(seed, 0, kRngInitB, index_offset + i);
+  double z0, z1, z2, z3;
+  rng_box_muller(rng_uniform53(a.w[0], a.w[1]), rng_uniform53(a.w[2], a.w[3]), z0, z1);
+  rng_box_muller(rng_uniform53(b.w[0], b.w[1]), rng_uniform53(b.w[2], b.w[3]), z2, z3);
+  const double vx = m0 + (t00 * z0 + t01 * z1 + t02 * z2);
+  const double vy = m1 + (t10 * z0 + t11 * z1 + t12 * z2);
+  const double vt = m2 + (t20 * z0 + t21 * z1 + t22 * z2);
+  store_pose(p, i, Pose2{rot_exp(vt), vx, vy});
+  p.w[i] = 1.0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill(double* p, uint64_t n, double v) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(kBlock) void k_aos_to_soa(const double* __restrict__ aos, ParticleSoA p, uint64_t n) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const double4 v = reinterpret_cast<const double4*>(aos)[i];
+  p.c[i] = v.x;
+  p.s[i] = v.y;
+  p.x[i] = v.z;
+  p.y[i] = v.w;
+}
+__global__ __launch_bounds__(kBlock) void k_soa_to_aos(ParticleSoA p, double* __restrict__ aos, uint64_t n) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  reinterpret_cast<double4*>(aos)[i] = double4{p.c[i], p.s[i], p.x[i], p.y[i]};
+}
+
+inline unsigned blocks_for(uint64_t n) { return static_cast<unsigned>((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+// =====================================================================================================
+void launch_propagate(hipStream_t st, ParticleSoA p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
+                      uint64_t index_offset) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_propagate, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, smp, seed, step, index_offset);
+}
+
+void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant) {
+  if (n == 0) return;
+  const bool idx32 = static_cast<uint64_t>(f.W) * f.H < (1ull << 31);
+  if (variant == kLfLanePerParticle) {
+    const dim3 grid(blocks_for(n));
+    if (idx32) hipLaunchKernelGGL(k_reweight_lf_lane<true>, grid, dim3(kBlock), 0, st, p, n, f, d_points, B);
+    else hipLaunchKernelGGL(k_reweight_lf_lane<false>, grid, dim3(kBlock), 0, st, p, n, f, d_points, B);
+  } else {
+    const uint64_t tiles = (n + kWave - 1) / kWave;
+    const dim3 grid(static_cast<unsigned>((tiles + (kBlock / kWave) - 1) / (kBlock / kWave)));
+    const size_t lds = static_cast<size_t>(B) * sizeof(double2);
+    const double2* pts = reinterpret_cast<const double2*>(d_points);
+    if (idx32) hipLaunchKernelGGL(k_reweight_lf_wave<true>, grid, dim3(kBlock), lds, st, p, n, f, pts, B);
+    else hipLaunchKernelGGL(k_reweight_lf_wave<false>, grid, dim3(kBlock), lds, st, p, n, f, pts, B);
+  }
+}
+
+void launch_reweight_beam(hipStream_t st, ParticleSoA p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
+                          unsigned long long* d_steps) {
+  if (n == 0) return;
+  const dim3 grid(static_cast<unsigned>((n + (kBlock / kWave) - 1) / (kBlock / kWave)));
+  hipLaunchKernelGGL(k_reweight_beam, grid, dim3(kBlock), static_cast<size_t>(B) * sizeof(double2), st, p, n, g, m,
+                     reinterpret_cast<const double2*>(d_points), B, d_steps);
+}
+
+void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_partials, double* d_out) {
+  const uint32_t chunks = num_chunks(n);
+  if (chunks) hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_partials);
+  hipLaunchKernelGGL(k_final_sum<1>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out);
+}
+
+void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_factor, double* d_chunk_sum, double* d_chunk_sumsq,
+                      double* d_out) {
+  const uint32_t chunks = num_chunks(n);
+  if (chunks) hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, d_factor, d_chunk_sum, d_chunk_sumsq);
+  // d_chunk_sum and d_chunk_sumsq are adjacent rows of one [2][stride] buffer (see context.cpp)
+  hipLaunchKernelGGL(k_final_sum<2>, dim3(1), dim3(kBlock), 0, st, d_chunk_sum, chunks,
+                     static_cast<uint32_t>(d_chunk_sumsq - d_chunk_sum), d_out);
+}
+
+void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
+                double* d_total) {
+  const uint32_t chunks = num_chunks(n);
+  if (!chunks) return;
+  hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_chunk_sum);
+  hipLaunchKernelGGL(k_scan_chunks<double>, dim3(1), dim3(kBlock), 0, st, d_chunk_sum, chunks, d_chunk_offset,
+                     static_cast<double*>(nullptr), static_cast<const double*>(nullptr));
+  hipLaunchKernelGGL(k_cdf, dim3(chunks), dim3(kBlock), 0, st, w, n, d_chunk_offset, cdf, d_total);
+}
+
+void launch_resample_draw(hipStream_t st, ParticleSoA src, const double* cdf, const double* d_total, ParticleSoA dst,
+                          ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes) {
+  if (a.count == 0) return;
+  hipLaunchKernelGGL(k_resample_draw, dim3(blocks_for(a.count)), dim3(kBlock), 0, st, src, cdf, d_total, dst, a, g, fc, hp,
+                     d_hashes);
+}
+
+void launch_gather_by_cdf(hipStream_t st, ParticleSoA src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
+                          double* ox, double* oy, double* oc, double* os) {
+  if (m == 0) return;
+  hipLaunchKernelGGL(k_gather_by_cdf, dim3(blocks_for(m)), dim3(kBlock), 0, st, src, cdf, n, d_targets, m, ox, oy, oc, os);
+}
+
+void launch_kld_insert(hipStream_t st, const unsigned long long* d_hashes, uint64_t first, uint64_t count, KldTable t) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_kld_insert, dim3(blocks_for(count)), dim3(kBlock), 0, st, d_hashes, first, count, t);
+}
+
+void launch_kld_scan(hipStream_t st, const unsigned long long* d_hashes, uint64_t first, uint64_t count, KldTable t,
+                     uint32_t* d_flags_scan, uint32_t* d_chunk_sum, uint32_t* d_chunk_offset, const uint32_t* d_k_base,
+                     uint32_t* d_k_total, uint64_t min_particles, double epsilon, double z, unsigned long long* d_first_fail) {
+  if (count == 0) return;
+  const uint32_t chunks = num_chunks(count);
+  hipLaunchKernelGGL(k_kld_flags, dim3(chunks), dim3(kBlock), 0, st, d_hashes, first, count, t, d_flags_scan, d_chunk_sum);
+  hipLaunchKernelGGL(k_scan_chunks<uint32_t>, dim3(1), dim3(kBlock), 0, st, d_chunk_sum, chunks, d_chunk_offset, d_k_total,
+                     d_k_base);
+  hipLaunchKernelGGL(k_kld_check, dim3(chunks), dim3(kBlock), 0, st, first, count, d_flags_scan, d_chunk_offset, min_particles,
+                     2 * epsilon, z, d_first_fail);
+}
+
+void launch_estimate_sums(hipStream_t st, ParticleSoA p, uint64_t n, double pivot_x, double pivot_y, double* d_partials,
+                          double* d_out) {
+  const uint32_t chunks = num_chunks(n);
+  if (chunks) hipLaunchKernelGGL(k_estimate_partials, dim3(chunks), dim3(kBlock), 0, st, p, n, pivot_x, pivot_y, d_partials, chunks);
+  hipLaunchKernelGGL(k_final_sum<kEstK>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out);
+}
+
+void launch_init_normal(hipStream_t st, ParticleSoA p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
+                        uint64_t index_offset) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_init_normal, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, mean[0], mean[1], mean[2], T[0], T[1], T[2],
+                     T[3], T[4], T[5], T[6], T[7], T[8], seed, index_offset);
+}
+
+void launch_fill(hipStream_t st, double* p, uint64_t n, double v) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_fill, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, v);
+}
+void launch_aos_to_soa(hipStream_t st, const double* aos, ParticleSoA p, uint64_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_aos_to_soa, dim3(blocks_for(n)), dim3(kBlock), 0, st, aos, p, n);
+}
+void launch_soa_to_aos(hipStream_t st, ParticleSoA p, double* aos, uint64_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_soa_to_aos, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, aos, n);
+}
+
+}  // namespace mcl

@@ -1,0 +1,231 @@
+/* beluga_mcl.h — C ABI of libbeluga_mcl.so: the MI355X-native MCL particle-filter update.
+ *
+ * This is the drop-in boundary for ONE hot path of Ekumen-OS/beluga: `beluga::Amcl::update`
+ * (beluga/include/beluga/algorithm/amcl_core.hpp:165-201) with DifferentialDriveModel +
+ * LikelihoodFieldModel | BeamSensorModel, multinomial / KLD-adaptive resampling and the SE2
+ * estimate.  The reference has no FFI for this path (it is header-only C++17 templates); these
+ * entry points are what a binding for the path binds: one per reference call named below.
+ * Plain pointers and sizes only, no C++/torch types, no exceptions across the boundary.
+ *
+ * Conventions
+ *   - An SE2 pose is 4 doubles (cos, sin, x, y) = Sophus::SE2d::data() order, the layout of the
+ *     reference's particle states (beluga/containers/tuple_vector.hpp:198 over Sophus::SE2d).
+ *   - Particle sets cross the boundary as `states[n*4]` + `weights[n]` (host memory, caller owned).
+ *     On the device they live as structure-of-arrays f64 buffers owned by the context.
+ *   - A measurement is `points_xy[B*2]` doubles: lidar hits in the robot base frame
+ *     (`std::vector<std::pair<double,double>>`, sensor/likelihood_field_model.hpp:48).
+ *   - Every call returns mcl_status (0 = OK, <0 = error; mcl_last_error() has the text).  Calls on
+ *     one context must be serialised by the caller (the reference filter is not thread-safe either:
+ *     beluga_amcl/src/ros2_common.cpp:407-409 uses one mutually exclusive callback group).
+ *   - All work is enqueued on the context's HIP stream; calls that return host data synchronise it.
+ *   - There is NO CPU fallback: mcl_create fails with MCL_ERR_NO_DEVICE when no gfx950 GPU is usable.
+ */
+#ifndef BELUGA_MCL_H
+#define BELUGA_MCL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcl_ctx mcl_ctx;
+typedef int32_t mcl_status;
+
+enum {
+  MCL_OK = 0,
+  MCL_ERR_INVALID_ARGUMENT = -1,
+  MCL_ERR_HIP = -2,
+  MCL_ERR_OUT_OF_MEMORY = -3,
+  MCL_ERR_NOT_READY = -4,      /* no map / no particles yet */
+  MCL_ERR_BAD_COVARIANCE = -5, /* std::runtime_error of multivariate_normal_distribution.hpp:114-124 */
+  MCL_ERR_NO_DEVICE = -6
+};
+
+enum { MCL_SENSOR_LIKELIHOOD_FIELD = 0, MCL_SENSOR_BEAM = 1 };
+
+/* beluga::AmclParams (algorithm/amcl_core.hpp:34-55) + the spatial-hash resolutions that
+ * beluga_ros::AmclParams adds (beluga_ros/include/beluga_ros/amcl.hpp:90-97). Same defaults. */
+typedef struct mcl_amcl_params {
+  double update_min_d;          /* 0.25 */
+  double update_min_a;          /* 0.2 */
+  uint64_t resample_interval;   /* 1 */
+  int32_t selective_resampling; /* 0 */
+  int32_t reserved0;
+  uint64_t min_particles; /* 500 */
+  uint64_t max_particles; /* 2000 */
+  double alpha_slow;      /* 0.001 */
+  double alpha_fast;      /* 0.1 */
+  double kld_epsilon;     /* 0.05 */
+  double kld_z;           /* 3.0 */
+  double spatial_resolution_x;     /* 0.5 */
+  double spatial_resolution_y;     /* 0.5 */
+  double spatial_resolution_theta; /* 10 deg in rad */
+} mcl_amcl_params;
+
+/* beluga::DifferentialDriveModelParam (motion/differential_drive_model.hpp:40-68). */
+typedef struct mcl_diffdrive_params {
+  double rotation_noise_from_rotation;       /* alpha1 */
+  double rotation_noise_from_translation;    /* alpha2 */
+  double translation_noise_from_translation; /* alpha3 */
+  double translation_noise_from_rotation;    /* alpha4 */
+  double distance_threshold;                 /* 0.01 */
+} mcl_diffdrive_params;
+
+/* beluga::LikelihoodFieldModelBaseParam (sensor/likelihood_field_model_base.hpp:42-64). */
+typedef struct mcl_lf_params {
+  double max_obstacle_distance; /* 100.0 */
+  double max_laser_distance;    /* 2.0 */
+  double z_hit;                 /* 0.5 */
+  double z_random;              /* 0.5 */
+  double sigma_hit;             /* 0.2 */
+  int32_t model_unknown_space;      /* 0 */
+  int32_t only_obstacle_boundaries; /* 0 */
+} mcl_lf_params;
+
+/* beluga::BeamModelParam (sensor/beam_model.hpp:43-58). */
+typedef struct mcl_beam_params {
+  double z_hit, z_short, z_max, z_rand, sigma_hit, lambda_short, beam_max_range;
+} mcl_beam_params;
+
+typedef struct mcl_config {
+  int32_t device_id;   /* HIP device ordinal */
+  int32_t sensor_kind; /* MCL_SENSOR_* */
+  uint64_t seed;       /* key of the counter-based Philox4x32-10 stream (DESIGN.md "RNG stream") */
+  mcl_amcl_params amcl;
+  mcl_diffdrive_params motion;
+  mcl_lf_params lf;
+  mcl_beam_params beam;
+  /* Particle sharding across processes (one context per GPU).  A single-GPU filter uses
+   * shard_offset = 0, shard_count = max_particles.  Random draws are addressed by GLOBAL index. */
+  uint64_t shard_offset;
+  uint64_t shard_capacity; /* 0 => amcl.max_particles */
+  void* hip_stream;        /* optional external hipStream_t (e.g. torch's current stream); NULL => own stream */
+} mcl_config;
+
+/* Fills `cfg` with the reference defaults listed above. */
+void mcl_default_config(mcl_config* cfg);
+
+/* beluga::Amcl ctor (amcl_core.hpp:105-124). */
+mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out);
+void mcl_destroy(mcl_ctx* ctx);
+const char* mcl_last_error(const mcl_ctx* ctx); /* ctx may be NULL: error of the last failed mcl_create */
+
+/* Sensor-model ctor / Amcl::update_map (amcl_core.hpp:150; likelihood_field_model_base.hpp:96-99,113-116,
+ * 130-185; beam_model.hpp:152-156).  `cells` is row-major H x W int8 with value traits
+ * {free, unknown, occupied} (beluga_ros/occupancy_grid.hpp:48-64 uses {0,-1,100}).
+ * Builds the likelihood field with the reference's algorithm and uploads grid, field and the
+ * free-cell list used by the random-state generator (random/multivariate_uniform_distribution.hpp:126-161). */
+mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32_t height, double resolution,
+                       const double origin[4], const int8_t value_traits[3]);
+/* LikelihoodFieldModelBase::likelihood_field() (likelihood_field_model_base.hpp:102). out: H*W floats. */
+mcl_status mcl_get_likelihood_field(mcl_ctx* ctx, float* out);
+/* Replace the device field with a caller-built one (same W,H as the current map). */
+mcl_status mcl_set_likelihood_field(mcl_ctx* ctx, const float* field);
+
+/* Amcl::initialize(pose, covariance) (amcl_core.hpp:145-147): max_particles samples of
+ * N(mean_xytheta, cov[3x3 row-major]) with weight 1; sets force_update. */
+mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], const double cov[9]);
+/* Amcl::initialize(distribution) with caller-drawn states (amcl_core.hpp:131-137); n <= capacity. */
+mcl_status mcl_set_particles(mcl_ctx* ctx, const double* states, const double* weights, uint64_t n);
+/* Amcl::particles() (amcl_core.hpp:127). */
+mcl_status mcl_num_particles(mcl_ctx* ctx, uint64_t* n);
+mcl_status mcl_get_particles(mcl_ctx* ctx, double* states, double* weights, uint64_t capacity, uint64_t* n);
+/* Amcl::force_update() (amcl_core.hpp:204). */
+mcl_status mcl_force_update(mcl_ctx* ctx);
+
+typedef struct mcl_estimate {
+  double pose[4];        /* (cos, sin, x, y) */
+  double covariance[9];  /* row-major 3x3: xy block + circular variance at [8] */
+} mcl_estimate;
+
+typedef struct mcl_update_info {
+  int32_t updated;    /* 0 <=> the reference returns std::nullopt (amcl_core.hpp:166-172) */
+  int32_t resampled;  /* resample_policy_ fired (amcl_core.hpp:181) */
+  uint64_t num_particles;          /* after the update */
+  double weight_sum;               /* sum of weights before normalisation */
+  double effective_sample_size;    /* -1 when the policy did not evaluate it */
+  double random_state_probability; /* ThrunRecoveryProbabilityEstimator output (amcl_core.hpp:179) */
+} mcl_update_info;
+
+/* Amcl::update(control_action, measurement) (amcl_core.hpp:165-201): the whole cycle. */
+mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* points_xy, uint64_t num_points,
+                      mcl_estimate* estimate, mcl_update_info* info);
+
+/* ---- Stage-level entry points (what update() composes; used by parity tests and by the
+ * multi-GPU driver, which interleaves collectives between them). -------------------------------- */
+
+/* actions::propagate with DifferentialDriveModel::operator() (actions/propagate.hpp:57-79;
+ * motion/differential_drive_model.hpp:129-164). `step` is the cycle counter word of the RNG stream. */
+mcl_status mcl_propagate(mcl_ctx* ctx, const double pose[4], const double previous_pose[4], uint32_t step);
+/* actions::reweight with the configured sensor model (actions/reweight.hpp:53-60;
+ * likelihood_field_model.hpp:68-91 or beam_model.hpp:104-150): w[i] *= model(state[i]). */
+mcl_status mcl_reweight(mcl_ctx* ctx, const double* points_xy, uint64_t num_points);
+
+typedef struct mcl_weight_stats {
+  double sum;        /* sum of weights before normalisation (actions/normalize.hpp:70) */
+  double norm_sum;   /* sum of the normalised weights (the Thrun estimator's total, Q1) */
+  double norm_sumsq; /* sum of squared normalised weights: ESS = norm_sum^2 / norm_sumsq */
+} mcl_weight_stats;
+/* Local sums of this shard's weights, no normalisation (multi-GPU: all-reduce `sum` first). */
+mcl_status mcl_weight_sum(mcl_ctx* ctx, double* sum);
+/* actions::normalize (actions/normalize.hpp:54-85) by `factor` (NaN => this shard's own sum) and
+ * the statistics the policies consume (effective_sample_size.hpp:46-59, thrun_..._estimator.hpp:79-80). */
+mcl_status mcl_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats);
+
+/* views::sample | random_intersperse | take_while_kld | actions::assign (amcl_core.hpp:188-196).
+ * New weights are 1 (type_traits/particle_traits.hpp:105). */
+mcl_status mcl_resample(mcl_ctx* ctx, double random_state_probability, uint32_t step, uint64_t* n_out);
+
+/* Sufficient statistics of beluga::estimate (algorithm/estimation.hpp:436-475) for this shard:
+ * {Sw, Sw2, Sw*c, Sw*s, Sw*dx, Sw*dy, Sw*dx*dx, Sw*dx*dy, Sw*dy*dy, pivot_x, pivot_y, 0} with
+ * dx = x - pivot_x.  Sums over shards are additive when every shard uses the same pivot. */
+mcl_status mcl_estimate_sums(mcl_ctx* ctx, const double pivot_xy[2], double sums[12]);
+/* Finishes the estimate from (all-reduced) sums. Pure host arithmetic. */
+mcl_status mcl_estimate_from_sums(const double sums[12], mcl_estimate* out);
+/* Convenience: single-shard estimate (estimation.hpp:436-475). */
+mcl_status mcl_estimate_pose(mcl_ctx* ctx, mcl_estimate* out);
+
+/* ---- Device access for zero-copy interop (torch / RCCL hand-off) -------------------------------- */
+typedef struct mcl_device_view {
+  double* x;
+  double* y;
+  double* c;
+  double* s;
+  double* w;
+  double* cdf;        /* inclusive scan of the normalised weights (valid after mcl_build_cdf) */
+  uint64_t n;         /* live particles in this shard */
+  uint64_t capacity;
+  void* hip_stream;
+} mcl_device_view;
+mcl_status mcl_get_device_view(mcl_ctx* ctx, mcl_device_view* view);
+mcl_status mcl_set_num_particles(mcl_ctx* ctx, uint64_t n);
+/* Inclusive scan of the (normalised) weights into the cdf buffer; returns the shard total. */
+mcl_status mcl_build_cdf(mcl_ctx* ctx, double* total);
+/* Sharded multinomial draw: for each of `m` targets t[j] (device pointer, values in this shard's cdf
+ * range [0,total]) write the state of the first particle i with cdf[i] >= t[j] to out_state[4][m] (SoA,
+ * device pointers). std::discrete_distribution's lower_bound (views/sample.hpp:133-135). */
+mcl_status mcl_gather_by_cdf(mcl_ctx* ctx, const double* d_targets, uint64_t m, double* d_out_x, double* d_out_y,
+                             double* d_out_c, double* d_out_s);
+mcl_status mcl_sync(mcl_ctx* ctx);
+
+/* ---- Measurement hooks (bench.py): HIP-event timing of each stage on the context's stream. ------ */
+enum {
+  MCL_STAGE_PROPAGATE = 0,
+  MCL_STAGE_REWEIGHT = 1,
+  MCL_STAGE_NORMALIZE = 2,
+  MCL_STAGE_RESAMPLE = 3,
+  MCL_STAGE_ESTIMATE = 4,
+  MCL_NUM_STAGES = 5
+};
+mcl_status mcl_profile_enable(mcl_ctx* ctx, int32_t on);
+/* Accumulated milliseconds and launch counts per stage since the last reset. */
+mcl_status mcl_profile_read(mcl_ctx* ctx, double ms[MCL_NUM_STAGES], uint64_t counts[MCL_NUM_STAGES], int32_t reset);
+
+const char* mcl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BELUGA_MCL_H */

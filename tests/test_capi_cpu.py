@@ -1,0 +1,97 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/beluga_mcl.h declares, and refuses to run without a GPU (no CPU fallback). No compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from beluga_amd import build as mcl_build
+from beluga_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    mcl_build.build()
+    return capi.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "beluga_mcl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in beluga_mcl.h but not exported"
+    assert sorted(capi.exported_names()) == declared, "capi.py signatures out of sync with beluga_mcl.h"
+
+
+def test_default_config_matches_reference_defaults(lib):
+    cfg = capi.Config()
+    lib.mcl_default_config(C.byref(cfg))
+    a = cfg.amcl  # amcl_core.hpp:34-55
+    assert (a.update_min_d, a.update_min_a, a.resample_interval, a.selective_resampling) == (0.25, 0.2, 1, 0)
+    assert (a.min_particles, a.max_particles, a.alpha_slow, a.alpha_fast, a.kld_epsilon, a.kld_z) == (500, 2000, 0.001, 0.1, 0.05, 3.0)
+    assert cfg.motion.distance_threshold == 0.01  # differential_drive_model.hpp:67
+    lf = cfg.lf  # likelihood_field_model_base.hpp:42-64
+    assert (lf.max_obstacle_distance, lf.max_laser_distance, lf.z_hit, lf.z_random, lf.sigma_hit) == (100.0, 2.0, 0.5, 0.5, 0.2)
+    b = cfg.beam  # beam_model.hpp:43-58
+    assert (b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range) == (0.5, 0.5, 0.05, 0.05, 0.2, 0.1, 60.0)
+
+
+def test_struct_sizes_match_c_layout(lib, tmp_path):
+    # Ask a C compiler for the layout of every struct in the header and compare with the ctypes mirrors.
+    import subprocess
+    names = ["mcl_amcl_params", "mcl_diffdrive_params", "mcl_lf_params", "mcl_beam_params", "mcl_config", "mcl_estimate",
+             "mcl_update_info", "mcl_weight_stats", "mcl_device_view"]
+    mirrors = [capi.AmclParams, capi.DiffDriveParams, capi.LfParams, capi.BeamParams, capi.Config, capi.Estimate,
+               capi.UpdateInfo, capi.WeightStats, capi.DeviceView]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "beluga_mcl.h"\nint main(void){' +
+                   "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) +
+                   'printf("%zu\\n", offsetof(mcl_config, shard_offset));return 0;}')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[:-1] == [C.sizeof(m) for m in mirrors]
+    assert out[-1] == capi.Config.shard_offset.offset
+
+
+def test_estimate_from_sums_is_pure_host_math(lib):
+    # two particles at (1,2,0) and (0,0,0), weights 1: test_estimation.cpp:129-139 (PureTranslation)
+    import numpy as np
+    from beluga_amd.amcl import estimate_from_sums
+    sums = np.array([2.0, 2.0, 2.0, 0.0, 1.0, 2.0, 1.0, 2.0, 4.0, 0.0, 0.0, 0.0])
+    pose, cov = estimate_from_sums(sums)
+    assert pose[2] == pytest.approx(0.5) and pose[3] == pytest.approx(1.0) and pose[0] == pytest.approx(1.0)
+    assert cov[0, 0] == pytest.approx(0.5) and cov[0, 1] == pytest.approx(1.0) and cov[1, 1] == pytest.approx(2.0)
+    assert cov[2, 2] == pytest.approx(0.0, abs=1e-12)
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    cfg = capi.Config()
+    lib.mcl_default_config(C.byref(cfg))
+    ctx = capi._ctx()
+    st = lib.mcl_create(C.byref(cfg), C.byref(ctx))
+    assert st == capi.MCL_ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.mcl_last_error(None)
+    assert not ctx.value
+
+
+def test_product_never_imports_oracle():
+    # The oracle is test infrastructure: nothing under beluga_amd/ may import, link or dlopen it.
+    pat = re.compile(r"(import\s+oracle|from\s+oracle|oracle[/.]binding|beluga_oracle|liboracle|orc_[a-z_]+\s*\()")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "beluga_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(text), f"{f} references the oracle"
