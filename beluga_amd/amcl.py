@@ -276,8 +276,8 @@ class Amcl:
         self._check(self._lib.mcl_profile_enable(self._ctx, int(on)))
 
     def profile_read(self, reset: bool = True):
-        ms = (C.c_double * 5)()
-        cnt = (C.c_uint64 * 5)()
+        ms = (C.c_double * len(capi.STAGES))()
+        cnt = (C.c_uint64 * len(capi.STAGES))()
         self._check(self._lib.mcl_profile_read(self._ctx, ms, cnt, int(reset)))
         return {name: (ms[i], cnt[i]) for i, name in enumerate(capi.STAGES)}
 

@@ -22,7 +22,7 @@ MCL_ERR_NO_DEVICE = -6
 MCL_SENSOR_LIKELIHOOD_FIELD = 0
 MCL_SENSOR_BEAM = 1
 
-STAGES = ("propagate", "reweight", "normalize", "resample", "estimate")
+STAGES = ("propagate", "reweight", "normalize", "resample", "estimate", "sensor_kernel")
 
 c_double_p = C.POINTER(C.c_double)
 c_float_p = C.POINTER(C.c_float)

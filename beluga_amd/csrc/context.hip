@@ -209,7 +209,10 @@ struct mcl_ctx {
   uint32_t step{0};
   bool have_pivot{false};
   double pivot[2]{0, 0};
-  int lf_variant{kLfWavePerParticle};
+  int lf_variant{kLfSortedLanes};
+  // scratch of the spatially binned likelihood-field kernel
+  DeviceBuffer<uint32_t> d_sort_u32;   // bins[cap] perm[cap] hist[kSortBins] chunk_sum chunk_off
+  DeviceBuffer<double> d_sort_f64;     // bbox[4 + 4*stride] tc ts tx ty [cap each]
 
   // profiling
   bool profile{false};
@@ -223,6 +226,21 @@ struct mcl_ctx {
   double* chunk_row(int k) { return d_chunk.ptr + static_cast<size_t>(k) * chunk_stride; }
   FieldView field_view() const {
     return FieldView{d_field.ptr, W, H, 1. / resolution, origin_inverse, static_cast<float>(1. / cfg.lf.max_laser_distance)};
+  }
+  SortScratch sort_scratch() {
+    SortScratch s{};
+    const uint32_t bin_chunks = kSortBins / kChunk;
+    s.bins = d_sort_u32.ptr;
+    s.perm = s.bins + capacity;
+    s.hist = s.perm + capacity;
+    s.chunk_sum = s.hist + kSortBins;
+    s.chunk_off = s.chunk_sum + bin_chunks;
+    s.bbox = d_sort_f64.ptr;
+    s.tc = s.bbox + 4 + 4 * static_cast<size_t>(chunk_stride);
+    s.ts = s.tc + capacity;
+    s.tx = s.ts + capacity;
+    s.ty = s.tx + capacity;
+    return s;
   }
   GridView grid_view() const { return GridView{d_cells.ptr, W, H, resolution, origin, origin_inverse, traits.free_value}; }
 };
@@ -285,6 +303,10 @@ mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
   MCL_HIP(ctx, ctx->d_cdf.ensure(cap));
   MCL_HIP(ctx, ctx->d_aos.ensure(cap * 4));
   ctx->capacity = cap;
+  if (ctx->cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD) {
+    MCL_HIP(ctx, ctx->d_sort_u32.ensure(2 * cap + kSortBins + 2 * (kSortBins / kChunk)));
+    MCL_HIP(ctx, ctx->d_sort_f64.ensure(4 + 4 * static_cast<size_t>(chunks) + 4 * cap));
+  }
   return MCL_OK;
 }
 
@@ -333,13 +355,21 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B) {
   stage_begin(ctx, MCL_STAGE_REWEIGHT);
   if (ctx->cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD) {
     MCL_REQUIRE(ctx, B * sizeof(double2) <= 160 * 1024 || ctx->lf_variant == kLfLanePerParticle, "scan too large for LDS staging");
-    launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B),
-                       ctx->lf_variant);
+    const SortScratch sort = ctx->sort_scratch();
+    // Below a few thousand particles the binning passes cost more than they save.
+    const int variant = (ctx->lf_variant == kLfSortedLanes && ctx->n < 16384) ? kLfLanePerParticle : ctx->lf_variant;
+    if (variant == kLfSortedLanes) launch_lf_bin_sort(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), &sort);
+    stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
+    launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B), variant,
+                       &sort);
+    stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
   } else {
     const mcl_beam_params& b = ctx->cfg.beam;
+    stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
     launch_reweight_beam(ctx->stream, ctx->cur(), ctx->n, ctx->grid_view(),
                          BeamModel{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range},
                          ctx->d_points.ptr, static_cast<uint32_t>(B), ctx->d_kld_scalars.ptr + 1);
+    stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
   }
   stage_end(ctx, MCL_STAGE_REWEIGHT);
   MCL_HIP(ctx, hipGetLastError());
@@ -526,7 +556,10 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_kld_scalars), 8 * sizeof(unsigned long long)));
     for (auto& pair : ctx->ev)
       for (auto& e : pair) MCL_HIP(ctx, hipEventCreate(&e));
-    if (const char* v = std::getenv("BELUGA_MCL_LF_VARIANT")) ctx->lf_variant = std::atoi(v) == 1 ? kLfLanePerParticle : kLfWavePerParticle;
+    if (const char* v = std::getenv("BELUGA_MCL_LF_VARIANT")) {  // kernel A/B switch for profiling; default = sorted lanes
+      const int k = std::atoi(v);
+      ctx->lf_variant = k == 0 ? kLfWavePerParticle : (k == 1 ? kLfLanePerParticle : kLfSortedLanes);
+    }
     return MCL_OK;
   };
   st = init();
@@ -558,6 +591,8 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_flags.release();
   ctx->d_uchunk.release();
   ctx->d_kld_scalars.release();
+  ctx->d_sort_u32.release();
+  ctx->d_sort_f64.release();
   if (ctx->h_points) (void)hipHostFree(ctx->h_points);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
   if (ctx->h_kld_scalars) (void)hipHostFree(ctx->h_kld_scalars);

@@ -66,13 +66,34 @@ struct ResampleArgs {
   uint64_t out_offset;      // where candidate `first_candidate` lands in the output set
 };
 
-enum LfVariant : int { kLfWavePerParticle = 0, kLfLanePerParticle = 1 };
+enum LfVariant : int { kLfWavePerParticle = 0, kLfLanePerParticle = 1, kLfSortedLanes = 2 };
+
+// Scratch of the spatially-binned variant (kLfSortedLanes): particles are counting-sorted into
+// (x, y, heading) bins so that the 64 lanes of a wave look up neighbouring field cells.
+constexpr uint32_t kSortBinBitsXY = 5;      // 32 x 32 position bins over the cloud's bounding box
+constexpr uint32_t kSortBinBitsTheta = 10;  // 1024 heading bins over the full circle
+constexpr uint32_t kSortBins = 1u << (2 * kSortBinBitsXY + kSortBinBitsTheta);
+struct SortScratch {
+  uint32_t* bins;       // [n] bin of particle i
+  uint32_t* hist;       // [kSortBins] histogram -> exclusive offsets -> running cursors
+  uint32_t* perm;       // [n] sorted position -> particle index
+  uint32_t* chunk_sum;  // [kSortBins / kChunk]
+  uint32_t* chunk_off;  // [kSortBins / kChunk]
+  double* bbox;         // [4] min x, max x, min y, max y  (+ [4 * chunks] partials behind it)
+  double* tc;           // [n] world->field transformed poses in sorted order
+  double* ts;
+  double* tx;
+  double* ty;
+};
 
 // K1  actions/propagate.hpp:57-79 + differential_drive_model.hpp:156-163
 void launch_propagate(hipStream_t st, ParticleSoA p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
                       uint64_t index_offset);
-// K2  actions/reweight.hpp:53-60 + likelihood_field_model.hpp:68-91
-void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant);
+// Counting sort of the particles into (heading, x, y) bins + their world->field poses in sorted order.
+void launch_lf_bin_sort(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const SortScratch* sort);
+// K2  actions/reweight.hpp:53-60 + likelihood_field_model.hpp:68-91 (kLfSortedLanes needs launch_lf_bin_sort first)
+void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
+                        const SortScratch* sort);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 void launch_reweight_beam(hipStream_t st, ParticleSoA p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
                           unsigned long long* d_steps);

@@ -169,6 +169,193 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_lane(ParticleSoA p, uint
   if (i < n) p.w[i] = p.w[i] * acc;
 }
 
+// Variant C — variant B's lane-per-particle walk over particles that have been counting-sorted into
+// (heading, x, y) bins.  The 64 lanes of a wave then hold nearly the same pose, so for a given beam their
+// end-points fall into a handful of 128-byte field lines: the vector L1 sees ~10 tag look-ups per gather
+// instead of 64 and the working set of a CU stays in its 32 KB L1 (profiles/r01: variants A/B are bound by
+// the L1/L2 request rate, not by HBM).  The order in which particles are visited does not change any
+// result: each lane still accumulates `1 + sum pz^3` over the scan in the reference's order.
+template <bool kIdx32>
+__global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restrict__ w, uint64_t n, FieldView f,
+                                                               const double* __restrict__ pts, uint32_t B,
+                                                               const uint32_t* __restrict__ perm, const double* __restrict__ tc,
+                                                               const double* __restrict__ ts, const double* __restrict__ tx,
+                                                               const double* __restrict__ ty) {
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const uint64_t tt = t < n ? t : n - 1;
+  const double ct = tc[tt], st = ts[tt], xt = tx[tt], yt = ty[tt];
+  double acc = 1.0;
+#pragma unroll 8
+  for (uint32_t b = 0; b < B; ++b) {
+    const double px = pts[2 * b], py = pts[2 * b + 1];
+    acc += lf_beam<kIdx32>(f, px, py, ct, st, xt, yt);
+  }
+  if (t < n) {
+    const uint32_t i = perm[t];
+    w[i] = w[i] * acc;
+  }
+}
+
+// -- spatial binning ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_bbox_partials(ParticleSoA p, uint64_t n, double* __restrict__ partials, uint32_t stride) {
+  __shared__ double scratch[(kBlock / 64) * 4];
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * (kChunk / kBlock);
+  double lo_x = INFINITY, hi_x = -INFINITY, lo_y = INFINITY, hi_y = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < kChunk / kBlock; ++k) {
+    const uint64_t i = base + k;
+    if (i < n) {
+      const double x = p.x[i], y = p.y[i];
+      lo_x = fmin(lo_x, x);
+      hi_x = fmax(hi_x, x);
+      lo_y = fmin(lo_y, y);
+      hi_y = fmax(hi_y, y);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo_x = fmin(lo_x, __shfl_down(lo_x, o));
+    hi_x = fmax(hi_x, __shfl_down(hi_x, o));
+    lo_y = fmin(lo_y, __shfl_down(lo_y, o));
+    hi_y = fmax(hi_y, __shfl_down(hi_y, o));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    scratch[wave * 4 + 0] = lo_x;
+    scratch[wave * 4 + 1] = hi_x;
+    scratch[wave * 4 + 2] = lo_y;
+    scratch[wave * 4 + 3] = hi_y;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < kBlock / 64; ++q) {
+      lo_x = fmin(lo_x, scratch[q * 4 + 0]);
+      hi_x = fmax(hi_x, scratch[q * 4 + 1]);
+      lo_y = fmin(lo_y, scratch[q * 4 + 2]);
+      hi_y = fmax(hi_y, scratch[q * 4 + 3]);
+    }
+    partials[0 * stride + blockIdx.x] = lo_x;
+    partials[1 * stride + blockIdx.x] = hi_x;
+    partials[2 * stride + blockIdx.x] = lo_y;
+    partials[3 * stride + blockIdx.x] = hi_y;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bbox_final(const double* __restrict__ partials, uint32_t count, uint32_t stride,
+                                                       double* __restrict__ out) {
+  __shared__ double scratch[(kBlock / 64) * 4];
+  double v[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+  for (uint32_t b = threadIdx.x; b < count; b += kBlock) {
+    v[0] = fmin(v[0], partials[0 * stride + b]);
+    v[1] = fmax(v[1], partials[1 * stride + b]);
+    v[2] = fmin(v[2], partials[2 * stride + b]);
+    v[3] = fmax(v[3], partials[3 * stride + b]);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    v[0] = fmin(v[0], __shfl_down(v[0], o));
+    v[1] = fmax(v[1], __shfl_down(v[1], o));
+    v[2] = fmin(v[2], __shfl_down(v[2], o));
+    v[3] = fmax(v[3], __shfl_down(v[3], o));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+    for (int k = 0; k < 4; ++k) scratch[wave * 4 + k] = v[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < kBlock / 64; ++q) {
+      v[0] = fmin(v[0], scratch[q * 4 + 0]);
+      v[1] = fmax(v[1], scratch[q * 4 + 1]);
+      v[2] = fmin(v[2], scratch[q * 4 + 2]);
+      v[3] = fmax(v[3], scratch[q * 4 + 3]);
+    }
+    for (int k = 0; k < 4; ++k) out[k] = v[k];
+  }
+}
+
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // ...edcba -> ..e00d00c00b00a
+  v &= 0x3FF;
+  v = (v | (v << 16)) & 0x030000FF;
+  v = (v | (v << 8)) & 0x0300F00F;
+  v = (v | (v << 4)) & 0x030C30C3;
+  v = (v | (v << 2)) & 0x09249249;
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_bin_count(ParticleSoA p, uint64_t n, const double* __restrict__ bbox,
+                                                      uint32_t* __restrict__ bins, uint32_t* __restrict__ hist) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  constexpr int kXY = 1 << kSortBinBitsXY, kT = 1 << kSortBinBitsTheta;
+  const double rx = bbox[1] - bbox[0], ry = bbox[3] - bbox[2];
+  int bx = rx > 0.0 ? static_cast<int>((p.x[i] - bbox[0]) / rx * kXY) : 0;
+  int by = ry > 0.0 ? static_cast<int>((p.y[i] - bbox[2]) / ry * kXY) : 0;
+  int bt = static_cast<int>((atan2(p.s[i], p.c[i]) + kPi) * (kT / (2.0 * kPi)));
+  bx = min(max(bx, 0), kXY - 1);
+  by = min(max(by, 0), kXY - 1);
+  bt = min(max(bt, 0), kT - 1);
+  // coarse heading first, then Morton-interleaved (x, y, fine heading)
+  const uint32_t lo = kSortBinBitsXY;
+  const uint32_t bin = (static_cast<uint32_t>(bt >> lo) << (3 * lo)) | spread3(bx) | (spread3(by) << 1) |
+                       (spread3(bt & ((1 << lo) - 1)) << 2);
+  bins[i] = bin;
+  atomicAdd(&hist[bin], 1u);
+}
+
+__global__ __launch_bounds__(kBlock) void k_u32_chunk_sum(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ chunk_sum) {
+  __shared__ uint32_t s_wave[kBlock / 64];
+  const uint32_t base = blockIdx.x * kChunk + threadIdx.x * (kChunk / kBlock);
+  uint32_t local = 0;
+#pragma unroll
+  for (int k = 0; k < kChunk / kBlock; ++k) local += (base + k < n) ? v[base + k] : 0u;
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_sum[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+// In-place exclusive scan of v within each chunk, offset by chunk_offset[chunk].
+__global__ __launch_bounds__(kBlock) void k_u32_exclusive_apply(uint32_t* __restrict__ v, uint32_t n,
+                                                                const uint32_t* __restrict__ chunk_offset) {
+  __shared__ uint32_t s_wave[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t base = blockIdx.x * kChunk + threadIdx.x * (kChunk / kBlock);
+  uint32_t loc[kChunk / kBlock];
+  uint32_t run = 0;
+#pragma unroll
+  for (int k = 0; k < kChunk / kBlock; ++k) {
+    loc[k] = run;
+    run += (base + k < n) ? v[base + k] : 0u;
+  }
+  uint32_t incl = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t prefix = chunk_offset[blockIdx.x];
+  for (int q = 0; q < wave; ++q) prefix += s_wave[q];
+  prefix += incl - run;
+#pragma unroll
+  for (int k = 0; k < kChunk / kBlock; ++k)
+    if (base + k < n) v[base + k] = prefix + loc[k];
+}
+
+__global__ __launch_bounds__(kBlock) void k_bin_scatter(ParticleSoA p, uint64_t n, Pose2 world_to_field,
+                                                        const uint32_t* __restrict__ bins, uint32_t* __restrict__ cursors,
+                                                        uint32_t* __restrict__ perm, double* __restrict__ tc,
+                                                        double* __restrict__ ts, double* __restrict__ tx, double* __restrict__ ty) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t slot = atomicAdd(&cursors[bins[i]], 1u);
+  const Pose2 T = pose_mul(world_to_field, load_pose(p, i));  // likelihood_field_model.hpp:70
+  perm[slot] = static_cast<uint32_t>(i);
+  tc[slot] = T.r.c;
+  ts[slot] = T.r.s;
+  tx[slot] = T.x;
+  ty[slot] = T.y;
+}
+
 // ---- K2' beam model ---------------------------------------------------------------------------------
 // One wavefront per particle, one lane per beam; each lane walks its own Bresenham line on the int8 grid.
 __device__ __forceinline__ void cell_near(const GridView& g, double px, double py, int& xi, int& yi) {
@@ -657,10 +844,37 @@ void launch_propagate(hipStream_t st, ParticleSoA p, uint64_t n, DiffDriveSample
   hipLaunchKernelGGL(k_propagate, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, smp, seed, step, index_offset);
 }
 
-void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant) {
+void launch_lf_bin_sort(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const SortScratch* sort) {
+  if (n == 0 || !sort || n >= (1ull << 32)) return;
+  const uint32_t chunks = num_chunks(n);
+  const uint32_t stride = chunks;
+  double* partials = sort->bbox + 4;
+  hipLaunchKernelGGL(k_bbox_partials, dim3(chunks), dim3(kBlock), 0, st, p, n, partials, stride);
+  hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(kBlock), 0, st, partials, chunks, stride, sort->bbox);
+  (void)hipMemsetAsync(sort->hist, 0, sizeof(uint32_t) * kSortBins, st);
+  hipLaunchKernelGGL(k_bin_count, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, sort->bbox, sort->bins, sort->hist);
+  const uint32_t bin_chunks = kSortBins / kChunk;
+  hipLaunchKernelGGL(k_u32_chunk_sum, dim3(bin_chunks), dim3(kBlock), 0, st, sort->hist, kSortBins, sort->chunk_sum);
+  hipLaunchKernelGGL(k_scan_chunks<uint32_t>, dim3(1), dim3(kBlock), 0, st, sort->chunk_sum, bin_chunks, sort->chunk_off,
+                     static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr));
+  hipLaunchKernelGGL(k_u32_exclusive_apply, dim3(bin_chunks), dim3(kBlock), 0, st, sort->hist, kSortBins, sort->chunk_off);
+  hipLaunchKernelGGL(k_bin_scatter, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, f.world_to_field, sort->bins, sort->hist,
+                     sort->perm, sort->tc, sort->ts, sort->tx, sort->ty);
+}
+
+void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
+                        const SortScratch* sort) {
   if (n == 0) return;
   const bool idx32 = static_cast<uint64_t>(f.W) * f.H < (1ull << 31);
-  if (variant == kLfLanePerParticle) {
+  if (variant == kLfSortedLanes && sort && n < (1ull << 32)) {
+    const dim3 grid(blocks_for(n));
+    if (idx32)
+      hipLaunchKernelGGL(k_reweight_lf_sorted<true>, grid, dim3(kBlock), 0, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
+                         sort->ts, sort->tx, sort->ty);
+    else
+      hipLaunchKernelGGL(k_reweight_lf_sorted<false>, grid, dim3(kBlock), 0, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
+                         sort->ts, sort->tx, sort->ty);
+  } else if (variant == kLfLanePerParticle || variant == kLfSortedLanes) {
     const dim3 grid(blocks_for(n));
     if (idx32) hipLaunchKernelGGL(k_reweight_lf_lane<true>, grid, dim3(kBlock), 0, st, p, n, f, d_points, B);
     else hipLaunchKernelGGL(k_reweight_lf_lane<false>, grid, dim3(kBlock), 0, st, p, n, f, d_points, B);

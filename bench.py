@@ -68,7 +68,7 @@ def cpu_baseline(cells, truth, odoms, scans, n_full: int, budget_s: float = 12.0
     from beluga_amd.amcl import se2_from_xytheta
     from oracle import binding as orc
     threads = orc.max_threads()
-    sample_n = 32768
+    sample_n = 32768 * max(1, threads // 8)
     f = orc.Amcl(min_particles=sample_n, max_particles=sample_n, alphas=ALPHAS, seed=42, threads=threads,
                  lf=(LF["max_obstacle_distance"], LF["max_laser_distance"], LF["z_hit"], LF["z_random"], LF["sigma_hit"]),
                  lf_model_unknown_space=LF["model_unknown_space"])
@@ -167,7 +167,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        lf_ms, lf_count = prof["reweight"]
+        lf_ms, lf_count = prof["sensor_kernel"]
         lf_avg_s = (lf_ms / max(lf_count, 1)) * 1e-3
         bytes_lf = lf_algorithmic_bytes(n_local, BEAMS)
         achieved = bytes_lf / lf_avg_s if lf_avg_s > 0 else 0.0
@@ -196,7 +196,7 @@ def main():
             },
             "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in prof.items()},
             "roofline": {
-                "kernel": "k_reweight_lf (likelihood-field reweight)",
+                "kernel": "k_reweight_lf_sorted (likelihood-field reweight)",
                 "bound": "hbm",
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK / 1e9,

@@ -217,7 +217,8 @@ enum {
   MCL_STAGE_NORMALIZE = 2,
   MCL_STAGE_RESAMPLE = 3,
   MCL_STAGE_ESTIMATE = 4,
-  MCL_NUM_STAGES = 5
+  MCL_STAGE_SENSOR_KERNEL = 5, /* the sensor-model kernel alone (inside MCL_STAGE_REWEIGHT) */
+  MCL_NUM_STAGES = 6
 };
 mcl_status mcl_profile_enable(mcl_ctx* ctx, int32_t on);
 /* Accumulated milliseconds and launch counts per stage since the last reset. */

@@ -106,14 +106,17 @@ def test_reference_golden_weights_through_the_c_abi():
     assert beam_w([(60.0, 60.0)]) == pytest.approx(0.00012500000000000003, abs=1e-6)
 
 
-@pytest.mark.parametrize("variant", ["0", "1"])
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
 @pytest.mark.parametrize("beams", [1, 63, 64, 65, 180, 1080])
 def test_reweight_lf_matches_oracle(variant, beams, monkeypatch):
+    """All three kernel variants (wave per particle / lane per particle / binned lanes = the default)."""
     monkeypatch.setenv("BELUGA_MCL_LF_VARIANT", variant)
     grid = rooms_grid()
     truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=2, clearance_cells=6)
     pts = make_scan(grid, truth, beams, max_range=12.0)
     n = 4097 if beams != 1080 else 1500  # ragged tail tile
+    if variant == "2":
+        n = 20_001  # the binned variant only engages above 16384 particles
     states = synth.normal_particles(n, truth, (0.5, 0.5, 0.2), seed=5)
     states[:8, 2] += 100.0  # some particles far outside the map: every beam out of grid
     w0 = np.random.Generator(np.random.MT19937(3)).uniform(0.5, 1.5, n)
@@ -124,7 +127,8 @@ def test_reweight_lf_matches_oracle(variant, beams, monkeypatch):
     field = f.likelihood_field()
     want = w0 * orc.lf_weights(field, grid.resolution, grid.origin, LF.max_laser_distance, states, pts)
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
-    assert got[0] == pytest.approx(w0[0] * (1.0 + beams * (1 / 100.0) ** 3), rel=1e-12)  # all-unknown particle
+    unknown = float(np.float32(1.0 / 100.0))  # float(1 / max_laser_distance), likelihood_field_model.hpp:75
+    assert got[0] == pytest.approx(w0[0] * (1.0 + beams * unknown ** 3), rel=1e-12)  # every beam out of the grid
     f.close()
 
 
