@@ -211,8 +211,9 @@ struct mcl_ctx {
   double pivot[2]{0, 0};
   int lf_variant{kLfSortedLanes};
   // scratch of the spatially binned likelihood-field kernel
-  DeviceBuffer<uint32_t> d_sort_u32;   // bins[cap] perm[cap] hist[kSortBins] chunk_sum chunk_off
-  DeviceBuffer<double> d_sort_f64;     // bbox[4 + 4*stride] tc ts tx ty [cap each]
+  DeviceBuffer<uint32_t> d_sort_u32;            // keys[cap] perm[cap] block_hist chunk_sum chunk_off
+  DeviceBuffer<unsigned long long> d_sort_u64;  // keyidx[cap]
+  DeviceBuffer<double> d_sort_f64;              // bbox[8 + 6*nblocks] tc ts tx ty [cap each]
 
   // profiling
   bool profile{false};
@@ -229,14 +230,16 @@ struct mcl_ctx {
   }
   SortScratch sort_scratch() {
     SortScratch s{};
-    const uint32_t bin_chunks = kSortBins / kChunk;
-    s.bins = d_sort_u32.ptr;
-    s.perm = s.bins + capacity;
-    s.hist = s.perm + capacity;
-    s.chunk_sum = s.hist + kSortBins;
-    s.chunk_off = s.chunk_sum + bin_chunks;
+    const size_t nblocks = num_chunks(capacity);
+    const size_t hist = kSortDigits * nblocks;
+    s.keys = d_sort_u32.ptr;
+    s.perm = s.keys + capacity;
+    s.block_hist = s.perm + capacity;
+    s.chunk_sum = s.block_hist + hist;
+    s.chunk_off = s.chunk_sum + (hist / kChunk + 1);
+    s.keyidx = d_sort_u64.ptr;
     s.bbox = d_sort_f64.ptr;
-    s.tc = s.bbox + 4 + 4 * static_cast<size_t>(chunk_stride);
+    s.tc = s.bbox + 8 + 6 * nblocks;
     s.ts = s.tc + capacity;
     s.tx = s.ts + capacity;
     s.ty = s.tx + capacity;
@@ -304,8 +307,10 @@ mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
   MCL_HIP(ctx, ctx->d_aos.ensure(cap * 4));
   ctx->capacity = cap;
   if (ctx->cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD) {
-    MCL_HIP(ctx, ctx->d_sort_u32.ensure(2 * cap + kSortBins + 2 * (kSortBins / kChunk)));
-    MCL_HIP(ctx, ctx->d_sort_f64.ensure(4 + 4 * static_cast<size_t>(chunks) + 4 * cap));
+    const size_t hist = static_cast<size_t>(kSortDigits) * num_chunks(cap);
+    MCL_HIP(ctx, ctx->d_sort_u32.ensure(2 * cap + hist + 2 * (hist / kChunk + 1)));
+    MCL_HIP(ctx, ctx->d_sort_u64.ensure(cap));
+    MCL_HIP(ctx, ctx->d_sort_f64.ensure(8 + 6 * static_cast<size_t>(chunks) + 4 * cap));
   }
   return MCL_OK;
 }
@@ -592,6 +597,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_uchunk.release();
   ctx->d_kld_scalars.release();
   ctx->d_sort_u32.release();
+  ctx->d_sort_u64.release();
   ctx->d_sort_f64.release();
   if (ctx->h_points) (void)hipHostFree(ctx->h_points);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);

@@ -68,19 +68,18 @@ struct ResampleArgs {
 
 enum LfVariant : int { kLfWavePerParticle = 0, kLfLanePerParticle = 1, kLfSortedLanes = 2 };
 
-// Scratch of the spatially-binned variant (kLfSortedLanes): particles are counting-sorted into
-// (x, y, heading) bins so that the 64 lanes of a wave look up neighbouring field cells.
-constexpr uint32_t kSortBinBitsXY = 5;      // 32 x 32 position bins over the cloud's bounding box
-constexpr uint32_t kSortBinBitsTheta = 10;  // 1024 heading bins over the full circle
-constexpr uint32_t kSortBins = 1u << (2 * kSortBinBitsXY + kSortBinBitsTheta);
+// Scratch of the spatially ordered variant (kLfSortedLanes): particles are sorted by a (heading, x, y)
+// bin key so that the 64 lanes of a wave look up neighbouring field cells.
+constexpr uint32_t kSortDigits = 1024;  // coarse partition digit (top 10 bits of the 20-bit key)
 struct SortScratch {
-  uint32_t* bins;       // [n] bin of particle i
-  uint32_t* hist;       // [kSortBins] histogram -> exclusive offsets -> running cursors
-  uint32_t* perm;       // [n] sorted position -> particle index
-  uint32_t* chunk_sum;  // [kSortBins / kChunk]
-  uint32_t* chunk_off;  // [kSortBins / kChunk]
-  double* bbox;         // [4] min x, max x, min y, max y  (+ [4 * chunks] partials behind it)
-  double* tc;           // [n] world->field transformed poses in sorted order
+  uint32_t* keys;                // [n] key of particle i
+  uint32_t* perm;                // [n] sorted position -> particle index
+  uint32_t* block_hist;          // [kSortDigits][nblocks] histogram -> exclusive offsets
+  uint32_t* chunk_sum;           // [kSortDigits * nblocks / 2048 + 1]
+  uint32_t* chunk_off;           // same
+  unsigned long long* keyidx;    // [n] (key << 32 | index), partitioned by digit
+  double* bbox;                  // [8] min/max of x, y, relative heading (+ [6 * nblocks] partials behind it)
+  double* tc;                    // [n] world->field transformed poses in sorted order
   double* ts;
   double* tx;
   double* ty;

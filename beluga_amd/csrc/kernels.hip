@@ -196,78 +196,87 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
   }
 }
 
-// -- spatial binning ----------------------------------------------------------------------------------
+// -- spatial ordering of the particles --------------------------------------------------------------
+// Order = sort by a 20-bit key (heading / x / y bins relative to the cloud's bounding box, Morton-interleaved).
+// Global atomics are slow on this part (~6 per ns, device scope resolves at the memory side), so the sort
+// uses none: (1) per-workgroup LDS histogram of the key's top 10 bits, (2) an exclusive scan of the
+// [digit][workgroup] table, (3) scatter through LDS cursors, (4) a bitonic sort of every 2048-element
+// block in LDS on the full key.  Runs that straddle a block edge stay split, which costs nothing: every
+// wave still gets 64 neighbours.
+constexpr uint32_t kKeyBitsXY = 6, kKeyBitsTheta = 8;                  // 64 x 64 x 256 bins
+constexpr uint32_t kKeyBits = 2 * kKeyBitsXY + kKeyBitsTheta;           // 20
+constexpr uint32_t kDigitBits = 10, kDigits = 1u << kDigitBits;         // coarse partition digit
+static_assert(kDigits == kSortDigits, "scratch sizing in context.hip assumes this digit width");
+
+__device__ __forceinline__ double heading_delta(double c, double s, double c0, double s0) {
+  return atan2(s * c0 - c * s0, c * c0 + s * s0);  // angle of (c,s) relative to (c0,s0), in (-pi, pi]
+}
+
+// bbox = {min x, max x, min y, max y, min dtheta, max dtheta}; dtheta relative to particle 0's heading.
 __global__ __launch_bounds__(kBlock) void k_bbox_partials(ParticleSoA p, uint64_t n, double* __restrict__ partials, uint32_t stride) {
-  __shared__ double scratch[(kBlock / 64) * 4];
+  __shared__ double scratch[(kBlock / 64) * 6];
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * (kChunk / kBlock);
-  double lo_x = INFINITY, hi_x = -INFINITY, lo_y = INFINITY, hi_y = -INFINITY;
+  const double c0 = p.c[0], s0 = p.s[0];
+  double v[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
 #pragma unroll
   for (int k = 0; k < kChunk / kBlock; ++k) {
     const uint64_t i = base + k;
     if (i < n) {
-      const double x = p.x[i], y = p.y[i];
-      lo_x = fmin(lo_x, x);
-      hi_x = fmax(hi_x, x);
-      lo_y = fmin(lo_y, y);
-      hi_y = fmax(hi_y, y);
+      const double x = p.x[i], y = p.y[i], d = heading_delta(p.c[i], p.s[i], c0, s0);
+      v[0] = fmin(v[0], x);
+      v[1] = fmax(v[1], x);
+      v[2] = fmin(v[2], y);
+      v[3] = fmax(v[3], y);
+      v[4] = fmin(v[4], d);
+      v[5] = fmax(v[5], d);
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
-    lo_x = fmin(lo_x, __shfl_down(lo_x, o));
-    hi_x = fmax(hi_x, __shfl_down(hi_x, o));
-    lo_y = fmin(lo_y, __shfl_down(lo_y, o));
-    hi_y = fmax(hi_y, __shfl_down(hi_y, o));
+#pragma unroll
+    for (int k = 0; k < 6; k += 2) {
+      v[k] = fmin(v[k], __shfl_down(v[k], o));
+      v[k + 1] = fmax(v[k + 1], __shfl_down(v[k + 1], o));
+    }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-    scratch[wave * 4 + 0] = lo_x;
-    scratch[wave * 4 + 1] = hi_x;
-    scratch[wave * 4 + 2] = lo_y;
-    scratch[wave * 4 + 3] = hi_y;
-  }
+  if (lane == 0)
+    for (int k = 0; k < 6; ++k) scratch[wave * 6 + k] = v[k];
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int q = 1; q < kBlock / 64; ++q) {
-      lo_x = fmin(lo_x, scratch[q * 4 + 0]);
-      hi_x = fmax(hi_x, scratch[q * 4 + 1]);
-      lo_y = fmin(lo_y, scratch[q * 4 + 2]);
-      hi_y = fmax(hi_y, scratch[q * 4 + 3]);
-    }
-    partials[0 * stride + blockIdx.x] = lo_x;
-    partials[1 * stride + blockIdx.x] = hi_x;
-    partials[2 * stride + blockIdx.x] = lo_y;
-    partials[3 * stride + blockIdx.x] = hi_y;
+    for (int q = 1; q < kBlock / 64; ++q)
+      for (int k = 0; k < 6; k += 2) {
+        v[k] = fmin(v[k], scratch[q * 6 + k]);
+        v[k + 1] = fmax(v[k + 1], scratch[q * 6 + k + 1]);
+      }
+    for (int k = 0; k < 6; ++k) partials[static_cast<size_t>(k) * stride + blockIdx.x] = v[k];
   }
 }
 
 __global__ __launch_bounds__(kBlock) void k_bbox_final(const double* __restrict__ partials, uint32_t count, uint32_t stride,
                                                        double* __restrict__ out) {
-  __shared__ double scratch[(kBlock / 64) * 4];
-  double v[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
-  for (uint32_t b = threadIdx.x; b < count; b += kBlock) {
-    v[0] = fmin(v[0], partials[0 * stride + b]);
-    v[1] = fmax(v[1], partials[1 * stride + b]);
-    v[2] = fmin(v[2], partials[2 * stride + b]);
-    v[3] = fmax(v[3], partials[3 * stride + b]);
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    v[0] = fmin(v[0], __shfl_down(v[0], o));
-    v[1] = fmax(v[1], __shfl_down(v[1], o));
-    v[2] = fmin(v[2], __shfl_down(v[2], o));
-    v[3] = fmax(v[3], __shfl_down(v[3], o));
-  }
+  __shared__ double scratch[(kBlock / 64) * 6];
+  double v[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+  for (uint32_t b = threadIdx.x; b < count; b += kBlock)
+    for (int k = 0; k < 6; k += 2) {
+      v[k] = fmin(v[k], partials[static_cast<size_t>(k) * stride + b]);
+      v[k + 1] = fmax(v[k + 1], partials[static_cast<size_t>(k + 1) * stride + b]);
+    }
+  for (int o = 32; o > 0; o >>= 1)
+    for (int k = 0; k < 6; k += 2) {
+      v[k] = fmin(v[k], __shfl_down(v[k], o));
+      v[k + 1] = fmax(v[k + 1], __shfl_down(v[k + 1], o));
+    }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0)
-    for (int k = 0; k < 4; ++k) scratch[wave * 4 + k] = v[k];
+    for (int k = 0; k < 6; ++k) scratch[wave * 6 + k] = v[k];
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int q = 1; q < kBlock / 64; ++q) {
-      v[0] = fmin(v[0], scratch[q * 4 + 0]);
-      v[1] = fmax(v[1], scratch[q * 4 + 1]);
-      v[2] = fmin(v[2], scratch[q * 4 + 2]);
-      v[3] = fmax(v[3], scratch[q * 4 + 3]);
-    }
-    for (int k = 0; k < 4; ++k) out[k] = v[k];
+    for (int q = 1; q < kBlock / 64; ++q)
+      for (int k = 0; k < 6; k += 2) {
+        v[k] = fmin(v[k], scratch[q * 6 + k]);
+        v[k + 1] = fmax(v[k + 1], scratch[q * 6 + k + 1]);
+      }
+    for (int k = 0; k < 6; ++k) out[k] = v[k];
   }
 }
 
@@ -279,25 +288,103 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // ...edcba -> ..e00d
   v = (v | (v << 2)) & 0x09249249;
   return v;
 }
+__device__ __forceinline__ int bin_of(double v, double lo, double hi, int bins) {
+  const double r = hi - lo;
+  int b = r > 0.0 ? static_cast<int>((v - lo) / r * bins) : 0;
+  return min(max(b, 0), bins - 1);
+}
+// 20-bit key: the two extra heading bits on top, then Morton (heading, y, x) over 6 bits each.
+__device__ __forceinline__ uint32_t sort_key(const ParticleSoA& p, uint64_t i, const double* __restrict__ bbox, double c0, double s0) {
+  const int bx = bin_of(p.x[i], bbox[0], bbox[1], 1 << kKeyBitsXY);
+  const int by = bin_of(p.y[i], bbox[2], bbox[3], 1 << kKeyBitsXY);
+  const int bt = bin_of(heading_delta(p.c[i], p.s[i], c0, s0), bbox[4], bbox[5], 1 << kKeyBitsTheta);
+  const uint32_t lo = kKeyBitsXY;
+  return (static_cast<uint32_t>(bt >> lo) << (3 * lo)) | spread3(bx) | (spread3(by) << 1) | (spread3(bt & ((1 << lo) - 1)) << 2);
+}
 
-__global__ __launch_bounds__(kBlock) void k_bin_count(ParticleSoA p, uint64_t n, const double* __restrict__ bbox,
-                                                      uint32_t* __restrict__ bins, uint32_t* __restrict__ hist) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i >= n) return;
-  constexpr int kXY = 1 << kSortBinBitsXY, kT = 1 << kSortBinBitsTheta;
-  const double rx = bbox[1] - bbox[0], ry = bbox[3] - bbox[2];
-  int bx = rx > 0.0 ? static_cast<int>((p.x[i] - bbox[0]) / rx * kXY) : 0;
-  int by = ry > 0.0 ? static_cast<int>((p.y[i] - bbox[2]) / ry * kXY) : 0;
-  int bt = static_cast<int>((atan2(p.s[i], p.c[i]) + kPi) * (kT / (2.0 * kPi)));
-  bx = min(max(bx, 0), kXY - 1);
-  by = min(max(by, 0), kXY - 1);
-  bt = min(max(bt, 0), kT - 1);
-  // coarse heading first, then Morton-interleaved (x, y, fine heading)
-  const uint32_t lo = kSortBinBitsXY;
-  const uint32_t bin = (static_cast<uint32_t>(bt >> lo) << (3 * lo)) | spread3(bx) | (spread3(by) << 1) |
-                       (spread3(bt & ((1 << lo) - 1)) << 2);
-  bins[i] = bin;
-  atomicAdd(&hist[bin], 1u);
+__global__ __launch_bounds__(kBlock) void k_sort_hist(ParticleSoA p, uint64_t n, const double* __restrict__ bbox,
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ block_hist,
+                                                      uint32_t nblocks) {
+  __shared__ uint32_t hist[kDigits];
+  for (uint32_t d = threadIdx.x; d < kDigits; d += kBlock) hist[d] = 0;
+  __syncthreads();
+  const double c0 = p.c[0], s0 = p.s[0];
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+#pragma unroll
+  for (int k = 0; k < kChunk / kBlock; ++k) {
+    const uint64_t i = base + k * kBlock + threadIdx.x;  // coalesced
+    if (i < n) {
+      const uint32_t key = sort_key(p, i, bbox, c0, s0);
+      keys[i] = key;
+      atomicAdd(&hist[key >> (kKeyBits - kDigitBits)], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t d = threadIdx.x; d < kDigits; d += kBlock) block_hist[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
+}
+
+__global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restrict__ keys, uint64_t n,
+                                                         const uint32_t* __restrict__ block_offsets, uint32_t nblocks,
+                                                         unsigned long long* __restrict__ out) {
+  __shared__ uint32_t cursor[kDigits];
+  for (uint32_t d = threadIdx.x; d < kDigits; d += kBlock) cursor[d] = block_offsets[static_cast<size_t>(d) * nblocks + blockIdx.x];
+  __syncthreads();
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+#pragma unroll
+  for (int k = 0; k < kChunk / kBlock; ++k) {
+    const uint64_t i = base + k * kBlock + threadIdx.x;
+    if (i < n) {
+      const uint32_t key = keys[i];
+      const uint32_t dest = atomicAdd(&cursor[key >> (kKeyBits - kDigitBits)], 1u);
+      out[dest] = (static_cast<unsigned long long>(key) << 32) | static_cast<uint32_t>(i);
+    }
+  }
+}
+
+// Bitonic sort of each 2048-element block of (key << 32 | index) in LDS, then emit the permutation and
+// the world->field pose of every particle in sorted order (likelihood_field_model.hpp:70).
+__global__ __launch_bounds__(kBlock) void k_sort_blocks(const unsigned long long* __restrict__ in, uint64_t n, ParticleSoA p,
+                                                        Pose2 world_to_field, uint32_t* __restrict__ perm, double* __restrict__ tc,
+                                                        double* __restrict__ ts, double* __restrict__ tx, double* __restrict__ ty) {
+  __shared__ unsigned long long v[kChunk];
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+#pragma unroll
+  for (int k = 0; k < kChunk / kBlock; ++k) {
+    const uint32_t t = k * kBlock + threadIdx.x;
+    v[t] = base + t < n ? in[base + t] : ~0ull;
+  }
+  __syncthreads();
+  for (uint32_t size = 2; size <= kChunk; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+      for (int k = 0; k < kChunk / 2 / kBlock; ++k) {
+        const uint32_t t = k * kBlock + threadIdx.x;                     // comparator index, 0 .. 1023
+        const uint32_t lo = 2 * t - (t & (stride - 1));                   // element with the `stride` bit clear
+        const uint32_t hi = lo + stride;
+        const bool ascending = (lo & size) == 0;
+        const unsigned long long a = v[lo], b = v[hi];
+        if ((a > b) == ascending) {
+          v[lo] = b;
+          v[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kChunk / kBlock; ++k) {
+    const uint32_t t = k * kBlock + threadIdx.x;
+    const uint64_t o = base + t;
+    if (o < n) {
+      const uint32_t i = static_cast<uint32_t>(v[t]);
+      const Pose2 T = pose_mul(world_to_field, load_pose(p, i));
+      perm[o] = i;
+      tc[o] = T.r.c;
+      ts[o] = T.r.s;
+      tx[o] = T.x;
+      ty[o] = T.y;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_u32_chunk_sum(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ chunk_sum) {
@@ -339,21 +426,6 @@ __global__ __launch_bounds__(kBlock) void k_u32_exclusive_apply(uint32_t* __rest
 #pragma unroll
   for (int k = 0; k < kChunk / kBlock; ++k)
     if (base + k < n) v[base + k] = prefix + loc[k];
-}
-
-__global__ __launch_bounds__(kBlock) void k_bin_scatter(ParticleSoA p, uint64_t n, Pose2 world_to_field,
-                                                        const uint32_t* __restrict__ bins, uint32_t* __restrict__ cursors,
-                                                        uint32_t* __restrict__ perm, double* __restrict__ tc,
-                                                        double* __restrict__ ts, double* __restrict__ tx, double* __restrict__ ty) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t slot = atomicAdd(&cursors[bins[i]], 1u);
-  const Pose2 T = pose_mul(world_to_field, load_pose(p, i));  // likelihood_field_model.hpp:70
-  perm[slot] = static_cast<uint32_t>(i);
-  tc[slot] = T.r.c;
-  ts[slot] = T.r.s;
-  tx[slot] = T.x;
-  ty[slot] = T.y;
 }
 
 // ---- K2' beam model ---------------------------------------------------------------------------------
@@ -846,20 +918,20 @@ void launch_propagate(hipStream_t st, ParticleSoA p, uint64_t n, DiffDriveSample
 
 void launch_lf_bin_sort(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const SortScratch* sort) {
   if (n == 0 || !sort || n >= (1ull << 32)) return;
-  const uint32_t chunks = num_chunks(n);
-  const uint32_t stride = chunks;
-  double* partials = sort->bbox + 4;
-  hipLaunchKernelGGL(k_bbox_partials, dim3(chunks), dim3(kBlock), 0, st, p, n, partials, stride);
-  hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(kBlock), 0, st, partials, chunks, stride, sort->bbox);
-  (void)hipMemsetAsync(sort->hist, 0, sizeof(uint32_t) * kSortBins, st);
-  hipLaunchKernelGGL(k_bin_count, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, sort->bbox, sort->bins, sort->hist);
-  const uint32_t bin_chunks = kSortBins / kChunk;
-  hipLaunchKernelGGL(k_u32_chunk_sum, dim3(bin_chunks), dim3(kBlock), 0, st, sort->hist, kSortBins, sort->chunk_sum);
-  hipLaunchKernelGGL(k_scan_chunks<uint32_t>, dim3(1), dim3(kBlock), 0, st, sort->chunk_sum, bin_chunks, sort->chunk_off,
+  const uint32_t nblocks = num_chunks(n);
+  double* partials = sort->bbox + 8;
+  hipLaunchKernelGGL(k_bbox_partials, dim3(nblocks), dim3(kBlock), 0, st, p, n, partials, nblocks);
+  hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(kBlock), 0, st, partials, nblocks, nblocks, sort->bbox);
+  hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(kBlock), 0, st, p, n, sort->bbox, sort->keys, sort->block_hist, nblocks);
+  const uint32_t m = kDigits * nblocks;
+  const uint32_t mchunks = num_chunks(m);
+  hipLaunchKernelGGL(k_u32_chunk_sum, dim3(mchunks), dim3(kBlock), 0, st, sort->block_hist, m, sort->chunk_sum);
+  hipLaunchKernelGGL(k_scan_chunks<uint32_t>, dim3(1), dim3(kBlock), 0, st, sort->chunk_sum, mchunks, sort->chunk_off,
                      static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr));
-  hipLaunchKernelGGL(k_u32_exclusive_apply, dim3(bin_chunks), dim3(kBlock), 0, st, sort->hist, kSortBins, sort->chunk_off);
-  hipLaunchKernelGGL(k_bin_scatter, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, f.world_to_field, sort->bins, sort->hist,
-                     sort->perm, sort->tc, sort->ts, sort->tx, sort->ty);
+  hipLaunchKernelGGL(k_u32_exclusive_apply, dim3(mchunks), dim3(kBlock), 0, st, sort->block_hist, m, sort->chunk_off);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(kBlock), 0, st, sort->keys, n, sort->block_hist, nblocks, sort->keyidx);
+  hipLaunchKernelGGL(k_sort_blocks, dim3(nblocks), dim3(kBlock), 0, st, sort->keyidx, n, p, f.world_to_field, sort->perm, sort->tc,
+                     sort->ts, sort->tx, sort->ty);
 }
 
 void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
