@@ -171,6 +171,7 @@ struct mcl_ctx {
   Pose2 origin{}, origin_inverse{};
   OccupancyTraits traits{0, -1, 100};
   DeviceBuffer<float> d_field;
+  DeviceBuffer<double> d_cube;  // pz^3 table of the field (+1 slot for out-of-grid beams)
   DeviceBuffer<int8_t> d_cells;
   DeviceBuffer<uint32_t> d_free;
   uint64_t n_free{0};
@@ -226,7 +227,8 @@ struct mcl_ctx {
   ParticleSoA other() const { return sets[live ^ 1].view(); }
   double* chunk_row(int k) { return d_chunk.ptr + static_cast<size_t>(k) * chunk_stride; }
   FieldView field_view() const {
-    return FieldView{d_field.ptr, W, H, 1. / resolution, origin_inverse, static_cast<float>(1. / cfg.lf.max_laser_distance)};
+    return FieldView{d_field.ptr, W, H, 1. / resolution, origin_inverse, static_cast<float>(1. / cfg.lf.max_laser_distance),
+                     d_cube.ptr};
   }
   SortScratch sort_scratch() {
     SortScratch s{};
@@ -325,6 +327,15 @@ mcl_status ensure_kld(mcl_ctx* ctx) {
   MCL_HIP(ctx, ctx->d_table_keys.ensure(tc));
   MCL_HIP(ctx, ctx->d_table_first.ensure(tc));
   ctx->table_capacity = tc;
+  return MCL_OK;
+}
+
+mcl_status rebuild_cube(mcl_ctx* ctx) {
+  const uint64_t cells = static_cast<uint64_t>(ctx->W) * ctx->H;
+  MCL_HIP(ctx, ctx->d_cube.ensure(cells + 1));
+  launch_cube_table(ctx->stream, ctx->d_field.ptr, cells, static_cast<float>(1. / ctx->cfg.lf.max_laser_distance), ctx->d_cube.ptr);
+  MCL_HIP(ctx, hipGetLastError());
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MCL_OK;
 }
 
@@ -583,6 +594,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& set : ctx->sets) set.release();
   ctx->d_field.release();
+  ctx->d_cube.release();
   ctx->d_cells.release();
   ctx->d_free.release();
   ctx->d_points.release();
@@ -635,6 +647,7 @@ mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32
     build_likelihood_field(cells, width, height, resolution, ctx->traits, ctx->cfg.lf, ctx->h_field);
     MCL_HIP(ctx, ctx->d_field.ensure(n));
     MCL_HIP(ctx, hipMemcpy(ctx->d_field.ptr, ctx->h_field.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    if (const mcl_status s = rebuild_cube(ctx)) return s;
   }
   ctx->have_map = true;
   return MCL_OK;
@@ -659,7 +672,7 @@ mcl_status mcl_set_likelihood_field(mcl_ctx* ctx, const float* field) {
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MCL_HIP(ctx, ctx->d_field.ensure(n));
   MCL_HIP(ctx, hipMemcpy(ctx->d_field.ptr, field, n * sizeof(float), hipMemcpyHostToDevice));
-  return MCL_OK;
+  return rebuild_cube(ctx);
 }
 
 mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], const double cov[9]) {

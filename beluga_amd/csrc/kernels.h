@@ -28,6 +28,9 @@ struct FieldView {
   double inv_resolution;  // 1. / resolution (regular_grid.hpp:76)
   Pose2 world_to_field;   // grid.origin().inverse() (likelihood_field_model_base.hpp:99)
   float unknown_value;    // float(1 / max_laser_distance) (likelihood_field_model.hpp:75)
+  // Derived table for the hot kernel: cube[i] = pz*pz*pz with pz = double(data[i]) — exactly the per-beam
+  // term of likelihood_field_model.hpp:84-88 — and cube[W*H] = the same for unknown_value.  8 B per cell.
+  const double* cube;
 };
 
 struct GridView {
@@ -135,6 +138,8 @@ void launch_estimate_sums(hipStream_t st, ParticleSoA p, uint64_t n, double pivo
 void launch_init_normal(hipStream_t st, ParticleSoA p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
                         uint64_t index_offset);
 void launch_fill(hipStream_t st, double* p, uint64_t n, double v);
+// cube[i] = double(field[i])^3 for i < cells, cube[cells] = double(unknown)^3
+void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube);
 // AoS (c,s,x,y) host layout <-> SoA device layout
 void launch_aos_to_soa(hipStream_t st, const double* aos, ParticleSoA p, uint64_t n);
 void launch_soa_to_aos(hipStream_t st, ParticleSoA p, double* aos, uint64_t n);

@@ -115,6 +115,21 @@ __device__ __forceinline__ double lf_beam(const FieldView& f, double px, double 
   return pz * pz * pz;
 }
 
+// The same term from the precomputed cube table through a raw buffer load: 32-bit byte offsets
+// (v_mad_u32_u24), no exec-mask branch, out-of-grid lanes redirected to the table's "unknown" slot.
+// Requires W*8 < 2^24 and (W*H+1)*8 < 2^32 (checked by the launcher).
+__device__ __forceinline__ double lf_beam_cube(__amdgpu_buffer_rsrc_t rsrc, const FieldView& f, uint32_t row_bytes,
+                                               uint32_t unknown_offset, double px, double py, double ct, double st, double xt,
+                                               double yt) {
+  const double x = px * ct - py * st + xt;
+  const double y = px * st + py * ct + yt;
+  const int xi = static_cast<int>(floor(x * f.inv_resolution));
+  const int yi = static_cast<int>(floor(y * f.inv_resolution));
+  const bool inside = static_cast<unsigned>(xi) < f.W && static_cast<unsigned>(yi) < f.H;
+  const uint32_t offset = inside ? __umul24(static_cast<unsigned>(yi), row_bytes) + (static_cast<unsigned>(xi) << 3) : unknown_offset;
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, offset, 0, 0));
+}
+
 // Variant A — one wavefront per particle, lanes stride over the beams, scan staged in LDS.
 // A wave owns a tile of 64 particles: the 64 world->field transforms are computed lane-parallel, then
 // broadcast one at a time through SGPRs (v_readlane), so the per-beam math has scalar pose operands.
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_lane(ParticleSoA p, uint
 // instead of 64 and the working set of a CU stays in its 32 KB L1 (profiles/r01: variants A/B are bound by
 // the L1/L2 request rate, not by HBM).  The order in which particles are visited does not change any
 // result: each lane still accumulates `1 + sum pz^3` over the scan in the reference's order.
-template <bool kIdx32>
+template <bool kCube>
 __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restrict__ w, uint64_t n, FieldView f,
                                                                const double* __restrict__ pts, uint32_t B,
                                                                const uint32_t* __restrict__ perm, const double* __restrict__ tc,
@@ -185,10 +200,22 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
   const uint64_t tt = t < n ? t : n - 1;
   const double ct = tc[tt], st = ts[tt], xt = tx[tt], yt = ty[tt];
   double acc = 1.0;
+  if (kCube) {
+    const uint32_t cells = f.W * f.H;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(f.cube), 0, static_cast<int>((cells + 1) * 8u), 0x00020000);
+    const uint32_t row_bytes = f.W * 8u, unknown_offset = cells * 8u;
 #pragma unroll 8
-  for (uint32_t b = 0; b < B; ++b) {
-    const double px = pts[2 * b], py = pts[2 * b + 1];
-    acc += lf_beam<kIdx32>(f, px, py, ct, st, xt, yt);
+    for (uint32_t b = 0; b < B; ++b) {
+      const double px = pts[2 * b], py = pts[2 * b + 1];
+      acc += lf_beam_cube(rsrc, f, row_bytes, unknown_offset, px, py, ct, st, xt, yt);
+    }
+  } else {
+#pragma unroll 8
+    for (uint32_t b = 0; b < B; ++b) {
+      const double px = pts[2 * b], py = pts[2 * b + 1];
+      acc += lf_beam<false>(f, px, py, ct, st, xt, yt);
+    }
   }
   if (t < n) {
     const uint32_t i = perm[t];
@@ -886,6 +913,13 @@ __global__ __launch_bounds__(kBlock) void k_init_normal(ParticleSoA p, uint64_t 
   p.w[i] = 1.0;
 }
 
+__global__ __launch_bounds__(kBlock) void k_cube_table(const float* __restrict__ field, uint64_t cells, float unknown_value,
+                                                       double* __restrict__ cube) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i > cells) return;
+  const double pz = static_cast<double>(i < cells ? field[i] : unknown_value);
+  cube[i] = pz * pz * pz;
+}
 __global__ __launch_bounds__(kBlock) void k_fill(double* p, uint64_t n, double v) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i < n) p[i] = v;
@@ -940,7 +974,9 @@ void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, 
   const bool idx32 = static_cast<uint64_t>(f.W) * f.H < (1ull << 31);
   if (variant == kLfSortedLanes && sort && n < (1ull << 32)) {
     const dim3 grid(blocks_for(n));
-    if (idx32)
+    const uint64_t cells = static_cast<uint64_t>(f.W) * f.H;
+    const bool cube_ok = f.cube != nullptr && f.W < (1u << 21) && (cells + 1) * 8 < (1ull << 31);
+    if (cube_ok)
       hipLaunchKernelGGL(k_reweight_lf_sorted<true>, grid, dim3(kBlock), 0, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
                          sort->ts, sort->tx, sort->ty);
     else
@@ -1037,6 +1073,9 @@ void launch_init_normal(hipStream_t st, ParticleSoA p, uint64_t n, const double 
                      T[3], T[4], T[5], T[6], T[7], T[8], seed, index_offset);
 }
 
+void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube) {
+  hipLaunchKernelGGL(k_cube_table, dim3(blocks_for(cells + 1)), dim3(kBlock), 0, st, field, cells, unknown_value, cube);
+}
 void launch_fill(hipStream_t st, double* p, uint64_t n, double v) {
   if (n == 0) return;
   hipLaunchKernelGGL(k_fill, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, v);
