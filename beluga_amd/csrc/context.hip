@@ -958,6 +958,31 @@ mcl_status mcl_gather_by_cdf(mcl_ctx* ctx, const double* d_targets, uint64_t m, 
   return MCL_OK;
 }
 
+mcl_status mcl_resample_targets(mcl_ctx* ctx, uint32_t step, double random_state_probability, double total,
+                                uint64_t first_slot, uint64_t count, double* d_targets) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, count == 0 || d_targets, "null targets");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  launch_resample_targets(ctx->stream, ctx->cfg.seed, step, random_state_probability, total, first_slot, count,
+                          ctx->have_map ? ctx->n_free : 0, d_targets);
+  MCL_HIP(ctx, hipGetLastError());
+  return MCL_OK;
+}
+
+mcl_status mcl_commit_resampled(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_x,
+                                const double* d_y, const double* d_c, const double* d_s, const double* d_targets) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, count <= ctx->capacity, "count exceeds shard capacity");
+  MCL_REQUIRE(ctx, count == 0 || (d_x && d_y && d_c && d_s && d_targets), "null argument");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  launch_commit_resampled(ctx->stream, ctx->other(), ctx->cfg.seed, step, first_slot, count, d_x, d_y, d_c, d_s, d_targets,
+                          ctx->grid_view(), FreeCells{ctx->d_free.ptr, ctx->have_map ? ctx->n_free : 0});
+  MCL_HIP(ctx, hipGetLastError());
+  ctx->live ^= 1;
+  ctx->n = count;
+  return MCL_OK;
+}
+
 mcl_status mcl_sync(mcl_ctx* ctx) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
   if (const mcl_status s = bind_device(ctx)) return s;

@@ -119,6 +119,12 @@ void launch_resample_draw(hipStream_t st, ParticleSoA src, const double* cdf, co
 // Sharded variant: targets given, no RNG (mcl_gather_by_cdf).
 void launch_gather_by_cdf(hipStream_t st, ParticleSoA src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
                           double* ox, double* oy, double* oc, double* os);
+// Sharded resampling helpers (mcl_resample_targets / mcl_commit_resampled).
+void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
+                             uint64_t count, uint64_t n_free, double* d_targets);
+void launch_commit_resampled(hipStream_t st, ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
+                             const double* x, const double* y, const double* c, const double* s, const double* targets, GridView g,
+                             FreeCells fc);
 // K7: exact parallel take_while_kld (take_while_kld.hpp:72-88).
 struct KldTable {
   unsigned long long* keys;  // 0 = empty (hash 0 is remapped)

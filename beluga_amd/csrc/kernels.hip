@@ -715,6 +715,30 @@ __device__ __forceinline__ uint64_t cdf_lower_bound(const double* __restrict__ c
   return lo < n ? lo : n - 1;
 }
 
+// multivariate_uniform_distribution.hpp:145-147 over occupancy_grid.hpp:140-146,164-171: uniform heading,
+// centre of a uniformly chosen free cell in the world frame.  Addressed by the candidate's global index.
+__device__ __forceinline__ Pose2 random_free_state(uint64_t seed, uint32_t step, uint64_t j, const GridView& g, const FreeCells& fc) {
+  const RngWords q = rng_draw(seed, step, kRngRandomState, j);
+  uint64_t cell = static_cast<uint64_t>(rng_uniform53(q.w[0], q.w[1]) * static_cast<double>(fc.count));
+  if (cell >= fc.count) cell = fc.count - 1;
+  const double theta = -kPi + 2.0 * kPi * rng_uniform53(q.w[2], q.w[3]);
+  const uint32_t idx = fc.index[cell];
+  const double lx = (static_cast<double>(static_cast<int>(idx % g.W)) + 0.5) * g.resolution;
+  const double ly = (static_cast<double>(static_cast<int>(idx / g.W)) + 0.5) * g.resolution;
+  double gx, gy;
+  rot_apply(g.origin.r, lx, ly, gx, gy);
+  Pose2 s;
+  s.r = rot_exp(theta);
+  s.x = gx + g.origin.x;
+  s.y = gy + g.origin.y;
+  return s;
+}
+
+// random_intersperse.hpp:90-100: never before the first element; Bernoulli(p) afterwards.
+__device__ __forceinline__ bool intersperse_here(const RngWords& r, uint64_t j, double p, uint64_t n_free) {
+  return j > 0 && p > 0.0 && rng_uniform32(r.w[2]) < p && n_free > 0;
+}
+
 __global__ __launch_bounds__(kBlock) void k_resample_draw(ParticleSoA src, const double* __restrict__ cdf, const double* __restrict__ d_total,
                                                           ParticleSoA dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
                                                           unsigned long long* __restrict__ hashes) {
@@ -723,23 +747,9 @@ __global__ __launch_bounds__(kBlock) void k_resample_draw(ParticleSoA src, const
   const uint64_t j = a.first_candidate + t;
   const RngWords r = rng_draw(a.seed, a.step, kRngResample, j);
   Pose2 s;
-  // random_intersperse.hpp:90-100: never before the first element; Bernoulli(p) afterwards.
-  const bool intersperse =
-      j > 0 && a.random_state_probability > 0.0 && rng_uniform32(r.w[2]) < a.random_state_probability && fc.count > 0;
+  const bool intersperse = intersperse_here(r, j, a.random_state_probability, fc.count);
   if (intersperse) {
-    // multivariate_uniform_distribution.hpp:145-147: uniform heading, centre of a uniformly chosen free cell (global frame)
-    const RngWords q = rng_draw(a.seed, a.step, kRngRandomState, j);
-    uint64_t cell = static_cast<uint64_t>(rng_uniform53(q.w[0], q.w[1]) * static_cast<double>(fc.count));
-    if (cell >= fc.count) cell = fc.count - 1;
-    const double theta = -kPi + 2.0 * kPi * rng_uniform53(q.w[2], q.w[3]);
-    const uint32_t idx = fc.index[cell];
-    const double lx = (static_cast<double>(static_cast<int>(idx % g.W)) + 0.5) * g.resolution;
-    const double ly = (static_cast<double>(static_cast<int>(idx / g.W)) + 0.5) * g.resolution;
-    double gx, gy;
-    rot_apply(g.origin.r, lx, ly, gx, gy);
-    s.r = rot_exp(theta);
-    s.x = gx + g.origin.x;
-    s.y = gy + g.origin.y;
+    s = random_free_state(a.seed, a.step, j, g, fc);
   } else {
     uint64_t idx = 0;
     if (a.n_in >= 2) {
@@ -764,6 +774,33 @@ __global__ __launch_bounds__(kBlock) void k_gather_by_cdf(ParticleSoA src, const
   oy[t] = src.y[idx];
   oc[t] = src.c[idx];
   os[t] = src.s[idx];
+}
+
+// -- sharded resampling (one context per GPU; the exchange between them is done by the caller) -----------
+// targets[t] = u_j * total for output slot j = first_slot + t, NaN where the slot takes an injected random state.
+__global__ __launch_bounds__(kBlock) void k_resample_targets(uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
+                                                             uint64_t count, uint64_t n_free, double* __restrict__ targets) {
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= count) return;
+  const uint64_t j = first_slot + t;
+  const RngWords r = rng_draw(seed, step, kRngResample, j);
+  targets[t] = intersperse_here(r, j, p, n_free) ? __builtin_nan("") : rng_uniform53(r.w[0], r.w[1]) * total;
+}
+
+__global__ __launch_bounds__(kBlock) void k_commit_resampled(ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot,
+                                                             uint64_t count, const double* __restrict__ x, const double* __restrict__ y,
+                                                             const double* __restrict__ c, const double* __restrict__ s,
+                                                             const double* __restrict__ targets, GridView g, FreeCells fc) {
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= count) return;
+  Pose2 v;
+  if (targets[t] != targets[t]) {
+    v = random_free_state(seed, step, first_slot + t, g, fc);
+  } else {
+    v = Pose2{Rot2{c[t], s[t]}, x[t], y[t]};
+  }
+  store_pose(dst, t, v);
+  dst.w[t] = 1.0;
 }
 
 // ---- K7 KLD ---------------------------------------------------------------------------------------------
@@ -1040,6 +1077,20 @@ void launch_gather_by_cdf(hipStream_t st, ParticleSoA src, const double* cdf, ui
                           double* ox, double* oy, double* oc, double* os) {
   if (m == 0) return;
   hipLaunchKernelGGL(k_gather_by_cdf, dim3(blocks_for(m)), dim3(kBlock), 0, st, src, cdf, n, d_targets, m, ox, oy, oc, os);
+}
+
+void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
+                             uint64_t count, uint64_t n_free, double* d_targets) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_resample_targets, dim3(blocks_for(count)), dim3(kBlock), 0, st, seed, step, p, total, first_slot, count, n_free,
+                     d_targets);
+}
+void launch_commit_resampled(hipStream_t st, ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
+                             const double* x, const double* y, const double* c, const double* s, const double* targets, GridView g,
+                             FreeCells fc) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_commit_resampled, dim3(blocks_for(count)), dim3(kBlock), 0, st, dst, seed, step, first_slot, count, x, y, c, s,
+                     targets, g, fc);
 }
 
 void launch_kld_insert(hipStream_t st, const unsigned long long* d_hashes, uint64_t first, uint64_t count, KldTable t) {

@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="use the sharded driver even with one GPU (measures its overhead)")
     args = ap.parse_args()
 
     import torch
@@ -114,9 +115,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MCL update has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_sharded = world > 1 or args.sharded
+    if use_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -133,7 +136,7 @@ def main():
     params = AmclParams(min_particles=n_total, max_particles=n_total)
     motion = DifferentialDriveModelParam(*ALPHAS)
     sensor = LikelihoodFieldModelParam(**LF)
-    if world == 1:
+    if not use_sharded:
         from beluga_amd.amcl import Amcl
         filt = Amcl(grid, motion, sensor, params, seed=42, device=local_rank)
     else:
@@ -191,7 +194,7 @@ def main():
                 "particles_total": n_total,
                 "beams": BEAMS,
                 "grid": f"{MAP_SIZE}x{MAP_SIZE}@{RESOLUTION}",
-                "parallelism": "1 GPU" if world == 1 else f"particle shards x{world} (RCCL all-reduce of weight sums + all-to-all ancestor exchange)",
+                "parallelism": "1 GPU" if not use_sharded else f"particle shards x{world} (RCCL all-reduce of weight sums + all-to-all ancestor exchange)",
                 "particle_beam_evals_per_s": n_total * BEAMS * args.steps / elapsed,
             },
             "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in prof.items()},
@@ -211,7 +214,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cells, truth, odoms, scans, n_total)
         print(json.dumps(out))
-    if world > 1:
+    if use_sharded:
         dist.barrier()
         dist.destroy_process_group()
 

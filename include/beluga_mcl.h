@@ -208,6 +208,17 @@ mcl_status mcl_build_cdf(mcl_ctx* ctx, double* total);
  * device pointers). std::discrete_distribution's lower_bound (views/sample.hpp:133-135). */
 mcl_status mcl_gather_by_cdf(mcl_ctx* ctx, const double* d_targets, uint64_t m, double* d_out_x, double* d_out_y,
                              double* d_out_c, double* d_out_s);
+/* Sharded views::sample | random_intersperse (views/sample.hpp:102,133-135; random_intersperse.hpp:90-115) for the
+ * `count` output slots [first_slot, first_slot+count) of the GLOBAL particle index space:
+ * d_targets[t] = u_j * total (a point of the global CDF, total = sum of all shards' weights), or NaN where the
+ * slot receives an injected random state.  u_j comes from the same Philox stream as the single-GPU path. */
+mcl_status mcl_resample_targets(mcl_ctx* ctx, uint32_t step, double random_state_probability, double total,
+                                uint64_t first_slot, uint64_t count, double* d_targets);
+/* actions::assign (actions/assign.hpp:56-64) of the exchanged ancestors: slot t takes (d_x,d_y,d_c,d_s)[t], or a
+ * random free-space state where d_targets[t] is NaN; weights become 1 (particle_traits.hpp:105); the shard then
+ * holds `count` particles. */
+mcl_status mcl_commit_resampled(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_x,
+                                const double* d_y, const double* d_c, const double* d_s, const double* d_targets);
 mcl_status mcl_sync(mcl_ctx* ctx);
 
 /* ---- Measurement hooks (bench.py): HIP-event timing of each stage on the context's stream. ------ */

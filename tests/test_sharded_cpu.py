@@ -1,0 +1,94 @@
+"""world_size-2 (and 3) gloo runs of the sharded update: the orchestration in beluga_amd/sharded.py — all-reduce of the
+weight sum, all-gather of shard totals, all-to-all ancestor exchange, all-reduce of the estimate sums — must reproduce
+the single-process filter.  Per-shard compute is the oracle here (no GPU in this container); on the GPU box the same
+class runs over the HIP library (tests/test_gpu_sharded.py)."""
+import math
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from beluga_amd import synth
+from beluga_amd.amcl import AmclParams, DifferentialDriveModelParam, LikelihoodFieldModelParam, OccupancyGrid, se2_from_xytheta
+from beluga_amd.sharded import ShardedAmcl, shard_bounds
+
+N_TOTAL, BEAMS, CYCLES, SEED = 3001, 90, 6, 77
+LF = LikelihoodFieldModelParam(2.0, 100.0, 0.5, 0.5, 0.2, True)
+MOTION = DifferentialDriveModelParam(0.1, 0.05, 0.1, 0.05)
+
+
+def workload():
+    cells = synth.make_rooms_map(200, 200, seed=3, n_rooms=6)
+    grid = OccupancyGrid(cells, 0.05, origin=se2_from_xytheta(-5.0, -5.0, 0.0))
+    truth = synth.find_free_pose(cells, 0.05, (-5.0, -5.0), seed=2, clearance_cells=6)
+    angles = synth.lidar_angles(BEAMS, 270.0)
+    steps, pose, odom = [], truth, (0.0, 0.0, 0.0)
+    for c in range(CYCLES):
+        fwd, turn = (0.3, 0.05) if c != 3 else (0.01, 0.0)  # one step below update_min_d
+        pose = synth.odometry_step(pose, fwd, turn)
+        odom = synth.odometry_step(odom, fwd, turn)
+        pts = synth.scan_points(synth.cast_scan(cells, 0.05, (-5.0, -5.0), pose, angles, 6.0, 0.01, seed=c), angles)
+        steps.append((se2_from_xytheta(*odom), pts))
+    return grid, truth, steps
+
+
+def reference_run(selective):
+    from oracle import binding as orc
+    grid, truth, steps = workload()
+    f = orc.Amcl(min_particles=N_TOTAL, max_particles=N_TOTAL, alphas=(0.1, 0.05, 0.1, 0.05), seed=SEED, lf=(2.0, 100.0, 0.5, 0.5, 0.2),
+                 lf_model_unknown_space=True, selective_resampling=selective, resample_interval=2 if selective else 1)
+    f.set_map(grid.cells, grid.resolution, grid.origin)
+    f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+    out = [f.update(c, p) for c, p in steps]
+    return out, f.particles()
+
+
+def _worker(rank, world, init_file, selective, result_file):
+    from shard_oracle_engine import OracleShardEngine
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    grid, truth, steps = workload()
+    params = AmclParams(min_particles=N_TOTAL, max_particles=N_TOTAL, selective_resampling=selective,
+                        resample_interval=2 if selective else 1)
+    f = ShardedAmcl(grid, MOTION, LF, params, seed=SEED, engine_factory=OracleShardEngine)
+    assert (f.first_slot, f.n_local) == shard_bounds(N_TOTAL, world, rank)
+    f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+    outs = [f.update(c, p) for c, p in steps]
+    states, w = f.gather_particles()
+    if rank == 0:
+        np.savez(result_file, states=states, w=w, updated=np.array([o is not None for o in outs]),
+                 poses=np.array([o[0] for o in outs if o is not None]), covs=np.array([o[1] for o in outs if o is not None]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,selective", [(2, False), (3, False), (2, True)])
+def test_sharded_update_matches_single_process(world, selective, tmp_path):
+    init_file = str(tmp_path / "rendezvous")
+    result_file = str(tmp_path / "result.npz")
+    mp.spawn(_worker, args=(world, init_file, selective, result_file), nprocs=world, join=True)
+    got = np.load(result_file)
+    ref_out, (ref_states, ref_w) = reference_run(selective)
+    assert list(got["updated"]) == [o is not None for o in ref_out]
+    ref_poses = np.array([o[0] for o in ref_out if o is not None])
+    ref_covs = np.array([o[1] for o in ref_out if o is not None])
+    np.testing.assert_allclose(got["poses"], ref_poses, atol=1e-9)
+    np.testing.assert_allclose(got["covs"], ref_covs, rtol=1e-8, atol=1e-11)
+    # same particle set in the same global order, up to a couple of CDF-boundary flips (summation order differs by shard)
+    assert got["states"].shape == ref_states.shape
+    assert int(np.any(np.abs(got["states"] - ref_states) > 1e-9, axis=1).sum()) <= 2
+    np.testing.assert_allclose(got["w"], ref_w, rtol=1e-9)
+
+
+def test_shard_bounds_cover_the_index_space():
+    for n, world in [(10, 3), (64_000_000, 8), (7, 8), (1, 1)]:
+        spans = [shard_bounds(n, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+        for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+            assert f0 + c0 == f1
