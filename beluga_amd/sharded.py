@@ -59,9 +59,14 @@ class HipShardEngine:
         from .amcl import Amcl
         self.torch = torch
         self.device = torch.device("cuda", device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        # One explicit stream shared by the library's kernels, torch's glue ops and the RCCL collectives
+        # (torch's default stream is the NULL stream, which the library would not adopt).
+        self.stream = torch.cuda.Stream(self.device)
         self.f = Amcl(grid, motion, sensor, params, seed=seed, device=device, shard_offset=shard_offset,
-                      shard_capacity=shard_capacity, hip_stream=stream)
+                      shard_capacity=shard_capacity, hip_stream=self.stream.cuda_stream)
+
+    def stream_scope(self):
+        return self.torch.cuda.stream(self.stream)
 
     def empty(self, *shape):
         return self.torch.empty(*shape, dtype=self.torch.float64, device=self.device)
@@ -217,7 +222,13 @@ class ShardedAmcl:
 
     def update(self, control_action, measurement):
         """Amcl::update (amcl_core.hpp:165-201) over the sharded set. Returns (pose, covariance) or None."""
-        torch, dist = self.torch, self.dist
+        scope = getattr(self.engine, "stream_scope", None)
+        if scope is None:
+            return self._update(control_action, measurement)
+        with scope():
+            return self._update(control_action, measurement)
+
+    def _update(self, control_action, measurement):
         if not self._initialized or self.n_total == 0:
             return None
         pose = np.asarray(control_action, dtype=np.float64)

@@ -115,6 +115,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MCL update has no CPU path")
     torch.cuda.set_device(local_rank)
+    # Native libraries (RCCL's version banner) write to fd 1; the contract is ONE JSON line on stdout, so fd 1 is
+    # parked on stderr until the result is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     use_sharded = world > 1 or args.sharded
     if use_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -213,7 +218,10 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cells, truth, odoms, scans, n_total)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_sharded:
         dist.barrier()
         dist.destroy_process_group()
