@@ -1,0 +1,284 @@
+// beluga_amd/amcl.hpp — header-only C++17 facade over the C ABI (include/beluga_mcl.h).
+//
+// Same public surface as `beluga::Amcl` (beluga/include/beluga/algorithm/amcl_core.hpp:81-233) for the
+// SE(2) / DifferentialDriveModel / LikelihoodFieldModel|BeamSensorModel instantiation that
+// `beluga_ros::Amcl` uses (beluga_ros/include/beluga_ros/amcl.hpp:102-282):
+//   ctor(map, motion params, sensor params, AmclParams) ; particles() ; initialize(pose, covariance) ;
+//   initialize(states) ; update_map(map) ; update(control_action, measurement) -> optional<pair<pose, cov>> ;
+//   force_update() ; likelihood_field().
+// Error behaviour follows the reference: `initialize` throws std::runtime_error on an invalid covariance
+// (random/multivariate_normal_distribution.hpp:114-124), `update` returns std::nullopt when no update ran
+// (amcl_core.hpp:166-172).  Any other failure of the device library throws std::runtime_error with its text.
+//
+// The reference's value types are Sophus::SE2d / Eigen::Matrix3d; neither library is required here.  `SE2d`
+// below has Sophus' memory layout (cos, sin, x, y) and, when <sophus/se2.hpp> is available, converts both ways.
+#ifndef BELUGA_AMD_AMCL_HPP
+#define BELUGA_AMD_AMCL_HPP
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "beluga_mcl.h"
+
+#if defined(__has_include)
+#if __has_include(<sophus/se2.hpp>)
+#include <sophus/se2.hpp>
+#define BELUGA_AMD_HAS_SOPHUS 1
+#endif
+#endif
+
+namespace beluga_amd {
+
+/// SE(2) pose with Sophus::SE2d's data() layout: unit complex (cos, sin) then translation (x, y).
+struct SE2d {
+  double c{1.0}, s{0.0}, x{0.0}, y{0.0};
+  SE2d() = default;
+  SE2d(double theta, double tx, double ty) : c(std::cos(theta)), s(std::sin(theta)), x(tx), y(ty) {}
+  [[nodiscard]] double angle() const { return std::atan2(s, c); }
+  [[nodiscard]] const double* data() const { return &c; }
+  [[nodiscard]] double* data() { return &c; }
+#ifdef BELUGA_AMD_HAS_SOPHUS
+  SE2d(const Sophus::SE2d& p) : c(p.data()[0]), s(p.data()[1]), x(p.data()[2]), y(p.data()[3]) {}  // NOLINT
+  operator Sophus::SE2d() const {                                                                    // NOLINT
+    Sophus::SE2d out;
+    out.so2().data()[0] = c;
+    out.so2().data()[1] = s;
+    out.translation() = Eigen::Vector2d{x, y};
+    return out;
+  }
+#endif
+};
+static_assert(sizeof(SE2d) == 4 * sizeof(double), "SE2d must be four packed doubles");
+
+using Matrix3d = std::array<double, 9>;  ///< row-major 3x3
+
+/// beluga::AmclParams (amcl_core.hpp:34-55) + the spatial hash resolutions of beluga_ros::AmclParams.
+struct AmclParams {
+  double update_min_d = 0.25;
+  double update_min_a = 0.2;
+  std::size_t resample_interval = 1UL;
+  bool selective_resampling = false;
+  std::size_t min_particles = 500UL;
+  std::size_t max_particles = 2000UL;
+  double alpha_slow = 0.001;
+  double alpha_fast = 0.1;
+  double kld_epsilon = 0.05;
+  double kld_z = 3.0;
+  double spatial_resolution_x = 0.5;
+  double spatial_resolution_y = 0.5;
+  double spatial_resolution_theta = 10.0 * 3.14159265358979323846 / 180.0;
+};
+
+/// beluga::DifferentialDriveModelParam (motion/differential_drive_model.hpp:40-68).
+struct DifferentialDriveModelParam {
+  double rotation_noise_from_rotation;
+  double rotation_noise_from_translation;
+  double translation_noise_from_translation;
+  double translation_noise_from_rotation;
+  double distance_threshold = 0.01;
+};
+
+/// beluga::LikelihoodFieldModelParam (sensor/likelihood_field_model_base.hpp:42-64).
+struct LikelihoodFieldModelParam {
+  double max_obstacle_distance = 100.0;
+  double max_laser_distance = 2.0;
+  double z_hit = 0.5;
+  double z_random = 0.5;
+  double sigma_hit = 0.2;
+  bool model_unknown_space = false;
+  bool only_obstacle_boundaries = false;
+};
+
+/// beluga::BeamModelParam (sensor/beam_model.hpp:43-58).
+struct BeamModelParam {
+  double z_hit{0.5};
+  double z_short{0.5};
+  double z_max{0.05};
+  double z_rand{0.05};
+  double sigma_hit{0.2};
+  double lambda_short{0.1};
+  double beam_max_range{60};
+};
+
+using SensorModelParam = std::variant<LikelihoodFieldModelParam, BeamModelParam>;
+
+/// A non-owning view of anything satisfying OccupancyGrid2 (sensor/data/occupancy_grid.hpp:39-75).
+struct OccupancyGridView {
+  const std::int8_t* cells{nullptr};  ///< row-major, height x width
+  std::uint32_t width{0}, height{0};
+  double resolution{0.0};
+  SE2d origin{};
+  std::int8_t free_value{0}, unknown_value{-1}, occupied_value{100};  ///< beluga_ros::OccupancyGrid::ValueTraits
+
+  /// Adapts a grid type with width()/height()/resolution()/origin()/data() whose cell type is int8.
+  template <class Grid>
+  static OccupancyGridView from(const Grid& grid) {
+    OccupancyGridView v;
+    v.cells = reinterpret_cast<const std::int8_t*>(&*std::begin(grid.data()));
+    v.width = static_cast<std::uint32_t>(grid.width());
+    v.height = static_cast<std::uint32_t>(grid.height());
+    v.resolution = grid.resolution();
+    const auto& o = grid.origin();
+    v.origin.c = o.data()[0];
+    v.origin.s = o.data()[1];
+    v.origin.x = o.data()[2];
+    v.origin.y = o.data()[3];
+    return v;
+  }
+};
+
+/// Host mirror of the particle set: what `beluga::TupleVector<std::tuple<SE2d, Weight>>` holds.
+struct ParticleSet {
+  std::vector<SE2d> states;
+  std::vector<double> weights;
+  [[nodiscard]] std::size_t size() const { return weights.size(); }
+  [[nodiscard]] bool empty() const { return weights.empty(); }
+};
+
+class Amcl {
+ public:
+  using state_type = SE2d;
+  using measurement_type = std::vector<std::pair<double, double>>;
+  using estimation_type = std::pair<SE2d, Matrix3d>;
+
+  Amcl(const OccupancyGridView& map, const DifferentialDriveModelParam& motion, const SensorModelParam& sensor,
+       const AmclParams& params = AmclParams{}, std::uint64_t seed = 0, int device = 0) {
+    mcl_config cfg;
+    mcl_default_config(&cfg);
+    cfg.device_id = device;
+    cfg.seed = seed;
+    cfg.amcl.update_min_d = params.update_min_d;
+    cfg.amcl.update_min_a = params.update_min_a;
+    cfg.amcl.resample_interval = params.resample_interval;
+    cfg.amcl.selective_resampling = params.selective_resampling ? 1 : 0;
+    cfg.amcl.min_particles = params.min_particles;
+    cfg.amcl.max_particles = params.max_particles;
+    cfg.amcl.alpha_slow = params.alpha_slow;
+    cfg.amcl.alpha_fast = params.alpha_fast;
+    cfg.amcl.kld_epsilon = params.kld_epsilon;
+    cfg.amcl.kld_z = params.kld_z;
+    cfg.amcl.spatial_resolution_x = params.spatial_resolution_x;
+    cfg.amcl.spatial_resolution_y = params.spatial_resolution_y;
+    cfg.amcl.spatial_resolution_theta = params.spatial_resolution_theta;
+    cfg.motion = mcl_diffdrive_params{motion.rotation_noise_from_rotation, motion.rotation_noise_from_translation,
+                                      motion.translation_noise_from_translation, motion.translation_noise_from_rotation,
+                                      motion.distance_threshold};
+    if (const auto* lf = std::get_if<LikelihoodFieldModelParam>(&sensor)) {
+      cfg.sensor_kind = MCL_SENSOR_LIKELIHOOD_FIELD;
+      cfg.lf = mcl_lf_params{lf->max_obstacle_distance, lf->max_laser_distance, lf->z_hit, lf->z_random, lf->sigma_hit,
+                             lf->model_unknown_space ? 1 : 0, lf->only_obstacle_boundaries ? 1 : 0};
+    } else {
+      const auto& b = std::get<BeamModelParam>(sensor);
+      cfg.sensor_kind = MCL_SENSOR_BEAM;
+      cfg.beam = mcl_beam_params{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range};
+    }
+    const mcl_status st = mcl_create(&cfg, &ctx_);
+    if (st != MCL_OK) throw std::runtime_error(std::string("beluga_amd::Amcl: ") + mcl_last_error(nullptr));
+    try {
+      update_map(map);
+    } catch (...) {
+      mcl_destroy(ctx_);
+      ctx_ = nullptr;
+      throw;
+    }
+  }
+  Amcl(const Amcl&) = delete;
+  Amcl& operator=(const Amcl&) = delete;
+  Amcl(Amcl&& other) noexcept : ctx_(other.ctx_), width_(other.width_), height_(other.height_) { other.ctx_ = nullptr; }
+  ~Amcl() { mcl_destroy(ctx_); }
+
+  /// Returns a reference to the current set of particles (amcl_core.hpp:127). Downloaded lazily.
+  [[nodiscard]] const ParticleSet& particles() const {
+    if (dirty_) {
+      std::uint64_t n = 0;
+      check(mcl_num_particles(ctx_, &n));
+      mirror_.states.resize(n);
+      mirror_.weights.resize(n);
+      if (n) check(mcl_get_particles(ctx_, mirror_.states.data()->data(), mirror_.weights.data(), n, &n));
+      dirty_ = false;
+    }
+    return mirror_;
+  }
+
+  /// Initialize particles with a given pose and covariance (amcl_core.hpp:145-147).
+  /// \throw std::runtime_error If the provided covariance is invalid.
+  void initialize(const SE2d& pose, const Matrix3d& covariance) {
+    const double mean[3] = {pose.x, pose.y, pose.angle()};
+    const mcl_status st = mcl_initialize_normal(ctx_, mean, covariance.data());
+    if (st == MCL_ERR_BAD_COVARIANCE) throw std::runtime_error("Invalid covariance matrix");
+    check(st);
+    dirty_ = true;
+  }
+
+  /// Initialize particles from caller-drawn states, weight 1 each (amcl_core.hpp:131-137).
+  void initialize(const std::vector<SE2d>& states) {
+    const std::vector<double> ones(states.size(), 1.0);
+    check(mcl_set_particles(ctx_, states.empty() ? nullptr : states.data()->data(), ones.data(), states.size()));
+    dirty_ = true;
+  }
+
+  /// Update the map used for localization (amcl_core.hpp:150).
+  void update_map(const OccupancyGridView& map) {
+    const std::int8_t traits[3] = {map.free_value, map.unknown_value, map.occupied_value};
+    check(mcl_set_map(ctx_, map.cells, map.width, map.height, map.resolution, map.origin.data(), traits));
+    width_ = map.width;
+    height_ = map.height;
+    field_.clear();
+  }
+
+  /// Update particles based on motion and sensor information (amcl_core.hpp:165-201).
+  auto update(const SE2d& control_action, const measurement_type& measurement) -> std::optional<estimation_type> {
+    static_assert(sizeof(std::pair<double, double>) == 2 * sizeof(double), "measurement points must be packed pairs");
+    mcl_estimate est;
+    mcl_update_info info;
+    check(mcl_update(ctx_, control_action.data(), measurement.empty() ? nullptr : &measurement.front().first, measurement.size(),
+                     &est, &info));
+    last_info_ = info;
+    if (!info.updated) return std::nullopt;
+    dirty_ = true;
+    estimation_type out;
+    out.first.c = est.pose[0];
+    out.first.s = est.pose[1];
+    out.first.x = est.pose[2];
+    out.first.y = est.pose[3];
+    for (int i = 0; i < 9; ++i) out.second[static_cast<std::size_t>(i)] = est.covariance[i];
+    return out;
+  }
+
+  /// Force a manual update of the particles on the next iteration of the filter (amcl_core.hpp:204).
+  void force_update() { check(mcl_force_update(ctx_)); }
+
+  /// LikelihoodFieldModelBase::likelihood_field() (likelihood_field_model_base.hpp:102), row-major height x width.
+  [[nodiscard]] const std::vector<float>& likelihood_field() const {
+    if (field_.empty()) {
+      field_.resize(static_cast<std::size_t>(width_) * height_);
+      check(mcl_get_likelihood_field(ctx_, field_.data()));
+    }
+    return field_;
+  }
+
+  [[nodiscard]] const mcl_update_info& last_update_info() const { return last_info_; }
+  [[nodiscard]] mcl_ctx* native_handle() const { return ctx_; }
+
+ private:
+  void check(mcl_status st) const {
+    if (st != MCL_OK) throw std::runtime_error(std::string("beluga_amd::Amcl: ") + mcl_last_error(ctx_));
+  }
+  mcl_ctx* ctx_{nullptr};
+  std::uint32_t width_{0}, height_{0};
+  mutable ParticleSet mirror_;
+  mutable bool dirty_{true};
+  mutable std::vector<float> field_;
+  mcl_update_info last_info_{};
+};
+
+}  // namespace beluga_amd
+
+#endif  // BELUGA_AMD_AMCL_HPP

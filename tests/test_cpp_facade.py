@@ -1,0 +1,66 @@
+"""The header-only C++17 facade (include/beluga_amd/amcl.hpp) compiles with plain g++ against the C ABI, reports the
+reference's error behaviour, and — on a GPU — produces the same estimates as the Python facade on the same inputs."""
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from beluga_amd import build as mcl_build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def demo(tmp_path_factory):
+    mcl_build.build()
+    exe = tmp_path_factory.mktemp("cpp") / "facade_demo"
+    lib_dir = os.path.join(ROOT, "beluga_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "facade_demo.cpp"), "-L", lib_dir, "-lbeluga_mcl",
+                           f"-Wl,-rpath,{lib_dir}", "-o", str(exe)])
+    return str(exe)
+
+
+def test_facade_compiles_and_fails_loudly_without_gpu(demo):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    out = subprocess.run([demo], capture_output=True, text=True)
+    assert out.returncode == 3
+    assert "runtime_error" in out.stdout and "no CPU fallback" in out.stdout
+
+
+@pytest.mark.gpu
+def test_facade_matches_python_facade(demo):
+    from beluga_amd.amcl import Amcl, AmclParams, DifferentialDriveModelParam, LikelihoodFieldModelParam, OccupancyGrid, se2_from_xytheta
+    out = subprocess.run([demo], capture_output=True, text=True, check=True).stdout.splitlines()
+    kv = {}
+    for line in out:
+        parts = line.split()
+        kv[" ".join(parts[:2]) if parts[0] == "update" else parts[0]] = parts[1:] if parts[0] != "update" else parts[2:]
+    assert kv["empty_update"] == ["0"] and kv["initial_particles"] == ["1500"]
+    assert kv["below_threshold"] == ["0"] and kv["forced"] == ["1"]
+
+    cells = np.zeros((64, 64), dtype=np.int8)
+    cells[40, :] = 100
+    cells[:, 50] = 100
+    grid = OccupancyGrid(cells, 0.1, origin=se2_from_xytheta(-1.0, -1.0, 0.0))
+    f = Amcl(grid, DifferentialDriveModelParam(0.1, 0.05, 0.1, 0.05), LikelihoodFieldModelParam(2.0, 100.0),
+             AmclParams(min_particles=300, max_particles=1500), seed=123)
+    f.initialize((1.0, 1.0, 0.3), np.diag([0.04, 0.04, 0.01]))
+    scan = [(1.8 * math.cos(-1.5 + b * (3.0 / 90)), 1.8 * math.sin(-1.5 + b * (3.0 / 90))) for b in range(90)]
+    ox = oy = ot = 0.0
+    for c in range(4):
+        ox += 0.3 * math.cos(ot)
+        oy += 0.3 * math.sin(ot)
+        ot += 0.05
+        pose, cov = f.update(se2_from_xytheta(ox, oy, ot), scan)
+        got = [float(v) for v in kv[f"update {c}"][:6]]
+        np.testing.assert_allclose(got, [pose[0], pose[1], pose[2], pose[3], cov[0, 0], cov[2, 2]], rtol=0, atol=1e-12)
+        assert int(kv[f"update {c}"][6]) == f.num_particles()
+    assert float(kv["field_center"][0]) == pytest.approx(float(f.likelihood_field()[40, 10]), rel=1e-7)
+    bad = subprocess.run([demo, "bad-covariance"], capture_output=True, text=True)
+    assert bad.returncode == 0 and "Invalid covariance matrix" in bad.stdout
+    f.close()
