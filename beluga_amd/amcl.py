@@ -274,6 +274,28 @@ class Amcl:
     def commit_resampled(self, step: int, first_slot: int, count: int, d_x: int, d_y: int, d_c: int, d_s: int, d_targets: int):
         self._check(self._lib.mcl_commit_resampled(self._ctx, step, first_slot, count, d_x, d_y, d_c, d_s, d_targets))
 
+    def route_targets(self, d_targets, count, d_ends, d_offsets, world, self_rank, d_send, d_order, d_counts):
+        self._check(self._lib.mcl_route_targets(self._ctx, d_targets, count, d_ends, d_offsets, world, self_rank, d_send, d_order, d_counts))
+
+    def serve_requests(self, d_requests, m, d_replies):
+        self._check(self._lib.mcl_serve_requests(self._ctx, d_requests, m, d_replies))
+
+    def commit_routed(self, step, first_slot, count, d_replies, d_order, d_targets):
+        self._check(self._lib.mcl_commit_routed(self._ctx, step, first_slot, count, d_replies, d_order, d_targets))
+
+    def weight_sum_device(self, d_sum: int):
+        self._check(self._lib.mcl_weight_sum_device(self._ctx, d_sum))
+
+    def normalize_device(self, d_factor: int, d_stats: int):
+        self._check(self._lib.mcl_normalize_device(self._ctx, d_factor, d_stats))
+
+    def build_cdf_device(self, d_total: int):
+        self._check(self._lib.mcl_build_cdf_device(self._ctx, d_total))
+
+    def estimate_sums_device(self, pivot, d_sums: int):
+        p = np.ascontiguousarray(pivot, dtype=np.float64)
+        self._check(self._lib.mcl_estimate_sums_device(self._ctx, _dp(p), d_sums))
+
     def sync(self):
         self._check(self._lib.mcl_sync(self._ctx))
 

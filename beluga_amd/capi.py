@@ -119,6 +119,13 @@ _SIGNATURES = {
     "mcl_gather_by_cdf": (C.c_int32, [_ctx, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcl_resample_targets": (C.c_int32, [_ctx, C.c_uint32, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_void_p]),
     "mcl_commit_resampled": (C.c_int32, [_ctx, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcl_route_targets": (C.c_int32, [_ctx, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcl_serve_requests": (C.c_int32, [_ctx, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "mcl_commit_routed": (C.c_int32, [_ctx, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcl_weight_sum_device": (C.c_int32, [_ctx, C.c_void_p]),
+    "mcl_normalize_device": (C.c_int32, [_ctx, C.c_void_p, C.c_void_p]),
+    "mcl_build_cdf_device": (C.c_int32, [_ctx, C.c_void_p]),
+    "mcl_estimate_sums_device": (C.c_int32, [_ctx, c_double_p, C.c_void_p]),
     "mcl_sync": (C.c_int32, [_ctx]),
     "mcl_profile_enable": (C.c_int32, [_ctx, C.c_int32]),
     "mcl_profile_read": (C.c_int32, [_ctx, c_double_p, c_u64_p, C.c_int32]),

@@ -212,6 +212,7 @@ struct mcl_ctx {
   double pivot[2]{0, 0};
   int lf_variant{kLfSortedLanes};
   // scratch of the spatially binned likelihood-field kernel
+  DeviceBuffer<uint32_t> d_route_u32;           // scratch of mcl_route_targets
   DeviceBuffer<uint32_t> d_sort_u32;            // keys[cap] perm[cap] block_hist chunk_sum chunk_off
   DeviceBuffer<unsigned long long> d_sort_u64;  // keyidx[cap]
   DeviceBuffer<double> d_sort_f64;              // bbox[8 + 6*nblocks] tc ts tx ty [cap each]
@@ -609,6 +610,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_uchunk.release();
   ctx->d_kld_scalars.release();
   ctx->d_sort_u32.release();
+  ctx->d_route_u32.release();
   ctx->d_sort_u64.release();
   ctx->d_sort_f64.release();
   if (ctx->h_points) (void)hipHostFree(ctx->h_points);
@@ -980,6 +982,92 @@ mcl_status mcl_commit_resampled(mcl_ctx* ctx, uint32_t step, uint64_t first_slot
   MCL_HIP(ctx, hipGetLastError());
   ctx->live ^= 1;
   ctx->n = count;
+  return MCL_OK;
+}
+
+mcl_status mcl_route_targets(mcl_ctx* ctx, const double* d_targets, uint64_t count, const double* d_ends, const double* d_offsets,
+                             uint32_t world, uint32_t self_rank, double* d_send_targets, uint32_t* d_order, int64_t* d_counts) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, world >= 1 && world <= 64 && self_rank < world, "world must be 1..64");
+  MCL_REQUIRE(ctx, d_ends && d_offsets && d_counts && (count == 0 || (d_targets && d_send_targets && d_order)), "null argument");
+  MCL_REQUIRE(ctx, count < (1ull << 32), "too many targets");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  const size_t nblocks = num_chunks(count);
+  const size_t hist = static_cast<size_t>(world) * nblocks;
+  MCL_HIP(ctx, ctx->d_route_u32.ensure(hist + 2 * (hist / kChunk + 1) + (count + 3) / 4 + 4));
+  uint32_t* block_hist = ctx->d_route_u32.ptr;
+  uint32_t* chunk_sum = block_hist + hist;
+  uint32_t* chunk_off = chunk_sum + (hist / kChunk + 1);
+  uint8_t* dest = reinterpret_cast<uint8_t*>(chunk_off + (hist / kChunk + 1));
+  launch_route_targets(ctx->stream, d_targets, count, d_ends, d_offsets, world, self_rank, dest, block_hist, chunk_sum, chunk_off,
+                       d_send_targets, d_order, reinterpret_cast<long long*>(d_counts));
+  MCL_HIP(ctx, hipGetLastError());
+  return MCL_OK;
+}
+
+mcl_status mcl_serve_requests(mcl_ctx* ctx, const double* d_requests, uint64_t m, double* d_replies) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, m == 0 || (d_requests && d_replies), "null argument");
+  MCL_REQUIRE(ctx, m == 0 || ctx->n > 0, "empty shard cannot serve draws");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  launch_gather_by_cdf_aos(ctx->stream, ctx->cur(), ctx->d_cdf.ptr, ctx->n, d_requests, m, d_replies);
+  MCL_HIP(ctx, hipGetLastError());
+  return MCL_OK;
+}
+
+mcl_status mcl_commit_routed(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,
+                             const uint32_t* d_order, const double* d_targets) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, count <= ctx->capacity, "count exceeds shard capacity");
+  MCL_REQUIRE(ctx, count == 0 || (d_replies && d_order && d_targets), "null argument");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  stage_begin(ctx, MCL_STAGE_RESAMPLE);
+  launch_commit_routed(ctx->stream, ctx->other(), ctx->cfg.seed, step, first_slot, count, d_replies, d_order, d_targets,
+                       ctx->grid_view(), FreeCells{ctx->d_free.ptr, ctx->have_map ? ctx->n_free : 0});
+  stage_end(ctx, MCL_STAGE_RESAMPLE);
+  MCL_HIP(ctx, hipGetLastError());
+  ctx->live ^= 1;
+  ctx->n = count;
+  return MCL_OK;
+}
+
+mcl_status mcl_weight_sum_device(mcl_ctx* ctx, double* d_sum) {
+  if (!ctx || !d_sum) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  launch_weight_sum(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), d_sum);
+  MCL_HIP(ctx, hipGetLastError());
+  return MCL_OK;
+}
+
+mcl_status mcl_normalize_device(mcl_ctx* ctx, const double* d_factor, double* d_stats) {
+  if (!ctx || !d_factor || !d_stats) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  stage_begin(ctx, MCL_STAGE_NORMALIZE);
+  launch_normalize(ctx->stream, ctx->cur().w, ctx->n, d_factor, ctx->chunk_row(1), ctx->chunk_row(2), d_stats);
+  stage_end(ctx, MCL_STAGE_NORMALIZE);
+  MCL_HIP(ctx, hipGetLastError());
+  return MCL_OK;
+}
+
+mcl_status mcl_build_cdf_device(mcl_ctx* ctx, double* d_total) {
+  if (!ctx || !d_total) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  if (ctx->n == 0) {
+    MCL_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(double), ctx->stream));
+    return MCL_OK;
+  }
+  launch_cdf(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(3), ctx->chunk_row(4), ctx->d_cdf.ptr, d_total);
+  MCL_HIP(ctx, hipGetLastError());
+  return MCL_OK;
+}
+
+mcl_status mcl_estimate_sums_device(mcl_ctx* ctx, const double pivot_xy[2], double* d_sums) {
+  if (!ctx || !pivot_xy || !d_sums) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  stage_begin(ctx, MCL_STAGE_ESTIMATE);
+  launch_estimate_sums(ctx->stream, ctx->cur(), ctx->n, pivot_xy[0], pivot_xy[1], ctx->chunk_row(0), d_sums);
+  stage_end(ctx, MCL_STAGE_ESTIMATE);
+  MCL_HIP(ctx, hipGetLastError());
   return MCL_OK;
 }
 

@@ -125,6 +125,14 @@ void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, doubl
 void launch_commit_resampled(hipStream_t st, ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
                              const double* x, const double* y, const double* c, const double* s, const double* targets, GridView g,
                              FreeCells fc);
+// Counting sort of resample targets by owning shard; d_block_hist needs world * num_chunks(count) words.
+void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t count, const double* d_ends, const double* d_offsets,
+                          uint32_t world, uint32_t self_rank, uint8_t* d_dest, uint32_t* d_block_hist, uint32_t* d_chunk_sum,
+                          uint32_t* d_chunk_off, double* d_send_targets, uint32_t* d_order, long long* d_counts);
+void launch_gather_by_cdf_aos(hipStream_t st, ParticleSoA src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
+                              double* d_out);
+void launch_commit_routed(hipStream_t st, ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
+                          const double* d_replies, const uint32_t* d_order, const double* d_targets, GridView g, FreeCells fc);
 // K7: exact parallel take_while_kld (take_while_kld.hpp:72-88).
 struct KldTable {
   unsigned long long* keys;  // 0 = empty (hash 0 is remapped)

@@ -803,6 +803,99 @@ __global__ __launch_bounds__(kBlock) void k_commit_resampled(ParticleSoA dst, ui
   dst.w[t] = 1.0;
 }
 
+// Routing of the resample targets to the shards that own them (counting sort by destination rank, <= 64 ranks).
+constexpr uint32_t kMaxRanks = 64;
+__global__ __launch_bounds__(kBlock) void k_route_hist(const double* __restrict__ targets, uint64_t count, const double* __restrict__ ends,
+                                                       uint32_t world, uint32_t self_rank, uint8_t* __restrict__ dest,
+                                                       uint32_t* __restrict__ block_hist, uint32_t nblocks) {
+  __shared__ uint32_t hist[kMaxRanks];
+  __shared__ double s_ends[kMaxRanks];
+  if (threadIdx.x < kMaxRanks) {
+    hist[threadIdx.x] = 0;
+    s_ends[threadIdx.x] = threadIdx.x < world ? ends[threadIdx.x] : INFINITY;
+  }
+  __syncthreads();
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+#pragma unroll
+  for (int k = 0; k < kChunk / kBlock; ++k) {
+    const uint64_t i = base + k * kBlock + threadIdx.x;
+    if (i < count) {
+      const double t = targets[i];
+      uint32_t d = self_rank;  // injected slots (NaN) are served locally and ignored at commit time
+      if (t == t) {
+        d = 0;
+        while (d + 1 < world && s_ends[d] < t) ++d;  // std::lower_bound over the shard interval ends
+      }
+      dest[i] = static_cast<uint8_t>(d);
+      atomicAdd(&hist[d], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < world) block_hist[static_cast<size_t>(threadIdx.x) * nblocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void k_route_scatter(const double* __restrict__ targets, uint64_t count,
+                                                          const double* __restrict__ shard_offsets, uint32_t world,
+                                                          const uint8_t* __restrict__ dest, const uint32_t* __restrict__ block_offsets,
+                                                          uint32_t nblocks, double* __restrict__ send_targets,
+                                                          uint32_t* __restrict__ order) {
+  __shared__ uint32_t cursor[kMaxRanks];
+  __shared__ double s_off[kMaxRanks];
+  if (threadIdx.x < world) {
+    cursor[threadIdx.x] = block_offsets[static_cast<size_t>(threadIdx.x) * nblocks + blockIdx.x];
+    s_off[threadIdx.x] = shard_offsets[threadIdx.x];
+  }
+  __syncthreads();
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+#pragma unroll
+  for (int k = 0; k < kChunk / kBlock; ++k) {
+    const uint64_t i = base + k * kBlock + threadIdx.x;
+    if (i < count) {
+      const uint32_t d = dest[i];
+      const double t = targets[i];
+      const uint32_t slot = atomicAdd(&cursor[d], 1u);
+      send_targets[slot] = t == t ? t - s_off[d] : 0.0;
+      order[slot] = static_cast<uint32_t>(i);
+    }
+  }
+}
+
+__global__ void k_route_counts(const uint32_t* __restrict__ block_offsets, uint32_t nblocks, uint32_t world, uint64_t count,
+                               long long* __restrict__ counts) {
+  const uint32_t d = threadIdx.x;
+  if (d >= world) return;
+  const uint64_t begin = block_offsets[static_cast<size_t>(d) * nblocks];
+  const uint64_t end = d + 1 < world ? block_offsets[static_cast<size_t>(d + 1) * nblocks] : count;
+  counts[d] = static_cast<long long>(end - begin);
+}
+
+// AoS variants for the exchange buffers: reply[t] = (x, y, c, s) of the served ancestor.
+__global__ __launch_bounds__(kBlock) void k_gather_by_cdf_aos(ParticleSoA src, const double* __restrict__ cdf, uint64_t n,
+                                                              const double* __restrict__ targets, uint64_t m, double4* __restrict__ out) {
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= m) return;
+  const uint64_t idx = cdf_lower_bound(cdf, n, targets[t]);
+  out[t] = double4{src.x[idx], src.y[idx], src.c[idx], src.s[idx]};
+}
+
+__global__ __launch_bounds__(kBlock) void k_commit_routed(ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot,
+                                                          uint64_t count, const double4* __restrict__ replies,
+                                                          const uint32_t* __restrict__ order, const double* __restrict__ targets,
+                                                          GridView g, FreeCells fc) {
+  const uint64_t k = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k >= count) return;
+  const uint32_t t = order[k];  // reply k answers output slot t
+  Pose2 v;
+  if (targets[t] != targets[t]) {
+    v = random_free_state(seed, step, first_slot + t, g, fc);
+  } else {
+    const double4 r = replies[k];
+    v = Pose2{Rot2{r.z, r.w}, r.x, r.y};
+  }
+  store_pose(dst, t, v);
+  dst.w[t] = 1.0;
+}
+
 // ---- K7 KLD ---------------------------------------------------------------------------------------------
 constexpr unsigned long long kEmptyKey = ~0ull;
 __device__ __forceinline__ unsigned long long kld_key(unsigned long long h) { return h == kEmptyKey ? h - 1 : h; }
@@ -1091,6 +1184,39 @@ void launch_commit_resampled(hipStream_t st, ParticleSoA dst, uint64_t seed, uin
   if (count == 0) return;
   hipLaunchKernelGGL(k_commit_resampled, dim3(blocks_for(count)), dim3(kBlock), 0, st, dst, seed, step, first_slot, count, x, y, c, s,
                      targets, g, fc);
+}
+
+void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t count, const double* d_ends, const double* d_offsets,
+                          uint32_t world, uint32_t self_rank, uint8_t* d_dest, uint32_t* d_block_hist, uint32_t* d_chunk_sum,
+                          uint32_t* d_chunk_off, double* d_send_targets, uint32_t* d_order, long long* d_counts) {
+  const uint32_t nblocks = num_chunks(count);
+  if (nblocks == 0) {
+    (void)hipMemsetAsync(d_counts, 0, sizeof(long long) * world, st);
+    return;
+  }
+  hipLaunchKernelGGL(k_route_hist, dim3(nblocks), dim3(kBlock), 0, st, d_targets, count, d_ends, world, self_rank, d_dest, d_block_hist,
+                     nblocks);
+  const uint32_t m = world * nblocks;
+  const uint32_t mchunks = num_chunks(m);
+  hipLaunchKernelGGL(k_u32_chunk_sum, dim3(mchunks), dim3(kBlock), 0, st, d_block_hist, m, d_chunk_sum);
+  hipLaunchKernelGGL(k_scan_chunks<uint32_t>, dim3(1), dim3(kBlock), 0, st, d_chunk_sum, mchunks, d_chunk_off,
+                     static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr));
+  hipLaunchKernelGGL(k_u32_exclusive_apply, dim3(mchunks), dim3(kBlock), 0, st, d_block_hist, m, d_chunk_off);
+  hipLaunchKernelGGL(k_route_counts, dim3(1), dim3(kMaxRanks), 0, st, d_block_hist, nblocks, world, count, d_counts);
+  hipLaunchKernelGGL(k_route_scatter, dim3(nblocks), dim3(kBlock), 0, st, d_targets, count, d_offsets, world, d_dest, d_block_hist,
+                     nblocks, d_send_targets, d_order);
+}
+void launch_gather_by_cdf_aos(hipStream_t st, ParticleSoA src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
+                              double* d_out) {
+  if (m == 0) return;
+  hipLaunchKernelGGL(k_gather_by_cdf_aos, dim3(blocks_for(m)), dim3(kBlock), 0, st, src, cdf, n, d_targets, m,
+                     reinterpret_cast<double4*>(d_out));
+}
+void launch_commit_routed(hipStream_t st, ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
+                          const double* d_replies, const uint32_t* d_order, const double* d_targets, GridView g, FreeCells fc) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_commit_routed, dim3(blocks_for(count)), dim3(kBlock), 0, st, dst, seed, step, first_slot, count,
+                     reinterpret_cast<const double4*>(d_replies), d_order, d_targets, g, fc);
 }
 
 void launch_kld_insert(hipStream_t st, const unsigned long long* d_hashes, uint64_t first, uint64_t count, KldTable t) {

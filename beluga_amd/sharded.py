@@ -89,28 +89,39 @@ class HipShardEngine:
     def reweight(self, points):
         self.f.reweight(points)
 
-    def weight_sum(self):
-        return self.f.weight_sum()
+    # scalars stay on the device: tensors in, tensors out, nothing synchronises
+    def weight_sum_into(self, t_sum):
+        self.f.weight_sum_device(t_sum.data_ptr())
 
-    def normalize(self, factor):
-        return self.f.normalize(factor)
+    def normalize_from(self, t_factor, t_stats2):
+        self.f.normalize_device(t_factor.data_ptr(), t_stats2.data_ptr())
 
-    def build_cdf(self):
-        return self.f.build_cdf()
+    def build_cdf_into(self, t_total):
+        self.f.build_cdf_device(t_total.data_ptr())
+
+    def estimate_sums_into(self, pivot, t_sums9):
+        self.f.estimate_sums_device(pivot, t_sums9.data_ptr())
 
     def resample_targets(self, step, p, total, first_slot, count, targets):
         self.f.resample_targets(step, p, total, first_slot, count, targets.data_ptr())
 
-    def gather_by_cdf(self, targets, out4):
-        m = targets.numel()
-        self.f.gather_by_cdf(targets.data_ptr(), m, out4[0].data_ptr(), out4[1].data_ptr(), out4[2].data_ptr(), out4[3].data_ptr())
+    def route_targets(self, targets, ends, offsets, self_rank):
+        """-> (shard-local targets grouped by owner rank, order[k] = slot answered by request k, int64 counts per rank)"""
+        torch, m, world = self.torch, targets.numel(), ends.numel()
+        send = self.empty(m)
+        order = torch.empty(m, dtype=torch.int32, device=self.device)
+        counts = torch.empty(world, dtype=torch.int64, device=self.device)
+        self.f.route_targets(targets.data_ptr(), m, ends.data_ptr(), offsets.data_ptr(), world, self_rank, send.data_ptr(),
+                             order.data_ptr(), counts.data_ptr())
+        return send, order, counts
 
-    def commit_resampled(self, step, first_slot, count, states4, targets):
-        self.f.commit_resampled(step, first_slot, count, states4[0].data_ptr(), states4[1].data_ptr(), states4[2].data_ptr(),
-                                states4[3].data_ptr(), targets.data_ptr())
+    def serve_requests(self, requests):
+        replies = self.empty(requests.numel(), 4)
+        self.f.serve_requests(requests.data_ptr(), requests.numel(), replies.data_ptr())
+        return replies
 
-    def estimate_sums(self, pivot):
-        return self.f.estimate_sums(pivot)
+    def commit_routed(self, step, first_slot, count, replies, order, targets):
+        self.f.commit_routed(step, first_slot, count, replies.data_ptr(), order.data_ptr(), targets.data_ptr())
 
     def sync(self):
         self.f.sync()
@@ -166,18 +177,6 @@ class ShardedAmcl:
         self.last_info = None
         self._initialized = False
 
-    # -- collectives ---------------------------------------------------------------------------------
-    def _all_reduce_sum(self, values):
-        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return t.cpu().numpy()
-
-    def _all_gather(self, values):
-        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.device)
-        out = self.torch.empty(self.world * t.numel(), dtype=self.torch.float64, device=self.device)
-        self.dist.all_gather_into_tensor(out, t, group=self.group)
-        return out.cpu().numpy().reshape(self.world, -1)
-
     # -- reference surface -----------------------------------------------------------------------------
     def initialize(self, pose_xytheta, covariance):
         """Amcl::initialize(pose, covariance): every rank draws its slice of the same global sample stream."""
@@ -229,6 +228,7 @@ class ShardedAmcl:
             return self._update(control_action, measurement)
 
     def _update(self, control_action, measurement):
+        torch, dist = self.torch, self.dist
         if not self._initialized or self.n_total == 0:
             return None
         pose = np.asarray(control_action, dtype=np.float64)
@@ -249,13 +249,22 @@ class ShardedAmcl:
 
         e.propagate(self._window[0], self._window[1], self._step)  # :174-175
         e.reweight(measurement)                                     # :176
-        weight_sum = float(self._all_reduce_sum([e.weight_sum()])[0])  # C1
-        local = e.normalize(weight_sum)                             # :177 with the GLOBAL sum; local sums of w, w^2 come back
         # every_n (every_n.hpp:47-50) does not depend on data: build the shard CDF only when it fires
         self._every_n = (self._every_n + 1) % self.params.resample_interval
         fires = self._every_n == 0
-        cdf_total = e.build_cdf() if fires else 0.0
-        stats = self._all_gather([cdf_total, local["norm_sum"], local["norm_sumsq"]])  # C2
+        # Scalars stay on the device between the kernels and the collectives; ONE host read-back for the policies.
+        buf = e.empty(4)                     # [global weight sum | shard cdf total, shard sum w, shard sum w^2]
+        buf.zero_()
+        e.weight_sum_into(buf[0:1])
+        dist.all_reduce(buf[0:1], op=dist.ReduceOp.SUM, group=self.group)          # C1
+        e.normalize_from(buf[0:1], buf[2:4])                                        # :177 with the GLOBAL sum
+        if fires:
+            e.build_cdf_into(buf[1:2])
+        gathered = e.empty(self.world * 3)
+        dist.all_gather_into_tensor(gathered, buf[1:4].contiguous(), group=self.group)  # C2
+        host = torch.cat([buf[0:1], gathered]).cpu().numpy()
+        weight_sum = float(host[0])
+        stats = host[1:].reshape(self.world, 3)
         totals, norm_sum, norm_sumsq = stats[:, 0], float(stats[:, 1].sum()), float(stats[:, 2].sum())
 
         # :179 ThrunRecoveryProbabilityEstimator on the normalised weights (thrun_..._estimator.hpp:69-89)
@@ -276,8 +285,10 @@ class ShardedAmcl:
             self._resample(totals, p_random)
         self._force = False  # :199
 
-        sums = np.asarray(e.estimate_sums(self._pivot), dtype=np.float64)  # :200
-        sums[:9] = self._all_reduce_sum(sums[:9].tolist())                 # C4
+        t_sums = e.empty(9)                                                 # :200
+        e.estimate_sums_into(self._pivot, t_sums)
+        dist.all_reduce(t_sums, op=dist.ReduceOp.SUM, group=self.group)     # C4
+        sums = np.concatenate([t_sums.cpu().numpy(), self._pivot, [0.0]])
         pose_est, cov = estimate_from_sums(sums)
         if np.all(np.isfinite(pose_est[2:])):
             self._pivot = np.array([pose_est[2], pose_est[3]])
@@ -296,28 +307,19 @@ class ShardedAmcl:
 
         targets = e.empty(m)
         e.resample_targets(self._step, p_random, total, self.first_slot, m, targets)
-        injected = torch.isnan(targets)
-        lookup = torch.where(injected, torch.zeros_like(targets), targets)
         # owner = first shard whose interval end is >= the target (std::lower_bound on the global CDF)
-        dest = torch.bucketize(lookup, ends, right=False).clamp_(max=world - 1)
-        dest = torch.where(injected, torch.full_like(dest, self.rank), dest)
-        local_targets = lookup - offsets[dest]
-        order = torch.argsort(dest, stable=True)
-        send_counts = torch.bincount(dest, minlength=world)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
-        send_list, recv_list = send_counts.tolist(), recv_counts.tolist()
+        requests_out, order, send_counts = e.route_targets(targets, ends, offsets, self.rank)
+        all_counts = torch.empty(world * world, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(all_counts, send_counts, group=self.group)   # counts[r][q]: r asks q for that many
+        counts = all_counts.cpu().view(world, world)
+        send_list, recv_list = counts[self.rank].tolist(), counts[:, self.rank].tolist()
 
-        requests = e.empty(int(sum(recv_list)))
-        dist.all_to_all_single(requests, local_targets[order].contiguous(), recv_list, send_list, group=self.group)
-        served = e.empty(4, requests.numel())
-        if requests.numel():
-            e.gather_by_cdf(requests, served)
+        requests_in = e.empty(int(sum(recv_list)))
+        dist.all_to_all_single(requests_in, requests_out, recv_list, send_list, group=self.group)
+        served = e.serve_requests(requests_in)                      # (m_in, 4) records (x, y, cos, sin)
         replies = e.empty(m, 4)
-        dist.all_to_all_single(replies, served.t().contiguous(), send_list, recv_list, group=self.group)
-        states = e.empty(4, m)
-        states[:, order] = replies.t()
-        e.commit_resampled(self._step, self.first_slot, m, states, targets)
+        dist.all_to_all_single(replies, served, send_list, recv_list, group=self.group)
+        e.commit_routed(self._step, self.first_slot, m, replies, order, targets)
 
     def close(self):
         self.engine.close()

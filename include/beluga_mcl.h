@@ -219,6 +219,26 @@ mcl_status mcl_resample_targets(mcl_ctx* ctx, uint32_t step, double random_state
  * holds `count` particles. */
 mcl_status mcl_commit_resampled(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_x,
                                 const double* d_y, const double* d_c, const double* d_s, const double* d_targets);
+/* Routing for the ancestor exchange (device pointers throughout, nothing synchronises):
+ * groups the `count` targets of mcl_resample_targets by the shard that owns them. `d_ends[r]` / `d_offsets[r]` are the
+ * inclusive end / exclusive start of shard r's interval of the global CDF (world <= 64).  Outputs: d_send_targets =
+ * shard-local targets ordered by destination rank, d_order[k] = output slot answered by the k-th request,
+ * d_counts[r] (int64) = requests for rank r.  NaN targets (injected slots) are routed to `self_rank`. */
+mcl_status mcl_route_targets(mcl_ctx* ctx, const double* d_targets, uint64_t count, const double* d_ends, const double* d_offsets,
+                             uint32_t world, uint32_t self_rank, double* d_send_targets, uint32_t* d_order, int64_t* d_counts);
+/* As mcl_gather_by_cdf with one (x, y, cos, sin) record of 4 doubles per request. */
+mcl_status mcl_serve_requests(mcl_ctx* ctx, const double* d_requests, uint64_t m, double* d_replies);
+/* As mcl_commit_resampled, taking the replies in request order plus the d_order of mcl_route_targets. */
+mcl_status mcl_commit_routed(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,
+                             const uint32_t* d_order, const double* d_targets);
+/* Device-side variants for callers that keep scalars on the GPU (e.g. to feed RCCL collectives without a host
+ * round trip).  All pointers are DEVICE pointers; nothing synchronises; work is enqueued on the context's stream. */
+mcl_status mcl_weight_sum_device(mcl_ctx* ctx, double* d_sum);
+/* d_factor: the (global) normalisation factor; d_stats[0] = sum of the new weights, d_stats[1] = sum of squares. */
+mcl_status mcl_normalize_device(mcl_ctx* ctx, const double* d_factor, double* d_stats);
+mcl_status mcl_build_cdf_device(mcl_ctx* ctx, double* d_total);
+/* d_sums[0..8] = the nine sums of mcl_estimate_sums for the given pivot. */
+mcl_status mcl_estimate_sums_device(mcl_ctx* ctx, const double pivot_xy[2], double* d_sums);
 mcl_status mcl_sync(mcl_ctx* ctx);
 
 /* ---- Measurement hooks (bench.py): HIP-event timing of each stage on the context's stream. ------ */

@@ -50,19 +50,19 @@ class OracleShardEngine:
     def reweight(self, points):
         self.w = self.w * orc.lf_weights(self.field, self.grid.resolution, self.grid.origin, self.lf[1], self.states, points)
 
-    def weight_sum(self):
-        return float(np.sum(self.w))
+    def weight_sum_into(self, t_sum):
+        t_sum[0] = float(np.sum(self.w))
 
-    def normalize(self, factor):
-        s = float(np.sum(self.w))
-        f = s if np.isnan(factor) else factor
+    def normalize_from(self, t_factor, t_stats2):
+        f = float(t_factor[0])
         if not abs(f - 1.0) < np.finfo(np.float64).eps:
             self.w = self.w / f
-        return {"sum": s, "norm_sum": float(np.sum(self.w)), "norm_sumsq": float(np.sum(self.w * self.w))}
+        t_stats2[0] = float(np.sum(self.w))
+        t_stats2[1] = float(np.sum(self.w * self.w))
 
-    def build_cdf(self):
+    def build_cdf_into(self, t_total):
         self.cdf = np.cumsum(self.w)
-        return float(self.cdf[-1]) if len(self.cdf) else 0.0
+        t_total[0] = float(self.cdf[-1]) if len(self.cdf) else 0.0
 
     def resample_targets(self, step, p, total, first_slot, count, targets):
         out = targets.numpy()
@@ -72,26 +72,38 @@ class OracleShardEngine:
             u = float(((int(r[0]) << 32) | int(r[1])) >> 11) * 2.0 ** -53
             out[t] = np.nan if inject else u * total
 
-    def gather_by_cdf(self, targets, out4):
-        idx = np.minimum(np.searchsorted(self.cdf, targets.numpy(), side="left"), len(self.cdf) - 1)
-        o = out4.numpy()
-        o[0], o[1], o[2], o[3] = self.states[idx, 2], self.states[idx, 3], self.states[idx, 0], self.states[idx, 1]
+    def route_targets(self, targets, ends, offsets, self_rank):
+        t = targets.numpy()
+        injected = np.isnan(t)
+        lookup = np.where(injected, 0.0, t)
+        dest = np.minimum(np.searchsorted(ends.numpy(), lookup, side="left"), len(ends) - 1)
+        dest = np.where(injected, self_rank, dest)
+        order = np.argsort(dest, kind="stable")
+        local = np.where(injected, 0.0, lookup - offsets.numpy()[dest])
+        counts = np.bincount(dest, minlength=len(ends)).astype(np.int64)
+        return torch.from_numpy(local[order].copy()), torch.from_numpy(order.astype(np.int32)), torch.from_numpy(counts)
 
-    def commit_resampled(self, step, first_slot, count, states4, targets):
-        s4, t = states4.numpy(), targets.numpy()
-        new = np.stack([s4[2], s4[3], s4[0], s4[1]], axis=1)
+    def serve_requests(self, requests):
+        idx = np.minimum(np.searchsorted(self.cdf, requests.numpy(), side="left"), len(self.cdf) - 1)
+        s = self.states[idx]
+        return torch.from_numpy(np.stack([s[:, 2], s[:, 3], s[:, 0], s[:, 1]], axis=1).copy())
+
+    def commit_routed(self, step, first_slot, count, replies, order, targets):
+        r, t, o = replies.numpy(), targets.numpy(), order.numpy()
+        new = np.zeros((count, 4))
+        new[o] = np.stack([r[:, 2], r[:, 3], r[:, 0], r[:, 1]], axis=1)
         for k in np.flatnonzero(np.isnan(t)):
-            r = orc.draw(self.seed, step, 3, first_slot + int(k))
-            cell = min(int((float(((int(r[0]) << 32) | int(r[1])) >> 11) * 2.0 ** -53) * len(self.free_xy)), len(self.free_xy) - 1)
-            theta = -np.pi + 2.0 * np.pi * (float(((int(r[2]) << 32) | int(r[3])) >> 11) * 2.0 ** -53)
+            d = orc.draw(self.seed, step, 3, first_slot + int(k))
+            cell = min(int((float(((int(d[0]) << 32) | int(d[1])) >> 11) * 2.0 ** -53) * len(self.free_xy)), len(self.free_xy) - 1)
+            theta = -np.pi + 2.0 * np.pi * (float(((int(d[2]) << 32) | int(d[3])) >> 11) * 2.0 ** -53)
             new[k] = orc.se2(self.free_xy[cell, 0], self.free_xy[cell, 1], theta)
         self.states, self.w = new, np.ones(count)
 
-    def estimate_sums(self, pivot):
+    def estimate_sums_into(self, pivot, t_sums9):
         w, s = self.w, self.states
         dx, dy = s[:, 2] - pivot[0], s[:, 3] - pivot[1]
-        return np.array([w.sum(), (w * w).sum(), (w * s[:, 0]).sum(), (w * s[:, 1]).sum(), (w * dx).sum(), (w * dy).sum(),
-                         (w * dx * dx).sum(), (w * dx * dy).sum(), (w * dy * dy).sum(), pivot[0], pivot[1], 0.0])
+        t_sums9.copy_(torch.tensor([w.sum(), (w * w).sum(), (w * s[:, 0]).sum(), (w * s[:, 1]).sum(), (w * dx).sum(), (w * dy).sum(),
+                                    (w * dx * dx).sum(), (w * dx * dy).sum(), (w * dy * dy).sum()], dtype=torch.float64))
 
     def sync(self):
         pass
