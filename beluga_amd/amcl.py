@@ -299,6 +299,11 @@ class Amcl:
     def sync(self):
         self._check(self._lib.mcl_sync(self._ctx))
 
+    def beam_cells_visited(self, reset: bool = True) -> int:
+        v = C.c_uint64(0)
+        self._check(self._lib.mcl_beam_cells_visited(self._ctx, C.byref(v), int(reset)))
+        return v.value
+
     # -- measurement hooks ---------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         self._check(self._lib.mcl_profile_enable(self._ctx, int(on)))

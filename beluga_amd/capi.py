@@ -129,6 +129,7 @@ _SIGNATURES = {
     "mcl_sync": (C.c_int32, [_ctx]),
     "mcl_profile_enable": (C.c_int32, [_ctx, C.c_int32]),
     "mcl_profile_read": (C.c_int32, [_ctx, c_double_p, c_u64_p, C.c_int32]),
+    "mcl_beam_cells_visited": (C.c_int32, [_ctx, c_u64_p, C.c_int32]),
     "mcl_version": (C.c_char_p, []),
 }
 

@@ -309,7 +309,7 @@ mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
   MCL_HIP(ctx, ctx->d_cdf.ensure(cap));
   MCL_HIP(ctx, ctx->d_aos.ensure(cap * 4));
   ctx->capacity = cap;
-  if (ctx->cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD) {
+  {
     const size_t hist = static_cast<size_t>(kSortDigits) * num_chunks(cap);
     MCL_HIP(ctx, ctx->d_sort_u32.ensure(2 * cap + hist + 2 * (hist / kChunk + 1)));
     MCL_HIP(ctx, ctx->d_sort_u64.ensure(cap));
@@ -382,10 +382,14 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B) {
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
   } else {
     const mcl_beam_params& b = ctx->cfg.beam;
+    const bool ordered = ctx->n >= 16384;  // same threshold as the likelihood-field path
+    const SortScratch sort = ctx->sort_scratch();
+    // The ordering pass also emits origin_inverse * state for every particle (Ray2d ctor, raycasting.hpp:69).
+    if (ordered) launch_lf_bin_sort(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), &sort);
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
     launch_reweight_beam(ctx->stream, ctx->cur(), ctx->n, ctx->grid_view(),
                          BeamModel{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range},
-                         ctx->d_points.ptr, static_cast<uint32_t>(B), ctx->d_kld_scalars.ptr + 1);
+                         ctx->d_points.ptr, static_cast<uint32_t>(B), ctx->d_kld_scalars.ptr + 1, ordered ? &sort : nullptr);
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
   }
   stage_end(ctx, MCL_STAGE_REWEIGHT);
@@ -449,17 +453,31 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
       if (const mcl_status s = ensure_kld(ctx)) return s;
     }
     MCL_REQUIRE(ctx, max_p < 0xFFFFFFFFull, "max_particles too large for KLD resampling");
-    MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_keys.ptr, 0xFF, ctx->table_capacity * sizeof(unsigned long long), ctx->stream));
-    MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_first.ptr, 0xFF, ctx->table_capacity * sizeof(unsigned int), ctx->stream));
     MCL_HIP(ctx, hipMemsetAsync(ctx->d_kld_scalars.ptr, 0xFF, sizeof(unsigned long long), ctx->stream));  // first_fail = ~0
     uint32_t* kwords = reinterpret_cast<uint32_t*>(ctx->d_kld_scalars.ptr + 4);                          // [0]=k_base,[1]=k_total
     MCL_HIP(ctx, hipMemsetAsync(kwords, 0, 2 * sizeof(uint32_t), ctx->stream));
-    const KldTable table{ctx->d_table_keys.ptr, ctx->d_table_first.ptr, ctx->table_capacity};
+    // The open-addressing table is sized for the candidates seen so far (load <= 1/2), not for max_particles: a tight
+    // cloud stops after ~min_particles candidates and must not pay for clearing a table of 2 * max_particles slots.
+    // When the next chunk outgrows it, it is cleared at the larger size and the earlier hashes are re-inserted.
+    uint64_t table_slots = 0;
+    auto grow_table = [&](uint64_t candidates, uint64_t already) -> mcl_status {
+      uint64_t want = 1024;
+      while (want < 2 * candidates) want <<= 1;
+      want = std::min<uint64_t>(want, ctx->table_capacity);
+      if (want <= table_slots) return MCL_OK;
+      table_slots = want;
+      MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_keys.ptr, 0xFF, table_slots * sizeof(unsigned long long), ctx->stream));
+      MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_first.ptr, 0xFF, table_slots * sizeof(unsigned int), ctx->stream));
+      launch_kld_insert(ctx->stream, ctx->d_hashes.ptr, 0, already, KldTable{ctx->d_table_keys.ptr, ctx->d_table_first.ptr, table_slots});
+      return MCL_OK;
+    };
     uint64_t pos = 0;
     uint64_t chunk = std::max<uint64_t>(a.min_particles + 1, 1ull << 16);
     int flip = 0;
     while (pos < max_p) {
       const uint64_t cnt = std::min(chunk, max_p - pos);
+      if (const mcl_status s = grow_table(pos + cnt, pos)) return s;
+      const KldTable table{ctx->d_table_keys.ptr, ctx->d_table_first.ptr, table_slots};
       ra.first_candidate = pos;
       ra.count = cnt;
       ra.out_offset = pos;
@@ -1076,6 +1094,17 @@ mcl_status mcl_sync(mcl_ctx* ctx) {
   if (const mcl_status s = bind_device(ctx)) return s;
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   stage_collect(ctx);
+  return MCL_OK;
+}
+
+mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset) {
+  if (!ctx || !cells) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  MCL_HIP(ctx, hipMemcpyAsync(ctx->h_kld_scalars + 1, ctx->d_kld_scalars.ptr + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  if (reset) MCL_HIP(ctx, hipMemsetAsync(ctx->d_kld_scalars.ptr + 1, 0, sizeof(unsigned long long), ctx->stream));
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *cells = ctx->h_kld_scalars[1];
   return MCL_OK;
 }
 

@@ -97,8 +97,9 @@ void launch_lf_bin_sort(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, 
 void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
+// `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_lf_bin_sort with world_to_field = origin_inverse first).
 void launch_reweight_beam(hipStream_t st, ParticleSoA p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
-                          unsigned long long* d_steps);
+                          unsigned long long* d_steps, const SortScratch* sorted);
 
 // Deterministic chunked reductions / scans.  Chunk = 2048 consecutive elements per workgroup.
 constexpr uint32_t kChunk = 2048;

@@ -463,6 +463,100 @@ __device__ __forceinline__ void cell_near(const GridView& g, double px, double p
   yi = static_cast<int>(floor(py * inv));
 }
 
+// Ray2d::cast over Bresenham2i's standard variant (raycasting.hpp:78-107, bresenham.hpp:84-160): walk the integer line
+// from the source cell towards the far-end cell, stop at the first cell that is outside the grid (no hit), non-free
+// (hit) or past the end of the line (no hit).  The walk is evaluated kSpec cells at a time: the Bresenham state of the
+// next cells does not depend on the grid, so their loads are issued together and examined in order — same cells, same
+// order, same result, but the load latency of a step is no longer serialised behind the previous step's compare.
+constexpr int kSpec = 4;
+__device__ __forceinline__ double cast_ray(const GridView& g, int sx, int sy, int fx, int fy, double max_range,
+                                           unsigned long long& steps) {
+  int x_ = sx, y_ = sy;
+  int xspan = fx - sx, xstep = 1;
+  if (xspan < 0) {
+    xspan = -xspan;
+    xstep = -1;
+  }
+  int yspan = fy - sy, ystep = 1;
+  if (yspan < 0) {
+    yspan = -yspan;
+    ystep = -1;
+  }
+  bool reversed = false;
+  if (xspan < yspan) {
+    int t = x_; x_ = y_; y_ = t;
+    t = xspan; xspan = yspan; yspan = t;
+    t = xstep; xstep = ystep; ystep = t;
+    reversed = true;
+  }
+  const int dxspan = 2 * xspan, dyspan = 2 * yspan;
+  int error = xspan, step = 0;
+  while (true) {
+    int cxs[kSpec], cys[kSpec];
+    bool inside[kSpec], last[kSpec];
+    int8_t vals[kSpec];
+#pragma unroll
+    for (int u = 0; u < kSpec; ++u) {
+      cxs[u] = reversed ? y_ : x_;
+      cys[u] = reversed ? x_ : y_;
+      inside[u] = static_cast<unsigned>(cxs[u]) < g.W && static_cast<unsigned>(cys[u]) < g.H;
+      ++step;
+      last[u] = step > xspan;  // `if (++step_ > xspan_) return` — the iterator reaches the sentinel after this cell
+      x_ += xstep;
+      error += dyspan;
+      if (error > dxspan) {
+        y_ += ystep;
+        error -= dxspan;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSpec; ++u) {
+      const size_t idx = inside[u] ? static_cast<size_t>(cys[u]) * g.W + static_cast<size_t>(cxs[u]) : size_t{0};
+      vals[u] = g.cells[idx];
+    }
+#pragma unroll
+    for (int u = 0; u < kSpec; ++u) {
+      if (!inside[u]) return max_range;  // take_while(contains) ended the trace: std::nullopt -> value_or(max_range)
+      ++steps;
+      if (vals[u] != g.free_value) {     // cast(): raycasting.hpp:97-107
+        const double ax = (static_cast<double>(sx) + 0.5) * g.resolution, ay = (static_cast<double>(sy) + 0.5) * g.resolution;
+        const double bx = (static_cast<double>(cxs[u]) + 0.5) * g.resolution, by = (static_cast<double>(cys[u]) + 0.5) * g.resolution;
+        const double dx = bx - ax, dy = by - ay;
+        return fmin(sqrt(dx * dx + dy * dy), max_range);
+      }
+      if (last[u]) return max_range;
+    }
+  }
+}
+
+// One beam of beam_model.hpp:110-147 for a source pose already in the grid frame (Ray2d ctor: raycasting.hpp:62-70).
+__device__ __forceinline__ double beam_term(const GridView& g, const BeamModel& m, double norm_hit, const Pose2& src, int sx, int sy,
+                                            double px, double py, unsigned long long& steps) {
+  const double z = sqrt(px * px + py * py);
+  const double bc = px / z, bs = py / z;
+  double ex, ey;  // trace(): raycasting.hpp:78-88
+  rot_apply(src.r, bc * m.beam_max_range, bs * m.beam_max_range, ex, ey);
+  ex += src.x;
+  ey += src.y;
+  int fx, fy;
+  cell_near(g, ex, ey, fx, fy);
+  const double z_mean = cast_ray(g, sx, sy, fx, fy, m.beam_max_range, steps);
+  const double eta_hit = 2. / (erf((m.beam_max_range - z_mean) / (sqrt(2.) * m.sigma_hit)) - erf(-z_mean / (sqrt(2.) * m.sigma_hit)));
+  const double d = (z - z_mean) / m.sigma_hit;
+  double pz = m.z_hit * eta_hit * norm_hit * exp(-(d * d) / 2.);
+  if (z < z_mean) {
+    const double eta_short = 1. / (1. - exp(-m.lambda_short * z_mean));
+    pz += m.z_short * m.lambda_short * eta_short * exp(-m.lambda_short * z);
+  }
+  if (z < m.beam_max_range) {
+    pz += m.z_rand / m.beam_max_range;
+  } else {
+    pz += m.z_max;
+  }
+  return pz * pz * pz;
+}
+
+// Variant A: one wavefront per particle, one lane per beam (small particle sets).
 __global__ __launch_bounds__(kBlock) void k_reweight_beam(ParticleSoA p, uint64_t n, GridView g, BeamModel m,
                                                           const double2* __restrict__ pts, uint32_t B, unsigned long long* d_steps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -472,7 +566,6 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam(ParticleSoA p, uint64_
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * (kBlock / kWave) + (threadIdx.x >> 6);
   if (i >= n) return;
-  // Ray2d ctor: raycasting.hpp:62-70
   const Pose2 src = pose_mul(g.origin_inverse, load_pose(p, i));
   int sx, sy;
   cell_near(g, src.x, src.y, sx, sy);
@@ -481,72 +574,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam(ParticleSoA p, uint64_
   unsigned long long steps = 0;
   for (uint32_t b = lane; b < B; b += kWave) {
     const double2 pt = s_pts[b];
-    const double z = sqrt(pt.x * pt.x + pt.y * pt.y);
-    const double bc = pt.x / z, bs = pt.y / z;
-    // trace(): raycasting.hpp:78-88
-    double ex, ey;
-    rot_apply(src.r, bc * m.beam_max_range, bs * m.beam_max_range, ex, ey);
-    ex += src.x;
-    ey += src.y;
-    int fx, fy;
-    cell_near(g, ex, ey, fx, fy);
-    // Bresenham2i standard variant: bresenham.hpp:84-160
-    int x_ = sx, y_ = sy;
-    int xspan = fx - sx, xstep = 1;
-    if (xspan < 0) {
-      xspan = -xspan;
-      xstep = -1;
-    }
-    int yspan = fy - sy, ystep = 1;
-    if (yspan < 0) {
-      yspan = -yspan;
-      ystep = -1;
-    }
-    bool reversed = false;
-    if (xspan < yspan) {
-      int t = x_; x_ = y_; y_ = t;
-      t = xspan; xspan = yspan; yspan = t;
-      t = xstep; xstep = ystep; ystep = t;
-      reversed = true;
-    }
-    const int dxspan = 2 * xspan, dyspan = 2 * yspan;
-    int error = xspan, step = 0;
-    int cx = sx, cy = sy;
-    double z_mean = m.beam_max_range;  // cast(...).value_or(max_range)
-    while (true) {
-      if (!(static_cast<unsigned>(cx) < g.W && static_cast<unsigned>(cy) < g.H)) break;  // take_while(contains)
-      ++steps;
-      if (g.cells[static_cast<size_t>(cy) * g.W + static_cast<size_t>(cx)] != g.free_value) {  // cast(): raycasting.hpp:97-107
-        const double ax = (static_cast<double>(sx) + 0.5) * g.resolution, ay = (static_cast<double>(sy) + 0.5) * g.resolution;
-        const double bx = (static_cast<double>(cx) + 0.5) * g.resolution, by = (static_cast<double>(cy) + 0.5) * g.resolution;
-        const double dx = bx - ax, dy = by - ay;
-        z_mean = fmin(sqrt(dx * dx + dy * dy), m.beam_max_range);
-        break;
-      }
-      if (++step > xspan) break;
-      x_ += xstep;
-      error += dyspan;
-      if (error > dxspan) {
-        y_ += ystep;
-        error -= dxspan;
-      }
-      cx = reversed ? y_ : x_;
-      cy = reversed ? x_ : y_;
-    }
-    // mixture: beam_model.hpp:124-147
-    const double eta_hit = 2. / (erf((m.beam_max_range - z_mean) / (sqrt(2.) * m.sigma_hit)) - erf(-z_mean / (sqrt(2.) * m.sigma_hit)));
-    const double d = (z - z_mean) / m.sigma_hit;
-    double pz = m.z_hit * eta_hit * norm_hit * exp(-(d * d) / 2.);
-    if (z < z_mean) {
-      const double eta_short = 1. / (1. - exp(-m.lambda_short * z_mean));
-      pz += m.z_short * m.lambda_short * eta_short * exp(-m.lambda_short * z);
-    }
-    if (z < m.beam_max_range) {
-      pz += m.z_rand / m.beam_max_range;
-    } else {
-      pz += m.z_max;
-    }
-    acc += pz * pz * pz;
+    acc += beam_term(g, m, norm_hit, src, sx, sy, pt.x, pt.y, steps);
   }
   const double total = wave_sum_f64(acc);
   if (d_steps) {
@@ -554,6 +582,37 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam(ParticleSoA p, uint64_
     if (lane == 0) atomicAdd(d_steps, steps);
   }
   if (lane == 0) p.w[i] = p.w[i] * total;
+}
+
+// Variant B (default above 16K particles): one lane per spatially ordered particle, every lane walks the same
+// beam at the same time.  Neighbouring lanes trace nearly the same line, so the byte loads of a step fall into one or
+// two cache lines and the lanes of a wave finish their walks together; the sum is the reference's sequential sum.
+__global__ __launch_bounds__(kBlock) void k_reweight_beam_sorted(double* __restrict__ w, uint64_t n, GridView g, BeamModel m,
+                                                                 const double* __restrict__ pts, uint32_t B,
+                                                                 const uint32_t* __restrict__ perm, const double* __restrict__ tc,
+                                                                 const double* __restrict__ ts, const double* __restrict__ tx,
+                                                                 const double* __restrict__ ty, unsigned long long* d_steps) {
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const uint64_t tt = t < n ? t : n - 1;
+  const Pose2 src{Rot2{tc[tt], ts[tt]}, tx[tt], ty[tt]};
+  int sx, sy;
+  cell_near(g, src.x, src.y, sx, sy);
+  const double norm_hit = 1. / (sqrt(2. * kPi) * m.sigma_hit);
+  double acc = 0.0;
+  unsigned long long steps = 0;
+  for (uint32_t b = 0; b < B; ++b) {
+    const double px = pts[2 * b], py = pts[2 * b + 1];
+    acc += beam_term(g, m, norm_hit, src, sx, sy, px, py, steps);
+  }
+  if (d_steps) {
+    if (t >= n) steps = 0;
+    for (int o = 32; o > 0; o >>= 1) steps += __shfl_down(steps, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(d_steps, steps);
+  }
+  if (t < n) {
+    const uint32_t i = perm[t];
+    w[i] = w[i] * acc;
+  }
 }
 
 // ---- K3 weight sums / normalize ----------------------------------------------------------------------
@@ -901,21 +960,51 @@ constexpr unsigned long long kEmptyKey = ~0ull;
 __device__ __forceinline__ unsigned long long kld_key(unsigned long long h) { return h == kEmptyKey ? h - 1 : h; }
 __device__ __forceinline__ uint64_t kld_slot(unsigned long long key, uint64_t mask) { return (key ^ (key >> 29) ^ (key >> 47)) & mask; }
 
+// Insert (hash -> smallest candidate index).  A tight particle cloud has a few hundred distinct bins, so a naive
+// per-candidate global atomic would serialise tens of thousands of updates on the same few addresses; each workgroup
+// first de-duplicates its 2048 candidates in an LDS table and only the per-workgroup winners touch global memory.
+constexpr uint32_t kLocalSlots = 4096;
 __global__ __launch_bounds__(kBlock) void k_kld_insert(const unsigned long long* __restrict__ hashes, uint64_t first, uint64_t count,
                                                        KldTable t) {
-  const uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (q >= count) return;
-  const uint64_t j = first + q;
-  const unsigned long long key = kld_key(hashes[j]);
-  const uint64_t mask = t.capacity - 1;
-  uint64_t slot = kld_slot(key, mask);
-  while (true) {
-    const unsigned long long prev = atomicCAS(&t.keys[slot], kEmptyKey, key);
-    if (prev == kEmptyKey || prev == key) {
-      atomicMin(&t.first[slot], static_cast<unsigned int>(j));
-      return;
+  __shared__ unsigned long long lkeys[kLocalSlots];
+  __shared__ unsigned int lfirst[kLocalSlots];
+  for (uint32_t s = threadIdx.x; s < kLocalSlots; s += kBlock) {
+    lkeys[s] = kEmptyKey;
+    lfirst[s] = 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+#pragma unroll
+  for (int k = 0; k < kChunk / kBlock; ++k) {
+    const uint64_t q = base + k * kBlock + threadIdx.x;
+    if (q < count) {
+      const uint64_t j = first + q;
+      const unsigned long long key = kld_key(hashes[j]);
+      uint32_t slot = static_cast<uint32_t>(kld_slot(key, kLocalSlots - 1));
+      while (true) {
+        const unsigned long long prev = atomicCAS(&lkeys[slot], kEmptyKey, key);
+        if (prev == kEmptyKey || prev == key) {
+          atomicMin(&lfirst[slot], static_cast<unsigned int>(j));
+          break;
+        }
+        slot = (slot + 1) & (kLocalSlots - 1);
+      }
     }
-    slot = (slot + 1) & mask;
+  }
+  __syncthreads();
+  const uint64_t mask = t.capacity - 1;
+  for (uint32_t s = threadIdx.x; s < kLocalSlots; s += kBlock) {
+    const unsigned long long key = lkeys[s];
+    if (key == kEmptyKey) continue;
+    uint64_t slot = kld_slot(key, mask);
+    while (true) {
+      const unsigned long long prev = atomicCAS(&t.keys[slot], kEmptyKey, key);
+      if (prev == kEmptyKey || prev == key) {
+        atomicMin(&t.first[slot], lfirst[s]);
+        break;
+      }
+      slot = (slot + 1) & mask;
+    }
   }
 }
 
@@ -1127,8 +1216,13 @@ void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, 
 }
 
 void launch_reweight_beam(hipStream_t st, ParticleSoA p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
-                          unsigned long long* d_steps) {
+                          unsigned long long* d_steps, const SortScratch* sorted) {
   if (n == 0) return;
+  if (sorted) {
+    hipLaunchKernelGGL(k_reweight_beam_sorted, dim3(blocks_for(n)), dim3(kBlock), 0, st, p.w, n, g, m, d_points, B, sorted->perm,
+                       sorted->tc, sorted->ts, sorted->tx, sorted->ty, d_steps);
+    return;
+  }
   const dim3 grid(static_cast<unsigned>((n + (kBlock / kWave) - 1) / (kBlock / kWave)));
   hipLaunchKernelGGL(k_reweight_beam, grid, dim3(kBlock), static_cast<size_t>(B) * sizeof(double2), st, p, n, g, m,
                      reinterpret_cast<const double2*>(d_points), B, d_steps);
@@ -1221,7 +1315,7 @@ void launch_commit_routed(hipStream_t st, ParticleSoA dst, uint64_t seed, uint32
 
 void launch_kld_insert(hipStream_t st, const unsigned long long* d_hashes, uint64_t first, uint64_t count, KldTable t) {
   if (count == 0) return;
-  hipLaunchKernelGGL(k_kld_insert, dim3(blocks_for(count)), dim3(kBlock), 0, st, d_hashes, first, count, t);
+  hipLaunchKernelGGL(k_kld_insert, dim3(num_chunks(count)), dim3(kBlock), 0, st, d_hashes, first, count, t);
 }
 
 void launch_kld_scan(hipStream_t st, const unsigned long long* d_hashes, uint64_t first, uint64_t count, KldTable t,

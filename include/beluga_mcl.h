@@ -255,6 +255,9 @@ mcl_status mcl_profile_enable(mcl_ctx* ctx, int32_t on);
 /* Accumulated milliseconds and launch counts per stage since the last reset. */
 mcl_status mcl_profile_read(mcl_ctx* ctx, double ms[MCL_NUM_STAGES], uint64_t counts[MCL_NUM_STAGES], int32_t reset);
 
+/* Beam model only: grid cells visited by the ray walks since the last reset (cells/s). */
+mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
+
 const char* mcl_version(void);
 
 #ifdef __cplusplus

@@ -148,11 +148,11 @@ def test_reweight_lf_rotated_origin_and_empty_scan():
     f.close()
 
 
-def test_reweight_beam_matches_oracle():
+@pytest.mark.parametrize("n,beams", [(777, 181), (20_001, 61)])  # wave-per-particle kernel / ordered-lanes kernel
+def test_reweight_beam_matches_oracle(n, beams):
     grid = rooms_grid(300, 4)
     truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=2, clearance_cells=6)
-    pts = make_scan(grid, truth, 181, max_range=10.0, fov=360.0)
-    n = 777
+    pts = make_scan(grid, truth, beams, max_range=10.0, fov=360.0)
     states = synth.normal_particles(n, truth, (0.3, 0.3, 0.2), seed=5)
     states[:3, 2] += 50.0  # source cell outside the grid: no trace at all
     beam = BeamModelParam(beam_max_range=10.0)
