@@ -30,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# k_reweight_lf_sorted at 1M x 1080: FETCH_SIZE 109581.8 KB, WRITE_SIZE 34063.3 KB per launch (round-1 PMC run)
+LF_KERNEL_HBM_BYTES_PER_LAUNCH = int(2 * 109581.8 * 1024 + 34063.3 * 1024)
 HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 
 MAP_SIZE, RESOLUTION, ORIGIN = 4000, 0.05, (-100.0, -100.0)
@@ -210,7 +212,9 @@ def main():
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
-                "traffic": None,
+                # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_calibration.txt):
+                # 2 * FETCH_SIZE (gfx950 counts half of every read, calibrated on known streams and gathers) + WRITE_SIZE.
+                "traffic": LF_KERNEL_HBM_BYTES_PER_LAUNCH if (n_local == 1_000_000 and not use_sharded) else None,
                 "algorithmic_bytes_per_launch": bytes_lf,
                 "avg_launch_ms": lf_avg_s * 1e3,
                 "launches": int(lf_count),
