@@ -173,6 +173,7 @@ struct mcl_ctx {
   DeviceBuffer<float> d_field;
   DeviceBuffer<double> d_cube;  // pz^3 table of the field (+1 slot for out-of-grid beams)
   DeviceBuffer<int8_t> d_cells;
+  DeviceBuffer<uint32_t> d_nonfree_bits;  // beam model: 1 bit per cell
   DeviceBuffer<uint32_t> d_free;
   uint64_t n_free{0};
   std::vector<float> h_field;
@@ -389,7 +390,8 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B) {
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
     launch_reweight_beam(ctx->stream, ctx->cur(), ctx->n, ctx->grid_view(),
                          BeamModel{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range},
-                         ctx->d_points.ptr, static_cast<uint32_t>(B), ctx->d_kld_scalars.ptr + 1, ordered ? &sort : nullptr);
+                         ctx->d_points.ptr, static_cast<uint32_t>(B), ctx->d_kld_scalars.ptr + 1, ordered ? &sort : nullptr,
+                         ctx->d_nonfree_bits.ptr);
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
   }
   stage_end(ctx, MCL_STAGE_REWEIGHT);
@@ -615,6 +617,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_field.release();
   ctx->d_cube.release();
   ctx->d_cells.release();
+  ctx->d_nonfree_bits.release();
   ctx->d_free.release();
   ctx->d_points.release();
   ctx->d_chunk.release();
@@ -663,6 +666,13 @@ mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32
   MCL_HIP(ctx, ctx->d_free.ensure(std::max<size_t>(free_cells.size(), 1)));
   if (!free_cells.empty())
     MCL_HIP(ctx, hipMemcpy(ctx->d_free.ptr, free_cells.data(), free_cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (ctx->cfg.sensor_kind == MCL_SENSOR_BEAM) {
+    MCL_REQUIRE(ctx, n < (1ull << 31), "mcl_set_map: beam model grids are limited to 2^31 cells");
+    MCL_HIP(ctx, ctx->d_nonfree_bits.ensure(static_cast<size_t>((width + 31) / 32) * height));
+    launch_pack_nonfree(ctx->stream, ctx->d_cells.ptr, width, height, ctx->traits.free_value, ctx->d_nonfree_bits.ptr);
+    MCL_HIP(ctx, hipGetLastError());
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   if (ctx->cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD) {
     build_likelihood_field(cells, width, height, resolution, ctx->traits, ctx->cfg.lf, ctx->h_field);
     MCL_HIP(ctx, ctx->d_field.ensure(n));

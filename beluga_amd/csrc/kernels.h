@@ -99,7 +99,9 @@ void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, 
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_lf_bin_sort with world_to_field = origin_inverse first).
 void launch_reweight_beam(hipStream_t st, ParticleSoA p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
-                          unsigned long long* d_steps, const SortScratch* sorted);
+                          unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits);
+// One bit per cell (1 = not free), ceil(W/32) words per row: the occupancy the ray walks read.
+void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32_t H, int8_t free_value, uint32_t* bits);
 
 // Deterministic chunked reductions / scans.  Chunk = 2048 consecutive elements per workgroup.
 constexpr uint32_t kChunk = 2048;

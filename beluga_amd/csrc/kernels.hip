@@ -476,9 +476,34 @@ constexpr int kSpec = 4;
 //    along the major axis the k-th cell is x0 + k*xstep; along the minor axis it is y0 + ystep*m_k with
 //    m_k = ceil((xspan + k*dyspan) / dxspan) - 1 (the error term stays in (0, dxspan]), so the first k that leaves
 //    the grid has a closed form.  Cells 0..last are then all inside and only their occupancy has to be read.
-__device__ __forceinline__ double cast_ray(const GridView& g, int sx, int sy, int fx, int fy, double max_range,
-                                           unsigned long long& steps) {
-  if (!(static_cast<unsigned>(sx) < g.W && static_cast<unsigned>(sy) < g.H)) return max_range;  // empty trace
+struct RayWalk {
+  int sx, sy;
+  bool steep;
+  int major_span, major_step, minor_step, dmajor, dminor;
+  int last;   // last cell index k of the trace that is inside the grid (-1: empty trace)
+  int k, error, trips;
+  int x, y;   // cell k
+};
+
+// Number of cells (minus one) of the walk that stay inside the box [lo_major, hi_major] x [lo_minor, hi_minor].
+__device__ __forceinline__ int walk_room(const RayWalk& r, int major_pos, int minor_pos, int lo_major, int hi_major, int lo_minor,
+                                         int hi_minor) {
+  if (major_pos < lo_major || major_pos > hi_major || minor_pos < lo_minor || minor_pos > hi_minor) return -1;
+  int last = r.major_span;
+  last = min(last, r.major_step > 0 ? hi_major - major_pos : major_pos - lo_major);
+  if (r.dminor > 0) {
+    const long long room_minor = r.minor_step > 0 ? hi_minor - minor_pos : minor_pos - lo_minor;  // trips that stay inside
+    // first k with m_k >= room_minor + 1  <=>  major_span + k*dminor > (room_minor + 1) * dmajor
+    const long long k_exit = ((room_minor + 1) * r.dmajor - r.major_span) / r.dminor + 1;
+    if (k_exit - 1 < last) last = static_cast<int>(k_exit - 1);
+  }
+  return last;
+}
+
+__device__ __forceinline__ RayWalk walk_begin(const GridView& g, int sx, int sy, int fx, int fy) {
+  RayWalk r;
+  r.sx = sx;
+  r.sy = sy;
   int xspan = fx - sx, xstep = 1;
   if (xspan < 0) {
     xspan = -xspan;
@@ -489,73 +514,171 @@ __device__ __forceinline__ double cast_ray(const GridView& g, int sx, int sy, in
     yspan = -yspan;
     ystep = -1;
   }
-  // major / minor axis (bresenham.hpp:98-106 swaps x and y when the line is steep)
-  const bool steep = xspan < yspan;
-  const int major_span = steep ? yspan : xspan, minor_span = steep ? xspan : yspan;
-  const int major_step = steep ? ystep : xstep, minor_step = steep ? xstep : ystep;
-  const int major_pos = steep ? sy : sx, minor_pos = steep ? sx : sy;
-  const int major_size = static_cast<int>(steep ? g.H : g.W), minor_size = static_cast<int>(steep ? g.W : g.H);
-  const int major_stride = steep ? static_cast<int>(g.W) * ystep : xstep;
-  const int minor_stride = steep ? xstep : static_cast<int>(g.W) * ystep;
-  const int dmajor = 2 * major_span, dminor = 2 * minor_span;
-  // last cell index k examined: the line has major_span + 1 cells (k = 0 .. major_span)
-  int last = major_span;
-  const int room_major = major_step > 0 ? major_size - 1 - major_pos : major_pos;  // steps that stay inside
-  last = min(last, room_major);
-  if (dminor > 0) {
-    const long long room_minor = minor_step > 0 ? minor_size - 1 - minor_pos : minor_pos;  // trips that stay inside
-    // first k with m_k >= room_minor + 1  <=>  major_span + k*dminor > (room_minor + 1) * dmajor
-    const long long k_exit = ((room_minor + 1) * dmajor - major_span) / dminor + 1;
-    if (k_exit - 1 < last) last = static_cast<int>(k_exit - 1);
-  }
-  int idx = sy * static_cast<int>(g.W) + sx;
-  int error = major_span;
-  int k = 0;
-  int hit_k = -1, hit_trips = 0, trips = 0;
-  while (k <= last) {
-    int idxs[kSpec], trip_after[kSpec];
+  r.steep = xspan < yspan;  // bresenham.hpp:98-106 swaps the axes of a steep line
+  r.major_span = r.steep ? yspan : xspan;
+  const int minor_span = r.steep ? xspan : yspan;
+  r.major_step = r.steep ? ystep : xstep;
+  r.minor_step = r.steep ? xstep : ystep;
+  r.dmajor = 2 * r.major_span;
+  r.dminor = 2 * minor_span;
+  r.last = walk_room(r, r.steep ? sy : sx, r.steep ? sx : sy, 0, static_cast<int>(r.steep ? g.H : g.W) - 1, 0,
+                     static_cast<int>(r.steep ? g.W : g.H) - 1);
+  r.k = 0;
+  r.error = r.major_span;
+  r.trips = 0;
+  r.x = sx;
+  r.y = sy;
+  return r;
+}
+
+// Examines cells k .. upto (inclusive) kSpec at a time; `occupied(x, y)` says whether a cell is non-free.
+// Returns true and leaves (x, y, k) at the hit; otherwise k = upto + 1 and the state is ready to continue.
+template <class Fetch>
+__device__ __forceinline__ bool walk_until(RayWalk& r, int upto, Fetch&& occupied) {
+  const int mx = r.steep ? 0 : r.major_step, my = r.steep ? r.major_step : 0;
+  const int nx = r.steep ? r.minor_step : 0, ny = r.steep ? 0 : r.minor_step;
+  while (r.k <= upto) {
+    int xs[kSpec], ys[kSpec];
+    int err[kSpec], trp[kSpec];
 #pragma unroll
     for (int u = 0; u < kSpec; ++u) {
-      idxs[u] = idx;
-      trip_after[u] = trips;
-      error += dminor;
-      const bool trip = error > dmajor;
-      idx += major_stride + (trip ? minor_stride : 0);
-      error -= trip ? dmajor : 0;
-      trips += trip ? 1 : 0;
+      xs[u] = r.x;
+      ys[u] = r.y;
+      err[u] = r.error;
+      trp[u] = r.trips;
+      r.error += r.dminor;
+      const bool trip = r.error > r.dmajor;
+      r.x += mx + (trip ? nx : 0);
+      r.y += my + (trip ? ny : 0);
+      r.error -= trip ? r.dmajor : 0;
+      r.trips += trip ? 1 : 0;
     }
-    int8_t vals[kSpec];
+    bool occ[kSpec];
 #pragma unroll
-    for (int u = 0; u < kSpec; ++u) vals[u] = (k + u <= last) ? g.cells[idxs[u]] : g.free_value;
-    bool found = false;
+    for (int u = 0; u < kSpec; ++u) occ[u] = (r.k + u <= upto) ? occupied(xs[u], ys[u]) : false;
 #pragma unroll
     for (int u = 0; u < kSpec; ++u) {
-      if (!found && k + u <= last && vals[u] != g.free_value) {
-        found = true;
-        hit_k = k + u;
-        hit_trips = trip_after[u];
+      if (occ[u]) {
+        r.x = xs[u];
+        r.y = ys[u];
+        r.k += u;
+        return true;
       }
     }
-    if (found) break;
-    k += kSpec;
+    if (r.k + kSpec > upto + 1) {  // rewind the speculative overshoot so that a later phase continues at upto + 1
+      const int keep = upto + 1 - r.k;  // 1 .. kSpec-1 cells of this group were real
+      r.x = xs[keep];
+      r.y = ys[keep];
+      r.error = err[keep];
+      r.trips = trp[keep];
+      r.k = upto + 1;
+      return false;
+    }
+    r.k += kSpec;
   }
-  if (hit_k < 0) {
-    steps += static_cast<unsigned long long>(last + 1);
-    return max_range;
+  return false;
+}
+
+__device__ __forceinline__ double walk_result(const GridView& g, const RayWalk& r, bool hit, double max_range,
+                                              unsigned long long& steps) {
+  if (!hit) {
+    steps += static_cast<unsigned long long>(r.last + 1);
+    return max_range;  // std::nullopt -> value_or(max_range)
   }
-  steps += static_cast<unsigned long long>(hit_k + 1);
+  steps += static_cast<unsigned long long>(r.k + 1);
   // cast(): distance between cell centres (raycasting.hpp:97-107)
-  const int hx = steep ? sx + minor_step * hit_trips : sx + major_step * hit_k;
-  const int hy = steep ? sy + major_step * hit_k : sy + minor_step * hit_trips;
-  const double ax = (static_cast<double>(sx) + 0.5) * g.resolution, ay = (static_cast<double>(sy) + 0.5) * g.resolution;
-  const double bx = (static_cast<double>(hx) + 0.5) * g.resolution, by = (static_cast<double>(hy) + 0.5) * g.resolution;
+  const double ax = (static_cast<double>(r.sx) + 0.5) * g.resolution, ay = (static_cast<double>(r.sy) + 0.5) * g.resolution;
+  const double bx = (static_cast<double>(r.x) + 0.5) * g.resolution, by = (static_cast<double>(r.y) + 0.5) * g.resolution;
   const double dx = bx - ax, dy = by - ay;
   return fmin(sqrt(dx * dx + dy * dy), max_range);
 }
 
+__device__ __forceinline__ double cast_ray(const GridView& g, int sx, int sy, int fx, int fy, double max_range,
+                                           unsigned long long& steps) {
+  RayWalk r = walk_begin(g, sx, sy, fx, fy);
+  const bool hit = walk_until(r, r.last, [&g](int x, int y) {
+    return g.cells[static_cast<size_t>(y) * g.W + static_cast<size_t>(x)] != g.free_value;
+  });
+  return walk_result(g, r, hit, max_range, steps);
+}
+
+// The same cast with the occupancy of a kWin x kWin cell window around the workgroup's particles staged in LDS as one
+// bit per cell (row stride kWinStride words: one word of padding keeps vertically adjacent cells on different banks).
+// Cells of the trace beyond the window (long rays near its edge) are read from the global bit mask.
+constexpr int kWin = 1024, kWinWords = kWin / 32, kWinStride = kWinWords + 1;
+struct BitWindow {
+  const uint32_t* lds;      // kWin rows x kWinStride words
+  int x0, y0;               // grid cell of window bit (0, 0); x0 is a multiple of 32
+  const uint32_t* global;   // whole-grid mask, words_per_row words per row
+  uint32_t words_per_row;
+};
+// Error trips after k steps of the walk: the error term stays in (0, dmajor], so m_k = ceil((major_span + k*dminor) / dmajor) - 1.
+__device__ __forceinline__ int walk_trips_at(const RayWalk& r, int k) {
+  if (r.dmajor == 0) return 0;
+  return static_cast<int>((r.major_span + static_cast<long long>(k) * r.dminor + r.dmajor - 1) / r.dmajor) - 1;
+}
+__device__ __forceinline__ void walk_seek(RayWalk& r, int k, int error) {
+  const int trips = walk_trips_at(r, k);
+  r.k = k;
+  r.error = error;
+  r.trips = trips;
+  r.x = r.steep ? r.sx + r.minor_step * trips : r.sx + r.major_step * k;
+  r.y = r.steep ? r.sy + r.major_step * k : r.sy + r.minor_step * trips;
+}
+
+__device__ __forceinline__ double cast_ray_window(const GridView& g, const BitWindow& w, int sx, int sy, int fx, int fy,
+                                                  double max_range, unsigned long long& steps) {
+  RayWalk r = walk_begin(g, sx, sy, fx, fy);
+  const int in_window = walk_room(r, r.steep ? sy : sx, r.steep ? sx : sy, r.steep ? w.y0 : w.x0, (r.steep ? w.y0 : w.x0) + kWin - 1,
+                                  r.steep ? w.x0 : w.y0, (r.steep ? w.x0 : w.y0) + kWin - 1);
+  const int upto = min(r.last, in_window);
+  if (upto >= kSpec - 1) {
+    // Hot loop: whole groups of kSpec cells, all inside the grid and the window, addressed incrementally in LDS
+    // (bit position along x, word-row offset along y); ~13 integer ops per cell.
+    int lx = sx - w.x0, lrow = (sy - w.y0) * kWinStride;
+    const int m_lx = r.steep ? 0 : r.major_step, m_row = r.steep ? r.major_step * kWinStride : 0;
+    const int b_lx = m_lx + (r.steep ? r.minor_step : 0), b_row = m_row + (r.steep ? 0 : r.minor_step * kWinStride);
+    int error = r.error, k = 0, hit_k = -1;
+    while (k + kSpec - 1 <= upto) {
+      uint32_t words[kSpec];
+      int bits[kSpec];
+#pragma unroll
+      for (int u = 0; u < kSpec; ++u) {
+        words[u] = w.lds[lrow + (lx >> 5)];
+        bits[u] = lx & 31;
+        error += r.dminor;
+        const bool trip = error > r.dmajor;
+        lx += trip ? b_lx : m_lx;
+        lrow += trip ? b_row : m_row;
+        error -= trip ? r.dmajor : 0;
+      }
+      uint32_t any = 0;
+#pragma unroll
+      for (int u = kSpec - 1; u >= 0; --u) {
+        const uint32_t occ = (words[u] >> bits[u]) & 1u;
+        any |= occ;
+        hit_k = occ ? k + u : hit_k;  // descending u: the smallest u with a set bit wins
+      }
+      if (any) break;
+      k += kSpec;
+    }
+    if (hit_k >= 0) {
+      walk_seek(r, hit_k, 0);
+      return walk_result(g, r, true, max_range, steps);
+    }
+    walk_seek(r, k, error);
+  }
+  // Remainder (a tail shorter than one group, or cells beyond the window): the global bit mask.
+  const bool hit = walk_until(r, r.last, [&w](int x, int y) {
+    return (w.global[static_cast<size_t>(y) * w.words_per_row + (static_cast<unsigned>(x) >> 5)] >> (x & 31)) & 1u;
+  });
+  return walk_result(g, r, hit, max_range, steps);
+}
+
 // One beam of beam_model.hpp:110-147 for a source pose already in the grid frame (Ray2d ctor: raycasting.hpp:62-70).
+template <class Cast>
 __device__ __forceinline__ double beam_term(const GridView& g, const BeamModel& m, double norm_hit, const Pose2& src, int sx, int sy,
-                                            double px, double py, unsigned long long& steps) {
+                                            double px, double py, Cast&& cast) {
   const double z = sqrt(px * px + py * py);
   const double bc = px / z, bs = py / z;
   double ex, ey;  // trace(): raycasting.hpp:78-88
@@ -564,7 +687,7 @@ __device__ __forceinline__ double beam_term(const GridView& g, const BeamModel& 
   ey += src.y;
   int fx, fy;
   cell_near(g, ex, ey, fx, fy);
-  const double z_mean = cast_ray(g, sx, sy, fx, fy, m.beam_max_range, steps);
+  const double z_mean = cast(fx, fy);
   const double eta_hit = 2. / (erf((m.beam_max_range - z_mean) / (sqrt(2.) * m.sigma_hit)) - erf(-z_mean / (sqrt(2.) * m.sigma_hit)));
   const double d = (z - z_mean) / m.sigma_hit;
   double pz = m.z_hit * eta_hit * norm_hit * exp(-(d * d) / 2.);
@@ -598,7 +721,8 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam(ParticleSoA p, uint64_
   unsigned long long steps = 0;
   for (uint32_t b = lane; b < B; b += kWave) {
     const double2 pt = s_pts[b];
-    acc += beam_term(g, m, norm_hit, src, sx, sy, pt.x, pt.y, steps);
+    acc += beam_term(g, m, norm_hit, src, sx, sy, pt.x, pt.y,
+                     [&](int fx, int fy) { return cast_ray(g, sx, sy, fx, fy, m.beam_max_range, steps); });
   }
   const double total = wave_sum_f64(acc);
   if (d_steps) {
@@ -608,16 +732,44 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam(ParticleSoA p, uint64_
   if (lane == 0) p.w[i] = p.w[i] * total;
 }
 
-// Variant B (default above 16K particles): one lane per spatially ordered particle, every lane walks the same
-// beam at the same time.  Neighbouring lanes trace nearly the same line, so the byte loads of a step fall into one or
-// two cache lines and the lanes of a wave finish their walks together; the sum is the reference's sequential sum.
-__global__ __launch_bounds__(kBlock) void k_reweight_beam_sorted(double* __restrict__ w, uint64_t n, GridView g, BeamModel m,
-                                                                 const double* __restrict__ pts, uint32_t B,
-                                                                 const uint32_t* __restrict__ perm, const double* __restrict__ tc,
-                                                                 const double* __restrict__ ts, const double* __restrict__ tx,
-                                                                 const double* __restrict__ ty, unsigned long long* d_steps) {
-  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+// Variant B (default above 16K particles): one lane per spatially ordered particle, every lane walks the same beam at
+// the same time.  Neighbouring lanes trace nearly the same line and finish together; the sum is the reference's
+// sequential sum.  Per-lane byte gathers top out at ~2 lanes/clk/CU on this chip (profiles/r01: the L1 handles a
+// gather lane by lane even when the lanes share a line), so the occupancy the walks read is staged ONCE per workgroup
+// into LDS as a 1024 x 1024-cell bit window (132 KB) centred on the workgroup's particles; LDS serves 32 lanes/clk.
+constexpr int kBeamBlock = 1024;
+__global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __restrict__ w, uint64_t n, GridView g, BeamModel m,
+                                                                     const uint32_t* __restrict__ nonfree_bits,
+                                                                     uint32_t words_per_row, const double* __restrict__ pts,
+                                                                     uint32_t B, const uint32_t* __restrict__ perm,
+                                                                     const double* __restrict__ tc, const double* __restrict__ ts,
+                                                                     const double* __restrict__ tx, const double* __restrict__ ty,
+                                                                     unsigned long long* d_steps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* win = reinterpret_cast<uint32_t*>(smem);
+  const uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * kBeamBlock;
+  const uint64_t t = t0 + threadIdx.x;
   const uint64_t tt = t < n ? t : n - 1;
+  // window centred on the middle particle of the workgroup (they are spatial neighbours after the ordering pass)
+  const uint64_t tm = t0 + kBeamBlock / 2 < n ? t0 + kBeamBlock / 2 : n - 1;
+  int cx, cy;
+  cell_near(g, tx[tm], ty[tm], cx, cy);
+  BitWindow bw;
+  bw.x0 = ((cx - kWin / 2) >> 5) << 5;
+  bw.y0 = cy - kWin / 2;
+  bw.lds = win;
+  bw.global = nonfree_bits;
+  bw.words_per_row = words_per_row;
+  for (int i = threadIdx.x; i < kWin * kWinWords; i += kBeamBlock) {
+    const int row = i >> 5, col = i & 31;
+    const int gy = bw.y0 + row, gw = (bw.x0 >> 5) + col;
+    uint32_t v = 0;
+    if (gy >= 0 && gy < static_cast<int>(g.H) && gw >= 0 && gw < static_cast<int>(words_per_row))
+      v = nonfree_bits[static_cast<size_t>(gy) * words_per_row + gw];
+    win[row * kWinStride + col] = v;
+  }
+  __syncthreads();
+
   const Pose2 src{Rot2{tc[tt], ts[tt]}, tx[tt], ty[tt]};
   int sx, sy;
   cell_near(g, src.x, src.y, sx, sy);
@@ -626,7 +778,8 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam_sorted(double* __restr
   unsigned long long steps = 0;
   for (uint32_t b = 0; b < B; ++b) {
     const double px = pts[2 * b], py = pts[2 * b + 1];
-    acc += beam_term(g, m, norm_hit, src, sx, sy, px, py, steps);
+    acc += beam_term(g, m, norm_hit, src, sx, sy, px, py,
+                     [&](int fx, int fy) { return cast_ray_window(g, bw, sx, sy, fx, fy, m.beam_max_range, steps); });
   }
   if (d_steps) {
     if (t >= n) steps = 0;
@@ -637,6 +790,20 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam_sorted(double* __restr
     const uint32_t i = perm[t];
     w[i] = w[i] * acc;
   }
+}
+
+// nonfree_bits: one bit per cell, row-major, words_per_row = ceil(W / 32) words per row.
+__global__ __launch_bounds__(kBlock) void k_pack_nonfree(const int8_t* __restrict__ cells, uint32_t W, uint32_t H, int8_t free_value,
+                                                         uint32_t words_per_row, uint32_t* __restrict__ bits) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= static_cast<uint64_t>(words_per_row) * H) return;
+  const uint32_t y = static_cast<uint32_t>(i / words_per_row), wx = static_cast<uint32_t>(i % words_per_row);
+  uint32_t v = 0;
+  for (uint32_t b = 0; b < 32; ++b) {
+    const uint32_t x = wx * 32 + b;
+    if (x < W && cells[static_cast<size_t>(y) * W + x] != free_value) v |= 1u << b;
+  }
+  bits[i] = v;
 }
 
 // ---- K3 weight sums / normalize ----------------------------------------------------------------------
@@ -1239,12 +1406,26 @@ void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, 
   }
 }
 
+void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32_t H, int8_t free_value, uint32_t* bits) {
+  const uint32_t words_per_row = (W + 31) / 32;
+  const uint64_t words = static_cast<uint64_t>(words_per_row) * H;
+  hipLaunchKernelGGL(k_pack_nonfree, dim3(blocks_for(words)), dim3(kBlock), 0, st, cells, W, H, free_value, words_per_row, bits);
+}
+
 void launch_reweight_beam(hipStream_t st, ParticleSoA p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
-                          unsigned long long* d_steps, const SortScratch* sorted) {
+                          unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits) {
   if (n == 0) return;
-  if (sorted) {
-    hipLaunchKernelGGL(k_reweight_beam_sorted, dim3(blocks_for(n)), dim3(kBlock), 0, st, p.w, n, g, m, d_points, B, sorted->perm,
-                       sorted->tc, sorted->ts, sorted->tx, sorted->ty, d_steps);
+  if (sorted && nonfree_bits) {
+    static bool configured = false;
+    const size_t lds = static_cast<size_t>(kWin) * kWinStride * sizeof(uint32_t);
+    if (!configured) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_beam_sorted), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds));
+      configured = true;
+    }
+    const dim3 grid(static_cast<unsigned>((n + kBeamBlock - 1) / kBeamBlock));
+    hipLaunchKernelGGL(k_reweight_beam_sorted, grid, dim3(kBeamBlock), lds, st, p.w, n, g, m, nonfree_bits, (g.W + 31) / 32, d_points,
+                       B, sorted->perm, sorted->tc, sorted->ts, sorted->tx, sorted->ty, d_steps);
     return;
   }
   const dim3 grid(static_cast<unsigned>((n + (kBlock / kWave) - 1) / (kBlock / kWave)));
