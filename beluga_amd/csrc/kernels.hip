@@ -10,9 +10,15 @@
 #include "kernels.h"
 
 #include <cfloat>
+#include <cstdio>
+#include <cstdlib>
 #include <climits>
 
 #include "rng.h"
+
+#ifndef LF_UNROLL
+#define LF_UNROLL 8
+#endif
 
 namespace mcl {
 namespace {
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(f.cube), 0, static_cast<int>((cells + 1) * 8u), 0x00020000);
     const uint32_t row_bytes = f.W * 8u, unknown_offset = cells * 8u;
-#pragma unroll 8
+#pragma unroll LF_UNROLL
     for (uint32_t b = 0; b < B; ++b) {
       const double px = pts[2 * b], py = pts[2 * b + 1];
       acc += lf_beam_cube(rsrc, f, row_bytes, unknown_offset, px, py, ct, st, xt, yt);
@@ -230,8 +236,11 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
 // [digit][workgroup] table, (3) scatter through LDS cursors, (4) a bitonic sort of every 2048-element
 // block in LDS on the full key.  Runs that straddle a block edge stay split, which costs nothing: every
 // wave still gets 64 neighbours.
-constexpr uint32_t kKeyBitsXY = 6, kKeyBitsTheta = 8;                  // 64 x 64 x 256 bins
-constexpr uint32_t kKeyBits = 2 * kKeyBitsXY + kKeyBitsTheta;           // 20
+// Bin resolution: kKeyBitsXY bits for x and for y, kKeyBitsTheta for the heading (relative to the cloud's extent).
+struct KeyBits {
+  uint32_t xy, theta;
+  __host__ __device__ uint32_t total() const { return 2 * xy + theta; }
+};
 constexpr uint32_t kDigitBits = 10, kDigits = 1u << kDigitBits;         // coarse partition digit
 static_assert(kDigits == kSortDigits, "scratch sizing in context.hip assumes this digit width");
 
@@ -320,18 +329,19 @@ __device__ __forceinline__ int bin_of(double v, double lo, double hi, int bins) 
   int b = r > 0.0 ? static_cast<int>((v - lo) / r * bins) : 0;
   return min(max(b, 0), bins - 1);
 }
-// 20-bit key: the two extra heading bits on top, then Morton (heading, y, x) over 6 bits each.
-__device__ __forceinline__ uint32_t sort_key(const ParticleSoA& p, uint64_t i, const double* __restrict__ bbox, double c0, double s0) {
-  const int bx = bin_of(p.x[i], bbox[0], bbox[1], 1 << kKeyBitsXY);
-  const int by = bin_of(p.y[i], bbox[2], bbox[3], 1 << kKeyBitsXY);
-  const int bt = bin_of(heading_delta(p.c[i], p.s[i], c0, s0), bbox[4], bbox[5], 1 << kKeyBitsTheta);
-  const uint32_t lo = kKeyBitsXY;
+// Key: the extra heading bits on top, then Morton (heading, y, x) over kb.xy bits each.
+__device__ __forceinline__ uint32_t sort_key(const ParticleSoA& p, uint64_t i, const double* __restrict__ bbox, double c0, double s0,
+                                             KeyBits kb) {
+  const int bx = bin_of(p.x[i], bbox[0], bbox[1], 1 << kb.xy);
+  const int by = bin_of(p.y[i], bbox[2], bbox[3], 1 << kb.xy);
+  const int bt = bin_of(heading_delta(p.c[i], p.s[i], c0, s0), bbox[4], bbox[5], 1 << kb.theta);
+  const uint32_t lo = kb.xy;
   return (static_cast<uint32_t>(bt >> lo) << (3 * lo)) | spread3(bx) | (spread3(by) << 1) | (spread3(bt & ((1 << lo) - 1)) << 2);
 }
 
 __global__ __launch_bounds__(kBlock) void k_sort_hist(ParticleSoA p, uint64_t n, const double* __restrict__ bbox,
                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ block_hist,
-                                                      uint32_t nblocks) {
+                                                      uint32_t nblocks, KeyBits kb) {
   __shared__ uint32_t hist[kDigits];
   for (uint32_t d = threadIdx.x; d < kDigits; d += kBlock) hist[d] = 0;
   __syncthreads();
@@ -341,9 +351,9 @@ __global__ __launch_bounds__(kBlock) void k_sort_hist(ParticleSoA p, uint64_t n,
   for (int k = 0; k < kChunk / kBlock; ++k) {
     const uint64_t i = base + k * kBlock + threadIdx.x;  // coalesced
     if (i < n) {
-      const uint32_t key = sort_key(p, i, bbox, c0, s0);
+      const uint32_t key = sort_key(p, i, bbox, c0, s0, kb);
       keys[i] = key;
-      atomicAdd(&hist[key >> (kKeyBits - kDigitBits)], 1u);
+      atomicAdd(&hist[key >> (kb.total() - kDigitBits)], 1u);
     }
   }
   __syncthreads();
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void k_sort_hist(ParticleSoA p, uint64_t n,
 
 __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restrict__ keys, uint64_t n,
                                                          const uint32_t* __restrict__ block_offsets, uint32_t nblocks,
-                                                         unsigned long long* __restrict__ out) {
+                                                         unsigned long long* __restrict__ out, KeyBits kb) {
   __shared__ uint32_t cursor[kDigits];
   for (uint32_t d = threadIdx.x; d < kDigits; d += kBlock) cursor[d] = block_offsets[static_cast<size_t>(d) * nblocks + blockIdx.x];
   __syncthreads();
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restr
     const uint64_t i = base + k * kBlock + threadIdx.x;
     if (i < n) {
       const uint32_t key = keys[i];
-      const uint32_t dest = atomicAdd(&cursor[key >> (kKeyBits - kDigitBits)], 1u);
+      const uint32_t dest = atomicAdd(&cursor[key >> (kb.total() - kDigitBits)], 1u);
       out[dest] = (static_cast<unsigned long long>(key) << 32) | static_cast<uint32_t>(i);
     }
   }
@@ -372,7 +382,8 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restr
 // the world->field pose of every particle in sorted order (likelihood_field_model.hpp:70).
 __global__ __launch_bounds__(kBlock) void k_sort_blocks(const unsigned long long* __restrict__ in, uint64_t n, ParticleSoA p,
                                                         Pose2 world_to_field, uint32_t* __restrict__ perm, double* __restrict__ tc,
-                                                        double* __restrict__ ts, double* __restrict__ tx, double* __restrict__ ty) {
+                                                        double* __restrict__ ts, double* __restrict__ tx, double* __restrict__ ty,
+                                                        int fine) {
   __shared__ unsigned long long v[kChunk];
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
 #pragma unroll
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(kBlock) void k_sort_blocks(const unsigned long long
     v[t] = base + t < n ? in[base + t] : ~0ull;
   }
   __syncthreads();
-  for (uint32_t size = 2; size <= kChunk; size <<= 1) {
+  for (uint32_t size = 2; fine && size <= kChunk; size <<= 1) {
     for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
 #pragma unroll
       for (int k = 0; k < kChunk / 2 / kBlock; ++k) {
@@ -1366,16 +1377,26 @@ void launch_lf_bin_sort(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, 
   double* partials = sort->bbox + 8;
   hipLaunchKernelGGL(k_bbox_partials, dim3(nblocks), dim3(kBlock), 0, st, p, n, partials, nblocks);
   hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(kBlock), 0, st, partials, nblocks, nblocks, sort->bbox);
-  hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(kBlock), 0, st, p, n, sort->bbox, sort->keys, sort->block_hist, nblocks);
+  static const KeyBits kb = [] {
+    const char* v = std::getenv("BELUGA_MCL_KEY_BITS");  // "xy,theta" (tuning hook); default 7,10 = 128 x 128 x 1024 bins (best of a sweep on the 1M-particle bench)
+    KeyBits k{7, 10};
+    if (v) {
+      unsigned a = 0, b = 0;
+      if (std::sscanf(v, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 10 && b >= a && b <= 10 && 2 * a + b >= kDigitBits) k = KeyBits{a, b};
+    }
+    return k;
+  }();
+  hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(kBlock), 0, st, p, n, sort->bbox, sort->keys, sort->block_hist, nblocks, kb);
   const uint32_t m = kDigits * nblocks;
   const uint32_t mchunks = num_chunks(m);
   hipLaunchKernelGGL(k_u32_chunk_sum, dim3(mchunks), dim3(kBlock), 0, st, sort->block_hist, m, sort->chunk_sum);
   hipLaunchKernelGGL(k_scan_chunks<uint32_t>, dim3(1), dim3(kBlock), 0, st, sort->chunk_sum, mchunks, sort->chunk_off,
                      static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr));
   hipLaunchKernelGGL(k_u32_exclusive_apply, dim3(mchunks), dim3(kBlock), 0, st, sort->block_hist, m, sort->chunk_off);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(kBlock), 0, st, sort->keys, n, sort->block_hist, nblocks, sort->keyidx);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(kBlock), 0, st, sort->keys, n, sort->block_hist, nblocks, sort->keyidx, kb);
+  static const int fine = [] { const char* v = std::getenv("BELUGA_MCL_SORT_FINE"); return v ? std::atoi(v) : 1; }();
   hipLaunchKernelGGL(k_sort_blocks, dim3(nblocks), dim3(kBlock), 0, st, sort->keyidx, n, p, f.world_to_field, sort->perm, sort->tc,
-                     sort->ts, sort->tx, sort->ty);
+                     sort->ts, sort->tx, sort->ty, fine);
 }
 
 void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,

@@ -475,3 +475,52 @@ def test_full_size_properties_1m_x_1080():
     pose, cov = f.estimate()
     assert np.all(np.isfinite(pose)) and np.all(np.isfinite(cov))
     f.close()
+
+
+def test_full_size_kld_cut_10m_is_exact():
+    """Config 3 shape: 10M max particles, min 100k, KLD (eps .05, z 3).  The cut length of take_while_kld is an integer
+    result; the sequential oracle can replay all 10M candidates in a few seconds, so it is compared exactly — once with
+    a tight cloud (stops right after min) and once with a cloud spread over thousands of bins (stops much later)."""
+    grid = rooms_grid(400, 3)
+    n = 200_000
+    for spread, expect_min in (((0.3, 0.3, 0.1), True), ((9.0, 9.0, 3.0), False)):
+        states = synth.normal_particles(n, (0.0, 0.0, 0.0), spread, seed=6)
+        w = np.random.Generator(np.random.MT19937(5)).gamma(2.0, 1.0, n)
+        params = AmclParams(min_particles=100_000, max_particles=10_000_000)
+        f = Amcl(grid, MOTION, LF, params, seed=11)
+        f.set_particles(states, w)
+        m = f.resample(0.0, step=2)
+        want, _ = orc.resample(states, w, 100_000, 10_000_000, 0.05, 3.0, (0.5, 0.5, math.radians(10)), 0.0, seed=11, step=2)
+        assert m == len(want)
+        assert (m == 100_000) == expect_min
+        got, gw = f.particles()
+        assert np.all(gw == 1.0)
+        assert int(np.any(got != want, axis=1).sum()) <= 5
+        f.close()
+
+
+def test_full_size_beam_model_1m_sample_against_oracle():
+    """Config 5 shape: 1M particles x 1080 beams, BeamSensorModel on the 4000x4000 int8 grid.  A 256-particle sample of
+    the full launch is checked against the oracle (each oracle particle walks ~3.5e5 cells), plus the cells-visited
+    count of the whole launch against the oracle's per-particle average."""
+    size = 4000
+    cells = synth.make_rooms_map(size, size, seed=42)
+    grid = OccupancyGrid(cells, 0.05, origin=se2_from_xytheta(-100.0, -100.0, 0.0))
+    truth = synth.find_free_pose(cells, 0.05, (-100.0, -100.0), seed=1)
+    pts = make_scan(grid, truth, 1080, max_range=30.0)
+    n = 1_000_000
+    beam = BeamModelParam(beam_max_range=30.0)
+    f = Amcl(grid, MOTION, beam, AmclParams(min_particles=n, max_particles=n), seed=3)
+    states = synth.normal_particles(n, truth, (0.5, 0.5, 0.2), seed=9)
+    f.set_particles(states, np.ones(n))
+    f.beam_cells_visited(reset=True)
+    f.reweight(pts)
+    w = f.particles()[1]
+    visited = f.beam_cells_visited()
+    sample = np.random.Generator(np.random.MT19937(1)).choice(n, 256, replace=False)
+    want, steps = orc.beam_weights(cells, 0.05, grid.origin, (0.5, 0.5, 0.05, 0.05, 0.2, 0.1, 30.0), states[sample], pts,
+                                   threads=orc.max_threads(), return_steps=True)
+    np.testing.assert_allclose(w[sample], want, rtol=1e-10, atol=1e-300)
+    assert visited / n == pytest.approx(steps / 256, rel=0.05)
+    assert np.all(np.isfinite(w)) and np.all(w >= 0)
+    f.close()
