@@ -48,6 +48,22 @@ class DifferentialDriveModelParam:
 
 
 @dataclass
+class OmnidirectionalDriveModelParam:
+    """motion/omnidirectional_drive_model.hpp:36-73."""
+    rotation_noise_from_rotation: float
+    rotation_noise_from_translation: float
+    translation_noise_from_translation: float
+    translation_noise_from_rotation: float
+    strafe_noise_from_translation: float
+    distance_threshold: float = 0.01
+
+
+@dataclass
+class StationaryModelParam:
+    """motion/stationary_model.hpp:40-62 takes no parameters."""
+
+
+@dataclass
 class LikelihoodFieldModelParam:
     """sensor/likelihood_field_model_base.hpp:42-64."""
     max_obstacle_distance: float = 100.0
@@ -57,6 +73,11 @@ class LikelihoodFieldModelParam:
     sigma_hit: float = 0.2
     model_unknown_space: bool = False
     only_obstacle_boundaries: bool = False
+
+
+@dataclass
+class LikelihoodFieldProbModelParam(LikelihoodFieldModelParam):
+    """sensor/likelihood_field_prob_model.hpp:34 (= LikelihoodFieldModelBaseParam)."""
 
 
 @dataclass
@@ -89,7 +110,7 @@ def _dp(a: np.ndarray):
 
 
 class Amcl:
-    def __init__(self, grid: OccupancyGrid, motion: DifferentialDriveModelParam, sensor, params: AmclParams = AmclParams(), *,
+    def __init__(self, grid: OccupancyGrid, motion, sensor, params: AmclParams = AmclParams(), *,
                  seed: int = 0, device: int = 0, shard_offset: int = 0, shard_capacity: int = 0, hip_stream: int = 0):
         self._lib = capi.load()
         cfg = capi.Config()
@@ -100,11 +121,18 @@ class Amcl:
                   "alpha_fast", "kld_epsilon", "kld_z", "spatial_resolution_x", "spatial_resolution_y", "spatial_resolution_theta"):
             setattr(cfg.amcl, k, getattr(params, k))
         cfg.amcl.selective_resampling = int(params.selective_resampling)
-        for k in ("rotation_noise_from_rotation", "rotation_noise_from_translation", "translation_noise_from_translation",
-                  "translation_noise_from_rotation", "distance_threshold"):
-            setattr(cfg.motion, k, getattr(motion, k))
+        if isinstance(motion, StationaryModelParam):
+            cfg.motion_kind = capi.MCL_MOTION_STATIONARY
+        else:
+            for k in ("rotation_noise_from_rotation", "rotation_noise_from_translation", "translation_noise_from_translation",
+                      "translation_noise_from_rotation", "distance_threshold"):
+                setattr(cfg.motion, k, getattr(motion, k))
+            if isinstance(motion, OmnidirectionalDriveModelParam):
+                cfg.motion_kind = capi.MCL_MOTION_OMNIDIRECTIONAL
+                cfg.strafe_noise_from_translation = motion.strafe_noise_from_translation
         if isinstance(sensor, LikelihoodFieldModelParam):
-            cfg.sensor_kind = capi.MCL_SENSOR_LIKELIHOOD_FIELD
+            cfg.sensor_kind = (capi.MCL_SENSOR_LIKELIHOOD_FIELD_PROB if isinstance(sensor, LikelihoodFieldProbModelParam)
+                               else capi.MCL_SENSOR_LIKELIHOOD_FIELD)
             for k in ("max_obstacle_distance", "max_laser_distance", "z_hit", "z_random", "sigma_hit"):
                 setattr(cfg.lf, k, getattr(sensor, k))
             cfg.lf.model_unknown_space = int(sensor.model_unknown_space)

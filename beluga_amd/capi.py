@@ -21,6 +21,8 @@ MCL_ERR_NO_DEVICE = -6
 
 MCL_SENSOR_LIKELIHOOD_FIELD = 0
 MCL_SENSOR_BEAM = 1
+MCL_SENSOR_LIKELIHOOD_FIELD_PROB = 2
+MCL_MOTION_DIFFERENTIAL, MCL_MOTION_OMNIDIRECTIONAL, MCL_MOTION_STATIONARY = 0, 1, 2
 
 STAGES = ("propagate", "reweight", "normalize", "resample", "estimate", "sensor_kernel")
 
@@ -63,7 +65,8 @@ class Config(C.Structure):
     _fields_ = [
         ("device_id", C.c_int32), ("sensor_kind", C.c_int32), ("seed", C.c_uint64), ("amcl", AmclParams),
         ("motion", DiffDriveParams), ("lf", LfParams), ("beam", BeamParams), ("shard_offset", C.c_uint64),
-        ("shard_capacity", C.c_uint64), ("hip_stream", C.c_void_p),
+        ("shard_capacity", C.c_uint64), ("hip_stream", C.c_void_p), ("motion_kind", C.c_int32), ("reserved1", C.c_int32),
+        ("strafe_noise_from_translation", C.c_double),
     ]
 
 

@@ -83,14 +83,28 @@ double rotation_variance(const Rot2& r) {
   const double delta = std::min(std::abs(rot_log(r)), std::abs(rot_log(flipped)));
   return delta * delta;
 }
-DiffDriveSampler make_sampler(const Pose2& pose, const Pose2& prev, const mcl_diffdrive_params& a) {
+DiffDriveSampler make_sampler(const Pose2& pose, const Pose2& prev, const mcl_diffdrive_params& a, int kind, double alpha5) {
   const double tx = pose.x - prev.x, ty = pose.y - prev.y;
   const double distance = std::sqrt(tx * tx + ty * ty);
   const double distance_variance = distance * distance;
   const Rot2 heading = rot_exp(std::atan2(ty, tx));
   const Rot2 first = distance > a.distance_threshold ? rot_mul(heading, rot_inverse(prev.r)) : Rot2{1.0, 0.0};
+  DiffDriveSampler s{};
+  s.kind = kind;
+  s.first_c = first.c;
+  s.first_s = first.s;
+  if (kind == MCL_MOTION_STATIONARY) return s;  // stationary_model.hpp:53-61 ignores the control action
+  if (kind == MCL_MOTION_OMNIDIRECTIONAL) {     // omnidirectional_drive_model.hpp:102-131
+    const Rot2 rotation = rot_mul(pose.r, rot_inverse(prev.r));
+    s.m1 = rot_log(rotation);
+    s.s1 = std::sqrt(a.rotation_noise_from_rotation * rotation_variance(rotation) + a.rotation_noise_from_translation * distance_variance);
+    s.mt = distance;
+    s.st = std::sqrt(a.translation_noise_from_translation * distance_variance + a.translation_noise_from_rotation * rotation_variance(rotation));
+    s.m2 = 0.0;
+    s.s2 = std::sqrt(alpha5 * distance_variance + a.translation_noise_from_rotation * rotation_variance(rotation));
+    return s;
+  }
   const Rot2 second = rot_mul(rot_mul(pose.r, rot_inverse(prev.r)), rot_inverse(first));
-  DiffDriveSampler s;
   s.m1 = rot_log(first);
   s.s1 = std::sqrt(a.rotation_noise_from_rotation * rotation_variance(first) + a.rotation_noise_from_translation * distance_variance);
   s.mt = distance;
@@ -230,7 +244,7 @@ struct mcl_ctx {
   double* chunk_row(int k) { return d_chunk.ptr + static_cast<size_t>(k) * chunk_stride; }
   FieldView field_view() const {
     return FieldView{d_field.ptr, W, H, 1. / resolution, origin_inverse, static_cast<float>(1. / cfg.lf.max_laser_distance),
-                     d_cube.ptr};
+                     d_cube.ptr, cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD_PROB ? 1 : 0};
   }
   SortScratch sort_scratch() {
     SortScratch s{};
@@ -335,7 +349,8 @@ mcl_status ensure_kld(mcl_ctx* ctx) {
 mcl_status rebuild_cube(mcl_ctx* ctx) {
   const uint64_t cells = static_cast<uint64_t>(ctx->W) * ctx->H;
   MCL_HIP(ctx, ctx->d_cube.ensure(cells + 1));
-  launch_cube_table(ctx->stream, ctx->d_field.ptr, cells, static_cast<float>(1. / ctx->cfg.lf.max_laser_distance), ctx->d_cube.ptr);
+  launch_cube_table(ctx->stream, ctx->d_field.ptr, cells, static_cast<float>(1. / ctx->cfg.lf.max_laser_distance), ctx->d_cube.ptr,
+                    ctx->cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD_PROB ? 1 : 0);
   MCL_HIP(ctx, hipGetLastError());
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MCL_OK;
@@ -359,7 +374,7 @@ mcl_status upload_points(mcl_ctx* ctx, const double* pts, uint64_t B) {
 
 mcl_status do_propagate(mcl_ctx* ctx, const Pose2& pose, const Pose2& prev, uint32_t step) {
   stage_begin(ctx, MCL_STAGE_PROPAGATE);
-  launch_propagate(ctx->stream, ctx->cur(), ctx->n, make_sampler(pose, prev, ctx->cfg.motion), ctx->cfg.seed, step,
+  launch_propagate(ctx->stream, ctx->cur(), ctx->n, make_sampler(pose, prev, ctx->cfg.motion, ctx->cfg.motion_kind, ctx->cfg.strafe_noise_from_translation), ctx->cfg.seed, step,
                    ctx->cfg.shard_offset);
   stage_end(ctx, MCL_STAGE_PROPAGATE);
   MCL_HIP(ctx, hipGetLastError());
@@ -371,7 +386,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B) {
   MCL_REQUIRE(ctx, B <= 0xFFFFFFFFull, "too many points");
   if (const mcl_status s = upload_points(ctx, pts, B)) return s;
   stage_begin(ctx, MCL_STAGE_REWEIGHT);
-  if (ctx->cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD) {
+  if (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM) {
     MCL_REQUIRE(ctx, B * sizeof(double2) <= 160 * 1024 || ctx->lf_variant == kLfLanePerParticle, "scan too large for LDS staging");
     const SortScratch sort = ctx->sort_scratch();
     // Below a few thousand particles the binning passes cost more than they save.
@@ -558,8 +573,10 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
   *out = nullptr;
   if (cfg->amcl.max_particles == 0 || cfg->amcl.resample_interval == 0)
     return fail(nullptr, MCL_ERR_INVALID_ARGUMENT, "mcl_create: max_particles and resample_interval must be > 0");
-  if (cfg->sensor_kind != MCL_SENSOR_LIKELIHOOD_FIELD && cfg->sensor_kind != MCL_SENSOR_BEAM)
+  if (cfg->sensor_kind < MCL_SENSOR_LIKELIHOOD_FIELD || cfg->sensor_kind > MCL_SENSOR_LIKELIHOOD_FIELD_PROB)
     return fail(nullptr, MCL_ERR_INVALID_ARGUMENT, "mcl_create: unknown sensor_kind");
+  if (cfg->motion_kind < MCL_MOTION_DIFFERENTIAL || cfg->motion_kind > MCL_MOTION_STATIONARY)
+    return fail(nullptr, MCL_ERR_INVALID_ARGUMENT, "mcl_create: unknown motion_kind");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
     return fail(nullptr, MCL_ERR_NO_DEVICE, "mcl_create: no HIP device (this library has no CPU fallback)");
@@ -673,7 +690,7 @@ mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32
     MCL_HIP(ctx, hipGetLastError());
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  if (ctx->cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD) {
+  if (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM) {
     build_likelihood_field(cells, width, height, resolution, ctx->traits, ctx->cfg.lf, ctx->h_field);
     MCL_HIP(ctx, ctx->d_field.ensure(n));
     MCL_HIP(ctx, hipMemcpy(ctx->d_field.ptr, ctx->h_field.data(), n * sizeof(float), hipMemcpyHostToDevice));

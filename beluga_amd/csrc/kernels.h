@@ -31,6 +31,7 @@ struct FieldView {
   // Derived table for the hot kernel: cube[i] = pz*pz*pz with pz = double(data[i]) — exactly the per-beam
   // term of likelihood_field_model.hpp:84-88 — and cube[W*H] = the same for unknown_value.  8 B per cell.
   const double* cube;
+  int prob;  // LikelihoodFieldProbModel: the table holds log(pz) and the weight is exp(sum) (likelihood_field_prob_model.hpp:76-88)
 };
 
 struct GridView {
@@ -46,8 +47,14 @@ struct BeamModel {
   double z_hit, z_short, z_max, z_rand, sigma_hit, lambda_short, beam_max_range;
 };
 
-struct DiffDriveSampler {  // three (mean, stddev) pairs: first rotation, translation, second rotation
+// Per-cycle constants of the motion model's sampling function (computed on the host from the control action).
+//   differential   : three (mean, stddev) pairs: first rotation, translation, second rotation
+//   omnidirectional: (mean, stddev) of the rotation and of the translation, stddev of the strafe, first rotation
+//   stationary     : nothing (N(0, 0.02) on heading, x, y)
+struct DiffDriveSampler {
+  int kind;  // MCL_MOTION_*
   double m1, s1, mt, st, m2, s2;
+  double first_c, first_s;
 };
 
 struct FreeCells {
@@ -155,8 +162,8 @@ void launch_estimate_sums(hipStream_t st, ParticleSoA p, uint64_t n, double pivo
 void launch_init_normal(hipStream_t st, ParticleSoA p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
                         uint64_t index_offset);
 void launch_fill(hipStream_t st, double* p, uint64_t n, double v);
-// cube[i] = double(field[i])^3 for i < cells, cube[cells] = double(unknown)^3
-void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube);
+// cube[i] = double(field[i])^3 (or log(double(field[i])) for the prob model) for i < cells, cube[cells] = same for `unknown`
+void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube, int prob);
 // AoS (c,s,x,y) host layout <-> SoA device layout
 void launch_aos_to_soa(hipStream_t st, const double* aos, ParticleSoA p, uint64_t n);
 void launch_soa_to_aos(hipStream_t st, ParticleSoA p, double* aos, uint64_t n);

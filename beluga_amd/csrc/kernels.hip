@@ -88,12 +88,26 @@ __global__ __launch_bounds__(kBlock) void k_propagate(ParticleSoA p, uint64_t n,
   double z0, z1, z2, z3;
   rng_box_muller(rng_uniform53(a.w[0], a.w[1]), rng_uniform53(a.w[2], a.w[3]), z0, z1);
   rng_box_muller(rng_uniform53(b.w[0], b.w[1]), rng_uniform53(b.w[2], b.w[3]), z2, z3);
-  const double r1 = z0 * smp.s1 + smp.m1;
-  const double t = z1 * smp.st + smp.mt;
-  const double r2 = z2 * smp.s2 + smp.m2;
-  const Pose2 first{rot_exp(r1), 0.0, 0.0};
-  const Pose2 second{rot_exp(r2), t, 0.0};
-  store_pose(p, i, pose_mul(pose_mul(load_pose(p, i), first), second));
+  const Pose2 state = load_pose(p, i);
+  Pose2 out;
+  if (smp.kind == 1) {
+    // omnidirectional_drive_model.hpp:133-144 — draws in source order: rotation, translation, strafe
+    const Rot2 first{smp.first_c, smp.first_s};
+    const Rot2 second = rot_mul(rot_exp(z0 * smp.s1 + smp.m1), rot_inverse(first));
+    const double t = z1 * smp.st + smp.mt;
+    const double strafe = z2 * smp.s2 + 0.0;
+    out = pose_mul(pose_mul(state, Pose2{first, 0.0, 0.0}), Pose2{second, t, -strafe});
+  } else if (smp.kind == 2) {
+    // stationary_model.hpp:55-61 — N(0, 0.02) on heading, x, y
+    out = pose_mul(state, Pose2{rot_exp(z0 * 0.02 + 0.0), z1 * 0.02 + 0.0, z2 * 0.02 + 0.0});
+  } else {
+    // differential_drive_model.hpp:156-163
+    const double r1 = z0 * smp.s1 + smp.m1;
+    const double t = z1 * smp.st + smp.mt;
+    const double r2 = z2 * smp.s2 + smp.m2;
+    out = pose_mul(pose_mul(state, Pose2{rot_exp(r1), 0.0, 0.0}), Pose2{rot_exp(r2), t, 0.0});
+  }
+  store_pose(p, i, out);
 }
 
 // ---- K2 likelihood-field reweight ------------------------------------------------------------------
@@ -118,7 +132,7 @@ __device__ __forceinline__ double lf_beam(const FieldView& f, double px, double 
   }
   v = inside ? v : f.unknown_value;
   const double pz = static_cast<double>(v);
-  return pz * pz * pz;
+  return f.prob ? log(pz) : pz * pz * pz;
 }
 
 // The same term from the precomputed cube table through a raw buffer load: 32-bit byte offsets
@@ -169,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_wave(ParticleSoA p, uint
     const double total = wave_sum_f64(acc);
     if (lane == q) mine = total;
   }
-  if (i < n) p.w[i] = p.w[i] * (1.0 + mine);
+  if (i < n) p.w[i] = p.w[i] * (f.prob ? exp(mine) : 1.0 + mine);
 }
 
 // Variant B — one lane per particle, every lane walks the scan in order; the scan is read with scalar
@@ -181,13 +195,13 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_lane(ParticleSoA p, uint
   Pose2 state = pose_identity();
   if (i < n) state = load_pose(p, i);
   const Pose2 T = pose_mul(f.world_to_field, state);
-  double acc = 1.0;
+  double acc = f.prob ? 0.0 : 1.0;
 #pragma unroll 8
   for (uint32_t b = 0; b < B; ++b) {
     const double px = pts[2 * b], py = pts[2 * b + 1];
     acc += lf_beam<kIdx32>(f, px, py, T.r.c, T.r.s, T.x, T.y);
   }
-  if (i < n) p.w[i] = p.w[i] * acc;
+  if (i < n) p.w[i] = p.w[i] * (f.prob ? exp(acc) : acc);
 }
 
 // Variant C — variant B's lane-per-particle walk over particles that have been counting-sorted into
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const uint64_t tt = t < n ? t : n - 1;
   const double ct = tc[tt], st = ts[tt], xt = tx[tt], yt = ty[tt];
-  double acc = 1.0;
+  double acc = f.prob ? 0.0 : 1.0;
   if (kCube) {
     const uint32_t cells = f.W * f.H;
     const __amdgpu_buffer_rsrc_t rsrc =
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
   }
   if (t < n) {
     const uint32_t i = perm[t];
-    w[i] = w[i] * acc;
+    w[i] = w[i] * (f.prob ? exp(acc) : acc);
   }
 }
 
@@ -1335,11 +1349,11 @@ __global__ __launch_bounds__(kBlock) void k_init_normal(ParticleSoA p, uint64_t 
 }
 
 __global__ __launch_bounds__(kBlock) void k_cube_table(const float* __restrict__ field, uint64_t cells, float unknown_value,
-                                                       double* __restrict__ cube) {
+                                                       double* __restrict__ cube, int prob) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i > cells) return;
   const double pz = static_cast<double>(i < cells ? field[i] : unknown_value);
-  cube[i] = pz * pz * pz;
+  cube[i] = prob ? log(pz) : pz * pz * pz;
 }
 __global__ __launch_bounds__(kBlock) void k_fill(double* p, uint64_t n, double v) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -1570,8 +1584,8 @@ void launch_init_normal(hipStream_t st, ParticleSoA p, uint64_t n, const double 
                      T[3], T[4], T[5], T[6], T[7], T[8], seed, index_offset);
 }
 
-void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube) {
-  hipLaunchKernelGGL(k_cube_table, dim3(blocks_for(cells + 1)), dim3(kBlock), 0, st, field, cells, unknown_value, cube);
+void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube, int prob) {
+  hipLaunchKernelGGL(k_cube_table, dim3(blocks_for(cells + 1)), dim3(kBlock), 0, st, field, cells, unknown_value, cube, prob);
 }
 void launch_fill(hipStream_t st, double* p, uint64_t n, double v) {
   if (n == 0) return;

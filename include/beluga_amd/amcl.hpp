@@ -85,6 +85,21 @@ struct DifferentialDriveModelParam {
   double distance_threshold = 0.01;
 };
 
+/// beluga::OmnidirectionalDriveModelParam (motion/omnidirectional_drive_model.hpp:36-73).
+struct OmnidirectionalDriveModelParam {
+  double rotation_noise_from_rotation;
+  double rotation_noise_from_translation;
+  double translation_noise_from_translation;
+  double translation_noise_from_rotation;
+  double strafe_noise_from_translation;
+  double distance_threshold = 0.01;
+};
+
+/// beluga::StationaryModel (motion/stationary_model.hpp:40-62) has no parameters.
+struct StationaryModelParam {};
+
+using MotionModelParam = std::variant<DifferentialDriveModelParam, OmnidirectionalDriveModelParam, StationaryModelParam>;
+
 /// beluga::LikelihoodFieldModelParam (sensor/likelihood_field_model_base.hpp:42-64).
 struct LikelihoodFieldModelParam {
   double max_obstacle_distance = 100.0;
@@ -107,7 +122,10 @@ struct BeamModelParam {
   double beam_max_range{60};
 };
 
-using SensorModelParam = std::variant<LikelihoodFieldModelParam, BeamModelParam>;
+/// beluga::LikelihoodFieldProbModelParam (sensor/likelihood_field_prob_model.hpp:34): same fields, other weighting.
+struct LikelihoodFieldProbModelParam : LikelihoodFieldModelParam {};
+
+using SensorModelParam = std::variant<LikelihoodFieldModelParam, BeamModelParam, LikelihoodFieldProbModelParam>;
 
 /// A non-owning view of anything satisfying OccupancyGrid2 (sensor/data/occupancy_grid.hpp:39-75).
 struct OccupancyGridView {
@@ -148,7 +166,7 @@ class Amcl {
   using measurement_type = std::vector<std::pair<double, double>>;
   using estimation_type = std::pair<SE2d, Matrix3d>;
 
-  Amcl(const OccupancyGridView& map, const DifferentialDriveModelParam& motion, const SensorModelParam& sensor,
+  Amcl(const OccupancyGridView& map, const MotionModelParam& motion, const SensorModelParam& sensor,
        const AmclParams& params = AmclParams{}, std::uint64_t seed = 0, int device = 0) {
     mcl_config cfg;
     mcl_default_config(&cfg);
@@ -167,11 +185,25 @@ class Amcl {
     cfg.amcl.spatial_resolution_x = params.spatial_resolution_x;
     cfg.amcl.spatial_resolution_y = params.spatial_resolution_y;
     cfg.amcl.spatial_resolution_theta = params.spatial_resolution_theta;
-    cfg.motion = mcl_diffdrive_params{motion.rotation_noise_from_rotation, motion.rotation_noise_from_translation,
-                                      motion.translation_noise_from_translation, motion.translation_noise_from_rotation,
-                                      motion.distance_threshold};
-    if (const auto* lf = std::get_if<LikelihoodFieldModelParam>(&sensor)) {
-      cfg.sensor_kind = MCL_SENSOR_LIKELIHOOD_FIELD;
+    if (const auto* dd = std::get_if<DifferentialDriveModelParam>(&motion)) {
+      cfg.motion_kind = MCL_MOTION_DIFFERENTIAL;
+      cfg.motion = mcl_diffdrive_params{dd->rotation_noise_from_rotation, dd->rotation_noise_from_translation,
+                                        dd->translation_noise_from_translation, dd->translation_noise_from_rotation,
+                                        dd->distance_threshold};
+    } else if (const auto* om = std::get_if<OmnidirectionalDriveModelParam>(&motion)) {
+      cfg.motion_kind = MCL_MOTION_OMNIDIRECTIONAL;
+      cfg.motion = mcl_diffdrive_params{om->rotation_noise_from_rotation, om->rotation_noise_from_translation,
+                                        om->translation_noise_from_translation, om->translation_noise_from_rotation,
+                                        om->distance_threshold};
+      cfg.strafe_noise_from_translation = om->strafe_noise_from_translation;
+    } else {
+      cfg.motion_kind = MCL_MOTION_STATIONARY;
+    }
+    const LikelihoodFieldModelParam* lf = std::get_if<LikelihoodFieldModelParam>(&sensor);
+    if (!lf) lf = std::get_if<LikelihoodFieldProbModelParam>(&sensor);
+    if (lf) {
+      cfg.sensor_kind = std::holds_alternative<LikelihoodFieldProbModelParam>(sensor) ? MCL_SENSOR_LIKELIHOOD_FIELD_PROB
+                                                                                     : MCL_SENSOR_LIKELIHOOD_FIELD;
       cfg.lf = mcl_lf_params{lf->max_obstacle_distance, lf->max_laser_distance, lf->z_hit, lf->z_random, lf->sigma_hit,
                              lf->model_unknown_space ? 1 : 0, lf->only_obstacle_boundaries ? 1 : 0};
     } else {

@@ -43,7 +43,12 @@ enum {
   MCL_ERR_NO_DEVICE = -6
 };
 
-enum { MCL_SENSOR_LIKELIHOOD_FIELD = 0, MCL_SENSOR_BEAM = 1 };
+/* LikelihoodFieldModel (sensor/likelihood_field_model.hpp), BeamSensorModel (sensor/beam_model.hpp),
+ * LikelihoodFieldProbModel (sensor/likelihood_field_prob_model.hpp): beluga_ros::Amcl's sensor variants. */
+enum { MCL_SENSOR_LIKELIHOOD_FIELD = 0, MCL_SENSOR_BEAM = 1, MCL_SENSOR_LIKELIHOOD_FIELD_PROB = 2 };
+/* DifferentialDriveModel, OmnidirectionalDriveModel (motion/omnidirectional_drive_model.hpp:102-146),
+ * StationaryModel (motion/stationary_model.hpp:55-61): beluga_ros::Amcl's motion variants. */
+enum { MCL_MOTION_DIFFERENTIAL = 0, MCL_MOTION_OMNIDIRECTIONAL = 1, MCL_MOTION_STATIONARY = 2 };
 
 /* beluga::AmclParams (algorithm/amcl_core.hpp:34-55) + the spatial-hash resolutions that
  * beluga_ros::AmclParams adds (beluga_ros/include/beluga_ros/amcl.hpp:90-97). Same defaults. */
@@ -102,6 +107,9 @@ typedef struct mcl_config {
   uint64_t shard_offset;
   uint64_t shard_capacity; /* 0 => amcl.max_particles */
   void* hip_stream;        /* optional external hipStream_t (e.g. torch's current stream); NULL => own stream */
+  int32_t motion_kind;     /* MCL_MOTION_*; the four alphas in `motion` are shared by the differential and omni models */
+  int32_t reserved1;
+  double strafe_noise_from_translation; /* OmnidirectionalDriveModelParam alpha5 (omnidirectional_drive_model.hpp:64-70) */
 } mcl_config;
 
 /* Fills `cfg` with the reference defaults listed above. */

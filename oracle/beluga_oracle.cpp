@@ -341,6 +341,29 @@ inline double lf_weight(
   return acc;
 }
 
+// sensor/likelihood_field_prob_model.hpp:68-90 — ONE particle: exp(sum log pz).
+inline double lf_prob_weight(
+    const float* field, int W, int H, double res, const SE2& world_to_field, double max_laser_distance, const SE2& state,
+    const double* pts, size_t B) {
+  const SE2 transform = se2_mul(world_to_field, state);
+  const double x_offset = transform.x, y_offset = transform.y;
+  const double cos_theta = transform.r.c, sin_theta = transform.r.s;
+  const float unknown_space_occupancy_prob = static_cast<float>(1. / max_laser_distance);
+  const double inv_resolution = 1. / res;
+  double acc = 0.0;
+  for (size_t b = 0; b < B; ++b) {
+    const double px = pts[2 * b], py = pts[2 * b + 1];
+    const double x = px * cos_theta - py * sin_theta + x_offset;
+    const double y = px * sin_theta + py * cos_theta + y_offset;
+    const int xi = static_cast<int>(std::floor(x * inv_resolution));
+    const int yi = static_cast<int>(std::floor(y * inv_resolution));
+    float v = unknown_space_occupancy_prob;
+    if (xi >= 0 && yi >= 0 && xi < W && yi < H) v = field[static_cast<size_t>(yi) * W + static_cast<size_t>(xi)];
+    acc += std::log(static_cast<double>(v));
+  }
+  return std::exp(acc);
+}
+
 // algorithm/raycasting/bresenham.hpp:84-192, iterator restated as a small state machine.
 struct Bresenham {
   int cx, cy;  // current_point_
@@ -523,6 +546,52 @@ inline SE2 diffdrive_apply(const SE2& state, const DiffDriveSampler& s, uint64_t
   const SE2 first{so2_exp(r1), 0.0, 0.0};
   const SE2 second{so2_exp(r2), t, 0.0};
   return se2_mul(se2_mul(state, first), second);
+}
+
+// motion/omnidirectional_drive_model.hpp:102-146 (+ rotation_variance :150-155)
+struct OmniSampler {
+  double m_rot, s_rot, m_trans, s_trans, s_strafe;
+  SO2 first;
+};
+OmniSampler omni_sampler(const SE2& pose, const SE2& prev, const double a[5], double distance_threshold) {
+  const double tx = pose.x - prev.x, ty = pose.y - prev.y;
+  const double distance = std::sqrt(tx * tx + ty * ty);
+  const double distance_variance = distance * distance;
+  const SO2 rotation = so2_mul(pose.r, so2_inverse(prev.r));
+  const SO2 heading = so2_exp(std::atan2(ty, tx));
+  OmniSampler s;
+  s.first = distance > distance_threshold ? so2_mul(heading, so2_inverse(prev.r)) : SO2{};
+  s.m_rot = so2_log(rotation);
+  s.s_rot = std::sqrt(a[0] * rotation_variance(rotation) + a[1] * distance_variance);
+  s.m_trans = distance;
+  s.s_trans = std::sqrt(a[2] * distance_variance + a[3] * rotation_variance(rotation));
+  s.s_strafe = std::sqrt(a[4] * distance_variance + a[3] * rotation_variance(rotation));
+  return s;
+}
+inline void three_normals(uint64_t seed, uint32_t step, uint64_t index, double z[3]) {
+  const Draw4 a = draw(seed, step, kPurposePropagateA, index);
+  const Draw4 b = draw(seed, step, kPurposePropagateB, index);
+  double z3;
+  box_muller(u53(a.r[0], a.r[1]), u53(a.r[2], a.r[3]), &z[0], &z[1]);
+  box_muller(u53(b.r[0], b.r[1]), u53(b.r[2], b.r[3]), &z[2], &z3);
+}
+// omnidirectional_drive_model.hpp:133-144 — draws in source order: rotation, translation, strafe.
+inline SE2 omni_apply(const SE2& state, const OmniSampler& s, uint64_t seed, uint32_t step, uint64_t index) {
+  double z[3];
+  three_normals(seed, step, index, z);
+  const SO2 second = so2_mul(so2_exp(z[0] * s.s_rot + s.m_rot), so2_inverse(s.first));
+  const double t = z[1] * s.s_trans + s.m_trans;
+  const double strafe = z[2] * s.s_strafe + 0.0;
+  const SE2 a{s.first, 0.0, 0.0};
+  const SE2 b{second, t, -strafe};
+  return se2_mul(se2_mul(state, a), b);
+}
+// motion/stationary_model.hpp:55-61 — N(0, 0.02) on rotation, x, y (in that order).
+inline SE2 stationary_apply(const SE2& state, uint64_t seed, uint32_t step, uint64_t index) {
+  double z[3];
+  three_normals(seed, step, index, z);
+  const SE2 d{so2_exp(z[0] * 0.02 + 0.0), z[1] * 0.02 + 0.0, z[2] * 0.02 + 0.0};
+  return se2_mul(state, d);
 }
 
 // algorithm/spatial_hash.hpp:45-75,87-94,190-193
@@ -753,9 +822,10 @@ struct AmclConfig {
   double alpha_slow, alpha_fast, kld_epsilon, kld_z;
   double hash_res[3];
   // DifferentialDriveModelParam
-  double alphas[4], distance_threshold;
+  double alphas[5], distance_threshold;  // alpha5 = strafe noise (omni only)
+  int motion_kind;  // 0 = differential, 1 = omnidirectional, 2 = stationary
   // sensor
-  int sensor_kind;  // 0 = likelihood field, 1 = beam
+  int sensor_kind;  // 0 = likelihood field, 1 = beam, 2 = likelihood field prob
   LfParams lf;
   BeamParams beam;
   uint64_t seed;
@@ -786,7 +856,7 @@ struct Amcl {
     cells.assign(c, c + static_cast<size_t>(W) * H);
     grid = Grid{cells.data(), W, H, res, se2_load(origin), t};
     world_to_field = se2_inverse(grid.origin);  // likelihood_field_model_base.hpp:99
-    if (cfg.sensor_kind == 0) {
+    if (cfg.sensor_kind != 1) {
       field.resize(grid.size());
       make_likelihood_field(grid, cfg.lf, field.data());
     }
@@ -932,6 +1002,27 @@ void orc_lf_weights(
   }
 }
 
+void orc_lf_prob_weights(
+    const float* field, int W, int H, double res, const double origin[4], double max_laser_distance, const double* states,
+    uint64_t n, const double* pts, uint64_t B, double* out) {
+  const SE2 w2f = se2_inverse(se2_load(origin));
+  for (uint64_t i = 0; i < n; ++i) out[i] = lf_prob_weight(field, W, H, res, w2f, max_laser_distance, se2_load(states + 4 * i), pts, B);
+}
+
+// kind 1 = omnidirectional (alphas[5]), kind 2 = stationary (control ignored)
+void orc_propagate_kind(double* states, uint64_t n, int kind, const double pose[4], const double prev[4], const double alphas[5],
+                        double distance_threshold, uint64_t seed, uint32_t step, uint64_t index_offset) {
+  if (kind == 1) {
+    const OmniSampler s = omni_sampler(se2_load(pose), se2_load(prev), alphas, distance_threshold);
+    for (uint64_t i = 0; i < n; ++i) se2_store(omni_apply(se2_load(states + 4 * i), s, seed, step, index_offset + i), states + 4 * i);
+  } else if (kind == 2) {
+    for (uint64_t i = 0; i < n; ++i) se2_store(stationary_apply(se2_load(states + 4 * i), seed, step, index_offset + i), states + 4 * i);
+  } else {
+    const DiffDriveSampler s = diffdrive_sampler(se2_load(pose), se2_load(prev), alphas, distance_threshold);
+    for (uint64_t i = 0; i < n; ++i) se2_store(diffdrive_apply(se2_load(states + 4 * i), s, seed, step, index_offset + i), states + 4 * i);
+  }
+}
+
 void orc_beam_weights(
     const int8_t* cells, int W, int H, double res, const double origin[4], const int8_t traits[3], const double beam_params[7],
     const double* states, uint64_t n, const double* pts, uint64_t B, int threads, double* out, int64_t* total_steps) {
@@ -1068,7 +1159,8 @@ struct orc_amcl_config {
   double beam[7];
   uint64_t seed;
   int32_t threads;
-  int32_t pad_;
+  int32_t motion_kind;
+  double alpha5;
 };
 
 void* orc_amcl_create(const orc_amcl_config* c) {
@@ -1086,6 +1178,8 @@ void* orc_amcl_create(const orc_amcl_config* c) {
   k.kld_z = c->kld_z;
   for (int i = 0; i < 3; ++i) k.hash_res[i] = c->hash_res[i];
   for (int i = 0; i < 4; ++i) k.alphas[i] = c->alphas[i];
+  k.alphas[4] = c->alpha5;
+  k.motion_kind = c->motion_kind;
   k.distance_threshold = c->distance_threshold;
   k.sensor_kind = c->sensor_kind;
   k.lf = LfParams{c->lf[0], c->lf[1], c->lf[2], c->lf[3], c->lf[4], c->lf_model_unknown_space, c->lf_only_obstacle_boundaries};
@@ -1164,12 +1258,25 @@ int orc_amcl_update(void* h, const double control[4], const double* pts, uint64_
 
   double t0 = now_s();
   // propagate (:174-175 ; actions/propagate.hpp:57-79)
-  const DiffDriveSampler sampler = diffdrive_sampler(a->window0, a->window1, k.alphas, k.distance_threshold);
   double* S = a->states.data();
   double* Wt = a->weights.data();
+  if (k.motion_kind == 0) {
+    const DiffDriveSampler sampler = diffdrive_sampler(a->window0, a->window1, k.alphas, k.distance_threshold);
 #pragma omp parallel for num_threads(threads) if (threads > 1) schedule(static)
-  for (long i = 0; i < static_cast<long>(n); ++i) {
-    se2_store(diffdrive_apply(se2_load(S + 4 * i), sampler, k.seed, a->step, static_cast<uint64_t>(i)), S + 4 * i);
+    for (long i = 0; i < static_cast<long>(n); ++i) {
+      se2_store(diffdrive_apply(se2_load(S + 4 * i), sampler, k.seed, a->step, static_cast<uint64_t>(i)), S + 4 * i);
+    }
+  } else if (k.motion_kind == 1) {
+    const OmniSampler sampler = omni_sampler(a->window0, a->window1, k.alphas, k.distance_threshold);
+#pragma omp parallel for num_threads(threads) if (threads > 1) schedule(static)
+    for (long i = 0; i < static_cast<long>(n); ++i) {
+      se2_store(omni_apply(se2_load(S + 4 * i), sampler, k.seed, a->step, static_cast<uint64_t>(i)), S + 4 * i);
+    }
+  } else {
+#pragma omp parallel for num_threads(threads) if (threads > 1) schedule(static)
+    for (long i = 0; i < static_cast<long>(n); ++i) {
+      se2_store(stationary_apply(se2_load(S + 4 * i), k.seed, a->step, static_cast<uint64_t>(i)), S + 4 * i);
+    }
   }
   double t1 = now_s();
   // reweight (:176 ; actions/reweight.hpp:53-60)
@@ -1179,6 +1286,12 @@ int orc_amcl_update(void* h, const double control[4], const double* pts, uint64_
     for (long i = 0; i < static_cast<long>(n); ++i) {
       Wt[i] = Wt[i] * lf_weight(a->field.data(), a->grid.W, a->grid.H, a->grid.res, a->world_to_field, k.lf.max_laser_distance,
                                 se2_load(S + 4 * i), pts, B);
+    }
+  } else if (k.sensor_kind == 2) {
+#pragma omp parallel for num_threads(threads) if (threads > 1) schedule(static)
+    for (long i = 0; i < static_cast<long>(n); ++i) {
+      Wt[i] = Wt[i] * lf_prob_weight(a->field.data(), a->grid.W, a->grid.H, a->grid.res, a->world_to_field, k.lf.max_laser_distance,
+                                     se2_load(S + 4 * i), pts, B);
     }
   } else {
 #pragma omp parallel for num_threads(threads) if (threads > 1) schedule(static) reduction(+ : steps)

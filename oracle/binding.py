@@ -55,7 +55,8 @@ class AmclConfig(C.Structure):
         ("beam", C.c_double * 7),
         ("seed", C.c_uint64),
         ("threads", C.c_int32),
-        ("pad_", C.c_int32),
+        ("motion_kind", C.c_int32),
+        ("alpha5", C.c_double),
     ]
 
 
@@ -172,6 +173,31 @@ def lf_weights(field, res, origin, max_laser_distance, states, points, threads=1
         field.ctypes.data_as(c_float_p), C.c_int(W), C.c_int(H), C.c_double(res), _d(origin), C.c_double(max_laser_distance),
         _d(states), C.c_uint64(len(states)), _d(points), C.c_uint64(len(points)), C.c_int(threads), _d(out))
     return out
+
+
+def lf_prob_weights(field, res, origin, max_laser_distance, states, points):
+    field = np.ascontiguousarray(field, dtype=np.float32)
+    H, W = field.shape
+    states = _dbl(states).reshape(-1, 4)
+    points = _dbl(points).reshape(-1, 2)
+    origin = _dbl(origin)
+    out = np.zeros(len(states))
+    lib().orc_lf_prob_weights(
+        field.ctypes.data_as(c_float_p), C.c_int(W), C.c_int(H), C.c_double(res), _d(origin), C.c_double(max_laser_distance),
+        _d(states), C.c_uint64(len(states)), _d(points), C.c_uint64(len(points)), _d(out))
+    return out
+
+
+MOTION_KINDS = {"differential": 0, "omnidirectional": 1, "stationary": 2}
+
+
+def propagate_kind(states, kind, pose, prev, alphas, seed, step, index_offset=0, distance_threshold=0.01):
+    s = _dbl(states).reshape(-1, 4).copy()
+    pose, prev = _dbl(pose), _dbl(prev)
+    a = (C.c_double * 5)(*(list(alphas) + [0.0] * (5 - len(alphas))))
+    lib().orc_propagate_kind(_d(s), C.c_uint64(len(s)), C.c_int(MOTION_KINDS[kind]), _d(pose), _d(prev), a,
+                             C.c_double(distance_threshold), C.c_uint64(seed), C.c_uint32(step), C.c_uint64(index_offset))
+    return s
 
 
 def beam_weights(cells, res, origin, beam_params, states, points, traits=ROS_TRAITS, threads=1, return_steps=False):
@@ -315,12 +341,15 @@ class Amcl:
                  min_particles=500, max_particles=2000, alpha_slow=0.001, alpha_fast=0.1, kld_epsilon=0.05, kld_z=3.0,
                  hash_res=(0.5, 0.5, np.deg2rad(10.0)), alphas=(0.1, 0.05, 0.1, 0.05), distance_threshold=0.01,
                  sensor="likelihood_field", lf=(100.0, 2.0, 0.5, 0.5, 0.2), lf_model_unknown_space=False,
-                 lf_only_obstacle_boundaries=False, beam=(0.5, 0.5, 0.05, 0.05, 0.2, 0.1, 60.0), seed=0, threads=1):
+                 lf_only_obstacle_boundaries=False, beam=(0.5, 0.5, 0.05, 0.05, 0.2, 0.1, 60.0), seed=0, threads=1,
+                 motion="differential", alpha5=0.0):
         cfg = AmclConfig()
         cfg.update_min_d, cfg.update_min_a = update_min_d, update_min_a
         cfg.resample_interval = resample_interval
         cfg.selective_resampling = int(selective_resampling)
-        cfg.sensor_kind = 0 if sensor == "likelihood_field" else 1
+        cfg.sensor_kind = {"likelihood_field": 0, "beam": 1, "likelihood_field_prob": 2}[sensor]
+        cfg.motion_kind = MOTION_KINDS[motion]
+        cfg.alpha5 = alpha5
         cfg.min_particles, cfg.max_particles = min_particles, max_particles
         cfg.alpha_slow, cfg.alpha_fast = alpha_slow, alpha_fast
         cfg.kld_epsilon, cfg.kld_z = kld_epsilon, kld_z

@@ -524,3 +524,76 @@ def test_full_size_beam_model_1m_sample_against_oracle():
     assert visited / n == pytest.approx(steps / 256, rel=0.05)
     assert np.all(np.isfinite(w)) and np.all(w >= 0)
     f.close()
+
+
+# ---- the other model closures of beluga_ros::Amcl's variant set -----------------------------
+def test_omnidirectional_and_stationary_propagation_match_oracle():
+    from beluga_amd.amcl import OmnidirectionalDriveModelParam, StationaryModelParam
+    grid = rooms_grid(64, 1)
+    n = 10_000
+    states = synth.normal_particles(n, (0.0, 0.0, 0.3), (1.0, 1.0, 1.0), seed=4)
+    pose, prev = se2_from_xytheta(1.3, 0.4, 0.35), se2_from_xytheta(1.0, 0.3, 0.30)
+    alphas = (0.1, 0.05, 0.1, 0.05, 0.08)
+    f = Amcl(grid, OmnidirectionalDriveModelParam(*alphas), LF, AmclParams(min_particles=n, max_particles=n), seed=11)
+    f.set_particles(states, np.ones(n))
+    f.propagate(pose, prev, step=7)
+    want = orc.propagate_kind(states, "omnidirectional", pose, prev, alphas, seed=11, step=7)
+    np.testing.assert_allclose(f.particles()[0], want, rtol=1e-11, atol=1e-13)
+    f.close()
+    f = Amcl(grid, StationaryModelParam(), LF, AmclParams(min_particles=n, max_particles=n), seed=11)
+    f.set_particles(states, np.ones(n))
+    f.propagate(pose, prev, step=3)
+    want = orc.propagate_kind(states, "stationary", pose, prev, (0.0,) * 5, seed=11, step=3)
+    np.testing.assert_allclose(f.particles()[0], want, rtol=1e-11, atol=1e-13)
+    f.close()
+
+
+@pytest.mark.parametrize("n", [3000, 20_001])  # lane kernel / ordered-lanes kernel with the log table
+def test_likelihood_field_prob_model_matches_oracle(n):
+    from beluga_amd.amcl import LikelihoodFieldProbModelParam
+    grid = rooms_grid()
+    truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=2, clearance_cells=6)
+    pts = make_scan(grid, truth, 120, max_range=12.0)
+    states = synth.normal_particles(n, truth, (0.5, 0.5, 0.2), seed=5)
+    prob = LikelihoodFieldProbModelParam(2.0, 100.0, 0.5, 0.5, 0.2, True)
+    f = Amcl(grid, MOTION, prob, AmclParams(min_particles=n, max_particles=n), seed=11)
+    f.set_particles(states, np.ones(n))
+    f.reweight(pts)
+    got = f.particles()[1]
+    want = orc.lf_prob_weights(f.likelihood_field(), grid.resolution, grid.origin, 100.0, states, pts)
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=0)  # exp() of a sum of ~120 logs
+    # reference golden (test_likelihood_field_prob_model.cpp:35-76) through the C ABI
+    center = np.array([0] * 12 + [100] + [0] * 12, dtype=np.int8).reshape(5, 5)
+    g = Amcl(OccupancyGrid(center, 0.5), MOTION, LikelihoodFieldProbModelParam(2.0, 20.0, 0.5, 0.5, 0.2), AmclParams(max_particles=4), seed=1)
+    g.set_particles(np.array([[1.0, 0.0, 0.0, 0.0]]), [1.0])
+    g.reweight([(1.20, 1.20), (1.25, 1.25), (1.30, 1.30)])
+    assert g.particles()[1][0] == pytest.approx(1.068, abs=0.01)
+    f.close()
+    g.close()
+
+
+def test_update_cycle_end_to_end_omni_and_prob_model():
+    from beluga_amd.amcl import LikelihoodFieldProbModelParam, OmnidirectionalDriveModelParam
+    grid = rooms_grid(400, 3)
+    origin_xy = (grid.origin[2], grid.origin[3])
+    truth = synth.find_free_pose(grid.cells, grid.resolution, origin_xy, seed=4, clearance_cells=8)
+    params = AmclParams(min_particles=500, max_particles=5000)
+    alphas = (0.1, 0.05, 0.1, 0.05, 0.08)
+    gpu = Amcl(grid, OmnidirectionalDriveModelParam(*alphas), LikelihoodFieldProbModelParam(2.0, 100.0, 0.5, 0.5, 0.2, True), params,
+               seed=5)
+    cpu = orc.Amcl(min_particles=500, max_particles=5000, alphas=alphas[:4], alpha5=alphas[4], motion="omnidirectional",
+                   sensor="likelihood_field_prob", lf=LF_T, lf_model_unknown_space=True, seed=5)
+    cpu.set_map(grid.cells, grid.resolution, grid.origin)
+    cov = np.diag([0.04, 0.04, 0.01])
+    gpu.initialize(truth, cov)
+    cpu.initialize(truth, cov)
+    pose, odom = truth, (0.0, 0.0, 0.0)
+    for c in range(6):
+        pose = synth.odometry_step(pose, 0.3, 0.05)
+        odom = synth.odometry_step(odom, 0.3, 0.05)
+        pts = make_scan(grid, pose, 60, max_range=8.0, seed=50 + c)  # few beams: the product of 60 likelihoods stays in range
+        g = gpu.update(se2_from_xytheta(*odom), pts)
+        o = cpu.update(se2_from_xytheta(*odom), pts)
+        assert gpu.last_info["num_particles"] == len(cpu.particles()[1]), f"cycle {c}"
+        np.testing.assert_allclose(g[0], o[0], atol=1e-8, err_msg=f"cycle {c}")
+    gpu.close()

@@ -434,3 +434,56 @@ def test_normalize_semantics():  # actions/test_normalize.cpp:27-99
     assert s == 10.0 and np.allclose(w, [0.1, 0.2, 0.3, 0.4])
     w, s = orc.normalize([0.25, 0.25, 0.5])  # already normalised: untouched
     assert list(w) == [0.25, 0.25, 0.5]
+
+
+# ---- "next" rows of SURVEY.md 8(f): the other model closures of beluga_ros::Amcl's variant set -------------------
+def test_lf_prob_importance_weight():  # sensor/test_likelihood_field_prob_model.cpp:35-76
+    field = orc.make_likelihood_field(CENTER, 0.5, LF_PARAMS)
+    w = lambda pts, state=IDENTITY: orc.lf_prob_weights(field, 0.5, IDENTITY, LF_PARAMS[1], [state], pts)[0]
+    assert w([(1.25, 1.25)]) == pytest.approx(1.022, abs=0.003)
+    assert w([(2.25, 2.25)]) == pytest.approx(0.025, abs=0.003)
+    assert w([(-50.0, 50.0)]) == pytest.approx(0.050, abs=0.003)
+    assert w([(1.20, 1.20), (1.25, 1.25), (1.30, 1.30)]) == pytest.approx(1.068, abs=0.01)
+    assert w([(0.0, 0.0)], orc.se2(1.25, 1.25, 0.0)) == pytest.approx(1.022, abs=0.003)
+
+
+def _omni(control, prev, state, alphas=(0.0,) * 5, n=1, seed=7):
+    return orc.propagate_kind(np.tile(state, (n, 1)), "omnidirectional", control, prev, alphas, seed=seed, step=1)
+
+
+def test_omnidirectional_noise_free():  # motion/test_omnidirectional_drive_model.cpp:53-100
+    pi = math.pi
+    pose = orc.se2(2.0, 5.0, pi / 3)
+    _se2_near(_omni(orc.se2(1.0, -2.0, pi), orc.se2(1.0, -2.0, pi), pose)[0], pose, 1e-3)
+    c, p = orc.se2(1.0, 0.0, 0.0), orc.se2(0.0, 0.0, 0.0)
+    _se2_near(_omni(c, p, orc.se2(2.0, 0.0, 0.0))[0], orc.se2(3.0, 0.0, 0.0), 1e-3)
+    _se2_near(_omni(c, p, orc.se2(0.0, 3.0, 0.0))[0], orc.se2(1.0, 3.0, 0.0), 1e-3)
+    c = orc.se2(0.0, 1.0, pi / 2)
+    _se2_near(_omni(c, p, orc.se2(0.0, 0.0, 0.0))[0], orc.se2(0.0, 1.0, pi / 2), 1e-3)
+    _se2_near(_omni(c, p, orc.se2(2.0, 3.0, -pi / 2))[0], orc.se2(3.0, 3.0, 0.0), 1e-3)
+    c = orc.se2(0.0, 0.0, pi / 4)
+    _se2_near(_omni(c, p, orc.se2(0.0, 0.0, pi))[0], orc.se2(0.0, 0.0, pi * 5 / 4), 1e-3)
+    _se2_near(_omni(c, p, orc.se2(0.0, 0.0, -pi / 2))[0], orc.se2(0.0, 0.0, -pi / 4), 1e-3)
+    _se2_near(_omni(orc.se2(0.0, 1.0, 0.0), p, orc.se2(0.0, 0.0, 0.0))[0], orc.se2(0.0, 1.0, 0.0), 1e-3)  # TranslateStrafe
+
+
+def test_omnidirectional_statistics():  # :116-178
+    pi, alpha, zero = math.pi, 0.2, orc.se2(0, 0, 0)
+    out = _omni(orc.se2(3.0, 0, 0), zero, orc.se2(5.0, 0, 0), (0, 0, alpha, 0, 0), n=100_000, seed=3)
+    assert out[:, 2].mean() == pytest.approx(8.0, abs=0.015) and out[:, 2].std() == pytest.approx(math.sqrt(alpha * 9.0), abs=0.015)
+    out = _omni(orc.se2(0, 0, pi / 4), zero, orc.se2(0, 0, pi / 6), (alpha, 0, 0, 0, 0), n=100_000, seed=4)
+    th = np.arctan2(out[:, 1], out[:, 0])
+    assert th.mean() == pytest.approx(pi / 6 + pi / 4, abs=0.01) and th.std() == pytest.approx(math.sqrt(alpha * (pi / 4) ** 2), abs=0.01)
+    out = _omni(orc.se2(0, 0, -pi * 3 / 4), zero, orc.se2(0, 0, pi / 6), (alpha, 0, 0, 0, 0), n=100_000, seed=5)
+    th = np.arctan2(out[:, 1], out[:, 0])
+    assert th.mean() == pytest.approx(pi / 6 - pi * 3 / 4, abs=0.01) and th.std() == pytest.approx(math.sqrt(alpha * (pi / 4) ** 2), abs=0.01)
+
+
+def test_stationary_model_statistics():  # motion/stationary_model.hpp:55-61: N(0, 0.02) on (theta, x, y), control ignored
+    start = orc.se2(1.0, -2.0, 0.5)
+    out = orc.propagate_kind(np.tile(start, (100_000, 1)), "stationary", orc.se2(9, 9, 1), orc.se2(0, 0, 0), (0.0,) * 5, seed=11, step=2)
+    local = np.array([orc.se2_mul(orc.se2_inverse(start), s) for s in out[:2000]])
+    assert abs(local[:, 2].mean()) < 0.002 and local[:, 2].std() == pytest.approx(0.02, abs=0.002)
+    assert abs(local[:, 3].mean()) < 0.002 and local[:, 3].std() == pytest.approx(0.02, abs=0.002)
+    th = np.arctan2(out[:, 1], out[:, 0]) - 0.5
+    assert abs(th.mean()) < 0.001 and th.std() == pytest.approx(0.02, abs=0.001)
