@@ -244,6 +244,20 @@ class Amcl:
             return None
         return np.array(est.pose), np.array(est.covariance).reshape(3, 3)
 
+    def update_laser_scan(self, control_action, scan):
+        """beluga_ros::Amcl::update(base_pose_in_odom, laser_scan) (beluga_ros/src/amcl.cpp:54-63)."""
+        ctrl = np.ascontiguousarray(control_action, dtype=np.float64)
+        est, info = capi.Estimate(), capi.UpdateInfo()
+        self._check(self._lib.mcl_update_laser_scan(self._ctx, _dp(ctrl), C.byref(scan), C.byref(est), C.byref(info)))
+        self.last_info = {
+            "updated": bool(info.updated), "resampled": bool(info.resampled), "num_particles": info.num_particles,
+            "weight_sum": info.weight_sum, "ess": info.effective_sample_size,
+            "random_state_probability": info.random_state_probability,
+        }
+        if not info.updated:
+            return None
+        return np.array(est.pose), np.array(est.covariance).reshape(3, 3)
+
     # -- stage-level entry points (parity tests, multi-GPU driver) ------------------------------------
     def propagate(self, pose, previous_pose, step: int):
         a = np.ascontiguousarray(pose, dtype=np.float64)
@@ -341,6 +355,33 @@ class Amcl:
         cnt = (C.c_uint64 * len(capi.STAGES))()
         self._check(self._lib.mcl_profile_read(self._ctx, ms, cnt, int(reset)))
         return {name: (ms[i], cnt[i]) for i, name in enumerate(capi.STAGES)}
+
+
+def make_laser_scan(ranges, angle_min, angle_increment, range_min, range_max, origin_se3=(0, 0, 0, 1, 0, 0, 0), max_beams=2 ** 64 - 1,
+                    min_range=float(np.finfo(np.float64).tiny), max_range=float(np.finfo(np.float64).max)):
+    """A beluga_ros::LaserScan (laser_scan.hpp:46-66): the message fields + origin + decimation / range limits."""
+    r = np.ascontiguousarray(ranges, dtype=np.float32)
+    scan = capi.LaserScan()
+    scan.ranges = r.ctypes.data_as(capi.c_float_p)
+    scan.num_ranges = len(r)
+    scan.angle_min, scan.angle_increment = angle_min, angle_increment
+    scan.range_min, scan.range_max = range_min, range_max
+    scan.origin_se3 = (C.c_double * 7)(*origin_se3)
+    scan.max_beams = max_beams
+    scan.min_range, scan.max_range = min_range, max_range
+    scan._keepalive = r
+    return scan
+
+
+def prepare_laser_scan(scan) -> np.ndarray:
+    """points in the base frame, as beluga_ros::Amcl::update builds them (beluga_ros/src/amcl.cpp:54-63)."""
+    lib = capi.load()
+    out = np.zeros((min(scan.num_ranges, scan.max_beams) + 1, 2))
+    m = C.c_uint64(0)
+    st = lib.mcl_prepare_laser_scan(C.byref(scan), _dp(out), C.byref(m))
+    if st != capi.MCL_OK:
+        raise capi.MclError(st, "mcl_prepare_laser_scan")
+    return out[:m.value].copy()
 
 
 def estimate_from_sums(sums: np.ndarray):

@@ -85,6 +85,14 @@ class WeightStats(C.Structure):
     _fields_ = [("sum", C.c_double), ("norm_sum", C.c_double), ("norm_sumsq", C.c_double)]
 
 
+class LaserScan(C.Structure):
+    _fields_ = [
+        ("ranges", c_float_p), ("num_ranges", C.c_uint64), ("angle_min", C.c_float), ("angle_increment", C.c_float),
+        ("range_min", C.c_float), ("range_max", C.c_float), ("origin_se3", C.c_double * 7), ("max_beams", C.c_uint64),
+        ("min_range", C.c_double), ("max_range", C.c_double),
+    ]
+
+
 class DeviceView(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("y", C.c_void_p), ("c", C.c_void_p), ("s", C.c_void_p), ("w", C.c_void_p), ("cdf", C.c_void_p),
@@ -108,6 +116,8 @@ _SIGNATURES = {
     "mcl_get_particles": (C.c_int32, [_ctx, c_double_p, c_double_p, C.c_uint64, c_u64_p]),
     "mcl_force_update": (C.c_int32, [_ctx]),
     "mcl_update": (C.c_int32, [_ctx, c_double_p, c_double_p, C.c_uint64, C.POINTER(Estimate), C.POINTER(UpdateInfo)]),
+    "mcl_prepare_laser_scan": (C.c_int32, [C.POINTER(LaserScan), c_double_p, c_u64_p]),
+    "mcl_update_laser_scan": (C.c_int32, [_ctx, c_double_p, C.POINTER(LaserScan), C.POINTER(Estimate), C.POINTER(UpdateInfo)]),
     "mcl_propagate": (C.c_int32, [_ctx, c_double_p, c_double_p, C.c_uint32]),
     "mcl_reweight": (C.c_int32, [_ctx, c_double_p, C.c_uint64]),
     "mcl_weight_sum": (C.c_int32, [_ctx, c_double_p]),

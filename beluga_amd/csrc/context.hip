@@ -956,6 +956,50 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   return MCL_OK;
 }
 
+mcl_status mcl_prepare_laser_scan(const mcl_laser_scan* scan, double* points_xy, uint64_t* num_points) {
+  if (!scan || !num_points || (scan->num_ranges && (!scan->ranges || !points_xy))) return MCL_ERR_INVALID_ARGUMENT;
+  const uint64_t n = scan->num_ranges, count = scan->max_beams;
+  const double lo = std::max(static_cast<double>(scan->range_min), scan->min_range);  // laser_scan.hpp:61-62
+  const double hi = std::min(static_cast<double>(scan->range_max), scan->max_range);
+  const double qx = scan->origin_se3[0], qy = scan->origin_se3[1], qz = scan->origin_se3[2], qw = scan->origin_se3[3];
+  const uint64_t taken = n == 0 ? 0 : std::min(n, count);  // take_evenly.hpp:47-57
+  uint64_t m = 0;
+  for (uint64_t k = 0; k < taken; ++k) {
+    uint64_t i = k;  // take_evenly.hpp:126-148: ceil(k * (size - 1) / (count - 1))
+    if (count <= n && k > 0) {
+      if (count == 1) break;
+      const int64_t a = static_cast<int64_t>(k) * (static_cast<int64_t>(n) - 1), b = static_cast<int64_t>(count) - 1;
+      i = static_cast<uint64_t>(a / b + ((a % b == 0) ? 0 : 1));
+    }
+    if (i >= n) break;
+    const double range = static_cast<double>(scan->ranges[i]);
+    // float arithmetic first, then widened (laser_scan.hpp:73-77)
+    const double theta = static_cast<double>(scan->angle_min + static_cast<float>(static_cast<int>(i)) * scan->angle_increment);
+    if (std::isnan(range) || !(range >= lo) || !(range <= hi)) continue;  // sensor/data/laser_scan.hpp:79-83
+    const double px = range * std::cos(theta), py = range * std::sin(theta), pz = 0.0;
+    // origin * (x, y, 0): Sophus SO3 rotates with uv = 2 (q.vec x p); p + q.w uv + q.vec x uv, then adds the translation
+    double ux = qy * pz - qz * py, uy = qz * px - qx * pz, uz = qx * py - qy * px;
+    ux += ux;
+    uy += uy;
+    uz += uz;
+    points_xy[2 * m] = (px + qw * ux + (qy * uz - qz * uy)) + scan->origin_se3[4];
+    points_xy[2 * m + 1] = (py + qw * uy + (qz * ux - qx * uz)) + scan->origin_se3[5];
+    ++m;
+  }
+  *num_points = m;
+  return MCL_OK;
+}
+
+mcl_status mcl_update_laser_scan(mcl_ctx* ctx, const double control_pose[4], const mcl_laser_scan* scan, mcl_estimate* estimate,
+                                 mcl_update_info* info) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, scan != nullptr, "null scan");
+  std::vector<double> pts(2 * std::min<uint64_t>(scan->num_ranges, scan->max_beams) + 2);
+  uint64_t m = 0;
+  if (mcl_prepare_laser_scan(scan, pts.data(), &m) != MCL_OK) return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "bad laser scan");
+  return mcl_update(ctx, control_pose, pts.data(), m, estimate, info);
+}
+
 mcl_status mcl_get_device_view(mcl_ctx* ctx, mcl_device_view* view) {
   if (!ctx || !view) return MCL_ERR_INVALID_ARGUMENT;
   const ParticleSoA p = ctx->cur();

@@ -15,6 +15,7 @@
 #ifndef BELUGA_AMD_AMCL_HPP
 #define BELUGA_AMD_AMCL_HPP
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -152,6 +153,18 @@ struct OccupancyGridView {
   }
 };
 
+/// What beluga_ros::LaserScan wraps (beluga_ros/include/beluga_ros/laser_scan.hpp:46-66): the sensor_msgs/LaserScan
+/// fields, the laser origin in the base frame and the decimation / range limits.
+struct LaserScan {
+  std::vector<float> ranges;
+  float angle_min{0.F}, angle_increment{0.F};
+  float range_min{0.F}, range_max{0.F};
+  std::array<double, 7> origin{0, 0, 0, 1, 0, 0, 0};  ///< Sophus::SE3d::data(): qx qy qz qw tx ty tz
+  std::size_t max_beams{static_cast<std::size_t>(-1)};
+  double min_range{2.2250738585072014e-308};
+  double max_range{1.7976931348623157e308};
+};
+
 /// Host mirror of the particle set: what `beluga::TupleVector<std::tuple<SE2d, Weight>>` holds.
 struct ParticleSet {
   std::vector<SE2d> states;
@@ -282,6 +295,26 @@ class Amcl {
     out.first.y = est.pose[3];
     for (int i = 0; i < 9; ++i) out.second[static_cast<std::size_t>(i)] = est.covariance[i];
     return out;
+  }
+
+  /// beluga_ros::Amcl::update(base_pose_in_odom, laser_scan) (beluga_ros/src/amcl.cpp:54-63).
+  auto update(const SE2d& base_pose_in_odom, const LaserScan& laser_scan) -> std::optional<estimation_type> {
+    mcl_laser_scan scan;
+    scan.ranges = laser_scan.ranges.data();
+    scan.num_ranges = laser_scan.ranges.size();
+    scan.angle_min = laser_scan.angle_min;
+    scan.angle_increment = laser_scan.angle_increment;
+    scan.range_min = laser_scan.range_min;
+    scan.range_max = laser_scan.range_max;
+    for (std::size_t i = 0; i < 7; ++i) scan.origin_se3[i] = laser_scan.origin[i];
+    scan.max_beams = laser_scan.max_beams;
+    scan.min_range = laser_scan.min_range;
+    scan.max_range = laser_scan.max_range;
+    measurement_type points(std::min<std::size_t>(laser_scan.ranges.size(), laser_scan.max_beams) + 1);
+    std::uint64_t m = 0;
+    check(mcl_prepare_laser_scan(&scan, &points.front().first, &m));
+    points.resize(m);
+    return update(base_pose_in_odom, points);
   }
 
   /// Force a manual update of the particles on the next iteration of the filter (amcl_core.hpp:204).

@@ -161,6 +161,26 @@ typedef struct mcl_update_info {
 mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* points_xy, uint64_t num_points,
                       mcl_estimate* estimate, mcl_update_info* info);
 
+/* Caller-side scan preparation, i.e. what beluga_ros::Amcl::update(pose, LaserScan) does before the filter sees the
+ * measurement (beluga_ros/src/amcl.cpp:54-63; beluga_ros/include/beluga_ros/laser_scan.hpp:46-100;
+ * beluga/sensor/data/laser_scan.hpp:64-90; beluga/views/take_evenly.hpp:126-148): decimate to `max_beams` evenly
+ * spaced beams, drop NaN and out-of-range readings, polar -> cartesian, move into the base frame with the laser origin
+ * `origin_se3` = Sophus::SE3d::data() = (qx, qy, qz, qw, tx, ty, tz).  sensor_msgs/LaserScan fields are float32.
+ * Pure host arithmetic (O(beams)); `points_xy` must hold 2 * min(n, max_beams) doubles. */
+typedef struct mcl_laser_scan {
+  const float* ranges;
+  uint64_t num_ranges;
+  float angle_min, angle_increment;
+  float range_min, range_max; /* from the message */
+  double origin_se3[7];
+  uint64_t max_beams;         /* SIZE_MAX: all */
+  double min_range, max_range; /* caller limits (laser_min_range / laser_max_range); combined with the message's */
+} mcl_laser_scan;
+mcl_status mcl_prepare_laser_scan(const mcl_laser_scan* scan, double* points_xy, uint64_t* num_points);
+/* mcl_prepare_laser_scan followed by mcl_update: beluga_ros::Amcl::update(base_pose_in_odom, laser_scan). */
+mcl_status mcl_update_laser_scan(mcl_ctx* ctx, const double control_pose[4], const mcl_laser_scan* scan, mcl_estimate* estimate,
+                                 mcl_update_info* info);
+
 /* ---- Stage-level entry points (what update() composes; used by parity tests and by the
  * multi-GPU driver, which interleaves collectives between them). -------------------------------- */
 

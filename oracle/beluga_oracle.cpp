@@ -1344,6 +1344,48 @@ int orc_amcl_update(void* h, const double control[4], const double* pts, uint64_
   return 1;
 }
 
+// Caller-side scan preparation: beluga_ros::Amcl::update(pose, LaserScan) (beluga_ros/src/amcl.cpp:54-63) over
+// beluga_ros::LaserScan (beluga_ros/include/beluga_ros/laser_scan.hpp:46-100), BaseLaserScan
+// (beluga/sensor/data/laser_scan.hpp:64-90) and views::take_evenly (beluga/views/take_evenly.hpp:126-148).
+// origin_se3 = Sophus::SE3d::data() = (qx, qy, qz, qw, tx, ty, tz).  Returns the number of points written.
+uint64_t orc_take_evenly_index(uint64_t pos, uint64_t size, uint64_t count) {  // index of the pos-th element taken
+  if (count > size) return pos;
+  if (pos == 0) return 0;
+  if (count == 1) return size;
+  const int64_t a = static_cast<int64_t>(pos) * (static_cast<int64_t>(size) - 1);
+  const int64_t b = static_cast<int64_t>(count) - 1;
+  return static_cast<uint64_t>(a / b + ((a % b == 0) ? 0 : 1));
+}
+
+uint64_t orc_prepare_laser_scan(const float* ranges, uint64_t n, float angle_min, float angle_increment, float range_min,
+                                float range_max, const double origin_se3[7], uint64_t max_beams, double min_range,
+                                double max_range, double* out_xy) {
+  const double lo = std::max(static_cast<double>(range_min), min_range);
+  const double hi = std::min(static_cast<double>(range_max), max_range);
+  const uint64_t taken = n == 0 ? 0 : (max_beams > n ? n : max_beams);
+  const double qx = origin_se3[0], qy = origin_se3[1], qz = origin_se3[2], qw = origin_se3[3];
+  uint64_t m = 0;
+  for (uint64_t k = 0; k < taken; ++k) {
+    const uint64_t i = orc_take_evenly_index(k, n, max_beams);
+    if (i >= n) break;
+    const double range = static_cast<double>(ranges[i]);
+    const double theta = static_cast<double>(angle_min + static_cast<float>(static_cast<int>(i)) * angle_increment);
+    if (std::isnan(range) || !(range >= lo) || !(range <= hi)) continue;
+    const double px = range * std::cos(theta), py = range * std::sin(theta), pz = 0.0;
+    // Sophus SO3 * point: uv = 2 * (q.vec x p); p + q.w * uv + q.vec x uv   (so3.hpp operator*)
+    double ux = qy * pz - qz * py, uy = qz * px - qx * pz, uz = qx * py - qy * px;
+    ux += ux;
+    uy += uy;
+    uz += uz;
+    const double rx = px + qw * ux + (qy * uz - qz * uy);
+    const double ry = py + qw * uy + (qz * ux - qx * uz);
+    out_xy[2 * m] = rx + origin_se3[4];
+    out_xy[2 * m + 1] = ry + origin_se3[5];
+    ++m;
+  }
+  return m;
+}
+
 int orc_max_threads() {
 #if defined(_OPENMP)
   return omp_get_max_threads();

@@ -431,5 +431,27 @@ class Amcl:
         return lib().orc_amcl_beam_steps(self._h)
 
 
+def take_evenly_indices(size, count):
+    L = lib()
+    L.orc_take_evenly_index.restype = C.c_uint64
+    L.orc_take_evenly_index.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    taken = 0 if size == 0 else min(size, count)
+    out = [L.orc_take_evenly_index(k, size, count) for k in range(taken)]
+    return [i for i in out if i < size]
+
+
+def prepare_laser_scan(ranges, angle_min, angle_increment, range_min, range_max, origin_se3=(0, 0, 0, 1, 0, 0, 0),
+                       max_beams=2 ** 63, min_range=np.finfo(np.float64).tiny, max_range=np.finfo(np.float64).max):
+    r = np.ascontiguousarray(ranges, dtype=np.float32)
+    o = _dbl(origin_se3)
+    out = np.zeros((len(r), 2))
+    L = lib()
+    L.orc_prepare_laser_scan.restype = C.c_uint64
+    m = L.orc_prepare_laser_scan(r.ctypes.data_as(c_float_p), C.c_uint64(len(r)), C.c_float(angle_min), C.c_float(angle_increment),
+                                 C.c_float(range_min), C.c_float(range_max), _d(o), C.c_uint64(max_beams), C.c_double(min_range),
+                                 C.c_double(max_range), _d(out))
+    return out[:m].copy()
+
+
 def max_threads():
     return lib().orc_max_threads()

@@ -95,3 +95,22 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(text), f"{f} references the oracle"
+
+
+def test_laser_scan_preparation_matches_oracle(lib):
+    """mcl_prepare_laser_scan is host arithmetic: bit-identical to the oracle's restatement."""
+    import numpy as np
+    from beluga_amd.amcl import make_laser_scan, prepare_laser_scan
+    from oracle import binding as orc
+    rng = np.random.Generator(np.random.MT19937(3))
+    ranges = rng.uniform(0.05, 40.0, 1081).astype(np.float32)
+    ranges[::17] = np.nan
+    ranges[5::29] = np.inf
+    q = (0.01, -0.02, 0.38, 0.9247, 0.2, 0.0, 0.4)
+    q = tuple(np.array(q[:4]) / np.linalg.norm(q[:4])) + q[4:]
+    for max_beams in (2 ** 64 - 1, 1081, 1080, 360, 100, 2, 1):
+        scan = make_laser_scan(ranges, -2.356, 0.004363, 0.1, 30.0, origin_se3=q, max_beams=max_beams, min_range=0.2, max_range=25.0)
+        got = prepare_laser_scan(scan)
+        want = orc.prepare_laser_scan(ranges, -2.356, 0.004363, 0.1, 30.0, origin_se3=q, max_beams=min(max_beams, 2 ** 63), min_range=0.2,
+                                      max_range=25.0)
+        assert got.shape == want.shape and np.array_equal(got, want)

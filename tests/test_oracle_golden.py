@@ -487,3 +487,27 @@ def test_stationary_model_statistics():  # motion/stationary_model.hpp:55-61: N(
     assert abs(local[:, 3].mean()) < 0.002 and local[:, 3].std() == pytest.approx(0.02, abs=0.002)
     th = np.arctan2(out[:, 1], out[:, 0]) - 0.5
     assert abs(th.mean()) < 0.001 and th.std() == pytest.approx(0.02, abs=0.001)
+
+
+# ---- caller-side scan preparation ------------------------------------------------------------
+@pytest.mark.parametrize("size,count,expected", [
+    (0, 0, []), (0, 1, []), (4, 0, []), (4, 1, [1]), (4, 10, [1, 2, 3, 4]), (4, 2, [1, 4]), (5, 3, [1, 3, 5]), (6, 3, [1, 4, 6]),
+    (9, 3, [1, 5, 9]), (4, 3, [1, 3, 4]), (10, 6, [1, 3, 5, 7, 9, 10]),
+])
+def test_take_evenly(size, count, expected):  # beluga/test/beluga/views/test_take_evenly.cpp:72-147 (1-based values there)
+    assert [i + 1 for i in orc.take_evenly_indices(size, count)] == expected
+
+
+def test_laser_scan_preparation():  # beluga_ros/test/test_laser_scan.cpp:30-89 + sensor/data/laser_scan.hpp:64-90
+    pts = orc.prepare_laser_scan([1.0, 2.0, 3.0], 0.0, 0.1, 0.0, 100.0)
+    ang = np.arctan2(pts[:, 1], pts[:, 0])
+    np.testing.assert_allclose(ang, [0.0, 0.1, 0.2], atol=0.001)  # AngleIncrements
+    np.testing.assert_allclose(np.hypot(pts[:, 0], pts[:, 1]), [1.0, 2.0, 3.0], rtol=1e-12)
+    assert len(orc.prepare_laser_scan([1.0, 2.0, 3.0], 0.0, 0.1, 0.0, 100.0, max_beams=2)) == 2  # LimitMaxBeams
+    # message limits and constructor limits combine (MinMaxRangeFrom*): [max(10,15), min(100,95)]
+    pts = orc.prepare_laser_scan([12.0, 20.0, 97.0, np.nan, 50.0], 0.0, 0.1, 10.0, 100.0, min_range=15.0, max_range=95.0)
+    np.testing.assert_allclose(np.hypot(pts[:, 0], pts[:, 1]), [20.0, 50.0], rtol=1e-12)
+    # laser origin: 90 deg yaw + offset, z ignored
+    q = (0.0, 0.0, math.sin(math.pi / 4), math.cos(math.pi / 4), 0.5, -0.25, 0.3)
+    pts = orc.prepare_laser_scan([2.0], 0.0, 0.1, 0.0, 100.0, origin_se3=q)
+    np.testing.assert_allclose(pts[0], [0.5, 1.75], atol=1e-12)
