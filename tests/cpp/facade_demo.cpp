@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
       }
     }
     // empty filter: update returns nullopt (amcl_core.hpp:166-168)
-    std::printf("empty_update %d\n", filter.update(SE2d{}, {{1.0, 0.0}}).has_value() ? 1 : 0);
+    std::printf("empty_update %d\n", filter.update(SE2d{}, Amcl::measurement_type{{1.0, 0.0}}).has_value() ? 1 : 0);
     filter.initialize(SE2d{0.3, 1.0, 1.0}, Matrix3d{0.04, 0, 0, 0, 0.04, 0, 0, 0, 0.01});
     std::printf("initial_particles %zu\n", filter.particles().size());
     std::vector<std::pair<double, double>> scan;
