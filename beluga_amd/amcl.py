@@ -294,6 +294,19 @@ class Amcl:
         self._check(self._lib.mcl_estimate_pose(self._ctx, C.byref(est)))
         return np.array(est.pose), np.array(est.covariance).reshape(3, 3)
 
+    def cluster_based_estimate(self, linear_hash_resolution=0.20, angular_hash_resolution=0.524, weight_cap_percentile=0.90):
+        """beluga::cluster_based_estimate (algorithm/cluster_based_estimation.hpp:415-433)."""
+        cp = capi.ClusterParams(linear_hash_resolution, angular_hash_resolution, weight_cap_percentile)
+        est = capi.Estimate()
+        self._check(self._lib.mcl_cluster_based_estimate(self._ctx, C.byref(cp), C.byref(est)))
+        return np.array(est.pose), np.array(est.covariance).reshape(3, 3)
+
+    def set_estimate_kind(self, cluster_based: bool, **cluster_params):
+        """What update() returns: beluga::estimate (beluga::Amcl) or cluster_based_estimate (beluga_ros::Amcl)."""
+        cp = capi.ClusterParams(cluster_params.get("linear_hash_resolution", 0.20), cluster_params.get("angular_hash_resolution", 0.524),
+                                cluster_params.get("weight_cap_percentile", 0.90))
+        self._check(self._lib.mcl_set_estimate_kind(self._ctx, int(cluster_based), C.byref(cp)))
+
     def build_cdf(self) -> float:
         t = C.c_double(0)
         self._check(self._lib.mcl_build_cdf(self._ctx, C.byref(t)))

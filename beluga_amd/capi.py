@@ -93,6 +93,10 @@ class LaserScan(C.Structure):
     ]
 
 
+class ClusterParams(C.Structure):
+    _fields_ = [("linear_hash_resolution", C.c_double), ("angular_hash_resolution", C.c_double), ("weight_cap_percentile", C.c_double)]
+
+
 class DeviceView(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("y", C.c_void_p), ("c", C.c_void_p), ("s", C.c_void_p), ("w", C.c_void_p), ("cdf", C.c_void_p),
@@ -126,6 +130,8 @@ _SIGNATURES = {
     "mcl_estimate_sums": (C.c_int32, [_ctx, c_double_p, c_double_p]),
     "mcl_estimate_from_sums": (C.c_int32, [c_double_p, C.POINTER(Estimate)]),
     "mcl_estimate_pose": (C.c_int32, [_ctx, C.POINTER(Estimate)]),
+    "mcl_cluster_based_estimate": (C.c_int32, [_ctx, C.POINTER(ClusterParams), C.POINTER(Estimate)]),
+    "mcl_set_estimate_kind": (C.c_int32, [_ctx, C.c_int32, C.POINTER(ClusterParams)]),
     "mcl_get_device_view": (C.c_int32, [_ctx, C.POINTER(DeviceView)]),
     "mcl_set_num_particles": (C.c_int32, [_ctx, C.c_uint64]),
     "mcl_build_cdf": (C.c_int32, [_ctx, c_double_p]),

@@ -12,7 +12,11 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <numeric>
+#include <optional>
+#include <queue>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "beluga_mcl.h"
@@ -213,6 +217,13 @@ struct mcl_ctx {
   DeviceBuffer<uint32_t> d_flags, d_uchunk;  // flags[cap]; uchunk[2][stride]
   DeviceBuffer<unsigned long long> d_kld_scalars;  // [0]=first_fail, [1]=beam steps; as u32 view: k words at [4..]
   unsigned long long* h_kld_scalars{nullptr};      // pinned, 8 words
+
+  // cluster_based_estimate scratch
+  DeviceBuffer<double> d_cell_f64;             // table wsum[cap_t] | list wsum[m_cap] | list state[4*m_cap]
+  DeviceBuffer<unsigned int> d_cell_u32;       // table count[cap_t] cluster[cap_t] | list first,count,slot,cluster[m_cap] | size
+  DeviceBuffer<unsigned long long> d_cell_u64; // list key[m_cap]
+  int estimate_kind{0};
+  mcl_cluster_params cluster_params{0.20, 0.524, 0.90};
 
   // host-side filter state (amcl_core.hpp:206-232)
   ExponentialFilter slow, fast;
@@ -539,6 +550,166 @@ mcl_status do_estimate_sums(mcl_ctx* ctx, const double pivot[2], double sums[12]
   return MCL_OK;
 }
 
+
+// algorithm/spatial_hash.hpp:45-75,87-94,190-193 on the host (neighbour cells of the cluster flood fill).
+uint64_t host_floor_and_fibo_hash(double value, unsigned shift) {
+  const int64_t sv = static_cast<int64_t>(std::floor(value));
+  const uint64_t h = 11400714819323198485ull * static_cast<uint64_t>(sv);
+  return shift ? ((h << shift) | (h >> (64 - shift))) : h;
+}
+uint64_t host_spatial_hash(const Pose2& s, double res_xy, double res_theta) {
+  return host_floor_and_fibo_hash(s.x / res_xy, 0) ^ host_floor_and_fibo_hash(s.y / res_xy, 21) ^
+         host_floor_and_fibo_hash(rot_log(s.r) / res_theta, 42);
+}
+
+// cluster_based_estimation.hpp:415-433.  Device: hashing, per-cell aggregation, masked sums.  Host: the cluster
+// assignment over the (few) occupied cells with std::unordered_map / std::priority_queue / std::nth_element, fed in
+// first-occurrence order so the containers evolve as they do in the reference.
+mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_estimate* out) {
+  const uint64_t n = ctx->n;
+  if (n == 0) return fail(ctx, MCL_ERR_NOT_READY, "no particles");
+  MCL_REQUIRE(ctx, cp.linear_hash_resolution > 0 && cp.angular_hash_resolution > 0 && cp.weight_cap_percentile >= 0 &&
+                       cp.weight_cap_percentile < 1.0, "bad cluster parameters");
+  MCL_REQUIRE(ctx, n < 0xFFFFFFFFull, "too many particles");
+  if (ctx->table_capacity == 0) {
+    if (const mcl_status s = ensure_kld(ctx)) return s;
+  }
+  uint64_t slots = 1024;
+  while (slots < 2 * n) slots <<= 1;
+  slots = std::min<uint64_t>(slots, ctx->table_capacity);
+  const uint64_t m_cap = std::min<uint64_t>(n, slots);
+  const uint64_t tcap = ctx->table_capacity;
+  MCL_HIP(ctx, ctx->d_cell_f64.ensure(tcap + 5 * ctx->capacity));
+  MCL_HIP(ctx, ctx->d_cell_u32.ensure(2 * tcap + 4 * ctx->capacity + 4));
+  MCL_HIP(ctx, ctx->d_cell_u64.ensure(ctx->capacity));
+  double* t_wsum = ctx->d_cell_f64.ptr;
+  double* c_wsum = t_wsum + tcap;
+  double* c_state = c_wsum + ctx->capacity;
+  unsigned int* t_count = ctx->d_cell_u32.ptr;
+  unsigned int* t_cluster = t_count + tcap;
+  unsigned int* c_first = t_cluster + tcap;
+  unsigned int* c_count = c_first + ctx->capacity;
+  unsigned int* c_slot = c_count + ctx->capacity;
+  unsigned int* c_cluster = c_slot + ctx->capacity;
+  unsigned int* c_size = c_cluster + ctx->capacity;
+  unsigned long long* c_key = ctx->d_cell_u64.ptr;
+
+  MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_keys.ptr, 0xFF, slots * sizeof(unsigned long long), ctx->stream));
+  MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_first.ptr, 0xFF, slots * sizeof(unsigned int), ctx->stream));
+  MCL_HIP(ctx, hipMemsetAsync(t_wsum, 0, slots * sizeof(double), ctx->stream));
+  MCL_HIP(ctx, hipMemsetAsync(t_count, 0, slots * sizeof(unsigned int), ctx->stream));
+  MCL_HIP(ctx, hipMemsetAsync(t_cluster, 0xFF, slots * sizeof(unsigned int), ctx->stream));
+  MCL_HIP(ctx, hipMemsetAsync(c_size, 0, sizeof(unsigned int), ctx->stream));
+  const HashParams hp{cp.linear_hash_resolution, cp.linear_hash_resolution, cp.angular_hash_resolution};
+  launch_cluster_cells(ctx->stream, ctx->cur(), n, hp, ctx->d_hashes.ptr, ctx->d_table_keys.ptr, ctx->d_table_first.ptr, t_wsum,
+                       t_count, t_cluster, slots, c_key, c_first, c_count, c_slot, c_wsum, c_state, c_size);
+  MCL_HIP(ctx, hipGetLastError());
+  unsigned int m = 0;
+  MCL_HIP(ctx, hipMemcpyAsync(&m, c_size, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MCL_REQUIRE(ctx, m >= 1 && m <= m_cap, "cell compaction failed");
+  std::vector<unsigned long long> key(m);
+  std::vector<unsigned int> first(m), count(m), slot(m);
+  std::vector<double> wsum(m), state(4 * static_cast<size_t>(m));
+  MCL_HIP(ctx, hipMemcpy(key.data(), c_key, m * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  MCL_HIP(ctx, hipMemcpy(first.data(), c_first, m * sizeof(unsigned int), hipMemcpyDeviceToHost));
+  MCL_HIP(ctx, hipMemcpy(count.data(), c_count, m * sizeof(unsigned int), hipMemcpyDeviceToHost));
+  MCL_HIP(ctx, hipMemcpy(slot.data(), c_slot, m * sizeof(unsigned int), hipMemcpyDeviceToHost));
+  MCL_HIP(ctx, hipMemcpy(wsum.data(), c_wsum, m * sizeof(double), hipMemcpyDeviceToHost));
+  MCL_HIP(ctx, hipMemcpy(state.data(), c_state, 4 * static_cast<size_t>(m) * sizeof(double), hipMemcpyDeviceToHost));
+
+  // make_cluster_map :137-157 — cells enter the map in the order their first particle appears in the set.
+  struct Cell {
+    Pose2 representative_state;
+    double weight;
+    size_t num_particles;
+    std::optional<size_t> cluster_id;
+    uint32_t k;
+  };
+  std::vector<uint32_t> order(m);
+  std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
+  std::unordered_map<size_t, Cell> map;
+  map.reserve(n / 5);
+  for (const uint32_t k : order) {
+    map.try_emplace(static_cast<size_t>(key[k]),
+                    Cell{Pose2{Rot2{state[4 * k], state[4 * k + 1]}, state[4 * k + 2], state[4 * k + 3]}, wsum[k], count[k],
+                         std::nullopt, k});
+  }
+  // normalize_and_cap_weights :173-189 (+ calculate_percentile_threshold :103-109)
+  for (auto& kv : map) kv.second.weight /= static_cast<double>(kv.second.num_particles);
+  {
+    std::vector<double> values;
+    values.reserve(map.size());
+    for (auto& kv : map) values.push_back(kv.second.weight);
+    const auto nth = static_cast<std::ptrdiff_t>(static_cast<double>(values.size()) * cp.weight_cap_percentile);
+    std::nth_element(values.begin(), values.begin() + nth, values.end());
+    const double max_weight = values[static_cast<size_t>(nth)];
+    for (auto& kv : map) kv.second.weight = std::min(kv.second.weight, max_weight);
+  }
+  // assign_clusters :203-238
+  struct KeyWithPriority {
+    double priority;
+    size_t key;
+    bool operator<(const KeyWithPriority& other) const { return priority < other.priority; }
+  };
+  std::vector<KeyWithPriority> init;
+  init.reserve(map.size());
+  for (auto& kv : map) init.push_back(KeyWithPriority{kv.second.weight, kv.first});
+  std::priority_queue<KeyWithPriority> queue(init.begin(), init.end());
+  const double max_priority = queue.top().priority;
+  const double lin = cp.linear_hash_resolution, ang = cp.angular_hash_resolution;
+  const Pose2 adjacent[6] = {Pose2{rot_exp(0.0), +lin, 0.0}, Pose2{rot_exp(0.0), -lin, 0.0}, Pose2{rot_exp(0.0), 0.0, +lin},
+                             Pose2{rot_exp(0.0), 0.0, -lin}, Pose2{rot_exp(+ang), 0.0, 0.0}, Pose2{rot_exp(-ang), 0.0, 0.0}};
+  size_t next_cluster_id = 0;
+  while (!queue.empty()) {
+    const size_t hash = queue.top().key;
+    queue.pop();
+    Cell& cell = map[hash];
+    if (!cell.cluster_id.has_value()) cell.cluster_id = next_cluster_id++;
+    for (const Pose2& adj : adjacent) {
+      uint64_t neighbor_hash = host_spatial_hash(pose_mul(cell.representative_state, adj), lin, ang);
+      if (neighbor_hash == ~0ull) neighbor_hash -= 1;  // the device table's reserved key
+      auto it = map.find(static_cast<size_t>(neighbor_hash));
+      if (it == map.end() || it->second.cluster_id.has_value() || !(it->second.weight <= cell.weight)) continue;
+      it->second.cluster_id = cell.cluster_id;
+      queue.push(KeyWithPriority{max_priority + it->second.weight, static_cast<size_t>(neighbor_hash)});
+    }
+  }
+  // estimate_clusters :345-411: clusters with more than one particle, the first one of maximum total weight
+  std::vector<double> total_w(next_cluster_id, 0.0);
+  std::vector<uint64_t> total_n(next_cluster_id, 0);
+  std::vector<unsigned int> cluster_of(m);
+  for (auto& kv : map) {
+    const Cell& c = kv.second;
+    cluster_of[c.k] = static_cast<unsigned int>(c.cluster_id.value());
+  }
+  for (const uint32_t k : order) {  // particle-order accumulation is not reproducible from cell sums; cell order is fixed
+    total_w[cluster_of[k]] += wsum[k];
+    total_n[cluster_of[k]] += count[k];
+  }
+  long best = -1;
+  for (size_t c = 0; c < next_cluster_id; ++c)
+    if (total_n[c] > 1 && (best < 0 || total_w[static_cast<size_t>(best)] < total_w[c])) best = static_cast<long>(c);
+  double sums[12];
+  if (best < 0) {  // :424-427 no cluster: overall mean and covariance
+    if (const mcl_status s = do_estimate_sums(ctx, ctx->pivot, sums)) return s;
+    return mcl_estimate_from_sums(sums, out);
+  }
+  MCL_HIP(ctx, hipMemcpy(c_cluster, cluster_of.data(), m * sizeof(unsigned int), hipMemcpyHostToDevice));
+  launch_cell_set_cluster(ctx->stream, c_slot, c_cluster, m, t_cluster);
+  launch_estimate_sums_cluster(ctx->stream, ctx->cur(), n, ctx->d_hashes.ptr, ctx->d_table_keys.ptr, t_cluster, slots,
+                               static_cast<unsigned int>(best), ctx->pivot[0], ctx->pivot[1], ctx->chunk_row(0), ctx->d_scalars.ptr + 8);
+  MCL_HIP(ctx, hipGetLastError());
+  MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, ctx->d_scalars.ptr + 8, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 9; ++k) sums[k] = ctx->h_scalars[8 + k];
+  sums[9] = ctx->pivot[0];
+  sums[10] = ctx->pivot[1];
+  sums[11] = 0.0;
+  return mcl_estimate_from_sums(sums, out);
+}
+
 }  // namespace
 
 extern "C" {
@@ -649,6 +820,9 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_kld_scalars.release();
   ctx->d_sort_u32.release();
   ctx->d_route_u32.release();
+  ctx->d_cell_f64.release();
+  ctx->d_cell_u32.release();
+  ctx->d_cell_u64.release();
   ctx->d_sort_u64.release();
   ctx->d_sort_f64.release();
   if (ctx->h_points) (void)hipHostFree(ctx->h_points);
@@ -943,7 +1117,15 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   }
   ctx->force_update = false;  // :199
   mcl_estimate est{};
-  if (const mcl_status s = mcl_estimate_pose(ctx, &est)) return s;  // :200
+  if (ctx->estimate_kind == 1) {  // beluga_ros::Amcl returns cluster_based_estimate (beluga_ros/src/amcl.cpp:125)
+    if (const mcl_status s = mcl_cluster_based_estimate(ctx, &ctx->cluster_params, &est)) return s;
+    if (std::isfinite(est.pose[2]) && std::isfinite(est.pose[3])) {
+      ctx->pivot[0] = est.pose[2];
+      ctx->pivot[1] = est.pose[3];
+    }
+  } else if (const mcl_status s = mcl_estimate_pose(ctx, &est)) {  // :200
+    return s;
+  }
   if (estimate) *estimate = est;
   if (info) {
     info->updated = 1;
@@ -998,6 +1180,27 @@ mcl_status mcl_update_laser_scan(mcl_ctx* ctx, const double control_pose[4], con
   uint64_t m = 0;
   if (mcl_prepare_laser_scan(scan, pts.data(), &m) != MCL_OK) return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "bad laser scan");
   return mcl_update(ctx, control_pose, pts.data(), m, estimate, info);
+}
+
+mcl_status mcl_cluster_based_estimate(mcl_ctx* ctx, const mcl_cluster_params* params, mcl_estimate* out) {
+  if (!ctx || !out) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  stage_begin(ctx, MCL_STAGE_ESTIMATE);
+  const mcl_status s = do_cluster_estimate(ctx, params ? *params : mcl_cluster_params{0.20, 0.524, 0.90}, out);
+  stage_end(ctx, MCL_STAGE_ESTIMATE);
+  if (s == MCL_OK) {
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    stage_collect(ctx);
+  }
+  return s;
+}
+
+mcl_status mcl_set_estimate_kind(mcl_ctx* ctx, int32_t kind, const mcl_cluster_params* params) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, kind == 0 || kind == 1, "estimate kind must be 0 (estimate) or 1 (cluster_based_estimate)");
+  ctx->estimate_kind = kind;
+  if (params) ctx->cluster_params = *params;
+  return MCL_OK;
 }
 
 mcl_status mcl_get_device_view(mcl_ctx* ctx, mcl_device_view* view) {

@@ -158,6 +158,17 @@ void launch_kld_scan(hipStream_t st, const unsigned long long* d_hashes, uint64_
 // K8: estimation.hpp:436-475 sufficient statistics; d_out[9].
 void launch_estimate_sums(hipStream_t st, ParticleSoA p, uint64_t n, double pivot_x, double pivot_y, double* d_partials,
                           double* d_out);
+// cluster_based_estimate (algorithm/cluster_based_estimation.hpp): hash + per-cell aggregation + compaction of the occupied
+// cells (for the host's cluster assignment), the write-back of the cells' cluster ids and the masked estimate sums.
+void launch_cluster_cells(hipStream_t st, ParticleSoA p, uint64_t n, HashParams hp, unsigned long long* d_hashes,
+                          unsigned long long* t_keys, unsigned int* t_first, double* t_wsum, unsigned int* t_count,
+                          unsigned int* t_cluster, uint64_t capacity, unsigned long long* c_key, unsigned int* c_first,
+                          unsigned int* c_count, unsigned int* c_slot, double* c_wsum, double* c_state, unsigned int* c_size);
+void launch_cell_set_cluster(hipStream_t st, const unsigned int* d_slot, const unsigned int* d_cluster, uint32_t m,
+                             unsigned int* t_cluster);
+void launch_estimate_sums_cluster(hipStream_t st, ParticleSoA p, uint64_t n, const unsigned long long* d_hashes,
+                                  unsigned long long* t_keys, unsigned int* t_cluster, uint64_t capacity, unsigned int wanted,
+                                  double pivot_x, double pivot_y, double* d_partials, double* d_out);
 // init: multivariate_normal_distribution.hpp:96-126 with T = V sqrt(L)
 void launch_init_normal(hipStream_t st, ParticleSoA p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
                         uint64_t index_offset);

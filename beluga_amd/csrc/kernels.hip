@@ -1330,6 +1330,140 @@ __global__ __launch_bounds__(kBlock) void k_estimate_partials(ParticleSoA p, uin
   }
 }
 
+// ---- cluster_based_estimate (algorithm/cluster_based_estimation.hpp) ---------------------------------------------
+// Device side: spatial hash of every particle, per-cell aggregation (weight sum, count, first particle), compaction of
+// the occupied cells for the host, and the masked estimate of the winning cluster.  The cluster assignment itself is
+// a priority-queue flood fill over a few hundred cells and stays on the host (context.hip), with the reference's own
+// standard containers so that ties resolve the same way.
+__global__ __launch_bounds__(kBlock) void k_cluster_hash(ParticleSoA p, uint64_t n, HashParams hp, unsigned long long* __restrict__ hashes) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) hashes[i] = spatial_hash(load_pose(p, i), hp);
+}
+
+struct CellTable {
+  unsigned long long* keys;
+  unsigned int* first;
+  double* wsum;
+  unsigned int* count;
+  unsigned int* cluster;  // written by the host pass
+  uint64_t capacity;      // power of two
+};
+
+__global__ __launch_bounds__(kBlock) void k_cell_aggregate(const unsigned long long* __restrict__ hashes, const double* __restrict__ w,
+                                                           uint64_t n, CellTable t) {
+  __shared__ unsigned long long lkeys[kLocalSlots];
+  __shared__ unsigned int lfirst[kLocalSlots];
+  __shared__ unsigned int lcount[kLocalSlots];
+  __shared__ double lsum[kLocalSlots];
+  for (uint32_t s = threadIdx.x; s < kLocalSlots; s += kBlock) {
+    lkeys[s] = kEmptyKey;
+    lfirst[s] = 0xFFFFFFFFu;
+    lcount[s] = 0;
+    lsum[s] = 0.0;
+  }
+  __syncthreads();
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+#pragma unroll
+  for (int k = 0; k < kChunk / kBlock; ++k) {
+    const uint64_t i = base + k * kBlock + threadIdx.x;
+    if (i < n) {
+      const unsigned long long key = kld_key(hashes[i]);
+      uint32_t slot = static_cast<uint32_t>(kld_slot(key, kLocalSlots - 1));
+      while (true) {
+        const unsigned long long prev = atomicCAS(&lkeys[slot], kEmptyKey, key);
+        if (prev == kEmptyKey || prev == key) break;
+        slot = (slot + 1) & (kLocalSlots - 1);
+      }
+      atomicMin(&lfirst[slot], static_cast<unsigned int>(i));
+      atomicAdd(&lcount[slot], 1u);
+      atomicAdd(&lsum[slot], w[i]);
+    }
+  }
+  __syncthreads();
+  const uint64_t mask = t.capacity - 1;
+  for (uint32_t s = threadIdx.x; s < kLocalSlots; s += kBlock) {
+    const unsigned long long key = lkeys[s];
+    if (key == kEmptyKey) continue;
+    uint64_t slot = kld_slot(key, mask);
+    while (true) {
+      const unsigned long long prev = atomicCAS(&t.keys[slot], kEmptyKey, key);
+      if (prev == kEmptyKey || prev == key) break;
+      slot = (slot + 1) & mask;
+    }
+    atomicMin(&t.first[slot], lfirst[s]);
+    atomicAdd(&t.count[slot], lcount[s]);
+    atomicAdd(&t.wsum[slot], lsum[s]);
+  }
+}
+
+struct CellList {  // compacted occupied cells, arbitrary order (the host sorts by `first`)
+  unsigned long long* key;
+  unsigned int* first;
+  unsigned int* count;
+  unsigned int* slot;
+  double* wsum;
+  double4* state;  // representative state = state of particle `first` as (c, s, x, y)
+  unsigned int* size;
+};
+
+__global__ __launch_bounds__(kBlock) void k_cell_compact(CellTable t, ParticleSoA p, CellList out) {
+  const uint64_t s = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (s >= t.capacity || t.keys[s] == kEmptyKey) return;
+  const unsigned int k = atomicAdd(out.size, 1u);
+  const unsigned int f = t.first[s];
+  out.key[k] = t.keys[s];
+  out.first[k] = f;
+  out.count[k] = t.count[s];
+  out.slot[k] = static_cast<unsigned int>(s);
+  out.wsum[k] = t.wsum[s];
+  out.state[k] = double4{p.c[f], p.s[f], p.x[f], p.y[f]};
+}
+
+__global__ __launch_bounds__(kBlock) void k_cell_set_cluster(const unsigned int* __restrict__ slot, const unsigned int* __restrict__ cluster,
+                                                             uint32_t m, unsigned int* __restrict__ table_cluster) {
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k < m) table_cluster[slot[k]] = cluster[k];
+}
+
+// estimation.hpp:436-475 restricted to the particles whose cell belongs to cluster `wanted`.
+__global__ __launch_bounds__(kBlock) void k_estimate_partials_cluster(ParticleSoA p, uint64_t n, const unsigned long long* __restrict__ hashes,
+                                                                      CellTable t, unsigned int wanted, double pivot_x, double pivot_y,
+                                                                      double* __restrict__ partials, uint32_t stride) {
+  __shared__ double scratch[(kBlock / 64) * kEstK];
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
+  const uint64_t mask = t.capacity - 1;
+  double v[kEstK];
+#pragma unroll
+  for (int k = 0; k < kEstK; ++k) v[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint64_t i = base + k;
+    if (i < n) {
+      const unsigned long long key = kld_key(hashes[i]);
+      uint64_t slot = kld_slot(key, mask);
+      while (t.keys[slot] != key) slot = (slot + 1) & mask;
+      if (t.cluster[slot] == wanted) {
+        const double w = p.w[i];
+        const double dx = p.x[i] - pivot_x, dy = p.y[i] - pivot_y;
+        v[0] += w;
+        v[1] += w * w;
+        v[2] += w * p.c[i];
+        v[3] += w * p.s[i];
+        v[4] += w * dx;
+        v[5] += w * dy;
+        v[6] += w * dx * dx;
+        v[7] += w * dx * dy;
+        v[8] += w * dy * dy;
+      }
+    }
+  }
+  block_reduce<kEstK>(v, scratch);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < kEstK; ++k) partials[static_cast<size_t>(k) * stride + blockIdx.x] = v[k];
+  }
+}
+
 // ---- misc -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_init_normal(ParticleSoA p, uint64_t n, double m0, double m1, double m2, double t00,
                                                         double t01, double t02, double t10, double t11, double t12, double t20,
@@ -1574,6 +1708,33 @@ void launch_estimate_sums(hipStream_t st, ParticleSoA p, uint64_t n, double pivo
                           double* d_out) {
   const uint32_t chunks = num_chunks(n);
   if (chunks) hipLaunchKernelGGL(k_estimate_partials, dim3(chunks), dim3(kBlock), 0, st, p, n, pivot_x, pivot_y, d_partials, chunks);
+  hipLaunchKernelGGL(k_final_sum<kEstK>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out);
+}
+
+void launch_cluster_cells(hipStream_t st, ParticleSoA p, uint64_t n, HashParams hp, unsigned long long* d_hashes,
+                          unsigned long long* t_keys, unsigned int* t_first, double* t_wsum, unsigned int* t_count,
+                          unsigned int* t_cluster, uint64_t capacity, unsigned long long* c_key, unsigned int* c_first,
+                          unsigned int* c_count, unsigned int* c_slot, double* c_wsum, double* c_state, unsigned int* c_size) {
+  if (n == 0) return;
+  const CellTable t{t_keys, t_first, t_wsum, t_count, t_cluster, capacity};
+  hipLaunchKernelGGL(k_cluster_hash, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, hp, d_hashes);
+  hipLaunchKernelGGL(k_cell_aggregate, dim3(num_chunks(n)), dim3(kBlock), 0, st, d_hashes, p.w, n, t);
+  const CellList out{c_key, c_first, c_count, c_slot, c_wsum, reinterpret_cast<double4*>(c_state), c_size};
+  hipLaunchKernelGGL(k_cell_compact, dim3(blocks_for(capacity)), dim3(kBlock), 0, st, t, p, out);
+}
+void launch_cell_set_cluster(hipStream_t st, const unsigned int* d_slot, const unsigned int* d_cluster, uint32_t m,
+                             unsigned int* t_cluster) {
+  if (m == 0) return;
+  hipLaunchKernelGGL(k_cell_set_cluster, dim3(blocks_for(m)), dim3(kBlock), 0, st, d_slot, d_cluster, m, t_cluster);
+}
+void launch_estimate_sums_cluster(hipStream_t st, ParticleSoA p, uint64_t n, const unsigned long long* d_hashes,
+                                  unsigned long long* t_keys, unsigned int* t_cluster, uint64_t capacity, unsigned int wanted,
+                                  double pivot_x, double pivot_y, double* d_partials, double* d_out) {
+  const uint32_t chunks = num_chunks(n);
+  const CellTable t{t_keys, nullptr, nullptr, nullptr, t_cluster, capacity};
+  if (chunks)
+    hipLaunchKernelGGL(k_estimate_partials_cluster, dim3(chunks), dim3(kBlock), 0, st, p, n, d_hashes, t, wanted, pivot_x, pivot_y,
+                       d_partials, chunks);
   hipLaunchKernelGGL(k_final_sum<kEstK>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out);
 }
 

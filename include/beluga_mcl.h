@@ -215,6 +215,19 @@ mcl_status mcl_estimate_from_sums(const double sums[12], mcl_estimate* out);
 /* Convenience: single-shard estimate (estimation.hpp:436-475). */
 mcl_status mcl_estimate_pose(mcl_ctx* ctx, mcl_estimate* out);
 
+/* beluga::cluster_based_estimate (algorithm/cluster_based_estimation.hpp:415-433) — what beluga_ros::Amcl::update
+ * returns (beluga_ros/src/amcl.cpp:125): particles are grouped into clusters around local maxima of the cell-averaged
+ * weight; the mean and covariance of the cluster with the highest total weight are returned, or the overall estimate
+ * if no cluster has more than one particle.  ParticleClusterizerParam :243-259 defaults: 0.20 m, 0.524 rad, 0.90. */
+typedef struct mcl_cluster_params {
+  double linear_hash_resolution;
+  double angular_hash_resolution;
+  double weight_cap_percentile;
+} mcl_cluster_params;
+mcl_status mcl_cluster_based_estimate(mcl_ctx* ctx, const mcl_cluster_params* params /* NULL: defaults */, mcl_estimate* out);
+/* Selects what mcl_update returns: 0 = beluga::estimate (beluga::Amcl), 1 = cluster_based_estimate (beluga_ros::Amcl). */
+mcl_status mcl_set_estimate_kind(mcl_ctx* ctx, int32_t kind, const mcl_cluster_params* params /* NULL: defaults */);
+
 /* ---- Device access for zero-copy interop (torch / RCCL hand-off) -------------------------------- */
 typedef struct mcl_device_view {
   double* x;

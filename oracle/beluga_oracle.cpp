@@ -38,6 +38,8 @@
 #include <limits>
 #include <numeric>
 #include <queue>
+#include <optional>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -714,6 +716,120 @@ void estimate(const double* states, const double* w, size_t n, double mean_out[4
   for (int k = 0; k < 4; ++k) mean_out[k] = m[k];
 }
 
+// ----------------------------------------------------------------------------------------------
+// algorithm/cluster_based_estimation.hpp — the estimate beluga_ros::Amcl returns (beluga_ros/src/amcl.cpp:125).
+// Same standard containers as the reference (std::unordered_map with reserve(n/5), std::priority_queue built from
+// the map's iteration order, std::nth_element) so that ties resolve the way libstdc++ resolves them upstream.
+// ----------------------------------------------------------------------------------------------
+struct ClusterCell {  // :113-119
+  SE2 representative_state;
+  double weight{0.0};
+  size_t num_particles{0};
+  std::optional<size_t> cluster_id;
+};
+using ClusterMap = std::unordered_map<size_t, ClusterCell>;
+
+struct ClusterParams {  // ParticleClusterizerParam :243-259
+  double linear_hash_resolution = 0.20, angular_hash_resolution = 0.524, weight_cap_percentile = 0.90;
+};
+
+std::vector<size_t> cluster_ids(const double* states, const double* w, size_t n, const ClusterParams& p) {
+  const double res[3] = {p.linear_hash_resolution, p.linear_hash_resolution, p.angular_hash_resolution};
+  std::vector<size_t> hashes(n);
+  for (size_t i = 0; i < n; ++i) hashes[i] = spatial_hash(se2_load(states + 4 * i), res);  // :291
+  // make_cluster_map :137-157
+  ClusterMap map;
+  map.reserve(n / 5);
+  for (size_t i = 0; i < n; ++i) {
+    auto [it, inserted] = map.try_emplace(hashes[i], ClusterCell{});
+    ClusterCell& entry = it->second;
+    entry.weight += w[i];
+    entry.num_particles++;
+    if (inserted) entry.representative_state = se2_load(states + 4 * i);
+  }
+  // normalize_and_cap_weights :173-189 ; calculate_percentile_threshold :103-109
+  for (auto& kv : map) kv.second.weight /= static_cast<double>(kv.second.num_particles);
+  {
+    std::vector<double> values;
+    values.reserve(map.size());
+    for (auto& kv : map) values.push_back(kv.second.weight);
+    const auto nth = static_cast<std::ptrdiff_t>(static_cast<double>(values.size()) * p.weight_cap_percentile);
+    std::nth_element(values.begin(), values.begin() + nth, values.end());
+    const double max_weight = values[static_cast<size_t>(nth)];
+    for (auto& kv : map) kv.second.weight = std::min(kv.second.weight, max_weight);
+  }
+  // assign_clusters :203-238 ; make_priority_queue :73-92
+  struct KeyWithPriority {
+    double priority;
+    size_t key;
+    bool operator<(const KeyWithPriority& other) const { return priority < other.priority; }
+  };
+  std::vector<KeyWithPriority> init;
+  init.reserve(map.size());
+  for (auto& kv : map) init.push_back(KeyWithPriority{kv.second.weight, kv.first});
+  std::priority_queue<KeyWithPriority> queue(init.begin(), init.end());
+  const double max_priority = queue.top().priority;
+  const SE2 adjacent[6] = {  // :323-331
+      SE2{so2_exp(0.0), +p.linear_hash_resolution, 0.0}, SE2{so2_exp(0.0), -p.linear_hash_resolution, 0.0},
+      SE2{so2_exp(0.0), 0.0, +p.linear_hash_resolution}, SE2{so2_exp(0.0), 0.0, -p.linear_hash_resolution},
+      SE2{so2_exp(+p.angular_hash_resolution), 0.0, 0.0}, SE2{so2_exp(-p.angular_hash_resolution), 0.0, 0.0}};
+  size_t next_cluster_id = 0;
+  while (!queue.empty()) {
+    const size_t hash = queue.top().key;
+    queue.pop();
+    ClusterCell& cell = map[hash];
+    if (!cell.cluster_id.has_value()) cell.cluster_id = next_cluster_id++;
+    for (const SE2& adj : adjacent) {
+      const size_t neighbor_hash = spatial_hash(se2_mul(cell.representative_state, adj), res);  // neighbors() :271-275
+      auto it = map.find(neighbor_hash);
+      const bool valid = it != map.end() && !it->second.cluster_id.has_value() && it->second.weight <= cell.weight;
+      if (!valid) continue;
+      ClusterCell& neighbor = map[neighbor_hash];
+      neighbor.cluster_id = cell.cluster_id;
+      queue.push(KeyWithPriority{max_priority + neighbor.weight, neighbor_hash});
+    }
+  }
+  std::vector<size_t> out(n);
+  for (size_t i = 0; i < n; ++i) out[i] = map[hashes[i]].cluster_id.value();
+  return out;
+}
+
+// estimate_clusters :345-411 + cluster_based_estimate :415-433
+void cluster_based_estimate(const double* states, const double* w, size_t n, const ClusterParams& p, double mean_out[4], double cov_out[9]) {
+  const std::vector<size_t> clusters = cluster_ids(states, w, n, p);
+  std::vector<size_t> order(n);
+  std::iota(order.begin(), order.end(), size_t{0});
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return clusters[a] < clusters[b]; });
+  bool have_best = false;
+  double best_weight = 0.0;
+  std::vector<double> cs, cw;
+  for (size_t begin = 0; begin < n;) {
+    size_t end = begin;
+    while (end < n && clusters[order[end]] == clusters[order[begin]]) ++end;
+    if (end - begin > 1) {  // a single sample has no covariance
+      cs.clear();
+      cw.clear();
+      double total = 0.0;
+      for (size_t k = begin; k < end; ++k) {
+        const size_t i = order[k];
+        cs.insert(cs.end(), states + 4 * i, states + 4 * i + 4);
+        cw.push_back(w[i]);
+        total += w[i];
+      }
+      if (!have_best || best_weight < total) {  // ranges::max_element keeps the first maximum
+        double m[4], c[9];
+        estimate(cs.data(), cw.data(), cw.size(), m, c);
+        std::memcpy(mean_out, m, sizeof(m));
+        std::memcpy(cov_out, c, sizeof(c));
+        best_weight = total;
+        have_best = true;
+      }
+    }
+    begin = end;
+  }
+  if (!have_best) estimate(states, w, n, mean_out, cov_out);
+}
+
 struct ResampleParams {
   uint64_t min_particles, max_particles;
   double kld_epsilon, kld_z;
@@ -1122,6 +1238,16 @@ uint64_t orc_resample(
 }
 
 void orc_estimate(const double* states, const double* w, uint64_t n, double mean[4], double cov[9]) { estimate(states, w, n, mean, cov); }
+
+void orc_cluster_ids(const double* states, const double* w, uint64_t n, double linear_res, double angular_res, double percentile,
+                     uint64_t* out) {
+  const std::vector<size_t> ids = cluster_ids(states, w, n, ClusterParams{linear_res, angular_res, percentile});
+  for (uint64_t i = 0; i < n; ++i) out[i] = ids[i];
+}
+void orc_cluster_based_estimate(const double* states, const double* w, uint64_t n, double linear_res, double angular_res,
+                                double percentile, double mean[4], double cov[9]) {
+  cluster_based_estimate(states, w, n, ClusterParams{linear_res, angular_res, percentile}, mean, cov);
+}
 
 int orc_covariance_transform(const double cov[9], double T[9]) { return covariance_transform(cov, T) ? 1 : 0; }
 

@@ -317,6 +317,22 @@ def estimate(states, w):
     return mean, cov.reshape(3, 3)
 
 
+def cluster_ids(states, w, linear_res=0.2, angular_res=0.524, percentile=0.9):
+    states, w = _dbl(states).reshape(-1, 4), _dbl(w)
+    out = np.zeros(len(w), dtype=np.uint64)
+    lib().orc_cluster_ids(_d(states), _d(w), C.c_uint64(len(w)), C.c_double(linear_res), C.c_double(angular_res), C.c_double(percentile),
+                          out.ctypes.data_as(c_u64_p))
+    return out
+
+
+def cluster_based_estimate(states, w, linear_res=0.2, angular_res=0.524, percentile=0.9):
+    states, w = _dbl(states).reshape(-1, 4), _dbl(w)
+    mean, cov = np.zeros(4), np.zeros(9)
+    lib().orc_cluster_based_estimate(_d(states), _d(w), C.c_uint64(len(w)), C.c_double(linear_res), C.c_double(angular_res),
+                                     C.c_double(percentile), _d(mean), _d(cov))
+    return mean, cov.reshape(3, 3)
+
+
 def covariance_transform(cov):
     cov = _dbl(cov).reshape(9)
     T = np.zeros(9)

@@ -597,3 +597,75 @@ def test_update_cycle_end_to_end_omni_and_prob_model():
         assert gpu.last_info["num_particles"] == len(cpu.particles()[1]), f"cycle {c}"
         np.testing.assert_allclose(g[0], o[0], atol=1e-8, err_msg=f"cycle {c}")
     gpu.close()
+
+
+# ---- cluster_based_estimate ---------------------------------------------------------------------
+def _multicluster(xmin, xmax, ymin, ymax, step):  # test_cluster_based_estimation.cpp:67-94
+    xw, yw = xmax - xmin, ymax - ymin
+    xs = np.arange(step / 2.0, xw + 1e-12, step)
+    ys = np.arange(step / 2.0, yw + 1e-12, step)
+    X, Y = np.meshgrid(xs, ys, indexing="ij")
+    k = (2 * X >= xw) * 1.0 + (2 * Y >= yw) * 2.0 + 1.0
+    wt = np.abs(np.sin(2.0 * np.pi * X / xw)) * np.abs(np.sin(2.0 * np.pi * Y / yw)) * k
+    wt = np.maximum(0.0, wt - k / 2.0)
+    states = np.stack([np.ones(X.size), np.zeros(X.size), X.ravel() + xmin, Y.ravel() + ymin], axis=1)
+    return states, wt.ravel()
+
+
+def test_cluster_based_estimate_matches_oracle_and_reference_vectors():
+    grid = rooms_grid(64, 1)
+    # HeaviestClusterSelectionTest (:357-386): the estimate equals the plain estimate of the heaviest quadrant
+    states, w = _multicluster(-2.0, 2.0, -2.0, 2.0, 0.025)
+    f = new_filter(grid, len(w))
+    f.set_particles(states, w)
+    pose, cov = f.cluster_based_estimate()
+    sel = (states[:, 2] >= 0.0) & (states[:, 3] >= 0.0)
+    exp_pose, exp_cov = orc.estimate(states[sel], w[sel])
+    np.testing.assert_allclose(pose, exp_pose, atol=1e-6)
+    np.testing.assert_allclose(cov, exp_cov, atol=1e-3)
+    want_pose, want_cov = orc.cluster_based_estimate(states, w)
+    np.testing.assert_allclose(pose, want_pose, atol=1e-9)
+    np.testing.assert_allclose(cov, want_cov, rtol=1e-8, atol=1e-11)
+    f.close()
+    # NightmareDistributionTest (:388-415): isolated particles -> overall estimate
+    far = np.array([se2_from_xytheta(-10, -10, 0), se2_from_xytheta(-10, 10, 0), se2_from_xytheta(10, -10, 0), se2_from_xytheta(10, 10, 0)])
+    f = new_filter(grid, 4)
+    f.set_particles(far, np.full(4, 0.2))
+    pose, cov = f.cluster_based_estimate()
+    exp_pose, exp_cov = orc.estimate(far, np.full(4, 0.2))
+    np.testing.assert_allclose(pose, exp_pose, atol=1e-9)
+    np.testing.assert_allclose(cov, exp_cov, rtol=1e-9, atol=1e-12)
+    f.close()
+
+
+def test_cluster_based_estimate_bimodal_cloud_and_update_path():
+    """Two pose hypotheses (60 % / 40 %) with random headings and weights: the heavier mode wins; and update() returns the
+    cluster-based estimate when asked to behave like beluga_ros::Amcl."""
+    grid = rooms_grid(400, 3)
+    n = 200_000
+    a = synth.normal_particles(int(n * 0.6), (2.0, 1.0, 0.5), (0.3, 0.3, 0.15), seed=1)
+    b = synth.normal_particles(n - len(a), (-4.0, -3.0, -2.0), (0.3, 0.3, 0.15), seed=2)
+    states = np.concatenate([a, b])
+    perm = np.random.Generator(np.random.MT19937(3)).permutation(n)
+    states = states[perm]
+    w = np.random.Generator(np.random.MT19937(4)).gamma(2.0, 1.0, n)
+    f = new_filter(grid, n)
+    f.set_particles(states, w)
+    pose, cov = f.cluster_based_estimate()
+    want_pose, want_cov = orc.cluster_based_estimate(states, w)
+    np.testing.assert_allclose(pose, want_pose, atol=1e-9)
+    np.testing.assert_allclose(cov, want_cov, rtol=1e-7, atol=1e-10)
+    assert abs(pose[2] - 2.0) < 0.05 and abs(pose[3] - 1.0) < 0.05
+    plain, _ = f.estimate()
+    assert abs(plain[2] - 2.0) > 1.0  # the plain mean sits between the modes
+    # update() path
+    f.set_estimate_kind(True)
+    truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=4, clearance_cells=8)
+    f.initialize(truth, np.diag([0.04, 0.04, 0.01]))
+    pts = make_scan(grid, truth, 90, max_range=8.0)
+    est = f.update(se2_from_xytheta(0, 0, 0), pts)
+    s, ww = f.particles()
+    want_pose, want_cov = orc.cluster_based_estimate(s, ww)
+    np.testing.assert_allclose(est[0], want_pose, atol=1e-9)
+    np.testing.assert_allclose(est[1], want_cov, rtol=1e-7, atol=1e-10)
+    f.close()

@@ -511,3 +511,50 @@ def test_laser_scan_preparation():  # beluga_ros/test/test_laser_scan.cpp:30-89 
     q = (0.0, 0.0, math.sin(math.pi / 4), math.cos(math.pi / 4), 0.5, -0.25, 0.3)
     pts = orc.prepare_laser_scan([2.0], 0.0, 0.1, 0.0, 100.0, origin_se3=q)
     np.testing.assert_allclose(pts[0], [0.5, 1.75], atol=1e-12)
+
+
+# ---- cluster_based_estimate (algorithm/test_cluster_based_estimation.cpp) ---------------------
+def _multicluster(xmin, xmax, ymin, ymax, step):  # make_particle_multicluster_dataset :67-94
+    xw, yw = xmax - xmin, ymax - ymin
+    states, weights = [], []
+    x = step / 2.0
+    while x <= xw:
+        y = step / 2.0
+        while y <= yw:
+            k = (0.0 if 2 * x < xw else 1.0) + (0.0 if 2 * y < yw else 2.0) + 1.0
+            wt = abs(math.sin(2.0 * math.pi * x / xw)) * abs(math.sin(2.0 * math.pi * y / yw)) * k
+            states.append(orc.se2(x + xmin, y + ymin, 0.0))
+            weights.append(max(0.0, wt - k / 2.0))
+            y += step
+        x += step
+    return np.array(states), np.array(weights)
+
+
+def test_cluster_state_estimation_step():  # :291-315 — four clusters, means at the four peaks
+    states, w = _multicluster(0.0, 36.0, 0.0, 36.0, 1.0)
+    ids = orc.cluster_ids(states, w, 1.0, math.pi / 2.0, 0.9)
+    ests = []
+    for cid in np.unique(ids):
+        sel = ids == cid
+        if sel.sum() > 1:
+            mean, _ = orc.estimate(states[sel], w[sel])
+            ests.append((w[sel].sum(), mean[2], mean[3]))
+    assert len(ests) == 4
+    ests.sort()
+    for (_, x, y), (ex, ey) in zip(ests, [(9.0, 9.0), (27.0, 9.0), (9.0, 27.0), (27.0, 27.0)]):
+        assert x == pytest.approx(ex, abs=1e-6) and y == pytest.approx(ey, abs=1e-6)
+
+
+def test_cluster_estimation_heaviest_and_nightmare():  # :357-415
+    states, w = _multicluster(-2.0, 2.0, -2.0, 2.0, 0.025)
+    sel = (states[:, 2] >= 0.0) & (states[:, 3] >= 0.0)
+    exp_mean, exp_cov = orc.estimate(states[sel], w[sel])
+    mean, cov = orc.cluster_based_estimate(states, w)
+    np.testing.assert_allclose(mean, exp_mean, atol=1e-6)
+    np.testing.assert_allclose(cov, exp_cov, atol=0.001)
+    far = np.array([orc.se2(-10, -10, 0), orc.se2(-10, 10, 0), orc.se2(10, -10, 0), orc.se2(10, 10, 0)])
+    fw = np.full(4, 0.2)
+    exp_mean, exp_cov = orc.estimate(far, fw)
+    mean, cov = orc.cluster_based_estimate(far, fw)
+    np.testing.assert_allclose(mean, exp_mean, atol=1e-6)
+    np.testing.assert_allclose(cov, exp_cov, atol=0.001)
