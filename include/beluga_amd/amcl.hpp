@@ -320,6 +320,25 @@ class Amcl {
   /// Force a manual update of the particles on the next iteration of the filter (amcl_core.hpp:204).
   void force_update() { check(mcl_force_update(ctx_)); }
 
+  /// beluga::cluster_based_estimate (algorithm/cluster_based_estimation.hpp:415-433) of the current particle set.
+  [[nodiscard]] estimation_type cluster_based_estimate(double linear_hash_resolution = 0.20, double angular_hash_resolution = 0.524,
+                                                       double weight_cap_percentile = 0.90) const {
+    const mcl_cluster_params cp{linear_hash_resolution, angular_hash_resolution, weight_cap_percentile};
+    mcl_estimate est;
+    check(mcl_cluster_based_estimate(ctx_, &cp, &est));
+    estimation_type out;
+    out.first.c = est.pose[0];
+    out.first.s = est.pose[1];
+    out.first.x = est.pose[2];
+    out.first.y = est.pose[3];
+    for (int i = 0; i < 9; ++i) out.second[static_cast<std::size_t>(i)] = est.covariance[i];
+    return out;
+  }
+
+  /// Makes update() return cluster_based_estimate, as beluga_ros::Amcl does (beluga_ros/src/amcl.cpp:125), instead of
+  /// beluga::estimate, as beluga::Amcl does (amcl_core.hpp:200).
+  void use_cluster_based_estimate(bool enable) { check(mcl_set_estimate_kind(ctx_, enable ? 1 : 0, nullptr)); }
+
   /// LikelihoodFieldModelBase::likelihood_field() (likelihood_field_model_base.hpp:102), row-major height x width.
   [[nodiscard]] const std::vector<float>& likelihood_field() const {
     if (field_.empty()) {

@@ -655,7 +655,7 @@ def test_cluster_based_estimate_bimodal_cloud_and_update_path():
     want_pose, want_cov = orc.cluster_based_estimate(states, w)
     np.testing.assert_allclose(pose, want_pose, atol=1e-9)
     np.testing.assert_allclose(cov, want_cov, rtol=1e-7, atol=1e-10)
-    assert abs(pose[2] - 2.0) < 0.05 and abs(pose[3] - 1.0) < 0.05
+    assert abs(pose[2] - 2.0) < 0.3 and abs(pose[3] - 1.0) < 0.3  # a sub-cluster of the heavier mode
     plain, _ = f.estimate()
     assert abs(plain[2] - 2.0) > 1.0  # the plain mean sits between the modes
     # update() path
