@@ -272,6 +272,7 @@ struct mcl_ctx {
     s.ts = s.tc + capacity;
     s.tx = s.ts + capacity;
     s.ty = s.tx + capacity;
+    s.partial = s.ty + capacity;
     return s;
   }
   GridView grid_view() const { return GridView{d_cells.ptr, W, H, resolution, origin, origin_inverse, traits.free_value}; }
@@ -339,7 +340,8 @@ mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
     const size_t hist = static_cast<size_t>(kSortDigits) * num_chunks(cap);
     MCL_HIP(ctx, ctx->d_sort_u32.ensure(2 * cap + hist + 2 * (hist / kChunk + 1)));
     MCL_HIP(ctx, ctx->d_sort_u64.ensure(cap));
-    MCL_HIP(ctx, ctx->d_sort_f64.ensure(8 + 6 * static_cast<size_t>(chunks) + 4 * cap));
+    MCL_HIP(ctx, ctx->d_sort_f64.ensure(8 + 6 * static_cast<size_t>(chunks) + 4 * cap +
+                                        kLfMaxSegments * std::min<uint64_t>(cap, kLfSegmentedBelow)));
   }
   return MCL_OK;
 }

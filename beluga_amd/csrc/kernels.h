@@ -93,7 +93,10 @@ struct SortScratch {
   double* ts;
   double* tx;
   double* ty;
+  double* partial;               // [kLfMaxSegments][min(n, 262144)] scan-segment sums (medium particle counts); may be null
 };
+constexpr uint32_t kLfMaxSegments = 16;
+constexpr uint64_t kLfSegmentedBelow = 262144;  // particles
 
 // K1  actions/propagate.hpp:57-79 + differential_drive_model.hpp:156-163
 void launch_propagate(hipStream_t st, ParticleSoA p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,

@@ -9,6 +9,7 @@
 // beam end-points across a cell boundary of `floor(x / resolution)` (regular_grid.hpp:75-78).
 #include "kernels.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
@@ -210,37 +211,58 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_lane(ParticleSoA p, uint
 // instead of 64 and the working set of a CU stays in its 32 KB L1 (profiles/r01: variants A/B are bound by
 // the L1/L2 request rate, not by HBM).  The order in which particles are visited does not change any
 // result: each lane still accumulates `1 + sum pz^3` over the scan in the reference's order.
+// `partial` == nullptr: the whole scan per lane, weights updated in place (the sum is the reference's sequential sum).
+// `partial` != nullptr (medium particle counts, where one lane per particle cannot fill 256 CUs): blockIdx.y selects a
+// contiguous segment of the scan; the segment's sum goes to partial[segment][t] and k_lf_combine adds the segments up in
+// order — same terms, fixed association, bit-reproducible, differs from the sequential sum only in rounding.
 template <bool kCube>
 __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restrict__ w, uint64_t n, FieldView f,
                                                                const double* __restrict__ pts, uint32_t B,
                                                                const uint32_t* __restrict__ perm, const double* __restrict__ tc,
                                                                const double* __restrict__ ts, const double* __restrict__ tx,
-                                                               const double* __restrict__ ty) {
+                                                               const double* __restrict__ ty, double* __restrict__ partial,
+                                                               uint32_t beams_per_segment) {
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const uint64_t tt = t < n ? t : n - 1;
   const double ct = tc[tt], st = ts[tt], xt = tx[tt], yt = ty[tt];
-  double acc = f.prob ? 0.0 : 1.0;
+  const uint32_t b_begin = partial ? blockIdx.y * beams_per_segment : 0u;
+  const uint32_t b_end = partial ? (b_begin + beams_per_segment < B ? b_begin + beams_per_segment : B) : B;
+  double acc = (f.prob || partial) ? 0.0 : 1.0;
   if (kCube) {
     const uint32_t cells = f.W * f.H;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(f.cube), 0, static_cast<int>((cells + 1) * 8u), 0x00020000);
     const uint32_t row_bytes = f.W * 8u, unknown_offset = cells * 8u;
 #pragma unroll LF_UNROLL
-    for (uint32_t b = 0; b < B; ++b) {
+    for (uint32_t b = b_begin; b < b_end; ++b) {
       const double px = pts[2 * b], py = pts[2 * b + 1];
       acc += lf_beam_cube(rsrc, f, row_bytes, unknown_offset, px, py, ct, st, xt, yt);
     }
   } else {
 #pragma unroll 8
-    for (uint32_t b = 0; b < B; ++b) {
+    for (uint32_t b = b_begin; b < b_end; ++b) {
       const double px = pts[2 * b], py = pts[2 * b + 1];
       acc += lf_beam<false>(f, px, py, ct, st, xt, yt);
     }
   }
   if (t < n) {
-    const uint32_t i = perm[t];
-    w[i] = w[i] * (f.prob ? exp(acc) : acc);
+    if (partial) {
+      partial[static_cast<size_t>(blockIdx.y) * n + t] = acc;
+    } else {
+      const uint32_t i = perm[t];
+      w[i] = w[i] * (f.prob ? exp(acc) : acc);
+    }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_lf_combine(double* __restrict__ w, uint64_t n, const uint32_t* __restrict__ perm,
+                                                       const double* __restrict__ partial, uint32_t segments, int prob) {
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= n) return;
+  double acc = prob ? 0.0 : 1.0;
+  for (uint32_t s = 0; s < segments; ++s) acc += partial[static_cast<size_t>(s) * n + t];
+  const uint32_t i = perm[t];
+  w[i] = w[i] * (prob ? exp(acc) : acc);
 }
 
 // -- spatial ordering of the particles --------------------------------------------------------------
@@ -1552,15 +1574,27 @@ void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, 
   if (n == 0) return;
   const bool idx32 = static_cast<uint64_t>(f.W) * f.H < (1ull << 31);
   if (variant == kLfSortedLanes && sort && n < (1ull << 32)) {
-    const dim3 grid(blocks_for(n));
     const uint64_t cells = static_cast<uint64_t>(f.W) * f.H;
     const bool cube_ok = f.cube != nullptr && f.W < (1u << 21) && (cells + 1) * 8 < (1ull << 31);
+    // One lane per particle fills the chip from ~260K particles (4096 waves).  Below that, split the scan into segments
+    // (second grid dimension) as long as a segment keeps >= 64 beams, and add the segment sums in a second pass.
+    uint32_t segments = 1;
+    const uint64_t waves = (n + kWave - 1) / kWave;
+    if (sort->partial && waves < 4096) {
+      segments = static_cast<uint32_t>(std::min<uint64_t>((4096 + waves - 1) / waves, kLfMaxSegments));
+      segments = std::max(1u, std::min(segments, B / 64));
+    }
+    const uint32_t per_segment = (B + segments - 1) / segments;
+    double* partial = segments > 1 ? sort->partial : nullptr;
+    const dim3 grid(blocks_for(n), segments);
     if (cube_ok)
       hipLaunchKernelGGL(k_reweight_lf_sorted<true>, grid, dim3(kBlock), 0, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
-                         sort->ts, sort->tx, sort->ty);
+                         sort->ts, sort->tx, sort->ty, partial, per_segment);
     else
       hipLaunchKernelGGL(k_reweight_lf_sorted<false>, grid, dim3(kBlock), 0, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
-                         sort->ts, sort->tx, sort->ty);
+                         sort->ts, sort->tx, sort->ty, partial, per_segment);
+    if (segments > 1)
+      hipLaunchKernelGGL(k_lf_combine, dim3(blocks_for(n)), dim3(kBlock), 0, st, p.w, n, sort->perm, partial, segments, f.prob);
   } else if (variant == kLfLanePerParticle || variant == kLfSortedLanes) {
     const dim3 grid(blocks_for(n));
     if (idx32) hipLaunchKernelGGL(k_reweight_lf_lane<true>, grid, dim3(kBlock), 0, st, p, n, f, d_points, B);
