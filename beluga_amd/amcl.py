@@ -338,6 +338,21 @@ class Amcl:
     def commit_routed(self, step, first_slot, count, d_replies, d_order, d_targets):
         self._check(self._lib.mcl_commit_routed(self._ctx, step, first_slot, count, d_replies, d_order, d_targets))
 
+    def finish_candidates(self, step, first_slot, count, d_replies, d_order, d_targets, d_states, d_hashes):
+        self._check(self._lib.mcl_finish_candidates(self._ctx, step, first_slot, count, d_replies, d_order, d_targets, d_states, d_hashes))
+
+    def kld_begin(self):
+        self._check(self._lib.mcl_kld_begin(self._ctx))
+
+    def kld_feed(self, d_hashes: int, count: int):
+        """-> global index of the first candidate failing kld_condition, or None if the whole block passes."""
+        fail = C.c_uint64(0)
+        self._check(self._lib.mcl_kld_feed(self._ctx, d_hashes, count, C.byref(fail)))
+        return None if fail.value == 0xFFFFFFFFFFFFFFFF else int(fail.value)
+
+    def load_shard(self, d_states: int, n: int, shard_offset: int):
+        self._check(self._lib.mcl_load_shard(self._ctx, d_states, n, shard_offset))
+
     def weight_sum_device(self, d_sum: int):
         self._check(self._lib.mcl_weight_sum_device(self._ctx, d_sum))
 

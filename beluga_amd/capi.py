@@ -141,6 +141,10 @@ _SIGNATURES = {
     "mcl_route_targets": (C.c_int32, [_ctx, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcl_serve_requests": (C.c_int32, [_ctx, C.c_void_p, C.c_uint64, C.c_void_p]),
     "mcl_commit_routed": (C.c_int32, [_ctx, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcl_finish_candidates": (C.c_int32, [_ctx, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcl_kld_begin": (C.c_int32, [_ctx]),
+    "mcl_kld_feed": (C.c_int32, [_ctx, C.c_void_p, C.c_uint64, c_u64_p]),
+    "mcl_load_shard": (C.c_int32, [_ctx, C.c_void_p, C.c_uint64, C.c_uint64]),
     "mcl_weight_sum_device": (C.c_int32, [_ctx, C.c_void_p]),
     "mcl_normalize_device": (C.c_int32, [_ctx, C.c_void_p, C.c_void_p]),
     "mcl_build_cdf_device": (C.c_int32, [_ctx, C.c_void_p]),

@@ -214,7 +214,12 @@ struct mcl_ctx {
   DeviceBuffer<unsigned long long> d_table_keys;
   DeviceBuffer<unsigned int> d_table_first;
   uint64_t table_capacity{0};
-  DeviceBuffer<uint32_t> d_flags, d_uchunk;  // flags[cap]; uchunk[2][stride]
+  DeviceBuffer<uint32_t> d_flags, d_uchunk;  // flags[kld_capacity]; uchunk[2][kld_chunks]
+  uint64_t kld_capacity{0};                  // candidates one KLD pass can hold (a shard sees the GLOBAL candidate stream)
+  uint32_t kld_chunks{0};
+  // state of the running KLD pass (do_resample, or mcl_kld_begin / mcl_kld_feed for the sharded driver)
+  uint64_t kld_pos{0}, kld_table_slots{0};
+  int kld_flip{0};
   DeviceBuffer<unsigned long long> d_kld_scalars;  // [0]=first_fail, [1]=beam steps; as u32 view: k words at [4..]
   unsigned long long* h_kld_scalars{nullptr};      // pinned, 8 words
 
@@ -347,15 +352,67 @@ mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
 }
 
 mcl_status ensure_kld(mcl_ctx* ctx) {
-  const uint64_t cap = ctx->capacity;
+  // A shard context (shard_capacity set) checks the KLD bound over the global candidate stream, not only its slice.
+  const uint64_t cap = std::max<uint64_t>(ctx->capacity, ctx->cfg.shard_capacity ? ctx->cfg.amcl.max_particles : 0);
   MCL_HIP(ctx, ctx->d_hashes.ensure(cap));
   MCL_HIP(ctx, ctx->d_flags.ensure(cap));
-  MCL_HIP(ctx, ctx->d_uchunk.ensure(static_cast<size_t>(2) * ctx->chunk_stride));
+  ctx->kld_chunks = num_chunks(cap) + 1;
+  MCL_HIP(ctx, ctx->d_uchunk.ensure(static_cast<size_t>(2) * ctx->kld_chunks));
   uint64_t tc = 1024;
   while (tc < 2 * cap) tc <<= 1;
   MCL_HIP(ctx, ctx->d_table_keys.ensure(tc));
   MCL_HIP(ctx, ctx->d_table_first.ensure(tc));
   ctx->table_capacity = tc;
+  ctx->kld_capacity = cap;
+  return MCL_OK;
+}
+
+// take_while_kld (views/take_while_kld.hpp:72-88,112-137) as a running pass over the candidate stream: kld_begin, then
+// kld_process(cnt) for every block of candidates whose hashes were appended to d_hashes[kld_pos ...).
+mcl_status kld_begin(mcl_ctx* ctx) {
+  if (ctx->table_capacity == 0) {
+    if (const mcl_status s = ensure_kld(ctx)) return s;
+  }
+  MCL_HIP(ctx, hipMemsetAsync(ctx->d_kld_scalars.ptr, 0xFF, sizeof(unsigned long long), ctx->stream));  // first_fail = ~0
+  uint32_t* kwords = reinterpret_cast<uint32_t*>(ctx->d_kld_scalars.ptr + 4);                          // [0]=k_base,[1]=k_total
+  MCL_HIP(ctx, hipMemsetAsync(kwords, 0, 2 * sizeof(uint32_t), ctx->stream));
+  ctx->kld_pos = 0;
+  ctx->kld_table_slots = 0;
+  ctx->kld_flip = 0;
+  return MCL_OK;
+}
+
+// The open-addressing table is sized for the candidates seen so far (load <= 1/2), not for max_particles: a tight
+// cloud stops after ~min_particles candidates and must not pay for clearing a table of 2 * max_particles slots.
+// When the next block outgrows it, it is cleared at the larger size and the earlier hashes are re-inserted.
+mcl_status kld_grow_table(mcl_ctx* ctx, uint64_t candidates) {
+  uint64_t want = 1024;
+  while (want < 2 * candidates) want <<= 1;
+  want = std::min<uint64_t>(want, ctx->table_capacity);
+  if (want <= ctx->kld_table_slots) return MCL_OK;
+  ctx->kld_table_slots = want;
+  MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_keys.ptr, 0xFF, want * sizeof(unsigned long long), ctx->stream));
+  MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_first.ptr, 0xFF, want * sizeof(unsigned int), ctx->stream));
+  launch_kld_insert(ctx->stream, ctx->d_hashes.ptr, 0, ctx->kld_pos, KldTable{ctx->d_table_keys.ptr, ctx->d_table_first.ptr, want});
+  return MCL_OK;
+}
+
+// -> *first_fail = index of the first candidate failing the predicate (it is dropped), ~0 if all cnt candidates pass.
+mcl_status kld_process(mcl_ctx* ctx, uint64_t cnt, uint64_t* first_fail) {
+  const mcl_amcl_params& a = ctx->cfg.amcl;
+  const KldTable table{ctx->d_table_keys.ptr, ctx->d_table_first.ptr, ctx->kld_table_slots};
+  uint32_t* kwords = reinterpret_cast<uint32_t*>(ctx->d_kld_scalars.ptr + 4);
+  launch_kld_insert(ctx->stream, ctx->d_hashes.ptr, ctx->kld_pos, cnt, table);
+  launch_kld_scan(ctx->stream, ctx->d_hashes.ptr, ctx->kld_pos, cnt, table, ctx->d_flags.ptr, ctx->d_uchunk.ptr,
+                  ctx->d_uchunk.ptr + ctx->kld_chunks, kwords + ctx->kld_flip, kwords + (ctx->kld_flip ^ 1), a.min_particles,
+                  a.kld_epsilon, a.kld_z, ctx->d_kld_scalars.ptr);
+  MCL_HIP(ctx, hipGetLastError());
+  MCL_HIP(ctx, hipMemcpyAsync(ctx->h_kld_scalars, ctx->d_kld_scalars.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *first_fail = ctx->h_kld_scalars[0];
+  ctx->kld_pos += cnt;
+  ctx->kld_flip ^= 1;
   return MCL_OK;
 }
 
@@ -479,54 +536,24 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
     launch_resample_draw(ctx->stream, ctx->cur(), ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp, nullptr);
     MCL_HIP(ctx, hipGetLastError());
   } else {
-    if (ctx->table_capacity == 0) {
-      if (const mcl_status s = ensure_kld(ctx)) return s;
-    }
     MCL_REQUIRE(ctx, max_p < 0xFFFFFFFFull, "max_particles too large for KLD resampling");
-    MCL_HIP(ctx, hipMemsetAsync(ctx->d_kld_scalars.ptr, 0xFF, sizeof(unsigned long long), ctx->stream));  // first_fail = ~0
-    uint32_t* kwords = reinterpret_cast<uint32_t*>(ctx->d_kld_scalars.ptr + 4);                          // [0]=k_base,[1]=k_total
-    MCL_HIP(ctx, hipMemsetAsync(kwords, 0, 2 * sizeof(uint32_t), ctx->stream));
-    // The open-addressing table is sized for the candidates seen so far (load <= 1/2), not for max_particles: a tight
-    // cloud stops after ~min_particles candidates and must not pay for clearing a table of 2 * max_particles slots.
-    // When the next chunk outgrows it, it is cleared at the larger size and the earlier hashes are re-inserted.
-    uint64_t table_slots = 0;
-    auto grow_table = [&](uint64_t candidates, uint64_t already) -> mcl_status {
-      uint64_t want = 1024;
-      while (want < 2 * candidates) want <<= 1;
-      want = std::min<uint64_t>(want, ctx->table_capacity);
-      if (want <= table_slots) return MCL_OK;
-      table_slots = want;
-      MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_keys.ptr, 0xFF, table_slots * sizeof(unsigned long long), ctx->stream));
-      MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_first.ptr, 0xFF, table_slots * sizeof(unsigned int), ctx->stream));
-      launch_kld_insert(ctx->stream, ctx->d_hashes.ptr, 0, already, KldTable{ctx->d_table_keys.ptr, ctx->d_table_first.ptr, table_slots});
-      return MCL_OK;
-    };
-    uint64_t pos = 0;
+    if (const mcl_status s = kld_begin(ctx)) return s;
     uint64_t chunk = std::max<uint64_t>(a.min_particles + 1, 1ull << 16);
-    int flip = 0;
-    while (pos < max_p) {
+    while (ctx->kld_pos < max_p) {
+      const uint64_t pos = ctx->kld_pos;
       const uint64_t cnt = std::min(chunk, max_p - pos);
-      if (const mcl_status s = grow_table(pos + cnt, pos)) return s;
-      const KldTable table{ctx->d_table_keys.ptr, ctx->d_table_first.ptr, table_slots};
+      if (const mcl_status s = kld_grow_table(ctx, pos + cnt)) return s;
       ra.first_candidate = pos;
       ra.count = cnt;
       ra.out_offset = pos;
       launch_resample_draw(ctx->stream, ctx->cur(), ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp,
                            ctx->d_hashes.ptr);
-      launch_kld_insert(ctx->stream, ctx->d_hashes.ptr, pos, cnt, table);
-      launch_kld_scan(ctx->stream, ctx->d_hashes.ptr, pos, cnt, table, ctx->d_flags.ptr, ctx->d_uchunk.ptr,
-                      ctx->d_uchunk.ptr + ctx->chunk_stride, kwords + flip, kwords + (flip ^ 1), a.min_particles, a.kld_epsilon,
-                      a.kld_z, ctx->d_kld_scalars.ptr);
-      MCL_HIP(ctx, hipGetLastError());
-      MCL_HIP(ctx, hipMemcpyAsync(ctx->h_kld_scalars, ctx->d_kld_scalars.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                                  ctx->stream));
-      MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (ctx->h_kld_scalars[0] != ~0ull) {
-        result = ctx->h_kld_scalars[0];  // the first element failing the predicate is dropped (take_while)
+      uint64_t first_fail = ~0ull;
+      if (const mcl_status s = kld_process(ctx, cnt, &first_fail)) return s;
+      if (first_fail != ~0ull) {
+        result = first_fail;  // the first element failing the predicate is dropped (take_while)
         break;
       }
-      pos += cnt;
-      flip ^= 1;
       chunk *= 2;
     }
     result = std::min(result, max_p);  // | take(max)
@@ -1322,6 +1349,56 @@ mcl_status mcl_commit_routed(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, u
   MCL_HIP(ctx, hipGetLastError());
   ctx->live ^= 1;
   ctx->n = count;
+  return MCL_OK;
+}
+
+mcl_status mcl_finish_candidates(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,
+                                 const uint32_t* d_order, const double* d_targets, double* d_states, uint64_t* d_hashes) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, count == 0 || (d_replies && d_order && d_targets && d_states && d_hashes), "null argument");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  const mcl_amcl_params& a = ctx->cfg.amcl;
+  stage_begin(ctx, MCL_STAGE_RESAMPLE);
+  launch_finish_candidates(ctx->stream, ctx->cfg.seed, step, first_slot, count, d_replies, d_order, d_targets, ctx->grid_view(),
+                           FreeCells{ctx->d_free.ptr, ctx->have_map ? ctx->n_free : 0},
+                           HashParams{a.spatial_resolution_x, a.spatial_resolution_y, a.spatial_resolution_theta}, d_states,
+                           reinterpret_cast<unsigned long long*>(d_hashes));
+  stage_end(ctx, MCL_STAGE_RESAMPLE);
+  MCL_HIP(ctx, hipGetLastError());
+  return MCL_OK;
+}
+
+mcl_status mcl_kld_begin(mcl_ctx* ctx) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  MCL_REQUIRE(ctx, ctx->cfg.amcl.max_particles < 0xFFFFFFFFull, "max_particles too large for KLD resampling");
+  return kld_begin(ctx);
+}
+
+mcl_status mcl_kld_feed(mcl_ctx* ctx, const uint64_t* d_hashes, uint64_t count, uint64_t* first_fail) {
+  if (!ctx || !first_fail) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  MCL_REQUIRE(ctx, ctx->kld_capacity > 0, "mcl_kld_feed before mcl_kld_begin");
+  MCL_REQUIRE(ctx, count == 0 || d_hashes, "null hashes");
+  MCL_REQUIRE(ctx, ctx->kld_pos + count <= ctx->kld_capacity, "more candidates than max_particles");
+  *first_fail = ~0ull;
+  if (count == 0) return MCL_OK;
+  MCL_HIP(ctx, hipMemcpyAsync(ctx->d_hashes.ptr + ctx->kld_pos, d_hashes, count * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                              ctx->stream));
+  if (const mcl_status s = kld_grow_table(ctx, ctx->kld_pos + count)) return s;
+  return kld_process(ctx, count, first_fail);
+}
+
+mcl_status mcl_load_shard(mcl_ctx* ctx, const double* d_states, uint64_t n, uint64_t shard_offset) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, n <= ctx->capacity, "n exceeds shard capacity");
+  MCL_REQUIRE(ctx, n == 0 || d_states, "null states");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  launch_aos_to_soa(ctx->stream, d_states, ctx->cur(), n);
+  launch_fill(ctx->stream, ctx->cur().w, n, 1.0);  // particle_traits.hpp:105
+  MCL_HIP(ctx, hipGetLastError());
+  ctx->n = n;
+  ctx->cfg.shard_offset = shard_offset;
   return MCL_OK;
 }
 

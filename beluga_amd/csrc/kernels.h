@@ -147,6 +147,9 @@ void launch_gather_by_cdf_aos(hipStream_t st, ParticleSoA src, const double* cdf
 void launch_commit_routed(hipStream_t st, ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
                           const double* d_replies, const uint32_t* d_order, const double* d_targets, GridView g, FreeCells fc);
 // K7: exact parallel take_while_kld (take_while_kld.hpp:72-88).
+void launch_finish_candidates(hipStream_t st, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,
+                              const uint32_t* d_order, const double* d_targets, GridView g, FreeCells fc, HashParams hp,
+                              double* d_states, unsigned long long* d_hashes);
 struct KldTable {
   unsigned long long* keys;  // 0 = empty (hash 0 is remapped)
   unsigned int* first;       // smallest candidate index that produced the key

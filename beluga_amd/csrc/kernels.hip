@@ -1193,6 +1193,27 @@ __global__ __launch_bounds__(kBlock) void k_commit_routed(ParticleSoA dst, uint6
   dst.w[t] = 1.0;
 }
 
+// KLD form of the routed exchange: the candidates of slots [first_slot, first_slot + count) are only *staged* (the cut
+// of take_while_kld is not known yet): states go to a caller buffer in API order (cos, sin, x, y) with their spatial hashes.
+__global__ __launch_bounds__(kBlock) void k_finish_candidates(uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
+                                                              const double4* __restrict__ replies, const uint32_t* __restrict__ order,
+                                                              const double* __restrict__ targets, GridView g, FreeCells fc,
+                                                              HashParams hp, double4* __restrict__ states,
+                                                              unsigned long long* __restrict__ hashes) {
+  const uint64_t k = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k >= count) return;
+  const uint32_t t = order[k];
+  Pose2 v;
+  if (targets[t] != targets[t]) {
+    v = random_free_state(seed, step, first_slot + t, g, fc);
+  } else {
+    const double4 r = replies[k];
+    v = Pose2{Rot2{r.z, r.w}, r.x, r.y};
+  }
+  states[t] = double4{v.r.c, v.r.s, v.x, v.y};
+  hashes[t] = spatial_hash(v, hp);
+}
+
 // ---- K7 KLD ---------------------------------------------------------------------------------------------
 constexpr unsigned long long kEmptyKey = ~0ull;
 __device__ __forceinline__ unsigned long long kld_key(unsigned long long h) { return h == kEmptyKey ? h - 1 : h; }
@@ -1719,6 +1740,15 @@ void launch_commit_routed(hipStream_t st, ParticleSoA dst, uint64_t seed, uint32
   if (count == 0) return;
   hipLaunchKernelGGL(k_commit_routed, dim3(blocks_for(count)), dim3(kBlock), 0, st, dst, seed, step, first_slot, count,
                      reinterpret_cast<const double4*>(d_replies), d_order, d_targets, g, fc);
+}
+
+void launch_finish_candidates(hipStream_t st, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,
+                              const uint32_t* d_order, const double* d_targets, GridView g, FreeCells fc, HashParams hp,
+                              double* d_states, unsigned long long* d_hashes) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_finish_candidates, dim3(blocks_for(count)), dim3(kBlock), 0, st, seed, step, first_slot, count,
+                     reinterpret_cast<const double4*>(d_replies), d_order, d_targets, g, fc, hp, reinterpret_cast<double4*>(d_states),
+                     d_hashes);
 }
 
 void launch_kld_insert(hipStream_t st, const unsigned long long* d_hashes, uint64_t first, uint64_t count, KldTable t) {

@@ -7,7 +7,11 @@ propagate / reweight are independent per particle; the couplings are
   C3  the ancestor exchange of multinomial resampling: every output slot j (global index space) draws
       u_j from the SAME Philox stream as the single-GPU path, finds the shard that owns that point of the global
       CDF, and fetches the ancestor's state from it (all-to-all of 8-byte targets out, 32-byte states back),
-  C4  all-reduce of the nine estimate sums (algorithm/estimation.hpp:436-475).
+  C4  all-reduce of the nine estimate sums (algorithm/estimation.hpp:436-475),
+  C5  (KLD-adaptive mode, min_particles < max_particles) the candidate stream of take_while_kld is drawn block by block,
+      each rank drawing a slice of the block through C3; the 8-byte spatial hashes of the block are all-gathered so that
+      every rank evaluates kld_condition over the same global sequence and finds the same cut; the kept candidates are
+      then re-balanced into contiguous shards of the new (smaller) set with one all-to-all per block.
 Because every random number is addressed by global index, the sharded filter reproduces the single-GPU
 particle set for any number of ranks (up to the rounding of the summation order).
 
@@ -123,6 +127,23 @@ class HipShardEngine:
     def commit_routed(self, step, first_slot, count, replies, order, targets):
         self.f.commit_routed(step, first_slot, count, replies.data_ptr(), order.data_ptr(), targets.data_ptr())
 
+    def finish_candidates(self, step, first_slot, count, replies, order, targets):
+        """-> (states (count, 4) as (cos, sin, x, y) in slot order, spatial hashes (count,) as int64 bit patterns)"""
+        states = self.empty(count, 4)
+        hashes = self.torch.empty(count, dtype=self.torch.int64, device=self.device)
+        self.f.finish_candidates(step, first_slot, count, replies.data_ptr(), order.data_ptr(), targets.data_ptr(), states.data_ptr(),
+                                 hashes.data_ptr())
+        return states, hashes
+
+    def kld_begin(self):
+        self.f.kld_begin()
+
+    def kld_feed(self, hashes):
+        return self.f.kld_feed(hashes.data_ptr(), hashes.numel())
+
+    def load_shard(self, states, shard_offset):
+        self.f.load_shard(states.data_ptr(), states.shape[0], shard_offset)
+
     def sync(self):
         self.f.sync()
 
@@ -143,9 +164,39 @@ def shard_bounds(n_total: int, world: int, rank: int):
     return first, base + (1 if rank < rem else 0)
 
 
+class _Transport:
+    """The collectives of the path.  RCCL takes device tensors directly; a gloo group (CPU ranks in the tests, or
+    several ranks sharing one GPU) gets device tensors staged through host memory — same orchestration, slower wire."""
+
+    def __init__(self, dist, group):
+        self.dist, self.group = dist, group
+        self.stage = dist.get_backend(group) == "gloo"
+
+    def _host(self, t):
+        return t.cpu() if (self.stage and t.is_cuda) else t
+
+    def all_reduce_sum(self, t):
+        h = self._host(t)
+        self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+        if h is not t:
+            t.copy_(h)
+
+    def all_gather(self, out, t):
+        ho, ht = self._host(out), self._host(t)
+        self.dist.all_gather_into_tensor(ho, ht.contiguous(), group=self.group)
+        if ho is not out:
+            out.copy_(ho)
+
+    def all_to_all(self, out, t, out_splits, in_splits):
+        ho, ht = self._host(out), self._host(t)
+        self.dist.all_to_all_single(ho, ht.contiguous(), out_splits, in_splits, group=self.group)
+        if ho is not out:
+            out.copy_(ho)
+
+
 class ShardedAmcl:
     def __init__(self, grid, motion, sensor, params: AmclParams = AmclParams(), *, seed: int = 0, device: Optional[int] = None,
-                 group=None, engine_factory=None):
+                 group=None, engine_factory=None, kld_block: Optional[int] = None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -154,9 +205,12 @@ class ShardedAmcl:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        if params.min_particles < params.max_particles:
-            raise NotImplementedError("sharded KLD-adaptive resampling is not implemented yet; use min_particles == max_particles")
         self.params = params
+        self.adaptive = params.min_particles < params.max_particles
+        if self.adaptive and params.min_particles < self.world:
+            raise ValueError("min_particles must be at least the number of ranks")
+        self.net = _Transport(dist, group)
+        self.kld_block = kld_block  # candidates drawn per round of C5 (doubles every round); None = max(min + 1, 8192 * world)
         self.n_total = params.max_particles
         self.first_slot, self.n_local = shard_bounds(self.n_total, self.world, self.rank)
         if engine_factory is None:
@@ -180,6 +234,10 @@ class ShardedAmcl:
     # -- reference surface -----------------------------------------------------------------------------
     def initialize(self, pose_xytheta, covariance):
         """Amcl::initialize(pose, covariance): every rank draws its slice of the same global sample stream."""
+        self.n_total = self.params.max_particles
+        self.first_slot, self.n_local = shard_bounds(self.n_total, self.world, self.rank)
+        if self.adaptive:  # a KLD cut may have moved this shard: back to its slice of max_particles
+            self.engine.load_shard(self.engine.empty(0, 4), self.first_slot)
         self.engine.initialize(pose_xytheta, covariance)
         self._pivot = np.array([float(pose_xytheta[0]), float(pose_xytheta[1])])
         self._force = True
@@ -256,12 +314,12 @@ class ShardedAmcl:
         buf = e.empty(4)                     # [global weight sum | shard cdf total, shard sum w, shard sum w^2]
         buf.zero_()
         e.weight_sum_into(buf[0:1])
-        dist.all_reduce(buf[0:1], op=dist.ReduceOp.SUM, group=self.group)          # C1
+        self.net.all_reduce_sum(buf[0:1])                                           # C1
         e.normalize_from(buf[0:1], buf[2:4])                                        # :177 with the GLOBAL sum
         if fires:
             e.build_cdf_into(buf[1:2])
         gathered = e.empty(self.world * 3)
-        dist.all_gather_into_tensor(gathered, buf[1:4].contiguous(), group=self.group)  # C2
+        self.net.all_gather(gathered, buf[1:4])                                     # C2
         host = torch.cat([buf[0:1], gathered]).cpu().numpy()
         weight_sum = float(host[0])
         stats = host[1:].reshape(self.world, 3)
@@ -282,12 +340,15 @@ class ShardedAmcl:
             if p_random > 0.0:  # :184-186
                 self._slow.reset()
                 self._fast.reset()
-            self._resample(totals, p_random)
+            if self.adaptive:
+                self._resample_kld(totals, p_random)
+            else:
+                self._resample(totals, p_random)
         self._force = False  # :199
 
         t_sums = e.empty(9)                                                 # :200
         e.estimate_sums_into(self._pivot, t_sums)
-        dist.all_reduce(t_sums, op=dist.ReduceOp.SUM, group=self.group)     # C4
+        self.net.all_reduce_sum(t_sums)                                     # C4
         sums = np.concatenate([t_sums.cpu().numpy(), self._pivot, [0.0]])
         pose_est, cov = estimate_from_sums(sums)
         if np.all(np.isfinite(pose_est[2:])):
@@ -296,30 +357,88 @@ class ShardedAmcl:
                           "ess": ess, "random_state_probability": p_random}
         return pose_est, cov
 
-    def _resample(self, totals: np.ndarray, p_random: float):
-        """views::sample | random_intersperse | actions::assign (amcl_core.hpp:188-196) across shards (C3)."""
-        torch, dist, e = self.torch, self.dist, self.engine
-        world, m = self.world, self.n_local
+    def _cdf_intervals(self, totals: np.ndarray):
         ends_host = np.cumsum(totals)            # inclusive end of every shard's interval of the global CDF
-        total = float(ends_host[-1])
-        offsets = torch.tensor(ends_host - totals, dtype=torch.float64, device=self.device)
-        ends = torch.tensor(ends_host, dtype=torch.float64, device=self.device)
+        offsets = self.torch.tensor(ends_host - totals, dtype=self.torch.float64, device=self.device)
+        ends = self.torch.tensor(ends_host, dtype=self.torch.float64, device=self.device)
+        return float(ends_host[-1]), ends, offsets
 
+    def _draw(self, total, ends, offsets, p_random, first_slot, m):
+        """Output slots [first_slot, first_slot + m) of views::sample | random_intersperse: the ancestor exchange (C3).
+        -> (targets, replies (m, 4) records (x, y, cos, sin) in request order, order)"""
+        torch, e, world = self.torch, self.engine, self.world
         targets = e.empty(m)
-        e.resample_targets(self._step, p_random, total, self.first_slot, m, targets)
+        e.resample_targets(self._step, p_random, total, first_slot, m, targets)
         # owner = first shard whose interval end is >= the target (std::lower_bound on the global CDF)
         requests_out, order, send_counts = e.route_targets(targets, ends, offsets, self.rank)
         all_counts = torch.empty(world * world, dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(all_counts, send_counts, group=self.group)   # counts[r][q]: r asks q for that many
+        self.net.all_gather(all_counts, send_counts)                 # counts[r][q]: r asks q for that many
         counts = all_counts.cpu().view(world, world)
         send_list, recv_list = counts[self.rank].tolist(), counts[:, self.rank].tolist()
-
         requests_in = e.empty(int(sum(recv_list)))
-        dist.all_to_all_single(requests_in, requests_out, recv_list, send_list, group=self.group)
+        self.net.all_to_all(requests_in, requests_out, recv_list, send_list)
         served = e.serve_requests(requests_in)                      # (m_in, 4) records (x, y, cos, sin)
         replies = e.empty(m, 4)
-        dist.all_to_all_single(replies, served, send_list, recv_list, group=self.group)
-        e.commit_routed(self._step, self.first_slot, m, replies, order, targets)
+        self.net.all_to_all(replies, served, send_list, recv_list)
+        return targets, replies, order
+
+    def _resample(self, totals: np.ndarray, p_random: float):
+        """views::sample | random_intersperse | actions::assign (amcl_core.hpp:188-196) across shards (C3)."""
+        total, ends, offsets = self._cdf_intervals(totals)
+        m = self.n_local
+        targets, replies, order = self._draw(total, ends, offsets, p_random, self.first_slot, m)
+        self.engine.commit_routed(self._step, self.first_slot, m, replies, order, targets)
+
+    def _resample_kld(self, totals: np.ndarray, p_random: float):
+        """views::sample | random_intersperse | take_while_kld | take(max) | actions::assign (amcl_core.hpp:188-196, C5)."""
+        torch, e, world, rank = self.torch, self.engine, self.world, self.rank
+        total, ends, offsets = self._cdf_intervals(totals)
+        max_p, min_p = self.params.max_particles, self.params.min_particles
+        e.kld_begin()
+        pos, block, blocks, n_out = 0, self.kld_block or max(min_p + 1, 8192 * world), [], max_p
+        while pos < max_p:
+            cnt = min(block, max_p - pos)
+            lo, m = shard_bounds(cnt, world, rank)
+            targets, replies, order = self._draw(total, ends, offsets, p_random, pos + lo, m)
+            states, hashes = e.finish_candidates(self._step, pos + lo, m, replies, order, targets)
+            # every rank checks kld_condition over the whole block, in global candidate order
+            width, rem = -(-cnt // world), cnt % world
+            if m < width:
+                hashes = torch.cat([hashes, hashes.new_zeros(width - m)])
+            gathered = torch.empty(world * width, dtype=torch.int64, device=self.device)
+            self.net.all_gather(gathered, hashes)
+            if rem:  # ranks >= rem hold one candidate less: drop their padding
+                rows = gathered.view(world, width)
+                gathered = torch.cat([rows[:rem].reshape(-1), rows[rem:, :width - 1].reshape(-1)])
+            blocks.append((pos, cnt, states))
+            fail = e.kld_feed(gathered)
+            if fail is not None:
+                n_out = fail        # the first candidate failing the predicate is dropped (take_while)
+                break
+            pos += cnt
+            block *= 2
+        n_out = min(n_out, max_p)   # | take(max)
+        # re-balance: the kept candidates [0, n_out) become contiguous shards of the new set
+        new_first, new_n = shard_bounds(n_out, world, rank)
+        final = e.empty(new_n, 4)
+        spans = [shard_bounds(n_out, world, r) for r in range(world)]
+
+        def overlap(a0, a1, b0, b1):
+            return max(0, min(a1, b1) - max(a0, b0))
+
+        for pos, cnt, states in blocks:
+            if pos >= n_out:
+                break
+            held = [(pos + lo, pos + lo + m) for lo, m in (shard_bounds(cnt, world, r) for r in range(world))]
+            mine = held[rank]
+            send = [overlap(mine[0], min(mine[1], n_out), f, f + c) for f, c in spans]
+            recv = [overlap(h0, min(h1, n_out), new_first, new_first + new_n) for h0, h1 in held]
+            # destinations are ordered by global index and cover [0, n_out): my kept candidates go out front to back,
+            # and what I receive from this block is one contiguous run of my new shard, in source-rank = global order
+            out0 = max(pos, new_first) - new_first
+            self.net.all_to_all(final[out0:out0 + sum(recv)], states[:sum(send)], recv, send)
+        e.load_shard(final, new_first)
+        self.n_total, self.first_slot, self.n_local = n_out, new_first, new_n
 
     def close(self):
         self.engine.close()

@@ -272,6 +272,20 @@ mcl_status mcl_serve_requests(mcl_ctx* ctx, const double* d_requests, uint64_t m
 /* As mcl_commit_resampled, taking the replies in request order plus the d_order of mcl_route_targets. */
 mcl_status mcl_commit_routed(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,
                              const uint32_t* d_order, const double* d_targets);
+/* KLD-adaptive resampling across shards (views/take_while_kld.hpp:72-88,112-137 over the GLOBAL candidate stream).
+ * The driver draws candidates block by block: each shard draws its slice of the block (mcl_resample_targets, routing,
+ * mcl_serve_requests as above), then mcl_finish_candidates writes the slice's states (4 doubles cos, sin, x, y per
+ * candidate, slot order) and spatial hashes (algorithm/spatial_hash.hpp:190-193) to caller buffers without touching the
+ * live set.  Every shard is fed the hashes of the whole block in global candidate order (all-gather) through
+ * mcl_kld_feed, which returns in *first_fail the global index of the first candidate failing kld_condition (it and
+ * everything after it is dropped), or ~0 if the block passes; mcl_kld_begin starts a pass.  After the cut the driver
+ * re-balances the kept candidates and installs each shard's slice with mcl_load_shard (weights 1,
+ * particle_traits.hpp:105); shard_offset is the global index of its first particle (used by the RNG addressing). */
+mcl_status mcl_finish_candidates(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,
+                                 const uint32_t* d_order, const double* d_targets, double* d_states, uint64_t* d_hashes);
+mcl_status mcl_kld_begin(mcl_ctx* ctx);
+mcl_status mcl_kld_feed(mcl_ctx* ctx, const uint64_t* d_hashes, uint64_t count, uint64_t* first_fail);
+mcl_status mcl_load_shard(mcl_ctx* ctx, const double* d_states, uint64_t n, uint64_t shard_offset);
 /* Device-side variants for callers that keep scalars on the GPU (e.g. to feed RCCL collectives without a host
  * round trip).  All pointers are DEVICE pointers; nothing synchronises; work is enqueued on the context's stream. */
 mcl_status mcl_weight_sum_device(mcl_ctx* ctx, double* d_sum);

@@ -21,6 +21,8 @@ class OracleShardEngine:
         self.field = orc.make_likelihood_field(grid.cells, grid.resolution, self.lf, sensor.model_unknown_space,
                                                sensor.only_obstacle_boundaries)
         self.offset, self.capacity = shard_offset, shard_capacity
+        self.hash_res = (params.spatial_resolution_x, params.spatial_resolution_y, params.spatial_resolution_theta)
+        self.kld = (params.min_particles, params.kld_epsilon, params.kld_z)
         self.states = np.zeros((0, 4))
         self.w = np.zeros(0)
         self.cdf = np.zeros(0)
@@ -89,6 +91,9 @@ class OracleShardEngine:
         return torch.from_numpy(np.stack([s[:, 2], s[:, 3], s[:, 0], s[:, 1]], axis=1).copy())
 
     def commit_routed(self, step, first_slot, count, replies, order, targets):
+        self.states, self.w = self._materialise(step, first_slot, count, replies, order, targets), np.ones(count)
+
+    def _materialise(self, step, first_slot, count, replies, order, targets):
         r, t, o = replies.numpy(), targets.numpy(), order.numpy()
         new = np.zeros((count, 4))
         new[o] = np.stack([r[:, 2], r[:, 3], r[:, 0], r[:, 1]], axis=1)
@@ -97,7 +102,25 @@ class OracleShardEngine:
             cell = min(int((float(((int(d[0]) << 32) | int(d[1])) >> 11) * 2.0 ** -53) * len(self.free_xy)), len(self.free_xy) - 1)
             theta = -np.pi + 2.0 * np.pi * (float(((int(d[2]) << 32) | int(d[3])) >> 11) * 2.0 ** -53)
             new[k] = orc.se2(self.free_xy[cell, 0], self.free_xy[cell, 1], theta)
-        self.states, self.w = new, np.ones(count)
+        return new
+
+    def finish_candidates(self, step, first_slot, count, replies, order, targets):
+        new = self._materialise(step, first_slot, count, replies, order, targets)
+        hashes = np.array([orc.spatial_hash(s, self.hash_res) for s in new], dtype=np.uint64)
+        return torch.from_numpy(new), torch.from_numpy(hashes.view(np.int64).copy())
+
+    def kld_begin(self):
+        self.kld_hashes = np.zeros(0, dtype=np.uint64)
+
+    def kld_feed(self, hashes):
+        self.kld_hashes = np.concatenate([self.kld_hashes, hashes.numpy().view(np.uint64)])
+        kept = orc.kld_take_while(self.kld_hashes, self.kld[0], self.kld[1], self.kld[2])
+        return None if kept >= len(self.kld_hashes) else int(kept)
+
+    def load_shard(self, states, shard_offset):
+        self.states = states.numpy().copy().reshape(-1, 4)
+        self.w = np.ones(len(self.states))
+        self.offset = shard_offset
 
     def estimate_sums_into(self, pivot, t_sums9):
         w, s = self.w, self.states

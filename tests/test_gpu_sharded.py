@@ -52,3 +52,106 @@ def test_sharded_world1_nccl_matches_single_gpu():
         sharded.close()
     finally:
         dist.destroy_process_group()
+
+
+# ---- two (three) ranks sharing the one GPU of the test box -------------------------------------------------------
+# RCCL refuses two ranks on one device, so these runs use a gloo group: ShardedAmcl stages the device tensors of every
+# collective through host memory, everything else (shard offsets, routing, serving, KLD feed, re-balancing) is the HIP
+# engine exactly as in a multi-GPU run.  The result must equal the single-context filter.
+def _workload(n_cycles=5, beams=360):
+    cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
+    grid = OccupancyGrid(cells, 0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
+    truth = synth.find_free_pose(cells, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
+    angles = synth.lidar_angles(beams, 270.0)
+    pose, odom, steps = truth, (0.0, 0.0, 0.0), []
+    for c in range(n_cycles):
+        pose = synth.odometry_step(pose, 0.3, 0.05)
+        odom = synth.odometry_step(odom, 0.3, 0.05)
+        pts = synth.scan_points(synth.cast_scan(cells, 0.05, (-10.0, -10.0), pose, angles, 12.0, 0.01, seed=c), angles)
+        steps.append((se2_from_xytheta(*odom), pts))
+    return grid, truth, steps
+
+
+MOTION = DifferentialDriveModelParam(0.1, 0.05, 0.1, 0.05)
+LF = LikelihoodFieldModelParam(2.0, 100.0, 0.5, 0.5, 0.2, True)
+
+
+def _shared_gpu_worker(rank, world, init_file, params, block, result_file):
+    import torch
+    import torch.distributed as dist
+
+    from beluga_amd.sharded import ShardedAmcl, shard_bounds
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    grid, truth, steps = _workload()
+    f = ShardedAmcl(grid, MOTION, LF, params, seed=9, device=0, kld_block=block)
+    f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+    outs, counts = [], []
+    for c, p in steps:
+        outs.append(f.update(c, p))
+        counts.append(f.n_total)
+        assert (f.first_slot, f.n_local) == shard_bounds(f.n_total, world, rank) and f.engine.num_particles() == f.n_local
+    states, w = f.gather_particles()
+    if rank == 0:
+        np.savez(result_file, states=states, w=w, counts=np.array(counts), poses=np.array([o[0] for o in outs]),
+                 covs=np.array([o[1] for o in outs]))
+    dist.barrier()
+    f.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,min_p,max_p,block", [(2, 50_001, 50_001, None), (2, 300, 200_000, None), (3, 300, 200_000, 4_099)])
+def test_sharded_ranks_sharing_one_gpu_match_single_context(world, min_p, max_p, block, tmp_path):
+    import torch.multiprocessing as mp
+    params = AmclParams(min_particles=min_p, max_particles=max_p)
+    init_file, result_file = str(tmp_path / "rendezvous"), str(tmp_path / "result.npz")
+    mp.spawn(_shared_gpu_worker, args=(world, init_file, params, block, result_file), nprocs=world, join=True)
+    got = np.load(result_file)
+    grid, truth, steps = _workload()
+    single = Amcl(grid, MOTION, LF, params, seed=9)
+    single.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+    ref, ref_counts = [], []
+    for c, p in steps:
+        ref.append(single.update(c, p))
+        ref_counts.append(single.num_particles())
+    sa, wa = single.particles()
+    single.close()
+    assert list(got["counts"]) == ref_counts
+    if min_p < max_p:
+        assert min_p < ref_counts[-1] < max_p  # the KLD cut is a real one
+    np.testing.assert_allclose(got["poses"], np.array([o[0] for o in ref]), atol=1e-9)
+    np.testing.assert_allclose(got["covs"], np.array([o[1] for o in ref]), rtol=1e-8, atol=1e-11)
+    assert got["states"].shape == sa.shape
+    assert int(np.any(got["states"] != sa, axis=1).sum()) <= 2  # a CDF-boundary flip (shard-wise summation order) at most
+    np.testing.assert_allclose(got["w"], wa, rtol=1e-12)
+
+
+def test_sharded_kld_world1_nccl_matches_single_gpu():
+    import torch
+    import torch.distributed as dist
+
+    from beluga_amd.sharded import ShardedAmcl
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29612"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        grid, truth, steps = _workload()
+        params = AmclParams(min_particles=300, max_particles=1_000_000)
+        single = Amcl(grid, MOTION, LF, params, seed=9)
+        sharded = ShardedAmcl(grid, MOTION, LF, params, seed=9, device=0)
+        single.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+        sharded.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+        for c, p in steps:
+            a, b = single.update(c, p), sharded.update(c, p)
+            assert sharded.n_total == single.num_particles()
+            np.testing.assert_allclose(b[0], a[0], atol=1e-9)
+            np.testing.assert_allclose(b[1], a[1], rtol=1e-8, atol=1e-11)
+        assert 300 < sharded.n_total < 1_000_000
+        (sa, wa), (sb, wb) = single.particles(), sharded.particles()
+        assert sa.shape == sb.shape and int(np.any(sa != sb, axis=1).sum()) <= 2 and np.array_equal(wa, wb)
+        single.close()
+        sharded.close()
+    finally:
+        dist.destroy_process_group()

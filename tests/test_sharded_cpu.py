@@ -86,6 +86,61 @@ def test_sharded_update_matches_single_process(world, selective, tmp_path):
     np.testing.assert_allclose(got["w"], ref_w, rtol=1e-9)
 
 
+KLD_MIN, KLD_MAX = 300, 3001
+
+
+def kld_reference_run():
+    from oracle import binding as orc
+    grid, truth, steps = workload()
+    f = orc.Amcl(min_particles=KLD_MIN, max_particles=KLD_MAX, alphas=(0.1, 0.05, 0.1, 0.05), seed=SEED, lf=(2.0, 100.0, 0.5, 0.5, 0.2),
+                 lf_model_unknown_space=True)
+    f.set_map(grid.cells, grid.resolution, grid.origin)
+    f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+    out, counts = [], []
+    for c, p in steps:
+        out.append(f.update(c, p))
+        counts.append(len(f.particles()[1]))
+    return out, counts, f.particles()
+
+
+def _kld_worker(rank, world, init_file, block, result_file):
+    from shard_oracle_engine import OracleShardEngine
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    grid, truth, steps = workload()
+    params = AmclParams(min_particles=KLD_MIN, max_particles=KLD_MAX)
+    f = ShardedAmcl(grid, MOTION, LF, params, seed=SEED, engine_factory=OracleShardEngine, kld_block=block)
+    f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+    outs, counts = [], []
+    for c, p in steps:
+        outs.append(f.update(c, p))
+        counts.append(f.n_total)
+        assert (f.first_slot, f.n_local) == shard_bounds(f.n_total, world, rank)
+        assert f.engine.num_particles() == f.n_local and f.engine.offset == f.first_slot
+    states, w = f.gather_particles()
+    if rank == 0:
+        np.savez(result_file, states=states, w=w, counts=np.array(counts), updated=np.array([o is not None for o in outs]),
+                 poses=np.array([o[0] for o in outs if o is not None]), covs=np.array([o[1] for o in outs if o is not None]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,block", [(2, None), (3, 257), (2, 1000)])
+def test_sharded_kld_resampling_matches_single_process(world, block, tmp_path):
+    """take_while_kld over the global candidate stream: same cut, same particles, for any block schedule and rank count."""
+    init_file, result_file = str(tmp_path / "rendezvous"), str(tmp_path / "result.npz")
+    mp.spawn(_kld_worker, args=(world, init_file, block, result_file), nprocs=world, join=True)
+    got = np.load(result_file)
+    ref_out, ref_counts, (ref_states, ref_w) = kld_reference_run()
+    assert list(got["updated"]) == [o is not None for o in ref_out]
+    assert list(got["counts"]) == ref_counts
+    assert KLD_MIN < ref_counts[-1] < KLD_MAX  # the cut is a real one
+    np.testing.assert_allclose(got["poses"], np.array([o[0] for o in ref_out if o is not None]), atol=1e-9)
+    np.testing.assert_allclose(got["covs"], np.array([o[1] for o in ref_out if o is not None]), rtol=1e-8, atol=1e-11)
+    assert got["states"].shape == ref_states.shape
+    assert int(np.any(np.abs(got["states"] - ref_states) > 1e-9, axis=1).sum()) <= 2
+    np.testing.assert_allclose(got["w"], ref_w, rtol=1e-9)
+
+
 def test_shard_bounds_cover_the_index_space():
     for n, world in [(10, 3), (64_000_000, 8), (7, 8), (1, 1)]:
         spans = [shard_bounds(n, world, r) for r in range(world)]
