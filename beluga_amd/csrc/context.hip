@@ -17,6 +17,7 @@
 #include <queue>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "beluga_mcl.h"
@@ -190,6 +191,11 @@ struct mcl_ctx {
   OccupancyTraits traits{0, -1, 100};
   DeviceBuffer<float> d_field;
   DeviceBuffer<double> d_cube;  // pz^3 table of the field (+1 slot for out-of-grid beams)
+  // palette form of the same table (FieldView::pal_*), built when the field has <= kMaxPalette distinct values
+  DeviceBuffer<uint16_t> d_pal_idx;
+  DeviceBuffer<double> d_pal_val;
+  DeviceBuffer<uint32_t> d_pal_keys;
+  uint32_t pal_count{0}, pal_pitch{0}, pal_base{0}, pal_bytes{0};
   DeviceBuffer<int8_t> d_cells;
   DeviceBuffer<uint32_t> d_nonfree_bits;  // beam model: 1 bit per cell
   DeviceBuffer<uint32_t> d_free;
@@ -260,7 +266,8 @@ struct mcl_ctx {
   double* chunk_row(int k) { return d_chunk.ptr + static_cast<size_t>(k) * chunk_stride; }
   FieldView field_view() const {
     return FieldView{d_field.ptr, W, H, 1. / resolution, origin_inverse, static_cast<float>(1. / cfg.lf.max_laser_distance),
-                     d_cube.ptr, cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD_PROB ? 1 : 0};
+                     d_cube.ptr, cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD_PROB ? 1 : 0,
+                     pal_count ? d_pal_idx.ptr : nullptr, d_pal_val.ptr, pal_count, pal_pitch, pal_base, pal_bytes};
   }
   SortScratch sort_scratch() {
     SortScratch s{};
@@ -416,12 +423,51 @@ mcl_status kld_process(mcl_ctx* ctx, uint64_t cnt, uint64_t* first_fail) {
   return MCL_OK;
 }
 
-mcl_status rebuild_cube(mcl_ctx* ctx) {
+mcl_status rebuild_cube(mcl_ctx* ctx, const float* h_field) {
   const uint64_t cells = static_cast<uint64_t>(ctx->W) * ctx->H;
+  const float unknown_value = static_cast<float>(1. / ctx->cfg.lf.max_laser_distance);
+  const int prob = ctx->cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD_PROB ? 1 : 0;
   MCL_HIP(ctx, ctx->d_cube.ensure(cells + 1));
-  launch_cube_table(ctx->stream, ctx->d_field.ptr, cells, static_cast<float>(1. / ctx->cfg.lf.max_laser_distance), ctx->d_cube.ptr,
-                    ctx->cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD_PROB ? 1 : 0);
+  launch_cube_table(ctx->stream, ctx->d_field.ptr, cells, unknown_value, ctx->d_cube.ptr, prob);
   MCL_HIP(ctx, hipGetLastError());
+  // Palette: the distinct values of the field (a distance map quantised to cell offsets has a few hundred).
+  ctx->pal_count = 0;
+  const uint64_t tiles_x = (ctx->W + 7) / 8 + 2, tiles_y = (ctx->H + 7) / 8 + 2;  // one border tile on every side
+  const uint32_t pal_base = ((ctx->H + 2) * 4u + 7u) & ~7u;                       // the kernel's row-offset table comes first in LDS
+  if (h_field && tiles_x * tiles_y * 128 < (1ull << 31) && ctx->W < (1u << 26) && pal_base + 8 <= 65536) {
+    const size_t max_entries = std::min<size_t>(kMaxPalette, (65536 - pal_base) / 8);
+    std::vector<uint32_t> keys;
+    {
+      std::unordered_set<uint32_t> seen;
+      uint32_t bits;
+      std::memcpy(&bits, &unknown_value, sizeof bits);
+      seen.insert(bits);
+      uint32_t last = bits;
+      for (uint64_t i = 0; i < cells && seen.size() <= max_entries; ++i) {
+        std::memcpy(&bits, h_field + i, sizeof bits);
+        if (bits != last) {
+          seen.insert(bits);
+          last = bits;
+        }
+      }
+      if (seen.size() <= max_entries) keys.assign(seen.begin(), seen.end());
+    }
+    if (!keys.empty()) {
+      std::sort(keys.begin(), keys.end());
+      MCL_HIP(ctx, ctx->d_pal_keys.ensure(keys.size()));
+      MCL_HIP(ctx, ctx->d_pal_val.ensure(keys.size()));
+      MCL_HIP(ctx, ctx->d_pal_idx.ensure(tiles_x * tiles_y * 64));
+      MCL_HIP(ctx, hipMemcpyAsync(ctx->d_pal_keys.ptr, keys.data(), keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+      launch_palette_table(ctx->stream, ctx->d_field.ptr, ctx->W, ctx->H, unknown_value, ctx->d_pal_keys.ptr,
+                           static_cast<uint32_t>(keys.size()), prob, ctx->d_pal_idx.ptr, ctx->d_pal_val.ptr, pal_base);
+      MCL_HIP(ctx, hipGetLastError());
+      MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // keys is a local
+      ctx->pal_count = static_cast<uint32_t>(keys.size());
+      ctx->pal_pitch = static_cast<uint32_t>(tiles_x * 128);
+      ctx->pal_base = pal_base;
+      ctx->pal_bytes = static_cast<uint32_t>(tiles_x * tiles_y * 128);
+    }
+  }
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MCL_OK;
 }
@@ -833,6 +879,9 @@ void mcl_destroy(mcl_ctx* ctx) {
   for (auto& set : ctx->sets) set.release();
   ctx->d_field.release();
   ctx->d_cube.release();
+  ctx->d_pal_idx.release();
+  ctx->d_pal_val.release();
+  ctx->d_pal_keys.release();
   ctx->d_cells.release();
   ctx->d_nonfree_bits.release();
   ctx->d_free.release();
@@ -897,7 +946,7 @@ mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32
     build_likelihood_field(cells, width, height, resolution, ctx->traits, ctx->cfg.lf, ctx->h_field);
     MCL_HIP(ctx, ctx->d_field.ensure(n));
     MCL_HIP(ctx, hipMemcpy(ctx->d_field.ptr, ctx->h_field.data(), n * sizeof(float), hipMemcpyHostToDevice));
-    if (const mcl_status s = rebuild_cube(ctx)) return s;
+    if (const mcl_status s = rebuild_cube(ctx, ctx->h_field.data())) return s;
   }
   ctx->have_map = true;
   return MCL_OK;
@@ -922,7 +971,7 @@ mcl_status mcl_set_likelihood_field(mcl_ctx* ctx, const float* field) {
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MCL_HIP(ctx, ctx->d_field.ensure(n));
   MCL_HIP(ctx, hipMemcpy(ctx->d_field.ptr, field, n * sizeof(float), hipMemcpyHostToDevice));
-  return rebuild_cube(ctx);
+  return rebuild_cube(ctx, field);
 }
 
 mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], const double cov[9]) {

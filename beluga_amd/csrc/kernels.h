@@ -32,7 +32,30 @@ struct FieldView {
   // term of likelihood_field_model.hpp:84-88 — and cube[W*H] = the same for unknown_value.  8 B per cell.
   const double* cube;
   int prob;  // LikelihoodFieldProbModel: the table holds log(pz) and the weight is exp(sum) (likelihood_field_prob_model.hpp:76-88)
+  // Palette form of the same table (used when the field has few distinct values, which a quantised distance map always
+  // has): pal_val[k] = the cube / log term of the k-th distinct field value; pal_idx = one uint16 per cell, stored in
+  // 8x8-cell tiles of 128 bytes (see palette_offset) with a border of one tile of "unknown" cells all around, so that
+  // clamping a cell coordinate to [-1, W] x [-1, H] replaces the in-grid test.  The uint16 is the LDS byte address of the
+  // cell's palette entry inside k_reweight_lf_palette's workgroup memory: pal_base + 8 * k.
+  // 2 B per cell instead of 8 and square tiles: a wave's gather touches ~4x fewer cache lines.
+  const uint16_t* pal_idx;
+  const double* pal_val;
+  uint32_t pal_count;  // 0 = no palette
+  uint32_t pal_pitch;  // bytes per row of tiles (border included)
+  uint32_t pal_base;   // LDS byte offset of the palette (after the row-offset table of H + 2 words)
+  uint32_t pal_bytes;  // size of pal_idx in bytes
 };
+
+constexpr uint32_t kMaxPalette = 2048;
+// Byte offset of cell (x, y), -8 <= x < W + 8, -8 <= y < H + 8, in the tiled uint16 table: tiles are 8x8 cells,
+// column-major inside a tile, so x contributes a plain shift and y = (row of tiles) * pitch + (y & 7) * 2.
+__host__ __device__ inline uint32_t palette_row_offset(int32_t y, uint32_t pitch) {
+  const uint32_t py = static_cast<uint32_t>(y + 8);
+  return (py >> 3) * pitch + ((py & 7u) << 1) + 128u;  // + 128: the x border tile
+}
+__host__ __device__ inline uint32_t palette_offset(int32_t x, int32_t y, uint32_t pitch) {
+  return palette_row_offset(y, pitch) + (static_cast<uint32_t>(x) << 4);
+}
 
 struct GridView {
   const int8_t* cells;
@@ -181,6 +204,9 @@ void launch_init_normal(hipStream_t st, ParticleSoA p, uint64_t n, const double 
 void launch_fill(hipStream_t st, double* p, uint64_t n, double v);
 // cube[i] = double(field[i])^3 (or log(double(field[i])) for the prob model) for i < cells, cube[cells] = same for `unknown`
 void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube, int prob);
+// keys: the sorted bit patterns of the distinct field values (count entries, unknown_value among them)
+void launch_palette_table(hipStream_t st, const float* field, uint32_t W, uint32_t H, float unknown_value, const uint32_t* keys,
+                          uint32_t count, int prob, uint16_t* idx, double* val, uint32_t pal_base);
 // AoS (c,s,x,y) host layout <-> SoA device layout
 void launch_aos_to_soa(hipStream_t st, const double* aos, ParticleSoA p, uint64_t n);
 void launch_soa_to_aos(hipStream_t st, ParticleSoA p, double* aos, uint64_t n);

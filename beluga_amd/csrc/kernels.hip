@@ -13,10 +13,14 @@
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <climits>
 
 #include "rng.h"
 
+#ifndef LF_MAGIC_FLOOR
+#define LF_MAGIC_FLOOR 1
+#endif
 #ifndef LF_UNROLL
 #define LF_UNROLL 8
 #endif
@@ -151,6 +155,37 @@ __device__ __forceinline__ double lf_beam_cube(__amdgpu_buffer_rsrc_t rsrc, cons
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, offset, 0, 0));
 }
 
+// floor() of 2*G doubles at once without v_floor_f64 + v_cvt_i32_f64: with the f64 rounding mode switched to
+// round-toward-minus-infinity, v + 1.5*2^52 is exactly 1.5*2^52 + floor(v), whose low mantissa word is floor(v) as a
+// two's complement int32 (|v| < 2^31; larger magnitudes are far outside any grid and undefined upstream as well).
+// One VALU op per value instead of two.  The mode switch and the adds sit in ONE asm statement so that no other
+// floating-point instruction can be scheduled into the round-down window.
+constexpr double kFloorMagic = 6755399441055744.0;  // 1.5 * 2^52
+#define MCL_RD_BEGIN "s_nop 1\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+#define MCL_RD_END "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+__device__ __forceinline__ void floor_rd_16(double (&v)[16]) {
+  asm volatile(MCL_RD_BEGIN
+               "v_add_f64 %0, %0, %16\n\tv_add_f64 %1, %1, %16\n\tv_add_f64 %2, %2, %16\n\tv_add_f64 %3, %3, %16\n\t"
+               "v_add_f64 %4, %4, %16\n\tv_add_f64 %5, %5, %16\n\tv_add_f64 %6, %6, %16\n\tv_add_f64 %7, %7, %16\n\t"
+               "v_add_f64 %8, %8, %16\n\tv_add_f64 %9, %9, %16\n\tv_add_f64 %10, %10, %16\n\tv_add_f64 %11, %11, %16\n\t"
+               "v_add_f64 %12, %12, %16\n\tv_add_f64 %13, %13, %16\n\tv_add_f64 %14, %14, %16\n\tv_add_f64 %15, %15, %16\n\t"
+               MCL_RD_END
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                 "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+               : "s"(kFloorMagic));
+}
+__device__ __forceinline__ void floor_rd_2(double& a, double& b) {
+  asm volatile(MCL_RD_BEGIN "v_add_f64 %0, %0, %2\n\tv_add_f64 %1, %1, %2\n\t" MCL_RD_END : "+v"(a), "+v"(b) : "s"(kFloorMagic));
+}
+__device__ __forceinline__ int floor_rd_result(double v) { return static_cast<int>(static_cast<uint32_t>(__builtin_bit_cast(uint64_t, v))); }
+
+__device__ __forceinline__ double lf_cube_fetch(__amdgpu_buffer_rsrc_t rsrc, const FieldView& f, uint32_t row_bytes,
+                                                uint32_t unknown_offset, int xi, int yi) {
+  const bool inside = static_cast<unsigned>(xi) < f.W && static_cast<unsigned>(yi) < f.H;
+  const uint32_t offset = inside ? __umul24(static_cast<unsigned>(yi), row_bytes) + (static_cast<unsigned>(xi) << 3) : unknown_offset;
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, offset, 0, 0));
+}
+
 // Variant A — one wavefront per particle, lanes stride over the beams, scan staged in LDS.
 // A wave owns a tile of 64 particles: the 64 world->field transforms are computed lane-parallel, then
 // broadcast one at a time through SGPRs (v_readlane), so the per-beam math has scalar pose operands.
@@ -233,17 +268,118 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(f.cube), 0, static_cast<int>((cells + 1) * 8u), 0x00020000);
     const uint32_t row_bytes = f.W * 8u, unknown_offset = cells * 8u;
+#if LF_MAGIC_FLOOR
+    uint32_t b = b_begin;
+    for (; b + 8 <= b_end; b += 8) {
+      double v[16];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double px = pts[2 * (b + k)], py = pts[2 * (b + k) + 1];
+        v[2 * k] = (px * ct - py * st + xt) * f.inv_resolution;
+        v[2 * k + 1] = (px * st + py * ct + yt) * f.inv_resolution;
+      }
+      floor_rd_16(v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        acc += lf_cube_fetch(rsrc, f, row_bytes, unknown_offset, floor_rd_result(v[2 * k]), floor_rd_result(v[2 * k + 1]));
+    }
+    for (; b < b_end; ++b) {
+      const double px = pts[2 * b], py = pts[2 * b + 1];
+      double vx = (px * ct - py * st + xt) * f.inv_resolution, vy = (px * st + py * ct + yt) * f.inv_resolution;
+      floor_rd_2(vx, vy);
+      acc += lf_cube_fetch(rsrc, f, row_bytes, unknown_offset, floor_rd_result(vx), floor_rd_result(vy));
+    }
+#else
 #pragma unroll LF_UNROLL
     for (uint32_t b = b_begin; b < b_end; ++b) {
       const double px = pts[2 * b], py = pts[2 * b + 1];
       acc += lf_beam_cube(rsrc, f, row_bytes, unknown_offset, px, py, ct, st, xt, yt);
     }
+#endif
   } else {
 #pragma unroll 8
     for (uint32_t b = b_begin; b < b_end; ++b) {
       const double px = pts[2 * b], py = pts[2 * b + 1];
       acc += lf_beam<false>(f, px, py, ct, st, xt, yt);
     }
+  }
+  if (t < n) {
+    if (partial) {
+      partial[static_cast<size_t>(blockIdx.y) * n + t] = acc;
+    } else {
+      const uint32_t i = perm[t];
+      w[i] = w[i] * (f.prob ? exp(acc) : acc);
+    }
+  }
+}
+
+// Variant C over the palette form of the table (FieldView::pal_*): the gather fetches a 2-byte LDS address from the
+// 8x8-tiled, bordered index table and the exact f64 term comes from the palette copy in LDS.  Same arithmetic, same
+// order, same bits as the reference's loop; per beam and lane: 8 f64 ops for the end-point, 2 to scale to cells, 2 for the
+// floors, 2 clamps, 2 for the table offset (the row part comes from a row-offset table in LDS), 1 add.
+// Workgroup memory: [0, (H+2)*4) row offsets for y = -1 .. H, [pal_base, pal_base + 8 * pal_count) the palette; the kernel
+// has no other LDS, so these are absolute LDS addresses.
+constexpr int kPalBlock = 512;
+typedef __attribute__((address_space(3))) const double lds_f64_t;
+typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
+__device__ __forceinline__ int clamp_cell(int v, uint32_t hi) {  // max(-1, min(v, hi)) in one instruction
+  int r;
+  asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(v), "s"(hi));
+  return r;
+}
+__device__ __forceinline__ uint32_t lf_palette_fetch(__amdgpu_buffer_rsrc_t rsrc, const FieldView& f, int xi, int yi) {
+  const int xc = clamp_cell(xi, f.W), yc = clamp_cell(yi, f.H);
+  const uint32_t row = *reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>(static_cast<uint32_t>(yc + 1) << 2));
+  const uint32_t offset = (static_cast<uint32_t>(xc) << 4) + row;
+  return static_cast<uint32_t>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, offset, 0, 0)));
+}
+__device__ __forceinline__ double lf_palette_value(uint32_t lds_address) {
+  return *reinterpret_cast<lds_f64_t*>(static_cast<uintptr_t>(lds_address));
+}
+
+__global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __restrict__ w, uint64_t n, FieldView f,
+                                                                   const double* __restrict__ pts, uint32_t B,
+                                                                   const uint32_t* __restrict__ perm, const double* __restrict__ tc,
+                                                                   const double* __restrict__ ts, const double* __restrict__ tx,
+                                                                   const double* __restrict__ ty, double* __restrict__ partial,
+                                                                   uint32_t beams_per_segment) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {
+    uint32_t* s_row = reinterpret_cast<uint32_t*>(smem);
+    for (uint32_t j = threadIdx.x; j < f.H + 2; j += kPalBlock) s_row[j] = palette_row_offset(static_cast<int32_t>(j) - 1, f.pal_pitch);
+    double* s_pal = reinterpret_cast<double*>(smem + f.pal_base);
+    for (uint32_t k = threadIdx.x; k < f.pal_count; k += kPalBlock) s_pal[k] = f.pal_val[k];
+  }
+  __syncthreads();
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kPalBlock + threadIdx.x;
+  const uint64_t tt = t < n ? t : n - 1;
+  const double ct = tc[tt], st = ts[tt], xt = tx[tt], yt = ty[tt];
+  const uint32_t b_begin = partial ? blockIdx.y * beams_per_segment : 0u;
+  const uint32_t b_end = partial ? (b_begin + beams_per_segment < B ? b_begin + beams_per_segment : B) : B;
+  double acc = (f.prob || partial) ? 0.0 : 1.0;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(f.pal_idx), 0, static_cast<int>(f.pal_bytes), 0x00020000);
+  uint32_t b = b_begin;
+  for (; b + 8 <= b_end; b += 8) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double px = pts[2 * (b + k)], py = pts[2 * (b + k) + 1];
+      v[2 * k] = (px * ct - py * st + xt) * f.inv_resolution;
+      v[2 * k + 1] = (px * st + py * ct + yt) * f.inv_resolution;
+    }
+    floor_rd_16(v);
+    uint32_t e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = lf_palette_fetch(rsrc, f, floor_rd_result(v[2 * k]), floor_rd_result(v[2 * k + 1]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += lf_palette_value(e[k]);
+  }
+  for (; b < b_end; ++b) {
+    const double px = pts[2 * b], py = pts[2 * b + 1];
+    double vx = (px * ct - py * st + xt) * f.inv_resolution, vy = (px * st + py * ct + yt) * f.inv_resolution;
+    floor_rd_2(vx, vy);
+    acc += lf_palette_value(lf_palette_fetch(rsrc, f, floor_rd_result(vx), floor_rd_result(vy)));
   }
   if (t < n) {
     if (partial) {
@@ -1532,6 +1668,35 @@ __global__ __launch_bounds__(kBlock) void k_cube_table(const float* __restrict__
   const double pz = static_cast<double>(i < cells ? field[i] : unknown_value);
   cube[i] = prob ? log(pz) : pz * pz * pz;
 }
+__device__ __forceinline__ uint32_t palette_find(const uint32_t* __restrict__ keys, uint32_t count, uint32_t bits) {
+  uint32_t lo = 0, hi = count;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (keys[mid] < bits) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(kBlock) void k_palette_values(const uint32_t* __restrict__ keys, uint32_t count, int prob,
+                                                           double* __restrict__ val) {
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= count) return;
+  const double pz = static_cast<double>(__builtin_bit_cast(float, keys[k]));
+  val[k] = prob ? log(pz) : pz * pz * pz;
+}
+// One thread per slot of the tiled table (border tiles and padding slots take the unknown entry).
+__global__ __launch_bounds__(kBlock) void k_palette_indices(const float* __restrict__ field, uint32_t W, uint32_t H, uint32_t tiles_x,
+                                                            uint32_t tiles_y, float unknown_value, const uint32_t* __restrict__ keys,
+                                                            uint32_t count, uint32_t pal_base, uint16_t* __restrict__ idx) {
+  const uint64_t slot = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (slot >= static_cast<uint64_t>(tiles_x) * tiles_y * 64) return;
+  const uint64_t tile = slot >> 6;
+  const uint32_t in = static_cast<uint32_t>(slot & 63);
+  const int64_t x = (static_cast<int64_t>(tile % tiles_x) - 1) * 8 + (in >> 3), y = (static_cast<int64_t>(tile / tiles_x) - 1) * 8 + (in & 7);
+  float v = unknown_value;
+  if (x >= 0 && x < W && y >= 0 && y < H) v = field[static_cast<size_t>(y) * W + static_cast<size_t>(x)];
+  idx[slot] = static_cast<uint16_t>(pal_base + palette_find(keys, count, __builtin_bit_cast(uint32_t, v)) * 8u);
+}
 __global__ __launch_bounds__(kBlock) void k_fill(double* p, uint64_t n, double v) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i < n) p[i] = v;
@@ -1608,7 +1773,18 @@ void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, 
     const uint32_t per_segment = (B + segments - 1) / segments;
     double* partial = segments > 1 ? sort->partial : nullptr;
     const dim3 grid(blocks_for(n), segments);
-    if (cube_ok)
+    static const int table_pref = [] {  // BELUGA_MCL_LF_TABLE=cube forces the 8-byte table (A/B measurements)
+      const char* v = std::getenv("BELUGA_MCL_LF_TABLE");
+      return (v && std::string(v) == "cube") ? 1 : 0;
+    }();
+    const size_t pal_lds = static_cast<size_t>(f.pal_base) + static_cast<size_t>(f.pal_count) * sizeof(double);
+    const bool palette_ok = table_pref == 0 && f.pal_idx != nullptr && f.pal_count > 0 && pal_lds <= 65536;
+    if (palette_ok) {
+      const dim3 pgrid(static_cast<unsigned>((n + kPalBlock - 1) / kPalBlock), segments);
+      hipLaunchKernelGGL(k_reweight_lf_palette, pgrid, dim3(kPalBlock), pal_lds, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
+                         sort->ts, sort->tx, sort->ty, partial, per_segment);
+    }
+    else if (cube_ok)
       hipLaunchKernelGGL(k_reweight_lf_sorted<true>, grid, dim3(kBlock), 0, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
                          sort->ts, sort->tx, sort->ty, partial, per_segment);
     else
@@ -1811,6 +1987,14 @@ void launch_init_normal(hipStream_t st, ParticleSoA p, uint64_t n, const double 
 
 void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube, int prob) {
   hipLaunchKernelGGL(k_cube_table, dim3(blocks_for(cells + 1)), dim3(kBlock), 0, st, field, cells, unknown_value, cube, prob);
+}
+void launch_palette_table(hipStream_t st, const float* field, uint32_t W, uint32_t H, float unknown_value, const uint32_t* keys,
+                          uint32_t count, int prob, uint16_t* idx, double* val, uint32_t pal_base) {
+  const uint32_t tiles_x = (W + 7) / 8 + 2, tiles_y = (H + 7) / 8 + 2;
+  hipLaunchKernelGGL(k_palette_values, dim3(blocks_for(count)), dim3(kBlock), 0, st, keys, count, prob, val);
+  const uint64_t slots = static_cast<uint64_t>(tiles_x) * tiles_y * 64;
+  hipLaunchKernelGGL(k_palette_indices, dim3(blocks_for(slots)), dim3(kBlock), 0, st, field, W, H, tiles_x, tiles_y, unknown_value,
+                     keys, count, pal_base, idx);
 }
 void launch_fill(hipStream_t st, double* p, uint64_t n, double v) {
   if (n == 0) return;
