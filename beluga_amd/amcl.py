@@ -320,14 +320,8 @@ class Amcl:
     def set_num_particles(self, n: int):
         self._check(self._lib.mcl_set_num_particles(self._ctx, n))
 
-    def gather_by_cdf(self, d_targets: int, m: int, d_x: int, d_y: int, d_c: int, d_s: int):
-        self._check(self._lib.mcl_gather_by_cdf(self._ctx, d_targets, m, d_x, d_y, d_c, d_s))
-
     def resample_targets(self, step: int, random_state_probability: float, total: float, first_slot: int, count: int, d_targets: int):
         self._check(self._lib.mcl_resample_targets(self._ctx, step, random_state_probability, total, first_slot, count, d_targets))
-
-    def commit_resampled(self, step: int, first_slot: int, count: int, d_x: int, d_y: int, d_c: int, d_s: int, d_targets: int):
-        self._check(self._lib.mcl_commit_resampled(self._ctx, step, first_slot, count, d_x, d_y, d_c, d_s, d_targets))
 
     def route_targets(self, d_targets, count, d_ends, d_offsets, world, self_rank, d_send, d_order, d_counts):
         self._check(self._lib.mcl_route_targets(self._ctx, d_targets, count, d_ends, d_offsets, world, self_rank, d_send, d_order, d_counts))

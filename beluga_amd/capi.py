@@ -99,7 +99,7 @@ class ClusterParams(C.Structure):
 
 class DeviceView(C.Structure):
     _fields_ = [
-        ("x", C.c_void_p), ("y", C.c_void_p), ("c", C.c_void_p), ("s", C.c_void_p), ("w", C.c_void_p), ("cdf", C.c_void_p),
+        ("states", C.c_void_p), ("w", C.c_void_p), ("cdf", C.c_void_p),
         ("n", C.c_uint64), ("capacity", C.c_uint64), ("hip_stream", C.c_void_p),
     ]
 
@@ -135,9 +135,7 @@ _SIGNATURES = {
     "mcl_get_device_view": (C.c_int32, [_ctx, C.POINTER(DeviceView)]),
     "mcl_set_num_particles": (C.c_int32, [_ctx, C.c_uint64]),
     "mcl_build_cdf": (C.c_int32, [_ctx, c_double_p]),
-    "mcl_gather_by_cdf": (C.c_int32, [_ctx, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcl_resample_targets": (C.c_int32, [_ctx, C.c_uint32, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_void_p]),
-    "mcl_commit_resampled": (C.c_int32, [_ctx, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcl_route_targets": (C.c_int32, [_ctx, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcl_serve_requests": (C.c_int32, [_ctx, C.c_void_p, C.c_uint64, C.c_void_p]),
     "mcl_commit_routed": (C.c_int32, [_ctx, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),

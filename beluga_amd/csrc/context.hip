@@ -61,23 +61,17 @@ struct DeviceBuffer {
 };
 
 struct ParticleSet {
-  DeviceBuffer<double> x, y, c, s, w;
+  DeviceBuffer<double4> pose;
+  DeviceBuffer<double> w;
   hipError_t ensure(size_t n) {
-    hipError_t e;
-    if ((e = x.ensure(n)) != hipSuccess) return e;
-    if ((e = y.ensure(n)) != hipSuccess) return e;
-    if ((e = c.ensure(n)) != hipSuccess) return e;
-    if ((e = s.ensure(n)) != hipSuccess) return e;
+    if (const hipError_t e = pose.ensure(n); e != hipSuccess) return e;
     return w.ensure(n);
   }
   void release() {
-    x.release();
-    y.release();
-    c.release();
-    s.release();
+    pose.release();
     w.release();
   }
-  ParticleSoA view() const { return ParticleSoA{x.ptr, y.ptr, c.ptr, s.ptr, w.ptr}; }
+  Particles view() const { return Particles{pose.ptr, w.ptr}; }
 };
 
 Pose2 pose_from(const double p[4]) { return Pose2{Rot2{p[0], p[1]}, p[2], p[3]}; }
@@ -213,7 +207,6 @@ struct mcl_ctx {
   DeviceBuffer<double> d_scalars;    // 32 doubles
   double* h_scalars{nullptr};        // pinned, 32 doubles
   DeviceBuffer<double> d_cdf;
-  DeviceBuffer<double> d_aos;        // host<->device AoS staging (cap*4)
 
   // KLD
   DeviceBuffer<unsigned long long> d_hashes;
@@ -261,8 +254,8 @@ struct mcl_ctx {
   double prof_ms[MCL_NUM_STAGES]{};
   uint64_t prof_count[MCL_NUM_STAGES]{};
 
-  ParticleSoA cur() const { return sets[live].view(); }
-  ParticleSoA other() const { return sets[live ^ 1].view(); }
+  Particles cur() const { return sets[live].view(); }
+  Particles other() const { return sets[live ^ 1].view(); }
   double* chunk_row(int k) { return d_chunk.ptr + static_cast<size_t>(k) * chunk_stride; }
   FieldView field_view() const {
     return FieldView{d_field.ptr, W, H, 1. / resolution, origin_inverse, static_cast<float>(1. / cfg.lf.max_laser_distance),
@@ -346,7 +339,6 @@ mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
   ctx->chunk_stride = chunks;
   MCL_HIP(ctx, ctx->d_chunk.ensure(static_cast<size_t>(12) * chunks));
   MCL_HIP(ctx, ctx->d_cdf.ensure(cap));
-  MCL_HIP(ctx, ctx->d_aos.ensure(cap * 4));
   ctx->capacity = cap;
   {
     const size_t hist = static_cast<size_t>(kSortDigits) * num_chunks(cap);
@@ -889,7 +881,6 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_chunk.release();
   ctx->d_scalars.release();
   ctx->d_cdf.release();
-  ctx->d_aos.release();
   ctx->d_hashes.release();
   ctx->d_table_keys.release();
   ctx->d_table_first.release();
@@ -995,11 +986,8 @@ mcl_status mcl_set_particles(mcl_ctx* ctx, const double* states, const double* w
   if (const mcl_status s = bind_device(ctx)) return s;
   if (n) {
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    MCL_HIP(ctx, hipMemcpy(ctx->d_aos.ptr, states, n * 4 * sizeof(double), hipMemcpyHostToDevice));
+    MCL_HIP(ctx, hipMemcpy(ctx->cur().pose, states, n * 4 * sizeof(double), hipMemcpyHostToDevice));  // same record layout
     MCL_HIP(ctx, hipMemcpy(ctx->cur().w, weights, n * sizeof(double), hipMemcpyHostToDevice));
-    launch_aos_to_soa(ctx->stream, ctx->d_aos.ptr, ctx->cur(), n);
-    MCL_HIP(ctx, hipGetLastError());
-    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   ctx->n = n;
   ctx->force_update = true;
@@ -1017,10 +1005,8 @@ mcl_status mcl_get_particles(mcl_ctx* ctx, double* states, double* weights, uint
   MCL_REQUIRE(ctx, capacity >= ctx->n, "mcl_get_particles: output too small");
   if (const mcl_status s = bind_device(ctx)) return s;
   if (ctx->n) {
-    launch_soa_to_aos(ctx->stream, ctx->cur(), ctx->d_aos.ptr, ctx->n);
-    MCL_HIP(ctx, hipGetLastError());
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (states) MCL_HIP(ctx, hipMemcpy(states, ctx->d_aos.ptr, ctx->n * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    if (states) MCL_HIP(ctx, hipMemcpy(states, ctx->cur().pose, ctx->n * 4 * sizeof(double), hipMemcpyDeviceToHost));
     if (weights) MCL_HIP(ctx, hipMemcpy(weights, ctx->cur().w, ctx->n * sizeof(double), hipMemcpyDeviceToHost));
   }
   if (n) *n = ctx->n;
@@ -1283,11 +1269,8 @@ mcl_status mcl_set_estimate_kind(mcl_ctx* ctx, int32_t kind, const mcl_cluster_p
 
 mcl_status mcl_get_device_view(mcl_ctx* ctx, mcl_device_view* view) {
   if (!ctx || !view) return MCL_ERR_INVALID_ARGUMENT;
-  const ParticleSoA p = ctx->cur();
-  view->x = p.x;
-  view->y = p.y;
-  view->c = p.c;
-  view->s = p.s;
+  const Particles p = ctx->cur();
+  view->states = reinterpret_cast<double*>(p.pose);
   view->w = p.w;
   view->cdf = ctx->d_cdf.ptr;
   view->n = ctx->n;
@@ -1319,17 +1302,6 @@ mcl_status mcl_build_cdf(mcl_ctx* ctx, double* total) {
   return MCL_OK;
 }
 
-mcl_status mcl_gather_by_cdf(mcl_ctx* ctx, const double* d_targets, uint64_t m, double* d_out_x, double* d_out_y, double* d_out_c,
-                             double* d_out_s) {
-  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
-  MCL_REQUIRE(ctx, m == 0 || (d_targets && d_out_x && d_out_y && d_out_c && d_out_s), "null argument");
-  MCL_REQUIRE(ctx, m == 0 || ctx->n > 0, "empty shard cannot serve draws");
-  if (const mcl_status s = bind_device(ctx)) return s;
-  launch_gather_by_cdf(ctx->stream, ctx->cur(), ctx->d_cdf.ptr, ctx->n, d_targets, m, d_out_x, d_out_y, d_out_c, d_out_s);
-  MCL_HIP(ctx, hipGetLastError());
-  return MCL_OK;
-}
-
 mcl_status mcl_resample_targets(mcl_ctx* ctx, uint32_t step, double random_state_probability, double total,
                                 uint64_t first_slot, uint64_t count, double* d_targets) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
@@ -1338,20 +1310,6 @@ mcl_status mcl_resample_targets(mcl_ctx* ctx, uint32_t step, double random_state
   launch_resample_targets(ctx->stream, ctx->cfg.seed, step, random_state_probability, total, first_slot, count,
                           ctx->have_map ? ctx->n_free : 0, d_targets);
   MCL_HIP(ctx, hipGetLastError());
-  return MCL_OK;
-}
-
-mcl_status mcl_commit_resampled(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_x,
-                                const double* d_y, const double* d_c, const double* d_s, const double* d_targets) {
-  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
-  MCL_REQUIRE(ctx, count <= ctx->capacity, "count exceeds shard capacity");
-  MCL_REQUIRE(ctx, count == 0 || (d_x && d_y && d_c && d_s && d_targets), "null argument");
-  if (const mcl_status s = bind_device(ctx)) return s;
-  launch_commit_resampled(ctx->stream, ctx->other(), ctx->cfg.seed, step, first_slot, count, d_x, d_y, d_c, d_s, d_targets,
-                          ctx->grid_view(), FreeCells{ctx->d_free.ptr, ctx->have_map ? ctx->n_free : 0});
-  MCL_HIP(ctx, hipGetLastError());
-  ctx->live ^= 1;
-  ctx->n = count;
   return MCL_OK;
 }
 
@@ -1443,7 +1401,7 @@ mcl_status mcl_load_shard(mcl_ctx* ctx, const double* d_states, uint64_t n, uint
   MCL_REQUIRE(ctx, n <= ctx->capacity, "n exceeds shard capacity");
   MCL_REQUIRE(ctx, n == 0 || d_states, "null states");
   if (const mcl_status s = bind_device(ctx)) return s;
-  launch_aos_to_soa(ctx->stream, d_states, ctx->cur(), n);
+  if (n) MCL_HIP(ctx, hipMemcpyAsync(ctx->cur().pose, d_states, n * sizeof(double4), hipMemcpyDeviceToDevice, ctx->stream));
   launch_fill(ctx->stream, ctx->cur().w, n, 1.0);  // particle_traits.hpp:105
   MCL_HIP(ctx, hipGetLastError());
   ctx->n = n;

@@ -14,11 +14,11 @@
 
 namespace mcl {
 
-struct ParticleSoA {
-  double* x;
-  double* y;
-  double* c;
-  double* s;
+// One particle set: poses as records of 4 doubles (cos, sin, x, y) — Sophus::SE2d::data() order, the order of the C ABI —
+// and the weights as a separate array.  Records, not one array per component: the multinomial draw and the spatial
+// ordering gather poses of random particles, and a record is one 32-byte access instead of four cache lines.
+struct Particles {
+  double4* pose;
   double* w;
 };
 
@@ -122,16 +122,16 @@ constexpr uint32_t kLfMaxSegments = 16;
 constexpr uint64_t kLfSegmentedBelow = 262144;  // particles
 
 // K1  actions/propagate.hpp:57-79 + differential_drive_model.hpp:156-163
-void launch_propagate(hipStream_t st, ParticleSoA p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
+void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
                       uint64_t index_offset);
 // Counting sort of the particles into (heading, x, y) bins + their world->field poses in sorted order.
-void launch_lf_bin_sort(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const SortScratch* sort);
+void launch_lf_bin_sort(hipStream_t st, Particles p, uint64_t n, FieldView f, const SortScratch* sort);
 // K2  actions/reweight.hpp:53-60 + likelihood_field_model.hpp:68-91 (kLfSortedLanes needs launch_lf_bin_sort first)
-void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
+void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_lf_bin_sort with world_to_field = origin_inverse first).
-void launch_reweight_beam(hipStream_t st, ParticleSoA p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
+void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
                           unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits);
 // One bit per cell (1 = not free), ceil(W/32) words per row: the occupancy the ray walks read.
 void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32_t H, int8_t free_value, uint32_t* bits);
@@ -150,24 +150,19 @@ void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_fac
 void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
                 double* d_total);
 // K6: one thread per candidate (views/sample.hpp:102,133-135; random_intersperse.hpp:90-115; particle_traits.hpp:105).
-void launch_resample_draw(hipStream_t st, ParticleSoA src, const double* cdf, const double* d_total, ParticleSoA dst,
+void launch_resample_draw(hipStream_t st, Particles src, const double* cdf, const double* d_total, Particles dst,
                           ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes);
 // Sharded variant: targets given, no RNG (mcl_gather_by_cdf).
-void launch_gather_by_cdf(hipStream_t st, ParticleSoA src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
-                          double* ox, double* oy, double* oc, double* os);
 // Sharded resampling helpers (mcl_resample_targets / mcl_commit_resampled).
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
                              uint64_t count, uint64_t n_free, double* d_targets);
-void launch_commit_resampled(hipStream_t st, ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
-                             const double* x, const double* y, const double* c, const double* s, const double* targets, GridView g,
-                             FreeCells fc);
 // Counting sort of resample targets by owning shard; d_block_hist needs world * num_chunks(count) words.
 void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t count, const double* d_ends, const double* d_offsets,
                           uint32_t world, uint32_t self_rank, uint8_t* d_dest, uint32_t* d_block_hist, uint32_t* d_chunk_sum,
                           uint32_t* d_chunk_off, double* d_send_targets, uint32_t* d_order, long long* d_counts);
-void launch_gather_by_cdf_aos(hipStream_t st, ParticleSoA src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
+void launch_gather_by_cdf_aos(hipStream_t st, Particles src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
                               double* d_out);
-void launch_commit_routed(hipStream_t st, ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
+void launch_commit_routed(hipStream_t st, Particles dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
                           const double* d_replies, const uint32_t* d_order, const double* d_targets, GridView g, FreeCells fc);
 // K7: exact parallel take_while_kld (take_while_kld.hpp:72-88).
 void launch_finish_candidates(hipStream_t st, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,
@@ -185,21 +180,21 @@ void launch_kld_scan(hipStream_t st, const unsigned long long* d_hashes, uint64_
                      uint32_t* d_flags_scan, uint32_t* d_chunk_sum, uint32_t* d_chunk_offset, const uint32_t* d_k_base,
                      uint32_t* d_k_total, uint64_t min_particles, double epsilon, double z, unsigned long long* d_first_fail);
 // K8: estimation.hpp:436-475 sufficient statistics; d_out[9].
-void launch_estimate_sums(hipStream_t st, ParticleSoA p, uint64_t n, double pivot_x, double pivot_y, double* d_partials,
+void launch_estimate_sums(hipStream_t st, Particles p, uint64_t n, double pivot_x, double pivot_y, double* d_partials,
                           double* d_out);
 // cluster_based_estimate (algorithm/cluster_based_estimation.hpp): hash + per-cell aggregation + compaction of the occupied
 // cells (for the host's cluster assignment), the write-back of the cells' cluster ids and the masked estimate sums.
-void launch_cluster_cells(hipStream_t st, ParticleSoA p, uint64_t n, HashParams hp, unsigned long long* d_hashes,
+void launch_cluster_cells(hipStream_t st, Particles p, uint64_t n, HashParams hp, unsigned long long* d_hashes,
                           unsigned long long* t_keys, unsigned int* t_first, double* t_wsum, unsigned int* t_count,
                           unsigned int* t_cluster, uint64_t capacity, unsigned long long* c_key, unsigned int* c_first,
                           unsigned int* c_count, unsigned int* c_slot, double* c_wsum, double* c_state, unsigned int* c_size);
 void launch_cell_set_cluster(hipStream_t st, const unsigned int* d_slot, const unsigned int* d_cluster, uint32_t m,
                              unsigned int* t_cluster);
-void launch_estimate_sums_cluster(hipStream_t st, ParticleSoA p, uint64_t n, const unsigned long long* d_hashes,
+void launch_estimate_sums_cluster(hipStream_t st, Particles p, uint64_t n, const unsigned long long* d_hashes,
                                   unsigned long long* t_keys, unsigned int* t_cluster, uint64_t capacity, unsigned int wanted,
                                   double pivot_x, double pivot_y, double* d_partials, double* d_out);
 // init: multivariate_normal_distribution.hpp:96-126 with T = V sqrt(L)
-void launch_init_normal(hipStream_t st, ParticleSoA p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
+void launch_init_normal(hipStream_t st, Particles p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
                         uint64_t index_offset);
 void launch_fill(hipStream_t st, double* p, uint64_t n, double v);
 // cube[i] = double(field[i])^3 (or log(double(field[i])) for the prob model) for i < cells, cube[cells] = same for `unknown`
@@ -208,7 +203,5 @@ void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float
 void launch_palette_table(hipStream_t st, const float* field, uint32_t W, uint32_t H, float unknown_value, const uint32_t* keys,
                           uint32_t count, int prob, uint16_t* idx, double* val, uint32_t pal_base);
 // AoS (c,s,x,y) host layout <-> SoA device layout
-void launch_aos_to_soa(hipStream_t st, const double* aos, ParticleSoA p, uint64_t n);
-void launch_soa_to_aos(hipStream_t st, ParticleSoA p, double* aos, uint64_t n);
 
 }  // namespace mcl

@@ -31,12 +31,12 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 
-__device__ __forceinline__ Pose2 load_pose(const ParticleSoA& p, uint64_t i) { return Pose2{Rot2{p.c[i], p.s[i]}, p.x[i], p.y[i]}; }
-__device__ __forceinline__ void store_pose(const ParticleSoA& p, uint64_t i, const Pose2& v) {
-  p.c[i] = v.r.c;
-  p.s[i] = v.r.s;
-  p.x[i] = v.x;
-  p.y[i] = v.y;
+__device__ __forceinline__ Pose2 load_pose(const Particles& p, uint64_t i) {
+  const double4 v = p.pose[i];
+  return Pose2{Rot2{v.x, v.y}, v.z, v.w};
+}
+__device__ __forceinline__ void store_pose(const Particles& p, uint64_t i, const Pose2& v) {
+  p.pose[i] = double4{v.r.c, v.r.s, v.x, v.y};
 }
 
 // ---- cross-lane helpers ---------------------------------------------------------------------------
@@ -84,7 +84,7 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], double* s_scratch /
 }
 
 // ---- K1 propagate ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_propagate(ParticleSoA p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
+__global__ __launch_bounds__(kBlock) void k_propagate(Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
                                                       uint64_t index_offset) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -190,7 +190,7 @@ __device__ __forceinline__ double lf_cube_fetch(__amdgpu_buffer_rsrc_t rsrc, con
 // A wave owns a tile of 64 particles: the 64 world->field transforms are computed lane-parallel, then
 // broadcast one at a time through SGPRs (v_readlane), so the per-beam math has scalar pose operands.
 template <bool kIdx32>
-__global__ __launch_bounds__(kBlock) void k_reweight_lf_wave(ParticleSoA p, uint64_t n, FieldView f, const double2* __restrict__ pts,
+__global__ __launch_bounds__(kBlock) void k_reweight_lf_wave(Particles p, uint64_t n, FieldView f, const double2* __restrict__ pts,
                                                              uint32_t B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2* s_pts = reinterpret_cast<double2*>(smem);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_wave(ParticleSoA p, uint
 // Variant B — one lane per particle, every lane walks the scan in order; the scan is read with scalar
 // loads (wave-uniform address), the sum is the reference's sequential `1 + sum pz^3` bit for bit.
 template <bool kIdx32>
-__global__ __launch_bounds__(kBlock) void k_reweight_lf_lane(ParticleSoA p, uint64_t n, FieldView f, const double* __restrict__ pts,
+__global__ __launch_bounds__(kBlock) void k_reweight_lf_lane(Particles p, uint64_t n, FieldView f, const double* __restrict__ pts,
                                                              uint32_t B) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   Pose2 state = pose_identity();
@@ -421,16 +421,17 @@ __device__ __forceinline__ double heading_delta(double c, double s, double c0, d
 }
 
 // bbox = {min x, max x, min y, max y, min dtheta, max dtheta}; dtheta relative to particle 0's heading.
-__global__ __launch_bounds__(kBlock) void k_bbox_partials(ParticleSoA p, uint64_t n, double* __restrict__ partials, uint32_t stride) {
+__global__ __launch_bounds__(kBlock) void k_bbox_partials(Particles p, uint64_t n, double* __restrict__ partials, uint32_t stride) {
   __shared__ double scratch[(kBlock / 64) * 6];
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * (kChunk / kBlock);
-  const double c0 = p.c[0], s0 = p.s[0];
+  const double c0 = p.pose[0].x, s0 = p.pose[0].y;
   double v[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
 #pragma unroll
   for (int k = 0; k < kChunk / kBlock; ++k) {
     const uint64_t i = base + k;
     if (i < n) {
-      const double x = p.x[i], y = p.y[i], d = heading_delta(p.c[i], p.s[i], c0, s0);
+      const double4 q = p.pose[i];
+      const double x = q.z, y = q.w, d = heading_delta(q.x, q.y, c0, s0);
       v[0] = fmin(v[0], x);
       v[1] = fmax(v[1], x);
       v[2] = fmin(v[2], y);
@@ -502,22 +503,23 @@ __device__ __forceinline__ int bin_of(double v, double lo, double hi, int bins) 
   return min(max(b, 0), bins - 1);
 }
 // Key: the extra heading bits on top, then Morton (heading, y, x) over kb.xy bits each.
-__device__ __forceinline__ uint32_t sort_key(const ParticleSoA& p, uint64_t i, const double* __restrict__ bbox, double c0, double s0,
+__device__ __forceinline__ uint32_t sort_key(const Particles& p, uint64_t i, const double* __restrict__ bbox, double c0, double s0,
                                              KeyBits kb) {
-  const int bx = bin_of(p.x[i], bbox[0], bbox[1], 1 << kb.xy);
-  const int by = bin_of(p.y[i], bbox[2], bbox[3], 1 << kb.xy);
-  const int bt = bin_of(heading_delta(p.c[i], p.s[i], c0, s0), bbox[4], bbox[5], 1 << kb.theta);
+  const double4 q = p.pose[i];
+  const int bx = bin_of(q.z, bbox[0], bbox[1], 1 << kb.xy);
+  const int by = bin_of(q.w, bbox[2], bbox[3], 1 << kb.xy);
+  const int bt = bin_of(heading_delta(q.x, q.y, c0, s0), bbox[4], bbox[5], 1 << kb.theta);
   const uint32_t lo = kb.xy;
   return (static_cast<uint32_t>(bt >> lo) << (3 * lo)) | spread3(bx) | (spread3(by) << 1) | (spread3(bt & ((1 << lo) - 1)) << 2);
 }
 
-__global__ __launch_bounds__(kBlock) void k_sort_hist(ParticleSoA p, uint64_t n, const double* __restrict__ bbox,
+__global__ __launch_bounds__(kBlock) void k_sort_hist(Particles p, uint64_t n, const double* __restrict__ bbox,
                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ block_hist,
                                                       uint32_t nblocks, KeyBits kb) {
   __shared__ uint32_t hist[kDigits];
   for (uint32_t d = threadIdx.x; d < kDigits; d += kBlock) hist[d] = 0;
   __syncthreads();
-  const double c0 = p.c[0], s0 = p.s[0];
+  const double c0 = p.pose[0].x, s0 = p.pose[0].y;
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
 #pragma unroll
   for (int k = 0; k < kChunk / kBlock; ++k) {
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restr
 
 // Bitonic sort of each 2048-element block of (key << 32 | index) in LDS, then emit the permutation and
 // the world->field pose of every particle in sorted order (likelihood_field_model.hpp:70).
-__global__ __launch_bounds__(kBlock) void k_sort_blocks(const unsigned long long* __restrict__ in, uint64_t n, ParticleSoA p,
+__global__ __launch_bounds__(kBlock) void k_sort_blocks(const unsigned long long* __restrict__ in, uint64_t n, Particles p,
                                                         Pose2 world_to_field, uint32_t* __restrict__ perm, double* __restrict__ tc,
                                                         double* __restrict__ ts, double* __restrict__ tx, double* __restrict__ ty,
                                                         int fine) {
@@ -887,7 +889,7 @@ __device__ __forceinline__ double beam_term(const GridView& g, const BeamModel& 
 }
 
 // Variant A: one wavefront per particle, one lane per beam (small particle sets).
-__global__ __launch_bounds__(kBlock) void k_reweight_beam(ParticleSoA p, uint64_t n, GridView g, BeamModel m,
+__global__ __launch_bounds__(kBlock) void k_reweight_beam(Particles p, uint64_t n, GridView g, BeamModel m,
                                                           const double2* __restrict__ pts, uint32_t B, unsigned long long* d_steps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2* s_pts = reinterpret_cast<double2*>(smem);
@@ -1172,8 +1174,8 @@ __device__ __forceinline__ bool intersperse_here(const RngWords& r, uint64_t j, 
   return j > 0 && p > 0.0 && rng_uniform32(r.w[2]) < p && n_free > 0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_resample_draw(ParticleSoA src, const double* __restrict__ cdf, const double* __restrict__ d_total,
-                                                          ParticleSoA dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
+__global__ __launch_bounds__(kBlock) void k_resample_draw(Particles src, const double* __restrict__ cdf, const double* __restrict__ d_total,
+                                                          Particles dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
                                                           unsigned long long* __restrict__ hashes) {
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (t >= a.count) return;
@@ -1197,18 +1199,6 @@ __global__ __launch_bounds__(kBlock) void k_resample_draw(ParticleSoA src, const
   if (hashes) hashes[o] = spatial_hash(s, hp);
 }
 
-__global__ __launch_bounds__(kBlock) void k_gather_by_cdf(ParticleSoA src, const double* __restrict__ cdf, uint64_t n,
-                                                          const double* __restrict__ targets, uint64_t m, double* ox, double* oy,
-                                                          double* oc, double* os) {
-  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (t >= m) return;
-  const uint64_t idx = cdf_lower_bound(cdf, n, targets[t]);
-  ox[t] = src.x[idx];
-  oy[t] = src.y[idx];
-  oc[t] = src.c[idx];
-  os[t] = src.s[idx];
-}
-
 // -- sharded resampling (one context per GPU; the exchange between them is done by the caller) -----------
 // targets[t] = u_j * total for output slot j = first_slot + t, NaN where the slot takes an injected random state.
 __global__ __launch_bounds__(kBlock) void k_resample_targets(uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
@@ -1218,22 +1208,6 @@ __global__ __launch_bounds__(kBlock) void k_resample_targets(uint64_t seed, uint
   const uint64_t j = first_slot + t;
   const RngWords r = rng_draw(seed, step, kRngResample, j);
   targets[t] = intersperse_here(r, j, p, n_free) ? __builtin_nan("") : rng_uniform53(r.w[0], r.w[1]) * total;
-}
-
-__global__ __launch_bounds__(kBlock) void k_commit_resampled(ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot,
-                                                             uint64_t count, const double* __restrict__ x, const double* __restrict__ y,
-                                                             const double* __restrict__ c, const double* __restrict__ s,
-                                                             const double* __restrict__ targets, GridView g, FreeCells fc) {
-  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (t >= count) return;
-  Pose2 v;
-  if (targets[t] != targets[t]) {
-    v = random_free_state(seed, step, first_slot + t, g, fc);
-  } else {
-    v = Pose2{Rot2{c[t], s[t]}, x[t], y[t]};
-  }
-  store_pose(dst, t, v);
-  dst.w[t] = 1.0;
 }
 
 // Routing of the resample targets to the shards that own them (counting sort by destination rank, <= 64 ranks).
@@ -1303,15 +1277,16 @@ __global__ void k_route_counts(const uint32_t* __restrict__ block_offsets, uint3
 }
 
 // AoS variants for the exchange buffers: reply[t] = (x, y, c, s) of the served ancestor.
-__global__ __launch_bounds__(kBlock) void k_gather_by_cdf_aos(ParticleSoA src, const double* __restrict__ cdf, uint64_t n,
+__global__ __launch_bounds__(kBlock) void k_gather_by_cdf_aos(Particles src, const double* __restrict__ cdf, uint64_t n,
                                                               const double* __restrict__ targets, uint64_t m, double4* __restrict__ out) {
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (t >= m) return;
   const uint64_t idx = cdf_lower_bound(cdf, n, targets[t]);
-  out[t] = double4{src.x[idx], src.y[idx], src.c[idx], src.s[idx]};
+  const double4 v = src.pose[idx];
+  out[t] = double4{v.z, v.w, v.x, v.y};
 }
 
-__global__ __launch_bounds__(kBlock) void k_commit_routed(ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot,
+__global__ __launch_bounds__(kBlock) void k_commit_routed(Particles dst, uint64_t seed, uint32_t step, uint64_t first_slot,
                                                           uint64_t count, const double4* __restrict__ replies,
                                                           const uint32_t* __restrict__ order, const double* __restrict__ targets,
                                                           GridView g, FreeCells fc) {
@@ -1478,7 +1453,7 @@ __global__ __launch_bounds__(kBlock) void k_kld_check(uint64_t first, uint64_t c
 
 // ---- K8 estimate -------------------------------------------------------------------------------------------
 constexpr int kEstK = 9;
-__global__ __launch_bounds__(kBlock) void k_estimate_partials(ParticleSoA p, uint64_t n, double pivot_x, double pivot_y,
+__global__ __launch_bounds__(kBlock) void k_estimate_partials(Particles p, uint64_t n, double pivot_x, double pivot_y,
                                                               double* __restrict__ partials, uint32_t stride) {
   __shared__ double scratch[(kBlock / 64) * kEstK];
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
@@ -1490,11 +1465,12 @@ __global__ __launch_bounds__(kBlock) void k_estimate_partials(ParticleSoA p, uin
     const uint64_t i = base + k;
     if (i < n) {
       const double w = p.w[i];
-      const double dx = p.x[i] - pivot_x, dy = p.y[i] - pivot_y;
+      const double4 q = p.pose[i];
+      const double dx = q.z - pivot_x, dy = q.w - pivot_y;
       v[0] += w;
       v[1] += w * w;
-      v[2] += w * p.c[i];
-      v[3] += w * p.s[i];
+      v[2] += w * q.x;
+      v[3] += w * q.y;
       v[4] += w * dx;
       v[5] += w * dy;
       v[6] += w * dx * dx;
@@ -1514,7 +1490,7 @@ __global__ __launch_bounds__(kBlock) void k_estimate_partials(ParticleSoA p, uin
 // the occupied cells for the host, and the masked estimate of the winning cluster.  The cluster assignment itself is
 // a priority-queue flood fill over a few hundred cells and stays on the host (context.hip), with the reference's own
 // standard containers so that ties resolve the same way.
-__global__ __launch_bounds__(kBlock) void k_cluster_hash(ParticleSoA p, uint64_t n, HashParams hp, unsigned long long* __restrict__ hashes) {
+__global__ __launch_bounds__(kBlock) void k_cluster_hash(Particles p, uint64_t n, HashParams hp, unsigned long long* __restrict__ hashes) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i < n) hashes[i] = spatial_hash(load_pose(p, i), hp);
 }
@@ -1585,7 +1561,7 @@ struct CellList {  // compacted occupied cells, arbitrary order (the host sorts 
   unsigned int* size;
 };
 
-__global__ __launch_bounds__(kBlock) void k_cell_compact(CellTable t, ParticleSoA p, CellList out) {
+__global__ __launch_bounds__(kBlock) void k_cell_compact(CellTable t, Particles p, CellList out) {
   const uint64_t s = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (s >= t.capacity || t.keys[s] == kEmptyKey) return;
   const unsigned int k = atomicAdd(out.size, 1u);
@@ -1595,7 +1571,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_compact(CellTable t, ParticleSo
   out.count[k] = t.count[s];
   out.slot[k] = static_cast<unsigned int>(s);
   out.wsum[k] = t.wsum[s];
-  out.state[k] = double4{p.c[f], p.s[f], p.x[f], p.y[f]};
+  out.state[k] = p.pose[f];
 }
 
 __global__ __launch_bounds__(kBlock) void k_cell_set_cluster(const unsigned int* __restrict__ slot, const unsigned int* __restrict__ cluster,
@@ -1605,7 +1581,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_set_cluster(const unsigned int*
 }
 
 // estimation.hpp:436-475 restricted to the particles whose cell belongs to cluster `wanted`.
-__global__ __launch_bounds__(kBlock) void k_estimate_partials_cluster(ParticleSoA p, uint64_t n, const unsigned long long* __restrict__ hashes,
+__global__ __launch_bounds__(kBlock) void k_estimate_partials_cluster(Particles p, uint64_t n, const unsigned long long* __restrict__ hashes,
                                                                       CellTable t, unsigned int wanted, double pivot_x, double pivot_y,
                                                                       double* __restrict__ partials, uint32_t stride) {
   __shared__ double scratch[(kBlock / 64) * kEstK];
@@ -1623,11 +1599,12 @@ __global__ __launch_bounds__(kBlock) void k_estimate_partials_cluster(ParticleSo
       while (t.keys[slot] != key) slot = (slot + 1) & mask;
       if (t.cluster[slot] == wanted) {
         const double w = p.w[i];
-        const double dx = p.x[i] - pivot_x, dy = p.y[i] - pivot_y;
+        const double4 q = p.pose[i];
+        const double dx = q.z - pivot_x, dy = q.w - pivot_y;
         v[0] += w;
         v[1] += w * w;
-        v[2] += w * p.c[i];
-        v[3] += w * p.s[i];
+        v[2] += w * q.x;
+        v[3] += w * q.y;
         v[4] += w * dx;
         v[5] += w * dy;
         v[6] += w * dx * dx;
@@ -1644,7 +1621,7 @@ __global__ __launch_bounds__(kBlock) void k_estimate_partials_cluster(ParticleSo
 }
 
 // ---- misc -----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_init_normal(ParticleSoA p, uint64_t n, double m0, double m1, double m2, double t00,
+__global__ __launch_bounds__(kBlock) void k_init_normal(Particles p, uint64_t n, double m0, double m1, double m2, double t00,
                                                         double t01, double t02, double t10, double t11, double t12, double t20,
                                                         double t21, double t22, uint64_t seed, uint64_t index_offset) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -1701,33 +1678,18 @@ __global__ __launch_bounds__(kBlock) void k_fill(double* p, uint64_t n, double v
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i < n) p[i] = v;
 }
-__global__ __launch_bounds__(kBlock) void k_aos_to_soa(const double* __restrict__ aos, ParticleSoA p, uint64_t n) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const double4 v = reinterpret_cast<const double4*>(aos)[i];
-  p.c[i] = v.x;
-  p.s[i] = v.y;
-  p.x[i] = v.z;
-  p.y[i] = v.w;
-}
-__global__ __launch_bounds__(kBlock) void k_soa_to_aos(ParticleSoA p, double* __restrict__ aos, uint64_t n) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i >= n) return;
-  reinterpret_cast<double4*>(aos)[i] = double4{p.c[i], p.s[i], p.x[i], p.y[i]};
-}
-
 inline unsigned blocks_for(uint64_t n) { return static_cast<unsigned>((n + kBlock - 1) / kBlock); }
 
 }  // namespace
 
 // =====================================================================================================
-void launch_propagate(hipStream_t st, ParticleSoA p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
+void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
                       uint64_t index_offset) {
   if (n == 0) return;
   hipLaunchKernelGGL(k_propagate, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, smp, seed, step, index_offset);
 }
 
-void launch_lf_bin_sort(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const SortScratch* sort) {
+void launch_lf_bin_sort(hipStream_t st, Particles p, uint64_t n, FieldView f, const SortScratch* sort) {
   if (n == 0 || !sort || n >= (1ull << 32)) return;
   const uint32_t nblocks = num_chunks(n);
   double* partials = sort->bbox + 8;
@@ -1755,7 +1717,7 @@ void launch_lf_bin_sort(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, 
                      sort->ts, sort->tx, sort->ty, fine);
 }
 
-void launch_reweight_lf(hipStream_t st, ParticleSoA p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
+void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort) {
   if (n == 0) return;
   const bool idx32 = static_cast<uint64_t>(f.W) * f.H < (1ull << 31);
@@ -1812,7 +1774,7 @@ void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32
   hipLaunchKernelGGL(k_pack_nonfree, dim3(blocks_for(words)), dim3(kBlock), 0, st, cells, W, H, free_value, words_per_row, bits);
 }
 
-void launch_reweight_beam(hipStream_t st, ParticleSoA p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
+void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
                           unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits) {
   if (n == 0) return;
   if (sorted && nonfree_bits) {
@@ -1858,31 +1820,19 @@ void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum
   hipLaunchKernelGGL(k_cdf, dim3(chunks), dim3(kBlock), 0, st, w, n, d_chunk_offset, cdf, d_total);
 }
 
-void launch_resample_draw(hipStream_t st, ParticleSoA src, const double* cdf, const double* d_total, ParticleSoA dst,
+void launch_resample_draw(hipStream_t st, Particles src, const double* cdf, const double* d_total, Particles dst,
                           ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes) {
   if (a.count == 0) return;
   hipLaunchKernelGGL(k_resample_draw, dim3(blocks_for(a.count)), dim3(kBlock), 0, st, src, cdf, d_total, dst, a, g, fc, hp,
                      d_hashes);
 }
 
-void launch_gather_by_cdf(hipStream_t st, ParticleSoA src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
-                          double* ox, double* oy, double* oc, double* os) {
-  if (m == 0) return;
-  hipLaunchKernelGGL(k_gather_by_cdf, dim3(blocks_for(m)), dim3(kBlock), 0, st, src, cdf, n, d_targets, m, ox, oy, oc, os);
-}
 
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
                              uint64_t count, uint64_t n_free, double* d_targets) {
   if (count == 0) return;
   hipLaunchKernelGGL(k_resample_targets, dim3(blocks_for(count)), dim3(kBlock), 0, st, seed, step, p, total, first_slot, count, n_free,
                      d_targets);
-}
-void launch_commit_resampled(hipStream_t st, ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
-                             const double* x, const double* y, const double* c, const double* s, const double* targets, GridView g,
-                             FreeCells fc) {
-  if (count == 0) return;
-  hipLaunchKernelGGL(k_commit_resampled, dim3(blocks_for(count)), dim3(kBlock), 0, st, dst, seed, step, first_slot, count, x, y, c, s,
-                     targets, g, fc);
 }
 
 void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t count, const double* d_ends, const double* d_offsets,
@@ -1905,13 +1855,13 @@ void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t coun
   hipLaunchKernelGGL(k_route_scatter, dim3(nblocks), dim3(kBlock), 0, st, d_targets, count, d_offsets, world, d_dest, d_block_hist,
                      nblocks, d_send_targets, d_order);
 }
-void launch_gather_by_cdf_aos(hipStream_t st, ParticleSoA src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
+void launch_gather_by_cdf_aos(hipStream_t st, Particles src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
                               double* d_out) {
   if (m == 0) return;
   hipLaunchKernelGGL(k_gather_by_cdf_aos, dim3(blocks_for(m)), dim3(kBlock), 0, st, src, cdf, n, d_targets, m,
                      reinterpret_cast<double4*>(d_out));
 }
-void launch_commit_routed(hipStream_t st, ParticleSoA dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
+void launch_commit_routed(hipStream_t st, Particles dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
                           const double* d_replies, const uint32_t* d_order, const double* d_targets, GridView g, FreeCells fc) {
   if (count == 0) return;
   hipLaunchKernelGGL(k_commit_routed, dim3(blocks_for(count)), dim3(kBlock), 0, st, dst, seed, step, first_slot, count,
@@ -1944,14 +1894,14 @@ void launch_kld_scan(hipStream_t st, const unsigned long long* d_hashes, uint64_
                      2 * epsilon, z, d_first_fail);
 }
 
-void launch_estimate_sums(hipStream_t st, ParticleSoA p, uint64_t n, double pivot_x, double pivot_y, double* d_partials,
+void launch_estimate_sums(hipStream_t st, Particles p, uint64_t n, double pivot_x, double pivot_y, double* d_partials,
                           double* d_out) {
   const uint32_t chunks = num_chunks(n);
   if (chunks) hipLaunchKernelGGL(k_estimate_partials, dim3(chunks), dim3(kBlock), 0, st, p, n, pivot_x, pivot_y, d_partials, chunks);
   hipLaunchKernelGGL(k_final_sum<kEstK>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out);
 }
 
-void launch_cluster_cells(hipStream_t st, ParticleSoA p, uint64_t n, HashParams hp, unsigned long long* d_hashes,
+void launch_cluster_cells(hipStream_t st, Particles p, uint64_t n, HashParams hp, unsigned long long* d_hashes,
                           unsigned long long* t_keys, unsigned int* t_first, double* t_wsum, unsigned int* t_count,
                           unsigned int* t_cluster, uint64_t capacity, unsigned long long* c_key, unsigned int* c_first,
                           unsigned int* c_count, unsigned int* c_slot, double* c_wsum, double* c_state, unsigned int* c_size) {
@@ -1967,7 +1917,7 @@ void launch_cell_set_cluster(hipStream_t st, const unsigned int* d_slot, const u
   if (m == 0) return;
   hipLaunchKernelGGL(k_cell_set_cluster, dim3(blocks_for(m)), dim3(kBlock), 0, st, d_slot, d_cluster, m, t_cluster);
 }
-void launch_estimate_sums_cluster(hipStream_t st, ParticleSoA p, uint64_t n, const unsigned long long* d_hashes,
+void launch_estimate_sums_cluster(hipStream_t st, Particles p, uint64_t n, const unsigned long long* d_hashes,
                                   unsigned long long* t_keys, unsigned int* t_cluster, uint64_t capacity, unsigned int wanted,
                                   double pivot_x, double pivot_y, double* d_partials, double* d_out) {
   const uint32_t chunks = num_chunks(n);
@@ -1978,7 +1928,7 @@ void launch_estimate_sums_cluster(hipStream_t st, ParticleSoA p, uint64_t n, con
   hipLaunchKernelGGL(k_final_sum<kEstK>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out);
 }
 
-void launch_init_normal(hipStream_t st, ParticleSoA p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
+void launch_init_normal(hipStream_t st, Particles p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
                         uint64_t index_offset) {
   if (n == 0) return;
   hipLaunchKernelGGL(k_init_normal, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, mean[0], mean[1], mean[2], T[0], T[1], T[2],
@@ -1999,14 +1949,6 @@ void launch_palette_table(hipStream_t st, const float* field, uint32_t W, uint32
 void launch_fill(hipStream_t st, double* p, uint64_t n, double v) {
   if (n == 0) return;
   hipLaunchKernelGGL(k_fill, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, v);
-}
-void launch_aos_to_soa(hipStream_t st, const double* aos, ParticleSoA p, uint64_t n) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(k_aos_to_soa, dim3(blocks_for(n)), dim3(kBlock), 0, st, aos, p, n);
-}
-void launch_soa_to_aos(hipStream_t st, ParticleSoA p, double* aos, uint64_t n) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(k_soa_to_aos, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, aos, n);
 }
 
 }  // namespace mcl

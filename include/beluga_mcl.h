@@ -230,10 +230,7 @@ mcl_status mcl_set_estimate_kind(mcl_ctx* ctx, int32_t kind, const mcl_cluster_p
 
 /* ---- Device access for zero-copy interop (torch / RCCL hand-off) -------------------------------- */
 typedef struct mcl_device_view {
-  double* x;
-  double* y;
-  double* c;
-  double* s;
+  double* states;     /* n records of 4 doubles (cos, sin, x, y) */
   double* w;
   double* cdf;        /* inclusive scan of the normalised weights (valid after mcl_build_cdf) */
   uint64_t n;         /* live particles in this shard */
@@ -244,22 +241,12 @@ mcl_status mcl_get_device_view(mcl_ctx* ctx, mcl_device_view* view);
 mcl_status mcl_set_num_particles(mcl_ctx* ctx, uint64_t n);
 /* Inclusive scan of the (normalised) weights into the cdf buffer; returns the shard total. */
 mcl_status mcl_build_cdf(mcl_ctx* ctx, double* total);
-/* Sharded multinomial draw: for each of `m` targets t[j] (device pointer, values in this shard's cdf
- * range [0,total]) write the state of the first particle i with cdf[i] >= t[j] to out_state[4][m] (SoA,
- * device pointers). std::discrete_distribution's lower_bound (views/sample.hpp:133-135). */
-mcl_status mcl_gather_by_cdf(mcl_ctx* ctx, const double* d_targets, uint64_t m, double* d_out_x, double* d_out_y,
-                             double* d_out_c, double* d_out_s);
 /* Sharded views::sample | random_intersperse (views/sample.hpp:102,133-135; random_intersperse.hpp:90-115) for the
  * `count` output slots [first_slot, first_slot+count) of the GLOBAL particle index space:
  * d_targets[t] = u_j * total (a point of the global CDF, total = sum of all shards' weights), or NaN where the
  * slot receives an injected random state.  u_j comes from the same Philox stream as the single-GPU path. */
 mcl_status mcl_resample_targets(mcl_ctx* ctx, uint32_t step, double random_state_probability, double total,
                                 uint64_t first_slot, uint64_t count, double* d_targets);
-/* actions::assign (actions/assign.hpp:56-64) of the exchanged ancestors: slot t takes (d_x,d_y,d_c,d_s)[t], or a
- * random free-space state where d_targets[t] is NaN; weights become 1 (particle_traits.hpp:105); the shard then
- * holds `count` particles. */
-mcl_status mcl_commit_resampled(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_x,
-                                const double* d_y, const double* d_c, const double* d_s, const double* d_targets);
 /* Routing for the ancestor exchange (device pointers throughout, nothing synchronises):
  * groups the `count` targets of mcl_resample_targets by the shard that owns them. `d_ends[r]` / `d_offsets[r]` are the
  * inclusive end / exclusive start of shard r's interval of the global CDF (world <= 64).  Outputs: d_send_targets =
@@ -267,9 +254,13 @@ mcl_status mcl_commit_resampled(mcl_ctx* ctx, uint32_t step, uint64_t first_slot
  * d_counts[r] (int64) = requests for rank r.  NaN targets (injected slots) are routed to `self_rank`. */
 mcl_status mcl_route_targets(mcl_ctx* ctx, const double* d_targets, uint64_t count, const double* d_ends, const double* d_offsets,
                              uint32_t world, uint32_t self_rank, double* d_send_targets, uint32_t* d_order, int64_t* d_counts);
-/* As mcl_gather_by_cdf with one (x, y, cos, sin) record of 4 doubles per request. */
+/* The owning shard's side of the exchange: for each of the `m` requests t[j] (values in this shard's cdf range
+ * [0, total]) the state of the first particle i with cdf[i] >= t[j] — std::discrete_distribution's lower_bound
+ * (views/sample.hpp:133-135) — as one (x, y, cos, sin) record of 4 doubles. */
 mcl_status mcl_serve_requests(mcl_ctx* ctx, const double* d_requests, uint64_t m, double* d_replies);
-/* As mcl_commit_resampled, taking the replies in request order plus the d_order of mcl_route_targets. */
+/* actions::assign (actions/assign.hpp:56-64) of the exchanged ancestors, replies in request order plus the d_order of
+ * mcl_route_targets: slot d_order[k] takes reply k, or a random free-space state where its target is NaN; weights become
+ * 1 (particle_traits.hpp:105); the shard then holds `count` particles. */
 mcl_status mcl_commit_routed(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,
                              const uint32_t* d_order, const double* d_targets);
 /* KLD-adaptive resampling across shards (views/take_while_kld.hpp:72-88,112-137 over the GLOBAL candidate stream).
