@@ -319,7 +319,13 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
 // floors, 2 clamps, 2 for the table offset (the row part comes from a row-offset table in LDS), 1 add.
 // Workgroup memory: [0, (H+2)*4) row offsets for y = -1 .. H, [pal_base, pal_base + 8 * pal_count) the palette; the kernel
 // has no other LDS, so these are absolute LDS addresses.
-constexpr int kPalBlock = 512;
+#ifndef LF_PAL_BLOCK
+#define LF_PAL_BLOCK 512
+#endif
+#ifndef LF_PAL_WAVES
+#define LF_PAL_WAVES 1
+#endif
+constexpr int kPalBlock = LF_PAL_BLOCK;
 typedef __attribute__((address_space(3))) const double lds_f64_t;
 typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
 __device__ __forceinline__ int clamp_cell(int v, uint32_t hi) {  // max(-1, min(v, hi)) in one instruction
@@ -327,17 +333,19 @@ __device__ __forceinline__ int clamp_cell(int v, uint32_t hi) {  // max(-1, min(
   asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(v), "s"(hi));
   return r;
 }
-__device__ __forceinline__ uint32_t lf_palette_fetch(__amdgpu_buffer_rsrc_t rsrc, const FieldView& f, int xi, int yi) {
+__device__ __forceinline__ uint32_t lf_palette_offset(const FieldView& f, int xi, int yi) {
   const int xc = clamp_cell(xi, f.W), yc = clamp_cell(yi, f.H);
   const uint32_t row = *reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>(static_cast<uint32_t>(yc + 1) << 2));
-  const uint32_t offset = (static_cast<uint32_t>(xc) << 4) + row;
-  return static_cast<uint32_t>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, offset, 0, 0)));
+  return (static_cast<uint32_t>(xc) << 4) + row;
+}
+__device__ __forceinline__ uint32_t lf_palette_fetch(__amdgpu_buffer_rsrc_t rsrc, const FieldView& f, int xi, int yi) {
+  return static_cast<uint32_t>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, lf_palette_offset(f, xi, yi), 0, 0)));
 }
 __device__ __forceinline__ double lf_palette_value(uint32_t lds_address) {
   return *reinterpret_cast<lds_f64_t*>(static_cast<uintptr_t>(lds_address));
 }
 
-__global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __restrict__ w, uint64_t n, FieldView f,
+__global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(LF_PAL_WAVES, 8))) void k_reweight_lf_palette(double* __restrict__ w, uint64_t n, FieldView f,
                                                                    const double* __restrict__ pts, uint32_t B,
                                                                    const uint32_t* __restrict__ perm, const double* __restrict__ tc,
                                                                    const double* __restrict__ ts, const double* __restrict__ tx,
@@ -359,21 +367,48 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
   double acc = (f.prob || partial) ? 0.0 : 1.0;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(f.pal_idx), 0, static_cast<int>(f.pal_bytes), 0x00020000);
-  uint32_t b = b_begin;
-  for (; b + 8 <= b_end; b += 8) {
+  // Software-pipelined over groups of 8 beams, two groups (A, B) in flight alternately: the index gathers of one group
+  // are outstanding while the end-points of the next are computed; a group's palette values are added, in beam order,
+  // one step later.
+  auto issue = [&](uint32_t (&e)[8], uint32_t b0) {
     double v[16];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const double px = pts[2 * (b + k)], py = pts[2 * (b + k) + 1];
+      const double px = pts[2 * (b0 + k)], py = pts[2 * (b0 + k) + 1];
       v[2 * k] = (px * ct - py * st + xt) * f.inv_resolution;
       v[2 * k + 1] = (px * st + py * ct + yt) * f.inv_resolution;
     }
     floor_rd_16(v);
-    uint32_t e[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) e[k] = lf_palette_fetch(rsrc, f, floor_rd_result(v[2 * k]), floor_rd_result(v[2 * k + 1]));
+  };
+  auto consume = [&](uint32_t (&e)[8], bool) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc += lf_palette_value(e[k]);
+  };
+  uint32_t b = b_begin;
+  uint32_t groups = (b_end - b_begin) / 8;
+  if (groups) {
+    uint32_t ea[8], eb[8];
+    issue(ea, b);
+    b += 8;
+    --groups;
+    while (groups >= 2) {
+      issue(eb, b);
+      consume(ea, true);
+      issue(ea, b + 8);
+      consume(eb, true);
+      b += 16;
+      groups -= 2;
+    }
+    if (groups) {
+      issue(eb, b);
+      consume(ea, true);
+      consume(eb, false);
+      b += 8;
+    } else {
+      consume(ea, false);
+    }
   }
   for (; b < b_end; ++b) {
     const double px = pts[2 * b], py = pts[2 * b + 1];
