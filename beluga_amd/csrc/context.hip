@@ -207,6 +207,8 @@ struct mcl_ctx {
   DeviceBuffer<double> d_scalars;    // 32 doubles
   double* h_scalars{nullptr};        // pinned, 32 doubles
   DeviceBuffer<double> d_cdf;
+  DeviceBuffer<double> d_cdf_tree;  // sampled levels of the 16-ary search tree over d_cdf (CdfTree)
+  CdfTree cdf_tree() const { return make_cdf_tree(d_cdf.ptr, d_cdf_tree.ptr, n); }
 
   // KLD
   DeviceBuffer<unsigned long long> d_hashes;
@@ -241,6 +243,7 @@ struct mcl_ctx {
   bool have_pivot{false};
   double pivot[2]{0, 0};
   int lf_variant{kLfSortedLanes};
+  bool device_policy_allowed{true};  // BELUGA_MCL_DEVICE_POLICY=0 keeps the recovery estimator on the host (A/B, tests)
   // scratch of the spatially binned likelihood-field kernel
   DeviceBuffer<uint32_t> d_route_u32;           // scratch of mcl_route_targets
   DeviceBuffer<uint32_t> d_sort_u32;            // keys[cap] perm[cap] block_hist chunk_sum chunk_off
@@ -339,6 +342,7 @@ mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
   ctx->chunk_stride = chunks;
   MCL_HIP(ctx, ctx->d_chunk.ensure(static_cast<size_t>(12) * chunks));
   MCL_HIP(ctx, ctx->d_cdf.ensure(cap));
+  MCL_HIP(ctx, ctx->d_cdf_tree.ensure(cdf_tree_doubles(cap)));
   ctx->capacity = cap;
   {
     const size_t hist = static_cast<size_t>(kSortDigits) * num_chunks(cap);
@@ -523,7 +527,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B) {
 }
 
 // d_scalars layout: [0] weight sum, [1] norm_sum, [2] norm_sumsq, [3] factor override, [4] cdf total, [8..16] estimate sums
-mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats) {
+mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats, bool read_back = true) {
   stage_begin(ctx, MCL_STAGE_NORMALIZE);
   launch_weight_sum(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->d_scalars.ptr + 0);
   const double* d_factor = ctx->d_scalars.ptr + 0;
@@ -533,6 +537,11 @@ mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats) {
     d_factor = ctx->d_scalars.ptr + 3;
   }
   launch_normalize(ctx->stream, ctx->cur().w, ctx->n, d_factor, ctx->chunk_row(1), ctx->chunk_row(2), ctx->d_scalars.ptr + 1);
+  if (!read_back) {  // the caller reads d_scalars[0..3) back later, with its own synchronisation
+    stage_end(ctx, MCL_STAGE_NORMALIZE);
+    MCL_HIP(ctx, hipGetLastError());
+    return MCL_OK;
+  }
   MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars.ptr, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   stage_end(ctx, MCL_STAGE_NORMALIZE);
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -546,12 +555,14 @@ mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats) {
 }
 
 mcl_status do_build_cdf(mcl_ctx* ctx) {
-  launch_cdf(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(3), ctx->chunk_row(4), ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4);
+  launch_cdf(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(3), ctx->chunk_row(4), ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4,
+             ctx->d_cdf_tree.ptr);
   MCL_HIP(ctx, hipGetLastError());
   return MCL_OK;
 }
 
-mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t step, uint64_t* n_out) {
+mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t step, uint64_t* n_out,
+                       const double* d_random_state_probability = nullptr) {
   const mcl_amcl_params& a = ctx->cfg.amcl;
   MCL_REQUIRE(ctx, ctx->n > 0, "mcl_resample: empty particle set");
   const uint64_t max_p = std::min<uint64_t>(a.max_particles, ctx->capacity);
@@ -561,6 +572,7 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
   ra.seed = ctx->cfg.seed;
   ra.step = step;
   ra.random_state_probability = random_state_probability;
+  ra.d_random_state_probability = d_random_state_probability;
   ra.n_in = ctx->n;
   const FreeCells fc{ctx->d_free.ptr, ctx->have_map ? ctx->n_free : 0};
   const HashParams hp{a.spatial_resolution_x, a.spatial_resolution_y, a.spatial_resolution_theta};
@@ -571,7 +583,7 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
     ra.first_candidate = 0;
     ra.count = max_p;
     ra.out_offset = 0;
-    launch_resample_draw(ctx->stream, ctx->cur(), ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp, nullptr);
+    launch_resample_draw(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp, nullptr);
     MCL_HIP(ctx, hipGetLastError());
   } else {
     MCL_REQUIRE(ctx, max_p < 0xFFFFFFFFull, "max_particles too large for KLD resampling");
@@ -584,7 +596,7 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
       ra.first_candidate = pos;
       ra.count = cnt;
       ra.out_offset = pos;
-      launch_resample_draw(ctx->stream, ctx->cur(), ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp,
+      launch_resample_draw(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp,
                            ctx->d_hashes.ptr);
       uint64_t first_fail = ~0ull;
       if (const mcl_status s = kld_process(ctx, cnt, &first_fail)) return s;
@@ -842,12 +854,14 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     const uint64_t cap = cfg->shard_capacity ? cfg->shard_capacity : cfg->amcl.max_particles;
     if (const mcl_status s = ensure_capacity(ctx, cap)) return s;
     MCL_HIP(ctx, ctx->d_scalars.ensure(32));
+    MCL_HIP(ctx, hipMemsetAsync(ctx->d_scalars.ptr, 0, 32 * sizeof(double), ctx->stream));  // incl. the recovery filters
     MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalars), 32 * sizeof(double)));
     MCL_HIP(ctx, ctx->d_kld_scalars.ensure(8));
     MCL_HIP(ctx, hipMemsetAsync(ctx->d_kld_scalars.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
     MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_kld_scalars), 8 * sizeof(unsigned long long)));
     for (auto& pair : ctx->ev)
       for (auto& e : pair) MCL_HIP(ctx, hipEventCreate(&e));
+    if (const char* v = std::getenv("BELUGA_MCL_DEVICE_POLICY")) ctx->device_policy_allowed = std::atoi(v) != 0;
     if (const char* v = std::getenv("BELUGA_MCL_LF_VARIANT")) {  // kernel A/B switch for profiling; default = sorted lanes
       const int k = std::atoi(v);
       ctx->lf_variant = k == 0 ? kLfWavePerParticle : (k == 1 ? kLfLanePerParticle : kLfSortedLanes);
@@ -881,6 +895,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_chunk.release();
   ctx->d_scalars.release();
   ctx->d_cdf.release();
+  ctx->d_cdf_tree.release();
   ctx->d_hashes.release();
   ctx->d_table_keys.release();
   ctx->d_table_first.release();
@@ -1153,10 +1168,31 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   if (const mcl_status s = do_propagate(ctx, ctx->window0, ctx->window1, ctx->step)) return s;  // :174-175
   if (const mcl_status s = do_reweight(ctx, points_xy, num_points)) return s;                    // :176
   mcl_weight_stats stats{};
+  double random_state_probability = 0.0;
+  double ess = -1.0;
+  bool do_resampling = false;
+  // With a fixed particle count and no selective resampling nothing in the cycle depends on a host-side decision: the
+  // recovery estimator runs on the device as well and the cycle synchronises once, at the estimate.
+  const mcl_amcl_params& ap = ctx->cfg.amcl;
+  const bool device_policy = !ap.selective_resampling && ap.min_particles >= std::min<uint64_t>(ap.max_particles, ctx->capacity) &&
+                             ctx->device_policy_allowed;
+  constexpr int kPolicySlot = 20;  // d_scalars[20..23) = {slow, fast, p}
+  if (device_policy) {
+    if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), nullptr, false)) return s;  // :177
+    ctx->every_n_current = (ctx->every_n_current + 1) % ap.resample_interval;                                      // :181
+    do_resampling = ctx->every_n_current == 0;
+    launch_recovery_policy(ctx->stream, ctx->d_scalars.ptr + 1, ctx->n, ap.alpha_slow, ap.alpha_fast, do_resampling ? 1 : 0,
+                           ctx->d_scalars.ptr + kPolicySlot);                                                      // :179, :184-186
+    if (do_resampling) {
+      if (const mcl_status s = do_resample(ctx, 0.0, ctx->step, nullptr, ctx->d_scalars.ptr + kPolicySlot + 2)) return s;  // :188-196
+    }
+    MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars.ptr, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + kPolicySlot, ctx->d_scalars.ptr + kPolicySlot, 3 * sizeof(double),
+                                hipMemcpyDeviceToHost, ctx->stream));
+  } else {
   if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), &stats)) return s;  // :177
 
   // :179 ThrunRecoveryProbabilityEstimator on the NORMALISED weights (thrun_..._estimator.hpp:69-89)
-  double random_state_probability = 0.0;
   {
     const double average = stats.norm_sum / static_cast<double>(ctx->n);
     const double fast_average = ctx->fast(average);
@@ -1166,8 +1202,7 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   }
   // :181 every_n [&& on_effective_size_drop] (every_n.hpp:47-50, on_effective_size_drop.hpp:45-49)
   ctx->every_n_current = (ctx->every_n_current + 1) % ctx->cfg.amcl.resample_interval;
-  bool do_resampling = ctx->every_n_current == 0;
-  double ess = -1.0;
+  do_resampling = ctx->every_n_current == 0;
   if (do_resampling && ctx->cfg.amcl.selective_resampling) {
     ess = stats.norm_sum == 0.0 ? 0.0 : (stats.norm_sum * stats.norm_sum) / stats.norm_sumsq;  // effective_sample_size.hpp:46-59
     do_resampling = ess < static_cast<double>(ctx->n) * 0.5;
@@ -1179,6 +1214,7 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
     }
     if (const mcl_status s = do_resample(ctx, random_state_probability, ctx->step, nullptr)) return s;  // :188-196
   }
+  }
   ctx->force_update = false;  // :199
   mcl_estimate est{};
   if (ctx->estimate_kind == 1) {  // beluga_ros::Amcl returns cluster_based_estimate (beluga_ros/src/amcl.cpp:125)
@@ -1189,6 +1225,12 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
     }
   } else if (const mcl_status s = mcl_estimate_pose(ctx, &est)) {  // :200
     return s;
+  }
+  if (device_policy) {  // read back together with the estimate
+    stats.sum = ctx->h_scalars[0];
+    stats.norm_sum = ctx->h_scalars[1];
+    stats.norm_sumsq = ctx->h_scalars[2];
+    random_state_probability = ctx->h_scalars[kPolicySlot + 2];
   }
   if (estimate) *estimate = est;
   if (info) {
@@ -1338,7 +1380,7 @@ mcl_status mcl_serve_requests(mcl_ctx* ctx, const double* d_requests, uint64_t m
   MCL_REQUIRE(ctx, m == 0 || (d_requests && d_replies), "null argument");
   MCL_REQUIRE(ctx, m == 0 || ctx->n > 0, "empty shard cannot serve draws");
   if (const mcl_status s = bind_device(ctx)) return s;
-  launch_gather_by_cdf_aos(ctx->stream, ctx->cur(), ctx->d_cdf.ptr, ctx->n, d_requests, m, d_replies);
+  launch_gather_by_cdf_aos(ctx->stream, ctx->cur(), ctx->cdf_tree(), d_requests, m, d_replies);
   MCL_HIP(ctx, hipGetLastError());
   return MCL_OK;
 }
@@ -1434,7 +1476,7 @@ mcl_status mcl_build_cdf_device(mcl_ctx* ctx, double* d_total) {
     MCL_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(double), ctx->stream));
     return MCL_OK;
   }
-  launch_cdf(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(3), ctx->chunk_row(4), ctx->d_cdf.ptr, d_total);
+  launch_cdf(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(3), ctx->chunk_row(4), ctx->d_cdf.ptr, d_total, ctx->d_cdf_tree.ptr);
   MCL_HIP(ctx, hipGetLastError());
   return MCL_OK;
 }

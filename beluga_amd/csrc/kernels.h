@@ -93,6 +93,7 @@ struct ResampleArgs {
   uint64_t seed;
   uint32_t step;
   double random_state_probability;
+  const double* d_random_state_probability;  // if set, read the probability from device memory instead (k_recovery_policy's output)
   uint64_t n_in;            // live particles of the source set
   uint64_t first_candidate; // global index of candidate 0 of this launch
   uint64_t count;           // candidates in this launch
@@ -147,10 +148,40 @@ void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_pa
 void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_factor, double* d_chunk_sum, double* d_chunk_sumsq,
                       double* d_out);
 // K5: cdf[i] = inclusive scan of w; d_chunk_sum is recomputed; d_total[0] = cdf[n-1].
+// 16-ary search tree over the cdf: level l (l = 1 .. depth) keeps every 16^l-th cumulative sum (the last of each group
+// of 16 entries of the level below, one 128-byte line per group), so that std::lower_bound touches one line per level:
+// the upper levels stay in cache, only the last two look-ups leave the L2.  Pure comparisons: the result is exactly
+// cdf_lower_bound's.
+constexpr int kCdfTreeMaxDepth = 8;
+struct CdfTree {
+  const double* cdf;
+  const double* levels;                   // level 1 first
+  uint32_t offset[kCdfTreeMaxDepth];      // of level l + 1 inside `levels`
+  uint32_t size[kCdfTreeMaxDepth];
+  int depth;                              // number of sampled levels (0 for n <= 16)
+  uint64_t n;
+};
+inline uint64_t cdf_tree_doubles(uint64_t n) { return n / 15 + 16 * kCdfTreeMaxDepth; }
+inline CdfTree make_cdf_tree(const double* cdf, const double* levels, uint64_t n) {
+  CdfTree t{};
+  t.cdf = cdf;
+  t.levels = levels;
+  t.n = n;
+  uint64_t size = n, off = 0;
+  while (size > 16 && t.depth < kCdfTreeMaxDepth) {
+    size = (size + 15) / 16;
+    t.offset[t.depth] = static_cast<uint32_t>(off);
+    t.size[t.depth] = static_cast<uint32_t>(size);
+    off += size;
+    ++t.depth;
+  }
+  return t;
+}
+// launch_cdf also fills the tree levels when `tree_levels` is given (cdf_tree_doubles(n) doubles).
 void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
-                double* d_total);
+                double* d_total, double* tree_levels);
 // K6: one thread per candidate (views/sample.hpp:102,133-135; random_intersperse.hpp:90-115; particle_traits.hpp:105).
-void launch_resample_draw(hipStream_t st, Particles src, const double* cdf, const double* d_total, Particles dst,
+void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst,
                           ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes);
 // Sharded variant: targets given, no RNG (mcl_gather_by_cdf).
 // Sharded resampling helpers (mcl_resample_targets / mcl_commit_resampled).
@@ -160,7 +191,7 @@ void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, doubl
 void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t count, const double* d_ends, const double* d_offsets,
                           uint32_t world, uint32_t self_rank, uint8_t* d_dest, uint32_t* d_block_hist, uint32_t* d_chunk_sum,
                           uint32_t* d_chunk_off, double* d_send_targets, uint32_t* d_order, long long* d_counts);
-void launch_gather_by_cdf_aos(hipStream_t st, Particles src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
+void launch_gather_by_cdf_aos(hipStream_t st, Particles src, CdfTree cdf, const double* d_targets, uint64_t m,
                               double* d_out);
 void launch_commit_routed(hipStream_t st, Particles dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
                           const double* d_replies, const uint32_t* d_order, const double* d_targets, GridView g, FreeCells fc);
@@ -168,6 +199,12 @@ void launch_commit_routed(hipStream_t st, Particles dst, uint64_t seed, uint32_t
 void launch_finish_candidates(hipStream_t st, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,
                               const uint32_t* d_order, const double* d_targets, GridView g, FreeCells fc, HashParams hp,
                               double* d_states, unsigned long long* d_hashes);
+// ThrunRecoveryProbabilityEstimator (thrun_recovery_probability_estimator.hpp:69-89, exponential_filter.hpp:32-44) evaluated
+// on the device so that a cycle without host-side decisions needs no mid-cycle read-back: policy = {slow, fast, p}.
+// average = *d_norm_sum / n; both filters advance; p = clamp(1 - fast / slow, 0, 1) (0 while |slow| < eps); if this cycle
+// resamples and p > 0 the filters are reset (amcl_core.hpp:184-186).
+void launch_recovery_policy(hipStream_t st, const double* d_norm_sum, uint64_t n, double alpha_slow, double alpha_fast, int resampling,
+                            double* d_policy);
 struct KldTable {
   unsigned long long* keys;  // 0 = empty (hash 0 is remapped)
   unsigned int* first;       // smallest candidate index that produced the key

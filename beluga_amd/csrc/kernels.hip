@@ -1122,8 +1122,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_chunks(const T* __restrict__ ch
   if (threadIdx.x == 0 && total) *total = s_carry;
 }
 
+// Also writes the sampled levels of the search tree (CdfTree): element e is entry (e + 1) / 16^l - 1 of level l whenever
+// 16^l divides e + 1, and the last element closes the last (partial) group of every level.
 __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, uint64_t n, const double* __restrict__ chunk_offset,
-                                                double* __restrict__ cdf, double* __restrict__ total) {
+                                                double* __restrict__ cdf, double* __restrict__ total, CdfTree tree,
+                                                double* __restrict__ levels) {
   __shared__ double s_wave[kBlock / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
@@ -1152,7 +1155,18 @@ __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, ui
     if (i < n) {
       const double v = prefix + loc[k];
       cdf[i] = v;
-      if (i == n - 1) *total = v;
+      if (levels) {
+        uint64_t q = i + 1;
+        for (int l = 0; l < tree.depth && (q & 15) == 0; ++l) {
+          q >>= 4;
+          levels[tree.offset[l] + q - 1] = v;
+        }
+      }
+      if (i == n - 1) {
+        *total = v;
+        if (levels)
+          for (int l = 0; l < tree.depth; ++l) levels[tree.offset[l] + tree.size[l] - 1] = v;
+      }
     }
   }
 }
@@ -1185,6 +1199,29 @@ __device__ __forceinline__ uint64_t cdf_lower_bound(const double* __restrict__ c
   return lo < n ? lo : n - 1;
 }
 
+// The same result through the 16-ary tree (CdfTree): one group of <= 16 entries (one cache line) per level.
+__device__ __forceinline__ uint64_t group_lower_bound(const double* __restrict__ a, uint64_t begin, uint64_t end, double target) {
+  uint64_t lo = begin, len = end - begin;
+  while (len > 0) {
+    const uint64_t half = len >> 1;
+    if (a[lo + half] < target) {
+      lo += half + 1;
+      len -= half + 1;
+    } else {
+      len = half;
+    }
+  }
+  return lo < end ? lo : end - 1;
+}
+__device__ __forceinline__ uint64_t cdf_tree_lower_bound(const CdfTree& t, double target) {
+  uint64_t pos = 0;
+  for (int l = t.depth - 1; l >= 0; --l) {
+    const uint64_t begin = pos * 16, size = t.size[l];
+    pos = group_lower_bound(t.levels + t.offset[l], begin, begin + 16 < size ? begin + 16 : size, target);
+  }
+  const uint64_t begin = pos * 16;
+  return group_lower_bound(t.cdf, begin, begin + 16 < t.n ? begin + 16 : t.n, target);
+}
 // multivariate_uniform_distribution.hpp:145-147 over occupancy_grid.hpp:140-146,164-171: uniform heading,
 // centre of a uniformly chosen free cell in the world frame.  Addressed by the candidate's global index.
 __device__ __forceinline__ Pose2 random_free_state(uint64_t seed, uint32_t step, uint64_t j, const GridView& g, const FreeCells& fc) {
@@ -1209,7 +1246,7 @@ __device__ __forceinline__ bool intersperse_here(const RngWords& r, uint64_t j, 
   return j > 0 && p > 0.0 && rng_uniform32(r.w[2]) < p && n_free > 0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_resample_draw(Particles src, const double* __restrict__ cdf, const double* __restrict__ d_total,
+__global__ __launch_bounds__(kBlock) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
                                                           Particles dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
                                                           unsigned long long* __restrict__ hashes) {
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -1217,14 +1254,15 @@ __global__ __launch_bounds__(kBlock) void k_resample_draw(Particles src, const d
   const uint64_t j = a.first_candidate + t;
   const RngWords r = rng_draw(a.seed, a.step, kRngResample, j);
   Pose2 s;
-  const bool intersperse = intersperse_here(r, j, a.random_state_probability, fc.count);
+  const double p_random = a.d_random_state_probability ? *a.d_random_state_probability : a.random_state_probability;
+  const bool intersperse = intersperse_here(r, j, p_random, fc.count);
   if (intersperse) {
     s = random_free_state(a.seed, a.step, j, g, fc);
   } else {
     uint64_t idx = 0;
     if (a.n_in >= 2) {
       const double u = rng_uniform53(r.w[0], r.w[1]);
-      idx = cdf_lower_bound(cdf, a.n_in, u * (*d_total));
+      idx = cdf_tree_lower_bound(cdf, u * (*d_total));
     }
     s = load_pose(src, idx);
   }
@@ -1232,6 +1270,21 @@ __global__ __launch_bounds__(kBlock) void k_resample_draw(Particles src, const d
   store_pose(dst, o, s);
   dst.w[o] = 1.0;  // particle_traits.hpp:105
   if (hashes) hashes[o] = spatial_hash(s, hp);
+}
+
+__global__ void k_recovery_policy(const double* __restrict__ d_norm_sum, uint64_t n, double alpha_slow, double alpha_fast, int resampling,
+                                  double* __restrict__ policy) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double average = *d_norm_sum / static_cast<double>(n);
+  double slow = policy[0], fast = policy[1];
+  fast += (fast == 0.) ? average : alpha_fast * (average - fast);
+  slow += (slow == 0.) ? average : alpha_slow * (average - slow);
+  double p = 0.0;
+  if (fabs(slow) >= 2.220446049250313e-16) p = fmin(fmax(1.0 - fast / slow, 0.0), 1.0);
+  if (resampling && p > 0.0) slow = fast = 0.0;
+  policy[0] = slow;
+  policy[1] = fast;
+  policy[2] = p;
 }
 
 // -- sharded resampling (one context per GPU; the exchange between them is done by the caller) -----------
@@ -1312,11 +1365,11 @@ __global__ void k_route_counts(const uint32_t* __restrict__ block_offsets, uint3
 }
 
 // AoS variants for the exchange buffers: reply[t] = (x, y, c, s) of the served ancestor.
-__global__ __launch_bounds__(kBlock) void k_gather_by_cdf_aos(Particles src, const double* __restrict__ cdf, uint64_t n,
+__global__ __launch_bounds__(kBlock) void k_gather_by_cdf_aos(Particles src, CdfTree cdf,
                                                               const double* __restrict__ targets, uint64_t m, double4* __restrict__ out) {
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (t >= m) return;
-  const uint64_t idx = cdf_lower_bound(cdf, n, targets[t]);
+  const uint64_t idx = cdf_tree_lower_bound(cdf, targets[t]);
   const double4 v = src.pose[idx];
   out[t] = double4{v.z, v.w, v.x, v.y};
 }
@@ -1846,22 +1899,28 @@ void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_fac
 }
 
 void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
-                double* d_total) {
+                double* d_total, double* tree_levels) {
   const uint32_t chunks = num_chunks(n);
   if (!chunks) return;
   hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_chunk_sum);
   hipLaunchKernelGGL(k_scan_chunks<double>, dim3(1), dim3(kBlock), 0, st, d_chunk_sum, chunks, d_chunk_offset,
                      static_cast<double*>(nullptr), static_cast<const double*>(nullptr));
-  hipLaunchKernelGGL(k_cdf, dim3(chunks), dim3(kBlock), 0, st, w, n, d_chunk_offset, cdf, d_total);
+  hipLaunchKernelGGL(k_cdf, dim3(chunks), dim3(kBlock), 0, st, w, n, d_chunk_offset, cdf, d_total,
+                     make_cdf_tree(cdf, tree_levels, n), tree_levels);
 }
 
-void launch_resample_draw(hipStream_t st, Particles src, const double* cdf, const double* d_total, Particles dst,
+void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst,
                           ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes) {
   if (a.count == 0) return;
   hipLaunchKernelGGL(k_resample_draw, dim3(blocks_for(a.count)), dim3(kBlock), 0, st, src, cdf, d_total, dst, a, g, fc, hp,
                      d_hashes);
 }
 
+
+void launch_recovery_policy(hipStream_t st, const double* d_norm_sum, uint64_t n, double alpha_slow, double alpha_fast, int resampling,
+                            double* d_policy) {
+  hipLaunchKernelGGL(k_recovery_policy, dim3(1), dim3(64), 0, st, d_norm_sum, n, alpha_slow, alpha_fast, resampling, d_policy);
+}
 
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
                              uint64_t count, uint64_t n_free, double* d_targets) {
@@ -1890,10 +1949,10 @@ void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t coun
   hipLaunchKernelGGL(k_route_scatter, dim3(nblocks), dim3(kBlock), 0, st, d_targets, count, d_offsets, world, d_dest, d_block_hist,
                      nblocks, d_send_targets, d_order);
 }
-void launch_gather_by_cdf_aos(hipStream_t st, Particles src, const double* cdf, uint64_t n, const double* d_targets, uint64_t m,
+void launch_gather_by_cdf_aos(hipStream_t st, Particles src, CdfTree cdf, const double* d_targets, uint64_t m,
                               double* d_out) {
   if (m == 0) return;
-  hipLaunchKernelGGL(k_gather_by_cdf_aos, dim3(blocks_for(m)), dim3(kBlock), 0, st, src, cdf, n, d_targets, m,
+  hipLaunchKernelGGL(k_gather_by_cdf_aos, dim3(blocks_for(m)), dim3(kBlock), 0, st, src, cdf, d_targets, m,
                      reinterpret_cast<double4*>(d_out));
 }
 void launch_commit_routed(hipStream_t st, Particles dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
