@@ -281,6 +281,10 @@ struct mcl_ctx {
     s.tx = s.ts + capacity;
     s.ty = s.tx + capacity;
     s.partial = s.ty + capacity;
+    {
+      const uintptr_t end = reinterpret_cast<uintptr_t>(s.partial + kLfMaxSegments * std::min<uint64_t>(capacity, kLfSegmentedBelow));
+      s.pose_part = reinterpret_cast<double4*>((end + 31) & ~static_cast<uintptr_t>(31));
+    }
     return s;
   }
   GridView grid_view() const { return GridView{d_cells.ptr, W, H, resolution, origin, origin_inverse, traits.free_value}; }
@@ -349,7 +353,7 @@ mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
     MCL_HIP(ctx, ctx->d_sort_u32.ensure(2 * cap + hist + 2 * (hist / kChunk + 1)));
     MCL_HIP(ctx, ctx->d_sort_u64.ensure(cap));
     MCL_HIP(ctx, ctx->d_sort_f64.ensure(8 + 6 * static_cast<size_t>(chunks) + 4 * cap +
-                                        kLfMaxSegments * std::min<uint64_t>(cap, kLfSegmentedBelow)));
+                                        kLfMaxSegments * std::min<uint64_t>(cap, kLfSegmentedBelow) + 4 * cap + 4));
   }
   return MCL_OK;
 }

@@ -118,6 +118,7 @@ struct SortScratch {
   double* tx;
   double* ty;
   double* partial;               // [kLfMaxSegments][min(n, 262144)] scan-segment sums (medium particle counts); may be null
+  double4* pose_part;            // [n] pose records in partitioned order (k_sort_scatter -> k_sort_blocks)
 };
 constexpr uint32_t kLfMaxSegments = 16;
 constexpr uint64_t kLfSegmentedBelow = 262144;  // particles

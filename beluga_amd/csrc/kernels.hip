@@ -569,9 +569,12 @@ __global__ __launch_bounds__(kBlock) void k_sort_hist(Particles p, uint64_t n, c
   for (uint32_t d = threadIdx.x; d < kDigits; d += kBlock) block_hist[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
 }
 
+// Besides (key, index) the pose record travels with the particle, so that k_sort_blocks finds the poses of its 2048
+// elements in one contiguous 64 KB window instead of gathering them from all over the set.
 __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restrict__ keys, uint64_t n,
                                                          const uint32_t* __restrict__ block_offsets, uint32_t nblocks,
-                                                         unsigned long long* __restrict__ out, KeyBits kb) {
+                                                         unsigned long long* __restrict__ out, KeyBits kb, Particles p,
+                                                         double4* __restrict__ pose_out) {
   __shared__ uint32_t cursor[kDigits];
   for (uint32_t d = threadIdx.x; d < kDigits; d += kBlock) cursor[d] = block_offsets[static_cast<size_t>(d) * nblocks + blockIdx.x];
   __syncthreads();
@@ -583,49 +586,112 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restr
       const uint32_t key = keys[i];
       const uint32_t dest = atomicAdd(&cursor[key >> (kb.total() - kDigitBits)], 1u);
       out[dest] = (static_cast<unsigned long long>(key) << 32) | static_cast<uint32_t>(i);
+      pose_out[dest] = p.pose[i];
     }
   }
 }
 
-// Bitonic sort of each 2048-element block of (key << 32 | index) in LDS, then emit the permutation and
-// the world->field pose of every particle in sorted order (likelihood_field_model.hpp:70).
-__global__ __launch_bounds__(kBlock) void k_sort_blocks(const unsigned long long* __restrict__ in, uint64_t n, Particles p,
-                                                        Pose2 world_to_field, uint32_t* __restrict__ perm, double* __restrict__ tc,
-                                                        double* __restrict__ ts, double* __restrict__ tx, double* __restrict__ ty,
-                                                        int fine) {
-  __shared__ unsigned long long v[kChunk];
+// Fine ordering of each 2048-element block of (key << 32 | index) in LDS, then the permutation and the world->field
+// pose of every particle in that order (likelihood_field_model.hpp:70).
+// Only locality matters downstream (which 64 particles share a wave), not a total order, so the block is ordered by a
+// counting sort in LDS on the key's position inside the block's own key range, 4096 bins: 3 passes over the block
+// instead of the 66 compare-exchange stages of a bitonic network.  Particles of one bin (a few adjacent Morton codes) stay
+// in arrival order.
+constexpr uint32_t kFineBins = 4096;
+__global__ __launch_bounds__(kBlock) void k_sort_blocks(const unsigned long long* __restrict__ in, uint64_t n,
+                                                        const double4* __restrict__ pose_in, Pose2 world_to_field,
+                                                        uint32_t* __restrict__ perm, double* __restrict__ tc, double* __restrict__ ts,
+                                                        double* __restrict__ tx, double* __restrict__ ty, int fine) {
+  __shared__ uint32_t key_of[kChunk];
+  __shared__ uint32_t index_of[kChunk];   // particle index of the element at that position
+  __shared__ uint32_t from_of[kChunk];    // output slot -> position inside this block
+  __shared__ uint32_t bins[kFineBins];
+  __shared__ uint32_t s_wave[2 * (kBlock / 64)];
+  __shared__ uint32_t s_range[2];
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+  const uint32_t m = static_cast<uint32_t>(n - base < kChunk ? n - base : kChunk);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
   for (int k = 0; k < kChunk / kBlock; ++k) {
     const uint32_t t = k * kBlock + threadIdx.x;
-    v[t] = base + t < n ? in[base + t] : ~0ull;
-  }
-  __syncthreads();
-  for (uint32_t size = 2; fine && size <= kChunk; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-#pragma unroll
-      for (int k = 0; k < kChunk / 2 / kBlock; ++k) {
-        const uint32_t t = k * kBlock + threadIdx.x;                     // comparator index, 0 .. 1023
-        const uint32_t lo = 2 * t - (t & (stride - 1));                   // element with the `stride` bit clear
-        const uint32_t hi = lo + stride;
-        const bool ascending = (lo & size) == 0;
-        const unsigned long long a = v[lo], b = v[hi];
-        if ((a > b) == ascending) {
-          v[lo] = b;
-          v[hi] = a;
-        }
-      }
-      __syncthreads();
+    if (t < m) {
+      const unsigned long long e = in[base + t];
+      const uint32_t key = static_cast<uint32_t>(e >> 32);
+      key_of[t] = key;
+      index_of[t] = static_cast<uint32_t>(e);
+      from_of[t] = t;
+      kmin = min(kmin, key);
+      kmax = max(kmax, key);
     }
   }
+  for (uint32_t b = threadIdx.x; b < kFineBins; b += kBlock) bins[b] = 0;
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, static_cast<uint32_t>(__shfl_down(kmin, o)));
+    kmax = max(kmax, static_cast<uint32_t>(__shfl_down(kmax, o)));
+  }
+  if (lane == 0) {
+    s_wave[2 * wave] = kmin;
+    s_wave[2 * wave + 1] = kmax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < kBlock / 64; ++q) {
+      kmin = min(kmin, s_wave[2 * q]);
+      kmax = max(kmax, s_wave[2 * q + 1]);
+    }
+    s_range[0] = kmin;
+    uint32_t shift = 0;
+    while (((kmax - kmin) >> shift) >= kFineBins) ++shift;
+    s_range[1] = shift;
+  }
+  __syncthreads();
+  if (fine) {
+    const uint32_t lo = s_range[0], shift = s_range[1];
+#pragma unroll
+    for (int k = 0; k < kChunk / kBlock; ++k) {
+      const uint32_t t = k * kBlock + threadIdx.x;
+      if (t < m) atomicAdd(&bins[(key_of[t] - lo) >> shift], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the bins: 16 consecutive bins per thread, then across the workgroup
+    uint32_t loc[kFineBins / kBlock];
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < static_cast<int>(kFineBins / kBlock); ++k) {
+      loc[k] = run;
+      run += bins[threadIdx.x * (kFineBins / kBlock) + k];
+    }
+    uint32_t incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t prefix = incl - run;
+    for (int q = 0; q < wave; ++q) prefix += s_wave[q];
+#pragma unroll
+    for (int k = 0; k < static_cast<int>(kFineBins / kBlock); ++k) bins[threadIdx.x * (kFineBins / kBlock) + k] = prefix + loc[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kChunk / kBlock; ++k) {
+      const uint32_t t = k * kBlock + threadIdx.x;
+      if (t < m) from_of[atomicAdd(&bins[(key_of[t] - lo) >> shift], 1u)] = t;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int k = 0; k < kChunk / kBlock; ++k) {
     const uint32_t t = k * kBlock + threadIdx.x;
-    const uint64_t o = base + t;
-    if (o < n) {
-      const uint32_t i = static_cast<uint32_t>(v[t]);
-      const Pose2 T = pose_mul(world_to_field, load_pose(p, i));
-      perm[o] = i;
+    if (t < m) {
+      const uint64_t o = base + t;
+      const uint32_t from = from_of[t];
+      const double4 q = pose_in[base + from];
+      const Pose2 T = pose_mul(world_to_field, Pose2{Rot2{q.x, q.y}, q.z, q.w});
+      perm[o] = index_of[from];
       tc[o] = T.r.c;
       ts[o] = T.r.s;
       tx[o] = T.x;
@@ -1799,9 +1865,10 @@ void launch_lf_bin_sort(hipStream_t st, Particles p, uint64_t n, FieldView f, co
   hipLaunchKernelGGL(k_scan_chunks<uint32_t>, dim3(1), dim3(kBlock), 0, st, sort->chunk_sum, mchunks, sort->chunk_off,
                      static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr));
   hipLaunchKernelGGL(k_u32_exclusive_apply, dim3(mchunks), dim3(kBlock), 0, st, sort->block_hist, m, sort->chunk_off);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(kBlock), 0, st, sort->keys, n, sort->block_hist, nblocks, sort->keyidx, kb);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(kBlock), 0, st, sort->keys, n, sort->block_hist, nblocks, sort->keyidx, kb, p,
+                     sort->pose_part);
   static const int fine = [] { const char* v = std::getenv("BELUGA_MCL_SORT_FINE"); return v ? std::atoi(v) : 1; }();
-  hipLaunchKernelGGL(k_sort_blocks, dim3(nblocks), dim3(kBlock), 0, st, sort->keyidx, n, p, f.world_to_field, sort->perm, sort->tc,
+  hipLaunchKernelGGL(k_sort_blocks, dim3(nblocks), dim3(kBlock), 0, st, sort->keyidx, n, sort->pose_part, f.world_to_field, sort->perm, sort->tc,
                      sort->ts, sort->tx, sort->ty, fine);
 }
 
