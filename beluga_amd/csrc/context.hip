@@ -206,6 +206,7 @@ struct mcl_ctx {
   uint32_t chunk_stride{0};
   DeviceBuffer<double> d_scalars;    // 32 doubles
   double* h_scalars{nullptr};        // pinned, 32 doubles
+  double* hd_scalars{nullptr};       // the same memory as the device sees it: kernels mirror their scalar results into it
   DeviceBuffer<double> d_cdf;
   DeviceBuffer<double> d_cdf_tree;  // sampled levels of the 16-ary search tree over d_cdf (CdfTree)
   CdfTree cdf_tree() const { return make_cdf_tree(d_cdf.ptr, d_cdf_tree.ptr, n); }
@@ -533,20 +534,20 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B) {
 // d_scalars layout: [0] weight sum, [1] norm_sum, [2] norm_sumsq, [3] factor override, [4] cdf total, [8..16] estimate sums
 mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats, bool read_back = true) {
   stage_begin(ctx, MCL_STAGE_NORMALIZE);
-  launch_weight_sum(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->d_scalars.ptr + 0);
+  launch_weight_sum(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0);
   const double* d_factor = ctx->d_scalars.ptr + 0;
   if (!std::isnan(factor)) {
     ctx->h_scalars[3] = factor;
     MCL_HIP(ctx, hipMemcpyAsync(ctx->d_scalars.ptr + 3, ctx->h_scalars + 3, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     d_factor = ctx->d_scalars.ptr + 3;
   }
-  launch_normalize(ctx->stream, ctx->cur().w, ctx->n, d_factor, ctx->chunk_row(1), ctx->chunk_row(2), ctx->d_scalars.ptr + 1);
+  launch_normalize(ctx->stream, ctx->cur().w, ctx->n, d_factor, ctx->chunk_row(1), ctx->chunk_row(2), ctx->d_scalars.ptr + 1,
+                   ctx->hd_scalars + 1);
   if (!read_back) {  // the caller reads d_scalars[0..3) back later, with its own synchronisation
     stage_end(ctx, MCL_STAGE_NORMALIZE);
     MCL_HIP(ctx, hipGetLastError());
     return MCL_OK;
   }
-  MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars.ptr, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   stage_end(ctx, MCL_STAGE_NORMALIZE);
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   stage_collect(ctx);
@@ -621,8 +622,8 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
 
 mcl_status do_estimate_sums(mcl_ctx* ctx, const double pivot[2], double sums[12]) {
   stage_begin(ctx, MCL_STAGE_ESTIMATE);
-  launch_estimate_sums(ctx->stream, ctx->cur(), ctx->n, pivot[0], pivot[1], ctx->chunk_row(0), ctx->d_scalars.ptr + 8);
-  MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, ctx->d_scalars.ptr + 8, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  launch_estimate_sums(ctx->stream, ctx->cur(), ctx->n, pivot[0], pivot[1], ctx->chunk_row(0), ctx->d_scalars.ptr + 8,
+                       ctx->hd_scalars + 8);
   stage_end(ctx, MCL_STAGE_ESTIMATE);
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   stage_collect(ctx);
@@ -859,7 +860,8 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     if (const mcl_status s = ensure_capacity(ctx, cap)) return s;
     MCL_HIP(ctx, ctx->d_scalars.ensure(32));
     MCL_HIP(ctx, hipMemsetAsync(ctx->d_scalars.ptr, 0, 32 * sizeof(double), ctx->stream));  // incl. the recovery filters
-    MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalars), 32 * sizeof(double)));
+    MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalars), 32 * sizeof(double), hipHostMallocMapped));
+    MCL_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->hd_scalars), ctx->h_scalars, 0));
     MCL_HIP(ctx, ctx->d_kld_scalars.ensure(8));
     MCL_HIP(ctx, hipMemsetAsync(ctx->d_kld_scalars.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
     MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_kld_scalars), 8 * sizeof(unsigned long long)));
@@ -1186,13 +1188,10 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
     ctx->every_n_current = (ctx->every_n_current + 1) % ap.resample_interval;                                      // :181
     do_resampling = ctx->every_n_current == 0;
     launch_recovery_policy(ctx->stream, ctx->d_scalars.ptr + 1, ctx->n, ap.alpha_slow, ap.alpha_fast, do_resampling ? 1 : 0,
-                           ctx->d_scalars.ptr + kPolicySlot);                                                      // :179, :184-186
+                           ctx->d_scalars.ptr + kPolicySlot, ctx->hd_scalars + kPolicySlot);                       // :179, :184-186
     if (do_resampling) {
       if (const mcl_status s = do_resample(ctx, 0.0, ctx->step, nullptr, ctx->d_scalars.ptr + kPolicySlot + 2)) return s;  // :188-196
     }
-    MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars.ptr, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + kPolicySlot, ctx->d_scalars.ptr + kPolicySlot, 3 * sizeof(double),
-                                hipMemcpyDeviceToHost, ctx->stream));
   } else {
   if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), &stats)) return s;  // :177
 

@@ -143,11 +143,12 @@ constexpr uint32_t kChunk = 2048;
 inline uint32_t num_chunks(uint64_t n) { return static_cast<uint32_t>((n + kChunk - 1) / kChunk); }
 
 // K3a: partial[b] = sum of w over chunk b ; then d_out[0] = sum of partials (fixed order).
-void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_partials, double* d_out);
+// host_mirror (here and below, optional): mapped pinned-host memory that also receives the result
+void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_partials, double* d_out, double* host_mirror = nullptr);
 // K3b: w[i] /= *d_factor unless |factor-1| < eps (normalize.hpp:73-82); chunk sums of the new w and w^2;
 //      d_out[0] = total of new w, d_out[1] = total of squares.
 void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_factor, double* d_chunk_sum, double* d_chunk_sumsq,
-                      double* d_out);
+                      double* d_out, double* host_mirror = nullptr);
 // K5: cdf[i] = inclusive scan of w; d_chunk_sum is recomputed; d_total[0] = cdf[n-1].
 // 16-ary search tree over the cdf: level l (l = 1 .. depth) keeps every 16^l-th cumulative sum (the last of each group
 // of 16 entries of the level below, one 128-byte line per group), so that std::lower_bound touches one line per level:
@@ -205,7 +206,7 @@ void launch_finish_candidates(hipStream_t st, uint64_t seed, uint32_t step, uint
 // average = *d_norm_sum / n; both filters advance; p = clamp(1 - fast / slow, 0, 1) (0 while |slow| < eps); if this cycle
 // resamples and p > 0 the filters are reset (amcl_core.hpp:184-186).
 void launch_recovery_policy(hipStream_t st, const double* d_norm_sum, uint64_t n, double alpha_slow, double alpha_fast, int resampling,
-                            double* d_policy);
+                            double* d_policy, double* host_mirror = nullptr);
 struct KldTable {
   unsigned long long* keys;  // 0 = empty (hash 0 is remapped)
   unsigned int* first;       // smallest candidate index that produced the key
@@ -219,7 +220,7 @@ void launch_kld_scan(hipStream_t st, const unsigned long long* d_hashes, uint64_
                      uint32_t* d_k_total, uint64_t min_particles, double epsilon, double z, unsigned long long* d_first_fail);
 // K8: estimation.hpp:436-475 sufficient statistics; d_out[9].
 void launch_estimate_sums(hipStream_t st, Particles p, uint64_t n, double pivot_x, double pivot_y, double* d_partials,
-                          double* d_out);
+                          double* d_out, double* host_mirror = nullptr);
 // cluster_based_estimate (algorithm/cluster_based_estimation.hpp): hash + per-cell aggregation + compaction of the occupied
 // cells (for the host's cluster assignment), the write-back of the cells' cluster ids and the masked estimate sums.
 void launch_cluster_cells(hipStream_t st, Particles p, uint64_t n, HashParams hp, unsigned long long* d_hashes,
@@ -230,7 +231,7 @@ void launch_cell_set_cluster(hipStream_t st, const unsigned int* d_slot, const u
                              unsigned int* t_cluster);
 void launch_estimate_sums_cluster(hipStream_t st, Particles p, uint64_t n, const unsigned long long* d_hashes,
                                   unsigned long long* t_keys, unsigned int* t_cluster, uint64_t capacity, unsigned int wanted,
-                                  double pivot_x, double pivot_y, double* d_partials, double* d_out);
+                                  double pivot_x, double pivot_y, double* d_partials, double* d_out, double* host_mirror = nullptr);
 // init: multivariate_normal_distribution.hpp:96-126 with T = V sqrt(L)
 void launch_init_normal(hipStream_t st, Particles p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
                         uint64_t index_offset);

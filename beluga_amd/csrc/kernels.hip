@@ -1110,9 +1110,11 @@ __global__ __launch_bounds__(kBlock) void k_chunk_sum(const double* __restrict__
 }
 
 // out[k] = sum_b partials[k][b] for k < K (partials laid out [K][stride]); single workgroup, fixed order.
+// host_mirror (optional): a mapped pinned-host copy of the result, written by the kernel itself — the host reads it after
+// the stream synchronisation, no separate device-to-host copy (a blit kernel of its own) is enqueued.
 template <int K>
 __global__ __launch_bounds__(kBlock) void k_final_sum(const double* __restrict__ partials, uint32_t count, uint32_t stride,
-                                                      double* __restrict__ out) {
+                                                      double* __restrict__ out, double* __restrict__ host_mirror) {
   __shared__ double scratch[(kBlock / 64) * K];
   double v[K];
 #pragma unroll
@@ -1125,6 +1127,10 @@ __global__ __launch_bounds__(kBlock) void k_final_sum(const double* __restrict__
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < K; ++k) out[k] = v[k];
+    if (host_mirror) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) host_mirror[k] = v[k];
+    }
   }
 }
 
@@ -1339,7 +1345,7 @@ __global__ __launch_bounds__(kBlock) void k_resample_draw(Particles src, CdfTree
 }
 
 __global__ void k_recovery_policy(const double* __restrict__ d_norm_sum, uint64_t n, double alpha_slow, double alpha_fast, int resampling,
-                                  double* __restrict__ policy) {
+                                  double* __restrict__ policy, double* __restrict__ host_mirror) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double average = *d_norm_sum / static_cast<double>(n);
   double slow = policy[0], fast = policy[1];
@@ -1351,6 +1357,7 @@ __global__ void k_recovery_policy(const double* __restrict__ d_norm_sum, uint64_
   policy[0] = slow;
   policy[1] = fast;
   policy[2] = p;
+  if (host_mirror) host_mirror[2] = p;
 }
 
 // -- sharded resampling (one context per GPU; the exchange between them is done by the caller) -----------
@@ -1950,19 +1957,19 @@ void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, B
                      reinterpret_cast<const double2*>(d_points), B, d_steps);
 }
 
-void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_partials, double* d_out) {
+void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_partials, double* d_out, double* host_mirror) {
   const uint32_t chunks = num_chunks(n);
   if (chunks) hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_partials);
-  hipLaunchKernelGGL(k_final_sum<1>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out);
+  hipLaunchKernelGGL(k_final_sum<1>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror);
 }
 
 void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_factor, double* d_chunk_sum, double* d_chunk_sumsq,
-                      double* d_out) {
+                      double* d_out, double* host_mirror) {
   const uint32_t chunks = num_chunks(n);
   if (chunks) hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, d_factor, d_chunk_sum, d_chunk_sumsq);
   // d_chunk_sum and d_chunk_sumsq are adjacent rows of one [2][stride] buffer (see context.cpp)
   hipLaunchKernelGGL(k_final_sum<2>, dim3(1), dim3(kBlock), 0, st, d_chunk_sum, chunks,
-                     static_cast<uint32_t>(d_chunk_sumsq - d_chunk_sum), d_out);
+                     static_cast<uint32_t>(d_chunk_sumsq - d_chunk_sum), d_out, host_mirror);
 }
 
 void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
@@ -1985,8 +1992,9 @@ void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const doub
 
 
 void launch_recovery_policy(hipStream_t st, const double* d_norm_sum, uint64_t n, double alpha_slow, double alpha_fast, int resampling,
-                            double* d_policy) {
-  hipLaunchKernelGGL(k_recovery_policy, dim3(1), dim3(64), 0, st, d_norm_sum, n, alpha_slow, alpha_fast, resampling, d_policy);
+                            double* d_policy, double* host_mirror) {
+  hipLaunchKernelGGL(k_recovery_policy, dim3(1), dim3(64), 0, st, d_norm_sum, n, alpha_slow, alpha_fast, resampling, d_policy,
+                     host_mirror);
 }
 
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
@@ -2056,10 +2064,10 @@ void launch_kld_scan(hipStream_t st, const unsigned long long* d_hashes, uint64_
 }
 
 void launch_estimate_sums(hipStream_t st, Particles p, uint64_t n, double pivot_x, double pivot_y, double* d_partials,
-                          double* d_out) {
+                          double* d_out, double* host_mirror) {
   const uint32_t chunks = num_chunks(n);
   if (chunks) hipLaunchKernelGGL(k_estimate_partials, dim3(chunks), dim3(kBlock), 0, st, p, n, pivot_x, pivot_y, d_partials, chunks);
-  hipLaunchKernelGGL(k_final_sum<kEstK>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out);
+  hipLaunchKernelGGL(k_final_sum<kEstK>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror);
 }
 
 void launch_cluster_cells(hipStream_t st, Particles p, uint64_t n, HashParams hp, unsigned long long* d_hashes,
@@ -2080,13 +2088,13 @@ void launch_cell_set_cluster(hipStream_t st, const unsigned int* d_slot, const u
 }
 void launch_estimate_sums_cluster(hipStream_t st, Particles p, uint64_t n, const unsigned long long* d_hashes,
                                   unsigned long long* t_keys, unsigned int* t_cluster, uint64_t capacity, unsigned int wanted,
-                                  double pivot_x, double pivot_y, double* d_partials, double* d_out) {
+                                  double pivot_x, double pivot_y, double* d_partials, double* d_out, double* host_mirror) {
   const uint32_t chunks = num_chunks(n);
   const CellTable t{t_keys, nullptr, nullptr, nullptr, t_cluster, capacity};
   if (chunks)
     hipLaunchKernelGGL(k_estimate_partials_cluster, dim3(chunks), dim3(kBlock), 0, st, p, n, d_hashes, t, wanted, pivot_x, pivot_y,
                        d_partials, chunks);
-  hipLaunchKernelGGL(k_final_sum<kEstK>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out);
+  hipLaunchKernelGGL(k_final_sum<kEstK>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror);
 }
 
 void launch_init_normal(hipStream_t st, Particles p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
