@@ -155,7 +155,14 @@ class Amcl:
             self._ctx = None
             raise capi.MclError(st, msg)
         self._shape = None
-        self.last_info = None
+        self._est, self._info = capi.Estimate(), capi.UpdateInfo()
+        self._est_ref, self._info_ref = C.byref(self._est), C.byref(self._info)
+        self._est_view = np.frombuffer(self._est, dtype=np.float64, count=13)  # pose[4] | covariance[9]
+        self._have_info = False
+        # a second handle of mcl_update that takes the arrays as raw addresses (no per-call pointer objects)
+        self._update_fn = self._lib["mcl_update"]
+        self._update_fn.restype = C.c_int32
+        self._update_fn.argtypes = [capi._ctx, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         self.update_map(grid)
 
     # -- lifetime ---------------------------------------------------------------------------------
@@ -231,32 +238,41 @@ class Amcl:
 
     def update(self, control_action, measurement) -> Optional[Tuple[np.ndarray, np.ndarray]]:
         """Amcl::update (amcl_core.hpp:165-201). Returns (pose (cos,sin,x,y), covariance 3x3) or None."""
-        ctrl = np.ascontiguousarray(control_action, dtype=np.float64)
-        pts = np.ascontiguousarray(measurement, dtype=np.float64).reshape(-1, 2)
-        est, info = capi.Estimate(), capi.UpdateInfo()
-        self._check(self._lib.mcl_update(self._ctx, _dp(ctrl), _dp(pts), len(pts), C.byref(est), C.byref(info)))
-        self.last_info = {
+        # This wrapper sits inside the measured cycle: no per-call ctypes objects, no dict, raw addresses for the arrays.
+        ctrl = control_action if (type(control_action) is np.ndarray and control_action.dtype == np.float64
+                                  and control_action.flags.c_contiguous) else np.ascontiguousarray(control_action, dtype=np.float64)
+        pts = measurement if (type(measurement) is np.ndarray and measurement.dtype == np.float64
+                              and measurement.flags.c_contiguous) else np.ascontiguousarray(measurement, dtype=np.float64)
+        status = self._update_fn(self._ctx, ctrl.ctypes.data, pts.ctypes.data, pts.size // 2, self._est_ref, self._info_ref)
+        if status != 0:
+            self._check(status)
+        self._have_info = True
+        if not self._info.updated:
+            return None
+        out = self._est_view.copy()
+        return out[:4], out[4:13].reshape(3, 3)
+
+    @property
+    def last_info(self):
+        """mcl_update_info of the last update as a dict (None before the first one)."""
+        if not self._have_info:
+            return None
+        info = self._info
+        return {
             "updated": bool(info.updated), "resampled": bool(info.resampled), "num_particles": info.num_particles,
             "weight_sum": info.weight_sum, "ess": info.effective_sample_size,
             "random_state_probability": info.random_state_probability,
         }
-        if not info.updated:
-            return None
-        return np.array(est.pose), np.array(est.covariance).reshape(3, 3)
 
     def update_laser_scan(self, control_action, scan):
         """beluga_ros::Amcl::update(base_pose_in_odom, laser_scan) (beluga_ros/src/amcl.cpp:54-63)."""
         ctrl = np.ascontiguousarray(control_action, dtype=np.float64)
-        est, info = capi.Estimate(), capi.UpdateInfo()
-        self._check(self._lib.mcl_update_laser_scan(self._ctx, _dp(ctrl), C.byref(scan), C.byref(est), C.byref(info)))
-        self.last_info = {
-            "updated": bool(info.updated), "resampled": bool(info.resampled), "num_particles": info.num_particles,
-            "weight_sum": info.weight_sum, "ess": info.effective_sample_size,
-            "random_state_probability": info.random_state_probability,
-        }
-        if not info.updated:
+        self._check(self._lib.mcl_update_laser_scan(self._ctx, _dp(ctrl), C.byref(scan), self._est_ref, self._info_ref))
+        self._have_info = True
+        if not self._info.updated:
             return None
-        return np.array(est.pose), np.array(est.covariance).reshape(3, 3)
+        out = self._est_view.copy()
+        return out[:4], out[4:13].reshape(3, 3)
 
     # -- stage-level entry points (parity tests, multi-GPU driver) ------------------------------------
     def propagate(self, pose, previous_pose, step: int):

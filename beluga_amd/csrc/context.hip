@@ -534,15 +534,16 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B) {
 // d_scalars layout: [0] weight sum, [1] norm_sum, [2] norm_sumsq, [3] factor override, [4] cdf total, [8..16] estimate sums
 mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats, bool read_back = true) {
   stage_begin(ctx, MCL_STAGE_NORMALIZE);
-  launch_weight_sum(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0);
-  const double* d_factor = ctx->d_scalars.ptr + 0;
-  if (!std::isnan(factor)) {
+  if (std::isnan(factor)) {  // by the set's own total
+    launch_sum_and_normalize(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->chunk_row(1), ctx->chunk_row(2),
+                             ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0);
+  } else {
+    launch_weight_sum(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0);
     ctx->h_scalars[3] = factor;
     MCL_HIP(ctx, hipMemcpyAsync(ctx->d_scalars.ptr + 3, ctx->h_scalars + 3, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    d_factor = ctx->d_scalars.ptr + 3;
+    launch_normalize(ctx->stream, ctx->cur().w, ctx->n, ctx->d_scalars.ptr + 3, ctx->chunk_row(1), ctx->chunk_row(2),
+                     ctx->d_scalars.ptr + 1, ctx->hd_scalars + 1);
   }
-  launch_normalize(ctx->stream, ctx->cur().w, ctx->n, d_factor, ctx->chunk_row(1), ctx->chunk_row(2), ctx->d_scalars.ptr + 1,
-                   ctx->hd_scalars + 1);
   if (!read_back) {  // the caller reads d_scalars[0..3) back later, with its own synchronisation
     stage_end(ctx, MCL_STAGE_NORMALIZE);
     MCL_HIP(ctx, hipGetLastError());
@@ -559,20 +560,22 @@ mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats, bo
   return MCL_OK;
 }
 
-mcl_status do_build_cdf(mcl_ctx* ctx) {
+// normalized_just_now: the chunk sums k_normalize left in chunk_row(1) are those of the current weights (same summation,
+// same bits as k_chunk_sum would produce) and are reused.
+mcl_status do_build_cdf(mcl_ctx* ctx, bool normalized_just_now = false) {
   launch_cdf(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(3), ctx->chunk_row(4), ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4,
-             ctx->d_cdf_tree.ptr);
+             ctx->d_cdf_tree.ptr, normalized_just_now ? ctx->chunk_row(1) : nullptr);
   MCL_HIP(ctx, hipGetLastError());
   return MCL_OK;
 }
 
 mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t step, uint64_t* n_out,
-                       const double* d_random_state_probability = nullptr) {
+                       const double* d_random_state_probability = nullptr, bool normalized_just_now = false) {
   const mcl_amcl_params& a = ctx->cfg.amcl;
   MCL_REQUIRE(ctx, ctx->n > 0, "mcl_resample: empty particle set");
   const uint64_t max_p = std::min<uint64_t>(a.max_particles, ctx->capacity);
   stage_begin(ctx, MCL_STAGE_RESAMPLE);
-  if (const mcl_status s = do_build_cdf(ctx)) return s;
+  if (const mcl_status s = do_build_cdf(ctx, normalized_just_now)) return s;
   ResampleArgs ra{};
   ra.seed = ctx->cfg.seed;
   ra.step = step;
@@ -1190,7 +1193,7 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
     launch_recovery_policy(ctx->stream, ctx->d_scalars.ptr + 1, ctx->n, ap.alpha_slow, ap.alpha_fast, do_resampling ? 1 : 0,
                            ctx->d_scalars.ptr + kPolicySlot, ctx->hd_scalars + kPolicySlot);                       // :179, :184-186
     if (do_resampling) {
-      if (const mcl_status s = do_resample(ctx, 0.0, ctx->step, nullptr, ctx->d_scalars.ptr + kPolicySlot + 2)) return s;  // :188-196
+      if (const mcl_status s = do_resample(ctx, 0.0, ctx->step, nullptr, ctx->d_scalars.ptr + kPolicySlot + 2, true)) return s;  // :188-196
     }
   } else {
   if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), &stats)) return s;  // :177
@@ -1215,7 +1218,7 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
       ctx->slow.reset();
       ctx->fast.reset();
     }
-    if (const mcl_status s = do_resample(ctx, random_state_probability, ctx->step, nullptr)) return s;  // :188-196
+    if (const mcl_status s = do_resample(ctx, random_state_probability, ctx->step, nullptr, nullptr, true)) return s;  // :188-196
   }
   }
   ctx->force_update = false;  // :199

@@ -149,6 +149,8 @@ void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_pa
 //      d_out[0] = total of new w, d_out[1] = total of squares.
 void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_factor, double* d_chunk_sum, double* d_chunk_sumsq,
                       double* d_out, double* host_mirror = nullptr);
+void launch_sum_and_normalize(hipStream_t st, double* w, uint64_t n, double* d_partials, double* d_chunk_sum, double* d_chunk_sumsq,
+                              double* d_sums, double* host_mirror);
 // K5: cdf[i] = inclusive scan of w; d_chunk_sum is recomputed; d_total[0] = cdf[n-1].
 // 16-ary search tree over the cdf: level l (l = 1 .. depth) keeps every 16^l-th cumulative sum (the last of each group
 // of 16 entries of the level below, one 128-byte line per group), so that std::lower_bound touches one line per level:
@@ -181,7 +183,7 @@ inline CdfTree make_cdf_tree(const double* cdf, const double* levels, uint64_t n
 }
 // launch_cdf also fills the tree levels when `tree_levels` is given (cdf_tree_doubles(n) doubles).
 void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
-                double* d_total, double* tree_levels);
+                double* d_total, double* tree_levels, const double* known_chunk_sum = nullptr);
 // K6: one thread per candidate (views/sample.hpp:102,133-135; random_intersperse.hpp:90-115; particle_traits.hpp:105).
 void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst,
                           ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes);

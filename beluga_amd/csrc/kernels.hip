@@ -1134,10 +1134,29 @@ __global__ __launch_bounds__(kBlock) void k_final_sum(const double* __restrict__
   }
 }
 
+// sum_partials != nullptr: the factor is the total of these chunk sums, added up by every workgroup exactly as
+// k_final_sum<1> does (same strides, same reduction tree, same bits) instead of being read from *d_factor — one launch
+// less on the cycle's critical path; workgroup 0 stores the total to d_sum_out (and its host mirror).
 __global__ __launch_bounds__(kBlock) void k_normalize(double* __restrict__ w, uint64_t n, const double* __restrict__ d_factor,
-                                                      double* __restrict__ chunk_sum, double* __restrict__ chunk_sumsq) {
+                                                      double* __restrict__ chunk_sum, double* __restrict__ chunk_sumsq,
+                                                      const double* __restrict__ sum_partials, uint32_t sum_count,
+                                                      double* __restrict__ d_sum_out, double* __restrict__ sum_mirror) {
   __shared__ double scratch[(kBlock / 64) * 2];
-  const double factor = *d_factor;
+  __shared__ double s_factor;
+  if (sum_partials) {
+    double t[1] = {0.0};
+    for (uint32_t b = threadIdx.x; b < sum_count; b += kBlock) t[0] += sum_partials[b];
+    block_reduce<1>(t, scratch);
+    if (threadIdx.x == 0) {
+      s_factor = t[0];
+      if (blockIdx.x == 0) {
+        d_sum_out[0] = t[0];
+        if (sum_mirror) sum_mirror[0] = t[0];
+      }
+    }
+    __syncthreads();
+  }
+  const double factor = sum_partials ? s_factor : *d_factor;
   const bool skip = fabs(factor - 1.0) < DBL_EPSILON;  // normalize.hpp:73
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
   double v[2] = {0.0, 0.0};
@@ -1196,10 +1215,42 @@ __global__ __launch_bounds__(kBlock) void k_scan_chunks(const T* __restrict__ ch
 
 // Also writes the sampled levels of the search tree (CdfTree): element e is entry (e + 1) / 16^l - 1 of level l whenever
 // 16^l divides e + 1, and the last element closes the last (partial) group of every level.
+// The offset of chunk `me` exactly as k_scan_chunks<double> computes it (same tiles, same order, same bits), replayed by
+// a whole workgroup for itself: for a few hundred chunks this is cheaper than a single-workgroup kernel in between.
+__device__ __forceinline__ double chunk_offset_replay(const double* __restrict__ chunk_sum, uint32_t count, uint32_t me) {
+  __shared__ double r_wave[kBlock / 64];
+  __shared__ double r_carry, r_result;
+  if (threadIdx.x == 0) r_carry = 0.0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t start = 0; start <= me; start += kBlock) {
+    const uint32_t i = start + threadIdx.x;
+    const double v = i < count ? chunk_sum[i] : 0.0;
+    double incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) r_wave[wave] = incl;
+    __syncthreads();
+    double wave_prefix = 0.0;
+    for (int q = 0; q < wave; ++q) wave_prefix += r_wave[q];
+    const double carry = r_carry;
+    if (i == me) r_result = carry + wave_prefix + (incl - v);
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) r_carry = carry + wave_prefix + incl;
+    __syncthreads();
+  }
+  return r_result;
+}
+
 __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, uint64_t n, const double* __restrict__ chunk_offset,
                                                 double* __restrict__ cdf, double* __restrict__ total, CdfTree tree,
-                                                double* __restrict__ levels) {
+                                                double* __restrict__ levels, const double* __restrict__ chunk_sum_to_scan,
+                                                uint32_t chunk_count) {
   __shared__ double s_wave[kBlock / 64];
+  const double my_offset = chunk_sum_to_scan ? chunk_offset_replay(chunk_sum_to_scan, chunk_count, blockIdx.x) : chunk_offset[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
   double loc[kItems];
@@ -1218,7 +1269,7 @@ __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, ui
   }
   if (lane == 63) s_wave[wave] = incl;
   __syncthreads();
-  double prefix = chunk_offset[blockIdx.x];
+  double prefix = my_offset;
   for (int q = 0; q < wave; ++q) prefix += s_wave[q];
   prefix += incl - run;
 #pragma unroll
@@ -1966,21 +2017,45 @@ void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_pa
 void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_factor, double* d_chunk_sum, double* d_chunk_sumsq,
                       double* d_out, double* host_mirror) {
   const uint32_t chunks = num_chunks(n);
-  if (chunks) hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, d_factor, d_chunk_sum, d_chunk_sumsq);
+  if (chunks)
+    hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, d_factor, d_chunk_sum, d_chunk_sumsq,
+                       static_cast<const double*>(nullptr), 0u, static_cast<double*>(nullptr), static_cast<double*>(nullptr));
   // d_chunk_sum and d_chunk_sumsq are adjacent rows of one [2][stride] buffer (see context.cpp)
   hipLaunchKernelGGL(k_final_sum<2>, dim3(1), dim3(kBlock), 0, st, d_chunk_sum, chunks,
                      static_cast<uint32_t>(d_chunk_sumsq - d_chunk_sum), d_out, host_mirror);
 }
 
+// actions::normalize by the set's own total (normalize.hpp:70): weight chunk sums, then the division with the total added
+// up inside k_normalize.  d_sums[0] = total before, d_sums[1], d_sums[2] = sum and sum of squares after (mirrored likewise).
+void launch_sum_and_normalize(hipStream_t st, double* w, uint64_t n, double* d_partials, double* d_chunk_sum, double* d_chunk_sumsq,
+                              double* d_sums, double* host_mirror) {
+  const uint32_t chunks = num_chunks(n);
+  if (chunks) {
+    hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_partials);
+    hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, static_cast<const double*>(nullptr), d_chunk_sum,
+                       d_chunk_sumsq, d_partials, chunks, d_sums, host_mirror);
+  } else {
+    hipLaunchKernelGGL(k_final_sum<1>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_sums, host_mirror);
+  }
+  hipLaunchKernelGGL(k_final_sum<2>, dim3(1), dim3(kBlock), 0, st, d_chunk_sum, chunks,
+                     static_cast<uint32_t>(d_chunk_sumsq - d_chunk_sum), d_sums + 1, host_mirror ? host_mirror + 1 : nullptr);
+}
+
 void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
-                double* d_total, double* tree_levels) {
+                double* d_total, double* tree_levels, const double* known_chunk_sum) {
   const uint32_t chunks = num_chunks(n);
   if (!chunks) return;
-  hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_chunk_sum);
-  hipLaunchKernelGGL(k_scan_chunks<double>, dim3(1), dim3(kBlock), 0, st, d_chunk_sum, chunks, d_chunk_offset,
-                     static_cast<double*>(nullptr), static_cast<const double*>(nullptr));
+  const double* sums = known_chunk_sum;
+  if (!sums) {
+    hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_chunk_sum);
+    sums = d_chunk_sum;
+  }
+  const bool replay = chunks <= 4 * kBlock;  // every workgroup re-derives its own offset: no single-workgroup scan in between
+  if (!replay)
+    hipLaunchKernelGGL(k_scan_chunks<double>, dim3(1), dim3(kBlock), 0, st, sums, chunks, d_chunk_offset,
+                       static_cast<double*>(nullptr), static_cast<const double*>(nullptr));
   hipLaunchKernelGGL(k_cdf, dim3(chunks), dim3(kBlock), 0, st, w, n, d_chunk_offset, cdf, d_total,
-                     make_cdf_tree(cdf, tree_levels, n), tree_levels);
+                     make_cdf_tree(cdf, tree_levels, n), tree_levels, replay ? sums : static_cast<const double*>(nullptr), chunks);
 }
 
 void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst,
