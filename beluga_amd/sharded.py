@@ -211,6 +211,7 @@ class ShardedAmcl:
             raise ValueError("min_particles must be at least the number of ranks")
         self.net = _Transport(dist, group)
         self.kld_block = kld_block  # candidates drawn per round of C5 (doubles every round); None = max(min + 1, 8192 * world)
+        self._pin_f64 = self._pin_i64 = self._pin_up = None  # pinned staging for the few scalars that cross to the host every cycle
         self.n_total = params.max_particles
         self.first_slot, self.n_local = shard_bounds(self.n_total, self.world, self.rank)
         if engine_factory is None:
@@ -320,7 +321,10 @@ class ShardedAmcl:
             e.build_cdf_into(buf[1:2])
         gathered = e.empty(self.world * 3)
         self.net.all_gather(gathered, buf[1:4])                                     # C2
-        host = torch.cat([buf[0:1], gathered]).cpu().numpy()
+        both = e.empty(1 + self.world * 3)
+        both[0:1] = buf[0:1]
+        both[1:] = gathered
+        host = self._to_host(both)
         weight_sum = float(host[0])
         stats = host[1:].reshape(self.world, 3)
         totals, norm_sum, norm_sumsq = stats[:, 0], float(stats[:, 1].sum()), float(stats[:, 2].sum())
@@ -349,7 +353,7 @@ class ShardedAmcl:
         t_sums = e.empty(9)                                                 # :200
         e.estimate_sums_into(self._pivot, t_sums)
         self.net.all_reduce_sum(t_sums)                                     # C4
-        sums = np.concatenate([t_sums.cpu().numpy(), self._pivot, [0.0]])
+        sums = np.concatenate([self._to_host(t_sums), self._pivot, [0.0]])
         pose_est, cov = estimate_from_sums(sums)
         if np.all(np.isfinite(pose_est[2:])):
             self._pivot = np.array([pose_est[2], pose_est[3]])
@@ -357,11 +361,38 @@ class ShardedAmcl:
                           "ess": ess, "random_state_probability": p_random}
         return pose_est, cov
 
+    def _to_host(self, t):
+        """Device tensor -> numpy through pinned memory (one asynchronous copy + one stream synchronisation)."""
+        if not t.is_cuda:
+            return t.numpy()
+        torch = self.torch
+        pin = self._pin_f64 if t.dtype == torch.float64 else self._pin_i64
+        if pin is None or pin.numel() < t.numel():
+            pin = torch.empty(max(256, t.numel()), dtype=t.dtype).pin_memory()
+            if t.dtype == torch.float64:
+                self._pin_f64 = pin
+            else:
+                self._pin_i64 = pin
+        view = pin[:t.numel()]
+        view.copy_(t.reshape(-1), non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return view.numpy().copy()
+
+    def _to_device(self, host: np.ndarray):
+        torch = self.torch
+        if self.device.type != "cuda":
+            return torch.from_numpy(np.ascontiguousarray(host, dtype=np.float64))
+        # persistent pinned staging: the previous upload has completed (every cycle synchronises after it)
+        if self._pin_up is None or self._pin_up.numel() < host.size:
+            self._pin_up = torch.empty(max(64, host.size), dtype=torch.float64).pin_memory()
+        stage = self._pin_up[:host.size]
+        stage.copy_(torch.from_numpy(np.ascontiguousarray(host, dtype=np.float64)))
+        return stage.to(self.device, non_blocking=True)
+
     def _cdf_intervals(self, totals: np.ndarray):
         ends_host = np.cumsum(totals)            # inclusive end of every shard's interval of the global CDF
-        offsets = self.torch.tensor(ends_host - totals, dtype=self.torch.float64, device=self.device)
-        ends = self.torch.tensor(ends_host, dtype=self.torch.float64, device=self.device)
-        return float(ends_host[-1]), ends, offsets
+        both = self._to_device(np.concatenate([ends_host, ends_host - totals]))
+        return float(ends_host[-1]), both[:self.world], both[self.world:]
 
     def _draw(self, total, ends, offsets, p_random, first_slot, m):
         """Output slots [first_slot, first_slot + m) of views::sample | random_intersperse: the ancestor exchange (C3).
@@ -373,7 +404,7 @@ class ShardedAmcl:
         requests_out, order, send_counts = e.route_targets(targets, ends, offsets, self.rank)
         all_counts = torch.empty(world * world, dtype=torch.int64, device=self.device)
         self.net.all_gather(all_counts, send_counts)                 # counts[r][q]: r asks q for that many
-        counts = all_counts.cpu().view(world, world)
+        counts = self._to_host(all_counts).reshape(world, world)
         send_list, recv_list = counts[self.rank].tolist(), counts[:, self.rank].tolist()
         requests_in = e.empty(int(sum(recv_list)))
         self.net.all_to_all(requests_in, requests_out, recv_list, send_list)

@@ -669,3 +669,38 @@ def test_cluster_based_estimate_bimodal_cloud_and_update_path():
     np.testing.assert_allclose(est[0], want_pose, atol=1e-9)
     np.testing.assert_allclose(est[1], want_cov, rtol=1e-7, atol=1e-10)
     f.close()
+
+
+# ---- the two table forms of the default kernel ---------------------------------------------------------------------
+@pytest.mark.parametrize("table", ["palette", "cube"])
+@pytest.mark.parametrize("field_kind", ["distance_map", "arbitrary"])
+def test_reweight_lf_table_forms_match_oracle(table, field_kind, monkeypatch):
+    """The hot kernel reads the field through a palette (2-byte index per cell + exact f64 values in LDS) when the field
+    has few distinct values, and through an 8-byte table otherwise (an arbitrary field pushed through
+    mcl_set_likelihood_field has millions).  Both must give the reference's weights, including for beams that end far
+    outside the grid (clamped to the border tiles / the table's "unknown" slot) and right on its edges."""
+    if table == "cube":
+        monkeypatch.setenv("BELUGA_MCL_LF_TABLE", "cube")
+    grid = rooms_grid()
+    truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=2, clearance_cells=6)
+    pts = make_scan(grid, truth, 200, max_range=12.0)
+    pts = np.concatenate([pts, [[500.0, -300.0], [-1e4, 2e4], [0.0, 0.0]]])  # far outside / the sensor itself
+    n = 30_011
+    states = synth.normal_particles(n, truth, (0.5, 0.5, 0.2), seed=5)
+    h, w = grid.cells.shape
+    # particles on the grid's corners and edges: their beams straddle cell -1 / 0 and W-1 / W
+    edge = np.array([[-10.0, -10.0], [-10.0 + w * 0.05, -10.0], [-10.0, -10.0 + h * 0.05], [-10.0 + w * 0.05, -10.0 + h * 0.05]])
+    states[:4, 2:] = edge
+    states[4:8, 2] += 100.0
+    w0 = np.random.Generator(np.random.MT19937(3)).uniform(0.5, 1.5, n)
+    f = new_filter(grid, n)
+    if field_kind == "arbitrary":
+        rng = np.random.Generator(np.random.MT19937(9))
+        f.set_likelihood_field(rng.uniform(0.01, 1.2, size=grid.cells.shape).astype(np.float32))
+    f.set_particles(states, w0)
+    f.reweight(pts)
+    _, got = f.particles()
+    field = f.likelihood_field()
+    want = w0 * orc.lf_weights(field, grid.resolution, grid.origin, LF.max_laser_distance, states, pts)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+    f.close()
