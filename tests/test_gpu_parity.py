@@ -334,7 +334,7 @@ def test_initialize_matches_oracle_and_rejects_bad_covariance():
     f.close()
 
 
-def _run_both(grid, params, sensor, sensor_oracle_kw, cycles, beams, max_range, seed=21, init_sigma=(0.5, 0.5, 0.2)):
+def _run_both(grid, params, sensor, sensor_oracle_kw, cycles, beams, max_range, seed=21, init_sigma=(0.5, 0.5, 0.2), kidnap_at=None):
     origin_xy = (grid.origin[2], grid.origin[3])
     truth = synth.find_free_pose(grid.cells, grid.resolution, origin_xy, seed=4, clearance_cells=8)
     gpu = Amcl(grid, MOTION, sensor, params, seed=seed)
@@ -355,6 +355,8 @@ def _run_both(grid, params, sensor, sensor_oracle_kw, cycles, beams, max_range, 
         step_fwd, step_turn = (0.3, 0.05) if c % 5 != 4 else (0.02, 0.01)  # every 5th step is below update_min_d/a
         pose = synth.odometry_step(pose, step_fwd, step_turn)
         odom = synth.odometry_step(odom, step_fwd, step_turn)
+        if kidnap_at is not None and c == kidnap_at:  # the robot is carried elsewhere: the scans stop matching the cloud
+            pose = synth.find_free_pose(grid.cells, grid.resolution, origin_xy, seed=77, clearance_cells=8)
         pts = make_scan(grid, pose, beams, max_range=max_range, seed=100 + c)
         ctrl = se2_from_xytheta(*odom)
         g = gpu.update(ctrl, pts)
@@ -384,6 +386,28 @@ def test_update_cycle_end_to_end_fixed_size():
     # and the filter actually localises (beluga_system_tests tolerance: 0.9 m / 30 deg)
     est = results[-1][1][0]
     assert math.hypot(est[2] - truth[0], est[3] - truth[1]) < 0.9
+    gpu.close()
+
+
+@pytest.mark.parametrize("device_policy", ["1", "0"])
+def test_update_cycle_recovery_injection_fixed_size(device_policy, monkeypatch):
+    """Fixed N, no selective resampling: the recovery estimator (thrun_recovery_probability_estimator.hpp:69-89) runs on
+    the device and the cycle synchronises once (BELUGA_MCL_DEVICE_POLICY=0: on the host).  A kidnapped robot makes the fast
+    average drop below the slow one: random states are injected; probabilities, decisions and particles follow the oracle."""
+    monkeypatch.setenv("BELUGA_MCL_DEVICE_POLICY", device_policy)
+    grid = rooms_grid(400, 3)
+    params = AmclParams(min_particles=20_000, max_particles=20_000, alpha_slow=0.001, alpha_fast=0.1)
+    gpu, cpu, results, truth = _run_both(grid, params, LF, dict(lf=LF_T, lf_model_unknown_space=True), 12, 180, 12.0, kidnap_at=5)
+    injected = 0
+    for c, (gp, gc), (op, oc), gi, oi in results:
+        assert gi["random_state_probability"] == pytest.approx(oi["random_state_probability"], abs=1e-12), f"cycle {c}"
+        assert gi["weight_sum"] == pytest.approx(oi["weight_sum"], rel=1e-11)
+        np.testing.assert_allclose(gp, op, atol=1e-9, err_msg=f"cycle {c}")
+        injected += oi["random_state_probability"] > 0.0
+    assert injected >= 1
+    gs, _ = gpu.particles()
+    os_, _ = cpu.particles()
+    assert int(np.any(np.abs(gs - os_) > 1e-9, axis=1).sum()) <= 3
     gpu.close()
 
 
