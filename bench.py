@@ -116,6 +116,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MCL update has no CPU path")
+    # BELUGA_BENCH_BACKEND=gloo lets several ranks share one GPU (a dry run of the multi-rank flow on a 1-GPU box; the
+    # collectives are then staged through host memory by beluga_amd/sharded.py and the timings mean nothing)
+    backend = os.environ.get("BELUGA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     # Native libraries (RCCL's version banner) write to fd 1; the contract is ONE JSON line on stdout, so fd 1 is
     # parked on stderr until the result is printed.
@@ -126,7 +131,10 @@ def main():
     if use_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -170,7 +178,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = filt.profile_read(reset=False)
