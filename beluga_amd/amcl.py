@@ -232,6 +232,14 @@ class Amcl:
         self._check(self._lib.mcl_get_particles(self._ctx, _dp(s), _dp(w), n, C.byref(got)))
         return s, w
 
+    def sample_particle_cloud(self, size: int, draw_id: int = 0) -> np.ndarray:
+        """beluga_ros::assign_particle_cloud(particles, size, message) (particle_cloud.hpp:131-149): `size` states drawn
+        with probability proportional to the weights, (size, 4) as (cos, sin, x, y); the set is not modified."""
+        out = np.zeros((size, 4))
+        if size:
+            self._check(self._lib.mcl_sample_particle_cloud(self._ctx, size, draw_id, _dp(out)))
+        return out if self.num_particles() else out[:0]
+
     def force_update(self):
         """Amcl::force_update() (amcl_core.hpp:204)."""
         self._check(self._lib.mcl_force_update(self._ctx))

@@ -132,6 +132,7 @@ _SIGNATURES = {
     "mcl_estimate_pose": (C.c_int32, [_ctx, C.POINTER(Estimate)]),
     "mcl_cluster_based_estimate": (C.c_int32, [_ctx, C.POINTER(ClusterParams), C.POINTER(Estimate)]),
     "mcl_set_estimate_kind": (C.c_int32, [_ctx, C.c_int32, C.POINTER(ClusterParams)]),
+    "mcl_sample_particle_cloud": (C.c_int32, [_ctx, C.c_uint64, C.c_uint32, c_double_p]),
     "mcl_get_device_view": (C.c_int32, [_ctx, C.POINTER(DeviceView)]),
     "mcl_set_num_particles": (C.c_int32, [_ctx, C.c_uint64]),
     "mcl_build_cdf": (C.c_int32, [_ctx, c_double_p]),

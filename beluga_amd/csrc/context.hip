@@ -208,6 +208,8 @@ struct mcl_ctx {
   double* h_scalars{nullptr};        // pinned, 32 doubles
   double* hd_scalars{nullptr};       // the same memory as the device sees it: kernels mirror their scalar results into it
   DeviceBuffer<double> d_cdf;
+  DeviceBuffer<double4> d_cloud;    // mcl_sample_particle_cloud staging
+  DeviceBuffer<double> d_cloud_w;
   DeviceBuffer<double> d_cdf_tree;  // sampled levels of the 16-ary search tree over d_cdf (CdfTree)
   CdfTree cdf_tree() const { return make_cdf_tree(d_cdf.ptr, d_cdf_tree.ptr, n); }
 
@@ -905,6 +907,8 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_scalars.release();
   ctx->d_cdf.release();
   ctx->d_cdf_tree.release();
+  ctx->d_cloud.release();
+  ctx->d_cloud_w.release();
   ctx->d_hashes.release();
   ctx->d_table_keys.release();
   ctx->d_table_first.release();
@@ -1312,6 +1316,30 @@ mcl_status mcl_set_estimate_kind(mcl_ctx* ctx, int32_t kind, const mcl_cluster_p
   MCL_REQUIRE(ctx, kind == 0 || kind == 1, "estimate kind must be 0 (estimate) or 1 (cluster_based_estimate)");
   ctx->estimate_kind = kind;
   if (params) ctx->cluster_params = *params;
+  return MCL_OK;
+}
+
+mcl_status mcl_sample_particle_cloud(mcl_ctx* ctx, uint64_t size, uint32_t draw_id, double* states) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, size == 0 || states, "null output");
+  if (size == 0 || ctx->n == 0) return MCL_OK;  // particle_cloud.hpp:141: an empty set yields an empty message
+  if (const mcl_status s = bind_device(ctx)) return s;
+  MCL_HIP(ctx, ctx->d_cloud.ensure(size));
+  MCL_HIP(ctx, ctx->d_cloud_w.ensure(size));
+  if (const mcl_status s = do_build_cdf(ctx)) return s;
+  ResampleArgs ra{};
+  ra.seed = ctx->cfg.seed;
+  ra.step = 0x80000000u | draw_id;
+  ra.random_state_probability = 0.0;
+  ra.n_in = ctx->n;
+  ra.first_candidate = 0;
+  ra.count = size;
+  ra.out_offset = 0;
+  launch_resample_draw(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, Particles{ctx->d_cloud.ptr, ctx->d_cloud_w.ptr}, ra,
+                       ctx->grid_view(), FreeCells{nullptr, 0}, HashParams{1.0, 1.0, 1.0}, nullptr);
+  MCL_HIP(ctx, hipGetLastError());
+  MCL_HIP(ctx, hipMemcpyAsync(states, ctx->d_cloud.ptr, size * sizeof(double4), hipMemcpyDeviceToHost, ctx->stream));
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MCL_OK;
 }
 

@@ -320,6 +320,17 @@ class Amcl {
   /// Force a manual update of the particles on the next iteration of the filter (amcl_core.hpp:204).
   void force_update() { check(mcl_force_update(ctx_)); }
 
+  /// The pose sample behind beluga_ros::assign_particle_cloud(particles, size, PoseArray&)
+  /// (beluga_ros/include/beluga_ros/particle_cloud.hpp:131-149): `size` states drawn with probability proportional to the
+  /// weights (`views::sample | take_exactly(size)`); the set is not modified.  Pass a new draw_id per publication.
+  [[nodiscard]] std::vector<SE2d> sample_particle_cloud(std::size_t size, std::uint32_t draw_id = 0) const {
+    std::uint64_t n = 0;
+    check(mcl_num_particles(ctx_, &n));
+    std::vector<SE2d> out(n ? size : 0);
+    if (!out.empty()) check(mcl_sample_particle_cloud(ctx_, out.size(), draw_id, reinterpret_cast<double*>(out.data())));
+    return out;
+  }
+
   /// beluga::cluster_based_estimate (algorithm/cluster_based_estimation.hpp:415-433) of the current particle set.
   [[nodiscard]] estimation_type cluster_based_estimate(double linear_hash_resolution = 0.20, double angular_hash_resolution = 0.524,
                                                        double weight_cap_percentile = 0.90) const {

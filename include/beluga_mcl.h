@@ -228,6 +228,12 @@ mcl_status mcl_cluster_based_estimate(mcl_ctx* ctx, const mcl_cluster_params* pa
 /* Selects what mcl_update returns: 0 = beluga::estimate (beluga::Amcl), 1 = cluster_based_estimate (beluga_ros::Amcl). */
 mcl_status mcl_set_estimate_kind(mcl_ctx* ctx, int32_t kind, const mcl_cluster_params* params /* NULL: defaults */);
 
+/* beluga_ros::assign_particle_cloud(particles, size, PoseArray&) (beluga_ros/include/beluga_ros/particle_cloud.hpp:131-149):
+ * `particles | views::sample | take_exactly(size)` — a weighted sample of `size` states of the current set, for
+ * publication; the set itself is not modified.  states: size x 4 doubles (cos, sin, x, y), host memory.  The draws come
+ * from the counter-based stream (seed; index, 0x80000000 | draw_id): pass a different draw_id per publication. */
+mcl_status mcl_sample_particle_cloud(mcl_ctx* ctx, uint64_t size, uint32_t draw_id, double* states);
+
 /* ---- Device access for zero-copy interop (torch / RCCL hand-off) -------------------------------- */
 typedef struct mcl_device_view {
   double* states;     /* n records of 4 doubles (cos, sin, x, y) */

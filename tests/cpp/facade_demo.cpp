@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
     std::printf("below_threshold %d\n", filter.update(SE2d{ot, ox + 0.001, oy}, scan).has_value() ? 1 : 0);
     filter.force_update();
     std::printf("forced %d\n", filter.update(SE2d{ot, ox + 0.001, oy}, scan).has_value() ? 1 : 0);
+    std::printf("cloud %zu\n", filter.sample_particle_cloud(64, 1).size());
     std::printf("field_center %.9g\n", static_cast<double>(filter.likelihood_field()[40 * W + 10]));
   } catch (const std::runtime_error& e) {
     std::printf("runtime_error %s\n", e.what());

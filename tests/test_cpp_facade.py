@@ -60,6 +60,7 @@ def test_facade_matches_python_facade(demo):
         got = [float(v) for v in kv[f"update {c}"][:6]]
         np.testing.assert_allclose(got, [pose[0], pose[1], pose[2], pose[3], cov[0, 0], cov[2, 2]], rtol=0, atol=1e-12)
         assert int(kv[f"update {c}"][6]) == f.num_particles()
+    assert kv["cloud"] == ["64"]
     assert float(kv["field_center"][0]) == pytest.approx(float(f.likelihood_field()[40, 10]), rel=1e-7)
     bad = subprocess.run([demo, "bad-covariance"], capture_output=True, text=True)
     assert bad.returncode == 0 and "Invalid covariance matrix" in bad.stdout

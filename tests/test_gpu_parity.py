@@ -728,3 +728,25 @@ def test_reweight_lf_table_forms_match_oracle(table, field_kind, monkeypatch):
     want = w0 * orc.lf_weights(field, grid.resolution, grid.origin, LF.max_laser_distance, states, pts)
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
     f.close()
+
+
+def test_particle_cloud_sample_matches_oracle():
+    """beluga_ros::assign_particle_cloud(particles, size, PoseArray&) (particle_cloud.hpp:131-149): a weighted sample of
+    `size` states (views::sample | take_exactly) that leaves the set alone.  Same Philox stream on both sides."""
+    grid = rooms_grid()
+    truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=2, clearance_cells=6)
+    n, size, seed = 50_000, 7_001, 11
+    states = synth.normal_particles(n, truth, (0.5, 0.5, 0.2), seed=5)
+    w = np.random.Generator(np.random.MT19937(3)).uniform(0.0, 1.0, n) ** 6
+    f = new_filter(grid, n)
+    f.set_particles(states, w)
+    cloud = f.sample_particle_cloud(size, draw_id=3)
+    want, anc = orc.resample(states, w, size, size, 0.05, 3.0, (0.5, 0.5, 0.1), 0.0, seed, 0x80000000 | 3)
+    assert cloud.shape == (size, 4) and want.shape == (size, 4)
+    assert int(np.any(cloud != want, axis=1).sum()) <= 2  # CDF-rounding boundary draws at most
+    assert len(np.unique(anc)) > size // 4                # a genuine weighted sample, not one particle repeated
+    s2, w2 = f.particles()
+    assert np.array_equal(s2, states) and np.array_equal(w2, w)  # the set is untouched
+    assert f.sample_particle_cloud(0).shape == (0, 4)
+    assert not np.array_equal(f.sample_particle_cloud(size, draw_id=4), cloud)
+    f.close()
