@@ -18,12 +18,6 @@
 
 #include "rng.h"
 
-#ifndef LF_MAGIC_FLOOR
-#define LF_MAGIC_FLOOR 1
-#endif
-#ifndef LF_UNROLL
-#define LF_UNROLL 8
-#endif
 
 namespace mcl {
 namespace {
@@ -140,21 +134,6 @@ __device__ __forceinline__ double lf_beam(const FieldView& f, double px, double 
   return f.prob ? log(pz) : pz * pz * pz;
 }
 
-// The same term from the precomputed cube table through a raw buffer load: 32-bit byte offsets
-// (v_mad_u32_u24), no exec-mask branch, out-of-grid lanes redirected to the table's "unknown" slot.
-// Requires W*8 < 2^24 and (W*H+1)*8 < 2^32 (checked by the launcher).
-__device__ __forceinline__ double lf_beam_cube(__amdgpu_buffer_rsrc_t rsrc, const FieldView& f, uint32_t row_bytes,
-                                               uint32_t unknown_offset, double px, double py, double ct, double st, double xt,
-                                               double yt) {
-  const double x = px * ct - py * st + xt;
-  const double y = px * st + py * ct + yt;
-  const int xi = static_cast<int>(floor(x * f.inv_resolution));
-  const int yi = static_cast<int>(floor(y * f.inv_resolution));
-  const bool inside = static_cast<unsigned>(xi) < f.W && static_cast<unsigned>(yi) < f.H;
-  const uint32_t offset = inside ? __umul24(static_cast<unsigned>(yi), row_bytes) + (static_cast<unsigned>(xi) << 3) : unknown_offset;
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, offset, 0, 0));
-}
-
 // floor() of 2*G doubles at once without v_floor_f64 + v_cvt_i32_f64: with the f64 rounding mode switched to
 // round-toward-minus-infinity, v + 1.5*2^52 is exactly 1.5*2^52 + floor(v), whose low mantissa word is floor(v) as a
 // two's complement int32 (|v| < 2^31; larger magnitudes are far outside any grid and undefined upstream as well).
@@ -268,7 +247,6 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(f.cube), 0, static_cast<int>((cells + 1) * 8u), 0x00020000);
     const uint32_t row_bytes = f.W * 8u, unknown_offset = cells * 8u;
-#if LF_MAGIC_FLOOR
     uint32_t b = b_begin;
     for (; b + 8 <= b_end; b += 8) {
       double v[16];
@@ -289,13 +267,6 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
       floor_rd_2(vx, vy);
       acc += lf_cube_fetch(rsrc, f, row_bytes, unknown_offset, floor_rd_result(vx), floor_rd_result(vy));
     }
-#else
-#pragma unroll LF_UNROLL
-    for (uint32_t b = b_begin; b < b_end; ++b) {
-      const double px = pts[2 * b], py = pts[2 * b + 1];
-      acc += lf_beam_cube(rsrc, f, row_bytes, unknown_offset, px, py, ct, st, xt, yt);
-    }
-#endif
   } else {
 #pragma unroll 8
     for (uint32_t b = b_begin; b < b_end; ++b) {
@@ -319,13 +290,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
 // floors, 2 clamps, 2 for the table offset (the row part comes from a row-offset table in LDS), 1 add.
 // Workgroup memory: [0, (H+2)*4) row offsets for y = -1 .. H, [pal_base, pal_base + 8 * pal_count) the palette; the kernel
 // has no other LDS, so these are absolute LDS addresses.
-#ifndef LF_PAL_BLOCK
-#define LF_PAL_BLOCK 512
-#endif
-#ifndef LF_PAL_WAVES
-#define LF_PAL_WAVES 1
-#endif
-constexpr int kPalBlock = LF_PAL_BLOCK;
+constexpr int kPalBlock = 512;
 typedef __attribute__((address_space(3))) const double lds_f64_t;
 typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
 __device__ __forceinline__ int clamp_cell(int v, uint32_t hi) {  // max(-1, min(v, hi)) in one instruction
@@ -345,7 +310,7 @@ __device__ __forceinline__ double lf_palette_value(uint32_t lds_address) {
   return *reinterpret_cast<lds_f64_t*>(static_cast<uintptr_t>(lds_address));
 }
 
-__global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(LF_PAL_WAVES, 8))) void k_reweight_lf_palette(double* __restrict__ w, uint64_t n, FieldView f,
+__global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __restrict__ w, uint64_t n, FieldView f,
                                                                    const double* __restrict__ pts, uint32_t B,
                                                                    const uint32_t* __restrict__ perm, const double* __restrict__ tc,
                                                                    const double* __restrict__ ts, const double* __restrict__ tx,
@@ -1306,23 +1271,8 @@ __device__ __forceinline__ unsigned long long spatial_hash(const Pose2& s, const
          floor_and_fibo_hash(rot_log(s.r) / hp.res_theta, 42);
 }
 
-// std::lower_bound over cdf[0..n): first index with cdf[i] >= target, clamped to n-1
-// (discrete_distribution forces the last cumulative probability to one).
-__device__ __forceinline__ uint64_t cdf_lower_bound(const double* __restrict__ cdf, uint64_t n, double target) {
-  uint64_t lo = 0, len = n;
-  while (len > 0) {
-    const uint64_t half = len >> 1;
-    if (cdf[lo + half] < target) {
-      lo += half + 1;
-      len -= half + 1;
-    } else {
-      len = half;
-    }
-  }
-  return lo < n ? lo : n - 1;
-}
-
-// The same result through the 16-ary tree (CdfTree): one group of <= 16 entries (one cache line) per level.
+// std::lower_bound over the cdf: first index with cdf[i] >= target, clamped to n-1 (discrete_distribution forces the last
+// cumulative probability to one), through the 16-ary tree (CdfTree): one group of <= 16 entries (one cache line) per level.
 __device__ __forceinline__ uint64_t group_lower_bound(const double* __restrict__ a, uint64_t begin, uint64_t end, double target) {
   uint64_t lo = begin, len = end - begin;
   while (len > 0) {
