@@ -11,7 +11,7 @@
  *   - An SE2 pose is 4 doubles (cos, sin, x, y) = Sophus::SE2d::data() order, the layout of the
  *     reference's particle states (beluga/containers/tuple_vector.hpp:198 over Sophus::SE2d).
  *   - Particle sets cross the boundary as `states[n*4]` + `weights[n]` (host memory, caller owned).
- *     On the device they live as structure-of-arrays f64 buffers owned by the context.
+ *     On the device the poses live as the same 4-double records (plus a weight array), owned by the context.
  *   - A measurement is `points_xy[B*2]` doubles: lidar hits in the robot base frame
  *     (`std::vector<std::pair<double,double>>`, sensor/likelihood_field_model.hpp:48).
  *   - Every call returns mcl_status (0 = OK, <0 = error; mcl_last_error() has the text).  Calls on
