@@ -750,3 +750,36 @@ def test_particle_cloud_sample_matches_oracle():
     assert f.sample_particle_cloud(0).shape == (0, 4)
     assert not np.array_equal(f.sample_particle_cloud(size, draw_id=4), cloud)
     f.close()
+
+
+def test_frozen_update_cycles_fixture():
+    """The HIP path against tests/golden/update_cycles_config1.npz — the committed end-to-end vectors (20 cycles of BASELINE
+    config 1: turtlebot3 grid, 500..2000 particles, KLD + recovery): decisions and particle counts exactly, estimates 1e-9."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_cycle_fixture", os.path.join(GOLDEN, "make_cycle_fixture.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    want = np.load(gen.OUT)
+    cells, res, origin, truth, steps = gen.scenario()
+    p = gen.PARAMS
+    params = AmclParams(min_particles=p["min_particles"], max_particles=p["max_particles"], alpha_slow=p["alpha_slow"],
+                        alpha_fast=p["alpha_fast"], kld_epsilon=p["kld_epsilon"], kld_z=p["kld_z"], spatial_resolution_x=p["hash_res"][0],
+                        spatial_resolution_y=p["hash_res"][1], spatial_resolution_theta=p["hash_res"][2])
+    f = Amcl(OccupancyGrid(cells=cells, resolution=res, origin=origin), MOTION, LF, params, seed=gen.SEED)
+    f.initialize(truth, np.diag([0.25, 0.25, 0.0685]))
+    k = 0
+    for c, (ctrl, pts) in enumerate(steps):
+        out = f.update(ctrl, pts)
+        assert (out is not None) == bool(want["updated"][c]), f"cycle {c}"
+        if out is None:
+            continue
+        np.testing.assert_allclose(out[0], want["poses"][k], atol=1e-9, err_msg=f"cycle {c}")
+        np.testing.assert_allclose(out[1], want["covs"][k], rtol=1e-8, atol=1e-11, err_msg=f"cycle {c}")
+        assert f.num_particles() == want["counts"][k], f"cycle {c}"
+        assert f.last_info["weight_sum"] == pytest.approx(want["weight_sums"][k], rel=1e-11)
+        assert f.last_info["random_state_probability"] == pytest.approx(want["random_state_probability"][k], abs=1e-12)
+        k += 1
+    states, _ = f.particles()
+    assert states.shape == want["final_states"].shape
+    assert int(np.any(np.abs(states - want["final_states"]) > 1e-9, axis=1).sum()) <= 2
+    f.close()

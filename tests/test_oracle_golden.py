@@ -558,3 +558,25 @@ def test_cluster_estimation_heaviest_and_nightmare():  # :357-415
     mean, cov = orc.cluster_based_estimate(far, fw)
     np.testing.assert_allclose(mean, exp_mean, atol=1e-6)
     np.testing.assert_allclose(cov, exp_cov, atol=0.001)
+
+
+def test_frozen_update_cycles_fixture_is_reproduced():
+    """tests/golden/update_cycles_config1.npz (20 cycles of BASELINE config 1: KLD + recovery on the turtlebot3 grid) is the
+    oracle's frozen answer for the end-to-end level, which the reference pins only with smoke tests: the oracle must keep
+    reproducing it bit for bit."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_cycle_fixture", os.path.join(here, "golden", "make_cycle_fixture.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    want = np.load(gen.OUT)
+    cells, res, origin, truth, steps = gen.scenario()
+    f = orc.Amcl(seed=gen.SEED, **gen.PARAMS)
+    f.set_map(cells, res, origin)
+    f.initialize(truth, np.diag([0.25, 0.25, 0.0685]))
+    outs = [f.update(c, p) for c, p in steps]
+    assert [o is not None for o in outs] == list(want["updated"])
+    assert np.array_equal(np.array([o[0] for o in outs if o is not None]), want["poses"])
+    assert np.array_equal(np.array([o[1] for o in outs if o is not None]), want["covs"])
+    assert np.array_equal(f.particles()[0], want["final_states"])
