@@ -209,6 +209,7 @@ struct mcl_ctx {
   double* hd_scalars{nullptr};       // the same memory as the device sees it: kernels mirror their scalar results into it
   DeviceBuffer<double> d_cdf;
   DeviceBuffer<double4> d_cloud;    // mcl_sample_particle_cloud staging
+  DeviceBuffer<double> d_est_partials;  // [9][ceil(n / 256)] estimate sums left by the draw kernel
   DeviceBuffer<double> d_cloud_w;
   DeviceBuffer<double> d_cdf_tree;  // sampled levels of the 16-ary search tree over d_cdf (CdfTree)
   CdfTree cdf_tree() const { return make_cdf_tree(d_cdf.ptr, d_cdf_tree.ptr, n); }
@@ -571,8 +572,11 @@ mcl_status do_build_cdf(mcl_ctx* ctx, bool normalized_just_now = false) {
   return MCL_OK;
 }
 
+// with_estimate (fixed-N path only): the draw kernel also leaves the estimate sums of the new set in d_scalars[8..17) and
+// their host mirror; *estimate_enqueued says whether it did.
 mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t step, uint64_t* n_out,
-                       const double* d_random_state_probability = nullptr, bool normalized_just_now = false) {
+                       const double* d_random_state_probability = nullptr, bool normalized_just_now = false,
+                       bool with_estimate = false, bool* estimate_enqueued = nullptr) {
   const mcl_amcl_params& a = ctx->cfg.amcl;
   MCL_REQUIRE(ctx, ctx->n > 0, "mcl_resample: empty particle set");
   const uint64_t max_p = std::min<uint64_t>(a.max_particles, ctx->capacity);
@@ -593,7 +597,15 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
     ra.first_candidate = 0;
     ra.count = max_p;
     ra.out_offset = 0;
-    launch_resample_draw(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp, nullptr);
+    if (with_estimate) {
+      MCL_HIP(ctx, ctx->d_est_partials.ensure(static_cast<size_t>(9) * ((max_p + 255) / 256)));
+      launch_resample_draw_and_estimate(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp,
+                                        ctx->pivot[0], ctx->pivot[1], ctx->d_est_partials.ptr, ctx->d_scalars.ptr + 8,
+                                        ctx->hd_scalars + 8);
+      if (estimate_enqueued) *estimate_enqueued = true;
+    } else {
+      launch_resample_draw(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp, nullptr);
+    }
     MCL_HIP(ctx, hipGetLastError());
   } else {
     MCL_REQUIRE(ctx, max_p < 0xFFFFFFFFull, "max_particles too large for KLD resampling");
@@ -908,6 +920,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_cdf.release();
   ctx->d_cdf_tree.release();
   ctx->d_cloud.release();
+  ctx->d_est_partials.release();
   ctx->d_cloud_w.release();
   ctx->d_hashes.release();
   ctx->d_table_keys.release();
@@ -1184,6 +1197,7 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   double random_state_probability = 0.0;
   double ess = -1.0;
   bool do_resampling = false;
+  bool estimate_enqueued = false;  // the estimate sums of the resampled set came out of the draw kernel
   // With a fixed particle count and no selective resampling nothing in the cycle depends on a host-side decision: the
   // recovery estimator runs on the device as well and the cycle synchronises once, at the estimate.
   const mcl_amcl_params& ap = ctx->cfg.amcl;
@@ -1197,7 +1211,8 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
     launch_recovery_policy(ctx->stream, ctx->d_scalars.ptr + 1, ctx->n, ap.alpha_slow, ap.alpha_fast, do_resampling ? 1 : 0,
                            ctx->d_scalars.ptr + kPolicySlot, ctx->hd_scalars + kPolicySlot);                       // :179, :184-186
     if (do_resampling) {
-      if (const mcl_status s = do_resample(ctx, 0.0, ctx->step, nullptr, ctx->d_scalars.ptr + kPolicySlot + 2, true)) return s;  // :188-196
+      if (const mcl_status s = do_resample(ctx, 0.0, ctx->step, nullptr, ctx->d_scalars.ptr + kPolicySlot + 2, true, ctx->estimate_kind == 0,
+                                           &estimate_enqueued)) return s;  // :188-196
     }
   } else {
   if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), &stats)) return s;  // :177
@@ -1222,13 +1237,29 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
       ctx->slow.reset();
       ctx->fast.reset();
     }
-    if (const mcl_status s = do_resample(ctx, random_state_probability, ctx->step, nullptr, nullptr, true)) return s;  // :188-196
+    if (const mcl_status s = do_resample(ctx, random_state_probability, ctx->step, nullptr, nullptr, true, ctx->estimate_kind == 0,
+                                         &estimate_enqueued)) return s;  // :188-196
   }
   }
   ctx->force_update = false;  // :199
   mcl_estimate est{};
   if (ctx->estimate_kind == 1) {  // beluga_ros::Amcl returns cluster_based_estimate (beluga_ros/src/amcl.cpp:125)
     if (const mcl_status s = mcl_cluster_based_estimate(ctx, &ctx->cluster_params, &est)) return s;
+    if (std::isfinite(est.pose[2]) && std::isfinite(est.pose[3])) {
+      ctx->pivot[0] = est.pose[2];
+      ctx->pivot[1] = est.pose[3];
+    }
+  } else if (estimate_enqueued) {  // :200, sums already produced by the draw kernel
+    stage_begin(ctx, MCL_STAGE_ESTIMATE);
+    stage_end(ctx, MCL_STAGE_ESTIMATE);
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    stage_collect(ctx);
+    double sums[12];
+    for (int k = 0; k < 9; ++k) sums[k] = ctx->h_scalars[8 + k];
+    sums[9] = ctx->pivot[0];
+    sums[10] = ctx->pivot[1];
+    sums[11] = 0.0;
+    if (const mcl_status s = mcl_estimate_from_sums(sums, &est)) return s;
     if (std::isfinite(est.pose[2]) && std::isfinite(est.pose[3])) {
       ctx->pivot[0] = est.pose[2];
       ctx->pivot[1] = est.pose[3];

@@ -187,6 +187,9 @@ void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum
 // K6: one thread per candidate (views/sample.hpp:102,133-135; random_intersperse.hpp:90-115; particle_traits.hpp:105).
 void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst,
                           ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes);
+void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst, ResampleArgs a,
+                                       GridView g, FreeCells fc, HashParams hp, double pivot_x, double pivot_y, double* d_partials,
+                                       double* d_sums, double* host_mirror);
 // Sharded variant: targets given, no RNG (mcl_gather_by_cdf).
 // Sharded resampling helpers (mcl_resample_targets / mcl_commit_resampled).
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,

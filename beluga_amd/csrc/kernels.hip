@@ -1319,30 +1319,56 @@ __device__ __forceinline__ bool intersperse_here(const RngWords& r, uint64_t j, 
   return j > 0 && p > 0.0 && rng_uniform32(r.w[2]) < p && n_free > 0;
 }
 
+// kEstimate: the nine sums of beluga::estimate (estimation.hpp:436-475) over the new set (weights 1) are accumulated on the
+// way out — est_partials[k][workgroup] — so that the estimate needs no pass of its own over the particles it just wrote.
+template <bool kEstimate>
 __global__ __launch_bounds__(kBlock) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
                                                           Particles dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
-                                                          unsigned long long* __restrict__ hashes) {
+                                                          unsigned long long* __restrict__ hashes, double pivot_x, double pivot_y,
+                                                          double* __restrict__ est_partials, uint32_t est_stride) {
+  __shared__ double scratch[kEstimate ? (kBlock / 64) * 9 : 1];
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (t >= a.count) return;
-  const uint64_t j = a.first_candidate + t;
-  const RngWords r = rng_draw(a.seed, a.step, kRngResample, j);
-  Pose2 s;
-  const double p_random = a.d_random_state_probability ? *a.d_random_state_probability : a.random_state_probability;
-  const bool intersperse = intersperse_here(r, j, p_random, fc.count);
-  if (intersperse) {
-    s = random_free_state(a.seed, a.step, j, g, fc);
-  } else {
-    uint64_t idx = 0;
-    if (a.n_in >= 2) {
-      const double u = rng_uniform53(r.w[0], r.w[1]);
-      idx = cdf_tree_lower_bound(cdf, u * (*d_total));
+  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (t < a.count) {
+    const uint64_t j = a.first_candidate + t;
+    const RngWords r = rng_draw(a.seed, a.step, kRngResample, j);
+    Pose2 s;
+    const double p_random = a.d_random_state_probability ? *a.d_random_state_probability : a.random_state_probability;
+    const bool intersperse = intersperse_here(r, j, p_random, fc.count);
+    if (intersperse) {
+      s = random_free_state(a.seed, a.step, j, g, fc);
+    } else {
+      uint64_t idx = 0;
+      if (a.n_in >= 2) {
+        const double u = rng_uniform53(r.w[0], r.w[1]);
+        idx = cdf_tree_lower_bound(cdf, u * (*d_total));
+      }
+      s = load_pose(src, idx);
     }
-    s = load_pose(src, idx);
+    const uint64_t o = a.out_offset + t;
+    store_pose(dst, o, s);
+    dst.w[o] = 1.0;  // particle_traits.hpp:105
+    if (hashes) hashes[o] = spatial_hash(s, hp);
+    if (kEstimate) {
+      const double dx = s.x - pivot_x, dy = s.y - pivot_y;
+      v[0] = 1.0;
+      v[1] = 1.0;
+      v[2] = s.r.c;
+      v[3] = s.r.s;
+      v[4] = dx;
+      v[5] = dy;
+      v[6] = dx * dx;
+      v[7] = dx * dy;
+      v[8] = dy * dy;
+    }
   }
-  const uint64_t o = a.out_offset + t;
-  store_pose(dst, o, s);
-  dst.w[o] = 1.0;  // particle_traits.hpp:105
-  if (hashes) hashes[o] = spatial_hash(s, hp);
+  if (kEstimate) {
+    block_reduce<9>(v, scratch);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) est_partials[static_cast<size_t>(k) * est_stride + blockIdx.x] = v[k];
+    }
+  }
 }
 
 __global__ void k_recovery_policy(const double* __restrict__ d_norm_sum, uint64_t n, double alpha_slow, double alpha_fast, int resampling,
@@ -2011,10 +2037,20 @@ void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum
 void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst,
                           ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes) {
   if (a.count == 0) return;
-  hipLaunchKernelGGL(k_resample_draw, dim3(blocks_for(a.count)), dim3(kBlock), 0, st, src, cdf, d_total, dst, a, g, fc, hp,
-                     d_hashes);
+  hipLaunchKernelGGL(k_resample_draw<false>, dim3(blocks_for(a.count)), dim3(kBlock), 0, st, src, cdf, d_total, dst, a, g, fc, hp,
+                     d_hashes, 0.0, 0.0, static_cast<double*>(nullptr), 0u);
 }
 
+// The draw plus the estimate sums of the set it produces: d_partials needs 9 * ceil(count / 256) doubles.
+void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst, ResampleArgs a,
+                                       GridView g, FreeCells fc, HashParams hp, double pivot_x, double pivot_y, double* d_partials,
+                                       double* d_sums, double* host_mirror) {
+  const uint32_t blocks = blocks_for(a.count);
+  if (blocks)
+    hipLaunchKernelGGL(k_resample_draw<true>, dim3(blocks), dim3(kBlock), 0, st, src, cdf, d_total, dst, a, g, fc, hp,
+                       static_cast<unsigned long long*>(nullptr), pivot_x, pivot_y, d_partials, blocks);
+  hipLaunchKernelGGL(k_final_sum<9>, dim3(1), dim3(kBlock), 0, st, d_partials, blocks, blocks, d_sums, host_mirror);
+}
 
 void launch_recovery_policy(hipStream_t st, const double* d_norm_sum, uint64_t n, double alpha_slow, double alpha_fast, int resampling,
                             double* d_policy, double* host_mirror) {
