@@ -783,3 +783,26 @@ def test_frozen_update_cycles_fixture():
     assert states.shape == want["final_states"].shape
     assert int(np.any(np.abs(states - want["final_states"]) > 1e-9, axis=1).sum()) <= 2
     f.close()
+
+
+def test_update_cycles_are_bitwise_reproducible():
+    """Two filters, same seed, same inputs: identical particles, weights and estimates bit for bit, although the spatial
+    ordering uses LDS atomics (their arrival order changes which lane serves which particle, never a result)."""
+    grid = rooms_grid(400, 3)
+    origin_xy = (grid.origin[2], grid.origin[3])
+    truth = synth.find_free_pose(grid.cells, grid.resolution, origin_xy, seed=4, clearance_cells=8)
+    outs = []
+    for _ in range(2):
+        f = new_filter(grid, 60_000, min_particles=5_000)  # KLD-adaptive: exercises the hash table as well
+        f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+        pose, odom, est = truth, (0.0, 0.0, 0.0), []
+        for c in range(10):
+            pose = synth.odometry_step(pose, 0.3, 0.05)
+            odom = synth.odometry_step(odom, 0.3, 0.05)
+            est.append(f.update(se2_from_xytheta(*odom), make_scan(grid, pose, 360, max_range=12.0, seed=100 + c)))
+        outs.append((est, f.particles()))
+        f.close()
+    (e0, (s0, w0)), (e1, (s1, w1)) = outs
+    assert np.array_equal(s0, s1) and np.array_equal(w0, w1)
+    for a, b in zip(e0, e1):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
