@@ -199,6 +199,7 @@ struct mcl_ctx {
   // scan
   DeviceBuffer<double> d_points;
   double* h_points{nullptr};  // pinned
+  double scan_extent{0.0};    // max |x| + |y| of the uploaded scan points (NaN if any is NaN)
   size_t h_points_cap{0};
 
   // reductions / scans
@@ -488,6 +489,18 @@ mcl_status upload_points(mcl_ctx* ctx, const double* pts, uint64_t B) {
   // The pinned staging copy lets the H2D run asynchronously; the previous cycle's copy has
   // completed because every update ends with a stream synchronisation.
   std::memcpy(ctx->h_points, pts, 2 * B * sizeof(double));
+  {
+    double extent = 0.0;  // maximum of |x| + |y| over the scan; a NaN point makes it NaN (and every comparison with it false)
+    for (uint64_t i = 0; i < 2 * B; i += 2) {
+      const double e = std::abs(pts[i]) + std::abs(pts[i + 1]);
+      if (e != e) {
+        extent = e;
+        break;
+      }
+      extent = e > extent ? e : extent;
+    }
+    ctx->scan_extent = extent;
+  }
   MCL_HIP(ctx, hipMemcpyAsync(ctx->d_points.ptr, ctx->h_points, 2 * B * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   return MCL_OK;
 }
@@ -514,7 +527,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B) {
     if (variant == kLfSortedLanes) launch_lf_bin_sort(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), &sort);
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
     launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B), variant,
-                       &sort);
+                       &sort, ctx->scan_extent / ctx->resolution < 8192.0);
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
   } else {
     const mcl_beam_params& b = ctx->cfg.beam;

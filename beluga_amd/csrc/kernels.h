@@ -129,8 +129,9 @@ void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler 
 // Counting sort of the particles into (heading, x, y) bins + their world->field poses in sorted order.
 void launch_lf_bin_sort(hipStream_t st, Particles p, uint64_t n, FieldView f, const SortScratch* sort);
 // K2  actions/reweight.hpp:53-60 + likelihood_field_model.hpp:68-91 (kLfSortedLanes needs launch_lf_bin_sort first)
+// scan_is_short: every scan point lies within 8192 cells of the sensor (precondition of the kernel's FMA variant)
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
-                        const SortScratch* sort);
+                        const SortScratch* sort, bool scan_is_short);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_lf_bin_sort with world_to_field = origin_inverse first).
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,

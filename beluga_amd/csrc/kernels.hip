@@ -298,18 +298,45 @@ __device__ __forceinline__ int clamp_cell(int v, uint32_t hi) {  // max(-1, min(
   asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(v), "s"(hi));
   return r;
 }
-__device__ __forceinline__ uint32_t lf_palette_offset(const FieldView& f, int xi, int yi) {
+// The fast variant of the kernel (kFast, below) works on cell coordinates biased by kFastBias (the high word of
+// v + 1.5 * 2^20); there the row-offset table in LDS is stored with the x part of that bias already subtracted and the
+// exact evaluation adds it back (row_fix = kFastBiasX; 0 in the plain kernel).
+constexpr uint32_t kFastBias = 0x41380000u;      // high word of the double 1.5 * 2^20
+constexpr uint32_t kFastBiasX = kFastBias << 4;  // (mod 2^32) what a biased x contributes to the byte offset
+constexpr double kFastMagic = 1572864.0;         // 1.5 * 2^20: v + kFastMagic has 32 fraction bits in its low word
+__device__ __forceinline__ uint32_t lf_palette_offset(const FieldView& f, int xi, int yi, uint32_t row_fix) {
   const int xc = clamp_cell(xi, f.W), yc = clamp_cell(yi, f.H);
   const uint32_t row = *reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>(static_cast<uint32_t>(yc + 1) << 2));
-  return (static_cast<uint32_t>(xc) << 4) + row;
+  return (static_cast<uint32_t>(xc) << 4) + row_fix + row;
 }
-__device__ __forceinline__ uint32_t lf_palette_fetch(__amdgpu_buffer_rsrc_t rsrc, const FieldView& f, int xi, int yi) {
-  return static_cast<uint32_t>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, lf_palette_offset(f, xi, yi), 0, 0)));
+__device__ __forceinline__ int med3_i32(int v, int lo /* in a VGPR: one scalar operand per instruction */, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "s"(hi));
+  return r;
+}
+__device__ __forceinline__ uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ uint32_t lf_palette_fetch(__amdgpu_buffer_rsrc_t rsrc, const FieldView& f, int xi, int yi, uint32_t row_fix) {
+  return static_cast<uint32_t>(
+      static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, lf_palette_offset(f, xi, yi, row_fix), 0, 0)));
 }
 __device__ __forceinline__ double lf_palette_value(uint32_t lds_address) {
   return *reinterpret_cast<lds_f64_t*>(static_cast<uintptr_t>(lds_address));
 }
 
+// kFast (dense sets): the cell of an end-point is floor(v), v = the reference's separately rounded (p.cos - q.sin + t) / res.
+// An FMA evaluation v~ of the same real number (pose pre-multiplied by 1/res: 2 ops per axis instead of 5) differs from v
+// by less than 2^-35 cells as long as every term stays below 2^15 cells (7 roundings of relative size 2^-53 in all), so
+// floor(v~) == floor(v) unless v~ lies within 2^-33 of an integer.  v~ + 1.5 * 2^20 (round to nearest) has exactly 32
+// fraction bits in its low word and kFastBias + floor(v~) in its high word whenever the low word is not zero; a zero low
+// word (once in 2^32 end-points) sends the whole group of 8 beams through the exact evaluation instead, and so does a wave
+// holding a particle farther than 2^14 cells from the grid origin.  Clamps and offsets work on the biased high words.
+// 12 VALU ops per end-point instead of 17, same cells bit for bit; it pays where a wave's end-points fall into few
+// tiles (the gather costs a cycle per distinct line: profiles/r01_calib_gather_cost.txt), i.e. for dense particle sets.
+template <bool kFast>
 __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __restrict__ w, uint64_t n, FieldView f,
                                                                    const double* __restrict__ pts, uint32_t B,
                                                                    const uint32_t* __restrict__ perm, const double* __restrict__ tc,
@@ -319,7 +346,9 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
     uint32_t* s_row = reinterpret_cast<uint32_t*>(smem);
-    for (uint32_t j = threadIdx.x; j < f.H + 2; j += kPalBlock) s_row[j] = palette_row_offset(static_cast<int32_t>(j) - 1, f.pal_pitch);
+    constexpr uint32_t row_fix_stored = kFast ? kFastBiasX : 0u;
+    for (uint32_t j = threadIdx.x; j < f.H + 2; j += kPalBlock)
+      s_row[j] = palette_row_offset(static_cast<int32_t>(j) - 1, f.pal_pitch) - row_fix_stored;
     double* s_pal = reinterpret_cast<double*>(smem + f.pal_base);
     for (uint32_t k = threadIdx.x; k < f.pal_count; k += kPalBlock) s_pal[k] = f.pal_val[k];
   }
@@ -335,6 +364,7 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
   // Software-pipelined over groups of 8 beams, two groups (A, B) in flight alternately: the index gathers of one group
   // are outstanding while the end-points of the next are computed; a group's palette values are added, in beam order,
   // one step later.
+  constexpr uint32_t row_fix = kFast ? kFastBiasX : 0u;
   auto issue = [&](uint32_t (&e)[8], uint32_t b0) {
     double v[16];
 #pragma unroll
@@ -345,7 +375,7 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
     }
     floor_rd_16(v);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) e[k] = lf_palette_fetch(rsrc, f, floor_rd_result(v[2 * k]), floor_rd_result(v[2 * k + 1]));
+    for (int k = 0; k < 8; ++k) e[k] = lf_palette_fetch(rsrc, f, floor_rd_result(v[2 * k]), floor_rd_result(v[2 * k + 1]), row_fix);
   };
   auto consume = [&](uint32_t (&e)[8], bool) {
 #pragma unroll
@@ -353,6 +383,53 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
   };
   uint32_t b = b_begin;
   uint32_t groups = (b_end - b_begin) / 8;
+  bool fast = false;
+  if constexpr (kFast) {
+    const double ict = ct * f.inv_resolution, ist = st * f.inv_resolution, ixt = xt * f.inv_resolution, iyt = yt * f.inv_resolution;
+    const bool lane_small = fabs(ixt) < 16384.0 && fabs(iyt) < 16384.0;  // false for NaN as well
+    fast = __builtin_amdgcn_ballot_w64(!lane_small) == 0;
+    if (groups && fast) {
+      const int c_lo = static_cast<int>(kFastBias) - 1, x_hi = static_cast<int>(kFastBias + f.W), y_hi = static_cast<int>(kFastBias + f.H);
+      const uint32_t row_bias = 4u - (kFastBias << 2);  // LDS byte address of the row entry = (biased y << 2) + row_bias
+      auto issue_fast = [&](uint32_t (&e)[8], uint32_t b0) {
+        uint32_t near_integer = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const double px = pts[2 * (b0 + k)], py = pts[2 * (b0 + k) + 1];
+          const double sx = __builtin_fma(px, ict, __builtin_fma(-py, ist, ixt)) + kFastMagic;
+          const double sy = __builtin_fma(px, ist, __builtin_fma(py, ict, iyt)) + kFastMagic;
+          const uint64_t bx = __builtin_bit_cast(uint64_t, sx), by = __builtin_bit_cast(uint64_t, sy);
+          near_integer = min3_u32(near_integer, static_cast<uint32_t>(bx), static_cast<uint32_t>(by));
+          const int xc = med3_i32(static_cast<int>(bx >> 32), c_lo, x_hi), yc = med3_i32(static_cast<int>(by >> 32), c_lo, y_hi);
+          const uint32_t row = *reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>((static_cast<uint32_t>(yc) << 2) + row_bias));
+          e[k] = static_cast<uint32_t>(
+              static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, (static_cast<uint32_t>(xc) << 4) + row, 0, 0)));
+        }
+        if (__builtin_amdgcn_ballot_w64(near_integer == 0) != 0) issue(e, b0);  // an end-point on a cell boundary: exact path
+      };
+      uint32_t ea[8], eb[8];
+      issue_fast(ea, b);
+      b += 8;
+      --groups;
+      while (groups >= 2) {
+        issue_fast(eb, b);
+        consume(ea, true);
+        issue_fast(ea, b + 8);
+        consume(eb, true);
+        b += 16;
+        groups -= 2;
+      }
+      if (groups) {
+        issue_fast(eb, b);
+        consume(ea, true);
+        consume(eb, false);
+        b += 8;
+      } else {
+        consume(ea, false);
+      }
+      groups = 0;
+    }
+  }
   if (groups) {
     uint32_t ea[8], eb[8];
     issue(ea, b);
@@ -379,7 +456,7 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
     const double px = pts[2 * b], py = pts[2 * b + 1];
     double vx = (px * ct - py * st + xt) * f.inv_resolution, vy = (px * st + py * ct + yt) * f.inv_resolution;
     floor_rd_2(vx, vy);
-    acc += lf_palette_value(lf_palette_fetch(rsrc, f, floor_rd_result(vx), floor_rd_result(vy)));
+    acc += lf_palette_value(lf_palette_fetch(rsrc, f, floor_rd_result(vx), floor_rd_result(vy), row_fix));
   }
   if (t < n) {
     if (partial) {
@@ -1907,7 +1984,7 @@ void launch_lf_bin_sort(hipStream_t st, Particles p, uint64_t n, FieldView f, co
 }
 
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
-                        const SortScratch* sort) {
+                        const SortScratch* sort, bool scan_is_short) {
   if (n == 0) return;
   const bool idx32 = static_cast<uint64_t>(f.W) * f.H < (1ull << 31);
   if (variant == kLfSortedLanes && sort && n < (1ull << 32)) {
@@ -1932,8 +2009,19 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
     const bool palette_ok = table_pref == 0 && f.pal_idx != nullptr && f.pal_count > 0 && pal_lds <= 65536;
     if (palette_ok) {
       const dim3 pgrid(static_cast<unsigned>((n + kPalBlock - 1) / kPalBlock), segments);
-      hipLaunchKernelGGL(k_reweight_lf_palette, pgrid, dim3(kPalBlock), pal_lds, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
-                         sort->ts, sort->tx, sort->ty, partial, per_segment);
+      // BELUGA_MCL_LF_FAST: 1 = the FMA fast variant at any size, 0 = never; default: dense sets only (it needs a short scan
+      // and a grid below 2^14 cells per side either way)
+      static const int fast_pref = [] {
+        const char* v = std::getenv("BELUGA_MCL_LF_FAST");
+        return v ? std::atoi(v) : -1;
+      }();
+      const bool fast = scan_is_short && f.W < 16384 && f.H < 16384 && (fast_pref == 1 || (fast_pref < 0 && n >= 4'000'000));
+      if (fast)
+        hipLaunchKernelGGL(k_reweight_lf_palette<true>, pgrid, dim3(kPalBlock), pal_lds, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
+                           sort->ts, sort->tx, sort->ty, partial, per_segment);
+      else
+        hipLaunchKernelGGL(k_reweight_lf_palette<false>, pgrid, dim3(kPalBlock), pal_lds, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
+                           sort->ts, sort->tx, sort->ty, partial, per_segment);
     }
     else if (cube_ok)
       hipLaunchKernelGGL(k_reweight_lf_sorted<true>, grid, dim3(kBlock), 0, st, p.w, n, f, d_points, B, sort->perm, sort->tc,

@@ -806,3 +806,32 @@ def test_update_cycles_are_bitwise_reproducible():
     assert np.array_equal(s0, s1) and np.array_equal(w0, w1)
     for a, b in zip(e0, e1):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("fast", ["1", "0"])
+def test_reweight_lf_fma_variant_is_bit_identical(fast, monkeypatch):
+    """The dense-set variant of the LF kernel evaluates beam end-points with FMAs and falls back to the separately rounded
+    evaluation whenever the two could disagree on the cell (end-point within 2^-33 of a cell boundary) or a particle is too
+    far away for the error bound.  Forced on here at a small size; a power-of-two resolution puts many end-points exactly
+    on cell boundaries (the fallback's trigger), some particles sit 10^6 cells away, some beams end far outside the map."""
+    monkeypatch.setenv("BELUGA_MCL_LF_FAST", fast)
+    cells = synth.make_rooms_map(512, 512, seed=5, n_rooms=14)
+    res = 0.0625
+    grid = OccupancyGrid(cells=cells, resolution=res, origin=se2_from_xytheta(-16.0, -16.0, 0.0))
+    truth = synth.find_free_pose(cells, res, (-16.0, -16.0), seed=2, clearance_cells=6)
+    pts = make_scan(grid, truth, 200, max_range=12.0)
+    on_boundary = np.array([[k * res, (k % 7) * res] for k in range(1, 40)])  # multiples of the resolution
+    pts = np.concatenate([pts, on_boundary, [[300.0, -200.0]]])
+    n = 40_003
+    states = synth.normal_particles(n, truth, (0.5, 0.5, 0.2), seed=5)
+    states[:2000, 0], states[:2000, 1] = 1.0, 0.0                     # heading exactly 0
+    states[:2000, 2:] = np.round(states[:2000, 2:] / res) * res       # positions on the cell lattice
+    states[2000:2004, 2] += 1e5                                        # beyond the fast path's range
+    w0 = np.random.Generator(np.random.MT19937(3)).uniform(0.5, 1.5, n)
+    f = new_filter(grid, n)
+    f.set_particles(states, w0)
+    f.reweight(pts)
+    _, got = f.particles()
+    want = w0 * orc.lf_weights(f.likelihood_field(), res, grid.origin, LF.max_laser_distance, states, pts)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+    f.close()
