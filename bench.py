@@ -230,6 +230,10 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_lf,
                 "avg_launch_ms": lf_avg_s * 1e3,
                 "launches": int(lf_count),
+                # The table is cache resident (see `traffic`): the kernel's real ceiling is VALU issue.  6 v_mul_f64 + 7 v_add_f64
+                # + 4 32-bit ops per (particle, beam) at the issue costs measured on this part
+                # (profiles/r01_calib_f64_issue_rate.txt: 5.52 / 4.92 / 2.95 nominal cycles per wave64 instruction).
+                "valu_issue_floor_ms": n_local * BEAMS / 64 * (6 * 5.52 + 7 * 4.92 + 4 * 2.95) / (1024 * 2.4e9) * 1e3,
             },
         }
         if not args.no_cpu_baseline:
