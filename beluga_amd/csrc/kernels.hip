@@ -954,6 +954,39 @@ __device__ __forceinline__ void walk_seek(RayWalk& r, int k, int error) {
   r.y = r.steep ? r.sy + r.major_step * k : r.sy + r.minor_step * trips;
 }
 
+// The window walk of cast_ray_window: kSpec cells per round.  Step constants (bit position / word-row increments for a
+// plain major step and for a major + minor step) are template parameters, or kRuntimeStep to take them from the arguments.
+constexpr int kRuntimeStep = 0x7FFFFFFF;
+template <int MLX, int MROW, int BLX, int BROW>
+__device__ __forceinline__ void window_walk(const uint32_t* lds, int& lx, int& lrow, int& error, int& k, int& hit_k, int upto, int dminor,
+                                            int dmajor, int r_m_lx, int r_m_row, int r_b_lx, int r_b_row) {
+  const int m_lx = MLX == kRuntimeStep ? r_m_lx : MLX, m_row = MROW == kRuntimeStep ? r_m_row : MROW;
+  const int b_lx = BLX == kRuntimeStep ? r_b_lx : BLX, b_row = BROW == kRuntimeStep ? r_b_row : BROW;
+  while (k + kSpec - 1 <= upto) {
+    uint32_t words[kSpec];
+    int bits[kSpec];
+#pragma unroll
+    for (int u = 0; u < kSpec; ++u) {
+      words[u] = lds[lrow + (lx >> 5)];
+      bits[u] = lx & 31;
+      error += dminor;
+      const bool trip = error > dmajor;
+      lx += trip ? b_lx : m_lx;
+      lrow += trip ? b_row : m_row;
+      error -= trip ? dmajor : 0;
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int u = kSpec - 1; u >= 0; --u) {
+      const uint32_t occ = (words[u] >> bits[u]) & 1u;
+      any |= occ;
+      hit_k = occ ? k + u : hit_k;  // descending u: the smallest u with a set bit wins
+    }
+    if (any) break;
+    k += kSpec;
+  }
+}
+
 __device__ __forceinline__ double cast_ray_window(const GridView& g, const BitWindow& w, int sx, int sy, int fx, int fy,
                                                   double max_range, unsigned long long& steps) {
   RayWalk r = walk_begin(g, sx, sy, fx, fy);
@@ -962,33 +995,30 @@ __device__ __forceinline__ double cast_ray_window(const GridView& g, const BitWi
   const int upto = min(r.last, in_window);
   if (upto >= kSpec - 1) {
     // Hot loop: whole groups of kSpec cells, all inside the grid and the window, addressed incrementally in LDS
-    // (bit position along x, word-row offset along y); ~13 integer ops per cell.
+    // (bit position along x, word-row offset along y).  The lanes of a wave follow the same beam from neighbouring
+    // poses, so they almost always share the octant of the line: the loop is instantiated per octant with the four
+    // step constants known at compile time (no per-cell selects), with a generic instance for mixed waves.
     int lx = sx - w.x0, lrow = (sy - w.y0) * kWinStride;
-    const int m_lx = r.steep ? 0 : r.major_step, m_row = r.steep ? r.major_step * kWinStride : 0;
-    const int b_lx = m_lx + (r.steep ? r.minor_step : 0), b_row = m_row + (r.steep ? 0 : r.minor_step * kWinStride);
     int error = r.error, k = 0, hit_k = -1;
-    while (k + kSpec - 1 <= upto) {
-      uint32_t words[kSpec];
-      int bits[kSpec];
-#pragma unroll
-      for (int u = 0; u < kSpec; ++u) {
-        words[u] = w.lds[lrow + (lx >> 5)];
-        bits[u] = lx & 31;
-        error += r.dminor;
-        const bool trip = error > r.dmajor;
-        lx += trip ? b_lx : m_lx;
-        lrow += trip ? b_row : m_row;
-        error -= trip ? r.dmajor : 0;
+    const int octant = (r.steep ? 4 : 0) | (r.major_step > 0 ? 2 : 0) | (r.minor_step > 0 ? 1 : 0);
+    const int wave_octant = __builtin_amdgcn_readfirstlane(octant);
+    constexpr int S = kWinStride;
+    if (__builtin_amdgcn_ballot_w64(octant != wave_octant) == 0) {
+      switch (wave_octant) {
+        case 0: window_walk<-1, 0, -1, -S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
+        case 1: window_walk<-1, 0, -1, +S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
+        case 2: window_walk<+1, 0, +1, -S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
+        case 3: window_walk<+1, 0, +1, +S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
+        case 4: window_walk<0, -S, -1, -S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
+        case 5: window_walk<0, -S, +1, -S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
+        case 6: window_walk<0, +S, -1, +S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
+        default: window_walk<0, +S, +1, +S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
       }
-      uint32_t any = 0;
-#pragma unroll
-      for (int u = kSpec - 1; u >= 0; --u) {
-        const uint32_t occ = (words[u] >> bits[u]) & 1u;
-        any |= occ;
-        hit_k = occ ? k + u : hit_k;  // descending u: the smallest u with a set bit wins
-      }
-      if (any) break;
-      k += kSpec;
+    } else {
+      const int m_lx = r.steep ? 0 : r.major_step, m_row = r.steep ? r.major_step * kWinStride : 0;
+      const int b_lx = m_lx + (r.steep ? r.minor_step : 0), b_row = m_row + (r.steep ? 0 : r.minor_step * kWinStride);
+      window_walk<kRuntimeStep, kRuntimeStep, kRuntimeStep, kRuntimeStep>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, m_lx,
+                                                                          m_row, b_lx, b_row);
     }
     if (hit_k >= 0) {
       walk_seek(r, hit_k, 0);
