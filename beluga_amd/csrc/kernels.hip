@@ -796,7 +796,7 @@ __device__ __forceinline__ void cell_near(const GridView& g, double px, double p
 // (hit) or past the end of the line (no hit).  The walk is evaluated kSpec cells at a time: the Bresenham state of the
 // next cells does not depend on the grid, so their loads are issued together and examined in order — same cells, same
 // order, same result, but the load latency of a step is no longer serialised behind the previous step's compare.
-constexpr int kSpec = 4;
+constexpr int kSpec = 8;
 // The loop below is the same walk in a form that costs ~8 integer ops per cell instead of ~30:
 //  * the line is expressed as a major step (every cell) and a minor step (when the error term trips), applied to
 //    the linear cell index, so there is no per-cell axis swap and no multiply;
