@@ -212,6 +212,39 @@ class Amcl:
             raise RuntimeError("Invalid covariance matrix")  # multivariate_normal_distribution.hpp:114-124
         self._check(st)
 
+    def initialize_from_map(self):
+        """beluga_ros::Amcl::initialize_from_map() (beluga_ros/include/beluga_ros/amcl.hpp:209): max_particles states drawn
+        uniformly over the free cells of the map (random/multivariate_uniform_distribution.hpp:126-161)."""
+        self._check(self._lib.mcl_initialize_from_map(self._ctx))
+
+    def has_likelihood_field(self) -> bool:
+        """beluga_ros::Amcl::has_likelihood_field() (amcl.hpp:181-188)."""
+        v = C.c_int32(0)
+        self._check(self._lib.mcl_has_likelihood_field(self._ctx, C.byref(v)))
+        return bool(v.value)
+
+    def likelihood_field_origin(self) -> np.ndarray:
+        """beluga_ros::Amcl::likelihood_field_origin() (amcl.hpp:161-178) as (cos, sin, x, y); RuntimeError for the beam model."""
+        out = np.zeros(4)
+        st = self._lib.mcl_get_likelihood_field_origin(self._ctx, _dp(out))
+        if st == capi.MCL_ERR_UNSUPPORTED:
+            raise RuntimeError("The current sensor model does not support likelihood field")
+        self._check(st)
+        return out
+
+    def update_point_cloud(self, control_action, points_xyz, origin_se3=(0, 0, 0, 1, 0, 0, 0)):
+        """beluga_ros::Amcl::update(base_pose_in_odom, SparsePointCloud3f) (beluga_ros/src/amcl.cpp:67-81)."""
+        ctrl = np.ascontiguousarray(control_action, dtype=np.float64)
+        pts = np.ascontiguousarray(points_xyz, dtype=np.float32).reshape(-1, 3)
+        origin = np.ascontiguousarray(origin_se3, dtype=np.float64)
+        self._check(self._lib.mcl_update_point_cloud(self._ctx, _dp(ctrl), pts.ctypes.data_as(capi.c_float_p), len(pts), _dp(origin),
+                                                     self._est_ref, self._info_ref))
+        self._have_info = True
+        if not self._info.updated:
+            return None
+        out = self._est_view.copy()
+        return out[:4], out[4:13].reshape(3, 3)
+
     def set_particles(self, states, weights):
         """Amcl::initialize(distribution) with caller-drawn states (amcl_core.hpp:131-137)."""
         s = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 4)
@@ -393,8 +426,27 @@ class Amcl:
         return v.value
 
     # -- measurement hooks ---------------------------------------------------------------------------
-    def profile_enable(self, on: bool = True):
-        self._check(self._lib.mcl_profile_enable(self._ctx, int(on)))
+    def profile_enable(self, on=True):
+        """True / 2: HIP events around every stage; 1: around the sensor kernel only (what a timed run can afford: an event
+        record costs ~5 us of stream time); False / 0: off."""
+        level = 2 if on is True else int(on)
+        self._check(self._lib.mcl_profile_enable(self._ctx, level))
+
+    def set_option(self, name: str, value: int):
+        """A/B switch of the library (include/beluga_mcl.h, mcl_set_option); no option changes a result."""
+        self._check(self._lib.mcl_set_option(self._ctx, name.encode(), int(value)))
+
+    def counter(self, name: str) -> int:
+        v = C.c_uint64(0)
+        self._check(self._lib.mcl_get_counter(self._ctx, name.encode(), C.byref(v)))
+        return v.value
+
+    def debug_order(self):
+        """(perm, keys) of the spatial ordering of the current set: keys[perm] is non-decreasing."""
+        n = self.num_particles()
+        perm, keys = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+        self._check(self._lib.mcl_debug_order(self._ctx, perm.ctypes.data_as(capi.c_u32_p), keys.ctypes.data_as(capi.c_u32_p)))
+        return perm, keys
 
     def profile_read(self, reset: bool = True):
         ms = (C.c_double * len(capi.STAGES))()
@@ -438,3 +490,15 @@ def estimate_from_sums(sums: np.ndarray):
     if st != capi.MCL_OK:
         raise capi.MclError(st, "mcl_estimate_from_sums")
     return np.array(est.pose), np.array(est.covariance).reshape(3, 3)
+
+
+def project_point_cloud(points_xyz, origin_se3=(0, 0, 0, 1, 0, 0, 0)) -> np.ndarray:
+    """Points of a beluga_ros::SparsePointCloud3f in the base frame, projected onto z = 0 (beluga_ros/src/amcl.cpp:73-76)."""
+    lib = capi.load()
+    pts = np.ascontiguousarray(points_xyz, dtype=np.float32).reshape(-1, 3)
+    origin = np.ascontiguousarray(origin_se3, dtype=np.float64)
+    out = np.zeros((len(pts), 2))
+    st = lib.mcl_project_point_cloud(pts.ctypes.data_as(capi.c_float_p), len(pts), _dp(origin), _dp(out))
+    if st != capi.MCL_OK:
+        raise capi.MclError(st, "mcl_project_point_cloud")
+    return out

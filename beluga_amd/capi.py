@@ -18,6 +18,7 @@ MCL_ERR_OUT_OF_MEMORY = -3
 MCL_ERR_NOT_READY = -4
 MCL_ERR_BAD_COVARIANCE = -5
 MCL_ERR_NO_DEVICE = -6
+MCL_ERR_UNSUPPORTED = -7
 
 MCL_SENSOR_LIKELIHOOD_FIELD = 0
 MCL_SENSOR_BEAM = 1
@@ -30,6 +31,7 @@ c_double_p = C.POINTER(C.c_double)
 c_float_p = C.POINTER(C.c_float)
 c_i8_p = C.POINTER(C.c_int8)
 c_u64_p = C.POINTER(C.c_uint64)
+c_u32_p = C.POINTER(C.c_uint32)
 
 
 class AmclParams(C.Structure):
@@ -152,6 +154,14 @@ _SIGNATURES = {
     "mcl_profile_enable": (C.c_int32, [_ctx, C.c_int32]),
     "mcl_profile_read": (C.c_int32, [_ctx, c_double_p, c_u64_p, C.c_int32]),
     "mcl_beam_cells_visited": (C.c_int32, [_ctx, c_u64_p, C.c_int32]),
+    "mcl_initialize_from_map": (C.c_int32, [_ctx]),
+    "mcl_has_likelihood_field": (C.c_int32, [_ctx, C.POINTER(C.c_int32)]),
+    "mcl_get_likelihood_field_origin": (C.c_int32, [_ctx, c_double_p]),
+    "mcl_project_point_cloud": (C.c_int32, [c_float_p, C.c_uint64, c_double_p, c_double_p]),
+    "mcl_update_point_cloud": (C.c_int32, [_ctx, c_double_p, c_float_p, C.c_uint64, c_double_p, C.POINTER(Estimate), C.POINTER(UpdateInfo)]),
+    "mcl_set_option": (C.c_int32, [_ctx, C.c_char_p, C.c_int64]),
+    "mcl_get_counter": (C.c_int32, [_ctx, C.c_char_p, c_u64_p]),
+    "mcl_debug_order": (C.c_int32, [_ctx, c_u32_p, c_u32_p]),
     "mcl_version": (C.c_char_p, []),
 }
 

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -196,11 +197,14 @@ struct mcl_ctx {
   uint64_t n_free{0};
   std::vector<float> h_field;
 
-  // scan
+  // scan: staged in mapped pinned host memory and pulled into d_points by a kernel of the cycle (no copy-engine hand-off)
   DeviceBuffer<double> d_points;
-  double* h_points{nullptr};  // pinned
-  double scan_extent{0.0};    // max |x| + |y| of the uploaded scan points (NaN if any is NaN)
+  double* h_points{nullptr};   // pinned, mapped
+  double* hd_points{nullptr};  // the same memory as the device sees it
+  double scan_extent{0.0};     // max |x| + |y| of the uploaded scan points (NaN if any is NaN)
   size_t h_points_cap{0};
+  hipEvent_t points_event{nullptr};  // recorded behind the kernel that pulls h_points
+  bool points_in_flight{false}, points_event_valid{false};
 
   // reductions / scans
   DeviceBuffer<double> d_chunk;      // [12][stride]
@@ -247,16 +251,21 @@ struct mcl_ctx {
   uint32_t step{0};
   bool have_pivot{false};
   double pivot[2]{0, 0};
-  int lf_variant{kLfSortedLanes};
-  bool device_policy_allowed{true};  // BELUGA_MCL_DEVICE_POLICY=0 keeps the recovery estimator on the host (A/B, tests)
-  // scratch of the spatially binned likelihood-field kernel
+  Tuning tuning{};  // mcl_set_option / BELUGA_MCL_* at mcl_create (A/B measurements, tests)
+  // Key frame of the spatial ordering (kernels.h KeyFrame): the last estimate of the set, when the host has one.
+  bool have_cloud_estimate{false};
+  double cloud_mean[3]{0, 0, 0};   // x, y, theta
+  double cloud_sigma[3]{0, 0, 0};  // standard deviations of x, y, theta
+  uint64_t lf_fast_launches{0};    // launches of the FMA variant of the LF kernel (mcl_get_counter)
+  // scratch of the spatial ordering
   DeviceBuffer<uint32_t> d_route_u32;           // scratch of mcl_route_targets
-  DeviceBuffer<uint32_t> d_sort_u32;            // keys[cap] perm[cap] block_hist chunk_sum chunk_off
+  DeviceBuffer<uint32_t> d_sort_u32;            // keys[cap] perm[cap] table[1024 * nblocks] totals[1024]
   DeviceBuffer<unsigned long long> d_sort_u64;  // keyidx[cap]
-  DeviceBuffer<double> d_sort_f64;              // bbox[8 + 6*nblocks] tc ts tx ty [cap each]
+  DeviceBuffer<double> d_sort_f64;              // frame[8] bbox[8 + 6*nblocks] partial[...]
 
-  // profiling
-  bool profile{false};
+  // profiling: 0 = off, 1 = the sensor kernel only (two events per cycle), 2 = every stage
+  int profile{0};
+  uint32_t profile_tick{0};  // reweight launches since profiling was switched on
   hipEvent_t ev[MCL_NUM_STAGES][2]{};
   bool ev_pending[MCL_NUM_STAGES]{};
   double prof_ms[MCL_NUM_STAGES]{};
@@ -273,23 +282,14 @@ struct mcl_ctx {
   SortScratch sort_scratch() {
     SortScratch s{};
     const size_t nblocks = num_chunks(capacity);
-    const size_t hist = kSortDigits * nblocks;
     s.keys = d_sort_u32.ptr;
     s.perm = s.keys + capacity;
-    s.block_hist = s.perm + capacity;
-    s.chunk_sum = s.block_hist + hist;
-    s.chunk_off = s.chunk_sum + (hist / kChunk + 1);
+    s.table = s.perm + capacity;
+    s.totals = s.table + kSortDigits * nblocks;
     s.keyidx = d_sort_u64.ptr;
-    s.bbox = d_sort_f64.ptr;
-    s.tc = s.bbox + 8 + 6 * nblocks;
-    s.ts = s.tc + capacity;
-    s.tx = s.ts + capacity;
-    s.ty = s.tx + capacity;
-    s.partial = s.ty + capacity;
-    {
-      const uintptr_t end = reinterpret_cast<uintptr_t>(s.partial + kLfMaxSegments * std::min<uint64_t>(capacity, kLfSegmentedBelow));
-      s.pose_part = reinterpret_cast<double4*>((end + 31) & ~static_cast<uintptr_t>(31));
-    }
+    s.frame = reinterpret_cast<KeyFrame*>(d_sort_f64.ptr);
+    s.bbox = d_sort_f64.ptr + 8;
+    s.partial = s.bbox + 8 + 6 * nblocks;
     return s;
   }
   GridView grid_view() const { return GridView{d_cells.ptr, W, H, resolution, origin, origin_inverse, traits.free_value}; }
@@ -322,17 +322,24 @@ mcl_status bind_device(mcl_ctx* ctx) {
   return MCL_OK;
 }
 
+// Level 1 times the sensor kernel of every kProfileSampleEvery-th cycle only: an event record costs ~5 us of stream time,
+// and this is the level a timed run uses.
+constexpr uint32_t kProfileSampleEvery = 4;
+bool stage_timed(const mcl_ctx* ctx, int stage) {
+  return ctx->profile >= 2 || (ctx->profile == 1 && stage == MCL_STAGE_SENSOR_KERNEL && ctx->profile_tick % kProfileSampleEvery == 0);
+}
 void stage_begin(mcl_ctx* ctx, int stage) {
-  if (!ctx->profile) return;
+  if (!stage_timed(ctx, stage)) return;
   (void)hipEventRecord(ctx->ev[stage][0], ctx->stream);
 }
 void stage_end(mcl_ctx* ctx, int stage) {
-  if (!ctx->profile) return;
+  if (!stage_timed(ctx, stage)) return;
   (void)hipEventRecord(ctx->ev[stage][1], ctx->stream);
   ctx->ev_pending[stage] = true;
 }
 // Call after the stream has been synchronised.
 void stage_collect(mcl_ctx* ctx) {
+  ctx->points_in_flight = false;  // the stream has been synchronised: the kernel that pulled the scan is done
   if (!ctx->profile) return;
   for (int s = 0; s < MCL_NUM_STAGES; ++s) {
     if (!ctx->ev_pending[s]) continue;
@@ -354,11 +361,11 @@ mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
   MCL_HIP(ctx, ctx->d_cdf_tree.ensure(cdf_tree_doubles(cap)));
   ctx->capacity = cap;
   {
-    const size_t hist = static_cast<size_t>(kSortDigits) * num_chunks(cap);
-    MCL_HIP(ctx, ctx->d_sort_u32.ensure(2 * cap + hist + 2 * (hist / kChunk + 1)));
+    static_assert(sizeof(KeyFrame) <= 8 * sizeof(double), "the key frame sits in the first 8 doubles of d_sort_f64");
+    const size_t table = static_cast<size_t>(kSortDigits) * num_chunks(cap);
+    MCL_HIP(ctx, ctx->d_sort_u32.ensure(2 * cap + table + kSortDigits));
     MCL_HIP(ctx, ctx->d_sort_u64.ensure(cap));
-    MCL_HIP(ctx, ctx->d_sort_f64.ensure(8 + 6 * static_cast<size_t>(chunks) + 4 * cap +
-                                        kLfMaxSegments * std::min<uint64_t>(cap, kLfSegmentedBelow) + 4 * cap + 4));
+    MCL_HIP(ctx, ctx->d_sort_f64.ensure(8 + 8 + 6 * static_cast<size_t>(chunks) + kLfMaxSegments * std::min<uint64_t>(cap, kLfSegmentedBelow)));
   }
   return MCL_OK;
 }
@@ -477,64 +484,154 @@ mcl_status rebuild_cube(mcl_ctx* ctx, const float* h_field) {
   return MCL_OK;
 }
 
-mcl_status upload_points(mcl_ctx* ctx, const double* pts, uint64_t B) {
+// Stages the scan in mapped pinned memory; a kernel of the cycle pulls it into d_points (pull_scan_args / launch_pull_scan).
+mcl_status stage_points(mcl_ctx* ctx, const double* pts, uint64_t B) {
   if (B == 0) return MCL_OK;
   MCL_HIP(ctx, ctx->d_points.ensure(2 * B));
+  if (ctx->points_in_flight) {  // an earlier call may still be reading the staging buffer
+    if (ctx->points_event_valid) MCL_HIP(ctx, hipEventSynchronize(ctx->points_event));
+    else MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->points_in_flight = false;
+  }
   if (ctx->h_points_cap < 2 * B) {
     if (ctx->h_points) (void)hipHostFree(ctx->h_points);
     ctx->h_points = nullptr;
-    MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_points), 2 * B * sizeof(double)));
+    ctx->hd_points = nullptr;
+    ctx->h_points_cap = 0;
+    MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_points), 2 * B * sizeof(double), hipHostMallocMapped));
+    MCL_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->hd_points), ctx->h_points, 0));
     ctx->h_points_cap = 2 * B;
   }
-  // The pinned staging copy lets the H2D run asynchronously; the previous cycle's copy has
-  // completed because every update ends with a stream synchronisation.
-  std::memcpy(ctx->h_points, pts, 2 * B * sizeof(double));
-  {
-    double extent = 0.0;  // maximum of |x| + |y| over the scan; a NaN point makes it NaN (and every comparison with it false)
-    for (uint64_t i = 0; i < 2 * B; i += 2) {
-      const double e = std::abs(pts[i]) + std::abs(pts[i + 1]);
-      if (e != e) {
-        extent = e;
-        break;
-      }
-      extent = e > extent ? e : extent;
-    }
-    ctx->scan_extent = extent;
+  double extent = 0.0;  // maximum of |x| + |y| over the scan; a NaN point makes it NaN (and every comparison with it false)
+  bool poisoned = false;
+  for (uint64_t i = 0; i < 2 * B; i += 2) {
+    const double x = pts[i], y = pts[i + 1];
+    ctx->h_points[i] = x;
+    ctx->h_points[i + 1] = y;
+    const double e = std::abs(x) + std::abs(y);
+    if (e != e) poisoned = true;
+    extent = e > extent ? e : extent;
   }
-  MCL_HIP(ctx, hipMemcpyAsync(ctx->d_points.ptr, ctx->h_points, 2 * B * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ctx->scan_extent = poisoned ? std::numeric_limits<double>::quiet_NaN() : extent;
   return MCL_OK;
 }
+// Call right behind the launch that pulls h_points.  with_event: a stage-level call that may return before the stream is
+// synchronised (mcl_update always ends with a synchronisation, which clears the flag: no event record on its stream).
+void points_pulled(mcl_ctx* ctx, bool with_event) {
+  if (with_event) (void)hipEventRecord(ctx->points_event, ctx->stream);
+  ctx->points_event_valid = with_event;
+  ctx->points_in_flight = true;
+}
 
-mcl_status do_propagate(mcl_ctx* ctx, const Pose2& pose, const Pose2& prev, uint32_t step) {
+// The frame of the ordering keys for the set as it will be AFTER this propagation: the last estimate moved by the mean
+// motion, spans widened by the motion noise.  Only the balance of the key's bins depends on it.
+bool predict_key_frame(const mcl_ctx* ctx, const DiffDriveSampler* motion, KeyFrame* out) {
+  if (!ctx->have_cloud_estimate) return false;
+  double x = ctx->cloud_mean[0], y = ctx->cloud_mean[1], t = ctx->cloud_mean[2];
+  double sx = ctx->cloud_sigma[0], sy = ctx->cloud_sigma[1], st = ctx->cloud_sigma[2];
+  if (motion && motion->kind != MCL_MOTION_STATIONARY) {
+    const double heading = t + (motion->kind == MCL_MOTION_DIFFERENTIAL ? motion->m1 : std::atan2(motion->first_s, motion->first_c));
+    x += motion->mt * std::cos(heading);
+    y += motion->mt * std::sin(heading);
+    t += motion->kind == MCL_MOTION_DIFFERENTIAL ? motion->m1 + motion->m2 : motion->m1;
+    const double lateral = motion->mt * st;  // a heading error turns into a lateral one over the translation
+    const double noise2 = motion->st * motion->st + lateral * lateral + (motion->kind == MCL_MOTION_OMNIDIRECTIONAL ? motion->s2 * motion->s2 : 0.0);
+    sx = std::sqrt(sx * sx + noise2);
+    sy = std::sqrt(sy * sy + noise2);
+    st = std::sqrt(st * st + motion->s1 * motion->s1 + (motion->kind == MCL_MOTION_DIFFERENTIAL ? motion->s2 * motion->s2 : 0.0));
+  } else if (motion) {
+    sx = std::sqrt(sx * sx + 0.02 * 0.02);
+    sy = std::sqrt(sy * sy + 0.02 * 0.02);
+    st = std::sqrt(st * st + 0.02 * 0.02);
+  }
+  if (!(std::isfinite(x) && std::isfinite(y) && std::isfinite(t) && std::isfinite(sx) && std::isfinite(sy) && std::isfinite(st))) return false;
+  auto inverse_span = [](double sigma) { return sigma > 0.0 ? static_cast<float>(1.0 / (8.0 * sigma)) : 0.f; };  // +- 4 sigma
+  out->cx = x;
+  out->cy = y;
+  out->c0 = std::cos(t);
+  out->s0 = std::sin(t);
+  out->inv_x = inverse_span(sx);
+  out->inv_y = inverse_span(sy);
+  out->inv_t = inverse_span(std::min(st, kPi / 4.0));  // the heading bins never span more than the circle
+  out->t_off = 0.f;
+  return true;
+}
+void remember_cloud_estimate(mcl_ctx* ctx, const mcl_estimate& est) {
+  const double vx = est.covariance[0], vy = est.covariance[4], vt = est.covariance[8];
+  ctx->cloud_mean[0] = est.pose[2];
+  ctx->cloud_mean[1] = est.pose[3];
+  ctx->cloud_mean[2] = std::atan2(est.pose[1], est.pose[0]);
+  ctx->cloud_sigma[0] = vx > 0.0 ? std::sqrt(vx) : 0.0;
+  ctx->cloud_sigma[1] = vy > 0.0 ? std::sqrt(vy) : 0.0;
+  ctx->cloud_sigma[2] = std::isfinite(vt) ? (vt > 0.0 ? std::sqrt(vt) : 0.0) : kPi;  // infinite circular variance: all headings
+  ctx->have_cloud_estimate = std::isfinite(ctx->cloud_mean[0]) && std::isfinite(ctx->cloud_mean[1]) && std::isfinite(ctx->cloud_mean[2]) &&
+                             std::isfinite(ctx->cloud_sigma[0]) && std::isfinite(ctx->cloud_sigma[1]);
+}
+
+bool wants_ordering(const mcl_ctx* ctx) {
+  if (ctx->n < static_cast<uint64_t>(ctx->tuning.sort_min_particles) || ctx->n >= (1ull << 32)) return false;
+  return ctx->cfg.sensor_kind == MCL_SENSOR_BEAM || ctx->tuning.lf_variant == kLfSortedLanes;
+}
+
+// fused (mcl_update): the scan staged by stage_points is pulled by the same kernel, and the ordering keys of the new poses
+// come out of it when the host knows where the set is (*keys_emitted).
+mcl_status do_propagate(mcl_ctx* ctx, const Pose2& pose, const Pose2& prev, uint32_t step, uint64_t scan_points = 0,
+                        bool* keys_emitted = nullptr) {
   stage_begin(ctx, MCL_STAGE_PROPAGATE);
-  launch_propagate(ctx->stream, ctx->cur(), ctx->n, make_sampler(pose, prev, ctx->cfg.motion, ctx->cfg.motion_kind, ctx->cfg.strafe_noise_from_translation), ctx->cfg.seed, step,
-                   ctx->cfg.shard_offset);
+  const DiffDriveSampler sampler = make_sampler(pose, prev, ctx->cfg.motion, ctx->cfg.motion_kind, ctx->cfg.strafe_noise_from_translation);
+  KeyFrame frame{};
+  const SortScratch sort = ctx->sort_scratch();
+  const bool keys = keys_emitted && wants_ordering(ctx) && predict_key_frame(ctx, &sampler, &frame);
+  launch_propagate(ctx->stream, ctx->cur(), ctx->n, sampler, ctx->cfg.seed, step, ctx->cfg.shard_offset,
+                   scan_points ? ctx->hd_points : nullptr, scan_points ? ctx->d_points.ptr : nullptr, static_cast<uint32_t>(2 * scan_points),
+                   keys ? &sort : nullptr, keys ? &frame : nullptr);
+  if (scan_points) points_pulled(ctx, false);
+  if (keys_emitted) *keys_emitted = keys;
   stage_end(ctx, MCL_STAGE_PROPAGATE);
   MCL_HIP(ctx, hipGetLastError());
   return MCL_OK;
 }
 
-mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B) {
+mcl_status reweight_preconditions(mcl_ctx* ctx, uint64_t B) {
   if (!ctx->have_map) return fail(ctx, MCL_ERR_NOT_READY, "mcl_reweight: no map set");
-  MCL_REQUIRE(ctx, B <= 0xFFFFFFFFull, "too many points");
-  if (const mcl_status s = upload_points(ctx, pts, B)) return s;
+  MCL_REQUIRE(ctx, B <= 0x7FFFFFFFull, "too many points");
+  if (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM)
+    MCL_REQUIRE(ctx, B * sizeof(double2) <= 160 * 1024 || ctx->tuning.lf_variant != kLfWavePerParticle, "scan too large for LDS staging");
+  return MCL_OK;
+}
+
+// points_staged: stage_points + the pull already happened (mcl_update); keys_ready: k_propagate emitted the ordering keys.
+mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_staged = false, bool keys_ready = false) {
+  if (const mcl_status s = reweight_preconditions(ctx, B)) return s;
+  if (!points_staged) {
+    if (const mcl_status s = stage_points(ctx, pts, B)) return s;
+    if (B) {
+      launch_pull_scan(ctx->stream, ctx->hd_points, ctx->d_points.ptr, static_cast<uint32_t>(2 * B));
+      points_pulled(ctx, true);
+    }
+  }
   stage_begin(ctx, MCL_STAGE_REWEIGHT);
+  const SortScratch sort = ctx->sort_scratch();
+  const bool ordered = wants_ordering(ctx);
+  if (ordered) {
+    KeyFrame frame{};
+    // The ordering also serves the beam model: both kernels gather the pose records through sort.perm.
+    const bool have_frame = !keys_ready && predict_key_frame(ctx, nullptr, &frame);
+    launch_order_particles(ctx->stream, ctx->cur(), ctx->n, &sort, have_frame ? &frame : nullptr, keys_ready);
+  }
   if (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM) {
-    MCL_REQUIRE(ctx, B * sizeof(double2) <= 160 * 1024 || ctx->lf_variant == kLfLanePerParticle, "scan too large for LDS staging");
-    const SortScratch sort = ctx->sort_scratch();
-    // Below a few thousand particles the binning passes cost more than they save.
-    const int variant = (ctx->lf_variant == kLfSortedLanes && ctx->n < 16384) ? kLfLanePerParticle : ctx->lf_variant;
-    if (variant == kLfSortedLanes) launch_lf_bin_sort(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), &sort);
+    // Below a few thousand particles the ordering passes cost more than they save.
+    const int variant = (ctx->tuning.lf_variant == kLfSortedLanes && !ordered) ? kLfLanePerParticle : ctx->tuning.lf_variant;
+    const bool scan_is_short = ctx->scan_extent / ctx->resolution < 8192.0;
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
-    launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B), variant,
-                       &sort, ctx->scan_extent / ctx->resolution < 8192.0);
+    launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B), variant, &sort,
+                       scan_is_short, ctx->tuning);
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
+    if (variant == kLfSortedLanes && ctx->tuning.lf_fast != 0 && scan_is_short && ctx->W < 16384 && ctx->H < 16384 && ctx->pal_count &&
+        ctx->tuning.lf_table == 0)
+      ctx->lf_fast_launches += 1;
   } else {
     const mcl_beam_params& b = ctx->cfg.beam;
-    const bool ordered = ctx->n >= 16384;  // same threshold as the likelihood-field path
-    const SortScratch sort = ctx->sort_scratch();
-    // The ordering pass also emits origin_inverse * state for every particle (Ray2d ctor, raycasting.hpp:69).
-    if (ordered) launch_lf_bin_sort(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), &sort);
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
     launch_reweight_beam(ctx->stream, ctx->cur(), ctx->n, ctx->grid_view(),
                          BeamModel{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range},
@@ -543,16 +640,19 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B) {
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
   }
   stage_end(ctx, MCL_STAGE_REWEIGHT);
+  ctx->profile_tick += 1;
   MCL_HIP(ctx, hipGetLastError());
   return MCL_OK;
 }
 
 // d_scalars layout: [0] weight sum, [1] norm_sum, [2] norm_sumsq, [3] factor override, [4] cdf total, [8..16] estimate sums
-mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats, bool read_back = true) {
+// finalize == false (only with factor = NaN and read_back == false): the totals of the normalised weights in d_scalars[1..3)
+// are left to the next kernel (do_build_cdf with a policy, or launch_norm_finalize).
+mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats, bool read_back = true, bool finalize = true) {
   stage_begin(ctx, MCL_STAGE_NORMALIZE);
   if (std::isnan(factor)) {  // by the set's own total
     launch_sum_and_normalize(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->chunk_row(1), ctx->chunk_row(2),
-                             ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0);
+                             ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0, finalize);
   } else {
     launch_weight_sum(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0);
     ctx->h_scalars[3] = factor;
@@ -577,10 +677,13 @@ mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats, bo
 }
 
 // normalized_just_now: the chunk sums k_normalize left in chunk_row(1) are those of the current weights (same summation,
-// same bits as k_chunk_sum would produce) and are reused.
-mcl_status do_build_cdf(mcl_ctx* ctx, bool normalized_just_now = false) {
+// same bits as k_chunk_sum would produce) and are reused.  policy (needs normalized_just_now): the CDF kernel's first
+// workgroup also finishes the normalisation's totals (d_scalars[1..3)) and runs the recovery estimator.
+mcl_status do_build_cdf(mcl_ctx* ctx, bool normalized_just_now = false, const RecoveryPolicy* policy = nullptr,
+                        bool finalize_norm = false) {
   launch_cdf(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(3), ctx->chunk_row(4), ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4,
-             ctx->d_cdf_tree.ptr, normalized_just_now ? ctx->chunk_row(1) : nullptr);
+             ctx->d_cdf_tree.ptr, normalized_just_now ? ctx->chunk_row(1) : nullptr, finalize_norm ? ctx->chunk_row(2) : nullptr,
+             finalize_norm ? ctx->d_scalars.ptr + 1 : nullptr, finalize_norm ? ctx->hd_scalars + 1 : nullptr, policy);
   MCL_HIP(ctx, hipGetLastError());
   return MCL_OK;
 }
@@ -589,12 +692,13 @@ mcl_status do_build_cdf(mcl_ctx* ctx, bool normalized_just_now = false) {
 // their host mirror; *estimate_enqueued says whether it did.
 mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t step, uint64_t* n_out,
                        const double* d_random_state_probability = nullptr, bool normalized_just_now = false,
-                       bool with_estimate = false, bool* estimate_enqueued = nullptr) {
+                       bool with_estimate = false, bool* estimate_enqueued = nullptr, const RecoveryPolicy* policy = nullptr,
+                       bool finalize_norm = false) {
   const mcl_amcl_params& a = ctx->cfg.amcl;
   MCL_REQUIRE(ctx, ctx->n > 0, "mcl_resample: empty particle set");
   const uint64_t max_p = std::min<uint64_t>(a.max_particles, ctx->capacity);
   stage_begin(ctx, MCL_STAGE_RESAMPLE);
-  if (const mcl_status s = do_build_cdf(ctx, normalized_just_now)) return s;
+  if (const mcl_status s = do_build_cdf(ctx, normalized_just_now, policy, finalize_norm)) return s;
   ResampleArgs ra{};
   ra.seed = ctx->cfg.seed;
   ra.step = step;
@@ -611,7 +715,7 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
     ra.count = max_p;
     ra.out_offset = 0;
     if (with_estimate) {
-      MCL_HIP(ctx, ctx->d_est_partials.ensure(static_cast<size_t>(9) * ((max_p + 255) / 256)));
+      MCL_HIP(ctx, ctx->d_est_partials.ensure(static_cast<size_t>(9) * ((max_p + 1023) / 1024)));
       launch_resample_draw_and_estimate(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp,
                                         ctx->pivot[0], ctx->pivot[1], ctx->d_est_partials.ptr, ctx->d_scalars.ptr + 8,
                                         ctx->hd_scalars + 8);
@@ -897,10 +1001,16 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_kld_scalars), 8 * sizeof(unsigned long long)));
     for (auto& pair : ctx->ev)
       for (auto& e : pair) MCL_HIP(ctx, hipEventCreate(&e));
-    if (const char* v = std::getenv("BELUGA_MCL_DEVICE_POLICY")) ctx->device_policy_allowed = std::atoi(v) != 0;
-    if (const char* v = std::getenv("BELUGA_MCL_LF_VARIANT")) {  // kernel A/B switch for profiling; default = sorted lanes
-      const int k = std::atoi(v);
-      ctx->lf_variant = k == 0 ? kLfWavePerParticle : (k == 1 ? kLfLanePerParticle : kLfSortedLanes);
+    MCL_HIP(ctx, hipEventCreateWithFlags(&ctx->points_event, hipEventDisableTiming));
+    configure_device_kernels();
+    // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
+    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "device_policy", "sort_min_particles"}) {
+      std::string env = "BELUGA_MCL_";
+      for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
+      if (const char* v = std::getenv(env.c_str())) {
+        if (std::string(name) == "lf_table") (void)mcl_set_option(ctx, name, std::string(v) == "cube" ? 1 : std::atoi(v));
+        else (void)mcl_set_option(ctx, name, std::atoi(v));
+      }
     }
     return MCL_OK;
   };
@@ -949,6 +1059,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_sort_u64.release();
   ctx->d_sort_f64.release();
   if (ctx->h_points) (void)hipHostFree(ctx->h_points);
+  if (ctx->points_event) (void)hipEventDestroy(ctx->points_event);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
   if (ctx->h_kld_scalars) (void)hipHostFree(ctx->h_kld_scalars);
   for (auto& pair : ctx->ev)
@@ -1030,6 +1141,11 @@ mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], con
   MCL_HIP(ctx, hipGetLastError());
   ctx->n = n;
   ctx->force_update = true;  // amcl_core.hpp:136
+  for (int k = 0; k < 3; ++k) {
+    ctx->cloud_mean[k] = mean_xytheta[k];
+    ctx->cloud_sigma[k] = std::sqrt(std::max(cov[4 * k], 0.0));
+  }
+  ctx->have_cloud_estimate = true;
   return MCL_OK;
 }
 
@@ -1045,6 +1161,7 @@ mcl_status mcl_set_particles(mcl_ctx* ctx, const double* states, const double* w
   }
   ctx->n = n;
   ctx->force_update = true;
+  ctx->have_cloud_estimate = false;  // the ordering falls back to a bounding-box pass until the next estimate
   return MCL_OK;
 }
 
@@ -1181,6 +1298,8 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   const Pose2 pose = pose_from(control_pose);
   // update_policy_ = on_motion (policies/on_motion.hpp:63-67,121-133); evaluated even when forced (:170)
   bool moved;
+  const bool had_latest = ctx->have_latest;
+  const Pose2 previous_latest = ctx->latest;
   if (!ctx->have_latest) {
     ctx->latest = pose;
     ctx->have_latest = true;
@@ -1192,7 +1311,24 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
     if (moved) ctx->latest = pose;
   }
   if (!moved && !ctx->force_update) return MCL_OK;
-  if (const mcl_status s = bind_device(ctx)) return s;
+  // Everything that can fail without touching a particle is checked before the filter state moves: an update that
+  // fails here leaves the motion unconsumed, as if it had not been called (the reference has no partial-update state).
+  auto undo_policy = [&] {
+    ctx->have_latest = had_latest;
+    ctx->latest = previous_latest;
+  };
+  if (const mcl_status s = bind_device(ctx)) {
+    undo_policy();
+    return s;
+  }
+  if (const mcl_status s = reweight_preconditions(ctx, num_points)) {
+    undo_policy();
+    return s;
+  }
+  if (const mcl_status s = stage_points(ctx, points_xy, num_points)) {
+    undo_policy();
+    return s;
+  }
 
   // control_action_window_ << control (RollingWindow<SE2,2>: newest first, extrapolates when short)
   if (!ctx->have_window) {
@@ -1204,8 +1340,9 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   }
   ctx->step += 1;
 
-  if (const mcl_status s = do_propagate(ctx, ctx->window0, ctx->window1, ctx->step)) return s;  // :174-175
-  if (const mcl_status s = do_reweight(ctx, points_xy, num_points)) return s;                    // :176
+  bool keys_ready = false;
+  if (const mcl_status s = do_propagate(ctx, ctx->window0, ctx->window1, ctx->step, num_points, &keys_ready)) return s;  // :174-175
+  if (const mcl_status s = do_reweight(ctx, points_xy, num_points, true, keys_ready)) return s;                         // :176
   mcl_weight_stats stats{};
   double random_state_probability = 0.0;
   double ess = -1.0;
@@ -1215,44 +1352,48 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   // recovery estimator runs on the device as well and the cycle synchronises once, at the estimate.
   const mcl_amcl_params& ap = ctx->cfg.amcl;
   const bool device_policy = !ap.selective_resampling && ap.min_particles >= std::min<uint64_t>(ap.max_particles, ctx->capacity) &&
-                             ctx->device_policy_allowed;
+                             ctx->tuning.device_policy != 0;
   constexpr int kPolicySlot = 20;  // d_scalars[20..23) = {slow, fast, p}
   if (device_policy) {
-    if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), nullptr, false)) return s;  // :177
-    ctx->every_n_current = (ctx->every_n_current + 1) % ap.resample_interval;                                      // :181
+    // :177; the totals of the normalised weights and the recovery estimator (:179, :184-186) ride on the next kernel
+    if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), nullptr, false, false)) return s;
+    ctx->every_n_current = (ctx->every_n_current + 1) % ap.resample_interval;  // :181
     do_resampling = ctx->every_n_current == 0;
-    launch_recovery_policy(ctx->stream, ctx->d_scalars.ptr + 1, ctx->n, ap.alpha_slow, ap.alpha_fast, do_resampling ? 1 : 0,
-                           ctx->d_scalars.ptr + kPolicySlot, ctx->hd_scalars + kPolicySlot);                       // :179, :184-186
+    const RecoveryPolicy policy{ap.alpha_slow, ap.alpha_fast, do_resampling ? 1 : 0, ctx->d_scalars.ptr + kPolicySlot,
+                                ctx->hd_scalars + kPolicySlot};
     if (do_resampling) {
-      if (const mcl_status s = do_resample(ctx, 0.0, ctx->step, nullptr, ctx->d_scalars.ptr + kPolicySlot + 2, true, ctx->estimate_kind == 0,
-                                           &estimate_enqueued)) return s;  // :188-196
+      if (const mcl_status s = do_resample(ctx, 0.0, ctx->step, nullptr, ctx->d_scalars.ptr + kPolicySlot + 2, true,
+                                           ctx->estimate_kind == 0, &estimate_enqueued, &policy, true)) return s;  // :188-196
+    } else {
+      launch_norm_finalize(ctx->stream, ctx->chunk_row(1), ctx->chunk_row(2), ctx->n, ctx->d_scalars.ptr + 1, ctx->hd_scalars + 1, &policy);
+      MCL_HIP(ctx, hipGetLastError());
     }
   } else {
-  if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), &stats)) return s;  // :177
+    if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), &stats)) return s;  // :177
 
-  // :179 ThrunRecoveryProbabilityEstimator on the NORMALISED weights (thrun_..._estimator.hpp:69-89)
-  {
-    const double average = stats.norm_sum / static_cast<double>(ctx->n);
-    const double fast_average = ctx->fast(average);
-    const double slow_average = ctx->slow(average);
-    if (std::abs(slow_average) >= std::numeric_limits<double>::epsilon())
-      random_state_probability = std::clamp(1.0 - fast_average / slow_average, 0.0, 1.0);
-  }
-  // :181 every_n [&& on_effective_size_drop] (every_n.hpp:47-50, on_effective_size_drop.hpp:45-49)
-  ctx->every_n_current = (ctx->every_n_current + 1) % ctx->cfg.amcl.resample_interval;
-  do_resampling = ctx->every_n_current == 0;
-  if (do_resampling && ctx->cfg.amcl.selective_resampling) {
-    ess = stats.norm_sum == 0.0 ? 0.0 : (stats.norm_sum * stats.norm_sum) / stats.norm_sumsq;  // effective_sample_size.hpp:46-59
-    do_resampling = ess < static_cast<double>(ctx->n) * 0.5;
-  }
-  if (do_resampling) {
-    if (random_state_probability > 0.0) {  // :184-186
-      ctx->slow.reset();
-      ctx->fast.reset();
+    // :179 ThrunRecoveryProbabilityEstimator on the NORMALISED weights (thrun_..._estimator.hpp:69-89)
+    {
+      const double average = stats.norm_sum / static_cast<double>(ctx->n);
+      const double fast_average = ctx->fast(average);
+      const double slow_average = ctx->slow(average);
+      if (std::abs(slow_average) >= std::numeric_limits<double>::epsilon())
+        random_state_probability = std::clamp(1.0 - fast_average / slow_average, 0.0, 1.0);
     }
-    if (const mcl_status s = do_resample(ctx, random_state_probability, ctx->step, nullptr, nullptr, true, ctx->estimate_kind == 0,
-                                         &estimate_enqueued)) return s;  // :188-196
-  }
+    // :181 every_n [&& on_effective_size_drop] (every_n.hpp:47-50, on_effective_size_drop.hpp:45-49)
+    ctx->every_n_current = (ctx->every_n_current + 1) % ctx->cfg.amcl.resample_interval;
+    do_resampling = ctx->every_n_current == 0;
+    if (do_resampling && ctx->cfg.amcl.selective_resampling) {
+      ess = stats.norm_sum == 0.0 ? 0.0 : (stats.norm_sum * stats.norm_sum) / stats.norm_sumsq;  // effective_sample_size.hpp:46-59
+      do_resampling = ess < static_cast<double>(ctx->n) * 0.5;
+    }
+    if (do_resampling) {
+      if (random_state_probability > 0.0) {  // :184-186
+        ctx->slow.reset();
+        ctx->fast.reset();
+      }
+      if (const mcl_status s = do_resample(ctx, random_state_probability, ctx->step, nullptr, nullptr, true, ctx->estimate_kind == 0,
+                                           &estimate_enqueued)) return s;  // :188-196
+    }
   }
   ctx->force_update = false;  // :199
   mcl_estimate est{};
@@ -1280,6 +1421,7 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   } else if (const mcl_status s = mcl_estimate_pose(ctx, &est)) {  // :200
     return s;
   }
+  remember_cloud_estimate(ctx, est);  // where the ordering keys of the next cycle are centred
   if (device_policy) {  // read back together with the estimate
     stats.sum = ctx->h_scalars[0];
     stats.norm_sum = ctx->h_scalars[1];
@@ -1526,6 +1668,7 @@ mcl_status mcl_load_shard(mcl_ctx* ctx, const double* d_states, uint64_t n, uint
   MCL_HIP(ctx, hipGetLastError());
   ctx->n = n;
   ctx->cfg.shard_offset = shard_offset;
+  ctx->have_cloud_estimate = false;
   return MCL_OK;
 }
 
@@ -1569,6 +1712,116 @@ mcl_status mcl_estimate_sums_device(mcl_ctx* ctx, const double pivot_xy[2], doub
   return MCL_OK;
 }
 
+mcl_status mcl_initialize_from_map(mcl_ctx* ctx) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  if (!ctx->have_map) return fail(ctx, MCL_ERR_NOT_READY, "mcl_initialize_from_map: no map set");
+  MCL_REQUIRE(ctx, ctx->n_free > 0, "mcl_initialize_from_map: the map has no free cell");  // the reference asserts (:136)
+  if (const mcl_status s = bind_device(ctx)) return s;
+  const uint64_t n = std::min<uint64_t>(ctx->cfg.amcl.max_particles, ctx->capacity);  // take_exactly(max_particles)
+  launch_init_from_map(ctx->stream, ctx->cur(), n, ctx->cfg.seed, ctx->cfg.shard_offset, ctx->grid_view(),
+                       FreeCells{ctx->d_free.ptr, ctx->n_free});
+  MCL_HIP(ctx, hipGetLastError());
+  ctx->n = n;
+  ctx->force_update = true;  // beluga_ros/include/beluga_ros/amcl.hpp:197
+  // the set covers the map: centre of the grid, spans of its extent, every heading
+  const double hx = 0.5 * ctx->W * ctx->resolution, hy = 0.5 * ctx->H * ctx->resolution;
+  double cx, cy;
+  rot_apply(ctx->origin.r, hx, hy, cx, cy);
+  const double reach = std::sqrt(hx * hx + hy * hy);
+  ctx->cloud_mean[0] = cx + ctx->origin.x;
+  ctx->cloud_mean[1] = cy + ctx->origin.y;
+  ctx->cloud_mean[2] = 0.0;
+  ctx->cloud_sigma[0] = ctx->cloud_sigma[1] = reach / 4.0;  // the bins span +-4 sigma
+  ctx->cloud_sigma[2] = kPi / 4.0;
+  ctx->have_cloud_estimate = true;
+  return MCL_OK;
+}
+
+mcl_status mcl_has_likelihood_field(const mcl_ctx* ctx, int32_t* has) {
+  if (!ctx || !has) return MCL_ERR_INVALID_ARGUMENT;
+  *has = ctx->cfg.sensor_kind != MCL_SENSOR_BEAM ? 1 : 0;  // beam_model.hpp has no likelihood_field() (has_likelihood_field_v)
+  return MCL_OK;
+}
+
+mcl_status mcl_get_likelihood_field_origin(mcl_ctx* ctx, double origin[4]) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, origin, "null output");
+  if (ctx->cfg.sensor_kind == MCL_SENSOR_BEAM)
+    return fail(ctx, MCL_ERR_UNSUPPORTED, "The current sensor model does not support likelihood field");
+  if (!ctx->have_map) return fail(ctx, MCL_ERR_NOT_READY, "no likelihood field");
+  // likelihood_field_model_base.hpp:105: world_to_likelihood_field_transform_.inverse(), i.e. inverse(inverse(grid.origin()))
+  const Pose2 o = pose_inverse(ctx->origin_inverse);
+  origin[0] = o.r.c;
+  origin[1] = o.r.s;
+  origin[2] = o.x;
+  origin[3] = o.y;
+  return MCL_OK;
+}
+
+mcl_status mcl_project_point_cloud(const float* points_xyz, uint64_t num_points, const double origin_se3[7], double* points_xy) {
+  if (!origin_se3 || (num_points && (!points_xyz || !points_xy))) return MCL_ERR_INVALID_ARGUMENT;
+  const double qx = origin_se3[0], qy = origin_se3[1], qz = origin_se3[2], qw = origin_se3[3];
+  for (uint64_t i = 0; i < num_points; ++i) {
+    // beluga_ros/src/amcl.cpp:73-76: origin * p.cast<double>(), keep x and y.  Sophus SO3 rotates with
+    // uv = 2 (q.vec x p); p + q.w uv + q.vec x uv, then adds the translation.
+    const double px = static_cast<double>(points_xyz[3 * i]), py = static_cast<double>(points_xyz[3 * i + 1]),
+                 pz = static_cast<double>(points_xyz[3 * i + 2]);
+    double ux = qy * pz - qz * py, uy = qz * px - qx * pz, uz = qx * py - qy * px;
+    ux += ux;
+    uy += uy;
+    uz += uz;
+    points_xy[2 * i] = (px + qw * ux + (qy * uz - qz * uy)) + origin_se3[4];
+    points_xy[2 * i + 1] = (py + qw * uy + (qz * ux - qx * uz)) + origin_se3[5];
+  }
+  return MCL_OK;
+}
+
+mcl_status mcl_update_point_cloud(mcl_ctx* ctx, const double control_pose[4], const float* points_xyz, uint64_t num_points,
+                                  const double origin_se3[7], mcl_estimate* estimate, mcl_update_info* info) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, origin_se3 && (num_points == 0 || points_xyz), "null argument");
+  std::vector<double> pts(2 * num_points + 2);
+  if (mcl_project_point_cloud(points_xyz, num_points, origin_se3, pts.data()) != MCL_OK) return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "bad point cloud");
+  return mcl_update(ctx, control_pose, pts.data(), num_points, estimate, info);
+}
+
+mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
+  if (!ctx || !name) return MCL_ERR_INVALID_ARGUMENT;
+  const std::string key(name);
+  Tuning& t = ctx->tuning;
+  if (key == "lf_variant") t.lf_variant = value == 0 ? kLfWavePerParticle : (value == 1 ? kLfLanePerParticle : kLfSortedLanes);
+  else if (key == "lf_fast") t.lf_fast = value < 0 ? -1 : (value ? 1 : 0);
+  else if (key == "lf_table") t.lf_table = value ? 1 : 0;
+  else if (key == "device_policy") t.device_policy = value ? 1 : 0;
+  else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
+  else return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "mcl_set_option: unknown option " + key);
+  return MCL_OK;
+}
+
+mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
+  if (!ctx || !name || !value) return MCL_ERR_INVALID_ARGUMENT;
+  const std::string key(name);
+  if (key == "lf_fast_launches") *value = ctx->lf_fast_launches;
+  else return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "mcl_get_counter: unknown counter " + key);
+  return MCL_OK;
+}
+
+mcl_status mcl_debug_order(mcl_ctx* ctx, uint32_t* perm, uint32_t* keys) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, perm && keys, "null output");
+  MCL_REQUIRE(ctx, ctx->n > 0 && ctx->n < (1ull << 32), "no particles");
+  if (const mcl_status s = bind_device(ctx)) return s;
+  const SortScratch sort = ctx->sort_scratch();
+  KeyFrame frame{};
+  const bool have_frame = predict_key_frame(ctx, nullptr, &frame);
+  launch_order_particles(ctx->stream, ctx->cur(), ctx->n, &sort, have_frame ? &frame : nullptr, false);
+  MCL_HIP(ctx, hipGetLastError());
+  MCL_HIP(ctx, hipMemcpyAsync(perm, sort.perm, ctx->n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MCL_HIP(ctx, hipMemcpyAsync(keys, sort.keys, ctx->n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MCL_OK;
+}
+
 mcl_status mcl_sync(mcl_ctx* ctx) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
   if (const mcl_status s = bind_device(ctx)) return s;
@@ -1590,7 +1843,8 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset) 
 
 mcl_status mcl_profile_enable(mcl_ctx* ctx, int32_t on) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
-  ctx->profile = on != 0;
+  ctx->profile_tick = 0;
+  ctx->profile = on < 0 ? 0 : (on > 2 ? 2 : on);  // 1: the sensor kernel only, 2: every stage
   return MCL_OK;
 }
 

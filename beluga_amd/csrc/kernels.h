@@ -1,6 +1,6 @@
 // kernels.h — launchers of the gfx950 kernels behind the C ABI (include/beluga_mcl.h).
 // Data layout in HBM (all owned by mcl_ctx):
-//   particles : structure of arrays, f64:  x[cap] y[cap] c[cap] s[cap] w[cap]   (two state sets: live + resample target)
+//   particles : pose records of 4 f64 (cos, sin, x, y) + w[cap]   (two sets: live + resample target)
 //   field     : f32 row-major H x W likelihood field (likelihood_field_model_base.hpp:120), 64 MB at 4000^2
 //   cells     : int8 row-major H x W occupancy grid (beam model + free-space sampling), 16 MB at 4000^2
 //   points    : f64 (x,y) pairs of the current scan, 17 KB at 1080 beams
@@ -93,7 +93,7 @@ struct ResampleArgs {
   uint64_t seed;
   uint32_t step;
   double random_state_probability;
-  const double* d_random_state_probability;  // if set, read the probability from device memory instead (k_recovery_policy's output)
+  const double* d_random_state_probability;  // if set, read the probability from device memory instead (the recovery estimator's output, see RecoveryPolicy)
   uint64_t n_in;            // live particles of the source set
   uint64_t first_candidate; // global index of candidate 0 of this launch
   uint64_t count;           // candidates in this launch
@@ -102,42 +102,63 @@ struct ResampleArgs {
 
 enum LfVariant : int { kLfWavePerParticle = 0, kLfLanePerParticle = 1, kLfSortedLanes = 2 };
 
-// Scratch of the spatially ordered variant (kLfSortedLanes): particles are sorted by a (heading, x, y)
-// bin key so that the 64 lanes of a wave look up neighbouring field cells.
-constexpr uint32_t kSortDigits = 1024;  // coarse partition digit (top 10 bits of the 20-bit key)
+// Per-context switches for A/B measurements and tests (mcl_set_option); no switch changes a result.
+struct Tuning {
+  int lf_variant = kLfSortedLanes;  // kernel family of the likelihood-field reweight
+  int lf_fast = -1;                 // FMA variant with exact fallback: -1 / 1 = whenever its preconditions hold, 0 = never
+  int lf_table = 0;                 // 0 = palette table when the field allows it, 1 = force the 8-byte cube table
+  int device_policy = 1;            // recovery estimator on the device when the cycle has no host-side decision
+  int sort_min_particles = 16384;   // below this the ordering passes cost more than they save
+};
+
+// Spatial ordering of the particles (kLfSortedLanes, ordered beam kernel): the 64 lanes of a wave should hold neighbouring
+// poses, so that their look-ups for a given beam fall into the same few table lines.  Order = full sort by a 20-bit key:
+// bins of x, y (6 bits each) and heading (8 bits) over +-4 sigma around the cloud's centre, the two extra heading bits on
+// top, the rest Morton-interleaved.  The frame of the bins comes from the previous cycle's estimate moved by the control
+// action (host, no pass over the particles), or from a bounding-box pass when the host has no estimate of the set.
+struct KeyFrame {
+  double cx, cy;          // centre of the x / y bins
+  double c0, s0;          // heading of the centre of the heading bins
+  float inv_x, inv_y;     // 1 / span of the x / y bins (span = 8 sigma)
+  float inv_t, t_off;     // heading bins: u = (delta - t_off) * inv_t + 0.5
+};
+constexpr uint32_t kSortDigits = 1024;  // two least-significant-digit-first passes of 10 bits each
 struct SortScratch {
   uint32_t* keys;                // [n] key of particle i
   uint32_t* perm;                // [n] sorted position -> particle index
-  uint32_t* block_hist;          // [kSortDigits][nblocks] histogram -> exclusive offsets
-  uint32_t* chunk_sum;           // [kSortDigits * nblocks / 2048 + 1]
-  uint32_t* chunk_off;           // same
-  unsigned long long* keyidx;    // [n] (key << 32 | index), partitioned by digit
+  uint32_t* table;               // [kSortDigits][nblocks] block histograms -> exclusive offsets (reused by both passes)
+  uint32_t* totals;              // [kSortDigits] digit totals
+  unsigned long long* keyidx;    // [n] (high digit << 32 | index) after the first pass
   double* bbox;                  // [8] min/max of x, y, relative heading (+ [6 * nblocks] partials behind it)
-  double* tc;                    // [n] world->field transformed poses in sorted order
-  double* ts;
-  double* tx;
-  double* ty;
+  KeyFrame* frame;               // key frame derived from the bounding box (device-resident fallback)
   double* partial;               // [kLfMaxSegments][min(n, 262144)] scan-segment sums (medium particle counts); may be null
-  double4* pose_part;            // [n] pose records in partitioned order (k_sort_scatter -> k_sort_blocks)
 };
 constexpr uint32_t kLfMaxSegments = 16;
 constexpr uint64_t kLfSegmentedBelow = 262144;  // particles
 
 // K1  actions/propagate.hpp:57-79 + differential_drive_model.hpp:156-163
+// scan_src / scan_dst (optional): the cycle's scan, copied by the kernel from mapped pinned host memory into HBM (no
+// copy-engine hand-off on the stream).  sort + frame (optional): the kernel also emits the ordering keys and the first
+// pass's block histograms (launch_order_particles then skips its own key pass).
 void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
-                      uint64_t index_offset);
-// Counting sort of the particles into (heading, x, y) bins + their world->field poses in sorted order.
-void launch_lf_bin_sort(hipStream_t st, Particles p, uint64_t n, FieldView f, const SortScratch* sort);
-// K2  actions/reweight.hpp:53-60 + likelihood_field_model.hpp:68-91 (kLfSortedLanes needs launch_lf_bin_sort first)
+                      uint64_t index_offset, const double* scan_src = nullptr, double* scan_dst = nullptr, uint32_t scan_doubles = 0,
+                      const SortScratch* sort = nullptr, const KeyFrame* frame = nullptr);
+void launch_pull_scan(hipStream_t st, const double* scan_src, double* scan_dst, uint32_t scan_doubles);
+// Full sort of the particles by the ordering key -> sort->perm.  frame == nullptr: bounding-box pass + device-resident frame.
+// keys_ready: launch_propagate already wrote sort->keys and the first pass's block histograms.
+void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortScratch* sort, const KeyFrame* frame, bool keys_ready);
+// K2  actions/reweight.hpp:53-60 + likelihood_field_model.hpp:68-91 (kLfSortedLanes needs launch_order_particles first)
 // scan_is_short: every scan point lies within 8192 cells of the sensor (precondition of the kernel's FMA variant)
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
-                        const SortScratch* sort, bool scan_is_short);
+                        const SortScratch* sort, bool scan_is_short, const Tuning& tuning);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
-// `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_lf_bin_sort with world_to_field = origin_inverse first).
+// `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_order_particles first).
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
                           unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits);
 // One bit per cell (1 = not free), ceil(W/32) words per row: the occupancy the ray walks read.
 void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32_t H, int8_t free_value, uint32_t* bits);
+// Per-device kernel attributes (dynamic LDS opt-in of the ordered beam kernel); call once per context after hipSetDevice.
+void configure_device_kernels();
 
 // Deterministic chunked reductions / scans.  Chunk = 2048 consecutive elements per workgroup.
 constexpr uint32_t kChunk = 2048;
@@ -151,12 +172,23 @@ void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_pa
 void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_factor, double* d_chunk_sum, double* d_chunk_sumsq,
                       double* d_out, double* host_mirror = nullptr);
 void launch_sum_and_normalize(hipStream_t st, double* w, uint64_t n, double* d_partials, double* d_chunk_sum, double* d_chunk_sumsq,
-                              double* d_sums, double* host_mirror);
+                              double* d_sums, double* host_mirror, bool finalize = true);
+// ThrunRecoveryProbabilityEstimator (thrun_recovery_probability_estimator.hpp:69-89, exponential_filter.hpp:32-44) evaluated
+// on the device so that a cycle without host-side decisions needs no mid-cycle read-back: d_policy = {slow, fast, p}.
+// It rides on the workgroup that adds up the totals of the normalised weights (launch_cdf / launch_norm_finalize).
+struct RecoveryPolicy {
+  double alpha_slow, alpha_fast;
+  int resampling;       // this cycle resamples: reset the filters when p > 0 (amcl_core.hpp:184-186)
+  double* d_policy;     // {slow, fast, p}
+  double* host_mirror;  // optional: p at [2]
+};
+// d_sums[0] = sum, d_sums[1] = sum of squares of the normalised weights (from k_normalize's chunk rows) + optional policy step.
+void launch_norm_finalize(hipStream_t st, const double* d_chunk_sum, const double* d_chunk_sumsq, uint64_t n, double* d_sums,
+                          double* sums_mirror, const RecoveryPolicy* policy);
 // K5: cdf[i] = inclusive scan of w; d_chunk_sum is recomputed; d_total[0] = cdf[n-1].
 // 16-ary search tree over the cdf: level l (l = 1 .. depth) keeps every 16^l-th cumulative sum (the last of each group
-// of 16 entries of the level below, one 128-byte line per group), so that std::lower_bound touches one line per level:
-// the upper levels stay in cache, only the last two look-ups leave the L2.  Pure comparisons: the result is exactly
-// cdf_lower_bound's.
+// of 16 entries of the level below, one 128-byte line per group), so that std::lower_bound touches one line per level.
+// Pure comparisons: the result is exactly cdf_lower_bound's.
 constexpr int kCdfTreeMaxDepth = 8;
 struct CdfTree {
   const double* cdf;
@@ -183,8 +215,11 @@ inline CdfTree make_cdf_tree(const double* cdf, const double* levels, uint64_t n
   return t;
 }
 // launch_cdf also fills the tree levels when `tree_levels` is given (cdf_tree_doubles(n) doubles).
+// finalize_*: the first workgroup also leaves the totals of known_chunk_sum / finalize_sumsq in finalize_sums[0..1] and runs
+// the recovery estimator (see launch_norm_finalize) — for the cycle that goes straight from k_normalize into a resample.
 void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
-                double* d_total, double* tree_levels, const double* known_chunk_sum = nullptr);
+                double* d_total, double* tree_levels, const double* known_chunk_sum = nullptr, const double* finalize_sumsq = nullptr,
+                double* finalize_sums = nullptr, double* finalize_mirror = nullptr, const RecoveryPolicy* policy = nullptr);
 // K6: one thread per candidate (views/sample.hpp:102,133-135; random_intersperse.hpp:90-115; particle_traits.hpp:105).
 void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst,
                           ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes);
@@ -207,12 +242,6 @@ void launch_commit_routed(hipStream_t st, Particles dst, uint64_t seed, uint32_t
 void launch_finish_candidates(hipStream_t st, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,
                               const uint32_t* d_order, const double* d_targets, GridView g, FreeCells fc, HashParams hp,
                               double* d_states, unsigned long long* d_hashes);
-// ThrunRecoveryProbabilityEstimator (thrun_recovery_probability_estimator.hpp:69-89, exponential_filter.hpp:32-44) evaluated
-// on the device so that a cycle without host-side decisions needs no mid-cycle read-back: policy = {slow, fast, p}.
-// average = *d_norm_sum / n; both filters advance; p = clamp(1 - fast / slow, 0, 1) (0 while |slow| < eps); if this cycle
-// resamples and p > 0 the filters are reset (amcl_core.hpp:184-186).
-void launch_recovery_policy(hipStream_t st, const double* d_norm_sum, uint64_t n, double alpha_slow, double alpha_fast, int resampling,
-                            double* d_policy, double* host_mirror = nullptr);
 struct KldTable {
   unsigned long long* keys;  // 0 = empty (hash 0 is remapped)
   unsigned int* first;       // smallest candidate index that produced the key
@@ -241,6 +270,8 @@ void launch_estimate_sums_cluster(hipStream_t st, Particles p, uint64_t n, const
 // init: multivariate_normal_distribution.hpp:96-126 with T = V sqrt(L)
 void launch_init_normal(hipStream_t st, Particles p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
                         uint64_t index_offset);
+// initialize_from_map: multivariate_uniform_distribution.hpp:126-161 over the free cells, weight 1
+void launch_init_from_map(hipStream_t st, Particles p, uint64_t n, uint64_t seed, uint64_t index_offset, GridView g, FreeCells fc);
 void launch_fill(hipStream_t st, double* p, uint64_t n, double v);
 // cube[i] = double(field[i])^3 (or log(double(field[i])) for the prob model) for i < cells, cube[cells] = same for `unknown`
 void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube, int prob);

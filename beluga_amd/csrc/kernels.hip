@@ -56,8 +56,8 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 // Deterministic block reduction of K doubles per thread.  Result valid in thread 0.
-template <int K>
-__device__ __forceinline__ void block_reduce(double (&v)[K], double* s_scratch /* [kBlock/64][K] */) {
+template <int K, int kThreads = kBlock>
+__device__ __forceinline__ void block_reduce(double (&v)[K], double* s_scratch /* [kThreads/64][K] */) {
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = wave_sum_f64(v[k]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -70,43 +70,119 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], double* s_scratch /
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       double acc = s_scratch[k];
-      for (int w = 1; w < kBlock / 64; ++w) acc += s_scratch[w * K + k];
+      for (int w = 1; w < kThreads / 64; ++w) acc += s_scratch[w * K + k];
       v[k] = acc;
     }
   }
   __syncthreads();
 }
 
-// ---- K1 propagate ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_propagate(Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
-                                                      uint64_t index_offset) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const RngWords a = rng_draw(seed, step, kRngPropagateA, index_offset + i);
-  const RngWords b = rng_draw(seed, step, kRngPropagateB, index_offset + i);
-  double z0, z1, z2, z3;
-  rng_box_muller(rng_uniform53(a.w[0], a.w[1]), rng_uniform53(a.w[2], a.w[3]), z0, z1);
-  rng_box_muller(rng_uniform53(b.w[0], b.w[1]), rng_uniform53(b.w[2], b.w[3]), z2, z3);
-  const Pose2 state = load_pose(p, i);
-  Pose2 out;
-  if (smp.kind == 1) {
-    // omnidirectional_drive_model.hpp:133-144 — draws in source order: rotation, translation, strafe
-    const Rot2 first{smp.first_c, smp.first_s};
-    const Rot2 second = rot_mul(rot_exp(z0 * smp.s1 + smp.m1), rot_inverse(first));
-    const double t = z1 * smp.st + smp.mt;
-    const double strafe = z2 * smp.s2 + 0.0;
-    out = pose_mul(pose_mul(state, Pose2{first, 0.0, 0.0}), Pose2{second, t, -strafe});
-  } else if (smp.kind == 2) {
-    // stationary_model.hpp:55-61 — N(0, 0.02) on heading, x, y
-    out = pose_mul(state, Pose2{rot_exp(z0 * 0.02 + 0.0), z1 * 0.02 + 0.0, z2 * 0.02 + 0.0});
-  } else {
-    // differential_drive_model.hpp:156-163
-    const double r1 = z0 * smp.s1 + smp.m1;
-    const double t = z1 * smp.st + smp.mt;
-    const double r2 = z2 * smp.s2 + smp.m2;
-    out = pose_mul(pose_mul(state, Pose2{rot_exp(r1), 0.0, 0.0}), Pose2{rot_exp(r2), t, 0.0});
+// ---- spatial ordering key ----------------------------------------------------------------------------
+// 20 bits: x, y in 64 bins each, heading in 256 bins over the key frame's span; the two top heading bits first, the
+// remaining 6 + 6 + 6 bits Morton-interleaved (heading, y, x).  Only locality depends on the key, never a result, so it
+// is evaluated in single precision.
+constexpr uint32_t kKeyBitsXY = 6, kKeyBitsTheta = 8, kKeyBits = 2 * kKeyBitsXY + kKeyBitsTheta;
+constexpr uint32_t kDigitBits = 10;
+static_assert((1u << kDigitBits) == kSortDigits && kKeyBits == 2 * kDigitBits, "two passes of one digit each");
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // ...edcba -> ..e00d00c00b00a
+  v &= 0x3FF;
+  v = (v | (v << 16)) & 0x030000FF;
+  v = (v | (v << 8)) & 0x0300F00F;
+  v = (v | (v << 4)) & 0x030C30C3;
+  v = (v | (v << 2)) & 0x09249249;
+  return v;
+}
+__device__ __forceinline__ int unit_bin(float u, int bins) {  // u in [0, 1) inside the span; clamped outside (NaN -> 0)
+  const int b = static_cast<int>(u * static_cast<float>(bins));
+  return min(max(b, 0), bins - 1);
+}
+__device__ __forceinline__ uint32_t order_key(const double4& q, const KeyFrame& kf) {
+  const float ux = static_cast<float>(q.z - kf.cx) * kf.inv_x + 0.5f;
+  const float uy = static_cast<float>(q.w - kf.cy) * kf.inv_y + 0.5f;
+  const float c = static_cast<float>(q.x), s = static_cast<float>(q.y);
+  const float c0 = static_cast<float>(kf.c0), s0 = static_cast<float>(kf.s0);
+  const float delta = atan2f(s * c0 - c * s0, c * c0 + s * s0);  // heading relative to the frame's, in (-pi, pi]
+  const float ut = (delta - kf.t_off) * kf.inv_t + 0.5f;
+  const uint32_t bx = static_cast<uint32_t>(unit_bin(ux, 1 << kKeyBitsXY)), by = static_cast<uint32_t>(unit_bin(uy, 1 << kKeyBitsXY));
+  const uint32_t bt = static_cast<uint32_t>(unit_bin(ut, 1 << kKeyBitsTheta));
+  return ((bt >> kKeyBitsXY) << (3 * kKeyBitsXY)) | spread3(bx) | (spread3(by) << 1) | (spread3(bt & ((1u << kKeyBitsXY) - 1)) << 2);
+}
+
+// The cycle's scan, pulled from mapped pinned host memory by one workgroup (17 KB at 1080 beams): an asynchronous
+// host-to-device copy on the stream costs a copy-engine hand-off of ~20 us between two kernels, this costs nothing.
+__device__ __forceinline__ void pull_scan(const double* __restrict__ src, double* __restrict__ dst, uint32_t doubles) {
+  const double2* s2 = reinterpret_cast<const double2*>(src);
+  double2* d2 = reinterpret_cast<double2*>(dst);
+  const uint32_t pairs = doubles / 2;
+  for (uint32_t j = threadIdx.x; j < pairs; j += 4 * blockDim.x) {
+    double2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (j + u * blockDim.x < pairs) v[u] = s2[j + u * blockDim.x];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (j + u * blockDim.x < pairs) d2[j + u * blockDim.x] = v[u];
   }
-  store_pose(p, i, out);
+  if ((doubles & 1u) && threadIdx.x == 0) dst[doubles - 1] = src[doubles - 1];
+}
+__global__ __launch_bounds__(kBlock) void k_pull_scan(const double* __restrict__ src, double* __restrict__ dst, uint32_t doubles) {
+  pull_scan(src, dst, doubles);
+}
+
+// ---- K1 propagate ----------------------------------------------------------------------------------
+// One workgroup per chunk of kChunk particles (coalesced 32-byte records).  kKeys: the ordering key of the NEW pose and the
+// chunk's histogram of the key's low digit come out of the same pass (the poses are in registers here).
+template <bool kKeys>
+__global__ __launch_bounds__(kBlock) void k_propagate(Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
+                                                      uint64_t index_offset, const double* __restrict__ scan_src,
+                                                      double* __restrict__ scan_dst, uint32_t scan_doubles, KeyFrame kf,
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ table, uint32_t nblocks) {
+  __shared__ uint32_t hist[kKeys ? kSortDigits : 1];
+  if (kKeys) {
+    for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) hist[d] = 0;
+    __syncthreads();
+  }
+  if (scan_dst && blockIdx.x == gridDim.x - 1) pull_scan(scan_src, scan_dst, scan_doubles);
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+#pragma unroll 1
+  for (int k = 0; k < kChunk / kBlock; ++k) {
+    const uint64_t i = base + static_cast<uint64_t>(k) * kBlock + threadIdx.x;
+    if (i >= n) break;
+    const RngWords a = rng_draw(seed, step, kRngPropagateA, index_offset + i);
+    const RngWords b = rng_draw(seed, step, kRngPropagateB, index_offset + i);
+    double z0, z1, z2, z3;
+    rng_box_muller(rng_uniform53(a.w[0], a.w[1]), rng_uniform53(a.w[2], a.w[3]), z0, z1);
+    rng_box_muller(rng_uniform53(b.w[0], b.w[1]), rng_uniform53(b.w[2], b.w[3]), z2, z3);
+    const Pose2 state = load_pose(p, i);
+    Pose2 out;
+    if (smp.kind == 1) {
+      // omnidirectional_drive_model.hpp:133-144 — draws in source order: rotation, translation, strafe
+      const Rot2 first{smp.first_c, smp.first_s};
+      const Rot2 second = rot_mul(rot_exp(z0 * smp.s1 + smp.m1), rot_inverse(first));
+      const double t = z1 * smp.st + smp.mt;
+      const double strafe = z2 * smp.s2 + 0.0;
+      out = pose_mul(pose_mul(state, Pose2{first, 0.0, 0.0}), Pose2{second, t, -strafe});
+    } else if (smp.kind == 2) {
+      // stationary_model.hpp:55-61 — N(0, 0.02) on heading, x, y
+      out = pose_mul(state, Pose2{rot_exp(z0 * 0.02 + 0.0), z1 * 0.02 + 0.0, z2 * 0.02 + 0.0});
+    } else {
+      // differential_drive_model.hpp:156-163
+      const double r1 = z0 * smp.s1 + smp.m1;
+      const double t = z1 * smp.st + smp.mt;
+      const double r2 = z2 * smp.s2 + smp.m2;
+      out = pose_mul(pose_mul(state, Pose2{rot_exp(r1), 0.0, 0.0}), Pose2{rot_exp(r2), t, 0.0});
+    }
+    store_pose(p, i, out);
+    if (kKeys) {
+      const uint32_t key = order_key(double4{out.r.c, out.r.s, out.x, out.y}, kf);
+      keys[i] = key;
+      atomicAdd(&hist[key & (kSortDigits - 1)], 1u);
+    }
+  }
+  if (kKeys) {
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
+  }
 }
 
 // ---- K2 likelihood-field reweight ------------------------------------------------------------------
@@ -229,16 +305,23 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_lane(Particles p, uint64
 // `partial` != nullptr (medium particle counts, where one lane per particle cannot fill 256 CUs): blockIdx.y selects a
 // contiguous segment of the scan; the segment's sum goes to partial[segment][t] and k_lf_combine adds the segments up in
 // order — same terms, fixed association, bit-reproducible, differs from the sequential sum only in rounding.
+// The pose of the particle at a position of the spatial order, moved into the table's frame.  A 32-byte record gather
+// per lane, once per kernel (the ordering passes move 8 bytes per particle, not the poses).
+__device__ __forceinline__ Pose2 ordered_pose(const Pose2& to_frame, const double4* __restrict__ pose, uint32_t i) {
+  const double4 q = pose[i];
+  return pose_mul(to_frame, Pose2{Rot2{q.x, q.y}, q.z, q.w});
+}
+
 template <bool kCube>
 __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restrict__ w, uint64_t n, FieldView f,
                                                                const double* __restrict__ pts, uint32_t B,
-                                                               const uint32_t* __restrict__ perm, const double* __restrict__ tc,
-                                                               const double* __restrict__ ts, const double* __restrict__ tx,
-                                                               const double* __restrict__ ty, double* __restrict__ partial,
-                                                               uint32_t beams_per_segment) {
+                                                               const uint32_t* __restrict__ perm, const double4* __restrict__ pose,
+                                                               double* __restrict__ partial, uint32_t beams_per_segment) {
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const uint64_t tt = t < n ? t : n - 1;
-  const double ct = tc[tt], st = ts[tt], xt = tx[tt], yt = ty[tt];
+  const uint32_t i = perm[tt];
+  const Pose2 T = ordered_pose(f.world_to_field, pose, i);  // likelihood_field_model.hpp:70
+  const double ct = T.r.c, st = T.r.s, xt = T.x, yt = T.y;
   const uint32_t b_begin = partial ? blockIdx.y * beams_per_segment : 0u;
   const uint32_t b_end = partial ? (b_begin + beams_per_segment < B ? b_begin + beams_per_segment : B) : B;
   double acc = (f.prob || partial) ? 0.0 : 1.0;
@@ -278,7 +361,6 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
     if (partial) {
       partial[static_cast<size_t>(blockIdx.y) * n + t] = acc;
     } else {
-      const uint32_t i = perm[t];
       w[i] = w[i] * (f.prob ? exp(acc) : acc);
     }
   }
@@ -339,10 +421,8 @@ __device__ __forceinline__ double lf_palette_value(uint32_t lds_address) {
 template <bool kFast>
 __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __restrict__ w, uint64_t n, FieldView f,
                                                                    const double* __restrict__ pts, uint32_t B,
-                                                                   const uint32_t* __restrict__ perm, const double* __restrict__ tc,
-                                                                   const double* __restrict__ ts, const double* __restrict__ tx,
-                                                                   const double* __restrict__ ty, double* __restrict__ partial,
-                                                                   uint32_t beams_per_segment) {
+                                                                   const uint32_t* __restrict__ perm, const double4* __restrict__ pose,
+                                                                   double* __restrict__ partial, uint32_t beams_per_segment) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
     uint32_t* s_row = reinterpret_cast<uint32_t*>(smem);
@@ -355,7 +435,9 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
   __syncthreads();
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kPalBlock + threadIdx.x;
   const uint64_t tt = t < n ? t : n - 1;
-  const double ct = tc[tt], st = ts[tt], xt = tx[tt], yt = ty[tt];
+  const uint32_t i = perm[tt];
+  const Pose2 T = ordered_pose(f.world_to_field, pose, i);  // likelihood_field_model.hpp:70
+  const double ct = T.r.c, st = T.r.s, xt = T.x, yt = T.y;
   const uint32_t b_begin = partial ? blockIdx.y * beams_per_segment : 0u;
   const uint32_t b_end = partial ? (b_begin + beams_per_segment < B ? b_begin + beams_per_segment : B) : B;
   double acc = (f.prob || partial) ? 0.0 : 1.0;
@@ -462,7 +544,6 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
     if (partial) {
       partial[static_cast<size_t>(blockIdx.y) * n + t] = acc;
     } else {
-      const uint32_t i = perm[t];
       w[i] = w[i] * (f.prob ? exp(acc) : acc);
     }
   }
@@ -479,20 +560,13 @@ __global__ __launch_bounds__(kBlock) void k_lf_combine(double* __restrict__ w, u
 }
 
 // -- spatial ordering of the particles --------------------------------------------------------------
-// Order = sort by a 20-bit key (heading / x / y bins relative to the cloud's bounding box, Morton-interleaved).
-// Global atomics are slow on this part (~6 per ns, device scope resolves at the memory side), so the sort
-// uses none: (1) per-workgroup LDS histogram of the key's top 10 bits, (2) an exclusive scan of the
-// [digit][workgroup] table, (3) scatter through LDS cursors, (4) a bitonic sort of every 2048-element
-// block in LDS on the full key.  Runs that straddle a block edge stay split, which costs nothing: every
-// wave still gets 64 neighbours.
-// Bin resolution: kKeyBitsXY bits for x and for y, kKeyBitsTheta for the heading (relative to the cloud's extent).
-struct KeyBits {
-  uint32_t xy, theta;
-  __host__ __device__ uint32_t total() const { return 2 * xy + theta; }
-};
-constexpr uint32_t kDigitBits = 10, kDigits = 1u << kDigitBits;         // coarse partition digit
-static_assert(kDigits == kSortDigits, "scratch sizing in context.hip assumes this digit width");
-
+// A full least-significant-digit-first radix sort of (key, index) by the 20-bit ordering key, two passes of 10 bits:
+//   keys + block histograms of the low digit (inside k_propagate, or k_order_keys)  ->  digit totals  ->  row scan  ->
+//   scatter by the low digit (order inside a digit irrelevant)  ->  block histograms of the high digit  ->  digit totals
+//   ->  row scan  ->  STABLE scatter by the high digit  ->  perm.
+// Global atomics are slow on this part (~6 per ns, device scope resolves at the memory side), so there are none: block
+// histograms in LDS, [digit][block] offset tables, LDS cursors.  Only 8 bytes per particle move; the kernels that
+// consume the order gather the pose records through perm.
 __device__ __forceinline__ double heading_delta(double c, double s, double c0, double s0) {
   return atan2(s * c0 - c * s0, c * c0 + s * s0);  // angle of (c,s) relative to (c0,s0), in (-pi, pi]
 }
@@ -538,8 +612,9 @@ __global__ __launch_bounds__(kBlock) void k_bbox_partials(Particles p, uint64_t 
   }
 }
 
+// Also turns the box into the key frame of the ordering keys (bins over the box instead of +-4 sigma).
 __global__ __launch_bounds__(kBlock) void k_bbox_final(const double* __restrict__ partials, uint32_t count, uint32_t stride,
-                                                       double* __restrict__ out) {
+                                                       double* __restrict__ out, Particles p, KeyFrame* __restrict__ frame) {
   __shared__ double scratch[(kBlock / 64) * 6];
   double v[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
   for (uint32_t b = threadIdx.x; b < count; b += kBlock)
@@ -563,62 +638,79 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final(const double* __restrict_
         v[k + 1] = fmax(v[k + 1], scratch[q * 6 + k + 1]);
       }
     for (int k = 0; k < 6; ++k) out[k] = v[k];
+    auto inverse_span = [](double lo, double hi) { return hi > lo ? static_cast<float>(1.0 / (hi - lo)) : 0.f; };
+    KeyFrame kf;
+    kf.cx = 0.5 * (v[0] + v[1]);
+    kf.cy = 0.5 * (v[2] + v[3]);
+    kf.c0 = p.pose[0].x;
+    kf.s0 = p.pose[0].y;
+    kf.inv_x = inverse_span(v[0], v[1]);
+    kf.inv_y = inverse_span(v[2], v[3]);
+    kf.inv_t = inverse_span(v[4], v[5]);
+    kf.t_off = static_cast<float>(0.5 * (v[4] + v[5]));
+    *frame = kf;
   }
 }
 
-__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // ...edcba -> ..e00d00c00b00a
-  v &= 0x3FF;
-  v = (v | (v << 16)) & 0x030000FF;
-  v = (v | (v << 8)) & 0x0300F00F;
-  v = (v | (v << 4)) & 0x030C30C3;
-  v = (v | (v << 2)) & 0x09249249;
-  return v;
-}
-__device__ __forceinline__ int bin_of(double v, double lo, double hi, int bins) {
-  const double r = hi - lo;
-  int b = r > 0.0 ? static_cast<int>((v - lo) / r * bins) : 0;
-  return min(max(b, 0), bins - 1);
-}
-// Key: the extra heading bits on top, then Morton (heading, y, x) over kb.xy bits each.
-__device__ __forceinline__ uint32_t sort_key(const Particles& p, uint64_t i, const double* __restrict__ bbox, double c0, double s0,
-                                             KeyBits kb) {
-  const double4 q = p.pose[i];
-  const int bx = bin_of(q.z, bbox[0], bbox[1], 1 << kb.xy);
-  const int by = bin_of(q.w, bbox[2], bbox[3], 1 << kb.xy);
-  const int bt = bin_of(heading_delta(q.x, q.y, c0, s0), bbox[4], bbox[5], 1 << kb.theta);
-  const uint32_t lo = kb.xy;
-  return (static_cast<uint32_t>(bt >> lo) << (3 * lo)) | spread3(bx) | (spread3(by) << 1) | (spread3(bt & ((1 << lo) - 1)) << 2);
-}
-
-__global__ __launch_bounds__(kBlock) void k_sort_hist(Particles p, uint64_t n, const double* __restrict__ bbox,
-                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ block_hist,
-                                                      uint32_t nblocks, KeyBits kb) {
-  __shared__ uint32_t hist[kDigits];
-  for (uint32_t d = threadIdx.x; d < kDigits; d += kBlock) hist[d] = 0;
+// Keys + block histograms of the low digit as a pass of its own (stage-level calls, where k_propagate did not emit them).
+__global__ __launch_bounds__(kBlock) void k_order_keys(Particles p, uint64_t n, KeyFrame kf_value, const KeyFrame* __restrict__ kf_device,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ table, uint32_t nblocks) {
+  __shared__ uint32_t hist[kSortDigits];
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) hist[d] = 0;
   __syncthreads();
-  const double c0 = p.pose[0].x, s0 = p.pose[0].y;
+  const KeyFrame kf = kf_device ? *kf_device : kf_value;
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
 #pragma unroll
   for (int k = 0; k < kChunk / kBlock; ++k) {
     const uint64_t i = base + k * kBlock + threadIdx.x;  // coalesced
     if (i < n) {
-      const uint32_t key = sort_key(p, i, bbox, c0, s0, kb);
+      const uint32_t key = order_key(p.pose[i], kf);
       keys[i] = key;
-      atomicAdd(&hist[key >> (kb.total() - kDigitBits)], 1u);
+      atomicAdd(&hist[key & (kSortDigits - 1)], 1u);
     }
   }
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < kDigits; d += kBlock) block_hist[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
 }
 
-// Besides (key, index) the pose record travels with the particle, so that k_sort_blocks finds the poses of its 2048
-// elements in one contiguous 64 KB window instead of gathering them from all over the set.
-__global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restrict__ keys, uint64_t n,
-                                                         const uint32_t* __restrict__ block_offsets, uint32_t nblocks,
-                                                         unsigned long long* __restrict__ out, KeyBits kb, Particles p,
-                                                         double4* __restrict__ pose_out) {
-  __shared__ uint32_t cursor[kDigits];
-  for (uint32_t d = threadIdx.x; d < kDigits; d += kBlock) cursor[d] = block_offsets[static_cast<size_t>(d) * nblocks + blockIdx.x];
+// totals[d] = sum of row d of the [digit][block] table; one wave per digit.
+__global__ __launch_bounds__(kBlock) void k_digit_totals(const uint32_t* __restrict__ table, uint32_t nblocks, uint32_t* __restrict__ totals) {
+  const uint32_t d = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t* row = table + static_cast<size_t>(d) * nblocks;
+  uint32_t acc = 0;
+  for (uint32_t b = lane; b < nblocks; b += 64) acc += row[b];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (lane == 0) totals[d] = acc;
+}
+// Row d of the table becomes its exclusive scan plus the total of all smaller digits: the offsets of the scatter.
+__global__ __launch_bounds__(kBlock) void k_row_scan(uint32_t* __restrict__ table, uint32_t nblocks, const uint32_t* __restrict__ totals) {
+  const uint32_t d = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  uint32_t below = 0;
+  for (uint32_t q = lane; q < d; q += 64) below += totals[q];
+  for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+  uint32_t* row = table + static_cast<size_t>(d) * nblocks;
+  uint32_t carry = below;
+  for (uint32_t start = 0; start < nblocks; start += 64) {
+    const uint32_t b = start + lane;
+    const uint32_t v = b < nblocks ? row[b] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o);
+      if (lane >= static_cast<uint32_t>(o)) incl += up;
+    }
+    if (b < nblocks) row[b] = carry + incl - v;
+    carry += __shfl(incl, 63);
+  }
+}
+
+// First pass: by the low digit.  Elements of one digit may land in any order (LDS cursors); the second pass orders
+// them by the high digit anyway and two particles with the same 20-bit key are interchangeable for locality.
+__global__ __launch_bounds__(kBlock) void k_sort_scatter_low(const uint32_t* __restrict__ keys, uint64_t n,
+                                                             const uint32_t* __restrict__ table, uint32_t nblocks,
+                                                             unsigned long long* __restrict__ out) {
+  __shared__ uint32_t cursor[kSortDigits];
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) cursor[d] = table[static_cast<size_t>(d) * nblocks + blockIdx.x];
   __syncthreads();
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
 #pragma unroll
@@ -626,119 +718,77 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restr
     const uint64_t i = base + k * kBlock + threadIdx.x;
     if (i < n) {
       const uint32_t key = keys[i];
-      const uint32_t dest = atomicAdd(&cursor[key >> (kb.total() - kDigitBits)], 1u);
-      out[dest] = (static_cast<unsigned long long>(key) << 32) | static_cast<uint32_t>(i);
-      pose_out[dest] = p.pose[i];
+      const uint32_t dest = atomicAdd(&cursor[key & (kSortDigits - 1)], 1u);
+      out[dest] = (static_cast<unsigned long long>(key >> kDigitBits) << 32) | static_cast<uint32_t>(i);
     }
   }
 }
-
-// Fine ordering of each 2048-element block of (key << 32 | index) in LDS, then the permutation and the world->field
-// pose of every particle in that order (likelihood_field_model.hpp:70).
-// Only locality matters downstream (which 64 particles share a wave), not a total order, so the block is ordered by a
-// counting sort in LDS on the key's position inside the block's own key range, 4096 bins: 3 passes over the block
-// instead of the 66 compare-exchange stages of a bitonic network.  Particles of one bin (a few adjacent Morton codes) stay
-// in arrival order.
-constexpr uint32_t kFineBins = 4096;
-__global__ __launch_bounds__(kBlock) void k_sort_blocks(const unsigned long long* __restrict__ in, uint64_t n,
-                                                        const double4* __restrict__ pose_in, Pose2 world_to_field,
-                                                        uint32_t* __restrict__ perm, double* __restrict__ tc, double* __restrict__ ts,
-                                                        double* __restrict__ tx, double* __restrict__ ty, int fine) {
-  __shared__ uint32_t key_of[kChunk];
-  __shared__ uint32_t index_of[kChunk];   // particle index of the element at that position
-  __shared__ uint32_t from_of[kChunk];    // output slot -> position inside this block
-  __shared__ uint32_t bins[kFineBins];
-  __shared__ uint32_t s_wave[2 * (kBlock / 64)];
-  __shared__ uint32_t s_range[2];
+__global__ __launch_bounds__(kBlock) void k_sort_hist_high(const unsigned long long* __restrict__ in, uint64_t n,
+                                                           uint32_t* __restrict__ table, uint32_t nblocks) {
+  __shared__ uint32_t hist[kSortDigits];
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) hist[d] = 0;
+  __syncthreads();
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
-  const uint32_t m = static_cast<uint32_t>(n - base < kChunk ? n - base : kChunk);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
   for (int k = 0; k < kChunk / kBlock; ++k) {
-    const uint32_t t = k * kBlock + threadIdx.x;
-    if (t < m) {
-      const unsigned long long e = in[base + t];
-      const uint32_t key = static_cast<uint32_t>(e >> 32);
-      key_of[t] = key;
-      index_of[t] = static_cast<uint32_t>(e);
-      from_of[t] = t;
-      kmin = min(kmin, key);
-      kmax = max(kmax, key);
-    }
-  }
-  for (uint32_t b = threadIdx.x; b < kFineBins; b += kBlock) bins[b] = 0;
-  for (int o = 32; o > 0; o >>= 1) {
-    kmin = min(kmin, static_cast<uint32_t>(__shfl_down(kmin, o)));
-    kmax = max(kmax, static_cast<uint32_t>(__shfl_down(kmax, o)));
-  }
-  if (lane == 0) {
-    s_wave[2 * wave] = kmin;
-    s_wave[2 * wave + 1] = kmax;
+    const uint64_t e = base + k * kBlock + threadIdx.x;
+    if (e < n) atomicAdd(&hist[static_cast<uint32_t>(in[e] >> 32) & (kSortDigits - 1)], 1u);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int q = 1; q < kBlock / 64; ++q) {
-      kmin = min(kmin, s_wave[2 * q]);
-      kmax = max(kmax, s_wave[2 * q + 1]);
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
+}
+// Second pass: by the high digit, stable.  Every wave owns a contiguous quarter of the block and walks it 64 elements at a
+// time: the lanes holding the same digit find each other with ten ballots (rank inside the group = lanes below with
+// the same digit), the wave's running count per digit lives in LDS; the four waves' counts are then chained in wave order
+// behind the block's offset of that digit.  No cross-wave step until every wave has ranked its quarter.
+__global__ __launch_bounds__(kBlock) void k_sort_scatter_high(const unsigned long long* __restrict__ in, uint64_t n,
+                                                              const uint32_t* __restrict__ table, uint32_t nblocks,
+                                                              uint32_t* __restrict__ perm) {
+  constexpr int kWaves = kBlock / 64, kRounds = kChunk / kBlock;
+  __shared__ uint16_t wave_count[kWaves][kSortDigits];
+  __shared__ uint32_t wave_base[kWaves][kSortDigits];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t d = threadIdx.x; d < kWaves * kSortDigits; d += kBlock) (&wave_count[0][0])[d] = 0;
+  __syncthreads();
+  volatile uint16_t* mine = wave_count[wave];
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + static_cast<uint64_t>(wave) * (kChunk / kWaves);
+  uint32_t index[kRounds], digit[kRounds], rank[kRounds];
+#pragma unroll
+  for (int k = 0; k < kRounds; ++k) {
+    const uint64_t e = base + static_cast<uint64_t>(k) * 64 + lane;
+    const bool valid = e < n;
+    const unsigned long long v = valid ? in[e] : 0ull;
+    index[k] = static_cast<uint32_t>(v);
+    digit[k] = static_cast<uint32_t>(v >> 32) & (kSortDigits - 1);
+    unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+    for (uint32_t bit = 0; bit < kDigitBits; ++bit) {
+      const bool set = (digit[k] >> bit) & 1u;
+      const unsigned long long b = __builtin_amdgcn_ballot_w64(set);
+      same &= set ? b : ~b;
     }
-    s_range[0] = kmin;
-    uint32_t shift = 0;
-    while (((kmax - kmin) >> shift) >= kFineBins) ++shift;
-    s_range[1] = shift;
+    const uint32_t below = static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
+    const uint32_t count = static_cast<uint32_t>(__popcll(same));
+    const uint32_t before = valid ? mine[digit[k]] : 0u;
+    rank[k] = before + below;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && below == 0) mine[digit[k]] = static_cast<uint16_t>(before + count);
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  if (fine) {
-    const uint32_t lo = s_range[0], shift = s_range[1];
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) {
+    uint32_t run = table[static_cast<size_t>(d) * nblocks + blockIdx.x];
 #pragma unroll
-    for (int k = 0; k < kChunk / kBlock; ++k) {
-      const uint32_t t = k * kBlock + threadIdx.x;
-      if (t < m) atomicAdd(&bins[(key_of[t] - lo) >> shift], 1u);
+    for (int q = 0; q < kWaves; ++q) {
+      wave_base[q][d] = run;
+      run += wave_count[q][d];
     }
-    __syncthreads();
-    // exclusive scan of the bins: 16 consecutive bins per thread, then across the workgroup
-    uint32_t loc[kFineBins / kBlock];
-    uint32_t run = 0;
-#pragma unroll
-    for (int k = 0; k < static_cast<int>(kFineBins / kBlock); ++k) {
-      loc[k] = run;
-      run += bins[threadIdx.x * (kFineBins / kBlock) + k];
-    }
-    uint32_t incl = run;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_up(incl, o);
-      if (lane >= o) incl += up;
-    }
-    __syncthreads();
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t prefix = incl - run;
-    for (int q = 0; q < wave; ++q) prefix += s_wave[q];
-#pragma unroll
-    for (int k = 0; k < static_cast<int>(kFineBins / kBlock); ++k) bins[threadIdx.x * (kFineBins / kBlock) + k] = prefix + loc[k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kChunk / kBlock; ++k) {
-      const uint32_t t = k * kBlock + threadIdx.x;
-      if (t < m) from_of[atomicAdd(&bins[(key_of[t] - lo) >> shift], 1u)] = t;
-    }
-    __syncthreads();
   }
+  __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kChunk / kBlock; ++k) {
-    const uint32_t t = k * kBlock + threadIdx.x;
-    if (t < m) {
-      const uint64_t o = base + t;
-      const uint32_t from = from_of[t];
-      const double4 q = pose_in[base + from];
-      const Pose2 T = pose_mul(world_to_field, Pose2{Rot2{q.x, q.y}, q.z, q.w});
-      perm[o] = index_of[from];
-      tc[o] = T.r.c;
-      ts[o] = T.r.s;
-      tx[o] = T.x;
-      ty[o] = T.y;
-    }
+  for (int k = 0; k < kRounds; ++k) {
+    const uint64_t e = base + static_cast<uint64_t>(k) * 64 + lane;
+    if (e < n) perm[wave_base[wave][digit[k]] + rank[k]] = index[k];
   }
 }
 
@@ -1100,9 +1150,7 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
                                                                      const uint32_t* __restrict__ nonfree_bits,
                                                                      uint32_t words_per_row, const double* __restrict__ pts,
                                                                      uint32_t B, const uint32_t* __restrict__ perm,
-                                                                     const double* __restrict__ tc, const double* __restrict__ ts,
-                                                                     const double* __restrict__ tx, const double* __restrict__ ty,
-                                                                     unsigned long long* d_steps) {
+                                                                     const double4* __restrict__ pose, unsigned long long* d_steps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* win = reinterpret_cast<uint32_t*>(smem);
   const uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * kBeamBlock;
@@ -1111,7 +1159,10 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
   // window centred on the middle particle of the workgroup (they are spatial neighbours after the ordering pass)
   const uint64_t tm = t0 + kBeamBlock / 2 < n ? t0 + kBeamBlock / 2 : n - 1;
   int cx, cy;
-  cell_near(g, tx[tm], ty[tm], cx, cy);
+  {
+    const Pose2 middle = ordered_pose(g.origin_inverse, pose, perm[tm]);
+    cell_near(g, middle.x, middle.y, cx, cy);
+  }
   BitWindow bw;
   bw.x0 = ((cx - kWin / 2) >> 5) << 5;
   bw.y0 = cy - kWin / 2;
@@ -1128,7 +1179,8 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
   }
   __syncthreads();
 
-  const Pose2 src{Rot2{tc[tt], ts[tt]}, tx[tt], ty[tt]};
+  const uint32_t i = perm[tt];
+  const Pose2 src = ordered_pose(g.origin_inverse, pose, i);  // Ray2d ctor: raycasting.hpp:69
   int sx, sy;
   cell_near(g, src.x, src.y, sx, sy);
   const double norm_hit = 1. / (sqrt(2. * kPi) * m.sigma_hit);
@@ -1144,10 +1196,7 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
     for (int o = 32; o > 0; o >>= 1) steps += __shfl_down(steps, o);
     if ((threadIdx.x & 63) == 0) atomicAdd(d_steps, steps);
   }
-  if (t < n) {
-    const uint32_t i = perm[t];
-    w[i] = w[i] * acc;
-  }
+  if (t < n) w[i] = w[i] * acc;
 }
 
 // nonfree_bits: one bit per cell, row-major, words_per_row = ceil(W / 32) words per row.
@@ -1181,33 +1230,28 @@ __global__ __launch_bounds__(kBlock) void k_chunk_sum(const double* __restrict__
   if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
 }
 
-// out[k] = sum_b partials[k][b] for k < K (partials laid out [K][stride]); single workgroup, fixed order.
+// out[k] = sum_b partials[k][b] (partials laid out [rows][stride]); one workgroup per row k = blockIdx.x, fixed order.
 // host_mirror (optional): a mapped pinned-host copy of the result, written by the kernel itself — the host reads it after
 // the stream synchronisation, no separate device-to-host copy (a blit kernel of its own) is enqueued.
-template <int K>
-__global__ __launch_bounds__(kBlock) void k_final_sum(const double* __restrict__ partials, uint32_t count, uint32_t stride,
-                                                      double* __restrict__ out, double* __restrict__ host_mirror) {
-  __shared__ double scratch[(kBlock / 64) * K];
-  double v[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = 0.0;
-  for (uint32_t b = threadIdx.x; b < count; b += kBlock) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] += partials[static_cast<size_t>(k) * stride + b];
-  }
-  block_reduce<K>(v, scratch);
+__device__ __forceinline__ double row_total(const double* __restrict__ row, uint32_t count, double* scratch /* [kBlock/64] */) {
+  double v[1] = {0.0};
+  for (uint32_t b = threadIdx.x; b < count; b += kBlock) v[0] += row[b];
+  block_reduce<1>(v, scratch);
+  return v[0];  // valid in thread 0
+}
+__global__ __launch_bounds__(kBlock) void k_final_rows(const double* __restrict__ partials, uint32_t count, uint32_t stride,
+                                                       double* __restrict__ out, double* __restrict__ host_mirror) {
+  __shared__ double scratch[kBlock / 64];
+  const uint32_t k = blockIdx.x;
+  const double total = row_total(partials + static_cast<size_t>(k) * stride, count, scratch);
   if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) out[k] = v[k];
-    if (host_mirror) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) host_mirror[k] = v[k];
-    }
+    out[k] = total;
+    if (host_mirror) host_mirror[k] = total;
   }
 }
 
 // sum_partials != nullptr: the factor is the total of these chunk sums, added up by every workgroup exactly as
-// k_final_sum<1> does (same strides, same reduction tree, same bits) instead of being read from *d_factor — one launch
+// k_final_rows does (same strides, same reduction tree, same bits) instead of being read from *d_factor — one launch
 // less on the cycle's critical path; workgroup 0 stores the total to d_sum_out (and its host mirror).
 __global__ __launch_bounds__(kBlock) void k_normalize(double* __restrict__ w, uint64_t n, const double* __restrict__ d_factor,
                                                       double* __restrict__ chunk_sum, double* __restrict__ chunk_sumsq,
@@ -1317,11 +1361,65 @@ __device__ __forceinline__ double chunk_offset_replay(const double* __restrict__
   return r_result;
 }
 
+// What the last normalisation kernel of a cycle leaves for the policies: the totals of the normalised weights and of their
+// squares (same rows, same reduction tree as k_final_rows) and, when the cycle takes no host-side decision, one step of
+// ThrunRecoveryProbabilityEstimator (thrun_recovery_probability_estimator.hpp:69-89, exponential_filter.hpp:32-44):
+// policy = {slow, fast, p}; both filters advance on average = norm_sum / n; p = clamp(1 - fast / slow, 0, 1) (0 while
+// |slow| < eps); if this cycle resamples and p > 0 the filters are reset (amcl_core.hpp:184-186).
+struct NormFinalize {
+  const double* chunk_sum;    // [chunks] sums of the normalised weights per chunk (k_normalize)
+  const double* chunk_sumsq;  // [chunks]
+  uint32_t chunks;
+  double* d_sums;             // d_sums[0] = norm_sum, d_sums[1] = norm_sumsq
+  double* sums_mirror;        // optional host mirror of the two
+  int policy;                 // run the recovery estimator
+  uint64_t n;
+  double alpha_slow, alpha_fast;
+  int resampling;
+  double* d_policy;           // {slow, fast, p}
+  double* policy_mirror;      // optional: receives p at [2]
+};
+__device__ __forceinline__ void recovery_policy_step(double norm_sum, const NormFinalize& f) {
+  const double average = norm_sum / static_cast<double>(f.n);
+  double slow = f.d_policy[0], fast = f.d_policy[1];
+  fast += (fast == 0.) ? average : f.alpha_fast * (average - fast);
+  slow += (slow == 0.) ? average : f.alpha_slow * (average - slow);
+  double p = 0.0;
+  if (fabs(slow) >= 2.220446049250313e-16) p = fmin(fmax(1.0 - fast / slow, 0.0), 1.0);
+  if (f.resampling && p > 0.0) slow = fast = 0.0;
+  f.d_policy[0] = slow;
+  f.d_policy[1] = fast;
+  f.d_policy[2] = p;
+  if (f.policy_mirror) f.policy_mirror[2] = p;
+}
+// Whole workgroup; scratch [kBlock/64].
+__device__ __forceinline__ void norm_finalize(const NormFinalize& f, double* scratch) {
+  const double sum = row_total(f.chunk_sum, f.chunks, scratch);
+  const double sumsq = row_total(f.chunk_sumsq, f.chunks, scratch);
+  if (threadIdx.x == 0) {
+    f.d_sums[0] = sum;
+    f.d_sums[1] = sumsq;
+    if (f.sums_mirror) {
+      f.sums_mirror[0] = sum;
+      f.sums_mirror[1] = sumsq;
+    }
+    if (f.policy) recovery_policy_step(sum, f);
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_norm_finalize(NormFinalize f) {
+  __shared__ double scratch[kBlock / 64];
+  norm_finalize(f, scratch);
+}
+
 __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, uint64_t n, const double* __restrict__ chunk_offset,
                                                 double* __restrict__ cdf, double* __restrict__ total, CdfTree tree,
                                                 double* __restrict__ levels, const double* __restrict__ chunk_sum_to_scan,
-                                                uint32_t chunk_count) {
+                                                uint32_t chunk_count, NormFinalize fin) {
   __shared__ double s_wave[kBlock / 64];
+  if (fin.d_sums && blockIdx.x == 0) {  // the totals (and the recovery estimator) ride on the first workgroup
+    norm_finalize(fin, s_wave);
+    __syncthreads();
+  }
   const double my_offset = chunk_sum_to_scan ? chunk_offset_replay(chunk_sum_to_scan, chunk_count, blockIdx.x) : chunk_offset[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
@@ -1402,6 +1500,35 @@ __device__ __forceinline__ uint64_t cdf_tree_lower_bound(const CdfTree& t, doubl
   const uint64_t begin = pos * 16;
   return group_lower_bound(t.cdf, begin, begin + 16 < t.n ? begin + 16 : t.n, target);
 }
+// The same search with the sampled levels >= first_staged read from a workgroup copy in LDS (they are contiguous in
+// t.levels from t.offset[first_staged] on): a look-up of 64 unrelated lines costs the vector-memory pipe a cycle per lane,
+// an LDS read two per wave.  Same comparisons, same result.
+__device__ __forceinline__ uint64_t lds_group_lower_bound(const double* a, uint32_t begin, uint32_t end, double target) {
+  uint32_t lo = begin, len = end - begin;
+  while (len > 0) {
+    const uint32_t half = len >> 1;
+    if (a[lo + half] < target) {
+      lo += half + 1;
+      len -= half + 1;
+    } else {
+      len = half;
+    }
+  }
+  return lo < end ? lo : end - 1;
+}
+__device__ __forceinline__ uint64_t cdf_tree_lower_bound_staged(const CdfTree& t, const double* staged, int first_staged, double target) {
+  uint64_t pos = 0;
+  for (int l = t.depth - 1; l >= first_staged; --l) {
+    const uint32_t begin = static_cast<uint32_t>(pos) * 16u, size = t.size[l];
+    pos = lds_group_lower_bound(staged + (t.offset[l] - t.offset[first_staged]), begin, begin + 16 < size ? begin + 16 : size, target);
+  }
+  for (int l = (first_staged < t.depth ? first_staged : t.depth) - 1; l >= 0; --l) {
+    const uint64_t begin = pos * 16, size = t.size[l];
+    pos = group_lower_bound(t.levels + t.offset[l], begin, begin + 16 < size ? begin + 16 : size, target);
+  }
+  const uint64_t begin = pos * 16;
+  return group_lower_bound(t.cdf, begin, begin + 16 < t.n ? begin + 16 : t.n, target);
+}
 // multivariate_uniform_distribution.hpp:145-147 over occupancy_grid.hpp:140-146,164-171: uniform heading,
 // centre of a uniformly chosen free cell in the world frame.  Addressed by the candidate's global index.
 __device__ __forceinline__ Pose2 random_free_state(uint64_t seed, uint32_t step, uint64_t j, const GridView& g, const FreeCells& fc) {
@@ -1428,13 +1555,25 @@ __device__ __forceinline__ bool intersperse_here(const RngWords& r, uint64_t j, 
 
 // kEstimate: the nine sums of beluga::estimate (estimation.hpp:436-475) over the new set (weights 1) are accumulated on the
 // way out — est_partials[k][workgroup] — so that the estimate needs no pass of its own over the particles it just wrote.
+// Workgroups of 1024 outputs share an LDS copy of the upper levels of the search tree (staged doubles from level
+// first_staged on; dynamic shared memory).
+constexpr int kDrawBlock = 1024;
+constexpr uint32_t kDrawStageMax = 4608;  // doubles (36 KB): two workgroups per CU
 template <bool kEstimate>
-__global__ __launch_bounds__(kBlock) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
-                                                          Particles dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
-                                                          unsigned long long* __restrict__ hashes, double pivot_x, double pivot_y,
-                                                          double* __restrict__ est_partials, uint32_t est_stride) {
-  __shared__ double scratch[kEstimate ? (kBlock / 64) * 9 : 1];
-  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+__global__ __launch_bounds__(kDrawBlock) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
+                                                              Particles dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
+                                                              unsigned long long* __restrict__ hashes, double pivot_x, double pivot_y,
+                                                              double* __restrict__ est_partials, uint32_t est_stride, int first_staged,
+                                                              uint32_t staged_doubles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* staged = reinterpret_cast<double*>(smem);
+  __shared__ double scratch[kEstimate ? (kDrawBlock / 64) * 9 : 1];
+  if (first_staged < cdf.depth) {
+    const double* from = cdf.levels + cdf.offset[first_staged];
+    for (uint32_t k = threadIdx.x; k < staged_doubles; k += kDrawBlock) staged[k] = from[k];
+  }
+  __syncthreads();
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kDrawBlock + threadIdx.x;
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (t < a.count) {
     const uint64_t j = a.first_candidate + t;
@@ -1448,7 +1587,7 @@ __global__ __launch_bounds__(kBlock) void k_resample_draw(Particles src, CdfTree
       uint64_t idx = 0;
       if (a.n_in >= 2) {
         const double u = rng_uniform53(r.w[0], r.w[1]);
-        idx = cdf_tree_lower_bound(cdf, u * (*d_total));
+        idx = cdf_tree_lower_bound_staged(cdf, staged, first_staged, u * (*d_total));
       }
       s = load_pose(src, idx);
     }
@@ -1470,28 +1609,12 @@ __global__ __launch_bounds__(kBlock) void k_resample_draw(Particles src, CdfTree
     }
   }
   if (kEstimate) {
-    block_reduce<9>(v, scratch);
+    block_reduce<9, kDrawBlock>(v, scratch);
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) est_partials[static_cast<size_t>(k) * est_stride + blockIdx.x] = v[k];
     }
   }
-}
-
-__global__ void k_recovery_policy(const double* __restrict__ d_norm_sum, uint64_t n, double alpha_slow, double alpha_fast, int resampling,
-                                  double* __restrict__ policy, double* __restrict__ host_mirror) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double average = *d_norm_sum / static_cast<double>(n);
-  double slow = policy[0], fast = policy[1];
-  fast += (fast == 0.) ? average : alpha_fast * (average - fast);
-  slow += (slow == 0.) ? average : alpha_slow * (average - slow);
-  double p = 0.0;
-  if (fabs(slow) >= 2.220446049250313e-16) p = fmin(fmax(1.0 - fast / slow, 0.0), 1.0);
-  if (resampling && p > 0.0) slow = fast = 0.0;
-  policy[0] = slow;
-  policy[1] = fast;
-  policy[2] = p;
-  if (host_mirror) host_mirror[2] = p;
 }
 
 // -- sharded resampling (one context per GPU; the exchange between them is done by the caller) -----------
@@ -1933,6 +2056,17 @@ __global__ __launch_bounds__(kBlock) void k_init_normal(Particles p, uint64_t n,
   p.w[i] = 1.0;
 }
 
+// beluga_ros::Amcl::initialize_from_map (beluga_ros/include/beluga_ros/amcl.hpp:191-198,209): particle i takes the i-th draw of
+// MultivariateUniformDistribution<SE2d, OccupancyGrid> (random/multivariate_uniform_distribution.hpp:145-147), weight 1.
+// Same generator as random_intersperse's injected states, addressed by (step 0, global particle index).
+__global__ __launch_bounds__(kBlock) void k_init_from_map(Particles p, uint64_t n, uint64_t seed, uint64_t index_offset, GridView g,
+                                                          FreeCells fc) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  store_pose(p, i, random_free_state(seed, 0u, index_offset + i, g, fc));
+  p.w[i] = 1.0;  // particle_traits.hpp:105
+}
+
 __global__ __launch_bounds__(kBlock) void k_cube_table(const float* __restrict__ field, uint64_t cells, float unknown_value,
                                                        double* __restrict__ cube, int prob) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -1979,42 +2113,52 @@ inline unsigned blocks_for(uint64_t n) { return static_cast<unsigned>((n + kBloc
 
 // =====================================================================================================
 void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
-                      uint64_t index_offset) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(k_propagate, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, smp, seed, step, index_offset);
+                      uint64_t index_offset, const double* scan_src, double* scan_dst, uint32_t scan_doubles, const SortScratch* sort,
+                      const KeyFrame* frame) {
+  if (n == 0) {
+    if (scan_dst && scan_doubles) launch_pull_scan(st, scan_src, scan_dst, scan_doubles);
+    return;
+  }
+  const uint32_t nblocks = num_chunks(n);
+  if (sort && frame && n < (1ull << 32))
+    hipLaunchKernelGGL(k_propagate<true>, dim3(nblocks), dim3(kBlock), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
+                       scan_doubles, *frame, sort->keys, sort->table, nblocks);
+  else
+    hipLaunchKernelGGL(k_propagate<false>, dim3(nblocks), dim3(kBlock), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
+                       scan_doubles, KeyFrame{}, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), nblocks);
 }
 
-void launch_lf_bin_sort(hipStream_t st, Particles p, uint64_t n, FieldView f, const SortScratch* sort) {
+void launch_pull_scan(hipStream_t st, const double* scan_src, double* scan_dst, uint32_t scan_doubles) {
+  if (scan_doubles == 0) return;
+  hipLaunchKernelGGL(k_pull_scan, dim3(1), dim3(kBlock), 0, st, scan_src, scan_dst, scan_doubles);
+}
+
+void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortScratch* sort, const KeyFrame* frame, bool keys_ready) {
   if (n == 0 || !sort || n >= (1ull << 32)) return;
   const uint32_t nblocks = num_chunks(n);
-  double* partials = sort->bbox + 8;
-  hipLaunchKernelGGL(k_bbox_partials, dim3(nblocks), dim3(kBlock), 0, st, p, n, partials, nblocks);
-  hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(kBlock), 0, st, partials, nblocks, nblocks, sort->bbox);
-  static const KeyBits kb = [] {
-    const char* v = std::getenv("BELUGA_MCL_KEY_BITS");  // "xy,theta" (tuning hook); default 7,10 = 128 x 128 x 1024 bins (best of a sweep on the 1M-particle bench)
-    KeyBits k{7, 10};
-    if (v) {
-      unsigned a = 0, b = 0;
-      if (std::sscanf(v, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 10 && b >= a && b <= 10 && 2 * a + b >= kDigitBits) k = KeyBits{a, b};
+  if (!keys_ready) {
+    const KeyFrame* device_frame = nullptr;
+    if (!frame) {  // no estimate of the set on the host: bins over its bounding box
+      double* partials = sort->bbox + 8;
+      hipLaunchKernelGGL(k_bbox_partials, dim3(nblocks), dim3(kBlock), 0, st, p, n, partials, nblocks);
+      hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(kBlock), 0, st, partials, nblocks, nblocks, sort->bbox, p, sort->frame);
+      device_frame = sort->frame;
     }
-    return k;
-  }();
-  hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(kBlock), 0, st, p, n, sort->bbox, sort->keys, sort->block_hist, nblocks, kb);
-  const uint32_t m = kDigits * nblocks;
-  const uint32_t mchunks = num_chunks(m);
-  hipLaunchKernelGGL(k_u32_chunk_sum, dim3(mchunks), dim3(kBlock), 0, st, sort->block_hist, m, sort->chunk_sum);
-  hipLaunchKernelGGL(k_scan_chunks<uint32_t>, dim3(1), dim3(kBlock), 0, st, sort->chunk_sum, mchunks, sort->chunk_off,
-                     static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr));
-  hipLaunchKernelGGL(k_u32_exclusive_apply, dim3(mchunks), dim3(kBlock), 0, st, sort->block_hist, m, sort->chunk_off);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(kBlock), 0, st, sort->keys, n, sort->block_hist, nblocks, sort->keyidx, kb, p,
-                     sort->pose_part);
-  static const int fine = [] { const char* v = std::getenv("BELUGA_MCL_SORT_FINE"); return v ? std::atoi(v) : 1; }();
-  hipLaunchKernelGGL(k_sort_blocks, dim3(nblocks), dim3(kBlock), 0, st, sort->keyidx, n, sort->pose_part, f.world_to_field, sort->perm, sort->tc,
-                     sort->ts, sort->tx, sort->ty, fine);
+    hipLaunchKernelGGL(k_order_keys, dim3(nblocks), dim3(kBlock), 0, st, p, n, frame ? *frame : KeyFrame{}, device_frame, sort->keys,
+                       sort->table, nblocks);
+  }
+  const dim3 rows(kSortDigits / (kBlock / 64));
+  hipLaunchKernelGGL(k_digit_totals, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
+  hipLaunchKernelGGL(k_row_scan, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
+  hipLaunchKernelGGL(k_sort_scatter_low, dim3(nblocks), dim3(kBlock), 0, st, sort->keys, n, sort->table, nblocks, sort->keyidx);
+  hipLaunchKernelGGL(k_sort_hist_high, dim3(nblocks), dim3(kBlock), 0, st, sort->keyidx, n, sort->table, nblocks);
+  hipLaunchKernelGGL(k_digit_totals, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
+  hipLaunchKernelGGL(k_row_scan, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
+  hipLaunchKernelGGL(k_sort_scatter_high, dim3(nblocks), dim3(kBlock), 0, st, sort->keyidx, n, sort->table, nblocks, sort->perm);
 }
 
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
-                        const SortScratch* sort, bool scan_is_short) {
+                        const SortScratch* sort, bool scan_is_short, const Tuning& tuning) {
   if (n == 0) return;
   const bool idx32 = static_cast<uint64_t>(f.W) * f.H < (1ull << 31);
   if (variant == kLfSortedLanes && sort && n < (1ull << 32)) {
@@ -2031,34 +2175,26 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
     const uint32_t per_segment = (B + segments - 1) / segments;
     double* partial = segments > 1 ? sort->partial : nullptr;
     const dim3 grid(blocks_for(n), segments);
-    static const int table_pref = [] {  // BELUGA_MCL_LF_TABLE=cube forces the 8-byte table (A/B measurements)
-      const char* v = std::getenv("BELUGA_MCL_LF_TABLE");
-      return (v && std::string(v) == "cube") ? 1 : 0;
-    }();
     const size_t pal_lds = static_cast<size_t>(f.pal_base) + static_cast<size_t>(f.pal_count) * sizeof(double);
-    const bool palette_ok = table_pref == 0 && f.pal_idx != nullptr && f.pal_count > 0 && pal_lds <= 65536;
+    const bool palette_ok = tuning.lf_table == 0 && f.pal_idx != nullptr && f.pal_count > 0 && pal_lds <= 65536;
     if (palette_ok) {
       const dim3 pgrid(static_cast<unsigned>((n + kPalBlock - 1) / kPalBlock), segments);
-      // BELUGA_MCL_LF_FAST: 1 = the FMA fast variant at any size, 0 = never; default: dense sets only (it needs a short scan
-      // and a grid below 2^14 cells per side either way)
-      static const int fast_pref = [] {
-        const char* v = std::getenv("BELUGA_MCL_LF_FAST");
-        return v ? std::atoi(v) : -1;
-      }();
-      const bool fast = scan_is_short && f.W < 16384 && f.H < 16384 && (fast_pref == 1 || (fast_pref < 0 && n >= 4'000'000));
+      // The FMA variant needs a scan within 8192 cells of the sensor and a grid below 2^14 cells per side (its exact
+      // fallback handles everything else inside the kernel); tuning.lf_fast = 0 forces the separately rounded arithmetic.
+      const bool fast = tuning.lf_fast != 0 && scan_is_short && f.W < 16384 && f.H < 16384;
       if (fast)
-        hipLaunchKernelGGL(k_reweight_lf_palette<true>, pgrid, dim3(kPalBlock), pal_lds, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
-                           sort->ts, sort->tx, sort->ty, partial, per_segment);
+        hipLaunchKernelGGL(k_reweight_lf_palette<true>, pgrid, dim3(kPalBlock), pal_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose,
+                           partial, per_segment);
       else
-        hipLaunchKernelGGL(k_reweight_lf_palette<false>, pgrid, dim3(kPalBlock), pal_lds, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
-                           sort->ts, sort->tx, sort->ty, partial, per_segment);
+        hipLaunchKernelGGL(k_reweight_lf_palette<false>, pgrid, dim3(kPalBlock), pal_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose,
+                           partial, per_segment);
+    } else if (cube_ok) {
+      hipLaunchKernelGGL(k_reweight_lf_sorted<true>, grid, dim3(kBlock), 0, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial,
+                         per_segment);
+    } else {
+      hipLaunchKernelGGL(k_reweight_lf_sorted<false>, grid, dim3(kBlock), 0, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial,
+                         per_segment);
     }
-    else if (cube_ok)
-      hipLaunchKernelGGL(k_reweight_lf_sorted<true>, grid, dim3(kBlock), 0, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
-                         sort->ts, sort->tx, sort->ty, partial, per_segment);
-    else
-      hipLaunchKernelGGL(k_reweight_lf_sorted<false>, grid, dim3(kBlock), 0, st, p.w, n, f, d_points, B, sort->perm, sort->tc,
-                         sort->ts, sort->tx, sort->ty, partial, per_segment);
     if (segments > 1)
       hipLaunchKernelGGL(k_lf_combine, dim3(blocks_for(n)), dim3(kBlock), 0, st, p.w, n, sort->perm, partial, segments, f.prob);
   } else if (variant == kLfLanePerParticle || variant == kLfSortedLanes) {
@@ -2081,20 +2217,21 @@ void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32
   hipLaunchKernelGGL(k_pack_nonfree, dim3(blocks_for(words)), dim3(kBlock), 0, st, cells, W, H, free_value, words_per_row, bits);
 }
 
+// hipFuncSetAttribute is per device: contexts on several GPUs of one process each opt in (mcl_create calls this).
+void configure_device_kernels() {
+  const size_t lds = static_cast<size_t>(kWin) * kWinStride * sizeof(uint32_t);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_beam_sorted), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds));
+}
+
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
                           unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits) {
   if (n == 0) return;
   if (sorted && nonfree_bits) {
-    static bool configured = false;
     const size_t lds = static_cast<size_t>(kWin) * kWinStride * sizeof(uint32_t);
-    if (!configured) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_beam_sorted), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds));
-      configured = true;
-    }
     const dim3 grid(static_cast<unsigned>((n + kBeamBlock - 1) / kBeamBlock));
     hipLaunchKernelGGL(k_reweight_beam_sorted, grid, dim3(kBeamBlock), lds, st, p.w, n, g, m, nonfree_bits, (g.W + 31) / 32, d_points,
-                       B, sorted->perm, sorted->tc, sorted->ts, sorted->tx, sorted->ty, d_steps);
+                       B, sorted->perm, p.pose, d_steps);
     return;
   }
   const dim3 grid(static_cast<unsigned>((n + (kBlock / kWave) - 1) / (kBlock / kWave)));
@@ -2105,7 +2242,7 @@ void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, B
 void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_partials, double* d_out, double* host_mirror) {
   const uint32_t chunks = num_chunks(n);
   if (chunks) hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_partials);
-  hipLaunchKernelGGL(k_final_sum<1>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror);
+  hipLaunchKernelGGL(k_final_rows, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror);
 }
 
 void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_factor, double* d_chunk_sum, double* d_chunk_sumsq,
@@ -2114,29 +2251,61 @@ void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_fac
   if (chunks)
     hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, d_factor, d_chunk_sum, d_chunk_sumsq,
                        static_cast<const double*>(nullptr), 0u, static_cast<double*>(nullptr), static_cast<double*>(nullptr));
-  // d_chunk_sum and d_chunk_sumsq are adjacent rows of one [2][stride] buffer (see context.cpp)
-  hipLaunchKernelGGL(k_final_sum<2>, dim3(1), dim3(kBlock), 0, st, d_chunk_sum, chunks,
-                     static_cast<uint32_t>(d_chunk_sumsq - d_chunk_sum), d_out, host_mirror);
+  // d_chunk_sum and d_chunk_sumsq are adjacent rows of one [2][stride] buffer (see context.hip)
+  hipLaunchKernelGGL(k_final_rows, dim3(2), dim3(kBlock), 0, st, d_chunk_sum, chunks, static_cast<uint32_t>(d_chunk_sumsq - d_chunk_sum),
+                     d_out, host_mirror);
 }
 
 // actions::normalize by the set's own total (normalize.hpp:70): weight chunk sums, then the division with the total added
 // up inside k_normalize.  d_sums[0] = total before, d_sums[1], d_sums[2] = sum and sum of squares after (mirrored likewise).
+// finalize == false: the totals after (and the recovery estimator) are left to the kernel that follows — launch_cdf with its
+// finalize arguments, or launch_norm_finalize.
 void launch_sum_and_normalize(hipStream_t st, double* w, uint64_t n, double* d_partials, double* d_chunk_sum, double* d_chunk_sumsq,
-                              double* d_sums, double* host_mirror) {
+                              double* d_sums, double* host_mirror, bool finalize) {
   const uint32_t chunks = num_chunks(n);
   if (chunks) {
     hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_partials);
     hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, static_cast<const double*>(nullptr), d_chunk_sum,
                        d_chunk_sumsq, d_partials, chunks, d_sums, host_mirror);
   } else {
-    hipLaunchKernelGGL(k_final_sum<1>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_sums, host_mirror);
+    hipLaunchKernelGGL(k_final_rows, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_sums, host_mirror);
   }
-  hipLaunchKernelGGL(k_final_sum<2>, dim3(1), dim3(kBlock), 0, st, d_chunk_sum, chunks,
-                     static_cast<uint32_t>(d_chunk_sumsq - d_chunk_sum), d_sums + 1, host_mirror ? host_mirror + 1 : nullptr);
+  if (finalize)
+    hipLaunchKernelGGL(k_final_rows, dim3(2), dim3(kBlock), 0, st, d_chunk_sum, chunks, static_cast<uint32_t>(d_chunk_sumsq - d_chunk_sum),
+                       d_sums + 1, host_mirror ? host_mirror + 1 : nullptr);
+}
+
+namespace {
+NormFinalize make_norm_finalize(const double* d_chunk_sum, const double* d_chunk_sumsq, uint64_t n, double* d_sums, double* sums_mirror,
+                                const RecoveryPolicy* policy) {
+  NormFinalize f{};
+  f.chunk_sum = d_chunk_sum;
+  f.chunk_sumsq = d_chunk_sumsq;
+  f.chunks = num_chunks(n);
+  f.d_sums = d_sums;
+  f.sums_mirror = sums_mirror;
+  f.n = n;
+  if (policy) {
+    f.policy = 1;
+    f.alpha_slow = policy->alpha_slow;
+    f.alpha_fast = policy->alpha_fast;
+    f.resampling = policy->resampling;
+    f.d_policy = policy->d_policy;
+    f.policy_mirror = policy->host_mirror;
+  }
+  return f;
+}
+}  // namespace
+
+void launch_norm_finalize(hipStream_t st, const double* d_chunk_sum, const double* d_chunk_sumsq, uint64_t n, double* d_sums,
+                          double* sums_mirror, const RecoveryPolicy* policy) {
+  hipLaunchKernelGGL(k_norm_finalize, dim3(1), dim3(kBlock), 0, st,
+                     make_norm_finalize(d_chunk_sum, d_chunk_sumsq, n, d_sums, sums_mirror, policy));
 }
 
 void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
-                double* d_total, double* tree_levels, const double* known_chunk_sum) {
+                double* d_total, double* tree_levels, const double* known_chunk_sum, const double* finalize_sumsq, double* finalize_sums,
+                double* finalize_mirror, const RecoveryPolicy* policy) {
   const uint32_t chunks = num_chunks(n);
   if (!chunks) return;
   const double* sums = known_chunk_sum;
@@ -2148,32 +2317,47 @@ void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum
   if (!replay)
     hipLaunchKernelGGL(k_scan_chunks<double>, dim3(1), dim3(kBlock), 0, st, sums, chunks, d_chunk_offset,
                        static_cast<double*>(nullptr), static_cast<const double*>(nullptr));
+  NormFinalize fin{};
+  if (finalize_sums) fin = make_norm_finalize(sums, finalize_sumsq, n, finalize_sums, finalize_mirror, policy);
   hipLaunchKernelGGL(k_cdf, dim3(chunks), dim3(kBlock), 0, st, w, n, d_chunk_offset, cdf, d_total,
-                     make_cdf_tree(cdf, tree_levels, n), tree_levels, replay ? sums : static_cast<const double*>(nullptr), chunks);
+                     make_cdf_tree(cdf, tree_levels, n), tree_levels, replay ? sums : static_cast<const double*>(nullptr), chunks, fin);
 }
+
+namespace {
+// Which sampled levels of the search tree the draw kernel stages in LDS: all from `first` on, as many as fit.
+void draw_staging(const CdfTree& t, int& first, uint32_t& doubles) {
+  first = t.depth;
+  doubles = 0;
+  while (first > 0 && doubles + t.size[first - 1] <= kDrawStageMax) {
+    --first;
+    doubles += t.size[first];
+  }
+}
+}  // namespace
 
 void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst,
                           ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes) {
   if (a.count == 0) return;
-  hipLaunchKernelGGL(k_resample_draw<false>, dim3(blocks_for(a.count)), dim3(kBlock), 0, st, src, cdf, d_total, dst, a, g, fc, hp,
-                     d_hashes, 0.0, 0.0, static_cast<double*>(nullptr), 0u);
+  int first;
+  uint32_t doubles;
+  draw_staging(cdf, first, doubles);
+  const unsigned blocks = static_cast<unsigned>((a.count + kDrawBlock - 1) / kDrawBlock);
+  hipLaunchKernelGGL(k_resample_draw<false>, dim3(blocks), dim3(kDrawBlock), doubles * sizeof(double), st, src, cdf, d_total, dst, a, g,
+                     fc, hp, d_hashes, 0.0, 0.0, static_cast<double*>(nullptr), 0u, first, doubles);
 }
 
-// The draw plus the estimate sums of the set it produces: d_partials needs 9 * ceil(count / 256) doubles.
+// The draw plus the estimate sums of the set it produces: d_partials needs 9 * ceil(count / 1024) doubles.
 void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst, ResampleArgs a,
                                        GridView g, FreeCells fc, HashParams hp, double pivot_x, double pivot_y, double* d_partials,
                                        double* d_sums, double* host_mirror) {
-  const uint32_t blocks = blocks_for(a.count);
+  int first;
+  uint32_t doubles;
+  draw_staging(cdf, first, doubles);
+  const unsigned blocks = static_cast<unsigned>((a.count + kDrawBlock - 1) / kDrawBlock);
   if (blocks)
-    hipLaunchKernelGGL(k_resample_draw<true>, dim3(blocks), dim3(kBlock), 0, st, src, cdf, d_total, dst, a, g, fc, hp,
-                       static_cast<unsigned long long*>(nullptr), pivot_x, pivot_y, d_partials, blocks);
-  hipLaunchKernelGGL(k_final_sum<9>, dim3(1), dim3(kBlock), 0, st, d_partials, blocks, blocks, d_sums, host_mirror);
-}
-
-void launch_recovery_policy(hipStream_t st, const double* d_norm_sum, uint64_t n, double alpha_slow, double alpha_fast, int resampling,
-                            double* d_policy, double* host_mirror) {
-  hipLaunchKernelGGL(k_recovery_policy, dim3(1), dim3(64), 0, st, d_norm_sum, n, alpha_slow, alpha_fast, resampling, d_policy,
-                     host_mirror);
+    hipLaunchKernelGGL(k_resample_draw<true>, dim3(blocks), dim3(kDrawBlock), doubles * sizeof(double), st, src, cdf, d_total, dst, a, g,
+                       fc, hp, static_cast<unsigned long long*>(nullptr), pivot_x, pivot_y, d_partials, blocks, first, doubles);
+  hipLaunchKernelGGL(k_final_rows, dim3(9), dim3(kBlock), 0, st, d_partials, blocks, blocks, d_sums, host_mirror);
 }
 
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
@@ -2246,7 +2430,7 @@ void launch_estimate_sums(hipStream_t st, Particles p, uint64_t n, double pivot_
                           double* d_out, double* host_mirror) {
   const uint32_t chunks = num_chunks(n);
   if (chunks) hipLaunchKernelGGL(k_estimate_partials, dim3(chunks), dim3(kBlock), 0, st, p, n, pivot_x, pivot_y, d_partials, chunks);
-  hipLaunchKernelGGL(k_final_sum<kEstK>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror);
+  hipLaunchKernelGGL(k_final_rows, dim3(kEstK), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror);
 }
 
 void launch_cluster_cells(hipStream_t st, Particles p, uint64_t n, HashParams hp, unsigned long long* d_hashes,
@@ -2273,7 +2457,7 @@ void launch_estimate_sums_cluster(hipStream_t st, Particles p, uint64_t n, const
   if (chunks)
     hipLaunchKernelGGL(k_estimate_partials_cluster, dim3(chunks), dim3(kBlock), 0, st, p, n, d_hashes, t, wanted, pivot_x, pivot_y,
                        d_partials, chunks);
-  hipLaunchKernelGGL(k_final_sum<kEstK>, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror);
+  hipLaunchKernelGGL(k_final_rows, dim3(kEstK), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror);
 }
 
 void launch_init_normal(hipStream_t st, Particles p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,
@@ -2281,6 +2465,11 @@ void launch_init_normal(hipStream_t st, Particles p, uint64_t n, const double me
   if (n == 0) return;
   hipLaunchKernelGGL(k_init_normal, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, mean[0], mean[1], mean[2], T[0], T[1], T[2],
                      T[3], T[4], T[5], T[6], T[7], T[8], seed, index_offset);
+}
+
+void launch_init_from_map(hipStream_t st, Particles p, uint64_t n, uint64_t seed, uint64_t index_offset, GridView g, FreeCells fc) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_init_from_map, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, seed, index_offset, g, fc);
 }
 
 void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube, int prob) {

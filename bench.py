@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--windows", type=int, default=5, help="repeated timing windows of --steps cycles behind the timed region")
+    ap.add_argument("--stage-steps", type=int, default=6, help="cycles of the per-stage breakdown pass")
     ap.add_argument("--sharded", action="store_true", help="use the sharded driver even with one GPU (measures its overhead)")
     args = ap.parse_args()
 
@@ -143,7 +145,7 @@ def main():
         dist.barrier()
     from beluga_amd.amcl import AmclParams, DifferentialDriveModelParam, LikelihoodFieldModelParam, OccupancyGrid, se2_from_xytheta
 
-    steps_total = args.warmup + args.steps
+    steps_total = args.warmup + args.steps * (1 + args.windows) + args.stage_steps
     cells, truth, odoms, scans = make_workload(steps_total)
     grid = OccupancyGrid(cells, RESOLUTION, origin=se2_from_xytheta(ORIGIN[0], ORIGIN[1], 0.0))
     n_local = args.particles
@@ -168,11 +170,13 @@ def main():
     controls = [se2_from_xytheta(*o) for o in odoms]
     for c in range(args.warmup):
         assert filt.update(controls[c], scans[c]) is not None
-    filt.profile_enable(True)
+    # Timed region: exactly `steps` update cycles.  Only the dominant kernel carries HIP events here (two records per cycle:
+    # an event record costs ~5 us of stream time); the per-stage breakdown comes from a separate pass below.
+    filt.profile_enable(1)
     filt.profile_read(reset=True)
     sync_all()
     t0 = time.perf_counter()
-    for c in range(args.warmup, steps_total):
+    for c in range(args.warmup, args.warmup + args.steps):
         est = filt.update(controls[c], scans[c])
         assert est is not None
     sync_all()
@@ -181,7 +185,28 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    prof = filt.profile_read(reset=False)
+    prof = filt.profile_read(reset=True)
+    # Repeated windows of the same length right behind the timed region (same filter, the trajectory continues): the spread
+    # says how much a single 20-step sample can be trusted.
+    window_rates = []
+    c = args.warmup + args.steps
+    for _ in range(args.windows):
+        sync_all()
+        w0 = time.perf_counter()
+        for _k in range(args.steps):
+            assert filt.update(controls[c], scans[c]) is not None
+            c += 1
+        sync_all()
+        window_rates.append(args.steps / (time.perf_counter() - w0))
+    # Per-stage breakdown (events around every stage; these cycles run ~40 us slower and are not part of any rate above).
+    filt.profile_enable(2)
+    filt.profile_read(reset=True)
+    for _k in range(args.stage_steps):
+        assert filt.update(controls[c], scans[c]) is not None
+        c += 1
+    sync_all()
+    stage_prof = filt.profile_read(reset=True)
+    filt.profile_enable(0)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -216,7 +241,11 @@ def main():
                 "global_cycles_per_s": args.steps / elapsed,
                 "unit_of_work": "one update cycle of 1M particles x 1080 beams; a global cycle over N GPUs = N units",
             },
-            "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in prof.items()},
+            "timed_region_s": elapsed,
+            "repeat_windows": {"steps_each": args.steps, "cycles_per_s": window_rates,
+                               "min": min(window_rates) if window_rates else None,
+                               "median": float(np.median(window_rates)) if window_rates else None},
+            "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in stage_prof.items()},
             "roofline": {
                 "kernel": "k_reweight_lf_palette (likelihood-field reweight)",
                 "bound": "hbm",

@@ -40,7 +40,8 @@ enum {
   MCL_ERR_OUT_OF_MEMORY = -3,
   MCL_ERR_NOT_READY = -4,      /* no map / no particles yet */
   MCL_ERR_BAD_COVARIANCE = -5, /* std::runtime_error of multivariate_normal_distribution.hpp:114-124 */
-  MCL_ERR_NO_DEVICE = -6
+  MCL_ERR_NO_DEVICE = -6,
+  MCL_ERR_UNSUPPORTED = -7     /* std::runtime_error "The current sensor model does not support likelihood field" (beluga_ros/amcl.hpp:154,174) */
 };
 
 /* LikelihoodFieldModel (sensor/likelihood_field_model.hpp), BeamSensorModel (sensor/beam_model.hpp),
@@ -129,12 +130,23 @@ mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32
                        const double origin[4], const int8_t value_traits[3]);
 /* LikelihoodFieldModelBase::likelihood_field() (likelihood_field_model_base.hpp:102). out: H*W floats. */
 mcl_status mcl_get_likelihood_field(mcl_ctx* ctx, float* out);
+/* beluga_ros::Amcl::has_likelihood_field() (beluga_ros/include/beluga_ros/amcl.hpp:181-188): 1 for the two likelihood-field
+ * models, 0 for the beam model. */
+mcl_status mcl_has_likelihood_field(const mcl_ctx* ctx, int32_t* has);
+/* beluga_ros::Amcl::likelihood_field_origin() (amcl.hpp:161-178; likelihood_field_model_base.hpp:105): the field's origin
+ * in world coordinates as (cos, sin, x, y).  MCL_ERR_UNSUPPORTED for the beam model (the reference throws). */
+mcl_status mcl_get_likelihood_field_origin(mcl_ctx* ctx, double origin[4]);
 /* Replace the device field with a caller-built one (same W,H as the current map). */
 mcl_status mcl_set_likelihood_field(mcl_ctx* ctx, const float* field);
 
 /* Amcl::initialize(pose, covariance) (amcl_core.hpp:145-147): max_particles samples of
  * N(mean_xytheta, cov[3x3 row-major]) with weight 1; sets force_update. */
 mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], const double cov[9]);
+/* beluga_ros::Amcl::initialize_from_map() (beluga_ros/include/beluga_ros/amcl.hpp:209, called at
+ * beluga_amcl/src/amcl_node.cpp:716): max_particles draws of MultivariateUniformDistribution<SE2d, OccupancyGrid>
+ * (random/multivariate_uniform_distribution.hpp:126-161: the centre of a uniformly chosen free cell in the world frame,
+ * uniform heading), weight 1; sets force_update.  Drawn on the device from the counter-based stream (step 0). */
+mcl_status mcl_initialize_from_map(mcl_ctx* ctx);
 /* Amcl::initialize(distribution) with caller-drawn states (amcl_core.hpp:131-137); n <= capacity. */
 mcl_status mcl_set_particles(mcl_ctx* ctx, const double* states, const double* weights, uint64_t n);
 /* Amcl::particles() (amcl_core.hpp:127). */
@@ -180,6 +192,13 @@ mcl_status mcl_prepare_laser_scan(const mcl_laser_scan* scan, double* points_xy,
 /* mcl_prepare_laser_scan followed by mcl_update: beluga_ros::Amcl::update(base_pose_in_odom, laser_scan). */
 mcl_status mcl_update_laser_scan(mcl_ctx* ctx, const double control_pose[4], const mcl_laser_scan* scan, mcl_estimate* estimate,
                                  mcl_update_info* info);
+
+/* beluga_ros::Amcl::update(base_pose_in_odom, SparsePointCloud3f) (beluga_ros/src/amcl.cpp:67-81): every point of the
+ * cloud (float x, y, z in the sensor frame) is moved into the base frame with the sensor origin `origin_se3` =
+ * Sophus::SE3d::data() = (qx, qy, qz, qw, tx, ty, tz) in double precision and projected onto z = 0. */
+mcl_status mcl_project_point_cloud(const float* points_xyz, uint64_t num_points, const double origin_se3[7], double* points_xy);
+mcl_status mcl_update_point_cloud(mcl_ctx* ctx, const double control_pose[4], const float* points_xyz, uint64_t num_points,
+                                  const double origin_se3[7], mcl_estimate* estimate, mcl_update_info* info);
 
 /* ---- Stage-level entry points (what update() composes; used by parity tests and by the
  * multi-GPU driver, which interleaves collectives between them). -------------------------------- */
@@ -303,12 +322,28 @@ enum {
   MCL_STAGE_SENSOR_KERNEL = 5, /* the sensor-model kernel alone (inside MCL_STAGE_REWEIGHT) */
   MCL_NUM_STAGES = 6
 };
+/* on: 0 = off, 1 = the sensor kernel of every 4th cycle only, 2 = every stage of every cycle (each event record costs ~5 us
+ * of stream time, so timed runs use 1). */
 mcl_status mcl_profile_enable(mcl_ctx* ctx, int32_t on);
 /* Accumulated milliseconds and launch counts per stage since the last reset. */
 mcl_status mcl_profile_read(mcl_ctx* ctx, double ms[MCL_NUM_STAGES], uint64_t counts[MCL_NUM_STAGES], int32_t reset);
 
 /* Beam model only: grid cells visited by the ray walks since the last reset (cells/s). */
 mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
+
+/* ---- Switches and hooks for A/B measurements and tests; no option changes a result. ---------------------------
+ * Options (defaults in parentheses; BELUGA_MCL_<NAME> in the environment sets the default at mcl_create):
+ *   lf_variant (2)  likelihood-field kernel family: 2 = spatially ordered lanes, 1 = lane per particle, 0 = wave per particle
+ *   lf_fast (-1)    FMA variant with exact fallback: nonzero = whenever its preconditions hold, 0 = never
+ *   lf_table (0)    1 = force the 8-byte table instead of the palette
+ *   device_policy (1)  recovery estimator on the device when the cycle takes no host-side decision
+ *   sort_min_particles (16384)  below this many particles the spatial ordering is skipped
+ * Counters: lf_fast_launches = launches of the FMA variant so far. */
+mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value);
+mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value);
+/* Runs the spatial ordering on the current set and returns it: perm[t] = particle at position t, keys[i] = ordering key
+ * of particle i (n entries each, host memory).  keys[perm[t]] is non-decreasing in t. */
+mcl_status mcl_debug_order(mcl_ctx* ctx, uint32_t* perm, uint32_t* keys);
 
 const char* mcl_version(void);
 

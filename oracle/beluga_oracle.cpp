@@ -1355,6 +1355,20 @@ int orc_amcl_init_normal(void* h, const double mean_xytheta[3], const double cov
   a->force_update = true;
   return 1;
 }
+// beluga_ros::Amcl::initialize_from_map (beluga_ros/include/beluga_ros/amcl.hpp:191-198,209): take_exactly(max_particles)
+// draws of MultivariateUniformDistribution over the free cells (random/multivariate_uniform_distribution.hpp:126-161),
+// weight 1 (particle_traits.hpp:92-107).  Particle i takes the stream's (step 0, index i) random state.
+int orc_amcl_init_from_map(void* h) {
+  auto* a = static_cast<Amcl*>(h);
+  const uint64_t n_free = a->free_xy.size() / 2;
+  if (n_free == 0) return 0;  // the reference asserts !free_states_.empty()
+  const uint64_t n = a->cfg.max_particles;
+  a->states.resize(4 * n);
+  a->weights.assign(n, 1.0);
+  for (uint64_t i = 0; i < n; ++i) se2_store(random_state(a->free_xy.data(), n_free, a->cfg.seed, 0, i), a->states.data() + 4 * i);
+  a->force_update = true;
+  return 1;
+}
 void orc_amcl_force_update(void* h) { static_cast<Amcl*>(h)->force_update = true; }
 void orc_amcl_stage_times(void* h, double out[5]) { std::memcpy(out, static_cast<Amcl*>(h)->t_stage, sizeof(double) * 5); }
 int64_t orc_amcl_beam_steps(void* h) { return static_cast<Amcl*>(h)->beam_steps; }
@@ -1510,6 +1524,21 @@ uint64_t orc_prepare_laser_scan(const float* ranges, uint64_t n, float angle_min
     ++m;
   }
   return m;
+}
+
+// beluga_ros::Amcl::update(pose, SparsePointCloud3f) (beluga_ros/src/amcl.cpp:67-81): origin * p.cast<double>(), x and y kept.
+void orc_project_point_cloud(const float* xyz, uint64_t n, const double origin_se3[7], double* out_xy) {
+  const double qx = origin_se3[0], qy = origin_se3[1], qz = origin_se3[2], qw = origin_se3[3];
+  for (uint64_t i = 0; i < n; ++i) {
+    const double px = static_cast<double>(xyz[3 * i]), py = static_cast<double>(xyz[3 * i + 1]), pz = static_cast<double>(xyz[3 * i + 2]);
+    // Sophus SO3 * point: uv = 2 * (q.vec x p); p + q.w * uv + q.vec x uv   (so3.hpp operator*)
+    double ux = qy * pz - qz * py, uy = qz * px - qx * pz, uz = qx * py - qy * px;
+    ux += ux;
+    uy += uy;
+    uz += uz;
+    out_xy[2 * i] = (px + qw * ux + (qy * uz - qz * uy)) + origin_se3[4];
+    out_xy[2 * i + 1] = (py + qw * uy + (qz * ux - qx * uz)) + origin_se3[5];
+  }
 }
 
 int orc_max_threads() {

@@ -87,7 +87,7 @@ def lib():
         L.orc_amcl_beam_steps.restype = C.c_int64
         for name in (
             "orc_amcl_destroy", "orc_amcl_set_map", "orc_amcl_set_field", "orc_amcl_get_field", "orc_amcl_num_free",
-            "orc_amcl_set_particles", "orc_amcl_num_particles", "orc_amcl_get_particles", "orc_amcl_init_normal",
+            "orc_amcl_set_particles", "orc_amcl_num_particles", "orc_amcl_get_particles", "orc_amcl_init_normal", "orc_amcl_init_from_map",
             "orc_amcl_force_update", "orc_amcl_stage_times", "orc_amcl_beam_steps", "orc_amcl_update",
         ):
             getattr(L, name).argtypes = None
@@ -425,6 +425,11 @@ class Amcl:
         if not lib().orc_amcl_init_normal(self._h, _d(m), _d(cv)):
             raise RuntimeError("Invalid covariance matrix")
 
+    def initialize_from_map(self):
+        """beluga_ros::Amcl::initialize_from_map() (beluga_ros/include/beluga_ros/amcl.hpp:209)."""
+        if not lib().orc_amcl_init_from_map(self._h):
+            raise RuntimeError("the map has no free cell")
+
     def force_update(self):
         lib().orc_amcl_force_update(self._h)
 
@@ -471,3 +476,12 @@ def prepare_laser_scan(ranges, angle_min, angle_increment, range_min, range_max,
 
 def max_threads():
     return lib().orc_max_threads()
+
+
+def project_point_cloud(points_xyz, origin_se3=(0, 0, 0, 1, 0, 0, 0)):
+    """beluga_ros::Amcl::update(pose, SparsePointCloud3f)'s measurement (beluga_ros/src/amcl.cpp:73-76)."""
+    pts = np.ascontiguousarray(points_xyz, dtype=np.float32).reshape(-1, 3)
+    origin = _dbl(origin_se3)
+    out = np.zeros((len(pts), 2))
+    lib().orc_project_point_cloud(pts.ctypes.data_as(c_float_p), C.c_uint64(len(pts)), _d(origin), _d(out))
+    return out

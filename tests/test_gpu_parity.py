@@ -108,9 +108,8 @@ def test_reference_golden_weights_through_the_c_abi():
 
 @pytest.mark.parametrize("variant", ["0", "1", "2"])
 @pytest.mark.parametrize("beams", [1, 63, 64, 65, 180, 1080])
-def test_reweight_lf_matches_oracle(variant, beams, monkeypatch):
-    """All three kernel variants (wave per particle / lane per particle / binned lanes = the default)."""
-    monkeypatch.setenv("BELUGA_MCL_LF_VARIANT", variant)
+def test_reweight_lf_matches_oracle(variant, beams):
+    """All three kernel variants (wave per particle / lane per particle / spatially ordered lanes = the default)."""
     grid = rooms_grid()
     truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=2, clearance_cells=6)
     pts = make_scan(grid, truth, beams, max_range=12.0)
@@ -121,6 +120,7 @@ def test_reweight_lf_matches_oracle(variant, beams, monkeypatch):
     states[:8, 2] += 100.0  # some particles far outside the map: every beam out of grid
     w0 = np.random.Generator(np.random.MT19937(3)).uniform(0.5, 1.5, n)
     f = new_filter(grid, n)
+    f.set_option("lf_variant", int(variant))
     f.set_particles(states, w0)
     f.reweight(pts)
     _, got = f.particles()
@@ -334,10 +334,13 @@ def test_initialize_matches_oracle_and_rejects_bad_covariance():
     f.close()
 
 
-def _run_both(grid, params, sensor, sensor_oracle_kw, cycles, beams, max_range, seed=21, init_sigma=(0.5, 0.5, 0.2), kidnap_at=None):
+def _run_both(grid, params, sensor, sensor_oracle_kw, cycles, beams, max_range, seed=21, init_sigma=(0.5, 0.5, 0.2), kidnap_at=None,
+              options=None, from_map=False):
     origin_xy = (grid.origin[2], grid.origin[3])
     truth = synth.find_free_pose(grid.cells, grid.resolution, origin_xy, seed=4, clearance_cells=8)
     gpu = Amcl(grid, MOTION, sensor, params, seed=seed)
+    for name, value in (options or {}).items():
+        gpu.set_option(name, value)
     cpu = orc.Amcl(update_min_d=params.update_min_d, update_min_a=params.update_min_a, resample_interval=params.resample_interval,
                    selective_resampling=params.selective_resampling, min_particles=params.min_particles,
                    max_particles=params.max_particles, alpha_slow=params.alpha_slow, alpha_fast=params.alpha_fast,
@@ -346,8 +349,12 @@ def _run_both(grid, params, sensor, sensor_oracle_kw, cycles, beams, max_range, 
                    alphas=MOTION_T, seed=seed, **sensor_oracle_kw)
     cpu.set_map(grid.cells, grid.resolution, grid.origin)
     cov = np.diag([s * s for s in init_sigma])
-    gpu.initialize(truth, cov)
-    cpu.initialize(truth, cov)
+    if from_map:
+        gpu.initialize_from_map()
+        cpu.initialize_from_map()
+    else:
+        gpu.initialize(truth, cov)
+        cpu.initialize(truth, cov)
     results = []
     pose = truth
     odom = (0.0, 0.0, 0.0)
@@ -390,14 +397,14 @@ def test_update_cycle_end_to_end_fixed_size():
 
 
 @pytest.mark.parametrize("device_policy", ["1", "0"])
-def test_update_cycle_recovery_injection_fixed_size(device_policy, monkeypatch):
+def test_update_cycle_recovery_injection_fixed_size(device_policy):
     """Fixed N, no selective resampling: the recovery estimator (thrun_recovery_probability_estimator.hpp:69-89) runs on
-    the device and the cycle synchronises once (BELUGA_MCL_DEVICE_POLICY=0: on the host).  A kidnapped robot makes the fast
+    the device and the cycle synchronises once (option device_policy = 0: on the host).  A kidnapped robot makes the fast
     average drop below the slow one: random states are injected; probabilities, decisions and particles follow the oracle."""
-    monkeypatch.setenv("BELUGA_MCL_DEVICE_POLICY", device_policy)
     grid = rooms_grid(400, 3)
     params = AmclParams(min_particles=20_000, max_particles=20_000, alpha_slow=0.001, alpha_fast=0.1)
-    gpu, cpu, results, truth = _run_both(grid, params, LF, dict(lf=LF_T, lf_model_unknown_space=True), 12, 180, 12.0, kidnap_at=5)
+    gpu, cpu, results, truth = _run_both(grid, params, LF, dict(lf=LF_T, lf_model_unknown_space=True), 12, 180, 12.0, kidnap_at=5,
+                                         options={"device_policy": int(device_policy)})
     injected = 0
     for c, (gp, gc), (op, oc), gi, oi in results:
         assert gi["random_state_probability"] == pytest.approx(oi["random_state_probability"], abs=1e-12), f"cycle {c}"
@@ -698,13 +705,11 @@ def test_cluster_based_estimate_bimodal_cloud_and_update_path():
 # ---- the two table forms of the default kernel ---------------------------------------------------------------------
 @pytest.mark.parametrize("table", ["palette", "cube"])
 @pytest.mark.parametrize("field_kind", ["distance_map", "arbitrary"])
-def test_reweight_lf_table_forms_match_oracle(table, field_kind, monkeypatch):
+def test_reweight_lf_table_forms_match_oracle(table, field_kind):
     """The hot kernel reads the field through a palette (2-byte index per cell + exact f64 values in LDS) when the field
     has few distinct values, and through an 8-byte table otherwise (an arbitrary field pushed through
     mcl_set_likelihood_field has millions).  Both must give the reference's weights, including for beams that end far
     outside the grid (clamped to the border tiles / the table's "unknown" slot) and right on its edges."""
-    if table == "cube":
-        monkeypatch.setenv("BELUGA_MCL_LF_TABLE", "cube")
     grid = rooms_grid()
     truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=2, clearance_cells=6)
     pts = make_scan(grid, truth, 200, max_range=12.0)
@@ -718,6 +723,7 @@ def test_reweight_lf_table_forms_match_oracle(table, field_kind, monkeypatch):
     states[4:8, 2] += 100.0
     w0 = np.random.Generator(np.random.MT19937(3)).uniform(0.5, 1.5, n)
     f = new_filter(grid, n)
+    f.set_option("lf_table", 1 if table == "cube" else 0)
     if field_kind == "arbitrary":
         rng = np.random.Generator(np.random.MT19937(9))
         f.set_likelihood_field(rng.uniform(0.01, 1.2, size=grid.cells.shape).astype(np.float32))
@@ -808,13 +814,13 @@ def test_update_cycles_are_bitwise_reproducible():
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
-@pytest.mark.parametrize("fast", ["1", "0"])
-def test_reweight_lf_fma_variant_is_bit_identical(fast, monkeypatch):
-    """The dense-set variant of the LF kernel evaluates beam end-points with FMAs and falls back to the separately rounded
+@pytest.mark.parametrize("fast", [1, 0])
+def test_reweight_lf_fma_variant_is_bit_identical(fast):
+    """The default variant of the LF kernel evaluates beam end-points with FMAs and falls back to the separately rounded
     evaluation whenever the two could disagree on the cell (end-point within 2^-33 of a cell boundary) or a particle is too
-    far away for the error bound.  Forced on here at a small size; a power-of-two resolution puts many end-points exactly
-    on cell boundaries (the fallback's trigger), some particles sit 10^6 cells away, some beams end far outside the map."""
-    monkeypatch.setenv("BELUGA_MCL_LF_FAST", fast)
+    far away for the error bound.  A power-of-two resolution puts many end-points exactly on cell boundaries (the
+    fallback's trigger), some particles sit 10^6 cells away, some beams end far outside the map.  Option lf_fast = 0 runs
+    the separately rounded kernel on the same input; the counter says which one ran."""
     cells = synth.make_rooms_map(512, 512, seed=5, n_rooms=14)
     res = 0.0625
     grid = OccupancyGrid(cells=cells, resolution=res, origin=se2_from_xytheta(-16.0, -16.0, 0.0))
@@ -829,9 +835,147 @@ def test_reweight_lf_fma_variant_is_bit_identical(fast, monkeypatch):
     states[2000:2004, 2] += 1e5                                        # beyond the fast path's range
     w0 = np.random.Generator(np.random.MT19937(3)).uniform(0.5, 1.5, n)
     f = new_filter(grid, n)
+    f.set_option("lf_fast", fast)
     f.set_particles(states, w0)
     f.reweight(pts)
+    assert f.counter("lf_fast_launches") == (1 if fast else 0)
     _, got = f.particles()
     want = w0 * orc.lf_weights(f.likelihood_field(), res, grid.origin, LF.max_laser_distance, states, pts)
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+    f.close()
+
+
+def test_spatial_order_is_a_sorted_permutation():
+    """The ordering pass (two-pass radix sort of the 20-bit keys, the second pass stable): perm is a permutation and
+    keys[perm] is non-decreasing — with the key frame from the host's estimate, from a bounding-box pass (set_particles
+    leaves the host without an estimate), for ragged sizes, a point-mass cloud and a cloud spread over the whole map."""
+    grid = rooms_grid()
+    truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=2, clearance_cells=6)
+    for n, spread, via_initialize in [(20_001, (0.5, 0.5, 0.2), False), (100_000, (0.5, 0.5, 0.2), True), (65_536, (0.0, 0.0, 0.0), False),
+                                      (300_017, (8.0, 8.0, 3.0), False), (1_000_000, (0.4, 0.2, 0.15), True)]:
+        f = new_filter(grid, n)
+        if via_initialize:
+            f.initialize(truth, np.diag([max(s * s, 1e-6) for s in spread]))
+        else:
+            f.set_particles(synth.normal_particles(n, truth, spread, seed=5), np.ones(n))
+        perm, keys = f.debug_order()
+        assert np.array_equal(np.sort(perm), np.arange(n, dtype=np.uint32)), (n, spread)
+        assert keys.max() < (1 << 20)
+        ordered = keys[perm]
+        assert np.all(ordered[1:] >= ordered[:-1]), (n, spread)
+        if spread[0] > 0:
+            assert len(np.unique(keys)) > 1000  # the frame resolves the cloud
+        f.close()
+
+
+def test_initialize_from_map_matches_oracle_and_localises():
+    """beluga_ros::Amcl::initialize_from_map() (beluga_ros/include/beluga_ros/amcl.hpp:209): max_particles draws over the free
+    cells (random/multivariate_uniform_distribution.hpp:126-161).  Same stream on both sides: the sets are identical; every
+    state sits on a free cell centre; and a global localisation run from it follows the oracle cycle by cycle."""
+    grid = rooms_grid(400, 3)
+    n = 50_000
+    f = new_filter(grid, n)
+    o = orc.Amcl(min_particles=n, max_particles=n, alphas=MOTION_T, seed=11, lf=LF_T, lf_model_unknown_space=True)
+    o.set_map(grid.cells, grid.resolution, grid.origin)
+    f.initialize_from_map()
+    o.initialize_from_map()
+    gs, gw = f.particles()
+    os_, ow = o.particles()
+    assert len(gw) == n and np.all(gw == 1.0)
+    np.testing.assert_allclose(gs, os_, rtol=0, atol=1e-12)
+    ij = np.floor((gs[:, 2:] - np.array([grid.origin[2], grid.origin[3]])) / grid.resolution).astype(int)
+    assert np.all(grid.cells[ij[:, 1], ij[:, 0]] == 0)
+    np.testing.assert_allclose(np.hypot(gs[:, 0], gs[:, 1]), 1.0, atol=1e-15)
+    f.close()
+    params = AmclParams(min_particles=2_000, max_particles=60_000, selective_resampling=False)
+    gpu, cpu, results, truth = _run_both(grid, params, LF, dict(lf=LF_T, lf_model_unknown_space=True), 10, 180, 12.0, from_map=True)
+    assert len(results) >= 6
+    for c, g, o_, gi, ci in results:
+        np.testing.assert_allclose(g[0], o_[0], atol=1e-9, err_msg=f"cycle {c}")
+    gpu.close()
+
+
+def test_likelihood_field_accessors_and_point_cloud_update():
+    """beluga_ros::Amcl's likelihood_field_origin() / has_likelihood_field() (amcl.hpp:161-188: the beam model throws
+    std::runtime_error) and update(pose, SparsePointCloud3f) (beluga_ros/src/amcl.cpp:67-81): the projected points equal the
+    oracle's and the update equals the update with those points."""
+    from beluga_amd.amcl import project_point_cloud
+    grid = OccupancyGrid(cells=rooms_grid().cells, resolution=0.05, origin=se2_from_xytheta(-3.0, 2.0, 0.3))
+    f = new_filter(grid, 3000)
+    assert f.has_likelihood_field()
+    np.testing.assert_allclose(f.likelihood_field_origin(), grid.origin, atol=1e-15)
+    b = Amcl(grid, MOTION, BeamModelParam(beam_max_range=10.0), AmclParams(min_particles=100, max_particles=100), seed=1)
+    assert not b.has_likelihood_field()
+    with pytest.raises(RuntimeError, match="does not support likelihood field"):
+        b.likelihood_field_origin()
+    b.close()
+    rng = np.random.Generator(np.random.MT19937(4))
+    cloud = rng.uniform(-6, 6, size=(300, 3)).astype(np.float32)
+    origin = (0.0, 0.0, math.sin(0.2), math.cos(0.2), 0.1, -0.05, 0.3)
+    pts = project_point_cloud(cloud, origin)
+    assert np.array_equal(pts, orc.project_point_cloud(cloud, origin))
+    truth = (2.0, 7.0, 0.4)
+    g = new_filter(grid, 3000)
+    cov = np.diag([0.04, 0.04, 0.01])
+    f.initialize(truth, cov)
+    g.initialize(truth, cov)
+    a = f.update_point_cloud(se2_from_xytheta(0.3, 0.0, 0.0), cloud, origin)
+    b2 = g.update(se2_from_xytheta(0.3, 0.0, 0.0), pts)
+    assert a is not None and b2 is not None
+    assert np.array_equal(a[0], b2[0]) and np.array_equal(a[1], b2[1])
+    f.close()
+    g.close()
+
+
+def test_ten_million_particles_sampled_against_oracle():
+    """Config 3 shape at its full size, no switches: the kernel the library picks for a 10M-particle reweight on the 4000^2
+    map (the FMA variant: the counter says so) against the oracle on 1024 sampled particles, and take_while_kld's cut from a
+    10M-particle SOURCE set against the sequential oracle (an integer result: exact)."""
+    size = 4000
+    cells = synth.make_rooms_map(size, size, seed=42)
+    grid = OccupancyGrid(cells, 0.05, origin=se2_from_xytheta(-100.0, -100.0, 0.0))
+    truth = synth.find_free_pose(cells, 0.05, (-100.0, -100.0), seed=1)
+    pts = make_scan(grid, truth, 1080, max_range=30.0)
+    n = 10_000_000
+    f = Amcl(grid, MOTION, LF, AmclParams(min_particles=100_000, max_particles=n), seed=3)
+    states = synth.normal_particles(n, truth, (0.5, 0.5, 0.2), seed=9)
+    f.set_particles(states, np.ones(n))
+    f.reweight(pts)
+    assert f.counter("lf_fast_launches") == 1
+    w = f.particles()[1]
+    sample = np.random.Generator(np.random.MT19937(1)).choice(n, 1024, replace=False)
+    want = orc.lf_weights(f.likelihood_field(), 0.05, grid.origin, 100.0, states[sample], pts, threads=orc.max_threads())
+    np.testing.assert_allclose(w[sample], want, rtol=RTOL)
+    stats = f.normalize()
+    assert stats["norm_sum"] == pytest.approx(1.0, abs=1e-9)
+    m = f.resample(0.0, step=2)
+    wn = w / stats["sum"]
+    want_states, _ = orc.resample(states, wn, 100_000, n, 0.05, 3.0, (0.5, 0.5, math.radians(10)), 0.0, seed=3, step=2)
+    assert m == len(want_states)
+    got, gw = f.particles()
+    assert np.all(gw == 1.0)
+    flips = int(np.any(got != want_states, axis=1).sum())
+    assert flips <= 5, flips
+    f.close()
+
+
+def test_dispersed_cloud_1m_sampled_against_oracle():
+    """The worst case for the spatially ordered lanes: 1M particles from initialize_from_map on the 4000^2 map (global
+    localisation; neighbours in the order are metres and radians apart).  Same kernel, same results: a 1024-particle sample
+    against the oracle."""
+    size = 4000
+    cells = synth.make_rooms_map(size, size, seed=42)
+    grid = OccupancyGrid(cells, 0.05, origin=se2_from_xytheta(-100.0, -100.0, 0.0))
+    truth = synth.find_free_pose(cells, 0.05, (-100.0, -100.0), seed=1)
+    pts = make_scan(grid, truth, 1080, max_range=30.0)
+    n = 1_000_000
+    f = Amcl(grid, MOTION, LF, AmclParams(min_particles=n, max_particles=n), seed=3)
+    f.initialize_from_map()
+    states, w0 = f.particles()
+    assert np.all(w0 == 1.0)
+    f.reweight(pts)
+    w = f.particles()[1]
+    sample = np.random.Generator(np.random.MT19937(1)).choice(n, 1024, replace=False)
+    want = orc.lf_weights(f.likelihood_field(), 0.05, grid.origin, 100.0, states[sample], pts, threads=orc.max_threads())
+    np.testing.assert_allclose(w[sample], want, rtol=RTOL)
     f.close()

@@ -15,6 +15,12 @@ __global__ __launch_bounds__(256) void k(const uint16_t* table, uint32_t bytes, 
     case 3: base = (lane >> 1) * 128; break;                   // two lines per quad
     case 4: base = lane * 128; break;                          // one line per lane
     case 5: base = (lane >> 4) * 128 + (lane & 15) * 2; break; // four lines per wave
+    case 7: base = (lane & 3) * 128 + (lane >> 2) * 2; break;  // four lines per wave, interleaved lane by lane (64 runs)
+    case 8: base = (lane & 1) * 128 + (lane >> 1) * 2; break;  // two lines per wave, interleaved lane by lane
+    case 9: base = ((lane >> 2) & 3) * 128 + (lane & 3) * 2 + (lane >> 4) * 8; break;  // four lines, runs of 4 lanes (16 runs)
+    case 10: base = ((lane >> 3) & 3) * 128 + (lane & 7) * 2 + (lane >> 5) * 16; break;  // four lines, runs of 8 lanes (8 runs)
+    case 11: base = ((lane * 37) & 63) * 2; break;              // one line, permuted lanes
+    case 12: base = (lane & 3) * 64 + (lane >> 2) * 2; break;  // two lines as four 64-byte halves, interleaved lane by lane
     default: base = lane * 2; break;                           // 6: fully coalesced
   }
   uint32_t acc = 0, off = base + (threadIdx.x >> 6) * 8192;
@@ -31,8 +37,8 @@ int main() {
   uint16_t* t; uint32_t* o;
   hipMalloc(&t, 65536); hipMemset(t, 0, 65536); hipMalloc(&o, 256 * 4096 * 4);
   const int blocks = 256 * 8, iters = 2048;  // 8 waves per SIMD
-  const char* names[] = {"same address", "1 line/quad (same cell)", "1 line/quad (4 cells)", "2 lines/quad", "1 line/lane", "4 lines/wave", "coalesced"};
-  for (int p = 0; p < 7; ++p) {
+  const char* names[] = {"same address", "1 line/quad (same cell)", "1 line/quad (4 cells)", "2 lines/quad", "1 line/lane", "4 lines/wave", "coalesced", "4 lines interleaved", "2 lines interleaved", "4 lines runs of 4", "4 lines runs of 8", "1 line permuted", "4 half-lines interleaved"};
+  for (int p = 0; p < 13; ++p) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, t, 65536u, o, p, iters);
     hipEventRecord(e0);
