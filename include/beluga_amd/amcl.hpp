@@ -19,9 +19,14 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <execution>
+#include <iterator>
 #include <optional>
+#include <random>
 #include <stdexcept>
 #include <string>
+#include <tuple>
+#include <type_traits>
 #include <utility>
 #include <variant>
 #include <vector>
@@ -42,11 +47,13 @@ struct SE2d {
   double c{1.0}, s{0.0}, x{0.0}, y{0.0};
   SE2d() = default;
   SE2d(double theta, double tx, double ty) : c(std::cos(theta)), s(std::sin(theta)), x(tx), y(ty) {}
+  /// From any SE(2) type with Sophus::SE2d's interface (so2() + data() = cos, sin, x, y).
+  template <class T, class = decltype(std::declval<const T&>().so2()), class = decltype(std::declval<const T&>().data())>
+  SE2d(const T& other) : c(other.data()[0]), s(other.data()[1]), x(other.data()[2]), y(other.data()[3]) {}  // NOLINT
   [[nodiscard]] double angle() const { return std::atan2(s, c); }
   [[nodiscard]] const double* data() const { return &c; }
   [[nodiscard]] double* data() { return &c; }
 #ifdef BELUGA_AMD_HAS_SOPHUS
-  SE2d(const Sophus::SE2d& p) : c(p.data()[0]), s(p.data()[1]), x(p.data()[2]), y(p.data()[3]) {}  // NOLINT
   operator Sophus::SE2d() const {                                                                    // NOLINT
     Sophus::SE2d out;
     out.so2().data()[0] = c;
@@ -136,7 +143,9 @@ struct OccupancyGridView {
   SE2d origin{};
   std::int8_t free_value{0}, unknown_value{-1}, occupied_value{100};  ///< beluga_ros::OccupancyGrid::ValueTraits
 
-  /// Adapts a grid type with width()/height()/resolution()/origin()/data() whose cell type is int8.
+  /// Adapts a grid type with width()/height()/resolution()/origin()/data() whose cell type is int8.  The value traits are
+  /// the grid's own (`Grid::ValueTraits::kFreeValue / kUnknownValue / kOccupiedValue`, beluga_ros/occupancy_grid.hpp:48-64)
+  /// when it declares them, the ROS trinary interpretation 0 / -1 / 100 otherwise.
   template <class Grid>
   static OccupancyGridView from(const Grid& grid) {
     OccupancyGridView v;
@@ -144,13 +153,20 @@ struct OccupancyGridView {
     v.width = static_cast<std::uint32_t>(grid.width());
     v.height = static_cast<std::uint32_t>(grid.height());
     v.resolution = grid.resolution();
-    const auto& o = grid.origin();
-    v.origin.c = o.data()[0];
-    v.origin.s = o.data()[1];
-    v.origin.x = o.data()[2];
-    v.origin.y = o.data()[3];
+    v.origin = SE2d{grid.origin()};
+    read_traits<Grid>(v, 0);
     return v;
   }
+
+ private:
+  template <class Grid>
+  static auto read_traits(OccupancyGridView& v, int) -> decltype(Grid::ValueTraits::kFreeValue, void()) {
+    v.free_value = static_cast<std::int8_t>(Grid::ValueTraits::kFreeValue);
+    v.unknown_value = static_cast<std::int8_t>(Grid::ValueTraits::kUnknownValue);
+    v.occupied_value = static_cast<std::int8_t>(Grid::ValueTraits::kOccupiedValue);
+  }
+  template <class Grid>
+  static void read_traits(OccupancyGridView&, long) {}
 };
 
 /// What beluga_ros::LaserScan wraps (beluga_ros/include/beluga_ros/laser_scan.hpp:46-66): the sensor_msgs/LaserScan
@@ -165,12 +181,82 @@ struct LaserScan {
   double max_range{1.7976931348623157e308};
 };
 
-/// Host mirror of the particle set: what `beluga::TupleVector<std::tuple<SE2d, Weight>>` holds.
+/// Host mirror of the particle set: what `beluga::TupleVector<std::tuple<SE2d, Weight>>` holds.  A sized random-access range
+/// of (state, weight) tuples — `std::get<0>(p)` / `std::get<1>(p)` are what `beluga::state(p)` / `beluga::weight(p)` read
+/// (type_traits/particle_traits.hpp) — plus the two component ranges `beluga::views::states / weights` project.
 struct ParticleSet {
+  using value_type = std::tuple<SE2d, double>;
+  using reference = std::tuple<const SE2d&, const double&>;
   std::vector<SE2d> states;
   std::vector<double> weights;
+
+  class const_iterator {
+   public:
+    using iterator_category = std::random_access_iterator_tag;
+    using value_type = ParticleSet::value_type;
+    using difference_type = std::ptrdiff_t;
+    using pointer = void;
+    using reference = ParticleSet::reference;
+    const_iterator() = default;
+    const_iterator(const ParticleSet* set, std::size_t index) : set_(set), index_(index) {}
+    reference operator*() const { return reference{set_->states[index_], set_->weights[index_]}; }
+    reference operator[](difference_type k) const { return *(*this + k); }
+    const_iterator& operator++() { ++index_; return *this; }
+    const_iterator operator++(int) { auto old = *this; ++index_; return old; }
+    const_iterator& operator--() { --index_; return *this; }
+    const_iterator operator--(int) { auto old = *this; --index_; return old; }
+    const_iterator& operator+=(difference_type k) { index_ = static_cast<std::size_t>(static_cast<difference_type>(index_) + k); return *this; }
+    const_iterator& operator-=(difference_type k) { return *this += -k; }
+    friend const_iterator operator+(const_iterator it, difference_type k) { return it += k; }
+    friend const_iterator operator+(difference_type k, const_iterator it) { return it += k; }
+    friend const_iterator operator-(const_iterator it, difference_type k) { return it -= k; }
+    friend difference_type operator-(const const_iterator& a, const const_iterator& b) {
+      return static_cast<difference_type>(a.index_) - static_cast<difference_type>(b.index_);
+    }
+    friend bool operator==(const const_iterator& a, const const_iterator& b) { return a.index_ == b.index_; }
+    friend bool operator!=(const const_iterator& a, const const_iterator& b) { return a.index_ != b.index_; }
+    friend bool operator<(const const_iterator& a, const const_iterator& b) { return a.index_ < b.index_; }
+    friend bool operator>(const const_iterator& a, const const_iterator& b) { return a.index_ > b.index_; }
+    friend bool operator<=(const const_iterator& a, const const_iterator& b) { return a.index_ <= b.index_; }
+    friend bool operator>=(const const_iterator& a, const const_iterator& b) { return a.index_ >= b.index_; }
+
+   private:
+    const ParticleSet* set_{nullptr};
+    std::size_t index_{0};
+  };
+  using iterator = const_iterator;
+
   [[nodiscard]] std::size_t size() const { return weights.size(); }
   [[nodiscard]] bool empty() const { return weights.empty(); }
+  [[nodiscard]] const_iterator begin() const { return {this, 0}; }
+  [[nodiscard]] const_iterator end() const { return {this, size()}; }
+  [[nodiscard]] reference operator[](std::size_t i) const { return reference{states[i], weights[i]}; }
+};
+
+/// `beluga::views::states(particles)` / `beluga::views::weights(particles)` for the host mirror (views/particles.hpp).
+namespace views {
+inline const std::vector<SE2d>& states(const ParticleSet& particles) { return particles.states; }
+inline const std::vector<double>& weights(const ParticleSet& particles) { return particles.weights; }
+}  // namespace views
+
+/// What `likelihood_field()` returns: the accessors of `beluga::ValueGrid2<float>` (sensor/data/value_grid.hpp:36-69) that
+/// `beluga_ros::assign_likelihood_field` reads (beluga_ros/include/beluga_ros/likelihood_field.hpp:31-66).
+template <class T>
+class ValueGrid2 {
+ public:
+  ValueGrid2() = default;
+  ValueGrid2(std::vector<T> data, std::size_t width, double resolution) : data_(std::move(data)), width_(width), resolution_(resolution) {}
+  [[nodiscard]] std::size_t size() const { return data_.size(); }
+  [[nodiscard]] const std::vector<T>& data() const { return data_; }
+  [[nodiscard]] std::size_t width() const { return width_; }
+  [[nodiscard]] std::size_t height() const { return width_ ? data_.size() / width_ : 0; }
+  [[nodiscard]] double resolution() const { return resolution_; }
+  [[nodiscard]] const T& operator[](std::size_t i) const { return data_[i]; }
+
+ private:
+  std::vector<T> data_;
+  std::size_t width_{0};
+  double resolution_{1.0};
 };
 
 class Amcl {
@@ -224,6 +310,7 @@ class Amcl {
       cfg.sensor_kind = MCL_SENSOR_BEAM;
       cfg.beam = mcl_beam_params{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range};
     }
+    max_particles_ = params.max_particles;
     const mcl_status st = mcl_create(&cfg, &ctx_);
     if (st != MCL_OK) throw std::runtime_error(std::string("beluga_amd::Amcl: ") + mcl_last_error(nullptr));
     try {
@@ -236,7 +323,15 @@ class Amcl {
   }
   Amcl(const Amcl&) = delete;
   Amcl& operator=(const Amcl&) = delete;
-  Amcl(Amcl&& other) noexcept : ctx_(other.ctx_), width_(other.width_), height_(other.height_) { other.ctx_ = nullptr; }
+  Amcl(Amcl&& other) noexcept
+      : ctx_(other.ctx_),
+        width_(other.width_),
+        height_(other.height_),
+        max_particles_(other.max_particles_),
+        resolution_(other.resolution_),
+        has_field_(other.has_field_) {
+    other.ctx_ = nullptr;
+  }
   ~Amcl() { mcl_destroy(ctx_); }
 
   /// Returns a reference to the current set of particles (amcl_core.hpp:127). Downloaded lazily.
@@ -275,7 +370,11 @@ class Amcl {
     check(mcl_set_map(ctx_, map.cells, map.width, map.height, map.resolution, map.origin.data(), traits));
     width_ = map.width;
     height_ = map.height;
-    field_.clear();
+    resolution_ = map.resolution;
+    std::int32_t has = 0;
+    check(mcl_has_likelihood_field(ctx_, &has));
+    has_field_ = has != 0;
+    field_.reset();
   }
 
   /// Update particles based on motion and sensor information (amcl_core.hpp:165-201).
@@ -350,16 +449,51 @@ class Amcl {
   /// beluga::estimate, as beluga::Amcl does (amcl_core.hpp:200).
   void use_cluster_based_estimate(bool enable) { check(mcl_set_estimate_kind(ctx_, enable ? 1 : 0, nullptr)); }
 
-  /// LikelihoodFieldModelBase::likelihood_field() (likelihood_field_model_base.hpp:102), row-major height x width.
-  [[nodiscard]] const std::vector<float>& likelihood_field() const {
-    if (field_.empty()) {
-      field_.resize(static_cast<std::size_t>(width_) * height_);
-      check(mcl_get_likelihood_field(ctx_, field_.data()));
+  /// beluga_ros::Amcl::likelihood_field() (beluga_ros/include/beluga_ros/amcl.hpp:141-158;
+  /// LikelihoodFieldModelBase::likelihood_field(), likelihood_field_model_base.hpp:102), row-major height x width.
+  /// \throw std::runtime_error If the sensor model has no likelihood field (the beam model).
+  [[nodiscard]] const ValueGrid2<float>& likelihood_field() const {
+    if (!has_field_) throw std::runtime_error("The current sensor model does not support likelihood field");
+    if (!field_) {
+      std::vector<float> data(static_cast<std::size_t>(width_) * height_);
+      check(mcl_get_likelihood_field(ctx_, data.data()));
+      field_.emplace(std::move(data), width_, resolution_);
     }
-    return field_;
+    return *field_;
+  }
+
+  /// beluga_ros::Amcl::likelihood_field_origin() (beluga_ros/include/beluga_ros/amcl.hpp:161-178).
+  /// \throw std::runtime_error If the sensor model has no likelihood field.
+  [[nodiscard]] SE2d likelihood_field_origin() const {
+    SE2d origin;
+    const mcl_status st = mcl_get_likelihood_field_origin(ctx_, origin.data());
+    if (st == MCL_ERR_UNSUPPORTED) throw std::runtime_error("The current sensor model does not support likelihood field");
+    check(st);
+    return origin;
+  }
+
+  /// beluga_ros::Amcl::has_likelihood_field() (beluga_ros/include/beluga_ros/amcl.hpp:181-188).
+  [[nodiscard]] bool has_likelihood_field() const { return has_field_; }
+
+  /// beluga_ros::Amcl::initialize_from_map() (beluga_ros/include/beluga_ros/amcl.hpp:209): max_particles states drawn
+  /// uniformly over the free cells of the map (random/multivariate_uniform_distribution.hpp:126-161).
+  void initialize_from_map() {
+    check(mcl_initialize_from_map(ctx_));
+    dirty_ = true;
+  }
+
+  /// beluga_ros::Amcl::update(base_pose_in_odom, point_cloud) (beluga_ros/src/amcl.cpp:67-81): `points_xyz` are the cloud's
+  /// points (3 floats each) in the sensor frame, `origin` the sensor pose in the base frame as Sophus::SE3d::data().
+  auto update(const SE2d& base_pose_in_odom, const std::vector<float>& points_xyz, const std::array<double, 7>& origin)
+      -> std::optional<estimation_type> {
+    measurement_type points(points_xyz.size() / 3 + 1);
+    check(mcl_project_point_cloud(points_xyz.data(), points_xyz.size() / 3, origin.data(), &points.front().first));
+    points.resize(points_xyz.size() / 3);
+    return update(base_pose_in_odom, points);
   }
 
   [[nodiscard]] const mcl_update_info& last_update_info() const { return last_info_; }
+  [[nodiscard]] std::size_t max_particles() const { return max_particles_; }
   [[nodiscard]] mcl_ctx* native_handle() const { return ctx_; }
 
  private:
@@ -368,9 +502,12 @@ class Amcl {
   }
   mcl_ctx* ctx_{nullptr};
   std::uint32_t width_{0}, height_{0};
+  std::size_t max_particles_{0};
+  double resolution_{0.0};
+  bool has_field_{false};
   mutable ParticleSet mirror_;
   mutable bool dirty_{true};
-  mutable std::vector<float> field_;
+  mutable std::optional<ValueGrid2<float>> field_;
   mcl_update_info last_info_{};
 };
 

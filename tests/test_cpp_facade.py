@@ -12,15 +12,26 @@ from beluga_amd import build as mcl_build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def demo(tmp_path_factory):
+def _compile(tmp_path_factory, name):
     mcl_build.build()
-    exe = tmp_path_factory.mktemp("cpp") / "facade_demo"
+    exe = tmp_path_factory.mktemp("cpp") / name
     lib_dir = os.path.join(ROOT, "beluga_amd", "lib")
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "facade_demo.cpp"), "-L", lib_dir, "-lbeluga_mcl",
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-L", lib_dir, "-lbeluga_mcl",
                            f"-Wl,-rpath,{lib_dir}", "-o", str(exe)])
     return str(exe)
+
+
+@pytest.fixture(scope="module")
+def demo(tmp_path_factory):
+    return _compile(tmp_path_factory, "facade_demo")
+
+
+@pytest.fixture(scope="module")
+def node_bodies(tmp_path_factory):
+    """tests/cpp/amcl_node_bodies.cpp: the filter-facing member functions of beluga_amcl::AmclNode
+    (beluga_amcl/src/amcl_node.cpp:350-433,456-476,500-514,683-721) over beluga_amd::ros::Amcl, -Werror."""
+    return _compile(tmp_path_factory, "amcl_node_bodies")
 
 
 def test_facade_compiles_and_fails_loudly_without_gpu(demo):
@@ -30,6 +41,36 @@ def test_facade_compiles_and_fails_loudly_without_gpu(demo):
     out = subprocess.run([demo], capture_output=True, text=True)
     assert out.returncode == 3
     assert "runtime_error" in out.stdout and "no CPU fallback" in out.stdout
+
+
+def test_node_bodies_compile_and_fail_loudly_without_gpu(node_bodies):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    out = subprocess.run([node_bodies], capture_output=True, text=True)
+    assert out.returncode == 3
+    assert "runtime_error" in out.stdout and "no CPU fallback" in out.stdout
+
+
+@pytest.mark.gpu
+def test_node_bodies_run_against_the_device_library(node_bodies):
+    """The node's own code paths on the GPU: construction through the model variants, likelihood-field publication,
+    initialize_from_map + particle-cloud message, initialize(pose, covariance) incl. the rejected covariance, update with a
+    laser scan and with a point cloud, update_map; and the beam model's missing likelihood field."""
+    out = subprocess.run([node_bodies], capture_output=True, text=True, check=True).stdout
+    kv = {line.split()[0]: line.split()[1:] for line in out.splitlines()}
+    assert kv["has_likelihood_field"] == ["1"]
+    assert kv["field_message"] == ["96", "80", str(96 * 80)]
+    assert [float(v) for v in kv["field_origin"]] == pytest.approx([-2.0, -1.0], abs=1e-12)
+    assert kv["from_map_particles"] == ["2000", "2000"] and float(kv["from_map_weight_sum"][0]) == 2000.0
+    assert kv["bad_covariance_rejected"] == ["1"]
+    assert kv["scan_update"] == ["1"] and kv["cloud_update"] == ["1"]
+    x, y = (float(v) for v in kv["estimate"])
+    assert abs(x - 1.3) < 0.6 and abs(y - 1.5) < 0.6
+    assert int(kv["after_update_map"][0]) >= 500
+    beam = subprocess.run([node_bodies, "beam"], capture_output=True, text=True, check=True).stdout
+    assert "has_likelihood_field 0" in beam
+    assert "beam_origin The current sensor model does not support likelihood field" in beam
 
 
 @pytest.mark.gpu
