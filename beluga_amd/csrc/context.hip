@@ -199,6 +199,7 @@ struct mcl_ctx {
 
   // scan: staged in mapped pinned host memory and pulled into d_points by a kernel of the cycle (no copy-engine hand-off)
   DeviceBuffer<double> d_points;
+  DeviceBuffer<double> d_beam_points;  // beam model: per-beam terms (kBeamPointDoubles per beam)
   double* h_points{nullptr};   // pinned, mapped
   double* hd_points{nullptr};  // the same memory as the device sees it
   double scan_extent{0.0};     // max |x| + |y| of the uploaded scan points (NaN if any is NaN)
@@ -488,6 +489,7 @@ mcl_status rebuild_cube(mcl_ctx* ctx, const float* h_field) {
 mcl_status stage_points(mcl_ctx* ctx, const double* pts, uint64_t B) {
   if (B == 0) return MCL_OK;
   MCL_HIP(ctx, ctx->d_points.ensure(2 * B));
+  if (ctx->cfg.sensor_kind == MCL_SENSOR_BEAM) MCL_HIP(ctx, ctx->d_beam_points.ensure(kBeamPointDoubles * B));
   if (ctx->points_in_flight) {  // an earlier call may still be reading the staging buffer
     if (ctx->points_event_valid) MCL_HIP(ctx, hipEventSynchronize(ctx->points_event));
     else MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -636,7 +638,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     launch_reweight_beam(ctx->stream, ctx->cur(), ctx->n, ctx->grid_view(),
                          BeamModel{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range},
                          ctx->d_points.ptr, static_cast<uint32_t>(B), ctx->d_kld_scalars.ptr + 1, ordered ? &sort : nullptr,
-                         ctx->d_nonfree_bits.ptr);
+                         ctx->d_nonfree_bits.ptr, ctx->d_beam_points.ptr);
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
   }
   stage_end(ctx, MCL_STAGE_REWEIGHT);
@@ -1038,6 +1040,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_nonfree_bits.release();
   ctx->d_free.release();
   ctx->d_points.release();
+  ctx->d_beam_points.release();
   ctx->d_chunk.release();
   ctx->d_scalars.release();
   ctx->d_cdf.release();
@@ -1093,7 +1096,7 @@ mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32
     MCL_HIP(ctx, hipMemcpy(ctx->d_free.ptr, free_cells.data(), free_cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   if (ctx->cfg.sensor_kind == MCL_SENSOR_BEAM) {
     MCL_REQUIRE(ctx, n < (1ull << 31), "mcl_set_map: beam model grids are limited to 2^31 cells");
-    MCL_HIP(ctx, ctx->d_nonfree_bits.ensure(static_cast<size_t>((width + 31) / 32) * height));
+    MCL_HIP(ctx, ctx->d_nonfree_bits.ensure(nonfree_words(width, height)));
     launch_pack_nonfree(ctx->stream, ctx->d_cells.ptr, width, height, ctx->traits.free_value, ctx->d_nonfree_bits.ptr);
     MCL_HIP(ctx, hipGetLastError());
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -153,9 +153,20 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_order_particles first).
+// d_beam_points: scratch of kBeamPointDoubles * B doubles (per-beam terms shared by all particles; ordered variant only).
+constexpr uint32_t kBeamPointDoubles = 5;
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
-                          unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits);
-// One bit per cell (1 = not free), ceil(W/32) words per row: the occupancy the ray walks read.
+                          unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points);
+// The occupancy the ray walks read, in one buffer of nonfree_words(W, H) words: one bit per cell (1 = not free), ceil(W/32)
+// words per row, followed by two coarse bitmaps — one bit per 8 x 8-cell block, "any cell not free" — row-major and column-major.
+struct NonFreeBits {
+  const uint32_t* fine;
+  const uint32_t* rows;     // [ceil(H/8)][row_words]
+  const uint32_t* columns;  // [ceil(W/8)][column_words]
+  uint32_t words_per_row, row_words, column_words;
+};
+NonFreeBits nonfree_layout(uint32_t W, uint32_t H, uint32_t* base);
+size_t nonfree_words(uint32_t W, uint32_t H);
 void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32_t H, int8_t free_value, uint32_t* bits);
 // Per-device kernel attributes (dynamic LDS opt-in of the ordered beam kernel); call once per context after hipSetDevice.
 void configure_device_kernels();

@@ -863,6 +863,13 @@ struct RayWalk {
   int x, y;   // cell k
 };
 
+// floor(num / den) for num >= 0, den > 0: a 32-bit division whenever the operands allow it (they do for every grid below
+// 2^16 cells per side), the 64-bit one (~4x the instructions) otherwise.
+__device__ __forceinline__ long long floor_div(long long num, int den) {
+  if (num < (1ll << 32)) return static_cast<long long>(static_cast<unsigned>(num) / static_cast<unsigned>(den));
+  return num / den;
+}
+
 // Number of cells (minus one) of the walk that stay inside the box [lo_major, hi_major] x [lo_minor, hi_minor].
 __device__ __forceinline__ int walk_room(const RayWalk& r, int major_pos, int minor_pos, int lo_major, int hi_major, int lo_minor,
                                          int hi_minor) {
@@ -872,12 +879,18 @@ __device__ __forceinline__ int walk_room(const RayWalk& r, int major_pos, int mi
   if (r.dminor > 0) {
     const long long room_minor = r.minor_step > 0 ? hi_minor - minor_pos : minor_pos - lo_minor;  // trips that stay inside
     // first k with m_k >= room_minor + 1  <=>  major_span + k*dminor > (room_minor + 1) * dmajor
-    const long long k_exit = ((room_minor + 1) * r.dmajor - r.major_span) / r.dminor + 1;
+    const long long k_exit = floor_div((room_minor + 1) * r.dmajor - r.major_span, r.dminor) + 1;
     if (k_exit - 1 < last) last = static_cast<int>(k_exit - 1);
   }
   return last;
 }
+__device__ __forceinline__ int walk_room_in_grid(const GridView& g, const RayWalk& r) {
+  return walk_room(r, r.steep ? r.sy : r.sx, r.steep ? r.sx : r.sy, 0, static_cast<int>(r.steep ? g.H : g.W) - 1, 0,
+                   static_cast<int>(r.steep ? g.W : g.H) - 1);
+}
 
+// kGridRoom == false leaves r.last unset (the caller bounds the walk itself and asks walk_room_in_grid only if it needs to).
+template <bool kGridRoom = true>
 __device__ __forceinline__ RayWalk walk_begin(const GridView& g, int sx, int sy, int fx, int fy) {
   RayWalk r;
   r.sx = sx;
@@ -899,8 +912,7 @@ __device__ __forceinline__ RayWalk walk_begin(const GridView& g, int sx, int sy,
   r.minor_step = r.steep ? xstep : ystep;
   r.dmajor = 2 * r.major_span;
   r.dminor = 2 * minor_span;
-  r.last = walk_room(r, r.steep ? sy : sx, r.steep ? sx : sy, 0, static_cast<int>(r.steep ? g.H : g.W) - 1, 0,
-                     static_cast<int>(r.steep ? g.W : g.H) - 1);
+  r.last = kGridRoom ? walk_room_in_grid(g, r) : -1;
   r.k = 0;
   r.error = r.major_span;
   r.trips = 0;
@@ -984,16 +996,10 @@ __device__ __forceinline__ double cast_ray(const GridView& g, int sx, int sy, in
 // bit per cell (row stride kWinStride words: one word of padding keeps vertically adjacent cells on different banks).
 // Cells of the trace beyond the window (long rays near its edge) are read from the global bit mask.
 constexpr int kWin = 1024, kWinWords = kWin / 32, kWinStride = kWinWords + 1;
-struct BitWindow {
-  const uint32_t* lds;      // kWin rows x kWinStride words
-  int x0, y0;               // grid cell of window bit (0, 0); x0 is a multiple of 32
-  const uint32_t* global;   // whole-grid mask, words_per_row words per row
-  uint32_t words_per_row;
-};
 // Error trips after k steps of the walk: the error term stays in (0, dmajor], so m_k = ceil((major_span + k*dminor) / dmajor) - 1.
 __device__ __forceinline__ int walk_trips_at(const RayWalk& r, int k) {
   if (r.dmajor == 0) return 0;
-  return static_cast<int>((r.major_span + static_cast<long long>(k) * r.dminor + r.dmajor - 1) / r.dmajor) - 1;
+  return static_cast<int>(floor_div(r.major_span + static_cast<long long>(k) * r.dminor + r.dmajor - 1, r.dmajor)) - 1;
 }
 __device__ __forceinline__ void walk_seek(RayWalk& r, int k, int error) {
   const int trips = walk_trips_at(r, k);
@@ -1004,110 +1010,243 @@ __device__ __forceinline__ void walk_seek(RayWalk& r, int k, int error) {
   r.y = r.steep ? r.sy + r.major_step * k : r.sy + r.minor_step * trips;
 }
 
-// The window walk of cast_ray_window: kSpec cells per round.  Step constants (bit position / word-row increments for a
-// plain major step and for a major + minor step) are template parameters, or kRuntimeStep to take them from the arguments.
+// The window walk of cast_ray_window.  The map is mostly free space, so the walk asks a coarse bitmap — one bit per
+// 8 x 8-cell block of the window, "any cell not free" — about a whole block column of the line at a time: 8 steps along the
+// major axis move the minor coordinate by at most 8 cells, so the 8 cells lie in the blocks of the first cell and of the
+// cell after the last one (a superset).  When both are empty the 8 cells are skipped; the Bresenham state after 8 steps
+// is exact and division free: error' = error + (8 * dminor mod dmajor), one more trip if that exceeds dmajor.  Otherwise
+// the 8 cells are examined one by one, exactly as a plain walk would.  Skipped cells are free by construction, so the
+// first non-free cell, and with it Ray2d::cast's result (raycasting.hpp:97-107, bresenham.hpp:122-160), is unchanged bit
+// for bit.  The coarse bitmap is stored twice, row-major and column-major, so that the block the line moves through
+// along its minor axis is always a bit position inside one row of 128 bits.
+// Step directions are template parameters (the lanes of a wave follow one beam from neighbouring poses and almost
+// always share the line's octant), or kRuntimeStep to take them from the arguments.
 constexpr int kRuntimeStep = 0x7FFFFFFF;
-template <int MLX, int MROW, int BLX, int BROW>
-__device__ __forceinline__ void window_walk(const uint32_t* lds, int& lx, int& lrow, int& error, int& k, int& hit_k, int upto, int dminor,
-                                            int dmajor, int r_m_lx, int r_m_row, int r_b_lx, int r_b_row) {
-  const int m_lx = MLX == kRuntimeStep ? r_m_lx : MLX, m_row = MROW == kRuntimeStep ? r_m_row : MROW;
-  const int b_lx = BLX == kRuntimeStep ? r_b_lx : BLX, b_row = BROW == kRuntimeStep ? r_b_row : BROW;
-  while (k + kSpec - 1 <= upto) {
-    uint32_t words[kSpec];
-    int bits[kSpec];
+constexpr int kCoarse = kWin / 8, kCoarseWords = kCoarse / 32;  // 128 x 128 blocks, 4 words per row of blocks
+
+// Cells u = 0 .. count-1 (count <= 8) from (lx, ly, error): their words are fetched together (where they lie does not depend
+// on what they hold) and examined in order.  Returns the index of the first non-free one or -1; `advance` also moves
+// (lx, ly, error) count cells on.
+// A bit-per-cell occupancy view the block walk reads: the LDS window (coordinates relative to its corner) or the whole grid in
+// global memory.  rows / columns: the coarse bitmap (one bit per 8 x 8 block), row-major and column-major.
+struct BlockMaps {
+  const uint32_t* fine;
+  int fine_stride;           // words per row of cells
+  int x_max, y_max;          // last valid cell coordinates
+  const uint32_t* rows;      // [ceil(height / 8)][row_words]
+  const uint32_t* columns;   // [ceil(width / 8)][column_words]
+  int row_words, column_words;
+};
+struct BitWindow {
+  const uint32_t* lds;      // kWin rows x kWinStride words, then the two coarse bitmaps of the window
+  int x0, y0;               // grid cell of window bit (0, 0); x0 is a multiple of 32, y0 of 8
+  BlockMaps grid_maps;      // the whole grid (cells beyond the window)
+};
+template <bool kAdvance, bool kClamp = true>
+__device__ __forceinline__ int examine_cells(const BlockMaps& maps, int& lx, int& ly, int& error, int count, int dminor, int dmajor,
+                                             bool steep, int major_step, int minor_step) {
+  int fx = lx, fy = ly, fe = error;
+  uint32_t words[8];
+  int bits[8];
 #pragma unroll
-    for (int u = 0; u < kSpec; ++u) {
-      words[u] = lds[lrow + (lx >> 5)];
-      bits[u] = lx & 31;
-      error += dminor;
-      const bool trip = error > dmajor;
-      lx += trip ? b_lx : m_lx;
-      lrow += trip ? b_row : m_row;
-      error -= trip ? dmajor : 0;
+  for (int u = 0; u < 8; ++u) {
+    // cells behind the last one are not examined; they may lie outside (kClamp == false: the caller knows all 8 are inside)
+    const int cx = kClamp ? min(max(fx, 0), maps.x_max) : fx, cy = kClamp ? min(max(fy, 0), maps.y_max) : fy;
+    words[u] = maps.fine[cy * maps.fine_stride + (cx >> 5)];
+    bits[u] = cx & 31;
+    if (kAdvance && u == count) {
+      lx = fx;
+      ly = fy;
+      error = fe;
     }
-    uint32_t any = 0;
+    fe += dminor;
+    const bool trip = fe > dmajor;
+    fe -= trip ? dmajor : 0;
+    if (steep) {
+      fy += major_step;
+      fx += trip ? minor_step : 0;
+    } else {
+      fx += major_step;
+      fy += trip ? minor_step : 0;
+    }
+  }
+  if (kAdvance && count == 8) {
+    lx = fx;
+    ly = fy;
+    error = fe;
+  }
+  int first = -1;
 #pragma unroll
-    for (int u = kSpec - 1; u >= 0; --u) {
-      const uint32_t occ = (words[u] >> bits[u]) & 1u;
-      any |= occ;
-      hit_k = occ ? k + u : hit_k;  // descending u: the smallest u with a set bit wins
+  for (int u = 7; u >= 0; --u) first = (u < count && ((words[u] >> bits[u]) & 1u)) ? u : first;  // the smallest u with a set bit wins
+  return first;
+}
+
+template <int STEEP, int MAJ, int MIN>
+__device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int& ly, int& error, int& k, int& hit_k, int upto, int dminor,
+                                            int dmajor, bool r_steep, int r_major_step, int r_minor_step) {
+  const bool steep = STEEP == kRuntimeStep ? r_steep : (STEEP != 0);
+  const int major_step = MAJ == kRuntimeStep ? r_major_step : MAJ, minor_step = MIN == kRuntimeStep ? r_minor_step : MIN;
+  if (k > upto) return;
+  // 1. up to the end of the first block column, cell by cell
+  {
+    const int major = steep ? ly : lx;
+    int j = major_step > 0 ? 8 - (major & 7) : (major & 7) + 1;
+    j = min(j, upto - k + 1);
+    const int first = examine_cells<true>(maps, lx, ly, error, j, dminor, dmajor, steep, major_step, minor_step);
+    if (first >= 0) {
+      hit_k = k + first;
+      return;
     }
-    if (any) break;
-    k += kSpec;
+    k += j;
+  }
+  // 2. whole block columns.  8 * dminor = trips8 * dmajor + rest8 (dminor <= dmajor: trips8 <= 8).
+  int trips8 = 0;
+  if (dmajor > 0) {
+    const int x = 8 * dminor;  // < 2^24: one float multiply and a +-1 correction
+    int q = static_cast<int>(static_cast<float>(x) * (1.0f / static_cast<float>(dmajor)));
+    const int rem = x - q * dmajor;
+    q += (rem >= dmajor ? 1 : 0) - (rem < 0 ? 1 : 0);
+    trips8 = q;
+  }
+  const int rest8 = 8 * dminor - trips8 * dmajor;
+  const int minor8 = trips8 * minor_step;
+  // rows of bits indexed by the block along the major axis, bit = block along the minor axis
+  const uint32_t* bitmap = steep ? maps.rows : maps.columns;
+  const int bitmap_words = steep ? maps.row_words : maps.column_words;
+  int major = steep ? ly : lx, minor = steep ? lx : ly;
+  while (k + 8 <= upto) {  // cells k .. k+7 and the cell behind them are inside
+    int raised = error + rest8;
+    const bool extra = raised > dmajor;
+    raised -= extra ? dmajor : 0;
+    const int minor_next = minor + minor8 + (extra ? minor_step : 0);
+    const uint32_t* row = bitmap + (major >> 3) * bitmap_words;
+    const int b0 = minor >> 3, b1 = minor_next >> 3;
+    const uint32_t occupied = ((row[b0 >> 5] >> (b0 & 31)) | (row[b1 >> 5] >> (b1 & 31))) & 1u;
+    if (occupied) {
+      int fx = steep ? minor : major, fy = steep ? major : minor, fe = error;
+      const int first = examine_cells<false, false>(maps, fx, fy, fe, 8, dminor, dmajor, steep, major_step, minor_step);
+      if (first >= 0) {
+        hit_k = k + first;
+        return;
+      }
+    }
+    k += 8;
+    major += 8 * major_step;
+    minor = minor_next;
+    error = raised;
+  }
+  lx = steep ? minor : major;
+  ly = steep ? major : minor;
+  // 3. the last cells
+  while (k <= upto) {
+    const int j = min(8, upto - k + 1);
+    const int first = examine_cells<true>(maps, lx, ly, error, j, dminor, dmajor, steep, major_step, minor_step);
+    if (first >= 0) {
+      hit_k = k + first;
+      return;
+    }
+    k += j;
+  }
+}
+// Dispatch on the line's orientation: a wave whose lanes agree on it (they follow one beam from neighbouring poses) runs the
+// instance with a compile-time major axis; the step directions stay run-time values (one instance per octant made the kernel
+// outgrow the instruction cache).
+__device__ __forceinline__ void walk_blocks_any(const BlockMaps& maps, const RayWalk& r, int& lx, int& ly, int& error, int& k, int& hit_k,
+                                                int upto) {
+  const int wave_steep = __builtin_amdgcn_readfirstlane(r.steep ? 1 : 0);
+  if (__builtin_amdgcn_ballot_w64((r.steep ? 1 : 0) != wave_steep) == 0) {
+    if (wave_steep) walk_blocks<1, kRuntimeStep, kRuntimeStep>(maps, lx, ly, error, k, hit_k, upto, r.dminor, r.dmajor, true, r.major_step, r.minor_step);
+    else walk_blocks<0, kRuntimeStep, kRuntimeStep>(maps, lx, ly, error, k, hit_k, upto, r.dminor, r.dmajor, false, r.major_step, r.minor_step);
+  } else {
+    walk_blocks<kRuntimeStep, kRuntimeStep, kRuntimeStep>(maps, lx, ly, error, k, hit_k, upto, r.dminor, r.dmajor, r.steep, r.major_step,
+                                                          r.minor_step);
   }
 }
 
 __device__ __forceinline__ double cast_ray_window(const GridView& g, const BitWindow& w, int sx, int sy, int fx, int fy,
                                                   double max_range, unsigned long long& steps) {
-  RayWalk r = walk_begin(g, sx, sy, fx, fy);
-  const int in_window = walk_room(r, r.steep ? sy : sx, r.steep ? sx : sy, r.steep ? w.y0 : w.x0, (r.steep ? w.y0 : w.x0) + kWin - 1,
-                                  r.steep ? w.x0 : w.y0, (r.steep ? w.x0 : w.y0) + kWin - 1);
-  const int upto = min(r.last, in_window);
-  if (upto >= kSpec - 1) {
-    // Hot loop: whole groups of kSpec cells, all inside the grid and the window, addressed incrementally in LDS
-    // (bit position along x, word-row offset along y).  The lanes of a wave follow the same beam from neighbouring
-    // poses, so they almost always share the octant of the line: the loop is instantiated per octant with the four
-    // step constants known at compile time (no per-cell selects), with a generic instance for mixed waves.
-    int lx = sx - w.x0, lrow = (sy - w.y0) * kWinStride;
-    int error = r.error, k = 0, hit_k = -1;
-    const int octant = (r.steep ? 4 : 0) | (r.major_step > 0 ? 2 : 0) | (r.minor_step > 0 ? 1 : 0);
-    const int wave_octant = __builtin_amdgcn_readfirstlane(octant);
-    constexpr int S = kWinStride;
-    if (__builtin_amdgcn_ballot_w64(octant != wave_octant) == 0) {
-      switch (wave_octant) {
-        case 0: window_walk<-1, 0, -1, -S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
-        case 1: window_walk<-1, 0, -1, +S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
-        case 2: window_walk<+1, 0, +1, -S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
-        case 3: window_walk<+1, 0, +1, +S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
-        case 4: window_walk<0, -S, -1, -S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
-        case 5: window_walk<0, -S, +1, -S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
-        case 6: window_walk<0, +S, -1, +S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
-        default: window_walk<0, +S, +1, +S>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, 0, 0, 0, 0); break;
-      }
-    } else {
-      const int m_lx = r.steep ? 0 : r.major_step, m_row = r.steep ? r.major_step * kWinStride : 0;
-      const int b_lx = m_lx + (r.steep ? r.minor_step : 0), b_row = m_row + (r.steep ? 0 : r.minor_step * kWinStride);
-      window_walk<kRuntimeStep, kRuntimeStep, kRuntimeStep, kRuntimeStep>(w.lds, lx, lrow, error, k, hit_k, upto, r.dminor, r.dmajor, m_lx,
-                                                                          m_row, b_lx, b_row);
-    }
+  RayWalk r = walk_begin<false>(g, sx, sy, fx, fy);
+  // Cells inside the grid AND the window (a box): one closed-form bound.  The grid's own bound is only needed by a ray that
+  // leaves the window without a hit.
+  const int gw = static_cast<int>(g.W) - 1, gh = static_cast<int>(g.H) - 1;
+  const int x_lo = max(w.x0, 0), x_hi = min(w.x0 + kWin - 1, gw), y_lo = max(w.y0, 0), y_hi = min(w.y0 + kWin - 1, gh);
+  const int upto = walk_room(r, r.steep ? sy : sx, r.steep ? sx : sy, r.steep ? y_lo : x_lo, r.steep ? y_hi : x_hi, r.steep ? x_lo : y_lo,
+                             r.steep ? x_hi : y_hi);
+  int k = 0, hit_k = -1, error = r.error;
+  if (upto >= 0) {
+    // Cells 0 .. upto are inside the grid and the window: walked in LDS, block column by block column.
+    int lx = sx - w.x0, ly = sy - w.y0;
+    const uint32_t* rows = w.lds + kWin * kWinStride;
+    const BlockMaps lds_maps{w.lds, kWinStride, kWin - 1, kWin - 1, rows, rows + kCoarse * kCoarseWords, kCoarseWords, kCoarseWords};
+    walk_blocks_any(lds_maps, r, lx, ly, error, k, hit_k, upto);
     if (hit_k >= 0) {
       walk_seek(r, hit_k, 0);
       return walk_result(g, r, true, max_range, steps);
     }
-    walk_seek(r, k, error);
   }
-  // Remainder (a tail shorter than one group, or cells beyond the window): the global bit mask.
-  const bool hit = walk_until(r, r.last, [&w](int x, int y) {
-    return (w.global[static_cast<size_t>(y) * w.words_per_row + (static_cast<unsigned>(x) >> 5)] >> (x & 31)) & 1u;
-  });
-  return walk_result(g, r, hit, max_range, steps);
+  // Cells beyond the window (long rays near its edge): the same walk over the whole-grid maps in global memory.
+  r.last = walk_room_in_grid(g, r);
+  if (k <= r.last) {
+    walk_seek(r, k, error);
+    int gx = r.x, gy = r.y;
+    walk_blocks_any(w.grid_maps, r, gx, gy, error, k, hit_k, r.last);
+    if (hit_k >= 0) {
+      walk_seek(r, hit_k, 0);
+      return walk_result(g, r, true, max_range, steps);
+    }
+  }
+  return walk_result(g, r, false, max_range, steps);
+}
+
+// What beam_model.hpp:110-147 computes from the scan point alone (the same for every particle): the measured range, the
+// far end of the trace in the sensor frame (raycasting.hpp:78-88: bearing * max_range), and the terms of the mixture that do
+// not depend on the expected range.  The ordered kernel reads them from a table (k_beam_points), one entry per beam.
+struct BeamPoint {
+  double z;         // |p|
+  double ux, uy;    // p / |p| * beam_max_range
+  double short_e;   // exp(-lambda_short * z)
+  double tail;      // z < beam_max_range ? z_rand / beam_max_range : z_max
+};
+__device__ __forceinline__ BeamPoint beam_point(const BeamModel& m, double px, double py) {
+  BeamPoint q;
+  q.z = sqrt(px * px + py * py);
+  const double bc = px / q.z, bs = py / q.z;
+  q.ux = bc * m.beam_max_range;
+  q.uy = bs * m.beam_max_range;
+  q.short_e = exp(-m.lambda_short * q.z);
+  q.tail = q.z < m.beam_max_range ? m.z_rand / m.beam_max_range : m.z_max;
+  return q;
+}
+__global__ __launch_bounds__(kBlock) void k_beam_points(const double* __restrict__ pts, uint32_t B, BeamModel m, BeamPoint* __restrict__ out) {
+  const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+  if (b < B) out[b] = beam_point(m, pts[2 * b], pts[2 * b + 1]);
 }
 
 // One beam of beam_model.hpp:110-147 for a source pose already in the grid frame (Ray2d ctor: raycasting.hpp:62-70).
+// erf saturates: for |x| >= 6.5 it is +-1 to the last bit (erfc(6.5) < 4e-20), so when the expected range is more than
+// 6.5 * sqrt(2) * sigma_hit away from both 0 and max_range — nearly every beam — the normaliser eta_hit is exactly 2 / 2
+// and neither erf is evaluated (a wave takes the general path only if one of its lanes needs it).
 template <class Cast>
-__device__ __forceinline__ double beam_term(const GridView& g, const BeamModel& m, double norm_hit, const Pose2& src, int sx, int sy,
-                                            double px, double py, Cast&& cast) {
-  const double z = sqrt(px * px + py * py);
-  const double bc = px / z, bs = py / z;
+__device__ __forceinline__ double beam_term(const GridView& g, const BeamModel& m, double norm_hit, const Pose2& src, const BeamPoint& q,
+                                            Cast&& cast) {
   double ex, ey;  // trace(): raycasting.hpp:78-88
-  rot_apply(src.r, bc * m.beam_max_range, bs * m.beam_max_range, ex, ey);
+  rot_apply(src.r, q.ux, q.uy, ex, ey);
   ex += src.x;
   ey += src.y;
   int fx, fy;
   cell_near(g, ex, ey, fx, fy);
   const double z_mean = cast(fx, fy);
-  const double eta_hit = 2. / (erf((m.beam_max_range - z_mean) / (sqrt(2.) * m.sigma_hit)) - erf(-z_mean / (sqrt(2.) * m.sigma_hit)));
-  const double d = (z - z_mean) / m.sigma_hit;
+  const double scale = sqrt(2.) * m.sigma_hit;
+  const double hi = (m.beam_max_range - z_mean) / scale, lo = -z_mean / scale;
+  double eta_hit = 1.0;
+  if (__builtin_amdgcn_ballot_w64(!(hi >= 6.5 && lo <= -6.5)) != 0) eta_hit = 2. / (erf(hi) - erf(lo));
+  const double d = (q.z - z_mean) / m.sigma_hit;
   double pz = m.z_hit * eta_hit * norm_hit * exp(-(d * d) / 2.);
-  if (z < z_mean) {
+  if (q.z < z_mean) {
     const double eta_short = 1. / (1. - exp(-m.lambda_short * z_mean));
-    pz += m.z_short * m.lambda_short * eta_short * exp(-m.lambda_short * z);
+    pz += m.z_short * m.lambda_short * eta_short * q.short_e;
   }
-  if (z < m.beam_max_range) {
-    pz += m.z_rand / m.beam_max_range;
-  } else {
-    pz += m.z_max;
-  }
+  pz += q.tail;
   return pz * pz * pz;
 }
 
@@ -1129,7 +1268,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam(Particles p, uint64_t 
   unsigned long long steps = 0;
   for (uint32_t b = lane; b < B; b += kWave) {
     const double2 pt = s_pts[b];
-    acc += beam_term(g, m, norm_hit, src, sx, sy, pt.x, pt.y,
+    acc += beam_term(g, m, norm_hit, src, beam_point(m, pt.x, pt.y),
                      [&](int fx, int fy) { return cast_ray(g, sx, sy, fx, fy, m.beam_max_range, steps); });
   }
   const double total = wave_sum_f64(acc);
@@ -1147,8 +1286,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam(Particles p, uint64_t 
 // into LDS as a 1024 x 1024-cell bit window (132 KB) centred on the workgroup's particles; LDS serves 32 lanes/clk.
 constexpr int kBeamBlock = 1024;
 __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __restrict__ w, uint64_t n, GridView g, BeamModel m,
-                                                                     const uint32_t* __restrict__ nonfree_bits,
-                                                                     uint32_t words_per_row, const double* __restrict__ pts,
+                                                                     NonFreeBits bits, const BeamPoint* __restrict__ pts,
                                                                      uint32_t B, const uint32_t* __restrict__ perm,
                                                                      const double4* __restrict__ pose, unsigned long long* d_steps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1165,10 +1303,12 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
   }
   BitWindow bw;
   bw.x0 = ((cx - kWin / 2) >> 5) << 5;
-  bw.y0 = cy - kWin / 2;
+  bw.y0 = ((cy - kWin / 2) >> 3) << 3;  // block rows of the coarse bitmap start on multiples of 8 cells
   bw.lds = win;
-  bw.global = nonfree_bits;
-  bw.words_per_row = words_per_row;
+  bw.grid_maps = BlockMaps{bits.fine, static_cast<int>(bits.words_per_row), static_cast<int>(g.W) - 1, static_cast<int>(g.H) - 1, bits.rows,
+                           bits.columns, static_cast<int>(bits.row_words), static_cast<int>(bits.column_words)};
+  const uint32_t* nonfree_bits = bits.fine;
+  const uint32_t words_per_row = bits.words_per_row;
   for (int i = threadIdx.x; i < kWin * kWinWords; i += kBeamBlock) {
     const int row = i >> 5, col = i & 31;
     const int gy = bw.y0 + row, gw = (bw.x0 >> 5) + col;
@@ -1176,6 +1316,33 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
     if (gy >= 0 && gy < static_cast<int>(g.H) && gw >= 0 && gw < static_cast<int>(words_per_row))
       v = nonfree_bits[static_cast<size_t>(gy) * words_per_row + gw];
     win[row * kWinStride + col] = v;
+  }
+  __syncthreads();
+  {  // coarse bitmap behind the window: bit (bx, by) = any cell of block (bx, by) not free
+    uint32_t* coarse = win + kWin * kWinStride;
+    for (int cw = threadIdx.x; cw < kCoarse * kCoarseWords; cw += kBeamBlock) {
+      const int by = cw / kCoarseWords, quarter = cw % kCoarseWords;
+      uint32_t bits = 0;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) any |= win[(by * 8 + rr) * kWinStride + quarter * 8 + f];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bits |= ((any >> (8 * q)) & 0xFFu) ? (1u << (f * 4 + q)) : 0u;
+      }
+      coarse[cw] = bits;
+    }
+    __syncthreads();
+    // column-major copy: word (bx, q) holds blocks (bx, 32 q .. 32 q + 31)
+    uint32_t* columns = coarse + kCoarse * kCoarseWords;
+    for (int cw = threadIdx.x; cw < kCoarse * kCoarseWords; cw += kBeamBlock) {
+      const int bx = cw / kCoarseWords, quarter = cw % kCoarseWords;
+      uint32_t bits = 0;
+#pragma unroll 8
+      for (int q = 0; q < 32; ++q) bits |= ((coarse[(quarter * 32 + q) * kCoarseWords + (bx >> 5)] >> (bx & 31)) & 1u) << q;
+      columns[cw] = bits;
+    }
   }
   __syncthreads();
 
@@ -1187,8 +1354,7 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
   double acc = 0.0;
   unsigned long long steps = 0;
   for (uint32_t b = 0; b < B; ++b) {
-    const double px = pts[2 * b], py = pts[2 * b + 1];
-    acc += beam_term(g, m, norm_hit, src, sx, sy, px, py,
+    acc += beam_term(g, m, norm_hit, src, pts[b],
                      [&](int fx, int fy) { return cast_ray_window(g, bw, sx, sy, fx, fy, m.beam_max_range, steps); });
   }
   if (d_steps) {
@@ -1211,6 +1377,38 @@ __global__ __launch_bounds__(kBlock) void k_pack_nonfree(const int8_t* __restric
     if (x < W && cells[static_cast<size_t>(y) * W + x] != free_value) v |= 1u << b;
   }
   bits[i] = v;
+}
+
+// Coarse bitmaps of the whole grid: bit (bx, by) = any cell of the 8 x 8 block not free (cells beyond the grid count as free:
+// the walks never go there).  rows[by][bx bits], columns[bx][by bits].
+__global__ __launch_bounds__(kBlock) void k_pack_coarse_rows(const uint32_t* __restrict__ fine, uint32_t words_per_row, uint32_t H,
+                                                             uint32_t block_rows, uint32_t row_words, uint32_t* __restrict__ rows) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= block_rows * row_words) return;
+  const uint32_t by = i / row_words, q = i % row_words;
+  uint32_t out = 0;
+  for (uint32_t f = 0; f < 8; ++f) {
+    const uint32_t word = q * 8 + f;
+    uint32_t any = 0;
+    if (word < words_per_row)
+      for (uint32_t r = 0; r < 8; ++r)
+        if (by * 8 + r < H) any |= fine[static_cast<size_t>(by * 8 + r) * words_per_row + word];
+    for (uint32_t b = 0; b < 4; ++b) out |= ((any >> (8 * b)) & 0xFFu) ? (1u << (f * 4 + b)) : 0u;
+  }
+  rows[i] = out;
+}
+__global__ __launch_bounds__(kBlock) void k_pack_coarse_columns(const uint32_t* __restrict__ rows, uint32_t block_rows, uint32_t row_words,
+                                                                uint32_t block_columns, uint32_t column_words,
+                                                                uint32_t* __restrict__ columns) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= block_columns * column_words) return;
+  const uint32_t bx = i / column_words, q = i % column_words;
+  uint32_t out = 0;
+  for (uint32_t b = 0; b < 32; ++b) {
+    const uint32_t by = q * 32 + b;
+    if (by < block_rows) out |= ((rows[static_cast<size_t>(by) * row_words + (bx >> 5)] >> (bx & 31)) & 1u) << b;
+  }
+  columns[i] = out;
 }
 
 // ---- K3 weight sums / normalize ----------------------------------------------------------------------
@@ -2211,27 +2409,49 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
   }
 }
 
+NonFreeBits nonfree_layout(uint32_t W, uint32_t H, uint32_t* base) {
+  NonFreeBits b{};
+  b.words_per_row = (W + 31) / 32;
+  const uint32_t block_columns = (W + 7) / 8, block_rows = (H + 7) / 8;
+  b.row_words = (block_columns + 31) / 32;
+  b.column_words = (block_rows + 31) / 32;
+  b.fine = base;
+  b.rows = base + static_cast<size_t>(b.words_per_row) * H;
+  b.columns = b.rows + static_cast<size_t>(block_rows) * b.row_words;
+  return b;
+}
+size_t nonfree_words(uint32_t W, uint32_t H) {
+  const NonFreeBits b = nonfree_layout(W, H, nullptr);
+  return static_cast<size_t>(b.columns - b.fine) + static_cast<size_t>((W + 7) / 8) * b.column_words;
+}
 void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32_t H, int8_t free_value, uint32_t* bits) {
-  const uint32_t words_per_row = (W + 31) / 32;
-  const uint64_t words = static_cast<uint64_t>(words_per_row) * H;
-  hipLaunchKernelGGL(k_pack_nonfree, dim3(blocks_for(words)), dim3(kBlock), 0, st, cells, W, H, free_value, words_per_row, bits);
+  const NonFreeBits b = nonfree_layout(W, H, bits);
+  const uint64_t words = static_cast<uint64_t>(b.words_per_row) * H;
+  hipLaunchKernelGGL(k_pack_nonfree, dim3(blocks_for(words)), dim3(kBlock), 0, st, cells, W, H, free_value, b.words_per_row, bits);
+  const uint32_t block_columns = (W + 7) / 8, block_rows = (H + 7) / 8;
+  hipLaunchKernelGGL(k_pack_coarse_rows, dim3(blocks_for(static_cast<uint64_t>(block_rows) * b.row_words)), dim3(kBlock), 0, st, b.fine,
+                     b.words_per_row, H, block_rows, b.row_words, const_cast<uint32_t*>(b.rows));
+  hipLaunchKernelGGL(k_pack_coarse_columns, dim3(blocks_for(static_cast<uint64_t>(block_columns) * b.column_words)), dim3(kBlock), 0, st,
+                     b.rows, block_rows, b.row_words, block_columns, b.column_words, const_cast<uint32_t*>(b.columns));
 }
 
 // hipFuncSetAttribute is per device: contexts on several GPUs of one process each opt in (mcl_create calls this).
 void configure_device_kernels() {
-  const size_t lds = static_cast<size_t>(kWin) * kWinStride * sizeof(uint32_t);
+  const size_t lds = (static_cast<size_t>(kWin) * kWinStride + 2 * kCoarse * kCoarseWords) * sizeof(uint32_t);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_beam_sorted), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(lds));
 }
 
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
-                          unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits) {
-  if (n == 0) return;
+                          unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points) {
+  if (n == 0 || B == 0) return;
   if (sorted && nonfree_bits) {
-    const size_t lds = static_cast<size_t>(kWin) * kWinStride * sizeof(uint32_t);
+    const size_t lds = (static_cast<size_t>(kWin) * kWinStride + 2 * kCoarse * kCoarseWords) * sizeof(uint32_t);
     const dim3 grid(static_cast<unsigned>((n + kBeamBlock - 1) / kBeamBlock));
-    hipLaunchKernelGGL(k_reweight_beam_sorted, grid, dim3(kBeamBlock), lds, st, p.w, n, g, m, nonfree_bits, (g.W + 31) / 32, d_points,
-                       B, sorted->perm, p.pose, d_steps);
+    BeamPoint* table = reinterpret_cast<BeamPoint*>(d_beam_points);
+    hipLaunchKernelGGL(k_beam_points, dim3(blocks_for(B)), dim3(kBlock), 0, st, d_points, B, m, table);
+    hipLaunchKernelGGL(k_reweight_beam_sorted, grid, dim3(kBeamBlock), lds, st, p.w, n, g, m,
+                       nonfree_layout(g.W, g.H, const_cast<uint32_t*>(nonfree_bits)), table, B, sorted->perm, p.pose, d_steps);
     return;
   }
   const dim3 grid(static_cast<unsigned>((n + (kBlock / kWave) - 1) / (kBlock / kWave)));

@@ -30,9 +30,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# k_reweight_lf_sorted at 1M x 1080: FETCH_SIZE 109581.8 KB, WRITE_SIZE 34063.3 KB per launch (round-1 PMC run)
-LF_KERNEL_HBM_BYTES_PER_LAUNCH = int(2 * 78118.6 * 1024 + 34773.0 * 1024)
-HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+HBM_PEAK = 8.0e12      # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_MEASURED = 6.29e12  # B/s, the float4-copy rate the same guide measures (79 % of spec)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "lf_kernel_traffic.json")
+KERNEL_SOURCE = os.path.join(ROOT, "beluga_amd", "csrc", "kernels.hip")
+
+
+def measured_lf_traffic(n_particles: int):
+    """HBM bytes per launch of the LF kernel from the PMC passes of tools/gpu_pmc_traffic.sh (2 x FETCH_SIZE + WRITE_SIZE, see
+    profiles/r01_pmc_traffic_calibration.txt), valid only for the kernel source it was collected on: the file records the
+    SHA-256 of kernels.hip and the particle count; anything else gives None."""
+    import hashlib
+    try:
+        with open(TRAFFIC_FILE) as fh:
+            rec = json.load(fh)
+        with open(KERNEL_SOURCE, "rb") as fh:
+            sha = hashlib.sha256(fh.read()).hexdigest()
+    except (OSError, ValueError):
+        return None
+    if rec.get("kernels_hip_sha256") != sha or rec.get("particles") != n_particles:
+        return None
+    return int(2 * rec["fetch_size_kb"] * 1024 + rec["write_size_kb"] * 1024)
+
 
 MAP_SIZE, RESOLUTION, ORIGIN = 4000, 0.05, (-100.0, -100.0)
 BEAMS, FOV_DEG, MAX_RANGE = 1080, 270.0, 30.0
@@ -96,6 +115,88 @@ def cpu_baseline(cells, truth, odoms, scans, n_full: int, budget_s: float = 12.0
     }
 
 
+def _timed_cycles(filt, controls, scans, first, count, reinit=None):
+    """Wall time of `count` update cycles, each synchronised; `reinit` (optional) restores the set before every cycle."""
+    ms = []
+    for k in range(count):
+        if reinit is not None:
+            reinit()
+        filt.sync()
+        t0 = time.perf_counter()
+        assert filt.update(controls[first + k], scans[first + k]) is not None
+        filt.sync()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    return ms
+
+
+def other_configs(grid, cells, truth, controls, scans, main_filter, device):
+    """The other single-GPU configurations of BASELINE.json, outside the timed headline region (reported, not the metric):
+    config 3 (10M particles, KLD + selective resampling), a fixed-size 10M and 8M cycle (the >=10M target and the per-GPU
+    share of config 4), config 5 (BeamSensorModel, 1M x 1080) and the worst case for the ordered-lanes kernel: 1M particles
+    dispersed over the whole map (initialize_from_map: global localisation)."""
+    from beluga_amd.amcl import Amcl, AmclParams, BeamModelParam, DifferentialDriveModelParam, LikelihoodFieldModelParam
+    motion = DifferentialDriveModelParam(*ALPHAS)
+    cov = np.diag([0.25, 0.25, 0.04])
+    out = {}
+    # dispersed cloud on the main filter (same map, same 1M capacity): every cycle starts from a fresh uniform set
+    f = main_filter
+    f.profile_enable(2)
+    f.profile_read(reset=True)
+    ms = _timed_cycles(f, controls, scans, 0, 4, reinit=f.initialize_from_map)
+    prof = f.profile_read(reset=True)
+    out["dispersed_1M"] = {"what": "1M particles from initialize_from_map on the 4000x4000 map, fixed N, one update cycle each",
+                           "ms_per_cycle": ms, "cycles_per_s": 1e3 / float(np.median(ms)),
+                           "sensor_kernel_ms": prof["sensor_kernel"][0] / max(prof["sensor_kernel"][1], 1)}
+    f.profile_enable(0)
+    # fixed-size large sets
+    for label, n in (("fixed_8M", 8_000_000), ("fixed_10M", 10_000_000)):
+        g = Amcl(grid, motion, LikelihoodFieldModelParam(**LF), AmclParams(min_particles=n, max_particles=n), seed=42, device=device)
+        g.initialize(truth, cov)
+        for c in range(3):
+            g.update(controls[c], scans[c])
+        g.profile_enable(2)
+        g.profile_read(reset=True)
+        ms = _timed_cycles(g, controls, scans, 3, 5)
+        prof = g.profile_read(reset=True)
+        out[label] = {"what": f"{n} particles x {BEAMS} beams, multinomial resample every cycle (same workload as the headline)",
+                      "ms_per_cycle": ms, "cycles_per_s": 1e3 / float(np.median(ms)),
+                      "sensor_kernel_ms": prof["sensor_kernel"][0] / max(prof["sensor_kernel"][1], 1),
+                      "algorithmic_GBps": lf_algorithmic_bytes(n, BEAMS) / (prof["sensor_kernel"][0] / max(prof["sensor_kernel"][1], 1) * 1e-3) / 1e9}
+        if n == 10_000_000:
+            # config 3 on the same capacity: KLD (eps .05, z 3) + selective resampling from a fresh 10M-particle set
+            g.close()
+            g = Amcl(grid, motion, LikelihoodFieldModelParam(**LF), AmclParams(min_particles=100_000, max_particles=n, selective_resampling=True),
+                     seed=42, device=device)
+            first, counts = [], []
+            for r in range(3):
+                g.initialize(truth, cov)
+                g.sync()
+                t0 = time.perf_counter()
+                assert g.update(controls[r], scans[r]) is not None
+                g.sync()
+                first.append((time.perf_counter() - t0) * 1e3)
+                counts.append(g.last_info["num_particles"])
+            steady = _timed_cycles(g, controls, scans, 3, 8)
+            out["3"] = {"what": "BASELINE configs[2]: max 10M / min 100k particles, KLD (eps .05, z 3) + selective resampling (ESS < N/2)",
+                        "first_cycle_ms_at_10M": first, "cycles_per_s_at_10M": 1e3 / float(np.median(first)),
+                        "particles_after_first_cycle": counts, "steady_state_ms_per_cycle": steady,
+                        "steady_state_particles": g.last_info["num_particles"]}
+        g.close()
+    # config 5
+    n = 1_000_000
+    b = Amcl(grid, motion, BeamModelParam(beam_max_range=MAX_RANGE), AmclParams(min_particles=n, max_particles=n), seed=42, device=device)
+    b.initialize(truth, cov)
+    b.update(controls[0], scans[0])
+    b.beam_cells_visited(reset=True)
+    ms = _timed_cycles(b, controls, scans, 1, 3)
+    visited = b.beam_cells_visited(reset=True)
+    out["5"] = {"what": "BASELINE configs[4]: BeamSensorModel (Bresenham ray casts on the int8 grid), 1M particles x 1080 beams, beam_max_range 30",
+                "ms_per_cycle": ms, "cycles_per_s": 1e3 / float(np.median(ms)), "cells_visited_per_cycle": visited / 3,
+                "cells_per_s": visited / (sum(ms) * 1e-3)}
+    b.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +204,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the 10M / beam / dispersed configurations (reported beside the metric)")
     ap.add_argument("--windows", type=int, default=5, help="repeated timing windows of --steps cycles behind the timed region")
     ap.add_argument("--stage-steps", type=int, default=6, help="cycles of the per-stage breakdown pass")
     ap.add_argument("--sharded", action="store_true", help="use the sharded driver even with one GPU (measures its overhead)")
@@ -214,6 +316,7 @@ def main():
         lf_avg_s = (lf_ms / max(lf_count, 1)) * 1e-3
         bytes_lf = lf_algorithmic_bytes(n_local, BEAMS)
         achieved = bytes_lf / lf_avg_s if lf_avg_s > 0 else 0.0
+        traffic = measured_lf_traffic(n_local) if not use_sharded else None
         out = {
             "metric": "MCL update cycles/sec (motion+sensor+resample), N particles x 1080 beams",
             # whole-job aggregate: one unit = one update cycle of 1M particles x 1080 beams (the configuration the metric is
@@ -247,24 +350,33 @@ def main():
                                "median": float(np.median(window_rates)) if window_rates else None},
             "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in stage_prof.items()},
             "roofline": {
-                "kernel": "k_reweight_lf_palette (likelihood-field reweight)",
+                "kernel": "k_reweight_lf_palette<fast> (likelihood-field reweight)",
+                # The contract's roofline: algorithmic bytes (4 B per particle-beam look-up + the particle's state and
+                # weight + the scan) over the kernel's HIP-event time, against the HBM peak.  It is a figure of merit, not HBM
+                # utilisation: the table is L1 / LDS resident (see `traffic`, `hbm_utilisation`), the kernel is bound by the
+                # vector-memory address pipe (`limiter`).
                 "bound": "hbm",
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
-                # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic_calibration.txt):
-                # 2 * FETCH_SIZE (gfx950 counts half of every read, calibrated on known streams and gathers) + WRITE_SIZE.
-                "traffic": LF_KERNEL_HBM_BYTES_PER_LAUNCH if (n_local == 1_000_000 and not use_sharded) else None,
+                "frac_of_measured_copy_rate": achieved / HBM_MEASURED,
+                "traffic": traffic,
+                "hbm_utilisation": (traffic / lf_avg_s / HBM_PEAK) if (traffic and lf_avg_s > 0) else None,
                 "algorithmic_bytes_per_launch": bytes_lf,
                 "avg_launch_ms": lf_avg_s * 1e3,
                 "launches": int(lf_count),
-                # The table is cache resident (see `traffic`): the kernel's real ceiling is VALU issue.  6 v_mul_f64 + 7 v_add_f64
-                # + 4 32-bit ops per (particle, beam) at the issue costs measured on this part
-                # (profiles/r01_calib_f64_issue_rate.txt: 5.52 / 4.92 / 2.95 nominal cycles per wave64 instruction).
-                "valu_issue_floor_ms": n_local * BEAMS / 64 * (6 * 5.52 + 7 * 4.92 + 4 * 2.95) / (1024 * 2.4e9) * 1e3,
+                "launches_sampled_every": 4,
+                # What actually bounds it (profiles/r02_calib_gather_cost.txt): a 64-lane 2-byte gather with unrelated addresses
+                # costs the CU's texture-address pipe one cycle per quad of lanes (16 per instruction) even inside one cache line;
+                # the VALU side (4 v_fma_f64 + 3 v_add_f64 + 5 32-bit ops per particle-beam) needs 52 SIMD cycles = 13 per CU.
+                "limiter": "vector-memory address pipe (TA): >= 16 CU cycles per scattered 64-lane gather",
+                "ta_floor_ms": n_local * BEAMS / 64 * 16 / (256 * 2.4e9) * 1e3,
+                "valu_issue_floor_ms": n_local * BEAMS / 64 * (4 * 5.76 + 3 * 4.92 + 5 * 2.95) / (1024 * 2.4e9) * 1e3,
             },
         }
+        if not args.no_other_configs and world == 1 and n_local == 1_000_000:
+            out["configs"] = other_configs(grid, cells, truth, controls, scans, filt, local_rank)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cells, truth, odoms, scans, n_total)
         sys.stdout.flush()
