@@ -111,7 +111,10 @@ def _dp(a: np.ndarray):
 
 class Amcl:
     def __init__(self, grid: OccupancyGrid, motion, sensor, params: AmclParams = AmclParams(), *,
-                 seed: int = 0, device: int = 0, shard_offset: int = 0, shard_capacity: int = 0, hip_stream: int = 0):
+                 seed: int = 0, device: int = 0, shard_offset: int = 0, shard_capacity: int = 0, hip_stream: int = 0,
+                 options: Optional[dict] = None):
+        """options: library switches applied before the map is installed (mcl_set_option), e.g. {"field_build": 1} to build
+        the likelihood field with the device's exact distance transform instead of the reference's wavefront on the host."""
         self._lib = capi.load()
         cfg = capi.Config()
         self._lib.mcl_default_config(C.byref(cfg))
@@ -163,6 +166,8 @@ class Amcl:
         self._update_fn = self._lib["mcl_update"]
         self._update_fn.restype = C.c_int32
         self._update_fn.argtypes = [capi._ctx, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
         self.update_map(grid)
 
     # -- lifetime ---------------------------------------------------------------------------------

@@ -196,6 +196,9 @@ struct mcl_ctx {
   DeviceBuffer<uint32_t> d_free;
   uint64_t n_free{0};
   std::vector<float> h_field;
+  DeviceBuffer<uint32_t> d_field_scratch;  // device field build: uint16 column distances + int16 offsets per cell
+  bool field_built_on_device{false};
+  double field_build_ms{0.0};
 
   // scan: staged in mapped pinned host memory and pulled into d_points by a kernel of the cycle (no copy-engine hand-off)
   DeviceBuffer<double> d_points;
@@ -1006,7 +1009,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     MCL_HIP(ctx, hipEventCreateWithFlags(&ctx->points_event, hipEventDisableTiming));
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
-    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "device_policy", "sort_min_particles"}) {
+    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "device_policy", "sort_min_particles", "field_build"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -1032,6 +1035,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& set : ctx->sets) set.release();
   ctx->d_field.release();
+  ctx->d_field_scratch.release();
   ctx->d_cube.release();
   ctx->d_pal_idx.release();
   ctx->d_pal_val.release();
@@ -1102,9 +1106,35 @@ mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   if (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM) {
-    build_likelihood_field(cells, width, height, resolution, ctx->traits, ctx->cfg.lf, ctx->h_field);
     MCL_HIP(ctx, ctx->d_field.ensure(n));
-    MCL_HIP(ctx, hipMemcpy(ctx->d_field.ptr, ctx->h_field.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    bool on_device = false;
+    ctx->field_build_ms = 0.0;
+    if (ctx->tuning.field_build == 1) {
+      // Exact Euclidean distance transform on the device (kernels.hip, "likelihood field on the device"); equal to the
+      // reference's wavefront at all but a few cells.  The default below is the bit-identical host wavefront.
+      const mcl_lf_params& lf = ctx->cfg.lf;
+      const FieldBuildParams fp{lf.max_obstacle_distance, lf.max_laser_distance, lf.z_hit, lf.z_random, lf.sigma_hit,
+                                lf.model_unknown_space, lf.only_obstacle_boundaries};
+      MCL_HIP(ctx, ctx->d_field_scratch.ensure(n));
+      MCL_HIP(ctx, hipEventRecord(ctx->ev[MCL_STAGE_REWEIGHT][0], ctx->stream));
+      on_device = launch_build_field(ctx->stream, ctx->d_cells.ptr, width, height, resolution, ctx->traits.free_value, ctx->traits.unknown_value,
+                                     ctx->traits.occupied_value, fp, reinterpret_cast<uint16_t*>(ctx->d_field_scratch.ptr),
+                                     reinterpret_cast<int16_t*>(ctx->d_field_scratch.ptr) + n, ctx->d_field.ptr);
+      MCL_HIP(ctx, hipGetLastError());
+      if (on_device) {
+        MCL_HIP(ctx, hipEventRecord(ctx->ev[MCL_STAGE_REWEIGHT][1], ctx->stream));
+        ctx->h_field.resize(n);
+        MCL_HIP(ctx, hipMemcpyAsync(ctx->h_field.data(), ctx->d_field.ptr, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[MCL_STAGE_REWEIGHT][0], ctx->ev[MCL_STAGE_REWEIGHT][1]) == hipSuccess) ctx->field_build_ms = ms;
+      }
+    }
+    if (!on_device) {
+      build_likelihood_field(cells, width, height, resolution, ctx->traits, ctx->cfg.lf, ctx->h_field);
+      MCL_HIP(ctx, hipMemcpy(ctx->d_field.ptr, ctx->h_field.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    ctx->field_built_on_device = on_device;
     if (const mcl_status s = rebuild_cube(ctx, ctx->h_field.data())) return s;
   }
   ctx->have_map = true;
@@ -1796,6 +1826,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "lf_fast") t.lf_fast = value < 0 ? -1 : (value ? 1 : 0);
   else if (key == "lf_table") t.lf_table = value ? 1 : 0;
   else if (key == "device_policy") t.device_policy = value ? 1 : 0;
+  else if (key == "field_build") t.field_build = value ? 1 : 0;
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "mcl_set_option: unknown option " + key);
   return MCL_OK;
@@ -1805,6 +1836,8 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
   if (!ctx || !name || !value) return MCL_ERR_INVALID_ARGUMENT;
   const std::string key(name);
   if (key == "lf_fast_launches") *value = ctx->lf_fast_launches;
+  else if (key == "field_build_us") *value = static_cast<uint64_t>(ctx->field_build_ms * 1e3);  // kernels of the last device field build
+  else if (key == "field_built_on_device") *value = ctx->field_built_on_device ? 1 : 0;
   else return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "mcl_get_counter: unknown counter " + key);
   return MCL_OK;
 }

@@ -109,6 +109,7 @@ struct Tuning {
   int lf_table = 0;                 // 0 = palette table when the field allows it, 1 = force the 8-byte cube table
   int device_policy = 1;            // recovery estimator on the device when the cycle has no host-side decision
   int sort_min_particles = 16384;   // below this the ordering passes cost more than they save
+  int field_build = 0;              // mcl_set_map: 0 = host wavefront (bit-identical to the reference), 1 = exact EDT on the device
 };
 
 // Spatial ordering of the particles (kLfSortedLanes, ordered beam kernel): the 64 lanes of a wave should hold neighbouring
@@ -284,6 +285,17 @@ void launch_init_normal(hipStream_t st, Particles p, uint64_t n, const double me
 // initialize_from_map: multivariate_uniform_distribution.hpp:126-161 over the free cells, weight 1
 void launch_init_from_map(hipStream_t st, Particles p, uint64_t n, uint64_t seed, uint64_t index_offset, GridView g, FreeCells fc);
 void launch_fill(hipStream_t st, double* p, uint64_t n, double v);
+// Likelihood field built on the device: exact Euclidean distance transform + the reference's Gaussian map, unknown-space
+// overlay and edge mask (likelihood_field_model_base.hpp:130-185).  Scratch: W * H uint16 and int16.  Returns false (nothing
+// launched) when max_obstacle_distance spans more than kFieldBuildMaxReach cells: the caller then builds on the host.
+constexpr double kFieldBuildMaxReach = 1024.0;
+struct FieldBuildParams {
+  double max_obstacle_distance, max_laser_distance, z_hit, z_random, sigma_hit;
+  int model_unknown_space, only_obstacle_boundaries;
+};
+bool launch_build_field(hipStream_t st, const int8_t* d_cells, uint32_t W, uint32_t H, double resolution, int8_t free_value,
+                        int8_t unknown_value, int8_t occupied_value, const FieldBuildParams& fp, uint16_t* d_column_distance,
+                        int16_t* d_column_offset, float* d_field);
 // cube[i] = double(field[i])^3 (or log(double(field[i])) for the prob model) for i < cells, cube[cells] = same for `unknown`
 void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube, int prob);
 // keys: the sorted bit patterns of the distinct field values (count entries, unknown_value among them)

@@ -2265,6 +2265,104 @@ __global__ __launch_bounds__(kBlock) void k_init_from_map(Particles p, uint64_t 
   p.w[i] = 1.0;  // particle_traits.hpp:105
 }
 
+// ---- likelihood field on the device -----------------------------------------------------------
+// LikelihoodFieldModelBase::make_likelihood_field (likelihood_field_model_base.hpp:130-185) with an EXACT Euclidean distance
+// transform in place of nearest_obstacle_distance_map (distance_map.hpp:55-98), whose priority-queue wavefront hands every
+// cell the obstacle of whichever neighbour reaches it first — not always the nearest one.  The device field is therefore
+// <= the reference's distance (>= its likelihood) and equal at all but a few cells; mcl_set_map's default stays the
+// bit-identical host wavefront (map_build.cpp), this build is selected with option field_build = 1.
+//   pass 1 (k_edt_columns): per column, distance in cells to the nearest seed of the column, capped (two sweeps);
+//   pass 2 (k_edt_field): per cell, min over the capped row neighbourhood of dx^2 + g^2 (row segment staged in LDS), the
+//   squared metric distance to that seed as the reference computes it (double arithmetic on cell centres, float result),
+//   the cap, the unknown-space overlay and the Gaussian map.
+constexpr int kEdtInf = 0xFFFF;
+struct EdtParams {
+  uint32_t W, H;
+  double resolution;
+  int8_t free_value, unknown_value, occupied_value;
+  int only_obstacle_boundaries, model_unknown_space;
+  int cap_cells;               // seeds farther than this (per axis) cannot be within max_obstacle_distance
+  float max_sq, overlay_sq;    // squared max_obstacle_distance; squared distance written over unknown space
+  double amplitude, two_squared_sigma, offset;
+};
+__device__ __forceinline__ bool edt_obstacle_edge(const int8_t* __restrict__ cells, const EdtParams& p, uint32_t x, uint32_t y) {
+  const size_t i = static_cast<size_t>(y) * p.W + x;  // occupancy_grid.hpp:191-206: occupied with a free 4-neighbour
+  if (cells[i] != p.occupied_value) return false;
+  return (x + 1 < p.W && cells[i + 1] == p.free_value) || (y + 1 < p.H && cells[i + p.W] == p.free_value) ||
+         (x > 0 && cells[i - 1] == p.free_value) || (y > 0 && cells[i - p.W] == p.free_value);
+}
+__device__ __forceinline__ bool edt_seed(const int8_t* __restrict__ cells, const EdtParams& p, uint32_t x, uint32_t y) {
+  return p.only_obstacle_boundaries ? edt_obstacle_edge(cells, p, x, y) : cells[static_cast<size_t>(y) * p.W + x] == p.occupied_value;
+}
+// column_distance[y][x] = |y - y'| of the nearest seed (x, y') of column x, kEdtInf beyond the cap; column_offset = y' - y.
+__global__ __launch_bounds__(kBlock) void k_edt_columns(const int8_t* __restrict__ cells, EdtParams p, uint16_t* __restrict__ column_distance,
+                                                        int16_t* __restrict__ column_offset) {
+  const uint32_t x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= p.W) return;
+  int since = kEdtInf;  // rows since the last seed, going down the column
+  for (uint32_t y = 0; y < p.H; ++y) {
+    since = edt_seed(cells, p, x, y) ? 0 : (since >= p.cap_cells ? kEdtInf : since + 1);
+    const size_t i = static_cast<size_t>(y) * p.W + x;
+    column_distance[i] = static_cast<uint16_t>(since);
+    column_offset[i] = static_cast<int16_t>(-since);
+  }
+  since = kEdtInf;
+  for (uint32_t yy = p.H; yy > 0; --yy) {
+    const uint32_t y = yy - 1;
+    const size_t i = static_cast<size_t>(y) * p.W + x;
+    since = column_distance[i] == 0 ? 0 : (since >= p.cap_cells ? kEdtInf : since + 1);
+    if (since < column_distance[i]) {
+      column_distance[i] = static_cast<uint16_t>(since);
+      column_offset[i] = static_cast<int16_t>(since);
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_edt_field(const int8_t* __restrict__ cells, EdtParams p, const uint16_t* __restrict__ column_distance,
+                                                      const int16_t* __restrict__ column_offset, float* __restrict__ field) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* s_g = reinterpret_cast<uint16_t*>(smem);
+  const uint32_t y = blockIdx.y;
+  const int x0 = static_cast<int>(blockIdx.x * kBlock), R = p.cap_cells;
+  const int span = kBlock + 2 * R;
+  for (int k = threadIdx.x; k < span; k += kBlock) {
+    const int xs = x0 - R + k;
+    s_g[k] = (xs >= 0 && xs < static_cast<int>(p.W)) ? column_distance[static_cast<size_t>(y) * p.W + xs] : static_cast<uint16_t>(kEdtInf);
+  }
+  __syncthreads();
+  const int x = x0 + static_cast<int>(threadIdx.x);
+  if (x >= static_cast<int>(p.W)) return;
+  int best = 0x7FFFFFFF, best_dx = 0;
+  for (int dx = 0; dx <= R && dx * dx < best; ++dx) {  // outwards: a candidate column farther than the best distance cannot win
+    const int gl = s_g[threadIdx.x + R - dx], gr = s_g[threadIdx.x + R + dx];
+    if (gl != kEdtInf && dx * dx + gl * gl < best) {
+      best = dx * dx + gl * gl;
+      best_dx = -dx;
+    }
+    if (gr != kEdtInf && dx * dx + gr * gr < best) {
+      best = dx * dx + gr * gr;
+      best_dx = dx;
+    }
+  }
+  const size_t i = static_cast<size_t>(y) * p.W + static_cast<size_t>(x);
+  float squared = p.max_sq;
+  if (best != 0x7FFFFFFF) {
+    const int ox = x + best_dx, oy = static_cast<int>(y) + column_offset[static_cast<size_t>(y) * p.W + ox];
+    // likelihood_field_model_base.hpp:131-133 over regular_grid.hpp:87-89: cell centres in double, float result
+    const double ax = (static_cast<double>(x) + 0.5) * p.resolution, ay = (static_cast<double>(static_cast<int>(y)) + 0.5) * p.resolution;
+    const double bx = (static_cast<double>(ox) + 0.5) * p.resolution, by = (static_cast<double>(oy) + 0.5) * p.resolution;
+    const double ddx = ax - bx, ddy = ay - by;
+    const float d = static_cast<float>(ddx * ddx + ddy * ddy);
+    if (d < p.max_sq) squared = d;  // distance_map.hpp:87-90
+  }
+  if (p.model_unknown_space) {  // :160-179
+    const int8_t c = cells[i];
+    const bool masked = p.only_obstacle_boundaries ? (c == p.unknown_value || (c == p.occupied_value && !edt_obstacle_edge(cells, p, x, y)))
+                                                   : c == p.unknown_value;
+    if (masked) squared = p.overlay_sq;
+  }
+  field[i] = static_cast<float>(p.amplitude * exp(-static_cast<double>(squared) / p.two_squared_sigma) + p.offset);  // :146,181-182
+}
+
 __global__ __launch_bounds__(kBlock) void k_cube_table(const float* __restrict__ field, uint64_t cells, float unknown_value,
                                                        double* __restrict__ cube, int prob) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -2690,6 +2788,34 @@ void launch_init_normal(hipStream_t st, Particles p, uint64_t n, const double me
 void launch_init_from_map(hipStream_t st, Particles p, uint64_t n, uint64_t seed, uint64_t index_offset, GridView g, FreeCells fc) {
   if (n == 0) return;
   hipLaunchKernelGGL(k_init_from_map, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, seed, index_offset, g, fc);
+}
+
+bool launch_build_field(hipStream_t st, const int8_t* d_cells, uint32_t W, uint32_t H, double resolution, int8_t free_value,
+                        int8_t unknown_value, int8_t occupied_value, const FieldBuildParams& fp, uint16_t* d_column_distance,
+                        int16_t* d_column_offset, float* d_field) {
+  constexpr double kPiD = 3.14159265358979323846264338327950288;
+  EdtParams p{};
+  p.W = W;
+  p.H = H;
+  p.resolution = resolution;
+  p.free_value = free_value;
+  p.unknown_value = unknown_value;
+  p.occupied_value = occupied_value;
+  p.only_obstacle_boundaries = fp.only_obstacle_boundaries;
+  p.model_unknown_space = fp.model_unknown_space;
+  const double cells_in_reach = std::ceil(fp.max_obstacle_distance / resolution) + 1.0;
+  if (!(cells_in_reach <= kFieldBuildMaxReach) || H >= 32768) return false;  // wide caps: the host build
+  p.cap_cells = static_cast<int>(cells_in_reach);
+  p.max_sq = static_cast<float>(fp.max_obstacle_distance * fp.max_obstacle_distance);
+  p.two_squared_sigma = 2 * fp.sigma_hit * fp.sigma_hit;
+  p.amplitude = fp.z_hit / (fp.sigma_hit * std::sqrt(2 * kPiD));
+  p.offset = fp.z_random / fp.max_laser_distance;
+  const double squared_background_distance = -p.two_squared_sigma * std::log((1 / fp.max_laser_distance - p.offset) / p.amplitude);
+  p.overlay_sq = std::min(p.max_sq, static_cast<float>(squared_background_distance));
+  hipLaunchKernelGGL(k_edt_columns, dim3(blocks_for(W)), dim3(kBlock), 0, st, d_cells, p, d_column_distance, d_column_offset);
+  const size_t lds = static_cast<size_t>(kBlock + 2 * p.cap_cells) * sizeof(uint16_t);
+  hipLaunchKernelGGL(k_edt_field, dim3(blocks_for(W), H), dim3(kBlock), lds, st, d_cells, p, d_column_distance, d_column_offset, d_field);
+  return true;
 }
 
 void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube, int prob) {

@@ -265,8 +265,11 @@ class Amcl {
   using measurement_type = std::vector<std::pair<double, double>>;
   using estimation_type = std::pair<SE2d, Matrix3d>;
 
+  /// `options`: library switches applied before the map is installed (mcl_set_option), e.g. {{"field_build", 1}} to build
+  /// the likelihood field with the device's exact distance transform instead of the reference's wavefront on the host.
   Amcl(const OccupancyGridView& map, const MotionModelParam& motion, const SensorModelParam& sensor,
-       const AmclParams& params = AmclParams{}, std::uint64_t seed = 0, int device = 0) {
+       const AmclParams& params = AmclParams{}, std::uint64_t seed = 0, int device = 0,
+       const std::vector<std::pair<std::string, std::int64_t>>& options = {}) {
     mcl_config cfg;
     mcl_default_config(&cfg);
     cfg.device_id = device;
@@ -314,6 +317,7 @@ class Amcl {
     const mcl_status st = mcl_create(&cfg, &ctx_);
     if (st != MCL_OK) throw std::runtime_error(std::string("beluga_amd::Amcl: ") + mcl_last_error(nullptr));
     try {
+      for (const auto& [name, value] : options) check(mcl_set_option(ctx_, name.c_str(), value));
       update_map(map);
     } catch (...) {
       mcl_destroy(ctx_);

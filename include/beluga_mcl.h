@@ -331,14 +331,19 @@ mcl_status mcl_profile_read(mcl_ctx* ctx, double ms[MCL_NUM_STAGES], uint64_t co
 /* Beam model only: grid cells visited by the ray walks since the last reset (cells/s). */
 mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
 
-/* ---- Switches and hooks for A/B measurements and tests; no option changes a result. ---------------------------
+/* ---- Switches and hooks for A/B measurements and tests; no option but field_build changes a result. -----------
  * Options (defaults in parentheses; BELUGA_MCL_<NAME> in the environment sets the default at mcl_create):
  *   lf_variant (2)  likelihood-field kernel family: 2 = spatially ordered lanes, 1 = lane per particle, 0 = wave per particle
  *   lf_fast (-1)    FMA variant with exact fallback: nonzero = whenever its preconditions hold, 0 = never
  *   lf_table (0)    1 = force the 8-byte table instead of the palette
  *   device_policy (1)  recovery estimator on the device when the cycle takes no host-side decision
  *   sort_min_particles (16384)  below this many particles the spatial ordering is skipped
- * Counters: lf_fast_launches = launches of the FMA variant so far. */
+ *   field_build (0)  how the NEXT mcl_set_map builds the likelihood field: 0 = the reference's priority-queue wavefront on the
+ *                    host (bit-identical field, seconds at 16 M cells), 1 = exact Euclidean distance transform on the device
+ *                    (milliseconds; equal at all but the few cells where the wavefront does not find the nearest obstacle,
+ *                    never farther from the truth; falls back to 0 when max_obstacle_distance spans more than 1024 cells).
+ *                    This one DOES change the field where the two algorithms differ; everything downstream follows the field.
+ * Counters: lf_fast_launches = launches of the FMA variant so far; field_built_on_device, field_build_us = the last mcl_set_map. */
 mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value);
 mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value);
 /* Runs the spatial ordering on the current set and returns it: perm[t] = particle at position t, keys[i] = ordering key
