@@ -437,6 +437,12 @@ class Amcl:
         level = 2 if on is True else int(on)
         self._check(self._lib.mcl_profile_enable(self._ctx, level))
 
+    def comm_attach_rccl(self, unique_id: bytes, rank: int, world: int):
+        """Joins the RCCL communicator of a sharded filter (include/beluga_mcl.h, "Particle shards"): this context must have been
+        created with its shard_offset / shard_capacity; update() then runs the cycle over all shards."""
+        assert len(unique_id) == 128
+        self._check(self._lib.mcl_comm_attach_rccl(self._ctx, unique_id, rank, world))
+
     def set_option(self, name: str, value: int):
         """A/B switch of the library (include/beluga_mcl.h, mcl_set_option); no option changes a result."""
         self._check(self._lib.mcl_set_option(self._ctx, name.encode(), int(value)))
@@ -507,3 +513,13 @@ def project_point_cloud(points_xyz, origin_se3=(0, 0, 0, 1, 0, 0, 0)) -> np.ndar
     if st != capi.MCL_OK:
         raise capi.MclError(st, "mcl_project_point_cloud")
     return out
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 calls it and hands the 128 bytes to the other ranks)."""
+    lib = capi.load()
+    buf = C.create_string_buffer(128)
+    st = lib.mcl_comm_unique_id(buf)
+    if st != capi.MCL_OK:
+        raise capi.MclError(st, lib.mcl_last_error(None).decode())
+    return buf.raw

@@ -159,6 +159,9 @@ _SIGNATURES = {
     "mcl_get_likelihood_field_origin": (C.c_int32, [_ctx, c_double_p]),
     "mcl_project_point_cloud": (C.c_int32, [c_float_p, C.c_uint64, c_double_p, c_double_p]),
     "mcl_update_point_cloud": (C.c_int32, [_ctx, c_double_p, c_float_p, C.c_uint64, c_double_p, C.POINTER(Estimate), C.POINTER(UpdateInfo)]),
+    "mcl_comm_attach": (C.c_int32, [_ctx, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "mcl_comm_unique_id": (C.c_int32, [C.c_char_p]),
+    "mcl_comm_attach_rccl": (C.c_int32, [_ctx, C.c_char_p, C.c_uint32, C.c_uint32]),
     "mcl_set_option": (C.c_int32, [_ctx, C.c_char_p, C.c_int64]),
     "mcl_get_counter": (C.c_int32, [_ctx, C.c_char_p, c_u64_p]),
     "mcl_debug_order": (C.c_int32, [_ctx, c_u32_p, c_u32_p]),

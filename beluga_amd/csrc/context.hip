@@ -5,6 +5,7 @@
 // device-computed sums; everything that touches N particles is a kernel launch on the context's
 // stream (kernels.hip).  There is no CPU fallback for any per-particle stage.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cctype>
@@ -266,6 +267,18 @@ struct mcl_ctx {
   DeviceBuffer<uint32_t> d_sort_u32;            // keys[cap] perm[cap] table[1024 * nblocks] totals[1024]
   DeviceBuffer<unsigned long long> d_sort_u64;  // keyidx[cap]
   DeviceBuffer<double> d_sort_f64;              // frame[8] bbox[8 + 6*nblocks] partial[...]
+
+  // particle shards: communicator + scratch of the exchange (sharded_update)
+  bool have_comm{false};
+  uint32_t comm_rank{0}, comm_world{1};
+  mcl_transport transport{};
+  void* rccl_comm{nullptr};                 // ncclComm_t when the transport is the built-in RCCL one
+  struct RcclUserStorage { void* comm; uint32_t rank, world; } rccl_user{nullptr, 0, 1};
+  DeviceBuffer<double> d_comm_f64;          // [0..8) locals | gathered scalars | ends, offsets | estimate gather
+  DeviceBuffer<long long> d_comm_i64;       // counts[world] | gathered counts[world * world]
+  DeviceBuffer<double> d_targets, d_send_targets, d_requests_in, d_replies_out, d_replies_in;
+  DeviceBuffer<uint32_t> d_route_order;
+  double* h_comm{nullptr};                  // pinned staging for the exchange's host reads / uploads
 
   // profiling: 0 = off, 1 = the sensor kernel only (two events per cycle), 2 = every stage
   int profile{0};
@@ -933,6 +946,256 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
   return mcl_estimate_from_sums(sums, out);
 }
 
+
+// ---- particle shards: the cycle over a communicator --------------------------------------------------------------------
+constexpr size_t kCommScalars = 16;  // d_comm_f64[0] local sum | [1] cdf total | [2] norm sum | [3] norm sumsq | [4] global sum | [5..14) estimate sums
+
+mcl_status comm_scratch(mcl_ctx* ctx) {
+  const size_t world = ctx->comm_world;
+  MCL_HIP(ctx, ctx->d_comm_f64.ensure(kCommScalars + world * (1 + 3 + 2 + 9)));
+  MCL_HIP(ctx, ctx->d_comm_i64.ensure(world + world * world));
+  if (!ctx->h_comm) MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_comm), (kCommScalars + 64 * (1 + 3 + 2 + 9) + 64 * 64 + 64) * sizeof(double)));
+  return MCL_OK;
+}
+mcl_status comm_gather(mcl_ctx* ctx, const void* d_send, void* d_recv, uint64_t bytes) {
+  if (ctx->transport.all_gather(ctx->transport.user, d_send, d_recv, bytes, ctx->stream) != 0)
+    return fail(ctx, MCL_ERR_HIP, "transport all_gather failed");
+  return MCL_OK;
+}
+mcl_status comm_exchange(mcl_ctx* ctx, const void* d_send, const uint64_t* send_bytes, void* d_recv, const uint64_t* recv_bytes) {
+  if (ctx->transport.all_to_all(ctx->transport.user, d_send, send_bytes, d_recv, recv_bytes, ctx->stream) != 0)
+    return fail(ctx, MCL_ERR_HIP, "transport all_to_all failed");
+  return MCL_OK;
+}
+
+// beluga::Amcl::update (amcl_core.hpp:165-201) over the sharded set; same statements as mcl_update, with the exchanges of
+// include/beluga_mcl.h ("Particle shards") between them.  Every rank takes the same decisions: they depend on the control
+// action (identical inputs) and on gathered sums (identical values, added in rank order everywhere).
+mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_xy, uint64_t num_points, mcl_estimate* estimate,
+                          mcl_update_info* info) {
+  const mcl_amcl_params& ap = ctx->cfg.amcl;
+  const uint32_t world = ctx->comm_world, rank = ctx->comm_rank;
+  const uint64_t n_total = ap.max_particles;
+  if (ap.min_particles < ap.max_particles)
+    return fail(ctx, MCL_ERR_UNSUPPORTED, "sharded mcl_update handles a fixed particle count (min_particles >= max_particles); the KLD-adaptive "
+                                          "cut over shards goes through the stage-level entry points");
+  if (ctx->estimate_kind != 0) return fail(ctx, MCL_ERR_UNSUPPORTED, "sharded mcl_update returns beluga::estimate");
+  if (const mcl_status s = comm_scratch(ctx)) return s;
+  if (const mcl_status s = stage_points(ctx, points_xy, num_points)) return s;
+  if (!ctx->have_window) {
+    ctx->window0 = ctx->window1 = pose;
+    ctx->have_window = true;
+  } else {
+    ctx->window1 = ctx->window0;
+    ctx->window0 = pose;
+  }
+  ctx->step += 1;
+  double* d = ctx->d_comm_f64.ptr;
+  double* d_gather_sums = d + kCommScalars;            // [world]
+  double* d_gather_stats = d_gather_sums + world;      // [world][3]
+  double* d_intervals = d_gather_stats + 3 * world;    // ends[world], offsets[world]
+  double* d_gather_est = d_intervals + 2 * world;      // [world][9]
+  long long* d_counts = ctx->d_comm_i64.ptr;           // [world]
+  long long* d_all_counts = d_counts + world;          // [world][world]
+  double* h = ctx->h_comm;
+
+  bool keys_ready = false;
+  if (const mcl_status s = do_propagate(ctx, ctx->window0, ctx->window1, ctx->step, num_points, &keys_ready)) return s;  // :174-175
+  if (const mcl_status s = do_reweight(ctx, points_xy, num_points, true, keys_ready)) return s;                         // :176
+  ctx->every_n_current = (ctx->every_n_current + 1) % ap.resample_interval;  // every_n does not depend on data
+  const bool fires = ctx->every_n_current == 0;
+  // :177 normalise by the GLOBAL sum: shard sums gathered, added in rank order by every rank
+  stage_begin(ctx, MCL_STAGE_NORMALIZE);
+  launch_weight_sum(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), d + 0);
+  if (const mcl_status s = comm_gather(ctx, d + 0, d_gather_sums, sizeof(double))) return s;
+  launch_sum_rows(ctx->stream, d_gather_sums, world, 1, d + 4, nullptr);
+  launch_normalize(ctx->stream, ctx->cur().w, ctx->n, d + 4, ctx->chunk_row(1), ctx->chunk_row(2), d + 2);
+  stage_end(ctx, MCL_STAGE_NORMALIZE);
+  if (fires) {
+    launch_cdf(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(3), ctx->chunk_row(4), ctx->d_cdf.ptr, d + 1, ctx->d_cdf_tree.ptr,
+               ctx->chunk_row(1));
+  } else {
+    MCL_HIP(ctx, hipMemsetAsync(d + 1, 0, sizeof(double), ctx->stream));
+  }
+  MCL_HIP(ctx, hipGetLastError());
+  if (const mcl_status s = comm_gather(ctx, d + 1, d_gather_stats, 3 * sizeof(double))) return s;
+  MCL_HIP(ctx, hipMemcpyAsync(h, d + 4, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MCL_HIP(ctx, hipMemcpyAsync(h + 1, d_gather_stats, 3 * world * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  stage_collect(ctx);
+  const double weight_sum = h[0];
+  double norm_sum = 0.0, norm_sumsq = 0.0;
+  for (uint32_t r = 0; r < world; ++r) {
+    norm_sum += h[1 + 3 * r + 1];
+    norm_sumsq += h[1 + 3 * r + 2];
+  }
+  // :179 ThrunRecoveryProbabilityEstimator on the normalised weights
+  double random_state_probability = 0.0;
+  {
+    const double average = norm_sum / static_cast<double>(n_total);
+    const double fast_average = ctx->fast(average), slow_average = ctx->slow(average);
+    if (std::abs(slow_average) >= std::numeric_limits<double>::epsilon())
+      random_state_probability = std::clamp(1.0 - fast_average / slow_average, 0.0, 1.0);
+  }
+  bool do_resampling = fires;
+  double ess = -1.0;
+  if (do_resampling && ap.selective_resampling) {  // :181 && on_effective_size_drop
+    ess = norm_sum == 0.0 ? 0.0 : (norm_sum * norm_sum) / norm_sumsq;
+    do_resampling = ess < static_cast<double>(n_total) * 0.5;
+  }
+  if (do_resampling) {
+    if (random_state_probability > 0.0) {  // :184-186
+      ctx->slow.reset();
+      ctx->fast.reset();
+    }
+    stage_begin(ctx, MCL_STAGE_RESAMPLE);
+    // intervals of the global CDF: ends[r] = inclusive end of shard r, offsets[r] = its start
+    double* up = h + 1 + 3 * world;
+    double run = 0.0;
+    for (uint32_t r = 0; r < world; ++r) {
+      up[world + r] = run;
+      run += h[1 + 3 * r];
+      up[r] = run;
+    }
+    const double total = run;
+    MCL_HIP(ctx, hipMemcpyAsync(d_intervals, up, 2 * world * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t m = ctx->n, first_slot = ctx->cfg.shard_offset;
+    MCL_HIP(ctx, ctx->d_targets.ensure(m));
+    MCL_HIP(ctx, ctx->d_send_targets.ensure(m));
+    MCL_HIP(ctx, ctx->d_route_order.ensure(m));
+    MCL_HIP(ctx, ctx->d_replies_in.ensure(4 * m));
+    if (const mcl_status s = mcl_resample_targets(ctx, ctx->step, random_state_probability, total, first_slot, m, ctx->d_targets.ptr)) return s;
+    if (const mcl_status s = mcl_route_targets(ctx, ctx->d_targets.ptr, m, d_intervals, d_intervals + world, world, rank, ctx->d_send_targets.ptr,
+                                               ctx->d_route_order.ptr, reinterpret_cast<int64_t*>(d_counts))) return s;
+    if (const mcl_status s = comm_gather(ctx, d_counts, d_all_counts, world * sizeof(long long))) return s;  // counts[r][q]: r asks q
+    long long* h_counts = reinterpret_cast<long long*>(up + 2 * world);
+    MCL_HIP(ctx, hipMemcpyAsync(h_counts, d_all_counts, world * world * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> send_requests(world), recv_requests(world), send_replies(world), recv_replies(world);
+    uint64_t incoming = 0;
+    for (uint32_t q = 0; q < world; ++q) {
+      const uint64_t out = static_cast<uint64_t>(h_counts[rank * world + q]), in = static_cast<uint64_t>(h_counts[q * world + rank]);
+      send_requests[q] = out * sizeof(double);
+      recv_requests[q] = in * sizeof(double);
+      send_replies[q] = in * 4 * sizeof(double);
+      recv_replies[q] = out * 4 * sizeof(double);
+      incoming += in;
+    }
+    MCL_HIP(ctx, ctx->d_requests_in.ensure(std::max<uint64_t>(incoming, 1)));
+    MCL_HIP(ctx, ctx->d_replies_out.ensure(std::max<uint64_t>(4 * incoming, 4)));
+    if (const mcl_status s = comm_exchange(ctx, ctx->d_send_targets.ptr, send_requests.data(), ctx->d_requests_in.ptr, recv_requests.data())) return s;
+    if (incoming) {
+      if (const mcl_status s = mcl_serve_requests(ctx, ctx->d_requests_in.ptr, incoming, ctx->d_replies_out.ptr)) return s;
+    }
+    if (const mcl_status s = comm_exchange(ctx, ctx->d_replies_out.ptr, send_replies.data(), ctx->d_replies_in.ptr, recv_replies.data())) return s;
+    if (const mcl_status s = mcl_commit_routed(ctx, ctx->step, first_slot, m, ctx->d_replies_in.ptr, ctx->d_route_order.ptr, ctx->d_targets.ptr)) return s;
+    stage_end(ctx, MCL_STAGE_RESAMPLE);
+  }
+  ctx->force_update = false;  // :199
+  // :200 estimate: nine sums per shard, gathered, added in rank order
+  stage_begin(ctx, MCL_STAGE_ESTIMATE);
+  launch_estimate_sums(ctx->stream, ctx->cur(), ctx->n, ctx->pivot[0], ctx->pivot[1], ctx->chunk_row(0), d + 5);
+  if (const mcl_status s = comm_gather(ctx, d + 5, d_gather_est, 9 * sizeof(double))) return s;
+  launch_sum_rows(ctx->stream, d_gather_est, world, 9, ctx->d_scalars.ptr + 8, ctx->hd_scalars + 8);
+  stage_end(ctx, MCL_STAGE_ESTIMATE);
+  MCL_HIP(ctx, hipGetLastError());
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  stage_collect(ctx);
+  double sums[12];
+  for (int k = 0; k < 9; ++k) sums[k] = ctx->h_scalars[8 + k];
+  sums[9] = ctx->pivot[0];
+  sums[10] = ctx->pivot[1];
+  sums[11] = 0.0;
+  mcl_estimate est{};
+  if (const mcl_status s = mcl_estimate_from_sums(sums, &est)) return s;
+  if (std::isfinite(est.pose[2]) && std::isfinite(est.pose[3])) {
+    ctx->pivot[0] = est.pose[2];
+    ctx->pivot[1] = est.pose[3];
+  }
+  remember_cloud_estimate(ctx, est);
+  if (estimate) *estimate = est;
+  if (info) {
+    info->updated = 1;
+    info->resampled = do_resampling ? 1 : 0;
+    info->num_particles = n_total;
+    info->weight_sum = weight_sum;
+    info->effective_sample_size = ess;
+    info->random_state_probability = random_state_probability;
+  }
+  return MCL_OK;
+}
+
+// ---- built-in RCCL transport (librccl.so loaded at run time) ------------------------------------------------------------
+struct RcclId {  // ncclUniqueId: 128 opaque bytes, passed by value
+  char internal[128];
+};
+struct RcclApi {
+  void* lib{nullptr};
+  int (*GetUniqueId)(void*){nullptr};
+  int (*CommInitRank)(void**, int, RcclId, int){nullptr};
+  int (*CommDestroy)(void*){nullptr};
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t){nullptr};
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t){nullptr};
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t){nullptr};
+  int (*GroupStart)(){nullptr};
+  int (*GroupEnd)(){nullptr};
+};
+RcclApi* rccl_api(std::string* error) {
+  static RcclApi api;
+  static bool tried = false;
+  static std::string load_error;
+  if (!tried) {
+    tried = true;
+    const char* candidates[] = {std::getenv("BELUGA_MCL_RCCL"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // a copy that is already in the process (torch ships one) is used first: two RCCLs in one process do not mix
+    for (const char* name : {"librccl.so", "librccl.so.1"})
+      if (!api.lib) api.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : candidates)
+      if (!api.lib && name) api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!api.lib) {
+      load_error = "librccl.so not found (set BELUGA_MCL_RCCL to its path)";
+    } else {
+      auto sym = [&](const char* n) { return dlsym(api.lib, n); };
+      api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+      api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+      api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+      api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+      api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+      api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+      api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+      api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
+        load_error = "librccl.so lacks an expected symbol";
+    }
+  }
+  if (!load_error.empty()) {
+    if (error) *error = load_error;
+    return nullptr;
+  }
+  return &api;
+}
+constexpr int kNcclChar = 0;  // ncclInt8 / ncclChar
+using RcclUser = mcl_ctx::RcclUserStorage;
+int32_t rccl_all_gather(void* user, const void* d_send, void* d_recv, uint64_t bytes, void* stream) {
+  auto* u = static_cast<RcclUser*>(user);
+  return rccl_api(nullptr)->AllGather(d_send, d_recv, bytes, kNcclChar, u->comm, static_cast<hipStream_t>(stream));
+}
+int32_t rccl_all_to_all(void* user, const void* d_send, const uint64_t* send_bytes, void* d_recv, const uint64_t* recv_bytes, void* stream) {
+  auto* u = static_cast<RcclUser*>(user);
+  RcclApi* api = rccl_api(nullptr);
+  int rc = api->GroupStart();
+  const char* out = static_cast<const char*>(d_send);
+  char* in = static_cast<char*>(d_recv);
+  for (uint32_t q = 0; q < u->world && rc == 0; ++q) {
+    if (send_bytes[q]) rc = api->Send(out, send_bytes[q], kNcclChar, static_cast<int>(q), u->comm, static_cast<hipStream_t>(stream));
+    if (rc == 0 && recv_bytes[q]) rc = api->Recv(in, recv_bytes[q], kNcclChar, static_cast<int>(q), u->comm, static_cast<hipStream_t>(stream));
+    out += send_bytes[q];
+    in += recv_bytes[q];
+  }
+  const int end = api->GroupEnd();
+  return rc ? rc : end;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1065,6 +1328,18 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_cell_u64.release();
   ctx->d_sort_u64.release();
   ctx->d_sort_f64.release();
+  if (ctx->rccl_comm) {
+    if (RcclApi* api = rccl_api(nullptr)) (void)api->CommDestroy(ctx->rccl_comm);
+  }
+  if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+  ctx->d_comm_f64.release();
+  ctx->d_comm_i64.release();
+  ctx->d_targets.release();
+  ctx->d_send_targets.release();
+  ctx->d_requests_in.release();
+  ctx->d_replies_out.release();
+  ctx->d_replies_in.release();
+  ctx->d_route_order.release();
   if (ctx->h_points) (void)hipHostFree(ctx->h_points);
   if (ctx->points_event) (void)hipEventDestroy(ctx->points_event);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
@@ -1358,6 +1633,7 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
     undo_policy();
     return s;
   }
+  if (ctx->have_comm && ctx->comm_world > 1) return sharded_update(ctx, pose, points_xy, num_points, estimate, info);
   if (const mcl_status s = stage_points(ctx, points_xy, num_points)) {
     undo_policy();
     return s;
@@ -1856,6 +2132,47 @@ mcl_status mcl_debug_order(mcl_ctx* ctx, uint32_t* perm, uint32_t* keys) {
   MCL_HIP(ctx, hipMemcpyAsync(keys, sort.keys, ctx->n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MCL_OK;
+}
+
+mcl_status mcl_comm_attach(mcl_ctx* ctx, uint32_t rank, uint32_t world, const mcl_transport* transport) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, world >= 1 && world <= 64 && rank < world, "mcl_comm_attach: world must be 1..64, rank < world");
+  MCL_REQUIRE(ctx, world == 1 || (transport && transport->all_gather && transport->all_to_all), "mcl_comm_attach: incomplete transport");
+  MCL_REQUIRE(ctx, world == 1 || ctx->cfg.shard_capacity > 0, "mcl_comm_attach: create the context with its shard_offset / shard_capacity");
+  ctx->comm_rank = rank;
+  ctx->comm_world = world;
+  ctx->transport = transport ? *transport : mcl_transport{};
+  ctx->have_comm = true;
+  return MCL_OK;
+}
+
+mcl_status mcl_comm_unique_id(uint8_t id[128]) {
+  if (!id) return MCL_ERR_INVALID_ARGUMENT;
+  std::string error;
+  RcclApi* api = rccl_api(&error);
+  if (!api) return fail(nullptr, MCL_ERR_UNSUPPORTED, "mcl_comm_unique_id: " + error);
+  RcclId uid;
+  if (api->GetUniqueId(&uid) != 0) return fail(nullptr, MCL_ERR_HIP, "ncclGetUniqueId failed");
+  std::memcpy(id, uid.internal, sizeof(uid.internal));
+  return MCL_OK;
+}
+
+mcl_status mcl_comm_attach_rccl(mcl_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t world) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, id && world >= 1 && world <= 64 && rank < world, "mcl_comm_attach_rccl: bad argument");
+  std::string error;
+  RcclApi* api = rccl_api(&error);
+  if (!api) return fail(ctx, MCL_ERR_UNSUPPORTED, "mcl_comm_attach_rccl: " + error);
+  if (const mcl_status s = bind_device(ctx)) return s;
+  RcclId uid;
+  std::memcpy(uid.internal, id, sizeof(uid.internal));
+  void* comm = nullptr;
+  if (api->CommInitRank(&comm, static_cast<int>(world), uid, static_cast<int>(rank)) != 0 || !comm)
+    return fail(ctx, MCL_ERR_HIP, "ncclCommInitRank failed");
+  ctx->rccl_comm = comm;
+  ctx->rccl_user = mcl_ctx::RcclUserStorage{comm, rank, world};
+  const mcl_transport t{&ctx->rccl_user, rccl_all_gather, rccl_all_to_all};
+  return mcl_comm_attach(ctx, rank, world, &t);
 }
 
 mcl_status mcl_sync(mcl_ctx* ctx) {

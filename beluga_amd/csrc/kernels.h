@@ -285,6 +285,8 @@ void launch_init_normal(hipStream_t st, Particles p, uint64_t n, const double me
 // initialize_from_map: multivariate_uniform_distribution.hpp:126-161 over the free cells, weight 1
 void launch_init_from_map(hipStream_t st, Particles p, uint64_t n, uint64_t seed, uint64_t index_offset, GridView g, FreeCells fc);
 void launch_fill(hipStream_t st, double* p, uint64_t n, double v);
+// d_out[k] = sum over r < rows (in order) of d_gathered[r * columns + k], columns <= 64 (gathered per-shard scalars)
+void launch_sum_rows(hipStream_t st, const double* d_gathered, uint32_t rows, uint32_t columns, double* d_out, double* host_mirror);
 // Likelihood field built on the device: exact Euclidean distance transform + the reference's Gaussian map, unknown-space
 // overlay and edge mask (likelihood_field_model_base.hpp:130-185).  Scratch: W * H uint16 and int16.  Returns false (nothing
 // launched) when max_obstacle_distance spans more than kFieldBuildMaxReach cells: the caller then builds on the host.

@@ -2363,6 +2363,17 @@ __global__ __launch_bounds__(kBlock) void k_edt_field(const int8_t* __restrict__
   field[i] = static_cast<float>(p.amplitude * exp(-static_cast<double>(squared) / p.two_squared_sigma) + p.offset);  // :146,181-182
 }
 
+// out[k] = sum over ranks r (in order) of gathered[r][k]: the shards' scalars after an all-gather.
+__global__ void k_sum_rows(const double* __restrict__ gathered, uint32_t rows, uint32_t columns, double* __restrict__ out,
+                           double* __restrict__ host_mirror) {
+  const uint32_t k = threadIdx.x;
+  if (k >= columns) return;
+  double acc = 0.0;
+  for (uint32_t r = 0; r < rows; ++r) acc += gathered[r * columns + k];
+  out[k] = acc;
+  if (host_mirror) host_mirror[k] = acc;
+}
+
 __global__ __launch_bounds__(kBlock) void k_cube_table(const float* __restrict__ field, uint64_t cells, float unknown_value,
                                                        double* __restrict__ cube, int prob) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -2816,6 +2827,10 @@ bool launch_build_field(hipStream_t st, const int8_t* d_cells, uint32_t W, uint3
   const size_t lds = static_cast<size_t>(kBlock + 2 * p.cap_cells) * sizeof(uint16_t);
   hipLaunchKernelGGL(k_edt_field, dim3(blocks_for(W), H), dim3(kBlock), lds, st, d_cells, p, d_column_distance, d_column_offset, d_field);
   return true;
+}
+
+void launch_sum_rows(hipStream_t st, const double* d_gathered, uint32_t rows, uint32_t columns, double* d_out, double* host_mirror) {
+  hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(64), 0, st, d_gathered, rows, columns, d_out, host_mirror);
 }
 
 void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float unknown_value, double* cube, int prob) {

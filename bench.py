@@ -255,19 +255,36 @@ def main():
     params = AmclParams(min_particles=n_total, max_particles=n_total)
     motion = DifferentialDriveModelParam(*ALPHAS)
     sensor = LikelihoodFieldModelParam(**LF)
-    if not use_sharded:
-        from beluga_amd.amcl import Amcl
-        filt = Amcl(grid, motion, sensor, params, seed=42, device=local_rank)
-    else:
-        from beluga_amd.sharded import ShardedAmcl
-        filt = ShardedAmcl(grid, motion, sensor, params, seed=42, device=local_rank)
+    def make_filter(per_gpu):
+        """One logical filter of per_gpu * world particles; with several ranks each holds a contiguous shard and the library runs
+        the cycle over RCCL (include/beluga_mcl.h, "Particle shards").  BELUGA_BENCH_DRIVER=python (or a gloo dry run) uses the
+        torch.distributed driver of beluga_amd/sharded.py instead."""
+        from beluga_amd.amcl import Amcl, comm_unique_id
+        total = per_gpu * world
+        p = AmclParams(min_particles=total, max_particles=total)
+        if not use_sharded:
+            return Amcl(grid, motion, sensor, p, seed=42, device=local_rank)
+        if backend != "nccl" or os.environ.get("BELUGA_BENCH_DRIVER", "library") == "python":
+            from beluga_amd.sharded import ShardedAmcl
+            return ShardedAmcl(grid, motion, sensor, p, seed=42, device=local_rank)
+        f = Amcl(grid, motion, sensor, p, seed=42, device=local_rank, shard_offset=rank * per_gpu, shard_capacity=per_gpu)
+        box = [comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        f.comm_attach_rccl(box[0], rank, world)
+        return f
+
+    filt = make_filter(n_local)
     filt.initialize(truth, np.diag([0.25, 0.25, 0.04]))
 
-    def sync_all():
-        filt.sync()
+    def sync_all_of(f):
+        f.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+
+    def sync_all():
+        sync_all_of(filt)
 
     controls = [se2_from_xytheta(*o) for o in odoms]
     for c in range(args.warmup):
@@ -310,6 +327,27 @@ def main():
     stage_prof = filt.profile_read(reset=True)
     filt.profile_enable(0)
 
+    # BASELINE configs[3] with several ranks: 8M particles per GPU behind one logical filter (64M at 8 GPUs); cycles/s of
+    # that filter, beside the metric.
+    config4 = None
+    if world > 1 and not args.no_other_configs:
+        filt.close()
+        big = make_filter(8_000_000)
+        big.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+        for c in range(2):
+            assert big.update(controls[c], scans[c]) is not None
+        sync_all_of(big)
+        t0 = time.perf_counter()
+        for c in range(2, 8):
+            assert big.update(controls[c], scans[c]) is not None
+        sync_all_of(big)
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        config4 = {"what": f"BASELINE configs[3]: {8 * world}M particles sharded over {world} GPUs (8M each), 1080 beams, multinomial resample every cycle",
+                   "cycles_per_s": 6 / float(t.item()), "ms_per_cycle": float(t.item()) / 6 * 1e3}
+        big.close()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         lf_ms, lf_count = prof["sensor_kernel"]
@@ -320,7 +358,8 @@ def main():
         out = {
             "metric": "MCL update cycles/sec (motion+sensor+resample), N particles x 1080 beams",
             # whole-job aggregate: one unit = one update cycle of 1M particles x 1080 beams (the configuration the metric is
-            # quoted on); with N GPUs every global cycle moves N such shards, so it counts N units
+            # quoted on); with N GPUs (weak scaling, 1M particles per GPU) every cycle of the logical N x 1M filter moves N such
+            # units.  config.global_cycles_per_s is the rate of the logical filter itself.
             "value": world * args.steps / elapsed,
             "unit": "cycles/s",
             "n_gpus": world,
@@ -339,7 +378,8 @@ def main():
                 "particles_total": n_total,
                 "beams": BEAMS,
                 "grid": f"{MAP_SIZE}x{MAP_SIZE}@{RESOLUTION}",
-                "parallelism": "1 GPU" if not use_sharded else f"particle shards x{world} (RCCL all-reduce of weight sums + all-to-all ancestor exchange)",
+                "parallelism": "1 GPU" if not use_sharded else f"particle shards x{world}: shard sums / CDF intervals / estimate sums all-gathered, "
+                                                                    f"ancestors exchanged all-to-all (RCCL over xGMI, inside libbeluga_mcl.so)",
                 "particle_beam_evals_per_s": n_total * BEAMS * args.steps / elapsed,
                 "global_cycles_per_s": args.steps / elapsed,
                 "unit_of_work": "one update cycle of 1M particles x 1080 beams; a global cycle over N GPUs = N units",
@@ -377,6 +417,8 @@ def main():
         }
         if not args.no_other_configs and world == 1 and n_local == 1_000_000:
             out["configs"] = other_configs(grid, cells, truth, controls, scans, filt, local_rank)
+        if config4 is not None:
+            out["configs"] = {"4": config4}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cells, truth, odoms, scans, n_total)
         sys.stdout.flush()

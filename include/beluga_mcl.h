@@ -253,6 +253,37 @@ mcl_status mcl_set_estimate_kind(mcl_ctx* ctx, int32_t kind, const mcl_cluster_p
  * from the counter-based stream (seed; index, 0x80000000 | draw_id): pass a different draw_id per publication. */
 mcl_status mcl_sample_particle_cloud(mcl_ctx* ctx, uint64_t size, uint32_t draw_id, double* states);
 
+/* ---- Particle shards across the GPUs of one node (one context per GPU, one process or thread per context) -------------
+ * The logical filter's particles are split into contiguous shards of the global index space (mcl_config.shard_offset /
+ * shard_capacity); the map is replicated and every rank passes the same control action and scan to mcl_update.  With a
+ * communicator attached, mcl_update runs the whole cycle over the sharded set: propagation and reweight are local; the weight
+ * normaliser is the sum of the gathered shard sums; the shard totals of the normalised weights are gathered into the
+ * intervals of the global CDF; every output slot's draw u_j * total (same counter-based stream as on one GPU) is routed to the
+ * shard that owns it, which answers with the ancestor's state (views::sample | random_intersperse | actions::assign,
+ * amcl_core.hpp:188-196); the estimate's nine sums are gathered and added in rank order.  Results do not depend on the
+ * number of ranks beyond the rounding of these sums.  Fixed particle count only (min_particles >= max_particles): the
+ * KLD-adaptive cut over shards is driven through the stage-level entry points below (beluga_amd/sharded.py).
+ *
+ * The collectives go through a transport: RCCL over xGMI (mcl_comm_attach_rccl; librccl.so is loaded at run time, the
+ * library has no link-time dependency on it), or caller-supplied functions (mcl_comm_attach: MPI, a shared-memory exchange
+ * between the threads of one process, ...).  All buffers are DEVICE pointers; calls are made in the same order on all ranks
+ * and must be complete (or stream-ordered on `hip_stream`) when they return. */
+typedef struct mcl_transport {
+  void* user;
+  /* every rank contributes `bytes` bytes at d_send; d_recv receives world * bytes, in rank order */
+  int32_t (*all_gather)(void* user, const void* d_send, void* d_recv, uint64_t bytes, void* hip_stream);
+  /* this rank sends send_bytes[q] bytes to rank q (consecutive blocks of d_send, in rank order) and receives recv_bytes[q]
+   * bytes from rank q (consecutive blocks of d_recv, in rank order) */
+  int32_t (*all_to_all)(void* user, const void* d_send, const uint64_t* send_bytes, void* d_recv, const uint64_t* recv_bytes,
+                        void* hip_stream);
+} mcl_transport;
+/* Attaches a communicator of `world` ranks to a context created with this rank's shard_offset / shard_capacity.  The transport
+ * struct is copied; `user` must outlive the context.  world == 1 is allowed (the cycle then needs no exchange). */
+mcl_status mcl_comm_attach(mcl_ctx* ctx, uint32_t rank, uint32_t world, const mcl_transport* transport);
+/* RCCL: rank 0 obtains an id (ncclGetUniqueId), hands its 128 bytes to the other ranks by any means, every rank attaches. */
+mcl_status mcl_comm_unique_id(uint8_t id[128]);
+mcl_status mcl_comm_attach_rccl(mcl_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t world);
+
 /* ---- Device access for zero-copy interop (torch / RCCL hand-off) -------------------------------- */
 typedef struct mcl_device_view {
   double* states;     /* n records of 4 doubles (cos, sin, x, y) */

@@ -1,0 +1,219 @@
+// A C++17 host sharding one logical filter over R contexts through the C ABI (include/beluga_mcl.h, "Particle shards"):
+// one thread per rank, every rank with its own context and shard, a shared-memory transport between the threads
+// (mcl_comm_attach) — what a host process driving the GPUs of one node does, here with all ranks on the GPU at hand so that
+// the exchange logic runs on a one-GPU box.  On a node with several GPUs the only change is device_id = rank and
+// mcl_comm_attach_rccl (or a peer-to-peer transport) in place of the host-staged one.
+// Prints the estimates of the sharded filter and of a single-context filter on the same inputs; tests/test_cpp_facade.py
+// compares them.  usage: sharded_demo [ranks = 2] [particles = 60000] [cycles = 6]
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "beluga_mcl.h"
+
+namespace {
+
+struct Barrier {  // reusable; C++17 has no std::barrier
+  std::mutex m;
+  std::condition_variable cv;
+  int count{0}, generation{0}, parties;
+  explicit Barrier(int n) : parties(n) {}
+  void wait() {
+    std::unique_lock<std::mutex> lock(m);
+    const int gen = generation;
+    if (++count == parties) {
+      count = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lock, [&] { return gen != generation; });
+    }
+  }
+};
+
+// Host-staged exchange between the threads of this process.
+struct Exchange {
+  int world;
+  Barrier barrier;
+  std::vector<std::vector<char>> boxes;                // all_gather: one box per rank
+  std::vector<std::vector<std::vector<char>>> mail;    // all_to_all: mail[from][to]
+  explicit Exchange(int n) : world(n), barrier(n), boxes(n), mail(n, std::vector<std::vector<char>>(n)) {}
+};
+struct Endpoint {
+  Exchange* x;
+  int rank;
+};
+
+int32_t all_gather(void* user, const void* d_send, void* d_recv, uint64_t bytes, void* stream) {
+  auto* e = static_cast<Endpoint*>(user);
+  if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return 1;
+  e->x->boxes[e->rank].resize(bytes);
+  if (hipMemcpy(e->x->boxes[e->rank].data(), d_send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  e->x->barrier.wait();
+  for (int r = 0; r < e->x->world; ++r)
+    if (hipMemcpy(static_cast<char*>(d_recv) + r * bytes, e->x->boxes[r].data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+  e->x->barrier.wait();
+  return 0;
+}
+int32_t all_to_all(void* user, const void* d_send, const uint64_t* send_bytes, void* d_recv, const uint64_t* recv_bytes, void* stream) {
+  auto* e = static_cast<Endpoint*>(user);
+  if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return 1;
+  const char* out = static_cast<const char*>(d_send);
+  for (int q = 0; q < e->x->world; ++q) {
+    auto& box = e->x->mail[e->rank][q];
+    box.resize(send_bytes[q]);
+    if (send_bytes[q] && hipMemcpy(box.data(), out, send_bytes[q], hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    out += send_bytes[q];
+  }
+  e->x->barrier.wait();
+  char* in = static_cast<char*>(d_recv);
+  for (int q = 0; q < e->x->world; ++q) {
+    const auto& box = e->x->mail[q][e->rank];
+    if (box.size() != recv_bytes[q]) return 2;
+    if (recv_bytes[q] && hipMemcpy(in, box.data(), recv_bytes[q], hipMemcpyHostToDevice) != hipSuccess) return 1;
+    in += recv_bytes[q];
+  }
+  e->x->barrier.wait();
+  return 0;
+}
+
+struct Scenario {
+  uint32_t W = 200, H = 160;
+  std::vector<int8_t> cells;
+  std::vector<std::vector<double>> scans;
+  std::vector<std::vector<double>> controls;
+  Scenario(int cycles) : cells(W * H, 0) {
+    for (uint32_t x = 0; x < W; ++x) cells[120 * W + x] = cells[10 * W + x] = 100;
+    for (uint32_t y = 0; y < H; ++y) cells[y * W + 150] = cells[y * W + 5] = 100;
+    double ox = 0, oy = 0, ot = 0;
+    for (int c = 0; c < cycles; ++c) {
+      ox += 0.3 * std::cos(ot);
+      oy += 0.3 * std::sin(ot);
+      ot += 0.04;
+      controls.push_back({std::cos(ot), std::sin(ot), ox, oy});
+      std::vector<double> scan;
+      for (int b = 0; b < 120; ++b) {
+        const double a = -2.0 + b * (4.0 / 120), r = 2.0 + 0.5 * std::sin(0.3 * b + c);
+        scan.push_back(r * std::cos(a));
+        scan.push_back(r * std::sin(a));
+      }
+      scans.push_back(scan);
+    }
+  }
+};
+
+mcl_config make_config(uint64_t n_total, uint64_t shard_offset, uint64_t shard_capacity) {
+  mcl_config cfg;
+  mcl_default_config(&cfg);
+  cfg.seed = 77;
+  cfg.amcl.min_particles = cfg.amcl.max_particles = n_total;
+  cfg.motion = mcl_diffdrive_params{0.1, 0.05, 0.1, 0.05, 0.01};
+  cfg.lf = mcl_lf_params{2.0, 100.0, 0.5, 0.5, 0.2, 1, 0};
+  cfg.shard_offset = shard_offset;
+  cfg.shard_capacity = shard_capacity;
+  return cfg;
+}
+
+bool run_filter(const Scenario& sc, mcl_ctx* ctx, std::vector<mcl_estimate>* out) {
+  const double origin[4] = {1.0, 0.0, -2.0, -3.0};
+  const int8_t traits[3] = {0, -1, 100};
+  if (mcl_set_map(ctx, sc.cells.data(), sc.W, sc.H, 0.05, origin, traits) != MCL_OK) return false;
+  const double mean[3] = {1.0, 1.0, 0.2}, cov[9] = {0.09, 0, 0, 0, 0.09, 0, 0, 0, 0.02};
+  if (mcl_initialize_normal(ctx, mean, cov) != MCL_OK) return false;
+  for (size_t c = 0; c < sc.scans.size(); ++c) {
+    mcl_estimate est;
+    mcl_update_info info;
+    if (mcl_update(ctx, sc.controls[c].data(), sc.scans[c].data(), sc.scans[c].size() / 2, &est, &info) != MCL_OK) {
+      std::printf("update_error %s\n", mcl_last_error(ctx));
+      return false;
+    }
+    if (!info.updated || !info.resampled) return false;
+    out->push_back(est);
+  }
+  return true;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  const int ranks = argc > 1 ? std::atoi(argv[1]) : 2;
+  const uint64_t n_total = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 60000;
+  const int cycles = argc > 3 ? std::atoi(argv[3]) : 6;
+  const Scenario sc(cycles);
+
+  mcl_ctx* single = nullptr;
+  const mcl_config whole = make_config(n_total, 0, 0);
+  if (mcl_create(&whole, &single) != MCL_OK) {
+    std::printf("runtime_error %s\n", mcl_last_error(nullptr));
+    return 3;
+  }
+  std::vector<mcl_estimate> reference;
+  if (!run_filter(sc, single, &reference)) return 4;
+  std::vector<double> ref_states(4 * n_total), ref_weights(n_total);
+  uint64_t got = 0;
+  mcl_get_particles(single, ref_states.data(), ref_weights.data(), n_total, &got);
+  mcl_destroy(single);
+
+  Exchange exchange(ranks);
+  std::vector<Endpoint> endpoints(ranks);
+  std::vector<std::vector<mcl_estimate>> estimates(ranks);
+  std::vector<std::vector<double>> shard_states(ranks);
+  std::vector<int> status(ranks, 0);
+  std::vector<std::thread> threads;
+  for (int r = 0; r < ranks; ++r) {
+    endpoints[r] = Endpoint{&exchange, r};
+    threads.emplace_back([&, r] {
+      const uint64_t base = n_total / ranks, rem = n_total % ranks;
+      const uint64_t first = r * base + std::min<uint64_t>(r, rem), mine = base + (static_cast<uint64_t>(r) < rem ? 1 : 0);
+      mcl_ctx* ctx = nullptr;
+      const mcl_config cfg = make_config(n_total, first, mine);
+      if (mcl_create(&cfg, &ctx) != MCL_OK) {
+        status[r] = 1;
+        return;
+      }
+      const mcl_transport transport{&endpoints[r], all_gather, all_to_all};
+      if (mcl_comm_attach(ctx, static_cast<uint32_t>(r), static_cast<uint32_t>(ranks), &transport) != MCL_OK) status[r] = 2;
+      if (!status[r] && !run_filter(sc, ctx, &estimates[r])) status[r] = 3;
+      if (!status[r]) {
+        shard_states[r].resize(4 * mine);
+        std::vector<double> w(mine);
+        uint64_t n = 0;
+        if (mcl_get_particles(ctx, shard_states[r].data(), w.data(), mine, &n) != MCL_OK || n != mine) status[r] = 4;
+      }
+      mcl_destroy(ctx);
+    });
+  }
+  for (auto& t : threads) t.join();
+  for (int r = 0; r < ranks; ++r)
+    if (status[r]) {
+      std::printf("rank_failed %d %d\n", r, status[r]);
+      return 5;
+    }
+  double worst_pose = 0, worst_cov = 0;
+  for (int c = 0; c < cycles; ++c) {
+    for (int r = 0; r < ranks; ++r) {  // every rank returns the same estimate
+      if (std::memcmp(&estimates[r][c], &estimates[0][c], sizeof(mcl_estimate)) != 0) {
+        std::printf("ranks_disagree %d %d\n", c, r);
+        return 6;
+      }
+    }
+    for (int k = 0; k < 4; ++k) worst_pose = std::max(worst_pose, std::abs(estimates[0][c].pose[k] - reference[c].pose[k]));
+    for (int k = 0; k < 9; ++k) worst_cov = std::max(worst_cov, std::abs(estimates[0][c].covariance[k] - reference[c].covariance[k]));
+  }
+  // the sharded set, concatenated in rank order, against the single-context set
+  uint64_t different = 0, at = 0;
+  for (int r = 0; r < ranks; ++r)
+    for (size_t i = 0; i < shard_states[r].size() / 4; ++i, ++at)
+      if (std::memcmp(&shard_states[r][4 * i], &ref_states[4 * at], 4 * sizeof(double)) != 0) ++different;
+  std::printf("ranks %d particles %llu cycles %d\n", ranks, static_cast<unsigned long long>(n_total), cycles);
+  std::printf("estimate_max_abs_difference %.3e %.3e\n", worst_pose, worst_cov);
+  std::printf("particles_that_differ %llu\n", static_cast<unsigned long long>(different));
+  return 0;
+}

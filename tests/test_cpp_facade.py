@@ -12,13 +12,15 @@ from beluga_amd import build as mcl_build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _compile(tmp_path_factory, name):
+def _compile(tmp_path_factory, name, hip_runtime=False):
     mcl_build.build()
     exe = tmp_path_factory.mktemp("cpp") / name
     lib_dir = os.path.join(ROOT, "beluga_amd", "lib")
+    extra = ["-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-L", "/opt/rocm/lib", "-lamdhip64", "-lpthread",
+             "-Wl,-rpath,/opt/rocm/lib"] if hip_runtime else []
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-L", lib_dir, "-lbeluga_mcl",
-                           f"-Wl,-rpath,{lib_dir}", "-o", str(exe)])
+                           f"-Wl,-rpath,{lib_dir}", "-o", str(exe)] + extra)
     return str(exe)
 
 
@@ -41,6 +43,35 @@ def test_facade_compiles_and_fails_loudly_without_gpu(demo):
     out = subprocess.run([demo], capture_output=True, text=True)
     assert out.returncode == 3
     assert "runtime_error" in out.stdout and "no CPU fallback" in out.stdout
+
+
+@pytest.fixture(scope="module")
+def sharded_demo(tmp_path_factory):
+    """tests/cpp/sharded_demo.cpp: a C++17 host sharding one filter over several contexts through mcl_comm_attach."""
+    return _compile(tmp_path_factory, "sharded_demo", hip_runtime=True)
+
+
+def test_sharded_demo_compiles_and_fails_loudly_without_gpu(sharded_demo):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    out = subprocess.run([sharded_demo], capture_output=True, text=True)
+    assert out.returncode == 3 and "no CPU fallback" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,particles", [(2, 60000), (3, 70001), (4, 131072)])
+def test_sharded_cycle_inside_the_library_matches_one_context(sharded_demo, ranks, particles):
+    """mcl_update over R shards (one thread and one context per rank, a shared-memory transport between them; all on the GPU
+    at hand) against the single-context filter on the same inputs: every rank returns the same estimate, it equals the
+    single-context one up to the rounding of the gathered sums, and the resampled sets are the same particles up to the
+    CDF-boundary draws that rounding can move."""
+    out = subprocess.run([sharded_demo, str(ranks), str(particles), "6"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    kv = {line.split()[0]: line.split()[1:] for line in out.stdout.splitlines()}
+    pose_diff, cov_diff = (float(v) for v in kv["estimate_max_abs_difference"])
+    assert pose_diff < 1e-9 and cov_diff < 1e-9, out.stdout
+    assert int(kv["particles_that_differ"][0]) <= max(5, particles // 10000), out.stdout
 
 
 def test_node_bodies_compile_and_fail_loudly_without_gpu(node_bodies):

@@ -155,3 +155,39 @@ def test_sharded_kld_world1_nccl_matches_single_gpu():
         sharded.close()
     finally:
         dist.destroy_process_group()
+
+
+MOTION = DifferentialDriveModelParam(0.1, 0.05, 0.1, 0.05)
+LF = LikelihoodFieldModelParam(2.0, 100.0, 0.5, 0.5, 0.2, True)
+
+
+def _grid():
+    cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
+    return OccupancyGrid(cells, 0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
+
+
+def test_library_rccl_transport_world_one():
+    """The built-in RCCL transport of the library (librccl.so loaded at run time; mcl_comm_unique_id / mcl_comm_attach_rccl) on a
+    communicator of one rank: the attach succeeds, the collectives' entry points resolve, and update() equals the plain filter
+    (a communicator of one needs no exchange)."""
+    from beluga_amd.amcl import comm_unique_id
+    grid = _grid()
+    params = AmclParams(min_particles=30_000, max_particles=30_000)
+    plain = Amcl(grid, MOTION, LF, params, seed=5)
+    sharded = Amcl(grid, MOTION, LF, params, seed=5, shard_offset=0, shard_capacity=30_000)
+    sharded.comm_attach_rccl(comm_unique_id(), 0, 1)
+    truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=4, clearance_cells=8)
+    cov = np.diag([0.25, 0.25, 0.04])
+    plain.initialize(truth, cov)
+    sharded.initialize(truth, cov)
+    pose, odom = truth, (0.0, 0.0, 0.0)
+    angles = synth.lidar_angles(180, 270.0)
+    for c in range(4):
+        pose = synth.odometry_step(pose, 0.3, 0.05)
+        odom = synth.odometry_step(odom, 0.3, 0.05)
+        pts = synth.scan_points(synth.cast_scan(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), pose, angles, 12.0, 0.01, 100 + c), angles)
+        a = plain.update(se2_from_xytheta(*odom), pts)
+        b = sharded.update(se2_from_xytheta(*odom), pts)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    plain.close()
+    sharded.close()
