@@ -24,6 +24,9 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
+// The chunk-granular kernels of the ordering (one workgroup per kChunk = 2048 elements, LDS histogram / cursors of 1024 digits)
+// run 1024 threads per workgroup: with 256 they put two waves on a SIMD and could not hide their own latencies.
+constexpr int kWide = 1024;
 
 __device__ __forceinline__ Pose2 load_pose(const Particles& p, uint64_t i) {
   const double4 v = p.pose[i];
@@ -133,20 +136,20 @@ __global__ __launch_bounds__(kBlock) void k_pull_scan(const double* __restrict__
 // One workgroup per chunk of kChunk particles (coalesced 32-byte records).  kKeys: the ordering key of the NEW pose and the
 // chunk's histogram of the key's low digit come out of the same pass (the poses are in registers here).
 template <bool kKeys>
-__global__ __launch_bounds__(kBlock) void k_propagate(Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
+__global__ __launch_bounds__(kWide) void k_propagate(Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
                                                       uint64_t index_offset, const double* __restrict__ scan_src,
                                                       double* __restrict__ scan_dst, uint32_t scan_doubles, KeyFrame kf,
                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ table, uint32_t nblocks) {
   __shared__ uint32_t hist[kKeys ? kSortDigits : 1];
   if (kKeys) {
-    for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) hist[d] = 0;
+    for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) hist[d] = 0;
     __syncthreads();
   }
   if (scan_dst && blockIdx.x == gridDim.x - 1) pull_scan(scan_src, scan_dst, scan_doubles);
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
 #pragma unroll 1
-  for (int k = 0; k < kChunk / kBlock; ++k) {
-    const uint64_t i = base + static_cast<uint64_t>(k) * kBlock + threadIdx.x;
+  for (int k = 0; k < kChunk / kWide; ++k) {
+    const uint64_t i = base + static_cast<uint64_t>(k) * kWide + threadIdx.x;
     if (i >= n) break;
     const RngWords a = rng_draw(seed, step, kRngPropagateA, index_offset + i);
     const RngWords b = rng_draw(seed, step, kRngPropagateB, index_offset + i);
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate(Particles p, uint64_t n, D
   }
   if (kKeys) {
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
+    for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
   }
 }
 
@@ -653,16 +656,16 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final(const double* __restrict_
 }
 
 // Keys + block histograms of the low digit as a pass of its own (stage-level calls, where k_propagate did not emit them).
-__global__ __launch_bounds__(kBlock) void k_order_keys(Particles p, uint64_t n, KeyFrame kf_value, const KeyFrame* __restrict__ kf_device,
+__global__ __launch_bounds__(kWide) void k_order_keys(Particles p, uint64_t n, KeyFrame kf_value, const KeyFrame* __restrict__ kf_device,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ table, uint32_t nblocks) {
   __shared__ uint32_t hist[kSortDigits];
-  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) hist[d] = 0;
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) hist[d] = 0;
   __syncthreads();
   const KeyFrame kf = kf_device ? *kf_device : kf_value;
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
 #pragma unroll
-  for (int k = 0; k < kChunk / kBlock; ++k) {
-    const uint64_t i = base + k * kBlock + threadIdx.x;  // coalesced
+  for (int k = 0; k < kChunk / kWide; ++k) {
+    const uint64_t i = base + k * kWide + threadIdx.x;  // coalesced
     if (i < n) {
       const uint32_t key = order_key(p.pose[i], kf);
       keys[i] = key;
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(kBlock) void k_order_keys(Particles p, uint64_t n, 
     }
   }
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
 }
 
 // totals[d] = sum of row d of the [digit][block] table; one wave per digit.
@@ -706,16 +709,16 @@ __global__ __launch_bounds__(kBlock) void k_row_scan(uint32_t* __restrict__ tabl
 
 // First pass: by the low digit.  Elements of one digit may land in any order (LDS cursors); the second pass orders
 // them by the high digit anyway and two particles with the same 20-bit key are interchangeable for locality.
-__global__ __launch_bounds__(kBlock) void k_sort_scatter_low(const uint32_t* __restrict__ keys, uint64_t n,
+__global__ __launch_bounds__(kWide) void k_sort_scatter_low(const uint32_t* __restrict__ keys, uint64_t n,
                                                              const uint32_t* __restrict__ table, uint32_t nblocks,
                                                              unsigned long long* __restrict__ out) {
   __shared__ uint32_t cursor[kSortDigits];
-  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) cursor[d] = table[static_cast<size_t>(d) * nblocks + blockIdx.x];
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) cursor[d] = table[static_cast<size_t>(d) * nblocks + blockIdx.x];
   __syncthreads();
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
 #pragma unroll
-  for (int k = 0; k < kChunk / kBlock; ++k) {
-    const uint64_t i = base + k * kBlock + threadIdx.x;
+  for (int k = 0; k < kChunk / kWide; ++k) {
+    const uint64_t i = base + k * kWide + threadIdx.x;
     if (i < n) {
       const uint32_t key = keys[i];
       const uint32_t dest = atomicAdd(&cursor[key & (kSortDigits - 1)], 1u);
@@ -723,32 +726,33 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter_low(const uint32_t* __r
     }
   }
 }
-__global__ __launch_bounds__(kBlock) void k_sort_hist_high(const unsigned long long* __restrict__ in, uint64_t n,
+__global__ __launch_bounds__(kWide) void k_sort_hist_high(const unsigned long long* __restrict__ in, uint64_t n,
                                                            uint32_t* __restrict__ table, uint32_t nblocks) {
   __shared__ uint32_t hist[kSortDigits];
-  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) hist[d] = 0;
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) hist[d] = 0;
   __syncthreads();
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
 #pragma unroll
-  for (int k = 0; k < kChunk / kBlock; ++k) {
-    const uint64_t e = base + k * kBlock + threadIdx.x;
+  for (int k = 0; k < kChunk / kWide; ++k) {
+    const uint64_t e = base + k * kWide + threadIdx.x;
     if (e < n) atomicAdd(&hist[static_cast<uint32_t>(in[e] >> 32) & (kSortDigits - 1)], 1u);
   }
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
 }
 // Second pass: by the high digit, stable.  Every wave owns a contiguous quarter of the block and walks it 64 elements at a
 // time: the lanes holding the same digit find each other with ten ballots (rank inside the group = lanes below with
 // the same digit), the wave's running count per digit lives in LDS; the four waves' counts are then chained in wave order
 // behind the block's offset of that digit.  No cross-wave step until every wave has ranked its quarter.
-__global__ __launch_bounds__(kBlock) void k_sort_scatter_high(const unsigned long long* __restrict__ in, uint64_t n,
+constexpr int kStable = 512;  // 8 waves x 256 elements: 48 KB of LDS counters per workgroup
+__global__ __launch_bounds__(kStable) void k_sort_scatter_high(const unsigned long long* __restrict__ in, uint64_t n,
                                                               const uint32_t* __restrict__ table, uint32_t nblocks,
                                                               uint32_t* __restrict__ perm) {
-  constexpr int kWaves = kBlock / 64, kRounds = kChunk / kBlock;
+  constexpr int kWaves = kStable / 64, kRounds = kChunk / kStable;
   __shared__ uint16_t wave_count[kWaves][kSortDigits];
   __shared__ uint32_t wave_base[kWaves][kSortDigits];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t d = threadIdx.x; d < kWaves * kSortDigits; d += kBlock) (&wave_count[0][0])[d] = 0;
+  for (uint32_t d = threadIdx.x; d < kWaves * kSortDigits; d += kStable) (&wave_count[0][0])[d] = 0;
   __syncthreads();
   volatile uint16_t* mine = wave_count[wave];
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + static_cast<uint64_t>(wave) * (kChunk / kWaves);
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter_high(const unsigned lon
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kBlock) {
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kStable) {
     uint32_t run = table[static_cast<size_t>(d) * nblocks + blockIdx.x];
 #pragma unroll
     for (int q = 0; q < kWaves; ++q) {
@@ -2428,10 +2432,10 @@ void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler 
   }
   const uint32_t nblocks = num_chunks(n);
   if (sort && frame && n < (1ull << 32))
-    hipLaunchKernelGGL(k_propagate<true>, dim3(nblocks), dim3(kBlock), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
+    hipLaunchKernelGGL(k_propagate<true>, dim3(nblocks), dim3(kWide), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
                        scan_doubles, *frame, sort->keys, sort->table, nblocks);
   else
-    hipLaunchKernelGGL(k_propagate<false>, dim3(nblocks), dim3(kBlock), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
+    hipLaunchKernelGGL(k_propagate<false>, dim3(nblocks), dim3(kWide), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
                        scan_doubles, KeyFrame{}, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), nblocks);
 }
 
@@ -2451,17 +2455,17 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
       hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(kBlock), 0, st, partials, nblocks, nblocks, sort->bbox, p, sort->frame);
       device_frame = sort->frame;
     }
-    hipLaunchKernelGGL(k_order_keys, dim3(nblocks), dim3(kBlock), 0, st, p, n, frame ? *frame : KeyFrame{}, device_frame, sort->keys,
+    hipLaunchKernelGGL(k_order_keys, dim3(nblocks), dim3(kWide), 0, st, p, n, frame ? *frame : KeyFrame{}, device_frame, sort->keys,
                        sort->table, nblocks);
   }
   const dim3 rows(kSortDigits / (kBlock / 64));
   hipLaunchKernelGGL(k_digit_totals, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
   hipLaunchKernelGGL(k_row_scan, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
-  hipLaunchKernelGGL(k_sort_scatter_low, dim3(nblocks), dim3(kBlock), 0, st, sort->keys, n, sort->table, nblocks, sort->keyidx);
-  hipLaunchKernelGGL(k_sort_hist_high, dim3(nblocks), dim3(kBlock), 0, st, sort->keyidx, n, sort->table, nblocks);
+  hipLaunchKernelGGL(k_sort_scatter_low, dim3(nblocks), dim3(kWide), 0, st, sort->keys, n, sort->table, nblocks, sort->keyidx);
+  hipLaunchKernelGGL(k_sort_hist_high, dim3(nblocks), dim3(kWide), 0, st, sort->keyidx, n, sort->table, nblocks);
   hipLaunchKernelGGL(k_digit_totals, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
   hipLaunchKernelGGL(k_row_scan, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
-  hipLaunchKernelGGL(k_sort_scatter_high, dim3(nblocks), dim3(kBlock), 0, st, sort->keyidx, n, sort->table, nblocks, sort->perm);
+  hipLaunchKernelGGL(k_sort_scatter_high, dim3(nblocks), dim3(kStable), 0, st, sort->keyidx, n, sort->table, nblocks, sort->perm);
 }
 
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
