@@ -1272,7 +1272,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     MCL_HIP(ctx, hipEventCreateWithFlags(&ctx->points_event, hipEventDisableTiming));
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
-    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "device_policy", "sort_min_particles", "field_build"}) {
+    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "device_policy", "sort_min_particles", "field_build"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2101,6 +2101,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   if (key == "lf_variant") t.lf_variant = value == 0 ? kLfWavePerParticle : (value == 1 ? kLfLanePerParticle : kLfSortedLanes);
   else if (key == "lf_fast") t.lf_fast = value < 0 ? -1 : (value ? 1 : 0);
   else if (key == "lf_table") t.lf_table = value ? 1 : 0;
+  else if (key == "lf_patch") t.lf_patch = value ? 1 : 0;
   else if (key == "device_policy") t.device_policy = value ? 1 : 0;
   else if (key == "field_build") t.field_build = value ? 1 : 0;
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));

@@ -107,6 +107,7 @@ struct Tuning {
   int lf_variant = kLfSortedLanes;  // kernel family of the likelihood-field reweight
   int lf_fast = -1;                 // FMA variant with exact fallback: -1 / 1 = whenever its preconditions hold, 0 = never
   int lf_table = 0;                 // 0 = palette table when the field allows it, 1 = force the 8-byte cube table
+  int lf_patch = 1;                 // index table read through per-workgroup LDS patches (0: per-lane gathers only)
   int device_policy = 1;            // recovery estimator on the device when the cycle has no host-side decision
   int sort_min_particles = 16384;   // below this the ordering passes cost more than they save
   int field_build = 0;              // mcl_set_map: 0 = host wavefront (bit-identical to the reference), 1 = exact EDT on the device

@@ -399,6 +399,16 @@ __device__ __forceinline__ int med3_i32(int v, int lo /* in a VGPR: one scalar o
   asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "s"(hi));
   return r;
 }
+__device__ __forceinline__ uint32_t lshl_add_u32(uint32_t a, int shift /* constant */, uint32_t b) {  // (a << shift) + b, one instruction
+  uint32_t r;
+  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(shift), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b /* uniform */, uint32_t c) {  // (a mod 2^24) * (b mod 2^24) + c
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t r;
   asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -543,6 +553,267 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
     floor_rd_2(vx, vy);
     acc += lf_palette_value(lf_palette_fetch(rsrc, f, floor_rd_result(vx), floor_rd_result(vy), row_fix));
   }
+  if (t < n) {
+    if (partial) {
+      partial[static_cast<size_t>(blockIdx.y) * n + t] = acc;
+    } else {
+      w[i] = w[i] * (f.prob ? exp(acc) : acc);
+    }
+  }
+}
+
+// The palette kernel with the index table read through LDS patches.
+// A scattered 64-lane 2-byte gather costs the CU's texture-address pipe one cycle per quad of lanes per line (16+ per
+// instruction, profiles/r02_calib_gather_cost.txt): the floor of k_reweight_lf_palette.  An LDS read of the same shape costs
+// two.  A workgroup holds 448 neighbours of the spatial order (waves 0-6, one lane per particle) and a PRODUCER (wave 7, no
+// particles).  For a group of 8 consecutive beams the end-point of particle p differs from that of the workgroup's middle
+// particle, the reference, by (t_p - t_ref) + (R_p - R_ref) q, at most
+//     (Dx, Dy) + |q| Drot      Dx, Dy = max |t_p - t_ref| per axis,  Drot = max |R_p - R_ref| = max 2 |sin(dtheta / 2)|
+// over the workgroup (one reduction in the prologue).  If the bounding box of the reference's 8 end-point cells, widened by
+// that margin (+2 cells for every rounding involved), fits into 64 x 64 cells, the group goes through a PATCH: the producer
+// copies that part of the index table into LDS - 512 coalesced 16-byte pieces (a tile column of the 8x8-tiled table = 8
+// cells in y), column-major, 144 bytes per column - and every look-up of the group is an LDS read at cx * 144 + cy * 2 + K,
+// with no test: the bound is the proof that it lies inside.  Otherwise (the cloud's fringe, a range discontinuity inside the
+// group) the group is gathered as in k_reweight_lf_palette.  Where a look-up comes from changes no result.
+// The plan - origin and mode of every group - is made once, in the prologue, one thread per group.  Then one s_barrier per
+// group: behind barrier g the patch of group g is visible and the buffer of g - 1 is free; the consumers evaluate group g
+// while the producer fetches g + 1 (the only wave that ever waits for that fetch).
+//
+// End-points: v = the reference's separately rounded (p.cos - q.sin + t) / res, cell = floor(v).  Evaluated here as
+//     s = fma(p, c', fma(-q, s', t' + M)),   c' = cos / res, s' = sin / res, t' = t / res,   M = 1.5 * 2^20 + 2^-31
+// every partial result lies in [2^20, 2^21) and is rounded to the grid u = 2^-32: three roundings of at most u / 2, plus the
+// roundings of c', s', t' and of the reference's own evaluation (below 2^-36 cells while every term stays below 2^15 cells),
+// so s = v + M + err with |err| < 2u.  With I = floor(v): s lies in (1.5 * 2^20 + I + frac(v), ... + 4u), on the grid, so
+// either its integer part is I (high word = kFastBias + I, whatever the low word) or it carried and its low word is below 4.
+// A group with a low word below 4 (4 in 2^32 end-points) is added by the exact evaluation, beam by beam, and so is every
+// group of a wave holding a particle farther than 2^14 cells from the grid origin.  4 VALU operations per end-point.
+constexpr int kPatchW = 64, kPatchH = 64;  // cells
+// Bytes per patch column: the 128 of its cells + 16, so that the bank of a cell is (4 x + y / 2) mod 32 - neighbouring
+// columns on different banks (with 128, every column of a row pair would share one).
+constexpr uint32_t kPatchPitch = kPatchH * 2 + 16;
+constexpr uint32_t kPatchBytes = kPatchW * kPatchPitch;
+constexpr uint32_t kPatchParticles = kPalBlock - 64;  // per workgroup
+constexpr uint32_t kPatchPlanned = 256;               // groups with a plan entry; the ones beyond are gathered
+constexpr uint32_t kPatchLds = 2 * kPatchBytes + kPatchPlanned * 8 + 32 * 4;  // two patches, the plan, the bound's partial maxima
+constexpr double kPatchMagic = 1572864.0 + 4.656612873077392578125e-10;     // 1.5 * 2^20 + 2^-31
+__global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restrict__ w, uint64_t n, FieldView f,
+                                                                 const double* __restrict__ pts, uint32_t B,
+                                                                 const uint32_t* __restrict__ perm, const double4* __restrict__ pose,
+                                                                 double* __restrict__ partial, uint32_t beams_per_segment,
+                                                                 uint32_t patch_base /* LDS byte offset, 16-aligned */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {
+    uint32_t* s_row = reinterpret_cast<uint32_t*>(smem);
+    for (uint32_t j = threadIdx.x; j < f.H + 2; j += kPalBlock)
+      s_row[j] = palette_row_offset(static_cast<int32_t>(j) - 1, f.pal_pitch) - kFastBiasX;
+    double* s_pal = reinterpret_cast<double*>(smem + f.pal_base);
+    for (uint32_t k = threadIdx.x; k < f.pal_count; k += kPalBlock) s_pal[k] = f.pal_val[k];
+  }
+  // plan entry of group g: biased x0; biased y0 (a multiple of 8) | 1 if the group goes through a patch
+  int2* s_plan = reinterpret_cast<int2*>(smem + patch_base + 2 * kPatchBytes);
+  float* s_bound = reinterpret_cast<float*>(smem + patch_base + 2 * kPatchBytes + kPatchPlanned * 8);  // [7][3] (+ padding)
+  const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPalBlock / 64 - 1);  // a scalar branch: the roles
+                                                                                                  // run different loops
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t first = static_cast<uint64_t>(blockIdx.x) * kPatchParticles;
+  const uint64_t t_ref = first + kPatchParticles / 2 < n ? first + kPatchParticles / 2 : n - 1;
+  const uint64_t t = producer ? t_ref : first + threadIdx.x;
+  const uint64_t tt = t < n ? t : n - 1;
+  const uint32_t i = perm[tt];
+  const Pose2 T = ordered_pose(f.world_to_field, pose, i);  // likelihood_field_model.hpp:70
+  const double ct = T.r.c, st = T.r.s, xt = T.x, yt = T.y;
+  const uint32_t b_begin = partial ? blockIdx.y * beams_per_segment : 0u;
+  const uint32_t b_end = partial ? (b_begin + beams_per_segment < B ? b_begin + beams_per_segment : B) : B;
+  const uint32_t groups = (b_end - b_begin) / 8;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(f.pal_idx), 0, static_cast<int>(f.pal_bytes), 0x00020000);
+  const double ict = ct * f.inv_resolution, ist = st * f.inv_resolution, ixt = xt * f.inv_resolution, iyt = yt * f.inv_resolution;
+  const double ixm = ixt + kPatchMagic, iym = iyt + kPatchMagic;
+  const bool lane_small = fabs(ixt) < 16384.0 && fabs(iyt) < 16384.0;  // false for NaN as well
+
+  // ---- the bound: every wave's lanes against the reference particle, then the workgroup's maxima
+  const Pose2 R = ordered_pose(f.world_to_field, pose, perm[t_ref]);
+  const double rc = R.r.c * f.inv_resolution, rs = R.r.s * f.inv_resolution;
+  const double rxm = R.x * f.inv_resolution + kPatchMagic, rym = R.y * f.inv_resolution + kPatchMagic;
+  if (!producer) {
+    const double dc = ct - R.r.c, ds = st - R.r.s;
+    float dx = static_cast<float>(fabs(ixt - R.x * f.inv_resolution)), dy = static_cast<float>(fabs(iyt - R.y * f.inv_resolution));
+    float dr = static_cast<float>(sqrt(dc * dc + ds * ds));
+    if (!(lane_small && dx < 1e6f && dy < 1e6f && dr < 4.f)) dx = dy = dr = INFINITY;  // a far or non-finite particle: no patches
+    for (int o = 32; o > 0; o >>= 1) {
+      dx = fmaxf(dx, __shfl_xor(dx, o));
+      dy = fmaxf(dy, __shfl_xor(dy, o));
+      dr = fmaxf(dr, __shfl_xor(dr, o));
+    }
+    if (lane == 0) {
+      float* mine = s_bound + 3 * (threadIdx.x >> 6);
+      mine[0] = dx;
+      mine[1] = dy;
+      mine[2] = dr;
+    }
+  }
+  __syncthreads();
+  // ---- the plan: thread g looks at group g through the reference particle
+  if (threadIdx.x < groups && threadIdx.x < kPatchPlanned) {
+    float Dx = 0.f, Dy = 0.f, Drot = 0.f;
+    for (uint32_t k = 0; k < kPalBlock / 64 - 1; ++k) {
+      Dx = fmaxf(Dx, s_bound[3 * k]);
+      Dy = fmaxf(Dy, s_bound[3 * k + 1]);
+      Drot = fmaxf(Drot, s_bound[3 * k + 2]);
+    }
+    // every float operation below may round down: scaled up by 1 + 2^-10 where it matters, and two cells of slack
+    Dx = Dx * 1.001f + 2.f;
+    Dy = Dy * 1.001f + 2.f;
+    int lo_x = INT_MAX, hi_x = INT_MIN, lo_y = INT_MAX, hi_y = INT_MIN;
+    float reach2 = 0.f;
+    const double2* q = reinterpret_cast<const double2*>(pts) + (b_begin + 8 * threadIdx.x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double2 p = q[k];
+      const double sx = __builtin_fma(p.x, rc, __builtin_fma(-p.y, rs, rxm));
+      const double sy = __builtin_fma(p.x, rs, __builtin_fma(p.y, rc, rym));
+      const int cx = static_cast<int>(__builtin_bit_cast(uint64_t, sx) >> 32), cy = static_cast<int>(__builtin_bit_cast(uint64_t, sy) >> 32);
+      lo_x = min(lo_x, cx);
+      hi_x = max(hi_x, cx);
+      lo_y = min(lo_y, cy);
+      hi_y = max(hi_y, cy);
+      const float qx = static_cast<float>(p.x), qy = static_cast<float>(p.y);
+      reach2 = fmaxf(reach2, qx * qx + qy * qy);
+    }
+    const float turn = sqrtf(reach2) * 1.001f * (static_cast<float>(f.inv_resolution) * 1.001f) * (Drot * 1.001f);  // cells
+    const float mx = ceilf(Dx + turn), my = ceilf(Dy + turn);
+    bool fits = mx < 64.f && my < 64.f;  // false for NaN and infinity
+    const int margin_x = fits ? static_cast<int>(mx) : 0, margin_y = fits ? static_cast<int>(my) : 0;
+    const int x0 = lo_x - margin_x, y0 = (lo_y - margin_y) & ~7;
+    fits = fits && hi_x + margin_x - x0 < kPatchW && hi_y + margin_y - y0 < kPatchH;
+    s_plan[threadIdx.x] = int2{x0, y0 | (fits ? 1 : 0)};
+  }
+  __syncthreads();
+  auto plan_of = [&](uint32_t g, int& x0, int& y0) -> bool {  // g uniform; scalar results
+    if (g >= kPatchPlanned) return false;
+    const int2 e = s_plan[g];
+    x0 = __builtin_amdgcn_readfirstlane(e.x);
+    const int y = __builtin_amdgcn_readfirstlane(e.y);
+    y0 = y & ~7;
+    return (y & 1) != 0;
+  };
+
+  if (producer) {
+    const int y_last = static_cast<int>((f.H + 7u) & ~7u);  // first row of the bottom border tiles
+    auto produce = [&](uint32_t g) {
+      int x0, y0;
+      if (!plan_of(g, x0, y0)) return;
+      // the patch, clamped into the bordered table (whatever lies outside the grid reads the unknown entry, like a clamped
+      // gather): this lane's column, tile row by tile row
+      const int xu = x0 + static_cast<int>(lane) - static_cast<int>(kFastBias);
+      const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W))) << 4;
+      uint4 piece[kPatchH / 8];
+#pragma unroll
+      for (int r = 0; r < kPatchH / 8; ++r) {
+        const int yu = y0 + 8 * r - static_cast<int>(kFastBias);
+        const int yc = min(max(yu, -8), y_last);  // scalar
+        piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, column, palette_row_offset(yc, f.pal_pitch), 0));
+      }
+      unsigned char* dst = smem + patch_base + (g & 1) * kPatchBytes + lane * kPatchPitch;
+#pragma unroll
+      for (int r = 0; r < kPatchH / 8; ++r) *reinterpret_cast<uint4*>(dst + r * 16) = piece[r];
+    };
+    if (groups) produce(0);
+    for (uint32_t g = 0; g < groups; ++g) {
+      __syncthreads();
+      if (g + 1 < groups) produce(g + 1);
+    }
+    return;
+  }
+
+  double acc = (f.prob || partial) ? 0.0 : 1.0;
+  const bool fast = __builtin_amdgcn_ballot_w64(!lane_small) == 0;  // per wave: a far particle sends its wave through the exact code
+  const int c_lo = static_cast<int>(kFastBias) - 1, x_hi = static_cast<int>(kFastBias + f.W), y_hi = static_cast<int>(kFastBias + f.H);
+  const uint32_t row_bias = 4u - (kFastBias << 2);  // LDS byte address of the row entry = (biased y << 2) + row_bias
+  struct Lookups {
+    uint16_t e[8];  // palette addresses; widened where they are used, after the wait for them
+  };
+  // The separately rounded evaluation, beam by beam with plain gathers.
+  auto add_exact = [&](uint32_t b0, uint32_t count) {
+#pragma unroll 1
+    for (uint32_t b = b0; b < b0 + count; ++b) {
+      const double px = pts[2 * b], py = pts[2 * b + 1];
+      double vx = (px * ct - py * st + xt) * f.inv_resolution, vy = (px * st + py * ct + yt) * f.inv_resolution;
+      floor_rd_2(vx, vy);
+      acc += lf_palette_value(lf_palette_fetch(rsrc, f, floor_rd_result(vx), floor_rd_result(vy), kFastBiasX));
+    }
+  };
+  auto consume = [&](const Lookups& e, uint32_t redo, uint32_t b0) {
+    if (redo) {
+      add_exact(b0, 8);
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += lf_palette_value(static_cast<uint32_t>(e.e[k]));
+  };
+  // One step: the end-points of group g, then the sum of the group before it (its gathers, if any, had the end-point
+  // arithmetic to arrive), then the look-ups of group g.  `redo`: 1 if the group has to be added by add_exact instead.
+  auto step = [&](auto add_before, uint32_t g_any, Lookups& now, uint32_t& now_redo, const Lookups& before, uint32_t before_redo) {
+    const uint32_t g = __builtin_amdgcn_readfirstlane(g_any);  // uniform anyway; this keeps the scan reads on the scalar unit
+    before_redo = __builtin_amdgcn_readfirstlane(before_redo);
+    const uint32_t b0 = b_begin + 8 * g;
+    int x0 = 0, y0 = 0;
+    const bool in_patch = plan_of(g, x0, y0);
+    const uint32_t K = patch_base + (g & 1) * kPatchBytes - (static_cast<uint32_t>(x0) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0) << 1);
+    __syncthreads();
+    now_redo = 1u;
+    if (!fast) {
+      if constexpr (decltype(add_before)::value) consume(before, before_redo, b0 - 8);
+      return;
+    }
+    const double* q = pts + 2 * b0;
+    int cx[8], cy[8];
+    uint32_t lowest = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double px = q[2 * k], py = q[2 * k + 1];
+      const double sx = __builtin_fma(px, ict, __builtin_fma(-py, ist, ixm));
+      const double sy = __builtin_fma(px, ist, __builtin_fma(py, ict, iym));
+      const uint64_t bx = __builtin_bit_cast(uint64_t, sx), by = __builtin_bit_cast(uint64_t, sy);
+      lowest = min3_u32(lowest, static_cast<uint32_t>(bx), static_cast<uint32_t>(by));
+      cx[k] = static_cast<int>(bx >> 32);
+      cy[k] = static_cast<int>(by >> 32);
+    }
+    if constexpr (decltype(add_before)::value) consume(before, before_redo, b0 - 8);
+    if (in_patch) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        now.e[k] = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(
+            static_cast<uintptr_t>(mad_u24(static_cast<uint32_t>(cx[k]), kPatchPitch, lshl_add_u32(static_cast<uint32_t>(cy[k]), 1, K))));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int xc = med3_i32(cx[k], c_lo, x_hi), yc = med3_i32(cy[k], c_lo, y_hi);
+        const uint32_t row = *reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>((static_cast<uint32_t>(yc) << 2) + row_bias));
+        now.e[k] = static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, (static_cast<uint32_t>(xc) << 4) + row, 0, 0));
+      }
+    }
+    now_redo = __builtin_amdgcn_ballot_w64(lowest < 4u) != 0 ? 1u : 0u;
+  };
+  if (groups) {
+    Lookups a, c;
+    uint32_t a_redo = 0, c_redo = 0;
+    uint32_t g;
+    if (groups & 1) {
+      step(std::false_type{}, 0, a, a_redo, a, 0);
+      g = 1;
+    } else {
+      step(std::false_type{}, 0, c, c_redo, c, 0);
+      step(std::true_type{}, 1, a, a_redo, c, c_redo);
+      g = 2;
+    }
+    for (; g < groups; g += 2) {  // `a` holds group g - 1
+      step(std::true_type{}, g, c, c_redo, a, a_redo);
+      step(std::true_type{}, g + 1, a, a_redo, c, c_redo);
+    }
+    consume(a, a_redo, b_begin + 8 * groups - 8);
+  }
+  add_exact(b_begin + 8 * groups, b_end - (b_begin + 8 * groups));
   if (t < n) {
     if (partial) {
       partial[static_cast<size_t>(blockIdx.y) * n + t] = acc;
@@ -2493,7 +2764,12 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
       // The FMA variant needs a scan within 8192 cells of the sensor and a grid below 2^14 cells per side (its exact
       // fallback handles everything else inside the kernel); tuning.lf_fast = 0 forces the separately rounded arithmetic.
       const bool fast = tuning.lf_fast != 0 && scan_is_short && f.W < 16384 && f.H < 16384;
-      if (fast)
+      const uint32_t patch_base = (static_cast<uint32_t>(pal_lds) + 15u) & ~15u;
+      const size_t patch_lds = patch_base + kPatchLds;
+      if (fast && tuning.lf_patch != 0 && patch_lds <= 65536)
+        hipLaunchKernelGGL(k_reweight_lf_patch, dim3(static_cast<unsigned>((n + kPatchParticles - 1) / kPatchParticles), segments),
+                           dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial, per_segment, patch_base);
+      else if (fast)
         hipLaunchKernelGGL(k_reweight_lf_palette<true>, pgrid, dim3(kPalBlock), pal_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose,
                            partial, per_segment);
       else
