@@ -700,28 +700,38 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
 
   if (producer) {
     const int y_last = static_cast<int>((f.H + 7u) & ~7u);  // first row of the bottom border tiles
-    auto produce = [&](uint32_t g) {
+    // The patch of group g, clamped into the bordered table (whatever lies outside the grid reads the unknown entry, like
+    // a clamped gather): this lane's column, tile row by tile row.  Fetched a step before it is stored: while the
+    // consumers work on group g the patch of g + 1 goes from registers to LDS and the one of g + 2 is on its way.
+    uint4 piece[kPatchH / 8];
+    auto fetch = [&](uint32_t g) {
       int x0, y0;
-      if (!plan_of(g, x0, y0)) return;
-      // the patch, clamped into the bordered table (whatever lies outside the grid reads the unknown entry, like a clamped
-      // gather): this lane's column, tile row by tile row
+      if (g >= groups || !plan_of(g, x0, y0)) return;
       const int xu = x0 + static_cast<int>(lane) - static_cast<int>(kFastBias);
-      const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W))) << 4;
-      uint4 piece[kPatchH / 8];
+      // + 8: the border tile's share of palette_row_offset goes here, so that the vector offset - the one the buffer's
+      // range check looks at - is never negative
+      const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W)) + 8) << 4;
 #pragma unroll
       for (int r = 0; r < kPatchH / 8; ++r) {
         const int yu = y0 + 8 * r - static_cast<int>(kFastBias);
         const int yc = min(max(yu, -8), y_last);  // scalar
-        piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, column, palette_row_offset(yc, f.pal_pitch), 0));
+        piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, column, palette_row_offset(yc, f.pal_pitch) - 128u, 0));
       }
+    };
+    auto store = [&](uint32_t g) {
+      int x0, y0;
+      if (g >= groups || !plan_of(g, x0, y0)) return;
       unsigned char* dst = smem + patch_base + (g & 1) * kPatchBytes + lane * kPatchPitch;
 #pragma unroll
       for (int r = 0; r < kPatchH / 8; ++r) *reinterpret_cast<uint4*>(dst + r * 16) = piece[r];
     };
-    if (groups) produce(0);
+    fetch(0);
+    store(0);
+    fetch(1);
     for (uint32_t g = 0; g < groups; ++g) {
-      __syncthreads();
-      if (g + 1 < groups) produce(g + 1);
+      __syncthreads();  // the consumers are done with group g - 1: its buffer takes the patch of g + 1
+      store(g + 1);
+      fetch(g + 2);
     }
     return;
   }
@@ -732,6 +742,7 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
   const uint32_t row_bias = 4u - (kFastBias << 2);  // LDS byte address of the row entry = (biased y << 2) + row_bias
   struct Lookups {
     uint16_t e[8];  // palette addresses; widened where they are used, after the wait for them
+    uint32_t redo;  // 1: the group is added by add_exact instead
   };
   // The separately rounded evaluation, beam by beam with plain gathers.
   auto add_exact = [&](uint32_t b0, uint32_t count) {
@@ -743,8 +754,8 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
       acc += lf_palette_value(lf_palette_fetch(rsrc, f, floor_rd_result(vx), floor_rd_result(vy), kFastBiasX));
     }
   };
-  auto consume = [&](const Lookups& e, uint32_t redo, uint32_t b0) {
-    if (redo) {
+  auto consume = [&](const Lookups& e, uint32_t b0) {
+    if (__builtin_amdgcn_readfirstlane(e.redo)) {
       add_exact(b0, 8);
       return;
     }
@@ -753,17 +764,16 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
   };
   // One step: the end-points of group g, then the sum of the group before it (its gathers, if any, had the end-point
   // arithmetic to arrive), then the look-ups of group g.  `redo`: 1 if the group has to be added by add_exact instead.
-  auto step = [&](auto add_before, uint32_t g_any, Lookups& now, uint32_t& now_redo, const Lookups& before, uint32_t before_redo) {
+  auto step = [&](auto add_before, uint32_t g_any, Lookups& now, const Lookups& before) {
     const uint32_t g = __builtin_amdgcn_readfirstlane(g_any);  // uniform anyway; this keeps the scan reads on the scalar unit
-    before_redo = __builtin_amdgcn_readfirstlane(before_redo);
     const uint32_t b0 = b_begin + 8 * g;
     int x0 = 0, y0 = 0;
     const bool in_patch = plan_of(g, x0, y0);
     const uint32_t K = patch_base + (g & 1) * kPatchBytes - (static_cast<uint32_t>(x0) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0) << 1);
     __syncthreads();
-    now_redo = 1u;
+    now.redo = 1u;
     if (!fast) {
-      if constexpr (decltype(add_before)::value) consume(before, before_redo, b0 - 8);
+      if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
       return;
     }
     const double* q = pts + 2 * b0;
@@ -779,7 +789,7 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
       cx[k] = static_cast<int>(bx >> 32);
       cy[k] = static_cast<int>(by >> 32);
     }
-    if constexpr (decltype(add_before)::value) consume(before, before_redo, b0 - 8);
+    if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
     if (in_patch) {
 #pragma unroll
       for (int k = 0; k < 8; ++k)
@@ -793,25 +803,24 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
         now.e[k] = static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, (static_cast<uint32_t>(xc) << 4) + row, 0, 0));
       }
     }
-    now_redo = __builtin_amdgcn_ballot_w64(lowest < 4u) != 0 ? 1u : 0u;
+    now.redo = __builtin_amdgcn_ballot_w64(lowest < 4u) != 0 ? 1u : 0u;
   };
   if (groups) {
     Lookups a, c;
-    uint32_t a_redo = 0, c_redo = 0;
     uint32_t g;
     if (groups & 1) {
-      step(std::false_type{}, 0, a, a_redo, a, 0);
+      step(std::false_type{}, 0, a, a);
       g = 1;
     } else {
-      step(std::false_type{}, 0, c, c_redo, c, 0);
-      step(std::true_type{}, 1, a, a_redo, c, c_redo);
+      step(std::false_type{}, 0, c, c);
+      step(std::true_type{}, 1, a, c);
       g = 2;
     }
     for (; g < groups; g += 2) {  // `a` holds group g - 1
-      step(std::true_type{}, g, c, c_redo, a, a_redo);
-      step(std::true_type{}, g + 1, a, a_redo, c, c_redo);
+      step(std::true_type{}, g, c, a);
+      step(std::true_type{}, g + 1, a, c);
     }
-    consume(a, a_redo, b_begin + 8 * groups - 8);
+    consume(a, b_begin + 8 * groups - 8);
   }
   add_exact(b_begin + 8 * groups, b_end - (b_begin + 8 * groups));
   if (t < n) {

@@ -845,6 +845,33 @@ def test_reweight_lf_fma_variant_is_bit_identical(fast):
     f.close()
 
 
+@pytest.mark.parametrize("n", [16_384, 66_667, 200_000, 300_000])
+def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n):
+    """The default LF kernel reads the index table through per-workgroup LDS patches wherever a bound on the workgroup's
+    spread proves the look-ups inside one (k_reweight_lf_patch); option lf_patch = 0 gathers every look-up from global memory.
+    Same cells, same sums: the weights are identical bit for bit - here on a small map, where a wide initial cloud puts
+    patches across all four grid edges (clamped columns and rows), over the segmented launches of small sets (57, 360 and
+    1080 beams: 1 to 16 segments, with and without a tail of beams) - and both agree with the oracle."""
+    cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
+    grid = OccupancyGrid(cells=cells, resolution=0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
+    truth = synth.find_free_pose(cells, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
+    for beams in (57, 360, 1080):
+        pts = make_scan(grid, truth, beams, max_range=12.0)
+        weights = []
+        for patch in (1, 0):
+            f = new_filter(grid, n)
+            f.set_option("lf_patch", patch)
+            f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+            states, w0 = f.particles()
+            f.reweight(pts)
+            weights.append(f.particles()[1].copy())
+            if patch == 1 and n <= 66_667:
+                want = w0 * orc.lf_weights(f.likelihood_field(), 0.05, grid.origin, LF.max_laser_distance, states, pts)
+                np.testing.assert_allclose(weights[0], want, rtol=RTOL, atol=0)
+            f.close()
+        assert np.array_equal(weights[0], weights[1]), (n, beams, int((weights[0] != weights[1]).sum()))
+
+
 def test_spatial_order_is_a_sorted_permutation():
     """The ordering pass (two-pass radix sort of the 20-bit keys, the second pass stable): perm is a permutation and
     keys[perm] is non-decreasing — with the key frame from the host's estimate, from a bounding-box pass (set_particles
