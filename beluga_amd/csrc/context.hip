@@ -262,6 +262,13 @@ struct mcl_ctx {
   double cloud_mean[3]{0, 0, 0};   // x, y, theta
   double cloud_sigma[3]{0, 0, 0};  // standard deviations of x, y, theta
   uint64_t lf_fast_launches{0};    // launches of the FMA variant of the LF kernel (mcl_get_counter)
+  // The LDS-patch kernel reports how many beam groups it planned and how many went through a patch (running totals in
+  // d_scalars[24..27), mirrored to h_scalars[28..30)); a launch that found few sends the next ones to the gather kernel,
+  // with a probe every 16th launch (option lf_patch = 1).
+  uint64_t lf_patch_launches{0};
+  uint64_t patch_seen_planned{0}, patch_seen_through{0};
+  bool patch_useful{true};
+  int patch_probe_in{0};
   // scratch of the spatial ordering
   DeviceBuffer<uint32_t> d_route_u32;           // scratch of mcl_route_targets
   DeviceBuffer<uint32_t> d_sort_u32;            // keys[cap] perm[cap] table[1024 * nblocks] totals[1024]
@@ -586,6 +593,34 @@ void remember_cloud_estimate(mcl_ctx* ctx, const mcl_estimate& est) {
                              std::isfinite(ctx->cloud_sigma[0]) && std::isfinite(ctx->cloud_sigma[1]);
 }
 
+// Whether the next LF launch goes to the LDS-patch kernel (where its other preconditions hold): by the verdict of the last
+// launch that has reported.  A dispersed set (global localisation) has no group that fits a patch, and the patch kernel's
+// workgroups carry a wave that would then do nothing.
+void patch_totals(const mcl_ctx* ctx, uint64_t* planned, uint64_t* through) {
+  const volatile uint64_t* mirror = reinterpret_cast<const volatile uint64_t*>(ctx->h_scalars + 28);
+  *planned = mirror[0];
+  *through = mirror[1];
+}
+bool wants_patches(mcl_ctx* ctx) {
+  if (ctx->tuning.lf_patch == 0) return false;
+  if (ctx->tuning.lf_patch != 1) return true;
+  uint64_t planned, through;
+  patch_totals(ctx, &planned, &through);
+  if (planned > ctx->patch_seen_planned) {  // a launch has reported since the last look
+    const uint64_t dp = planned - ctx->patch_seen_planned, dt = through - ctx->patch_seen_through;
+    ctx->patch_seen_planned = planned;
+    ctx->patch_seen_through = through;
+    ctx->patch_useful = 4 * dt >= dp;
+    if (!ctx->patch_useful) ctx->patch_probe_in = 16;
+  }
+  if (ctx->patch_useful) return true;
+  if (--ctx->patch_probe_in <= 0) {
+    ctx->patch_probe_in = 16;
+    return true;  // a probe
+  }
+  return false;
+}
+
 bool wants_ordering(const mcl_ctx* ctx) {
   if (ctx->n < static_cast<uint64_t>(ctx->tuning.sort_min_particles) || ctx->n >= (1ull << 32)) return false;
   return ctx->cfg.sensor_kind == MCL_SENSOR_BEAM || ctx->tuning.lf_variant == kLfSortedLanes;
@@ -642,12 +677,18 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     const int variant = (ctx->tuning.lf_variant == kLfSortedLanes && !ordered) ? kLfLanePerParticle : ctx->tuning.lf_variant;
     const bool scan_is_short = ctx->scan_extent / ctx->resolution < 8192.0;
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
+    const bool use_patches = wants_patches(ctx);
     launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B), variant, &sort,
-                       scan_is_short, ctx->tuning);
+                       scan_is_short, ctx->tuning, use_patches,
+                       PatchStats{reinterpret_cast<unsigned long long*>(ctx->d_scalars.ptr + 24),
+                                  reinterpret_cast<unsigned long long*>(ctx->hd_scalars + 28)});
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
     if (variant == kLfSortedLanes && ctx->tuning.lf_fast != 0 && scan_is_short && ctx->W < 16384 && ctx->H < 16384 && ctx->pal_count &&
         ctx->tuning.lf_table == 0)
+    {
       ctx->lf_fast_launches += 1;
+      if (use_patches) ctx->lf_patch_launches += 1;  // (unless the tables leave no room in LDS for the patches: launch_reweight_lf)
+    }
   } else {
     const mcl_beam_params& b = ctx->cfg.beam;
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
@@ -2101,7 +2142,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   if (key == "lf_variant") t.lf_variant = value == 0 ? kLfWavePerParticle : (value == 1 ? kLfLanePerParticle : kLfSortedLanes);
   else if (key == "lf_fast") t.lf_fast = value < 0 ? -1 : (value ? 1 : 0);
   else if (key == "lf_table") t.lf_table = value ? 1 : 0;
-  else if (key == "lf_patch") t.lf_patch = value ? 1 : 0;
+  else if (key == "lf_patch") t.lf_patch = value < 0 || value > 2 ? 1 : static_cast<int>(value);
   else if (key == "device_policy") t.device_policy = value ? 1 : 0;
   else if (key == "field_build") t.field_build = value ? 1 : 0;
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
@@ -2113,6 +2154,14 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
   if (!ctx || !name || !value) return MCL_ERR_INVALID_ARGUMENT;
   const std::string key(name);
   if (key == "lf_fast_launches") *value = ctx->lf_fast_launches;
+  else if (key == "lf_patch_launches") *value = ctx->lf_patch_launches;
+  else if (key == "lf_patch_groups_planned" || key == "lf_patch_groups_through") {
+    if (const mcl_status s = bind_device(ctx)) return s;
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t planned, through;
+    patch_totals(ctx, &planned, &through);
+    *value = key == "lf_patch_groups_planned" ? planned : through;
+  }
   else if (key == "field_build_us") *value = static_cast<uint64_t>(ctx->field_build_ms * 1e3);  // kernels of the last device field build
   else if (key == "field_built_on_device") *value = ctx->field_built_on_device ? 1 : 0;
   else return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "mcl_get_counter: unknown counter " + key);

@@ -107,7 +107,8 @@ struct Tuning {
   int lf_variant = kLfSortedLanes;  // kernel family of the likelihood-field reweight
   int lf_fast = -1;                 // FMA variant with exact fallback: -1 / 1 = whenever its preconditions hold, 0 = never
   int lf_table = 0;                 // 0 = palette table when the field allows it, 1 = force the 8-byte cube table
-  int lf_patch = 1;                 // index table read through per-workgroup LDS patches (0: per-lane gathers only)
+  int lf_patch = 1;                 // index table through per-workgroup LDS patches: 1 = where the last launch found them useful,
+                                    // 0 = never (per-lane gathers only), 2 = always
   int device_policy = 1;            // recovery estimator on the device when the cycle has no host-side decision
   int sort_min_particles = 16384;   // below this the ordering passes cost more than they save
   int field_build = 0;              // mcl_set_map: 0 = host wavefront (bit-identical to the reference), 1 = exact EDT on the device
@@ -151,8 +152,13 @@ void launch_pull_scan(hipStream_t st, const double* scan_src, double* scan_dst, 
 void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortScratch* sort, const KeyFrame* frame, bool keys_ready);
 // K2  actions/reweight.hpp:53-60 + likelihood_field_model.hpp:68-91 (kLfSortedLanes needs launch_order_particles first)
 // scan_is_short: every scan point lies within 8192 cells of the sensor (precondition of the kernel's FMA variant)
+// use_patches: the LDS-patch kernel where its preconditions hold (dense sets); patch_stats: running totals it reports
+struct PatchStats {
+  unsigned long long* device;  // [3]: groups planned, groups through a patch, workgroups reported (never reset)
+  unsigned long long* mirror;  // [2]: mapped host copy of the first two, written by the last workgroup of a launch
+};
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
-                        const SortScratch* sort, bool scan_is_short, const Tuning& tuning);
+                        const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_order_particles first).
 // d_beam_points: scratch of kBeamPointDoubles * B doubles (per-beam terms shared by all particles; ordered variant only).

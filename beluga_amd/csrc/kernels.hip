@@ -566,8 +566,8 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
 // A scattered 64-lane 2-byte gather costs the CU's texture-address pipe one cycle per quad of lanes per line (16+ per
 // instruction, profiles/r02_calib_gather_cost.txt): the floor of k_reweight_lf_palette.  An LDS read of the same shape costs
 // two.  A workgroup holds 448 neighbours of the spatial order (waves 0-6, one lane per particle) and a PRODUCER (wave 7, no
-// particles).  For a group of 8 consecutive beams the end-point of particle p differs from that of the workgroup's middle
-// particle, the reference, by (t_p - t_ref) + (R_p - R_ref) q, at most
+// particles).  For a group of 8 consecutive beams the end-point of particle p differs from that of a reference pose in the
+// middle of the workgroup's particles by (t_p - t_ref) + (R_p - R_ref) q, at most
 //     (Dx, Dy) + |q| Drot      Dx, Dy = max |t_p - t_ref| per axis,  Drot = max |R_p - R_ref| = max 2 |sin(dtheta / 2)|
 // over the workgroup (one reduction in the prologue).  If the bounding box of the reference's 8 end-point cells, widened by
 // that margin (+2 cells for every rounding involved), fits into 64 x 64 cells, the group goes through a PATCH: the producer
@@ -594,13 +594,15 @@ constexpr uint32_t kPatchPitch = kPatchH * 2 + 16;
 constexpr uint32_t kPatchBytes = kPatchW * kPatchPitch;
 constexpr uint32_t kPatchParticles = kPalBlock - 64;  // per workgroup
 constexpr uint32_t kPatchPlanned = 256;               // groups with a plan entry; the ones beyond are gathered
-constexpr uint32_t kPatchLds = 2 * kPatchBytes + kPatchPlanned * 8 + 32 * 4;  // two patches, the plan, the bound's partial maxima
+constexpr uint32_t kPatchLds = 2 * kPatchBytes + kPatchPlanned * 8 + 48 * 4;  // two patches, the plan, the prologue's partial results
 constexpr double kPatchMagic = 1572864.0 + 4.656612873077392578125e-10;     // 1.5 * 2^20 + 2^-31
-__global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restrict__ w, uint64_t n, FieldView f,
+// 6 waves per SIMD = three workgroups per CU: at most 80 registers
+__global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reweight_lf_patch(double* __restrict__ w, uint64_t n, FieldView f,
                                                                  const double* __restrict__ pts, uint32_t B,
                                                                  const uint32_t* __restrict__ perm, const double4* __restrict__ pose,
                                                                  double* __restrict__ partial, uint32_t beams_per_segment,
-                                                                 uint32_t patch_base /* LDS byte offset, 16-aligned */) {
+                                                                 uint32_t patch_base /* LDS byte offset, 16-aligned */,
+                                                                 PatchStats stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
     uint32_t* s_row = reinterpret_cast<uint32_t*>(smem);
@@ -611,13 +613,12 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
   }
   // plan entry of group g: biased x0; biased y0 (a multiple of 8) | 1 if the group goes through a patch
   int2* s_plan = reinterpret_cast<int2*>(smem + patch_base + 2 * kPatchBytes);
-  float* s_bound = reinterpret_cast<float*>(smem + patch_base + 2 * kPatchBytes + kPatchPlanned * 8);  // [7][3] (+ padding)
+  float* s_bound = reinterpret_cast<float*>(smem + patch_base + 2 * kPatchBytes + kPatchPlanned * 8);  // [7][6]
   const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPalBlock / 64 - 1);  // a scalar branch: the roles
                                                                                                   // run different loops
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t first = static_cast<uint64_t>(blockIdx.x) * kPatchParticles;
-  const uint64_t t_ref = first + kPatchParticles / 2 < n ? first + kPatchParticles / 2 : n - 1;
-  const uint64_t t = producer ? t_ref : first + threadIdx.x;
+  const uint64_t t = producer ? first : first + threadIdx.x;  // (the producer holds no particle; it reads a valid one)
   const uint64_t tt = t < n ? t : n - 1;
   const uint32_t i = perm[tt];
   const Pose2 T = ordered_pose(f.world_to_field, pose, i);  // likelihood_field_model.hpp:70
@@ -631,13 +632,55 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
   const double ixm = ixt + kPatchMagic, iym = iyt + kPatchMagic;
   const bool lane_small = fabs(ixt) < 16384.0 && fabs(iyt) < 16384.0;  // false for NaN as well
 
-  // ---- the bound: every wave's lanes against the reference particle, then the workgroup's maxima
-  const Pose2 R = ordered_pose(f.world_to_field, pose, perm[t_ref]);
-  const double rc = R.r.c * f.inv_resolution, rs = R.r.s * f.inv_resolution;
-  const double rxm = R.x * f.inv_resolution + kPatchMagic, rym = R.y * f.inv_resolution + kPatchMagic;
+  // ---- the reference pose: the middle of the workgroup's box in x and y, its mean heading (any pose would do: the bound
+  // below is taken against whatever is chosen here; a central one makes it small).  In cells, like ixt, iyt.
+  float* s_part = s_bound;  // [7][6] partial results, then [7][3]
   if (!producer) {
-    const double dc = ct - R.r.c, ds = st - R.r.s;
-    float dx = static_cast<float>(fabs(ixt - R.x * f.inv_resolution)), dy = static_cast<float>(fabs(iyt - R.y * f.inv_resolution));
+    float lo_x = static_cast<float>(ixt), hi_x = lo_x, lo_y = static_cast<float>(iyt), hi_y = lo_y;
+    float sum_c = static_cast<float>(ct), sum_s = static_cast<float>(st);
+    for (int o = 32; o > 0; o >>= 1) {
+      lo_x = fminf(lo_x, __shfl_xor(lo_x, o));
+      hi_x = fmaxf(hi_x, __shfl_xor(hi_x, o));
+      lo_y = fminf(lo_y, __shfl_xor(lo_y, o));
+      hi_y = fmaxf(hi_y, __shfl_xor(hi_y, o));
+      sum_c += __shfl_xor(sum_c, o);
+      sum_s += __shfl_xor(sum_s, o);
+    }
+    if (lane == 0) {
+      float* mine = s_part + 6 * (threadIdx.x >> 6);
+      mine[0] = lo_x;
+      mine[1] = hi_x;
+      mine[2] = lo_y;
+      mine[3] = hi_y;
+      mine[4] = sum_c;
+      mine[5] = sum_s;
+    }
+  }
+  __syncthreads();
+  double ref_c, ref_s, ref_x, ref_y;
+  {
+    float lo_x = s_part[0], hi_x = s_part[1], lo_y = s_part[2], hi_y = s_part[3], sum_c = s_part[4], sum_s = s_part[5];
+    for (uint32_t k = 1; k < kPalBlock / 64 - 1; ++k) {
+      lo_x = fminf(lo_x, s_part[6 * k]);
+      hi_x = fmaxf(hi_x, s_part[6 * k + 1]);
+      lo_y = fminf(lo_y, s_part[6 * k + 2]);
+      hi_y = fmaxf(hi_y, s_part[6 * k + 3]);
+      sum_c += s_part[6 * k + 4];
+      sum_s += s_part[6 * k + 5];
+    }
+    const float len = sqrtf(sum_c * sum_c + sum_s * sum_s);
+    ref_c = len > 0.f ? static_cast<double>(sum_c / len) : 1.0;  // a NaN stays one, and switches the patches off below
+    ref_s = len > 0.f ? static_cast<double>(sum_s / len) : 0.0;
+    ref_x = static_cast<double>(0.5f * (lo_x + hi_x));
+    ref_y = static_cast<double>(0.5f * (lo_y + hi_y));
+  }
+  const double rc = ref_c * f.inv_resolution, rs = ref_s * f.inv_resolution;
+  const double rxm = ref_x + kPatchMagic, rym = ref_y + kPatchMagic;
+  __syncthreads();  // the partial results are read; their place takes the next ones
+  // ---- the bound: every wave's lanes against the reference pose, then the workgroup's maxima
+  if (!producer) {
+    const double dc = ct - ref_c, ds = st - ref_s;
+    float dx = static_cast<float>(fabs(ixt - ref_x)), dy = static_cast<float>(fabs(iyt - ref_y));
     float dr = static_cast<float>(sqrt(dc * dc + ds * ds));
     if (!(lane_small && dx < 1e6f && dy < 1e6f && dr < 4.f)) dx = dy = dr = INFINITY;  // a far or non-finite particle: no patches
     for (int o = 32; o > 0; o >>= 1) {
@@ -653,7 +696,8 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
     }
   }
   __syncthreads();
-  // ---- the plan: thread g looks at group g through the reference particle
+  // ---- the plan: thread g looks at group g through the reference pose
+  bool mine_fits = false;
   if (threadIdx.x < groups && threadIdx.x < kPatchPlanned) {
     float Dx = 0.f, Dy = 0.f, Drot = 0.f;
     for (uint32_t k = 0; k < kPalBlock / 64 - 1; ++k) {
@@ -687,8 +731,19 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
     const int x0 = lo_x - margin_x, y0 = (lo_y - margin_y) & ~7;
     fits = fits && hi_x + margin_x - x0 < kPatchW && hi_y + margin_y - y0 < kPatchH;
     s_plan[threadIdx.x] = int2{x0, y0 | (fits ? 1 : 0)};
+    mine_fits = fits;
+  }
+  // A workgroup with (almost) no group through a patch - a dispersed set - drops the machinery: no producer, no barriers.
+  // (counted by hand: __syncthreads_count brings a static LDS variable with it, and this kernel addresses LDS from 0)
+  uint32_t* s_count = reinterpret_cast<uint32_t*>(s_bound) + 24;  // behind the bound's [7][3]
+  {
+    const uint32_t in_wave = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine_fits)));
+    if (lane == 0) s_count[threadIdx.x >> 6] = in_wave;
   }
   __syncthreads();
+  uint32_t fitting = 0;
+  for (uint32_t k = 0; k < kPalBlock / 64; ++k) fitting += s_count[k];
+  const bool loose = __builtin_amdgcn_readfirstlane(fitting) * 8u < groups;
   auto plan_of = [&](uint32_t g, int& x0, int& y0) -> bool {  // g uniform; scalar results
     if (g >= kPatchPlanned) return false;
     const int2 e = s_plan[g];
@@ -699,6 +754,28 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
   };
 
   if (producer) {
+    // The launch's statistics (what the host picks the next launch's kernel by): groups planned and groups through a
+    // patch, summed over a sample of the workgroups - every 16th of a large launch: thousands of atomic operations on one
+    // address would cost more than the kernel's other work - ; the last one to report copies the running totals to the
+    // host's mirror.
+    auto report = [&]() {
+      const uint32_t stride = gridDim.x >= 256 ? 16u : 1u;
+      if (stats.device && lane == 0 && blockIdx.x % stride == 0) {
+        atomicAdd(stats.device + 0, static_cast<unsigned long long>(groups));
+        atomicAdd(stats.device + 1, static_cast<unsigned long long>(loose ? 0u : fitting));
+        __threadfence();
+        const unsigned long long reporters = static_cast<unsigned long long>((gridDim.x + stride - 1) / stride) * gridDim.y;
+        const unsigned long long ticket = atomicAdd(stats.device + 2, 1ull) + 1ull;
+        if (ticket % reporters == 0 && stats.mirror) {
+          stats.mirror[0] = atomicAdd(stats.device + 0, 0ull);
+          stats.mirror[1] = atomicAdd(stats.device + 1, 0ull);
+        }
+      }
+    };
+    if (loose) {
+      report();
+      return;
+    }
     const int y_last = static_cast<int>((f.H + 7u) & ~7u);  // first row of the bottom border tiles
     // The patch of group g, clamped into the bordered table (whatever lies outside the grid reads the unknown entry, like
     // a clamped gather): this lane's column, tile row by tile row.  Fetched a step before it is stored: while the
@@ -733,6 +810,7 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
       store(g + 1);
       fetch(g + 2);
     }
+    report();  // off the consumers' path: they are still at their last group
     return;
   }
 
@@ -764,13 +842,14 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
   };
   // One step: the end-points of group g, then the sum of the group before it (its gathers, if any, had the end-point
   // arithmetic to arrive), then the look-ups of group g.  `redo`: 1 if the group has to be added by add_exact instead.
-  auto step = [&](auto add_before, uint32_t g_any, Lookups& now, const Lookups& before) {
+  auto step = [&](auto is_loose, auto add_before, uint32_t g_any, Lookups& now, const Lookups& before) {
     const uint32_t g = __builtin_amdgcn_readfirstlane(g_any);  // uniform anyway; this keeps the scan reads on the scalar unit
     const uint32_t b0 = b_begin + 8 * g;
     int x0 = 0, y0 = 0;
-    const bool in_patch = plan_of(g, x0, y0);
+    bool in_patch = false;
+    if constexpr (!decltype(is_loose)::value) in_patch = plan_of(g, x0, y0);
     const uint32_t K = patch_base + (g & 1) * kPatchBytes - (static_cast<uint32_t>(x0) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0) << 1);
-    __syncthreads();
+    if constexpr (!decltype(is_loose)::value) __syncthreads();
     now.redo = 1u;
     if (!fast) {
       if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
@@ -805,22 +884,26 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_patch(double* __restr
     }
     now.redo = __builtin_amdgcn_ballot_w64(lowest < 4u) != 0 ? 1u : 0u;
   };
-  if (groups) {
+  auto run = [&](auto is_loose) {
     Lookups a, c;
     uint32_t g;
     if (groups & 1) {
-      step(std::false_type{}, 0, a, a);
+      step(is_loose, std::false_type{}, 0, a, a);
       g = 1;
     } else {
-      step(std::false_type{}, 0, c, c);
-      step(std::true_type{}, 1, a, c);
+      step(is_loose, std::false_type{}, 0, c, c);
+      step(is_loose, std::true_type{}, 1, a, c);
       g = 2;
     }
     for (; g < groups; g += 2) {  // `a` holds group g - 1
-      step(std::true_type{}, g, c, a);
-      step(std::true_type{}, g + 1, a, c);
+      step(is_loose, std::true_type{}, g, c, a);
+      step(is_loose, std::true_type{}, g + 1, a, c);
     }
     consume(a, b_begin + 8 * groups - 8);
+  };
+  if (groups) {
+    if (loose) run(std::true_type{});
+    else run(std::false_type{});
   }
   add_exact(b_begin + 8 * groups, b_end - (b_begin + 8 * groups));
   if (t < n) {
@@ -2749,7 +2832,7 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
 }
 
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
-                        const SortScratch* sort, bool scan_is_short, const Tuning& tuning) {
+                        const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats) {
   if (n == 0) return;
   const bool idx32 = static_cast<uint64_t>(f.W) * f.H < (1ull << 31);
   if (variant == kLfSortedLanes && sort && n < (1ull << 32)) {
@@ -2775,9 +2858,10 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
       const bool fast = tuning.lf_fast != 0 && scan_is_short && f.W < 16384 && f.H < 16384;
       const uint32_t patch_base = (static_cast<uint32_t>(pal_lds) + 15u) & ~15u;
       const size_t patch_lds = patch_base + kPatchLds;
-      if (fast && tuning.lf_patch != 0 && patch_lds <= 65536)
+      if (fast && use_patches && patch_lds <= 65536)
         hipLaunchKernelGGL(k_reweight_lf_patch, dim3(static_cast<unsigned>((n + kPatchParticles - 1) / kPatchParticles), segments),
-                           dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial, per_segment, patch_base);
+                           dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial, per_segment, patch_base,
+                           patch_stats);
       else if (fast)
         hipLaunchKernelGGL(k_reweight_lf_palette<true>, pgrid, dim3(kPalBlock), pal_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose,
                            partial, per_segment);

@@ -367,6 +367,9 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *   lf_variant (2)  likelihood-field kernel family: 2 = spatially ordered lanes, 1 = lane per particle, 0 = wave per particle
  *   lf_fast (-1)    FMA variant with exact fallback: nonzero = whenever its preconditions hold, 0 = never
  *   lf_table (0)    1 = force the 8-byte table instead of the palette
+ *   lf_patch (1)    index table through per-workgroup LDS patches (dense sets): 1 = where the last launch found them useful
+ *                   (a dispersed set - global localisation - has none, and is sent to the per-lane gathers, with a probe every
+ *                   16th launch), 0 = never, 2 = always
  *   device_policy (1)  recovery estimator on the device when the cycle takes no host-side decision
  *   sort_min_particles (16384)  below this many particles the spatial ordering is skipped
  *   field_build (0)  how the NEXT mcl_set_map builds the likelihood field: 0 = the reference's priority-queue wavefront on the
@@ -374,7 +377,9 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                    (milliseconds; equal at all but the few cells where the wavefront does not find the nearest obstacle,
  *                    never farther from the truth; falls back to 0 when max_obstacle_distance spans more than 1024 cells).
  *                    This one DOES change the field where the two algorithms differ; everything downstream follows the field.
- * Counters: lf_fast_launches = launches of the FMA variant so far; field_built_on_device, field_build_us = the last mcl_set_map. */
+ * Counters: lf_fast_launches = launches of the FMA variant so far; lf_patch_launches = those of them sent to the LDS-patch
+ *   kernel; lf_patch_groups_planned / lf_patch_groups_through = groups of 8 beams (per workgroup) that kernel has looked at /
+ *   has read through a patch, running totals over a sample of the workgroups; field_built_on_device, field_build_us = the last mcl_set_map. */
 mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value);
 mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value);
 /* Runs the spatial ordering on the current set and returns it: perm[t] = particle at position t, keys[i] = ordering key

@@ -848,7 +848,7 @@ def test_reweight_lf_fma_variant_is_bit_identical(fast):
 @pytest.mark.parametrize("n", [16_384, 66_667, 200_000, 300_000])
 def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n):
     """The default LF kernel reads the index table through per-workgroup LDS patches wherever a bound on the workgroup's
-    spread proves the look-ups inside one (k_reweight_lf_patch); option lf_patch = 0 gathers every look-up from global memory.
+    spread proves the look-ups inside one (k_reweight_lf_patch, forced by option lf_patch = 2); lf_patch = 0 gathers every look-up.
     Same cells, same sums: the weights are identical bit for bit - here on a small map, where a wide initial cloud puts
     patches across all four grid edges (clamped columns and rows), over the segmented launches of small sets (57, 360 and
     1080 beams: 1 to 16 segments, with and without a tail of beams) - and both agree with the oracle."""
@@ -858,14 +858,14 @@ def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n):
     for beams in (57, 360, 1080):
         pts = make_scan(grid, truth, beams, max_range=12.0)
         weights = []
-        for patch in (1, 0):
+        for patch in (2, 0):  # always / never
             f = new_filter(grid, n)
             f.set_option("lf_patch", patch)
             f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
             states, w0 = f.particles()
             f.reweight(pts)
             weights.append(f.particles()[1].copy())
-            if patch == 1 and n <= 66_667:
+            if patch == 2 and n <= 66_667:
                 want = w0 * orc.lf_weights(f.likelihood_field(), 0.05, grid.origin, LF.max_laser_distance, states, pts)
                 np.testing.assert_allclose(weights[0], want, rtol=RTOL, atol=0)
             f.close()
@@ -1005,4 +1005,11 @@ def test_dispersed_cloud_1m_sampled_against_oracle():
     sample = np.random.Generator(np.random.MT19937(1)).choice(n, 1024, replace=False)
     want = orc.lf_weights(f.likelihood_field(), 0.05, grid.origin, 100.0, states[sample], pts, threads=orc.max_threads())
     np.testing.assert_allclose(w[sample], want, rtol=RTOL)
+    # The first launch went to the LDS-patch kernel, which found (next to) no group of beams that fits a patch and said so:
+    # the next launches gather (option lf_patch = 1), same weights.
+    planned, through = f.counter("lf_patch_groups_planned"), f.counter("lf_patch_groups_through")
+    assert f.counter("lf_patch_launches") == 1 and planned >= (n // 448 // 16) * 135 and through * 4 < planned
+    f.set_particles(states, w0)
+    f.reweight(pts)
+    assert f.counter("lf_patch_launches") == 1 and np.array_equal(f.particles()[1], w)
     f.close()
