@@ -217,7 +217,7 @@ struct CdfTree {
   int depth;                              // number of sampled levels (0 for n <= 16)
   uint64_t n;
 };
-inline uint64_t cdf_tree_doubles(uint64_t n) { return n / 15 + 16 * kCdfTreeMaxDepth; }
+inline uint64_t cdf_tree_doubles(uint64_t n) { return n / 15 + 32 * kCdfTreeMaxDepth; }
 inline CdfTree make_cdf_tree(const double* cdf, const double* levels, uint64_t n) {
   CdfTree t{};
   t.cdf = cdf;
@@ -228,7 +228,7 @@ inline CdfTree make_cdf_tree(const double* cdf, const double* levels, uint64_t n
     size = (size + 15) / 16;
     t.offset[t.depth] = static_cast<uint32_t>(off);
     t.size[t.depth] = static_cast<uint32_t>(size);
-    off += size;
+    off += (size + 15) & ~15ull;  // every group of 16 entries in a 128-byte line of its own
     ++t.depth;
   }
   return t;

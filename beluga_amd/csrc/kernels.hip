@@ -2081,18 +2081,46 @@ __device__ __forceinline__ uint64_t lds_group_lower_bound(const double* a, uint3
   }
   return lo < end ? lo : end - 1;
 }
+// One group of the search, for all 64 lanes of a wave at once (every lane has to be here).  A lane's group is one 128-byte
+// line somewhere in `a`; four dependent 8-byte loads per lane - the binary search - make four instructions of 64 unrelated
+// lines each.  Instead the 8 lanes of an octet read ONE lane's line together, 16 bytes each (a fully coalesced access), eight
+// times; every lane compares its two entries with the served lane's target, and that lane counts the entries below the
+// target among the ballots' bits of its octet: in a sorted group that count is std::lower_bound's offset.
+__device__ __forceinline__ uint64_t wave_group_lower_bound(const double* __restrict__ a, uint32_t pos, uint64_t size, double target) {
+  const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, octet = lane & ~7u;
+  uint32_t below = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 8; ++j) {
+    const uint32_t served = octet + j;
+    const uint64_t first = static_cast<uint64_t>(__shfl(pos, served)) * 16u + 2u * sub;  // this lane's two entries of that group
+    const double their_target = __shfl(target, served);
+    double2 v;
+    if (first + 1 < size) {
+      v = *reinterpret_cast<const double2*>(a + first);
+    } else {  // the array's last, partial group
+      v.x = first < size ? a[first] : INFINITY;
+      v.y = INFINITY;
+    }
+    const uint64_t low = __builtin_amdgcn_ballot_w64(v.x < their_target), high = __builtin_amdgcn_ballot_w64(v.y < their_target);
+    if (sub == j)
+      below = static_cast<uint32_t>(__builtin_popcountll((low >> octet) & 0xFFull) + __builtin_popcountll((high >> octet) & 0xFFull));
+  }
+  const uint64_t begin = static_cast<uint64_t>(pos) * 16u, end = begin + 16 < size ? begin + 16 : size;
+  const uint64_t at = begin + below;
+  return at < end ? at : end - 1;
+}
+// The search with the sampled levels >= first_staged read from a workgroup copy in LDS (they are contiguous in t.levels
+// from t.offset[first_staged] on) and the groups in global memory read a wave at a time.  Same comparisons as
+// cdf_tree_lower_bound, same result.  Every lane of the wave has to call it (lanes with nothing to draw: any target).
 __device__ __forceinline__ uint64_t cdf_tree_lower_bound_staged(const CdfTree& t, const double* staged, int first_staged, double target) {
   uint64_t pos = 0;
   for (int l = t.depth - 1; l >= first_staged; --l) {
     const uint32_t begin = static_cast<uint32_t>(pos) * 16u, size = t.size[l];
     pos = lds_group_lower_bound(staged + (t.offset[l] - t.offset[first_staged]), begin, begin + 16 < size ? begin + 16 : size, target);
   }
-  for (int l = (first_staged < t.depth ? first_staged : t.depth) - 1; l >= 0; --l) {
-    const uint64_t begin = pos * 16, size = t.size[l];
-    pos = group_lower_bound(t.levels + t.offset[l], begin, begin + 16 < size ? begin + 16 : size, target);
-  }
-  const uint64_t begin = pos * 16;
-  return group_lower_bound(t.cdf, begin, begin + 16 < t.n ? begin + 16 : t.n, target);
+  for (int l = (first_staged < t.depth ? first_staged : t.depth) - 1; l >= 0; --l)
+    pos = wave_group_lower_bound(t.levels + t.offset[l], static_cast<uint32_t>(pos), t.size[l], target);
+  return wave_group_lower_bound(t.cdf, static_cast<uint32_t>(pos), t.n, target);
 }
 // multivariate_uniform_distribution.hpp:145-147 over occupancy_grid.hpp:140-146,164-171: uniform heading,
 // centre of a uniformly chosen free cell in the world frame.  Addressed by the candidate's global index.
@@ -2123,9 +2151,9 @@ __device__ __forceinline__ bool intersperse_here(const RngWords& r, uint64_t j, 
 // Workgroups of 1024 outputs share an LDS copy of the upper levels of the search tree (staged doubles from level
 // first_staged on; dynamic shared memory).
 constexpr int kDrawBlock = 1024;
-constexpr uint32_t kDrawStageMax = 4608;  // doubles (36 KB): two workgroups per CU
+constexpr uint32_t kDrawStageMax = 4608;  // doubles (36 KB): two workgroups per CU (which also takes 8 waves per SIMD: 64 registers)
 template <bool kEstimate>
-__global__ __launch_bounds__(kDrawBlock) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
+__global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
                                                               Particles dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
                                                               unsigned long long* __restrict__ hashes, double pivot_x, double pivot_y,
                                                               double* __restrict__ est_partials, uint32_t est_stride, int first_staged,
@@ -2140,20 +2168,22 @@ __global__ __launch_bounds__(kDrawBlock) void k_resample_draw(Particles src, Cdf
   __syncthreads();
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kDrawBlock + threadIdx.x;
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // The search reads global memory a wave at a time: every lane goes through it, the ones with nothing to draw (beyond
+  // the count, or taking an injected random state) with a target of zero.
+  const uint64_t j = a.first_candidate + t;
+  const RngWords r = rng_draw(a.seed, a.step, kRngResample, j);
+  const double p_random = a.d_random_state_probability ? *a.d_random_state_probability : a.random_state_probability;
+  const bool intersperse = t < a.count && intersperse_here(r, j, p_random, fc.count);
+  uint64_t idx = 0;
+  if (a.n_in >= 2) {
+    const double target = (t < a.count && !intersperse) ? rng_uniform53(r.w[0], r.w[1]) * (*d_total) : 0.0;
+    idx = cdf_tree_lower_bound_staged(cdf, staged, first_staged, target);
+  }
   if (t < a.count) {
-    const uint64_t j = a.first_candidate + t;
-    const RngWords r = rng_draw(a.seed, a.step, kRngResample, j);
     Pose2 s;
-    const double p_random = a.d_random_state_probability ? *a.d_random_state_probability : a.random_state_probability;
-    const bool intersperse = intersperse_here(r, j, p_random, fc.count);
     if (intersperse) {
       s = random_free_state(a.seed, a.step, j, g, fc);
     } else {
-      uint64_t idx = 0;
-      if (a.n_in >= 2) {
-        const double u = rng_uniform53(r.w[0], r.w[1]);
-        idx = cdf_tree_lower_bound_staged(cdf, staged, first_staged, u * (*d_total));
-      }
       s = load_pose(src, idx);
     }
     const uint64_t o = a.out_offset + t;
@@ -3030,9 +3060,9 @@ namespace {
 void draw_staging(const CdfTree& t, int& first, uint32_t& doubles) {
   first = t.depth;
   doubles = 0;
-  while (first > 0 && doubles + t.size[first - 1] <= kDrawStageMax) {
+  while (first > 0 && t.offset[t.depth - 1] + t.size[t.depth - 1] - t.offset[first - 1] <= kDrawStageMax) {
     --first;
-    doubles += t.size[first];
+    doubles = t.offset[t.depth - 1] + t.size[t.depth - 1] - t.offset[first];  // the levels' padding included
   }
 }
 }  // namespace

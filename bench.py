@@ -355,6 +355,10 @@ def main():
         bytes_lf = lf_algorithmic_bytes(n_local, BEAMS)
         achieved = bytes_lf / lf_avg_s if lf_avg_s > 0 else 0.0
         traffic = measured_lf_traffic(n_local) if not use_sharded else None
+        patch_fraction = None
+        if hasattr(filt, "counter"):
+            planned, through = filt.counter("lf_patch_groups_planned"), filt.counter("lf_patch_groups_through")
+            patch_fraction = through / planned if planned else None
         out = {
             "metric": "MCL update cycles/sec (motion+sensor+resample), N particles x 1080 beams",
             # whole-job aggregate: one unit = one update cycle of 1M particles x 1080 beams (the configuration the metric is
@@ -390,11 +394,11 @@ def main():
                                "median": float(np.median(window_rates)) if window_rates else None},
             "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in stage_prof.items()},
             "roofline": {
-                "kernel": "k_reweight_lf_palette<fast> (likelihood-field reweight)",
+                "kernel": "k_reweight_lf_patch (likelihood-field reweight; look-ups through per-workgroup LDS patches)",
                 # The contract's roofline: algorithmic bytes (4 B per particle-beam look-up + the particle's state and
                 # weight + the scan) over the kernel's HIP-event time, against the HBM peak.  It is a figure of merit, not HBM
-                # utilisation: the table is L1 / LDS resident (see `traffic`, `hbm_utilisation`), the kernel is bound by the
-                # vector-memory address pipe (`limiter`).
+                # utilisation: the table is L2 / LDS resident (see `traffic`, `hbm_utilisation`); the kernel is bound by vector
+                # instruction issue (`limiter`).
                 "bound": "hbm",
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK / 1e9,
@@ -407,12 +411,15 @@ def main():
                 "avg_launch_ms": lf_avg_s * 1e3,
                 "launches": int(lf_count),
                 "launches_sampled_every": 4,
-                # What actually bounds it (profiles/r02_calib_gather_cost.txt): a 64-lane 2-byte gather with unrelated addresses
-                # costs the CU's texture-address pipe one cycle per quad of lanes (16 per instruction) even inside one cache line;
-                # the VALU side (4 v_fma_f64 + 3 v_add_f64 + 5 32-bit ops per particle-beam) needs 52 SIMD cycles = 13 per CU.
-                "limiter": "vector-memory address pipe (TA): >= 16 CU cycles per scattered 64-lane gather",
-                "ta_floor_ms": n_local * BEAMS / 64 * 16 / (256 * 2.4e9) * 1e3,
-                "valu_issue_floor_ms": n_local * BEAMS / 64 * (4 * 5.76 + 3 * 4.92 + 5 * 2.95) / (1024 * 2.4e9) * 1e3,
+                # What actually bounds it (profiles/r02_pmc_bench_1M.txt): 11 vector instructions per wave and beam - 4 v_fma_f64
+                # for the end-point, 1 for the exactness check, 2 for the LDS address, 2 to fetch and widen the palette address,
+                # 1 v_add_f64, the rest prologue - at 4 cycles each on 7 of the 8 waves of a workgroup (the eighth fetches the
+                # patches).  Groups of beams that do not fit a patch are gathered from global memory instead: those pay the
+                # texture-address pipe, 16 CU cycles per scattered 64-lane gather (profiles/r02_calib_gather_cost.txt).
+                "limiter": "vector instruction issue (VALU): ~11 instructions per wave-beam on 7/8 of the waves; gathered groups: texture-address pipe",
+                "groups_through_lds_patch": patch_fraction,
+                "valu_issue_floor_ms": n_local * BEAMS / 64 * 11 * 4 * (8 / 7) / (1024 * 2.4e9) * 1e3,
+                "ta_floor_ms_if_all_gathered": n_local * BEAMS / 64 * 16 / (256 * 2.4e9) * 1e3,
             },
         }
         if not args.no_other_configs and world == 1 and n_local == 1_000_000:
