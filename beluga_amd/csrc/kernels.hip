@@ -927,9 +927,9 @@ __global__ __launch_bounds__(kBlock) void k_lf_combine(double* __restrict__ w, u
 
 // -- spatial ordering of the particles --------------------------------------------------------------
 // A full least-significant-digit-first radix sort of (key, index) by the 20-bit ordering key, two passes of 10 bits:
-//   keys + block histograms of the low digit (inside k_propagate, or k_order_keys)  ->  digit totals  ->  row scan  ->
-//   scatter by the low digit (order inside a digit irrelevant)  ->  block histograms of the high digit  ->  digit totals
-//   ->  row scan  ->  STABLE scatter by the high digit  ->  perm.
+//   keys + block histograms of the low digit (inside k_propagate, or k_order_keys)  ->  row scan (+ digit totals)  ->
+//   scatter by the low digit (order inside a digit irrelevant; digit bases scanned per workgroup)  ->  block histograms of
+//   the high digit  ->  row scan  ->  STABLE scatter by the high digit  ->  perm.     5 launches behind the keys.
 // Global atomics are slow on this part (~6 per ns, device scope resolves at the memory side), so there are none: block
 // histograms in LDS, [digit][block] offset tables, LDS cursors.  Only 8 bytes per particle move; the kernels that
 // consume the order gather the pose records through perm.
@@ -1040,22 +1040,12 @@ __global__ __launch_bounds__(kWide) void k_order_keys(Particles p, uint64_t n, K
 }
 
 // totals[d] = sum of row d of the [digit][block] table; one wave per digit.
-__global__ __launch_bounds__(kBlock) void k_digit_totals(const uint32_t* __restrict__ table, uint32_t nblocks, uint32_t* __restrict__ totals) {
+// Row d of the table (block histograms of digit d) becomes its exclusive scan; totals[d] = the row's sum.  The scatter
+// kernels add the sum of all smaller digits themselves (digit_bases): one launch less per pass.
+__global__ __launch_bounds__(kBlock) void k_row_scan(uint32_t* __restrict__ table, uint32_t nblocks, uint32_t* __restrict__ totals) {
   const uint32_t d = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t* row = table + static_cast<size_t>(d) * nblocks;
-  uint32_t acc = 0;
-  for (uint32_t b = lane; b < nblocks; b += 64) acc += row[b];
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-  if (lane == 0) totals[d] = acc;
-}
-// Row d of the table becomes its exclusive scan plus the total of all smaller digits: the offsets of the scatter.
-__global__ __launch_bounds__(kBlock) void k_row_scan(uint32_t* __restrict__ table, uint32_t nblocks, const uint32_t* __restrict__ totals) {
-  const uint32_t d = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  uint32_t below = 0;
-  for (uint32_t q = lane; q < d; q += 64) below += totals[q];
-  for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
   uint32_t* row = table + static_cast<size_t>(d) * nblocks;
-  uint32_t carry = below;
+  uint32_t carry = 0;
   for (uint32_t start = 0; start < nblocks; start += 64) {
     const uint32_t b = start + lane;
     const uint32_t v = b < nblocks ? row[b] : 0u;
@@ -1068,15 +1058,45 @@ __global__ __launch_bounds__(kBlock) void k_row_scan(uint32_t* __restrict__ tabl
     if (b < nblocks) row[b] = carry + incl - v;
     carry += __shfl(incl, 63);
   }
+  if (lane == 0) totals[d] = carry;
+}
+// s_base[d] = sum of totals[q], q < d, for the kSortDigits digits; T threads, every one of them.
+template <int T>
+__device__ __forceinline__ void digit_bases(const uint32_t* __restrict__ totals, uint32_t* s_base, uint32_t* s_wave /* [T / 64] */) {
+  constexpr int kPer = kSortDigits / T;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t v[kPer], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    v[k] = totals[threadIdx.x * kPer + k];
+    sum += v[k];
+  }
+  uint32_t incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(incl, o);
+    if (lane >= static_cast<uint32_t>(o)) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t prefix = incl - sum;
+  for (uint32_t q = 0; q < wave; ++q) prefix += s_wave[q];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    s_base[threadIdx.x * kPer + k] = prefix;
+    prefix += v[k];
+  }
+  __syncthreads();
 }
 
 // First pass: by the low digit.  Elements of one digit may land in any order (LDS cursors); the second pass orders
 // them by the high digit anyway and two particles with the same 20-bit key are interchangeable for locality.
 __global__ __launch_bounds__(kWide) void k_sort_scatter_low(const uint32_t* __restrict__ keys, uint64_t n,
                                                              const uint32_t* __restrict__ table, uint32_t nblocks,
-                                                             unsigned long long* __restrict__ out) {
-  __shared__ uint32_t cursor[kSortDigits];
-  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) cursor[d] = table[static_cast<size_t>(d) * nblocks + blockIdx.x];
+                                                             const uint32_t* __restrict__ totals, unsigned long long* __restrict__ out) {
+  __shared__ uint32_t cursor[kSortDigits], base_of[kSortDigits], wave_sums[kWide / 64];
+  digit_bases<kWide>(totals, base_of, wave_sums);
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) cursor[d] = base_of[d] + table[static_cast<size_t>(d) * nblocks + blockIdx.x];
   __syncthreads();
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
 #pragma unroll
@@ -1110,11 +1130,13 @@ __global__ __launch_bounds__(kWide) void k_sort_hist_high(const unsigned long lo
 constexpr int kStable = 512;  // 8 waves x 256 elements: 48 KB of LDS counters per workgroup
 __global__ __launch_bounds__(kStable) void k_sort_scatter_high(const unsigned long long* __restrict__ in, uint64_t n,
                                                               const uint32_t* __restrict__ table, uint32_t nblocks,
-                                                              uint32_t* __restrict__ perm) {
+                                                              const uint32_t* __restrict__ totals, uint32_t* __restrict__ perm) {
   constexpr int kWaves = kStable / 64, kRounds = kChunk / kStable;
   __shared__ uint16_t wave_count[kWaves][kSortDigits];
   __shared__ uint32_t wave_base[kWaves][kSortDigits];
+  __shared__ uint32_t base_of[kSortDigits], wave_sums[kWaves];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  digit_bases<kStable>(totals, base_of, wave_sums);
   for (uint32_t d = threadIdx.x; d < kWaves * kSortDigits; d += kStable) (&wave_count[0][0])[d] = 0;
   __syncthreads();
   volatile uint16_t* mine = wave_count[wave];
@@ -1144,7 +1166,7 @@ __global__ __launch_bounds__(kStable) void k_sort_scatter_high(const unsigned lo
   }
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < kSortDigits; d += kStable) {
-    uint32_t run = table[static_cast<size_t>(d) * nblocks + blockIdx.x];
+    uint32_t run = base_of[d] + table[static_cast<size_t>(d) * nblocks + blockIdx.x];
 #pragma unroll
     for (int q = 0; q < kWaves; ++q) {
       wave_base[q][d] = run;
@@ -2852,13 +2874,12 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
                        sort->table, nblocks);
   }
   const dim3 rows(kSortDigits / (kBlock / 64));
-  hipLaunchKernelGGL(k_digit_totals, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
   hipLaunchKernelGGL(k_row_scan, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
-  hipLaunchKernelGGL(k_sort_scatter_low, dim3(nblocks), dim3(kWide), 0, st, sort->keys, n, sort->table, nblocks, sort->keyidx);
+  hipLaunchKernelGGL(k_sort_scatter_low, dim3(nblocks), dim3(kWide), 0, st, sort->keys, n, sort->table, nblocks, sort->totals, sort->keyidx);
   hipLaunchKernelGGL(k_sort_hist_high, dim3(nblocks), dim3(kWide), 0, st, sort->keyidx, n, sort->table, nblocks);
-  hipLaunchKernelGGL(k_digit_totals, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
   hipLaunchKernelGGL(k_row_scan, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
-  hipLaunchKernelGGL(k_sort_scatter_high, dim3(nblocks), dim3(kStable), 0, st, sort->keyidx, n, sort->table, nblocks, sort->perm);
+  hipLaunchKernelGGL(k_sort_scatter_high, dim3(nblocks), dim3(kStable), 0, st, sort->keyidx, n, sort->table, nblocks, sort->totals,
+                     sort->perm);
 }
 
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
