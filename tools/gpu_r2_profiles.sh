@@ -18,7 +18,8 @@ bash tools/gpu_pmc_traffic.sh > /dev/null 2>&1
 cp gpurun_out/lf_kernel_traffic.json gpurun_out/pmc_fetch.txt gpurun_out/pmc_write.txt $O/ 2>/dev/null
 cd /tmp
 i=0
-for pmc in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" "GRBM_GUI_ACTIVE"; do
+rm -f $O/pmc_bench_1M.txt
+for pmc in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" "SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_SCA" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout 200 rocprofv3 --kernel-trace --pmc $pmc -d $GRAFT_REPO_ROOT/gpurun_out/prof/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 5 --windows 0 --stage-steps 0 --no-cpu-baseline --no-other-configs > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/prof/p$i.err || echo "pass $i failed"
   python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $GRAFT_REPO_ROOT/gpurun_out/prof/p$i/pmc_results.db pmc 2>/dev/null | grep "^PMC" | grep -E "reweight_lf|resample_draw|propagate|sort_scatter" >> $O/pmc_bench_1M.txt

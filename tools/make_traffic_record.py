@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def counter(db_path, name):
     db = sqlite3.connect(db_path)
     rows = db.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? group by kernel_name", (name,)).fetchall()
-    rows = [r for r in rows if "k_reweight_lf_palette" in r[0]]
+    rows = [r for r in rows if "k_reweight_lf_patch" in r[0]] or [r for r in rows if "k_reweight_lf_palette" in r[0]]
     assert rows, f"no LF kernel in {db_path}"
     return rows[0][0], rows[0][1], rows[0][2]
 
@@ -17,7 +17,7 @@ kernel, fetch, n1 = counter(sys.argv[1], "FETCH_SIZE")
 _, write, n2 = counter(sys.argv[2], "WRITE_SIZE")
 with open(os.path.join(ROOT, "beluga_amd", "csrc", "kernels.hip"), "rb") as fh:
     sha = hashlib.sha256(fh.read()).hexdigest()
-rec = {"kernel": kernel.split("(")[0].replace("void mcl::(anonymous namespace)::", ""), "particles": int(sys.argv[4]) if len(sys.argv) > 4 else 1_000_000,
+rec = {"kernel": kernel.replace("void ", "").replace("mcl::(anonymous namespace)::", "").split("(")[0], "particles": int(sys.argv[4]) if len(sys.argv) > 4 else 1_000_000,
        "fetch_size_kb": fetch, "write_size_kb": write, "launches_averaged": [n1, n2], "kernels_hip_sha256": sha,
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py`; HBM bytes per launch = "
                "2 x FETCH_SIZE + WRITE_SIZE (gfx950 reports half of every read: profiles/r01_pmc_traffic_calibration.txt)"}
