@@ -269,6 +269,10 @@ struct mcl_ctx {
   uint64_t patch_seen_planned{0}, patch_seen_through{0};
   bool patch_useful{true};
   int patch_probe_in{0};
+  // What this cycle's LF launch uses, decided once per cycle (the ordering pass in front of it depends on it):
+  // patches = the LDS-patch kernel; beams = a dispersed set goes to k_reweight_lf_beams (wave per particle, no ordering).
+  struct LfMode { bool decided, patches, beams; } lf_mode{false, false, false};
+  uint64_t lf_beams_launches{0};   // launches of k_reweight_lf_beams (mcl_get_counter)
   // scratch of the spatial ordering
   DeviceBuffer<uint32_t> d_route_u32;           // scratch of mcl_route_targets
   DeviceBuffer<uint32_t> d_sort_u32;            // keys[cap] perm[cap] table[1024 * nblocks] totals[1024]
@@ -621,9 +625,31 @@ bool wants_patches(mcl_ctx* ctx) {
   return false;
 }
 
+// The LF launch of this cycle: the patch kernel, the gather kernel, or - for a set the patch kernel has reported as
+// dispersed (no probe due) - the wave-per-particle kernel, which needs no ordering pass.  Decided once per cycle, before the
+// propagation kernel (which emits the ordering keys); cleared by do_reweight.
+void decide_lf_mode(mcl_ctx* ctx) {
+  if (ctx->lf_mode.decided) return;
+  ctx->lf_mode.decided = true;
+  ctx->lf_mode.patches = false;
+  ctx->lf_mode.beams = false;
+  if (ctx->cfg.sensor_kind == MCL_SENSOR_BEAM) return;
+  const bool palette = ctx->pal_count != 0 && ctx->tuning.lf_table == 0;
+  if (ctx->tuning.lf_variant == kLfBeamLanes) {
+    ctx->lf_mode.beams = palette;
+    return;
+  }
+  if (ctx->tuning.lf_variant != kLfSortedLanes) return;
+  ctx->lf_mode.patches = wants_patches(ctx);
+  ctx->lf_mode.beams = !ctx->lf_mode.patches && ctx->tuning.lf_patch == 1 && ctx->tuning.lf_dispersed != 0 && !ctx->patch_useful && palette &&
+                       ctx->n >= static_cast<uint64_t>(ctx->tuning.sort_min_particles);
+}
+
 bool wants_ordering(const mcl_ctx* ctx) {
   if (ctx->n < static_cast<uint64_t>(ctx->tuning.sort_min_particles) || ctx->n >= (1ull << 32)) return false;
-  return ctx->cfg.sensor_kind == MCL_SENSOR_BEAM || ctx->tuning.lf_variant == kLfSortedLanes;
+  if (ctx->cfg.sensor_kind == MCL_SENSOR_BEAM) return true;
+  if (ctx->lf_mode.decided && ctx->lf_mode.beams) return false;
+  return ctx->tuning.lf_variant == kLfSortedLanes;
 }
 
 // fused (mcl_update): the scan staged by stage_points is pulled by the same kernel, and the ordering keys of the new poses
@@ -634,6 +660,7 @@ mcl_status do_propagate(mcl_ctx* ctx, const Pose2& pose, const Pose2& prev, uint
   const DiffDriveSampler sampler = make_sampler(pose, prev, ctx->cfg.motion, ctx->cfg.motion_kind, ctx->cfg.strafe_noise_from_translation);
   KeyFrame frame{};
   const SortScratch sort = ctx->sort_scratch();
+  if (keys_emitted) decide_lf_mode(ctx);  // the fused cycle: the reweight follows, and the keys depend on its kernel
   const bool keys = keys_emitted && wants_ordering(ctx) && predict_key_frame(ctx, &sampler, &frame);
   launch_propagate(ctx->stream, ctx->cur(), ctx->n, sampler, ctx->cfg.seed, step, ctx->cfg.shard_offset,
                    scan_points ? ctx->hd_points : nullptr, scan_points ? ctx->d_points.ptr : nullptr, static_cast<uint32_t>(2 * scan_points),
@@ -664,8 +691,11 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     }
   }
   stage_begin(ctx, MCL_STAGE_REWEIGHT);
+  decide_lf_mode(ctx);
+  const mcl_ctx::LfMode mode = ctx->lf_mode;
+  ctx->lf_mode.decided = false;  // the next cycle decides again
   const SortScratch sort = ctx->sort_scratch();
-  const bool ordered = wants_ordering(ctx);
+  const bool ordered = wants_ordering(ctx) && !mode.beams;
   if (ordered) {
     KeyFrame frame{};
     // The ordering also serves the beam model: both kernels gather the pose records through sort.perm.
@@ -674,10 +704,14 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
   }
   if (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM) {
     // Below a few thousand particles the ordering passes cost more than they save.
-    const int variant = (ctx->tuning.lf_variant == kLfSortedLanes && !ordered) ? kLfLanePerParticle : ctx->tuning.lf_variant;
+    const int variant = mode.beams ? kLfBeamLanes
+                                   : ((ctx->tuning.lf_variant == kLfSortedLanes || ctx->tuning.lf_variant == kLfBeamLanes) && !ordered)
+                                         ? kLfLanePerParticle
+                                         : ctx->tuning.lf_variant;
     const bool scan_is_short = ctx->scan_extent / ctx->resolution < 8192.0;
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
-    const bool use_patches = wants_patches(ctx);
+    const bool use_patches = mode.patches;
+    if (mode.beams) ctx->lf_beams_launches += 1;
     launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B), variant, &sort,
                        scan_is_short, ctx->tuning, use_patches,
                        PatchStats{reinterpret_cast<unsigned long long*>(ctx->d_scalars.ptr + 24),
@@ -1313,7 +1347,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     MCL_HIP(ctx, hipEventCreateWithFlags(&ctx->points_event, hipEventDisableTiming));
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
-    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "device_policy", "sort_min_particles", "field_build"}) {
+    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "device_policy", "sort_min_particles", "field_build"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -1495,6 +1529,9 @@ mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], con
     ctx->cloud_sigma[k] = std::sqrt(std::max(cov[4 * k], 0.0));
   }
   ctx->have_cloud_estimate = true;
+  // a new set: whatever earlier launches reported about the old one is history; the next LF launch finds out
+  patch_totals(ctx, &ctx->patch_seen_planned, &ctx->patch_seen_through);
+  ctx->patch_useful = true;
   return MCL_OK;
 }
 
@@ -1511,6 +1548,8 @@ mcl_status mcl_set_particles(mcl_ctx* ctx, const double* states, const double* w
   ctx->n = n;
   ctx->force_update = true;
   ctx->have_cloud_estimate = false;  // the ordering falls back to a bounding-box pass until the next estimate
+  patch_totals(ctx, &ctx->patch_seen_planned, &ctx->patch_seen_through);  // (as in mcl_initialize_normal)
+  ctx->patch_useful = true;
   return MCL_OK;
 }
 
@@ -2084,6 +2123,11 @@ mcl_status mcl_initialize_from_map(mcl_ctx* ctx) {
   ctx->cloud_sigma[0] = ctx->cloud_sigma[1] = reach / 4.0;  // the bins span +-4 sigma
   ctx->cloud_sigma[2] = kPi / 4.0;
   ctx->have_cloud_estimate = true;
+  // A set spread over the whole map is what the patch kernel would report as dispersed after its first launch: say so now
+  // (reports of earlier launches are history), so that the first cycle already takes the kernel for dispersed sets.
+  patch_totals(ctx, &ctx->patch_seen_planned, &ctx->patch_seen_through);
+  ctx->patch_useful = false;
+  ctx->patch_probe_in = 16;
   return MCL_OK;
 }
 
@@ -2139,7 +2183,8 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   if (!ctx || !name) return MCL_ERR_INVALID_ARGUMENT;
   const std::string key(name);
   Tuning& t = ctx->tuning;
-  if (key == "lf_variant") t.lf_variant = value == 0 ? kLfWavePerParticle : (value == 1 ? kLfLanePerParticle : kLfSortedLanes);
+  if (key == "lf_variant") t.lf_variant = value == 0 ? kLfWavePerParticle : (value == 1 ? kLfLanePerParticle : (value == 3 ? kLfBeamLanes : kLfSortedLanes));
+  else if (key == "lf_dispersed") t.lf_dispersed = value ? 1 : 0;
   else if (key == "lf_fast") t.lf_fast = value < 0 ? -1 : (value ? 1 : 0);
   else if (key == "lf_table") t.lf_table = value ? 1 : 0;
   else if (key == "lf_patch") t.lf_patch = value < 0 || value > 2 ? 1 : static_cast<int>(value);
@@ -2155,6 +2200,7 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
   const std::string key(name);
   if (key == "lf_fast_launches") *value = ctx->lf_fast_launches;
   else if (key == "lf_patch_launches") *value = ctx->lf_patch_launches;
+  else if (key == "lf_beams_launches") *value = ctx->lf_beams_launches;
   else if (key == "lf_patch_groups_planned" || key == "lf_patch_groups_through") {
     if (const mcl_status s = bind_device(ctx)) return s;
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));

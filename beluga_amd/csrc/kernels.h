@@ -100,7 +100,12 @@ struct ResampleArgs {
   uint64_t out_offset;      // where candidate `first_candidate` lands in the output set
 };
 
-enum LfVariant : int { kLfWavePerParticle = 0, kLfLanePerParticle = 1, kLfSortedLanes = 2 };
+enum LfVariant : int {
+  kLfWavePerParticle = 0,  // wave per particle over the f32 field (small sets)
+  kLfLanePerParticle = 1,
+  kLfSortedLanes = 2,      // default: lanes = spatial neighbours (ordering pass), palette table, LDS patches
+  kLfBeamLanes = 3         // wave per particle, lanes = beams, palette table: dispersed sets (chosen by the cycle, or forced)
+};
 
 // Per-context switches for A/B measurements and tests (mcl_set_option); no switch changes a result.
 struct Tuning {
@@ -109,6 +114,9 @@ struct Tuning {
   int lf_table = 0;                 // 0 = palette table when the field allows it, 1 = force the 8-byte cube table
   int lf_patch = 1;                 // index table through per-workgroup LDS patches: 1 = where the last launch found them useful,
                                     // 0 = never (per-lane gathers only), 2 = always
+  int lf_dispersed = 0;             // a set the patch kernel reports as dispersed (lf_patch = 1): 0 = the ordered-lanes gather kernel,
+                                    // 1 = wave per particle / lane per beam (k_reweight_lf_beams, no ordering pass; measured
+                                    // 20 % slower at 1M x 1080: profiles/r02_dispersed_study.txt)
   int device_policy = 1;            // recovery estimator on the device when the cycle has no host-side decision
   int sort_min_particles = 16384;   // below this the ordering passes cost more than they save
   int field_build = 0;              // mcl_set_map: 0 = host wavefront (bit-identical to the reference), 1 = exact EDT on the device

@@ -232,6 +232,14 @@ __device__ __forceinline__ void floor_rd_16(double (&v)[16]) {
                  "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
                : "s"(kFloorMagic));
 }
+__device__ __forceinline__ void floor_rd_8(double (&v)[8]) {
+  asm volatile(MCL_RD_BEGIN
+               "v_add_f64 %0, %0, %8\n\tv_add_f64 %1, %1, %8\n\tv_add_f64 %2, %2, %8\n\tv_add_f64 %3, %3, %8\n\t"
+               "v_add_f64 %4, %4, %8\n\tv_add_f64 %5, %5, %8\n\tv_add_f64 %6, %6, %8\n\tv_add_f64 %7, %7, %8\n\t"
+               MCL_RD_END
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+               : "s"(kFloorMagic));
+}
 __device__ __forceinline__ void floor_rd_2(double& a, double& b) {
   asm volatile(MCL_RD_BEGIN "v_add_f64 %0, %0, %2\n\tv_add_f64 %1, %1, %2\n\t" MCL_RD_END : "+v"(a), "+v"(b) : "s"(kFloorMagic));
 }
@@ -562,6 +570,75 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
   }
 }
 
+// Variant D — one wavefront per PARTICLE, one lane per BEAM, over the palette form of the table: an alternative for a
+// dispersed set (global localisation: initialize_from_map, a kidnapped robot), behind option lf_dispersed = 1 / lf_variant = 3.
+// The 64 lanes of a gather hold 64 consecutive beams of ONE pose: their end-points trace the walls the scan saw and
+// neighbouring beams share 8x8-cell tiles, whatever the cloud looks like.  Measured on 1M particles spread over the 4000^2 map
+// (profiles/r02_dispersed_study.txt): 23 lines per gather, 398 M L2 requests per launch - the same as the ordered-lanes gather
+// kernel gets out of that set (400 M) - but fewer of them hit in L2 (33 % vs 48 %), and the launch is bound by what the L2
+// misses pull in (33 GB per launch at 7.5 TB/s): 4.46 ms vs 3.72 ms.  Kept as a switch, not chosen by default.
+// A wave owns a tile of 64 particles (index order, no ordering pass): the 64 world->field transforms are computed
+// lane-parallel and broadcast one at a time through SGPRs.
+// End-points by the reference's separately rounded arithmetic; a lane adds its beams in scan order, the 64 lane sums are
+// added in a fixed tree (wave_sum_f64): the weight differs from the sequential sum of the other kernels in rounding only.
+// Workgroup memory as in k_reweight_lf_palette: [0, (H+2)*4) row offsets, [pal_base, ...) the palette; no other LDS.
+constexpr int kBeamsBlock = 256;
+__global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, uint64_t n, FieldView f, const double2* __restrict__ pts,
+                                                                   uint32_t B) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {
+    uint32_t* s_row = reinterpret_cast<uint32_t*>(smem);
+    for (uint32_t j = threadIdx.x; j < f.H + 2; j += kBeamsBlock) s_row[j] = palette_row_offset(static_cast<int32_t>(j) - 1, f.pal_pitch);
+    double* s_pal = reinterpret_cast<double*>(smem + f.pal_base);
+    for (uint32_t k = threadIdx.x; k < f.pal_count; k += kBeamsBlock) s_pal[k] = f.pal_val[k];
+  }
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t tile = static_cast<uint64_t>(blockIdx.x) * (kBeamsBlock / kWave) + (threadIdx.x >> 6);
+  const uint64_t base = tile * kWave;
+  if (base >= n) return;
+  const uint64_t i = base + lane;
+  Pose2 state = pose_identity();
+  if (i < n) state = load_pose(p, i);
+  const Pose2 T = pose_mul(f.world_to_field, state);  // likelihood_field_model.hpp:70
+  const uint32_t cnt = static_cast<uint32_t>(n - base < kWave ? n - base : kWave);
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(f.pal_idx), 0, static_cast<int>(f.pal_bytes), 0x00020000);
+  const uint32_t full = B & ~255u;  // beams taken four per lane at a time (their gathers in flight together)
+  double mine = 0.0;
+#pragma unroll 1
+  for (uint32_t q = 0; q < cnt; ++q) {
+    const double ct = readlane_f64(T.r.c, q), st = readlane_f64(T.r.s, q);
+    const double xt = readlane_f64(T.x, q), yt = readlane_f64(T.y, q);
+    double acc = 0.0;
+#pragma unroll 1
+    for (uint32_t b0 = 0; b0 < full; b0 += 256) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double2 pt = pts[b0 + 64 * k + lane];
+        v[2 * k] = (pt.x * ct - pt.y * st + xt) * f.inv_resolution;
+        v[2 * k + 1] = (pt.x * st + pt.y * ct + yt) * f.inv_resolution;
+      }
+      floor_rd_8(v);
+      uint32_t e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = lf_palette_fetch(rsrc, f, floor_rd_result(v[2 * k]), floor_rd_result(v[2 * k + 1]), 0u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc += lf_palette_value(e[k]);
+    }
+    for (uint32_t b = full + lane; b < B; b += kWave) {
+      const double2 pt = pts[b];
+      double vx = (pt.x * ct - pt.y * st + xt) * f.inv_resolution, vy = (pt.x * st + pt.y * ct + yt) * f.inv_resolution;
+      floor_rd_2(vx, vy);
+      acc += lf_palette_value(lf_palette_fetch(rsrc, f, floor_rd_result(vx), floor_rd_result(vy), 0u));
+    }
+    const double total = wave_sum_f64(acc);
+    if (lane == q) mine = total;
+  }
+  if (i < n) p.w[i] = p.w[i] * (f.prob ? exp(mine) : 1.0 + mine);
+}
+
 // The palette kernel with the index table read through LDS patches.
 // A scattered 64-lane 2-byte gather costs the CU's texture-address pipe one cycle per quad of lanes per line (16+ per
 // instruction, profiles/r02_calib_gather_cost.txt): the floor of k_reweight_lf_palette.  An LDS read of the same shape costs
@@ -778,12 +855,20 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     }
     const int y_last = static_cast<int>((f.H + 7u) & ~7u);  // first row of the bottom border tiles
     // The patch of group g, clamped into the bordered table (whatever lies outside the grid reads the unknown entry, like
-    // a clamped gather): this lane's column, tile row by tile row.  Fetched a step before it is stored: while the
-    // consumers work on group g the patch of g + 1 goes from registers to LDS and the one of g + 2 is on its way.
-    uint4 piece[kPatchH / 8];
-    auto fetch = [&](uint32_t g) {
+    // a clamped gather): this lane's column, tile row by tile row.  While the consumers work on group g the patch of g + 1
+    // goes from registers to LDS and the ones of g + 2 and g + 3 are on their way.
+    using Pieces = uint4[kPatchH / 8];
+    // Fetches and stores are unconditional (a group without a patch, or past the last one, moves a patch nobody reads):
+    // straight-line code lets the compiler count the loads in flight exactly, so that a store waits for ITS fetch only.
+    const uint32_t last_planned = (groups < kPatchPlanned ? groups : kPatchPlanned) - 1u;
+    auto origin_of = [&](uint32_t g, int& x0, int& y0) {
+      const int2 e = s_plan[g < last_planned ? g : last_planned];
+      x0 = __builtin_amdgcn_readfirstlane(e.x);
+      y0 = __builtin_amdgcn_readfirstlane(e.y) & ~7;
+    };
+    auto fetch = [&](uint32_t g, Pieces& piece) {
       int x0, y0;
-      if (g >= groups || !plan_of(g, x0, y0)) return;
+      origin_of(g, x0, y0);
       const int xu = x0 + static_cast<int>(lane) - static_cast<int>(kFastBias);
       // + 8: the border tile's share of palette_row_offset goes here, so that the vector offset - the one the buffer's
       // range check looks at - is never negative
@@ -795,21 +880,28 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, column, palette_row_offset(yc, f.pal_pitch) - 128u, 0));
       }
     };
-    auto store = [&](uint32_t g) {
-      int x0, y0;
-      if (g >= groups || !plan_of(g, x0, y0)) return;
+    auto store = [&](uint32_t g, const Pieces& piece) {
       unsigned char* dst = smem + patch_base + (g & 1) * kPatchBytes + lane * kPatchPitch;
 #pragma unroll
       for (int r = 0; r < kPatchH / 8; ++r) *reinterpret_cast<uint4*>(dst + r * 16) = piece[r];
     };
-    fetch(0);
-    store(0);
-    fetch(1);
-    for (uint32_t g = 0; g < groups; ++g) {
+    // Two register sets (even / odd groups): a patch is fetched two steps before it is stored (measured against one set and
+    // one step: 0.478 vs 0.485 ms on a fixed cloud, tools/exp_lf_fixed.py).
+    Pieces even, odd;
+    fetch(0, even);
+    store(0, even);
+    fetch(1, odd);
+    fetch(2, even);
+    uint32_t g = 0;
+    for (; g + 1 < groups; g += 2) {
       __syncthreads();  // the consumers are done with group g - 1: its buffer takes the patch of g + 1
-      store(g + 1);
-      fetch(g + 2);
+      store(g + 1, odd);
+      fetch(g + 3, odd);
+      __syncthreads();
+      store(g + 2, even);
+      fetch(g + 4, even);
     }
+    if (g < groups) __syncthreads();
     report();  // off the consumers' path: they are still at their last group
     return;
   }
@@ -818,8 +910,12 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   const bool fast = __builtin_amdgcn_ballot_w64(!lane_small) == 0;  // per wave: a far particle sends its wave through the exact code
   const int c_lo = static_cast<int>(kFastBias) - 1, x_hi = static_cast<int>(kFastBias + f.W), y_hi = static_cast<int>(kFastBias + f.H);
   const uint32_t row_bias = 4u - (kFastBias << 2);  // LDS byte address of the row entry = (biased y << 2) + row_bias
+  // Palette addresses are kept 32 bits wide from the load on: ds_read_u16 / buffer_load_ushort zero-extend for free.  The
+  // gathered look-ups are OR-ed with a zero the compiler cannot see through (pal_bytes < 2^31): without it the two sources
+  // are merged as 16-bit values and every look-up pays a v_and_b32 to widen it again (8 per group on the LDS path).
+  const uint32_t opaque_zero = f.pal_bytes >> 31;
   struct Lookups {
-    uint16_t e[8];  // palette addresses; widened where they are used, after the wait for them
+    uint32_t e[8];  // palette addresses (LDS byte addresses of the f64 terms)
     uint32_t redo;  // 1: the group is added by add_exact instead
   };
   // The separately rounded evaluation, beam by beam with plain gathers.
@@ -838,7 +934,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       return;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc += lf_palette_value(static_cast<uint32_t>(e.e[k]));
+    for (int k = 0; k < 8; ++k) acc += lf_palette_value(e.e[k]);
   };
   // One step: the end-points of group g, then the sum of the group before it (its gathers, if any, had the end-point
   // arithmetic to arrive), then the look-ups of group g.  `redo`: 1 if the group has to be added by add_exact instead.
@@ -872,14 +968,14 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     if (in_patch) {
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        now.e[k] = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(
-            static_cast<uintptr_t>(mad_u24(static_cast<uint32_t>(cx[k]), kPatchPitch, lshl_add_u32(static_cast<uint32_t>(cy[k]), 1, K))));
+        now.e[k] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(
+            static_cast<uintptr_t>(mad_u24(static_cast<uint32_t>(cx[k]), kPatchPitch, lshl_add_u32(static_cast<uint32_t>(cy[k]), 1, K)))));
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int xc = med3_i32(cx[k], c_lo, x_hi), yc = med3_i32(cy[k], c_lo, y_hi);
         const uint32_t row = *reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>((static_cast<uint32_t>(yc) << 2) + row_bias));
-        now.e[k] = static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, (static_cast<uint32_t>(xc) << 4) + row, 0, 0));
+        now.e[k] = static_cast<uint32_t>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, (static_cast<uint32_t>(xc) << 4) + row, 0, 0))) | opaque_zero;
       }
     }
     now.redo = __builtin_amdgcn_ballot_w64(lowest < 4u) != 0 ? 1u : 0u;
@@ -1412,6 +1508,9 @@ __device__ __forceinline__ void walk_seek(RayWalk& r, int k, int error) {
 // always share the line's octant), or kRuntimeStep to take them from the arguments.
 constexpr int kRuntimeStep = 0x7FFFFFFF;
 constexpr int kCoarse = kWin / 8, kCoarseWords = kCoarse / 32;  // 128 x 128 blocks, 4 words per row of blocks
+constexpr int kDistCap = 9;                                     // block distances 0 .. 9 (9 = nothing within 8 blocks)
+// LDS of the ordered beam kernel: the bit window, its two coarse bitmaps, the block distance map
+constexpr size_t kBeamLds = (static_cast<size_t>(kWin) * kWinStride + 2 * kCoarse * kCoarseWords) * sizeof(uint32_t) + kCoarse * kCoarse;
 
 // Cells u = 0 .. count-1 (count <= 8) from (lx, ly, error): their words are fetched together (where they lie does not depend
 // on what they hold) and examined in order.  Returns the index of the first non-free one or -1; `advance` also moves
@@ -1425,12 +1524,29 @@ struct BlockMaps {
   const uint32_t* rows;      // [ceil(height / 8)][row_words]
   const uint32_t* columns;   // [ceil(width / 8)][column_words]
   int row_words, column_words;
+  const uint8_t* dist;       // optional [block row][kCoarse]: Chebyshev distance, in blocks, to the nearest block with a non-free
+                             // cell (0 = this one), capped at kDistCap; nullptr: no such map (the whole-grid maps)
 };
 struct BitWindow {
   const uint32_t* lds;      // kWin rows x kWinStride words, then the two coarse bitmaps of the window
   int x0, y0;               // grid cell of window bit (0, 0); x0 is a multiple of 32, y0 of 8
   BlockMaps grid_maps;      // the whole grid (cells beyond the window)
 };
+// Measurement build (-DMCL_BEAM_STATS, tools/gpu_beam_stats.sh): how often a wave / a lane passes the stages of the walk.
+// g_beam_stats[2 i] counts waves, [2 i + 1] lanes.  Compiled out of the product.
+#ifdef MCL_BEAM_STATS
+__device__ unsigned long long g_beam_stats[32];
+__device__ __forceinline__ void beam_stat(int i) {
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+  if ((threadIdx.x & 63) == static_cast<unsigned>(__builtin_ctzll(m))) {
+    atomicAdd(&g_beam_stats[2 * i], 1ull);
+    atomicAdd(&g_beam_stats[2 * i + 1], static_cast<unsigned long long>(__builtin_popcountll(m)));
+  }
+}
+#define MCL_BEAM_STAT(i) beam_stat(i)
+#else
+#define MCL_BEAM_STAT(i)
+#endif
 template <bool kAdvance, bool kClamp = true>
 __device__ __forceinline__ int examine_cells(const BlockMaps& maps, int& lx, int& ly, int& error, int count, int dminor, int dmajor,
                                              bool steep, int major_step, int minor_step) {
@@ -1470,12 +1586,52 @@ __device__ __forceinline__ int examine_cells(const BlockMaps& maps, int& lx, int
   return first;
 }
 
+// The 8 cells of one whole block column of the line (all of them inside the map), major axis known at compile time: the
+// same cells in the same order as examine_cells, for about half the instructions.  Along x (kSteep == false) the cells share
+// one word column of the bit map and the row moves when the error term trips; along y every cell is a row further and the
+// bit moves on a trip.  v_bfe_u32 takes the bit position modulo 32 by itself.  Returns the first non-free cell or -1.
+template <bool kSteep>
+__device__ __forceinline__ int examine_column(const BlockMaps& maps, int major, int minor, int error, int dminor, int dmajor, int major_step,
+                                              int minor_step) {
+  uint32_t hits = 0;  // bit u: cell u is not free
+  int fe = error;
+  if (!kSteep) {
+    const uint32_t* p = maps.fine + minor * maps.fine_stride + (major >> 5);
+    const int row_step = minor_step * maps.fine_stride;
+    int x = major;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      hits |= __builtin_amdgcn_ubfe(*p, static_cast<uint32_t>(x), 1u) << u;
+      x += major_step;
+      fe += dminor;
+      const bool trip = fe > dmajor;
+      fe -= trip ? dmajor : 0;
+      p += trip ? row_step : 0;
+    }
+  } else {
+    const uint32_t* row = maps.fine + major * maps.fine_stride;
+    const int row_step = major_step * maps.fine_stride;
+    int x = minor;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      hits |= __builtin_amdgcn_ubfe(row[x >> 5], static_cast<uint32_t>(x), 1u) << u;
+      row += row_step;
+      fe += dminor;
+      const bool trip = fe > dmajor;
+      fe -= trip ? dmajor : 0;
+      x += trip ? minor_step : 0;
+    }
+  }
+  return hits ? __builtin_ctz(hits) : -1;
+}
+
 template <int STEEP, int MAJ, int MIN>
 __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int& ly, int& error, int& k, int& hit_k, int upto, int dminor,
                                             int dmajor, bool r_steep, int r_major_step, int r_minor_step) {
   const bool steep = STEEP == kRuntimeStep ? r_steep : (STEEP != 0);
   const int major_step = MAJ == kRuntimeStep ? r_major_step : MAJ, minor_step = MIN == kRuntimeStep ? r_minor_step : MIN;
   if (k > upto) return;
+  MCL_BEAM_STAT(STEEP == kRuntimeStep ? 2 : 1);  // a walk (1: major axis shared by the wave, 2: not)
   // 1. up to the end of the first block column, cell by cell
   {
     const int major = steep ? ly : lx;
@@ -1504,6 +1660,38 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   const int bitmap_words = steep ? maps.row_words : maps.column_words;
   int major = steep ? ly : lx, minor = steep ? lx : ly;
   while (k + 8 <= upto) {  // cells k .. k+7 and the cell behind them are inside
+    if (maps.dist) {
+      // Empty space in closed form: d = block distance from the block of cell k to the nearest block holding anything.  The next
+      // 8 s cells stay within s blocks of it along either axis (8 s - 1 steps along the major axis, at most as many along the
+      // minor one), so with d >= s + 1 they are all free: s = the largest power of two within d - 1 and within the cells left,
+      // and the state after 8 s steps by the same rule as for 8 (8 s dminor = t dmajor + r by doubling t8, r8; one more trip if
+      // error + r exceeds dmajor).  Same cells skipped as a cell-by-cell walk would have found free.
+      const uint32_t d = maps.dist[steep ? (major >> 3) * kCoarse + (minor >> 3) : (minor >> 3) * kCoarse + (major >> 3)];
+      if (d >= 2u) {
+        const uint32_t room = static_cast<uint32_t>(upto - k) >> 3;  // >= 1
+        const uint32_t most = min(d - 1u, room);
+        const int doublings = 31 - __builtin_clz(most);  // s = 2^doublings, 0 .. 3 (d <= kDistCap)
+        int t = trips8, r = rest8;
+#pragma unroll
+        for (int j = 1; j <= 3; ++j) {
+          const bool on = doublings >= j;
+          const int r2 = 2 * r;
+          const bool carry = r2 >= dmajor;
+          const int rn = r2 - (carry ? dmajor : 0), tn = 2 * t + (carry ? 1 : 0);
+          r = on ? rn : r;
+          t = on ? tn : t;
+        }
+        int raised = error + r;
+        const bool extra = raised > dmajor;
+        raised -= extra ? dmajor : 0;
+        const int cells = 8 << doublings;
+        k += cells;
+        major += cells * major_step;
+        minor += (t + (extra ? 1 : 0)) * minor_step;
+        error = raised;
+        continue;
+      }
+    }
     int raised = error + rest8;
     const bool extra = raised > dmajor;
     raised -= extra ? dmajor : 0;
@@ -1511,10 +1699,18 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
     const uint32_t* row = bitmap + (major >> 3) * bitmap_words;
     const int b0 = minor >> 3, b1 = minor_next >> 3;
     const uint32_t occupied = ((row[b0 >> 5] >> (b0 & 31)) | (row[b1 >> 5] >> (b1 & 31))) & 1u;
+    MCL_BEAM_STAT(3);  // a whole block column
     if (occupied) {
-      int fx = steep ? minor : major, fy = steep ? major : minor, fe = error;
-      const int first = examine_cells<false, false>(maps, fx, fy, fe, 8, dminor, dmajor, steep, major_step, minor_step);
+      MCL_BEAM_STAT(4);  // ... examined cell by cell
+      int first;
+      if (STEEP == kRuntimeStep) {
+        int fx = steep ? minor : major, fy = steep ? major : minor, fe = error;
+        first = examine_cells<false, false>(maps, fx, fy, fe, 8, dminor, dmajor, steep, major_step, minor_step);
+      } else {
+        first = examine_column<(STEEP != 0 && STEEP != kRuntimeStep)>(maps, major, minor, error, dminor, dmajor, major_step, minor_step);
+      }
       if (first >= 0) {
+        MCL_BEAM_STAT(5);  // ... with a hit
         hit_k = k + first;
         return;
       }
@@ -1528,6 +1724,7 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   ly = steep ? major : minor;
   // 3. the last cells
   while (k <= upto) {
+    MCL_BEAM_STAT(6);  // tail cells
     const int j = min(8, upto - k + 1);
     const int first = examine_cells<true>(maps, lx, ly, error, j, dminor, dmajor, steep, major_step, minor_step);
     if (first >= 0) {
@@ -1566,7 +1763,9 @@ __device__ __forceinline__ double cast_ray_window(const GridView& g, const BitWi
     // Cells 0 .. upto are inside the grid and the window: walked in LDS, block column by block column.
     int lx = sx - w.x0, ly = sy - w.y0;
     const uint32_t* rows = w.lds + kWin * kWinStride;
-    const BlockMaps lds_maps{w.lds, kWinStride, kWin - 1, kWin - 1, rows, rows + kCoarse * kCoarseWords, kCoarseWords, kCoarseWords};
+    const BlockMaps lds_maps{w.lds, kWinStride, kWin - 1, kWin - 1, rows, rows + kCoarse * kCoarseWords, kCoarseWords, kCoarseWords,
+                             reinterpret_cast<const uint8_t*>(rows + 2 * kCoarse * kCoarseWords)};
+    MCL_BEAM_STAT(7);  // a walk inside the LDS window
     walk_blocks_any(lds_maps, r, lx, ly, error, k, hit_k, upto);
     if (hit_k >= 0) {
       walk_seek(r, hit_k, 0);
@@ -1576,6 +1775,7 @@ __device__ __forceinline__ double cast_ray_window(const GridView& g, const BitWi
   // Cells beyond the window (long rays near its edge): the same walk over the whole-grid maps in global memory.
   r.last = walk_room_in_grid(g, r);
   if (k <= r.last) {
+    MCL_BEAM_STAT(8);  // a walk over the whole-grid maps (the ray left the window)
     walk_seek(r, k, error);
     int gx = r.x, gy = r.y;
     walk_blocks_any(w.grid_maps, r, gx, gy, error, k, hit_k, r.last);
@@ -1695,7 +1895,7 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
   bw.y0 = ((cy - kWin / 2) >> 3) << 3;  // block rows of the coarse bitmap start on multiples of 8 cells
   bw.lds = win;
   bw.grid_maps = BlockMaps{bits.fine, static_cast<int>(bits.words_per_row), static_cast<int>(g.W) - 1, static_cast<int>(g.H) - 1, bits.rows,
-                           bits.columns, static_cast<int>(bits.row_words), static_cast<int>(bits.column_words)};
+                           bits.columns, static_cast<int>(bits.row_words), static_cast<int>(bits.column_words), nullptr};
   const uint32_t* nonfree_bits = bits.fine;
   const uint32_t words_per_row = bits.words_per_row;
   for (int i = threadIdx.x; i < kWin * kWinWords; i += kBeamBlock) {
@@ -1732,6 +1932,36 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
       for (int q = 0; q < 32; ++q) bits |= ((coarse[(quarter * 32 + q) * kCoarseWords + (bx >> 5)] >> (bx & 31)) & 1u) << q;
       columns[cw] = bits;
     }
+    // block distance map: for every block the Chebyshev distance to the nearest block with a bit in the coarse bitmap
+    // (rows of 17 bits around the block's column, 8 rows up and down; blocks beyond the window count as empty: the walk
+    // never enters them)
+    uint8_t* dist = reinterpret_cast<uint8_t*>(columns + kCoarse * kCoarseWords);
+    for (int blk = threadIdx.x; blk < kCoarse * kCoarse; blk += kBeamBlock) {
+      const int by = blk / kCoarse, bx = blk % kCoarse;
+      int best = kDistCap;
+#pragma unroll 1
+      for (int dy = -(kDistCap - 1); dy <= kDistCap - 1; ++dy) {
+        const int row = by + dy;
+        if (row < 0 || row >= kCoarse) continue;
+        const int ady = dy < 0 ? -dy : dy;
+        if (ady >= best) continue;
+        // bits bx - 8 .. bx + 8 of the 128-bit row, bit 8 = this column
+        const uint32_t* rw = coarse + row * kCoarseWords;
+        const int first = bx - (kDistCap - 1);  // may be negative
+        const int word = first >> 5;            // floor
+        const uint64_t lo = (word >= 0 && word < kCoarseWords) ? rw[word] : 0u;
+        const uint64_t hi = (word + 1 >= 0 && word + 1 < kCoarseWords) ? rw[word + 1] : 0u;
+        const uint32_t around = static_cast<uint32_t>(((hi << 32) | lo) >> (first & 31)) & 0x1FFFFu;
+        if (around == 0u) continue;
+        const uint32_t right = around >> (kDistCap - 1);              // bit 0 = this column, bit j = j columns to the right
+        const uint32_t left = around & ((1u << (kDistCap - 1)) - 1);  // bit 7 = one column to the left, bit 0 = eight
+        int across = kDistCap;
+        if (right) across = __builtin_ctz(right);
+        if (left) across = min(across, (kDistCap - 1) - (31 - __builtin_clz(left)));
+        best = min(best, max(ady, across));
+      }
+      dist[blk] = static_cast<uint8_t>(best);
+    }
   }
   __syncthreads();
 
@@ -1743,6 +1973,7 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
   double acc = 0.0;
   unsigned long long steps = 0;
   for (uint32_t b = 0; b < B; ++b) {
+    MCL_BEAM_STAT(0);  // a beam
     acc += beam_term(g, m, norm_hit, src, pts[b],
                      [&](int fx, int fy) { return cast_ray_window(g, bw, sx, sy, fx, fy, m.beam_max_range, steps); });
   }
@@ -2928,7 +3159,13 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
     }
     if (segments > 1)
       hipLaunchKernelGGL(k_lf_combine, dim3(blocks_for(n)), dim3(kBlock), 0, st, p.w, n, sort->perm, partial, segments, f.prob);
-  } else if (variant == kLfLanePerParticle || variant == kLfSortedLanes) {
+  } else if (variant == kLfBeamLanes && tuning.lf_table == 0 && f.pal_idx != nullptr && f.pal_count > 0 &&
+             static_cast<size_t>(f.pal_base) + static_cast<size_t>(f.pal_count) * sizeof(double) <= 65536) {
+    const uint64_t tiles = (n + kWave - 1) / kWave;
+    const dim3 grid(static_cast<unsigned>((tiles + (kBeamsBlock / kWave) - 1) / (kBeamsBlock / kWave)));
+    const size_t pal_lds = static_cast<size_t>(f.pal_base) + static_cast<size_t>(f.pal_count) * sizeof(double);
+    hipLaunchKernelGGL(k_reweight_lf_beams, grid, dim3(kBeamsBlock), pal_lds, st, p, n, f, reinterpret_cast<const double2*>(d_points), B);
+  } else if (variant == kLfLanePerParticle || variant == kLfSortedLanes || variant == kLfBeamLanes) {  // (kLfBeamLanes without a palette)
     const dim3 grid(blocks_for(n));
     if (idx32) hipLaunchKernelGGL(k_reweight_lf_lane<true>, grid, dim3(kBlock), 0, st, p, n, f, d_points, B);
     else hipLaunchKernelGGL(k_reweight_lf_lane<false>, grid, dim3(kBlock), 0, st, p, n, f, d_points, B);
@@ -2968,9 +3205,21 @@ void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32
                      b.rows, block_rows, b.row_words, block_columns, b.column_words, const_cast<uint32_t*>(b.columns));
 }
 
+#ifdef MCL_BEAM_STATS
+}  // namespace mcl
+extern "C" int mcl_debug_beam_stats(unsigned long long* out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(mcl::g_beam_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    static const unsigned long long zeros[32] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mcl::g_beam_stats), zeros, sizeof(zeros)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+namespace mcl {
+#endif
 // hipFuncSetAttribute is per device: contexts on several GPUs of one process each opt in (mcl_create calls this).
 void configure_device_kernels() {
-  const size_t lds = (static_cast<size_t>(kWin) * kWinStride + 2 * kCoarse * kCoarseWords) * sizeof(uint32_t);
+  const size_t lds = kBeamLds;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_beam_sorted), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(lds));
 }
@@ -2979,7 +3228,7 @@ void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, B
                           unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points) {
   if (n == 0 || B == 0) return;
   if (sorted && nonfree_bits) {
-    const size_t lds = (static_cast<size_t>(kWin) * kWinStride + 2 * kCoarse * kCoarseWords) * sizeof(uint32_t);
+    const size_t lds = kBeamLds;
     const dim3 grid(static_cast<unsigned>((n + kBeamBlock - 1) / kBeamBlock));
     BeamPoint* table = reinterpret_cast<BeamPoint*>(d_beam_points);
     hipLaunchKernelGGL(k_beam_points, dim3(blocks_for(B)), dim3(kBlock), 0, st, d_points, B, m, table);

@@ -106,10 +106,11 @@ def test_reference_golden_weights_through_the_c_abi():
     assert beam_w([(60.0, 60.0)]) == pytest.approx(0.00012500000000000003, abs=1e-6)
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
 @pytest.mark.parametrize("beams", [1, 63, 64, 65, 180, 1080])
 def test_reweight_lf_matches_oracle(variant, beams):
-    """All three kernel variants (wave per particle / lane per particle / spatially ordered lanes = the default)."""
+    """All kernel variants (wave per particle / lane per particle / spatially ordered lanes = the default / wave per particle
+    with a lane per beam over the palette table = the one for dispersed sets)."""
     grid = rooms_grid()
     truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=2, clearance_cells=6)
     pts = make_scan(grid, truth, beams, max_range=12.0)
@@ -988,8 +989,12 @@ def test_ten_million_particles_sampled_against_oracle():
 
 def test_dispersed_cloud_1m_sampled_against_oracle():
     """The worst case for the spatially ordered lanes: 1M particles from initialize_from_map on the 4000^2 map (global
-    localisation; neighbours in the order are metres and radians apart).  Same kernel, same results: a 1024-particle sample
-    against the oracle."""
+    localisation; neighbours in any order are metres and radians apart).  initialize_from_map says so, and the reweight goes
+    straight to the ordered-lanes gather kernel; the LDS-patch kernel, tried on the same set, finds next to no group of beams
+    that fits a patch and reports it, which sends the launches after it to the gather kernel as well (option lf_patch = 1).
+    Same weights bit for bit; a 1024-particle sample against the oracle.  Option lf_dispersed = 1 sends such sets to
+    k_reweight_lf_beams instead (wave per particle, lane per beam, no ordering pass: measured slower, kept as a switch); its
+    lane sums are added in a tree: same weights up to rounding."""
     size = 4000
     cells = synth.make_rooms_map(size, size, seed=42)
     grid = OccupancyGrid(cells, 0.05, origin=se2_from_xytheta(-100.0, -100.0, 0.0))
@@ -1001,15 +1006,25 @@ def test_dispersed_cloud_1m_sampled_against_oracle():
     states, w0 = f.particles()
     assert np.all(w0 == 1.0)
     f.reweight(pts)
+    assert f.counter("lf_beams_launches") == 0 and f.counter("lf_patch_launches") == 0 and f.counter("lf_fast_launches") == 1
     w = f.particles()[1]
     sample = np.random.Generator(np.random.MT19937(1)).choice(n, 1024, replace=False)
     want = orc.lf_weights(f.likelihood_field(), 0.05, grid.origin, 100.0, states[sample], pts, threads=orc.max_threads())
     np.testing.assert_allclose(w[sample], want, rtol=RTOL)
-    # The first launch went to the LDS-patch kernel, which found (next to) no group of beams that fits a patch and said so:
-    # the next launches gather (option lf_patch = 1), same weights.
-    planned, through = f.counter("lf_patch_groups_planned"), f.counter("lf_patch_groups_through")
-    assert f.counter("lf_patch_launches") == 1 and planned >= (n // 448 // 16) * 135 and through * 4 < planned
+    # a set the library knows nothing about goes to the LDS-patch kernel first, which reports what it found
     f.set_particles(states, w0)
     f.reweight(pts)
-    assert f.counter("lf_patch_launches") == 1 and np.array_equal(f.particles()[1], w)
+    planned, through = f.counter("lf_patch_groups_planned"), f.counter("lf_patch_groups_through")
+    assert f.counter("lf_patch_launches") == 1 and planned >= (n // 448 // 16) * 135 and through * 4 < planned
+    assert np.array_equal(f.particles()[1], w)
+    # ... and the launch after that report gathers again (the weights multiply)
+    f.reweight(pts)
+    assert f.counter("lf_patch_launches") == 1 and f.counter("lf_beams_launches") == 0
+    assert np.array_equal(f.particles()[1], w * w)
+    # option lf_dispersed = 1: the wave-per-particle kernel for sets reported as dispersed
+    f.set_option("lf_dispersed", 1)
+    f.initialize_from_map()
+    f.reweight(pts)
+    assert f.counter("lf_patch_launches") == 1 and f.counter("lf_beams_launches") == 1
+    np.testing.assert_allclose(f.particles()[1], w, rtol=1e-13)
     f.close()
