@@ -174,12 +174,15 @@ constexpr uint32_t kBeamPointDoubles = 5;
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
                           unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points);
 // The occupancy the ray walks read, in one buffer of nonfree_words(W, H) words: one bit per cell (1 = not free), ceil(W/32)
-// words per row, followed by two coarse bitmaps — one bit per 8 x 8-cell block, "any cell not free" — row-major and column-major.
+// words per row, followed by two coarse bitmaps — one bit per 8 x 8-cell block, "any cell not free" — row-major and column-major —
+// and the block distance map (one byte per block).
 struct NonFreeBits {
   const uint32_t* fine;
   const uint32_t* rows;     // [ceil(H/8)][row_words]
   const uint32_t* columns;  // [ceil(W/8)][column_words]
-  uint32_t words_per_row, row_words, column_words;
+  const uint8_t* dist;      // [ceil(H/8)][dist_stride]: Chebyshev distance, in blocks, to the nearest block with a bit in `rows`
+                            // (0 = the block itself), capped at 9
+  uint32_t words_per_row, row_words, column_words, dist_stride;
 };
 NonFreeBits nonfree_layout(uint32_t W, uint32_t H, uint32_t* base);
 size_t nonfree_words(uint32_t W, uint32_t H);

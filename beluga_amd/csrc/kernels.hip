@@ -1508,7 +1508,6 @@ __device__ __forceinline__ void walk_seek(RayWalk& r, int k, int error) {
 // always share the line's octant), or kRuntimeStep to take them from the arguments.
 constexpr int kRuntimeStep = 0x7FFFFFFF;
 constexpr int kCoarse = kWin / 8, kCoarseWords = kCoarse / 32;  // 128 x 128 blocks, 4 words per row of blocks
-constexpr int kDistCap = 9;                                     // block distances 0 .. 9 (9 = nothing within 8 blocks)
 // LDS of the ordered beam kernel: the bit window, its two coarse bitmaps, the block distance map
 constexpr size_t kBeamLds = (static_cast<size_t>(kWin) * kWinStride + 2 * kCoarse * kCoarseWords) * sizeof(uint32_t) + kCoarse * kCoarse;
 
@@ -1524,14 +1523,43 @@ struct BlockMaps {
   const uint32_t* rows;      // [ceil(height / 8)][row_words]
   const uint32_t* columns;   // [ceil(width / 8)][column_words]
   int row_words, column_words;
-  const uint8_t* dist;       // optional [block row][kCoarse]: Chebyshev distance, in blocks, to the nearest block with a non-free
-                             // cell (0 = this one), capped at kDistCap; nullptr: no such map (the whole-grid maps)
+  const uint8_t* dist;       // [block row][dist_stride]: Chebyshev distance, in blocks, to the nearest block with a non-free cell
+  int dist_stride;           // (0 = this one), capped at kDistCap
 };
 struct BitWindow {
   const uint32_t* lds;      // kWin rows x kWinStride words, then the two coarse bitmaps of the window
   int x0, y0;               // grid cell of window bit (0, 0); x0 is a multiple of 32, y0 of 8
   BlockMaps grid_maps;      // the whole grid (cells beyond the window)
 };
+// Chebyshev distance, in blocks, from block (bx, by) to the nearest block with a bit in the row-major coarse bitmap (rows of
+// row_words words, block_rows of them; blocks beyond the bitmap count as empty), capped at kDistCap: per row within reach, the
+// 17 bits around the block's column.
+constexpr int kDistCap = 9;  // block distances 0 .. 9 (9 = nothing within 8 blocks)
+__device__ __forceinline__ int block_distance(const uint32_t* coarse_rows, int row_words, int block_rows, int bx, int by) {
+  int best = kDistCap;
+#pragma unroll 1
+  for (int dy = -(kDistCap - 1); dy <= kDistCap - 1; ++dy) {
+    const int row = by + dy;
+    if (row < 0 || row >= block_rows) continue;
+    const int ady = dy < 0 ? -dy : dy;
+    if (ady >= best) continue;
+    const uint32_t* rw = coarse_rows + static_cast<size_t>(row) * row_words;
+    const int first = bx - (kDistCap - 1);  // may be negative
+    const int word = first >> 5;            // floor
+    const uint64_t lo = (word >= 0 && word < row_words) ? rw[word] : 0u;
+    const uint64_t hi = (word + 1 >= 0 && word + 1 < row_words) ? rw[word + 1] : 0u;
+    const uint32_t around = static_cast<uint32_t>(((hi << 32) | lo) >> (first & 31)) & 0x1FFFFu;  // bit 8 = this column
+    if (around == 0u) continue;
+    const uint32_t right = around >> (kDistCap - 1);              // bit j = j columns to the right (0 = this one)
+    const uint32_t left = around & ((1u << (kDistCap - 1)) - 1);  // bit 7 = one column to the left, bit 0 = eight
+    int across = kDistCap;
+    if (right) across = __builtin_ctz(right);
+    if (left) across = min(across, (kDistCap - 1) - (31 - __builtin_clz(left)));
+    best = min(best, max(ady, across));
+  }
+  return best;
+}
+
 // Measurement build (-DMCL_BEAM_STATS, tools/gpu_beam_stats.sh): how often a wave / a lane passes the stages of the walk.
 // g_beam_stats[2 i] counts waves, [2 i + 1] lanes.  Compiled out of the product.
 #ifdef MCL_BEAM_STATS
@@ -1632,15 +1660,40 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   const int major_step = MAJ == kRuntimeStep ? r_major_step : MAJ, minor_step = MIN == kRuntimeStep ? r_minor_step : MIN;
   if (k > upto) return;
   MCL_BEAM_STAT(STEEP == kRuntimeStep ? 2 : 1);  // a walk (1: major axis shared by the wave, 2: not)
-  // 1. up to the end of the first block column, cell by cell
+  // Up to 8 cells that stay inside one block column: with nothing in that block or around it (block distance >= 2) they are
+  // free, and the state behind them has a closed form - error + j dminor brought back into (0, dmajor], one trip per dmajor
+  // taken off (a float quotient and a +-1 correction: the operands are far below 2^24).
+  const float inv_dmajor = dmajor > 0 ? 1.0f / static_cast<float>(dmajor) : 0.f;
+  auto clear_ahead = [&](int cx, int cy) { return maps.dist[(cy >> 3) * maps.dist_stride + (cx >> 3)] >= 2; };
+  auto advance_free = [&](int j) {
+    if (dmajor > 0) {
+      const int total = error + j * dminor;
+      int trips = static_cast<int>(static_cast<float>(total - 1) * inv_dmajor);
+      int rem = total - trips * dmajor;
+      const int up = rem > dmajor ? 1 : 0, down = rem <= 0 ? 1 : 0;
+      trips += up - down;
+      rem -= (up - down) * dmajor;
+      error = rem;
+      if (steep) lx += trips * minor_step;
+      else ly += trips * minor_step;
+    }
+    if (steep) ly += j * major_step;
+    else lx += j * major_step;
+  };
+  // 1. up to the end of the first block column
   {
     const int major = steep ? ly : lx;
     int j = major_step > 0 ? 8 - (major & 7) : (major & 7) + 1;
     j = min(j, upto - k + 1);
-    const int first = examine_cells<true>(maps, lx, ly, error, j, dminor, dmajor, steep, major_step, minor_step);
-    if (first >= 0) {
-      hit_k = k + first;
-      return;
+    if (clear_ahead(lx, ly)) {
+      advance_free(j);
+    } else {
+      MCL_BEAM_STAT(14);  // head cells examined
+      const int first = examine_cells<true>(maps, lx, ly, error, j, dminor, dmajor, steep, major_step, minor_step);
+      if (first >= 0) {
+        hit_k = k + first;
+        return;
+      }
     }
     k += j;
   }
@@ -1648,7 +1701,7 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   int trips8 = 0;
   if (dmajor > 0) {
     const int x = 8 * dminor;  // < 2^24: one float multiply and a +-1 correction
-    int q = static_cast<int>(static_cast<float>(x) * (1.0f / static_cast<float>(dmajor)));
+    int q = static_cast<int>(static_cast<float>(x) * inv_dmajor);
     const int rem = x - q * dmajor;
     q += (rem >= dmajor ? 1 : 0) - (rem < 0 ? 1 : 0);
     trips8 = q;
@@ -1660,17 +1713,24 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   const int bitmap_words = steep ? maps.row_words : maps.column_words;
   int major = steep ? ly : lx, minor = steep ? lx : ly;
   while (k + 8 <= upto) {  // cells k .. k+7 and the cell behind them are inside
-    if (maps.dist) {
+    {
       // Empty space in closed form: d = block distance from the block of cell k to the nearest block holding anything.  The next
       // 8 s cells stay within s blocks of it along either axis (8 s - 1 steps along the major axis, at most as many along the
       // minor one), so with d >= s + 1 they are all free: s = the largest power of two within d - 1 and within the cells left,
       // and the state after 8 s steps by the same rule as for 8 (8 s dminor = t dmajor + r by doubling t8, r8; one more trip if
       // error + r exceeds dmajor).  Same cells skipped as a cell-by-cell walk would have found free.
-      const uint32_t d = maps.dist[steep ? (major >> 3) * kCoarse + (minor >> 3) : (minor >> 3) * kCoarse + (major >> 3)];
+      const uint32_t d = maps.dist[steep ? (major >> 3) * maps.dist_stride + (minor >> 3) : (minor >> 3) * maps.dist_stride + (major >> 3)];
       if (d >= 2u) {
         const uint32_t room = static_cast<uint32_t>(upto - k) >> 3;  // >= 1
         const uint32_t most = min(d - 1u, room);
         const int doublings = 31 - __builtin_clz(most);  // s = 2^doublings, 0 .. 3 (d <= kDistCap)
+        MCL_BEAM_STAT(9);  // a skip (10..13: of 1, 2, 4, 8 block columns)
+#ifdef MCL_BEAM_STATS
+        if (doublings == 0) beam_stat(10);
+        if (doublings == 1) beam_stat(11);
+        if (doublings == 2) beam_stat(12);
+        if (doublings == 3) beam_stat(13);
+#endif
         int t = trips8, r = rest8;
 #pragma unroll
         for (int j = 1; j <= 3; ++j) {
@@ -1722,14 +1782,19 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   }
   lx = steep ? minor : major;
   ly = steep ? major : minor;
-  // 3. the last cells
+  // 3. the last cells (fewer than a block column)
   while (k <= upto) {
     MCL_BEAM_STAT(6);  // tail cells
     const int j = min(8, upto - k + 1);
-    const int first = examine_cells<true>(maps, lx, ly, error, j, dminor, dmajor, steep, major_step, minor_step);
-    if (first >= 0) {
-      hit_k = k + first;
-      return;
+    if (clear_ahead(lx, ly)) {
+      advance_free(j);
+    } else {
+      MCL_BEAM_STAT(15);  // ... examined
+      const int first = examine_cells<true>(maps, lx, ly, error, j, dminor, dmajor, steep, major_step, minor_step);
+      if (first >= 0) {
+        hit_k = k + first;
+        return;
+      }
     }
     k += j;
   }
@@ -1764,7 +1829,7 @@ __device__ __forceinline__ double cast_ray_window(const GridView& g, const BitWi
     int lx = sx - w.x0, ly = sy - w.y0;
     const uint32_t* rows = w.lds + kWin * kWinStride;
     const BlockMaps lds_maps{w.lds, kWinStride, kWin - 1, kWin - 1, rows, rows + kCoarse * kCoarseWords, kCoarseWords, kCoarseWords,
-                             reinterpret_cast<const uint8_t*>(rows + 2 * kCoarse * kCoarseWords)};
+                             reinterpret_cast<const uint8_t*>(rows + 2 * kCoarse * kCoarseWords), kCoarse};
     MCL_BEAM_STAT(7);  // a walk inside the LDS window
     walk_blocks_any(lds_maps, r, lx, ly, error, k, hit_k, upto);
     if (hit_k >= 0) {
@@ -1826,9 +1891,13 @@ __device__ __forceinline__ double beam_term(const GridView& g, const BeamModel& 
   cell_near(g, ex, ey, fx, fy);
   const double z_mean = cast(fx, fy);
   const double scale = sqrt(2.) * m.sigma_hit;
-  const double hi = (m.beam_max_range - z_mean) / scale, lo = -z_mean / scale;
   double eta_hit = 1.0;
-  if (__builtin_amdgcn_ballot_w64(!(hi >= 6.5 && lo <= -6.5)) != 0) eta_hit = 2. / (erf(hi) - erf(lo));
+  // (a margin of 6.6 scales, compared without the divisions, implies both arguments beyond 6.5)
+  const bool saturated = m.beam_max_range - z_mean >= 6.6 * scale && z_mean >= 6.6 * scale;
+  if (__builtin_amdgcn_ballot_w64(!saturated) != 0) {
+    const double hi = (m.beam_max_range - z_mean) / scale, lo = -z_mean / scale;
+    eta_hit = 2. / (erf(hi) - erf(lo));
+  }
   const double d = (q.z - z_mean) / m.sigma_hit;
   double pz = m.z_hit * eta_hit * norm_hit * exp(-(d * d) / 2.);
   if (q.z < z_mean) {
@@ -1895,7 +1964,8 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
   bw.y0 = ((cy - kWin / 2) >> 3) << 3;  // block rows of the coarse bitmap start on multiples of 8 cells
   bw.lds = win;
   bw.grid_maps = BlockMaps{bits.fine, static_cast<int>(bits.words_per_row), static_cast<int>(g.W) - 1, static_cast<int>(g.H) - 1, bits.rows,
-                           bits.columns, static_cast<int>(bits.row_words), static_cast<int>(bits.column_words), nullptr};
+                           bits.columns, static_cast<int>(bits.row_words), static_cast<int>(bits.column_words), bits.dist,
+                           static_cast<int>(bits.dist_stride)};
   const uint32_t* nonfree_bits = bits.fine;
   const uint32_t words_per_row = bits.words_per_row;
   for (int i = threadIdx.x; i < kWin * kWinWords; i += kBeamBlock) {
@@ -1932,36 +2002,10 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
       for (int q = 0; q < 32; ++q) bits |= ((coarse[(quarter * 32 + q) * kCoarseWords + (bx >> 5)] >> (bx & 31)) & 1u) << q;
       columns[cw] = bits;
     }
-    // block distance map: for every block the Chebyshev distance to the nearest block with a bit in the coarse bitmap
-    // (rows of 17 bits around the block's column, 8 rows up and down; blocks beyond the window count as empty: the walk
-    // never enters them)
+    // block distance map of the window (blocks beyond it count as empty: the window walk never enters them)
     uint8_t* dist = reinterpret_cast<uint8_t*>(columns + kCoarse * kCoarseWords);
-    for (int blk = threadIdx.x; blk < kCoarse * kCoarse; blk += kBeamBlock) {
-      const int by = blk / kCoarse, bx = blk % kCoarse;
-      int best = kDistCap;
-#pragma unroll 1
-      for (int dy = -(kDistCap - 1); dy <= kDistCap - 1; ++dy) {
-        const int row = by + dy;
-        if (row < 0 || row >= kCoarse) continue;
-        const int ady = dy < 0 ? -dy : dy;
-        if (ady >= best) continue;
-        // bits bx - 8 .. bx + 8 of the 128-bit row, bit 8 = this column
-        const uint32_t* rw = coarse + row * kCoarseWords;
-        const int first = bx - (kDistCap - 1);  // may be negative
-        const int word = first >> 5;            // floor
-        const uint64_t lo = (word >= 0 && word < kCoarseWords) ? rw[word] : 0u;
-        const uint64_t hi = (word + 1 >= 0 && word + 1 < kCoarseWords) ? rw[word + 1] : 0u;
-        const uint32_t around = static_cast<uint32_t>(((hi << 32) | lo) >> (first & 31)) & 0x1FFFFu;
-        if (around == 0u) continue;
-        const uint32_t right = around >> (kDistCap - 1);              // bit 0 = this column, bit j = j columns to the right
-        const uint32_t left = around & ((1u << (kDistCap - 1)) - 1);  // bit 7 = one column to the left, bit 0 = eight
-        int across = kDistCap;
-        if (right) across = __builtin_ctz(right);
-        if (left) across = min(across, (kDistCap - 1) - (31 - __builtin_clz(left)));
-        best = min(best, max(ady, across));
-      }
-      dist[blk] = static_cast<uint8_t>(best);
-    }
+    for (int blk = threadIdx.x; blk < kCoarse * kCoarse; blk += kBeamBlock)
+      dist[blk] = static_cast<uint8_t>(block_distance(coarse, kCoarseWords, kCoarse, blk % kCoarse, blk / kCoarse));
   }
   __syncthreads();
 
@@ -2029,6 +2073,17 @@ __global__ __launch_bounds__(kBlock) void k_pack_coarse_columns(const uint32_t* 
     if (by < block_rows) out |= ((rows[static_cast<size_t>(by) * row_words + (bx >> 5)] >> (bx & 31)) & 1u) << b;
   }
   columns[i] = out;
+}
+
+// Block distance map of the whole grid (block_distance above), one byte per block, dist_stride bytes per row of blocks.
+__global__ __launch_bounds__(kBlock) void k_block_distances(const uint32_t* __restrict__ rows, uint32_t block_rows, uint32_t row_words,
+                                                            uint32_t block_columns, uint32_t dist_stride, uint8_t* __restrict__ dist) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= static_cast<uint64_t>(block_rows) * dist_stride) return;
+  const uint32_t by = static_cast<uint32_t>(i / dist_stride), bx = static_cast<uint32_t>(i % dist_stride);
+  dist[i] = bx < block_columns ? static_cast<uint8_t>(block_distance(rows, static_cast<int>(row_words), static_cast<int>(block_rows),
+                                                                     static_cast<int>(bx), static_cast<int>(by)))
+                               : static_cast<uint8_t>(kDistCap);
 }
 
 // ---- K3 weight sums / normalize ----------------------------------------------------------------------
@@ -3188,11 +3243,14 @@ NonFreeBits nonfree_layout(uint32_t W, uint32_t H, uint32_t* base) {
   b.fine = base;
   b.rows = base + static_cast<size_t>(b.words_per_row) * H;
   b.columns = b.rows + static_cast<size_t>(block_rows) * b.row_words;
+  b.dist_stride = (block_columns + 3u) & ~3u;
+  b.dist = reinterpret_cast<const uint8_t*>(b.columns + static_cast<size_t>(block_columns) * b.column_words);
   return b;
 }
 size_t nonfree_words(uint32_t W, uint32_t H) {
   const NonFreeBits b = nonfree_layout(W, H, nullptr);
-  return static_cast<size_t>(b.columns - b.fine) + static_cast<size_t>((W + 7) / 8) * b.column_words;
+  return static_cast<size_t>(b.columns - b.fine) + static_cast<size_t>((W + 7) / 8) * b.column_words +
+         static_cast<size_t>((H + 7) / 8) * (b.dist_stride / 4);
 }
 void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32_t H, int8_t free_value, uint32_t* bits) {
   const NonFreeBits b = nonfree_layout(W, H, bits);
@@ -3203,6 +3261,8 @@ void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32
                      b.words_per_row, H, block_rows, b.row_words, const_cast<uint32_t*>(b.rows));
   hipLaunchKernelGGL(k_pack_coarse_columns, dim3(blocks_for(static_cast<uint64_t>(block_columns) * b.column_words)), dim3(kBlock), 0, st,
                      b.rows, block_rows, b.row_words, block_columns, b.column_words, const_cast<uint32_t*>(b.columns));
+  hipLaunchKernelGGL(k_block_distances, dim3(blocks_for(static_cast<uint64_t>(block_rows) * b.dist_stride)), dim3(kBlock), 0, st, b.rows,
+                     block_rows, b.row_words, block_columns, b.dist_stride, const_cast<uint8_t*>(b.dist));
 }
 
 #ifdef MCL_BEAM_STATS

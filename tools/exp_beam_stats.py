@@ -14,14 +14,14 @@ f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), BeamModelParam(beam_m
 f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
 lib = capi.load()
 out = (C.c_ulonglong * 32)()
-for c in range(3):
+for c in range(1):
     f.update(controls[c], scans[c])
     f.sync()
     assert lib.mcl_debug_beam_stats(out, 1) == 0
     v = list(out)
     beams_w = max(v[0], 1)
     names = ["beams", "walks, shared axis", "walks, mixed axes", "block columns", "columns examined", "columns with a hit", "tail groups",
-             "window walks", "grid walks"]
+             "window walks", "grid walks", "skips", "skips of 1 column", "skips of 2 columns", "skips of 4 columns", "skips of 8 columns", "head cells examined", "tail cells examined"]
     print(f"cycle {c}:")
     for i, name in enumerate(names):
         print(f"  {name:22s} waves {v[2*i]:14d} ({v[2*i]/beams_w:8.3f} per wave-beam)   lanes {v[2*i+1]:16d} ({v[2*i+1]/max(v[2*i],1):6.2f} lanes per wave event)")
