@@ -181,7 +181,7 @@ struct NonFreeBits {
   const uint32_t* rows;     // [ceil(H/8)][row_words]
   const uint32_t* columns;  // [ceil(W/8)][column_words]
   const uint8_t* dist;      // [ceil(H/8)][dist_stride]: Chebyshev distance, in blocks, to the nearest block with a bit in `rows`
-                            // (0 = the block itself), capped at 9
+                            // (0 = the block itself), capped at 17
   uint32_t words_per_row, row_words, column_words, dist_stride;
 };
 NonFreeBits nonfree_layout(uint32_t W, uint32_t H, uint32_t* base);

@@ -1351,6 +1351,15 @@ struct RayWalk {
 // floor(num / den) for num >= 0, den > 0: a 32-bit division whenever the operands allow it (they do for every grid below
 // 2^16 cells per side), the 64-bit one (~4x the instructions) otherwise.
 __device__ __forceinline__ long long floor_div(long long num, int den) {
+  if (num < (1ll << 22)) {
+    // the numerator is an exact float and the quotient stays below 2^22: with v_rcp_f32's one ulp and the two roundings
+    // around it the product is off by less than one (~8 instructions instead of ~30 for the integer division)
+    const int n = static_cast<int>(num);
+    int q = static_cast<int>(static_cast<float>(n) * __builtin_amdgcn_rcpf(static_cast<float>(den)));
+    const int rem = n - q * den;
+    q += (rem >= den ? 1 : 0) - (rem < 0 ? 1 : 0);
+    return q;
+  }
   if (num < (1ll << 32)) return static_cast<long long>(static_cast<unsigned>(num) / static_cast<unsigned>(den));
   return num / den;
 }
@@ -1533,8 +1542,8 @@ struct BitWindow {
 };
 // Chebyshev distance, in blocks, from block (bx, by) to the nearest block with a bit in the row-major coarse bitmap (rows of
 // row_words words, block_rows of them; blocks beyond the bitmap count as empty), capped at kDistCap: per row within reach, the
-// 17 bits around the block's column.
-constexpr int kDistCap = 9;  // block distances 0 .. 9 (9 = nothing within 8 blocks)
+// bits around the block's column.
+constexpr int kDistCap = 17;  // block distances 0 .. 17 (17 = nothing within 16 blocks)
 __device__ __forceinline__ int block_distance(const uint32_t* coarse_rows, int row_words, int block_rows, int bx, int by) {
   int best = kDistCap;
 #pragma unroll 1
@@ -1548,10 +1557,11 @@ __device__ __forceinline__ int block_distance(const uint32_t* coarse_rows, int r
     const int word = first >> 5;            // floor
     const uint64_t lo = (word >= 0 && word < row_words) ? rw[word] : 0u;
     const uint64_t hi = (word + 1 >= 0 && word + 1 < row_words) ? rw[word + 1] : 0u;
-    const uint32_t around = static_cast<uint32_t>(((hi << 32) | lo) >> (first & 31)) & 0x1FFFFu;  // bit 8 = this column
+    // the 2 kDistCap - 1 = 33 bits around the column (the shifted pair holds at least 33: 64 - 31)
+    const uint64_t around = (((hi << 32) | lo) >> (first & 31)) & ((1ull << (2 * kDistCap - 1)) - 1);  // bit kDistCap - 1 = this column
     if (around == 0u) continue;
-    const uint32_t right = around >> (kDistCap - 1);              // bit j = j columns to the right (0 = this one)
-    const uint32_t left = around & ((1u << (kDistCap - 1)) - 1);  // bit 7 = one column to the left, bit 0 = eight
+    const uint32_t right = static_cast<uint32_t>(around >> (kDistCap - 1));              // bit j = j columns to the right (0 = this one)
+    const uint32_t left = static_cast<uint32_t>(around) & ((1u << (kDistCap - 1)) - 1);  // top bit = one column to the left
     int across = kDistCap;
     if (right) across = __builtin_ctz(right);
     if (left) across = min(across, (kDistCap - 1) - (31 - __builtin_clz(left)));
@@ -1663,8 +1673,9 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   // Up to 8 cells that stay inside one block column: with nothing in that block or around it (block distance >= 2) they are
   // free, and the state behind them has a closed form - error + j dminor brought back into (0, dmajor], one trip per dmajor
   // taken off (a float quotient and a +-1 correction: the operands are far below 2^24).
-  const float inv_dmajor = dmajor > 0 ? 1.0f / static_cast<float>(dmajor) : 0.f;
-  auto clear_ahead = [&](int cx, int cy) { return maps.dist[(cy >> 3) * maps.dist_stride + (cx >> 3)] >= 2; };
+  const float inv_dmajor = dmajor > 0 ? __builtin_amdgcn_rcpf(static_cast<float>(dmajor)) : 0.f;  // (quotients below 2^8: one ulp is plenty)
+  const bool closed_forms = dmajor < (1 << 16);  // (lines of 32K cells and more walk block column by block column)
+  auto clear_ahead = [&](int cx, int cy) { return closed_forms && maps.dist[(cy >> 3) * maps.dist_stride + (cx >> 3)] >= 2; };
   auto advance_free = [&](int j) {
     if (dmajor > 0) {
       const int total = error + j * dminor;
@@ -1716,39 +1727,25 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
     {
       // Empty space in closed form: d = block distance from the block of cell k to the nearest block holding anything.  The next
       // 8 s cells stay within s blocks of it along either axis (8 s - 1 steps along the major axis, at most as many along the
-      // minor one), so with d >= s + 1 they are all free: s = the largest power of two within d - 1 and within the cells left,
-      // and the state after 8 s steps by the same rule as for 8 (8 s dminor = t dmajor + r by doubling t8, r8; one more trip if
-      // error + r exceeds dmajor).  Same cells skipped as a cell-by-cell walk would have found free.
+      // minor one), so with d >= s + 1 they are all free: s = d - 1, or what is left of the walk, and the state after 8 s steps
+      // is error + 8 s dminor brought back into (0, dmajor] (advance_free's rule; dmajor > 0 here: the line has more than 8
+      // cells).  Same cells skipped as a cell-by-cell walk would have found free.
       const uint32_t d = maps.dist[steep ? (major >> 3) * maps.dist_stride + (minor >> 3) : (minor >> 3) * maps.dist_stride + (major >> 3)];
-      if (d >= 2u) {
+      if (d >= 2u && closed_forms) {
         const uint32_t room = static_cast<uint32_t>(upto - k) >> 3;  // >= 1
-        const uint32_t most = min(d - 1u, room);
-        const int doublings = 31 - __builtin_clz(most);  // s = 2^doublings, 0 .. 3 (d <= kDistCap)
-        MCL_BEAM_STAT(9);  // a skip (10..13: of 1, 2, 4, 8 block columns)
-#ifdef MCL_BEAM_STATS
-        if (doublings == 0) beam_stat(10);
-        if (doublings == 1) beam_stat(11);
-        if (doublings == 2) beam_stat(12);
-        if (doublings == 3) beam_stat(13);
-#endif
-        int t = trips8, r = rest8;
-#pragma unroll
-        for (int j = 1; j <= 3; ++j) {
-          const bool on = doublings >= j;
-          const int r2 = 2 * r;
-          const bool carry = r2 >= dmajor;
-          const int rn = r2 - (carry ? dmajor : 0), tn = 2 * t + (carry ? 1 : 0);
-          r = on ? rn : r;
-          t = on ? tn : t;
-        }
-        int raised = error + r;
-        const bool extra = raised > dmajor;
-        raised -= extra ? dmajor : 0;
-        const int cells = 8 << doublings;
+        const int s_columns = static_cast<int>(min(d - 1u, room));
+        MCL_BEAM_STAT(9);  // a skip
+        const int cells = 8 * s_columns;
+        const int total = error + cells * dminor;  // <= 129 dmajor, far below 2^24
+        int trips = static_cast<int>(static_cast<float>(total - 1) * inv_dmajor);
+        int rem = total - trips * dmajor;
+        const int up = rem > dmajor ? 1 : 0, down = rem <= 0 ? 1 : 0;
+        trips += up - down;
+        rem -= (up - down) * dmajor;
         k += cells;
         major += cells * major_step;
-        minor += (t + (extra ? 1 : 0)) * minor_step;
-        error = raised;
+        minor += trips * minor_step;
+        error = rem;
         continue;
       }
     }

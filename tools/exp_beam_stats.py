@@ -24,5 +24,7 @@ for c in range(1):
              "window walks", "grid walks", "skips", "skips of 1 column", "skips of 2 columns", "skips of 4 columns", "skips of 8 columns", "head cells examined", "tail cells examined"]
     print(f"cycle {c}:")
     for i, name in enumerate(names):
+        if v[2 * i] == 0:
+            continue
         print(f"  {name:22s} waves {v[2*i]:14d} ({v[2*i]/beams_w:8.3f} per wave-beam)   lanes {v[2*i+1]:16d} ({v[2*i+1]/max(v[2*i],1):6.2f} lanes per wave event)")
 f.close()
