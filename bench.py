@@ -255,6 +255,8 @@ def main():
     params = AmclParams(min_particles=n_total, max_particles=n_total)
     motion = DifferentialDriveModelParam(*ALPHAS)
     sensor = LikelihoodFieldModelParam(**LF)
+    driver_used = [None]
+
     def make_filter(per_gpu):
         """One logical filter of per_gpu * world particles; with several ranks each holds a contiguous shard and the library runs
         the cycle over RCCL (include/beluga_mcl.h, "Particle shards").  BELUGA_BENCH_DRIVER=python (or a gloo dry run) uses the
@@ -268,11 +270,32 @@ def main():
             from beluga_amd.sharded import ShardedAmcl
             return ShardedAmcl(grid, motion, sensor, p, seed=42, device=local_rank)
         f = Amcl(grid, motion, sensor, p, seed=42, device=local_rank, shard_offset=rank * per_gpu, shard_capacity=per_gpu)
-        box = [comm_unique_id() if rank == 0 else None]
+        ok = 1
+        try:
+            box = [comm_unique_id() if rank == 0 else None]
+        except Exception as exc:  # no usable librccl for the library on this box
+            print(f"[bench] rank {rank}: {exc}", file=sys.stderr)
+            box, ok = [None], 0
         if world > 1:
             dist.broadcast_object_list(box, src=0)
-        f.comm_attach_rccl(box[0], rank, world)
-        return f
+        if box[0] is None:
+            ok = 0
+        if ok:
+            try:
+                f.comm_attach_rccl(box[0], rank, world)
+            except Exception as exc:
+                print(f"[bench] rank {rank}: {exc}", file=sys.stderr)
+                ok = 0
+        if world > 1:  # every rank takes the same path: the library's communicator everywhere, or the torch.distributed driver everywhere
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            return f
+        f.close()
+        from beluga_amd.sharded import ShardedAmcl
+        driver_used[0] = "torch.distributed driver (beluga_amd/sharded.py): the library's RCCL communicator could not be set up"
+        return ShardedAmcl(grid, motion, sensor, p, seed=42, device=local_rank)
 
     filt = make_filter(n_local)
     filt.initialize(truth, np.diag([0.25, 0.25, 0.04]))
@@ -383,7 +406,8 @@ def main():
                 "beams": BEAMS,
                 "grid": f"{MAP_SIZE}x{MAP_SIZE}@{RESOLUTION}",
                 "parallelism": "1 GPU" if not use_sharded else f"particle shards x{world}: shard sums / CDF intervals / estimate sums all-gathered, "
-                                                                    f"ancestors exchanged all-to-all (RCCL over xGMI, inside libbeluga_mcl.so)",
+                                                                    f"ancestors exchanged all-to-all (RCCL over xGMI, "
+                                                                    f"{driver_used[0] or 'inside libbeluga_mcl.so'})",
                 "particle_beam_evals_per_s": n_total * BEAMS * args.steps / elapsed,
                 "global_cycles_per_s": args.steps / elapsed,
                 "unit_of_work": "one update cycle of 1M particles x 1080 beams; a global cycle over N GPUs = N units",
