@@ -704,10 +704,13 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
   }
   if (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM) {
     // Below a few thousand particles the ordering passes cost more than they save.
+    // Sets below the ordering threshold (the reference's usual sizes): one or a few particles per wave, lanes over the beams
+    // (launch_reweight_lf falls back to the lane-per-particle kernel where the field has no palette form).
     const int variant = mode.beams ? kLfBeamLanes
                                    : ((ctx->tuning.lf_variant == kLfSortedLanes || ctx->tuning.lf_variant == kLfBeamLanes) && !ordered)
-                                         ? kLfLanePerParticle
+                                         ? (ctx->n < static_cast<uint64_t>(ctx->tuning.sort_min_particles) ? kLfBeamLanes : kLfLanePerParticle)
                                          : ctx->tuning.lf_variant;
+    if (variant == kLfBeamLanes && !mode.beams) ctx->lf_beams_launches += 1;
     const bool scan_is_short = ctx->scan_extent / ctx->resolution < 8192.0;
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
     const bool use_patches = mode.patches;

@@ -135,6 +135,43 @@ __global__ __launch_bounds__(kBlock) void k_pull_scan(const double* __restrict__
 // ---- K1 propagate ----------------------------------------------------------------------------------
 // One workgroup per chunk of kChunk particles (coalesced 32-byte records).  kKeys: the ordering key of the NEW pose and the
 // chunk's histogram of the key's low digit come out of the same pass (the poses are in registers here).
+// One particle through the motion model (the body of actions::propagate for the three models).
+__device__ __forceinline__ Pose2 propagate_one(const Pose2& state, const DiffDriveSampler& smp, uint64_t seed, uint32_t step, uint64_t index) {
+  const RngWords a = rng_draw(seed, step, kRngPropagateA, index);
+  const RngWords b = rng_draw(seed, step, kRngPropagateB, index);
+  double z0, z1, z2, z3;
+  rng_box_muller(rng_uniform53(a.w[0], a.w[1]), rng_uniform53(a.w[2], a.w[3]), z0, z1);
+  rng_box_muller(rng_uniform53(b.w[0], b.w[1]), rng_uniform53(b.w[2], b.w[3]), z2, z3);
+  if (smp.kind == 1) {
+    // omnidirectional_drive_model.hpp:133-144 — draws in source order: rotation, translation, strafe
+    const Rot2 first{smp.first_c, smp.first_s};
+    const Rot2 second = rot_mul(rot_exp(z0 * smp.s1 + smp.m1), rot_inverse(first));
+    const double t = z1 * smp.st + smp.mt;
+    const double strafe = z2 * smp.s2 + 0.0;
+    return pose_mul(pose_mul(state, Pose2{first, 0.0, 0.0}), Pose2{second, t, -strafe});
+  }
+  if (smp.kind == 2) {
+    // stationary_model.hpp:55-61 — N(0, 0.02) on heading, x, y
+    return pose_mul(state, Pose2{rot_exp(z0 * 0.02 + 0.0), z1 * 0.02 + 0.0, z2 * 0.02 + 0.0});
+  }
+  // differential_drive_model.hpp:156-163
+  const double r1 = z0 * smp.s1 + smp.m1;
+  const double t = z1 * smp.st + smp.mt;
+  const double r2 = z2 * smp.s2 + smp.m2;
+  return pose_mul(pose_mul(state, Pose2{rot_exp(r1), 0.0, 0.0}), Pose2{rot_exp(r2), t, 0.0});
+}
+
+// Small sets (no ordering keys): one particle per lane, 256 per workgroup - 2000 particles are 8 workgroups on 8 CUs, a wave
+// per SIMD, instead of one workgroup of the chunked kernel working through them on one (256 lanes rather than 64 for the sake
+// of the scan pull, which is bound by the reads in flight over PCIe).
+__global__ __launch_bounds__(kBlock) void k_propagate_small(Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
+                                                           uint64_t index_offset, const double* __restrict__ scan_src,
+                                                           double* __restrict__ scan_dst, uint32_t scan_doubles) {
+  if (scan_dst && blockIdx.x == gridDim.x - 1) pull_scan(scan_src, scan_dst, scan_doubles);
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) store_pose(p, i, propagate_one(load_pose(p, i), smp, seed, step, index_offset + i));
+}
+
 template <bool kKeys>
 __global__ __launch_bounds__(kWide) void k_propagate(Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
                                                       uint64_t index_offset, const double* __restrict__ scan_src,
@@ -151,30 +188,7 @@ __global__ __launch_bounds__(kWide) void k_propagate(Particles p, uint64_t n, Di
   for (int k = 0; k < kChunk / kWide; ++k) {
     const uint64_t i = base + static_cast<uint64_t>(k) * kWide + threadIdx.x;
     if (i >= n) break;
-    const RngWords a = rng_draw(seed, step, kRngPropagateA, index_offset + i);
-    const RngWords b = rng_draw(seed, step, kRngPropagateB, index_offset + i);
-    double z0, z1, z2, z3;
-    rng_box_muller(rng_uniform53(a.w[0], a.w[1]), rng_uniform53(a.w[2], a.w[3]), z0, z1);
-    rng_box_muller(rng_uniform53(b.w[0], b.w[1]), rng_uniform53(b.w[2], b.w[3]), z2, z3);
-    const Pose2 state = load_pose(p, i);
-    Pose2 out;
-    if (smp.kind == 1) {
-      // omnidirectional_drive_model.hpp:133-144 — draws in source order: rotation, translation, strafe
-      const Rot2 first{smp.first_c, smp.first_s};
-      const Rot2 second = rot_mul(rot_exp(z0 * smp.s1 + smp.m1), rot_inverse(first));
-      const double t = z1 * smp.st + smp.mt;
-      const double strafe = z2 * smp.s2 + 0.0;
-      out = pose_mul(pose_mul(state, Pose2{first, 0.0, 0.0}), Pose2{second, t, -strafe});
-    } else if (smp.kind == 2) {
-      // stationary_model.hpp:55-61 — N(0, 0.02) on heading, x, y
-      out = pose_mul(state, Pose2{rot_exp(z0 * 0.02 + 0.0), z1 * 0.02 + 0.0, z2 * 0.02 + 0.0});
-    } else {
-      // differential_drive_model.hpp:156-163
-      const double r1 = z0 * smp.s1 + smp.m1;
-      const double t = z1 * smp.st + smp.mt;
-      const double r2 = z2 * smp.s2 + smp.m2;
-      out = pose_mul(pose_mul(state, Pose2{rot_exp(r1), 0.0, 0.0}), Pose2{rot_exp(r2), t, 0.0});
-    }
+    const Pose2 out = propagate_one(load_pose(p, i), smp, seed, step, index_offset + i);
     store_pose(p, i, out);
     if (kKeys) {
       const uint32_t key = order_key(double4{out.r.c, out.r.s, out.x, out.y}, kf);
@@ -577,14 +591,16 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
 // (profiles/r02_dispersed_study.txt): 23 lines per gather, 398 M L2 requests per launch - the same as the ordered-lanes gather
 // kernel gets out of that set (400 M) - but fewer of them hit in L2 (33 % vs 48 %), and the launch is bound by what the L2
 // misses pull in (33 GB per launch at 7.5 TB/s): 4.46 ms vs 3.72 ms.  Kept as a switch, not chosen by default.
-// A wave owns a tile of 64 particles (index order, no ordering pass): the 64 world->field transforms are computed
-// lane-parallel and broadcast one at a time through SGPRs.
+// A wave owns a tile of per_wave particles (index order, no ordering pass): their world->field transforms are computed
+// lane-parallel and broadcast one at a time through SGPRs.  SMALL sets (below the ordering threshold: the reference's usual
+// 500 - 2000 particles) come here with one or a few particles per wave: 2000 particles x 1080 beams are 2000 waves of 17
+// gathers each instead of 32 waves walking 1080 beams one after the other (0.48 -> 0.0x ms).
 // End-points by the reference's separately rounded arithmetic; a lane adds its beams in scan order, the 64 lane sums are
 // added in a fixed tree (wave_sum_f64): the weight differs from the sequential sum of the other kernels in rounding only.
 // Workgroup memory as in k_reweight_lf_palette: [0, (H+2)*4) row offsets, [pal_base, ...) the palette; no other LDS.
 constexpr int kBeamsBlock = 256;
 __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, uint64_t n, FieldView f, const double2* __restrict__ pts,
-                                                                   uint32_t B) {
+                                                                   uint32_t B, uint32_t per_wave /* particles of a wave: 1 .. 64 */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
     uint32_t* s_row = reinterpret_cast<uint32_t*>(smem);
@@ -595,13 +611,13 @@ __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, 
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t tile = static_cast<uint64_t>(blockIdx.x) * (kBeamsBlock / kWave) + (threadIdx.x >> 6);
-  const uint64_t base = tile * kWave;
+  const uint64_t base = tile * per_wave;
   if (base >= n) return;
+  const uint32_t cnt = static_cast<uint32_t>(n - base < per_wave ? n - base : per_wave);
   const uint64_t i = base + lane;
   Pose2 state = pose_identity();
-  if (i < n) state = load_pose(p, i);
+  if (lane < cnt) state = load_pose(p, i);
   const Pose2 T = pose_mul(f.world_to_field, state);  // likelihood_field_model.hpp:70
-  const uint32_t cnt = static_cast<uint32_t>(n - base < kWave ? n - base : kWave);
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(f.pal_idx), 0, static_cast<int>(f.pal_bytes), 0x00020000);
   const uint32_t full = B & ~255u;  // beams taken four per lane at a time (their gathers in flight together)
@@ -636,7 +652,7 @@ __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, 
     const double total = wave_sum_f64(acc);
     if (lane == q) mine = total;
   }
-  if (i < n) p.w[i] = p.w[i] * (f.prob ? exp(mine) : 1.0 + mine);
+  if (lane < cnt) p.w[i] = p.w[i] * (f.prob ? exp(mine) : 1.0 + mine);
 }
 
 // The palette kernel with the index table read through LDS patches.
@@ -3129,6 +3145,11 @@ void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler 
     return;
   }
   const uint32_t nblocks = num_chunks(n);
+  if (!(sort && frame) && n <= 65536) {
+    hipLaunchKernelGGL(k_propagate_small, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, smp, seed, step,
+                       index_offset, scan_src, scan_dst, scan_doubles);
+    return;
+  }
   if (sort && frame && n < (1ull << 32))
     hipLaunchKernelGGL(k_propagate<true>, dim3(nblocks), dim3(kWide), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
                        scan_doubles, *frame, sort->keys, sort->table, nblocks);
@@ -3213,10 +3234,13 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
       hipLaunchKernelGGL(k_lf_combine, dim3(blocks_for(n)), dim3(kBlock), 0, st, p.w, n, sort->perm, partial, segments, f.prob);
   } else if (variant == kLfBeamLanes && tuning.lf_table == 0 && f.pal_idx != nullptr && f.pal_count > 0 &&
              static_cast<size_t>(f.pal_base) + static_cast<size_t>(f.pal_count) * sizeof(double) <= 65536) {
-    const uint64_t tiles = (n + kWave - 1) / kWave;
+    // particles per wave: enough waves to fill the chip (4096) before a wave takes a second particle
+    const uint32_t per_wave = static_cast<uint32_t>(std::min<uint64_t>(kWave, std::max<uint64_t>(1, (n + 4095) / 4096)));
+    const uint64_t tiles = (n + per_wave - 1) / per_wave;
     const dim3 grid(static_cast<unsigned>((tiles + (kBeamsBlock / kWave) - 1) / (kBeamsBlock / kWave)));
     const size_t pal_lds = static_cast<size_t>(f.pal_base) + static_cast<size_t>(f.pal_count) * sizeof(double);
-    hipLaunchKernelGGL(k_reweight_lf_beams, grid, dim3(kBeamsBlock), pal_lds, st, p, n, f, reinterpret_cast<const double2*>(d_points), B);
+    hipLaunchKernelGGL(k_reweight_lf_beams, grid, dim3(kBeamsBlock), pal_lds, st, p, n, f, reinterpret_cast<const double2*>(d_points), B,
+                       per_wave);
   } else if (variant == kLfLanePerParticle || variant == kLfSortedLanes || variant == kLfBeamLanes) {  // (kLfBeamLanes without a palette)
     const dim3 grid(blocks_for(n));
     if (idx32) hipLaunchKernelGGL(k_reweight_lf_lane<true>, grid, dim3(kBlock), 0, st, p, n, f, d_points, B);
