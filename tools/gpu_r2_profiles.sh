@@ -34,4 +34,19 @@ python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $GRAFT_REPO_ROOT/gpurun_out/prof/
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof/c3
 cd $GRAFT_REPO_ROOT
 timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null > $O/bench_1M.json
+# beam kernel: instruction counters, then the walk statistics of the measurement build (rebuilds the library twice)
+cd /tmp
+rm -f $O/pmc_config5.txt
+i=0
+for pmc in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --kernel-trace --pmc $pmc -d $GRAFT_REPO_ROOT/gpurun_out/prof/b$i -o pmc -- python $GRAFT_REPO_ROOT/tools/bench_configs.py 5 --steps 2 > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/prof/b$i.err || echo "beam pass $i failed"
+  python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $GRAFT_REPO_ROOT/gpurun_out/prof/b$i/pmc_results.db pmc 2>/dev/null | grep "^PMC" | grep -E "reweight_beam" >> $O/pmc_config5.txt
+  rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof/b$i
+done
+cd $GRAFT_REPO_ROOT
+python tools/exp_small.py 2>/dev/null > $O/small_filters.txt
+python tools/exp_lf_series.py 2>/dev/null > $O/lf_series.txt
+bash tools/gpu_beam_stats.sh > /dev/null 2>&1
+cp gpurun_out/beam_stats.txt $O/beam_walk_stats.txt 2>/dev/null
 ls -la $O
