@@ -166,6 +166,52 @@ def test_reweight_beam_matches_oracle(n, beams):
     f.close()
 
 
+@pytest.mark.parametrize("kind", ["empty", "salt", "stripes", "unknown_frame", "rotated_rooms"])
+def test_beam_walk_closed_forms_on_adversarial_maps(kind):
+    """The ordered beam kernel's empty-space skips (block distance map, closed-form Bresenham state), its head / tail shortcuts
+    and the walks over the whole-grid maps (rays that leave a workgroup's 1024^2 LDS window, particles outside it altogether),
+    on maps built to stress them: nothing at all (every ray runs to its end or off the grid in the longest skips), salt noise
+    (distance 0 / 1 nearly everywhere: cell-by-cell examination), thin diagonal stripes, an unknown frame around free space, and
+    a rooms map behind a rotated origin.  20 000 particles spread over tens of metres.  Weights against the oracle's cell-by-cell
+    Bresenham (raycasting.hpp:97-107, bresenham.hpp:122-160) and the number of cells visited EXACTLY (an integer result)."""
+    rng = np.random.Generator(np.random.MT19937(7))
+    W, H, res = 1500, 1200, 0.05
+    origin = se2_from_xytheta(-37.5, -30.0, 0.0)
+    cells = np.zeros((H, W), dtype=np.int8)
+    if kind == "salt":
+        cells[rng.random((H, W)) < 0.003] = 100
+    elif kind == "stripes":
+        yy, xx = np.mgrid[0:H, 0:W]
+        cells[((xx + yy) % 97 == 0) & ((xx // 61 + yy // 53) % 3 != 0)] = 100
+    elif kind == "unknown_frame":
+        cells[:] = -1
+        cells[150:-150, 200:-200] = 0
+        cells[600, 300:900] = 100
+    elif kind == "rotated_rooms":
+        cells = synth.make_rooms_map(W, H, seed=9, n_rooms=40)
+        origin = se2_from_xytheta(-20.0, -45.0, 0.6)
+    grid = OccupancyGrid(cells=cells, resolution=res, origin=origin)
+    centre = (0.0, 0.0, 0.3)
+    beams, max_range = 61, 40.0
+    pts = make_scan(grid, centre, beams, max_range=max_range, fov=360.0)
+    pts[::7] *= 3.0  # some measured ranges far beyond what the map returns
+    n = 20_000
+    states = synth.normal_particles(n, centre, (8.0, 8.0, 1.5), seed=5)
+    states[:5, 2] += 500.0  # source cells outside the grid
+    beam = BeamModelParam(beam_max_range=max_range)
+    f = new_filter(grid, n, sensor=beam)
+    f.set_particles(states, np.ones(n))
+    f.beam_cells_visited(reset=True)
+    f.reweight(pts)
+    got = f.particles()[1]
+    visited = f.beam_cells_visited()
+    want, steps = orc.beam_weights(grid.cells, res, grid.origin, (0.5, 0.5, 0.05, 0.05, 0.2, 0.1, max_range), states, pts,
+                                   threads=orc.max_threads(), return_steps=True)
+    assert visited == steps
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-300)
+    f.close()
+
+
 def test_propagate_matches_oracle():
     grid = rooms_grid(64, 1)
     n = 10_000
