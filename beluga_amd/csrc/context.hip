@@ -625,6 +625,11 @@ bool wants_patches(mcl_ctx* ctx) {
   return false;
 }
 
+// Likelihood-field sets below the threshold of the ordered kernels (the larger of the two options: the ordering itself and
+// the LF kernels' own crossover).
+bool lf_set_is_small(const mcl_ctx* ctx) {
+  return ctx->n < static_cast<uint64_t>(std::max(ctx->tuning.sort_min_particles, ctx->tuning.lf_small_particles));
+}
 // The LF launch of this cycle: the patch kernel, the gather kernel, or - for a set the patch kernel has reported as
 // dispersed (no probe due) - the wave-per-particle kernel, which needs no ordering pass.  Decided once per cycle, before the
 // propagation kernel (which emits the ordering keys); cleared by do_reweight.
@@ -642,14 +647,14 @@ void decide_lf_mode(mcl_ctx* ctx) {
   if (ctx->tuning.lf_variant != kLfSortedLanes) return;
   ctx->lf_mode.patches = wants_patches(ctx);
   ctx->lf_mode.beams = !ctx->lf_mode.patches && ctx->tuning.lf_patch == 1 && ctx->tuning.lf_dispersed != 0 && !ctx->patch_useful && palette &&
-                       ctx->n >= static_cast<uint64_t>(ctx->tuning.sort_min_particles);
+                       !lf_set_is_small(ctx);
 }
 
 bool wants_ordering(const mcl_ctx* ctx) {
   if (ctx->n < static_cast<uint64_t>(ctx->tuning.sort_min_particles) || ctx->n >= (1ull << 32)) return false;
   if (ctx->cfg.sensor_kind == MCL_SENSOR_BEAM) return true;
   if (ctx->lf_mode.decided && ctx->lf_mode.beams) return false;
-  return ctx->tuning.lf_variant == kLfSortedLanes;
+  return ctx->tuning.lf_variant == kLfSortedLanes && !(lf_set_is_small(ctx) && ctx->pal_count != 0 && ctx->tuning.lf_table == 0);
 }
 
 // fused (mcl_update): the scan staged by stage_points is pulled by the same kernel, and the ordering keys of the new poses
@@ -708,7 +713,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     // (launch_reweight_lf falls back to the lane-per-particle kernel where the field has no palette form).
     const int variant = mode.beams ? kLfBeamLanes
                                    : ((ctx->tuning.lf_variant == kLfSortedLanes || ctx->tuning.lf_variant == kLfBeamLanes) && !ordered)
-                                         ? (ctx->n < static_cast<uint64_t>(ctx->tuning.sort_min_particles) ? kLfBeamLanes : kLfLanePerParticle)
+                                         ? (lf_set_is_small(ctx) ? kLfBeamLanes : kLfLanePerParticle)
                                          : ctx->tuning.lf_variant;
     if (variant == kLfBeamLanes && !mode.beams) ctx->lf_beams_launches += 1;
     const bool scan_is_short = ctx->scan_extent / ctx->resolution < 8192.0;
@@ -1350,7 +1355,8 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     MCL_HIP(ctx, hipEventCreateWithFlags(&ctx->points_event, hipEventDisableTiming));
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
-    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "device_policy", "sort_min_particles", "field_build"}) {
+    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_small_particles", "device_policy",
+                             "sort_min_particles", "field_build"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2188,6 +2194,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   Tuning& t = ctx->tuning;
   if (key == "lf_variant") t.lf_variant = value == 0 ? kLfWavePerParticle : (value == 1 ? kLfLanePerParticle : (value == 3 ? kLfBeamLanes : kLfSortedLanes));
   else if (key == "lf_dispersed") t.lf_dispersed = value ? 1 : 0;
+  else if (key == "lf_small_particles") t.lf_small_particles = value < 0 ? 0 : static_cast<int>(std::min<int64_t>(value, INT32_MAX));
   else if (key == "lf_fast") t.lf_fast = value < 0 ? -1 : (value ? 1 : 0);
   else if (key == "lf_table") t.lf_table = value ? 1 : 0;
   else if (key == "lf_patch") t.lf_patch = value < 0 || value > 2 ? 1 : static_cast<int>(value);

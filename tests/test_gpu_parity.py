@@ -47,8 +47,13 @@ def make_scan(grid, pose, beams, max_range=30.0, fov=270.0, seed=1):
 
 
 def new_filter(grid, n, sensor=LF, **kw):
+    """The ordered kernels engage from 16 384 particles here (option lf_small_particles pinned to the ordering threshold: the
+    library's own crossover to them, 65 536 particles, is exercised by test_mid_size_sets_take_the_kernel_for_small_sets)."""
+    small = kw.pop("lf_small_particles", 16_384)
     params = AmclParams(min_particles=kw.pop("min_particles", n), max_particles=n, **kw)
-    return Amcl(grid, MOTION, sensor, params, seed=11)
+    f = Amcl(grid, MOTION, sensor, params, seed=11)
+    f.set_option("lf_small_particles", small)
+    return f
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -131,6 +136,26 @@ def test_reweight_lf_matches_oracle(variant, beams):
     unknown = float(np.float32(1.0 / 100.0))  # float(1 / max_laser_distance), likelihood_field_model.hpp:75
     assert got[0] == pytest.approx(w0[0] * (1.0 + beams * unknown ** 3), rel=1e-12)  # every beam out of the grid
     f.close()
+
+
+def test_mid_size_sets_take_the_kernel_for_small_sets():
+    """Default options: likelihood-field sets below 65 536 particles go to k_reweight_lf_beams (a wave per few particles, the
+    lanes over the beams, no ordering pass - faster than the ordered kernels up to there), sets from there on to the ordered
+    kernels; same weights up to the rounding of the lane sums."""
+    grid = rooms_grid()
+    truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=2, clearance_cells=6)
+    pts = make_scan(grid, truth, 360, max_range=12.0)
+    for n, beams_kernel in ((30_000, True), (65_535, True), (65_536, False)):
+        states = synth.normal_particles(n, truth, (0.5, 0.5, 0.2), seed=5)
+        f = Amcl(grid, MOTION, LF, AmclParams(min_particles=n, max_particles=n), seed=11)
+        f.set_particles(states, np.ones(n))
+        f.reweight(pts)
+        assert f.counter("lf_beams_launches") == (1 if beams_kernel else 0)
+        assert f.counter("lf_fast_launches") == (0 if beams_kernel else 1)
+        sample = np.random.Generator(np.random.MT19937(2)).choice(n, 2048, replace=False)
+        want = orc.lf_weights(f.likelihood_field(), grid.resolution, grid.origin, LF.max_laser_distance, states[sample], pts)
+        np.testing.assert_allclose(f.particles()[1][sample], want, rtol=RTOL)
+        f.close()
 
 
 def test_reweight_lf_rotated_origin_and_empty_scan():
