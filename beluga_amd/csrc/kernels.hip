@@ -584,17 +584,19 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
   }
 }
 
-// Variant D — one wavefront per PARTICLE, one lane per BEAM, over the palette form of the table: an alternative for a
-// dispersed set (global localisation: initialize_from_map, a kidnapped robot), behind option lf_dispersed = 1 / lf_variant = 3.
-// The 64 lanes of a gather hold 64 consecutive beams of ONE pose: their end-points trace the walls the scan saw and
+// Variant D — one wavefront per PARTICLE (or per few), one lane per BEAM, over the palette form of the table.
+// (1) The kernel of SMALL sets (below 65 536 particles by default, option lf_small_particles - the reference's usual 500 - 2000
+// among them): a wave owns a tile of per_wave = 1 .. 16 particles in index order, no ordering pass; their world->field
+// transforms are computed lane-parallel and broadcast one at a time through SGPRs, and the 64 lanes take 64 consecutive beams
+// at a time.  2000 particles x 1080 beams are 2000 waves of 17 gathers each instead of 32 waves walking 1080 beams one after the
+// other (whole update 0.35 -> 0.06 ms, profiles/r02_small_filters.txt); it stays ahead of the ordered kernels up to ~60K
+// particles, whose sparse clouds fit few LDS patches (tools/exp_mid.py).
+// (2) An alternative for large DISPERSED sets (global localisation), behind option lf_dispersed = 1 / lf_variant = 3, 64
+// particles per wave: the 64 look-ups of a gather belong to ONE pose - their end-points trace the walls the scan saw and
 // neighbouring beams share 8x8-cell tiles, whatever the cloud looks like.  Measured on 1M particles spread over the 4000^2 map
 // (profiles/r02_dispersed_study.txt): 23 lines per gather, 398 M L2 requests per launch - the same as the ordered-lanes gather
 // kernel gets out of that set (400 M) - but fewer of them hit in L2 (33 % vs 48 %), and the launch is bound by what the L2
-// misses pull in (33 GB per launch at 7.5 TB/s): 4.46 ms vs 3.72 ms.  Kept as a switch, not chosen by default.
-// A wave owns a tile of per_wave particles (index order, no ordering pass): their world->field transforms are computed
-// lane-parallel and broadcast one at a time through SGPRs.  SMALL sets (below the ordering threshold: the reference's usual
-// 500 - 2000 particles) come here with one or a few particles per wave: 2000 particles x 1080 beams are 2000 waves of 17
-// gathers each instead of 32 waves walking 1080 beams one after the other (0.48 -> 0.0x ms).
+// misses pull in (33 GB per launch at 7.5 TB/s): 4.46 ms vs 3.72 ms.  Not chosen by default there.
 // End-points by the reference's separately rounded arithmetic; a lane adds its beams in scan order, the 64 lane sums are
 // added in a fixed tree (wave_sum_f64): the weight differs from the sequential sum of the other kernels in rounding only.
 // Workgroup memory as in k_reweight_lf_palette: [0, (H+2)*4) row offsets, [pal_base, ...) the palette; no other LDS.
