@@ -289,6 +289,11 @@ struct mcl_ctx {
   DeviceBuffer<long long> d_comm_i64;       // counts[world] | gathered counts[world * world]
   DeviceBuffer<double> d_targets, d_send_targets, d_requests_in, d_replies_out, d_replies_in;
   DeviceBuffer<uint32_t> d_route_order;
+  // KLD-adaptive resampling over shards: this rank's slices of the candidate blocks, hash staging, the re-balanced shard
+  DeviceBuffer<double> d_cand_states, d_new_shard;
+  DeviceBuffer<unsigned long long> d_cand_hashes, d_block_hashes;
+  uint64_t global_n{0};                     // particles of the logical filter over all shards (0: max_particles)
+  bool global_n_unknown{false};             // the caller loaded this shard itself (mcl_set_particles): counts are gathered first
   double* h_comm{nullptr};                  // pinned staging for the exchange's host reads / uploads
 
   // profiling: 0 = off, 1 = the sensor kernel only (two events per cycle), 2 = every stage
@@ -1051,6 +1056,134 @@ mcl_status comm_exchange(mcl_ctx* ctx, const void* d_send, const uint64_t* send_
   return MCL_OK;
 }
 
+// Contiguous, balanced split of [0, n_total) over the ranks.
+void shard_bounds(uint64_t n_total, uint32_t world, uint32_t rank, uint64_t* first, uint64_t* count) {
+  const uint64_t base = n_total / world, rem = n_total % world;
+  *first = rank * base + std::min<uint64_t>(rank, rem);
+  *count = base + (rank < rem ? 1 : 0);
+}
+
+// The ancestor exchange for the output slots [first_slot, first_slot + m) of views::sample | random_intersperse: every
+// slot's point of the global CDF goes to the shard that owns it, which answers with the state.  Leaves the targets in
+// d_targets, the replies (request order) in d_replies_in and the slot of every request in d_route_order.
+mcl_status sharded_draw(mcl_ctx* ctx, double random_state_probability, double total, const double* d_intervals, uint64_t first_slot,
+                        uint64_t m) {
+  const uint32_t world = ctx->comm_world, rank = ctx->comm_rank;
+  long long* d_counts = ctx->d_comm_i64.ptr;   // [world]
+  long long* d_all_counts = d_counts + world;  // [world][world]
+  MCL_HIP(ctx, ctx->d_targets.ensure(std::max<uint64_t>(m, 1)));
+  MCL_HIP(ctx, ctx->d_send_targets.ensure(std::max<uint64_t>(m, 1)));
+  MCL_HIP(ctx, ctx->d_route_order.ensure(std::max<uint64_t>(m, 1)));
+  MCL_HIP(ctx, ctx->d_replies_in.ensure(std::max<uint64_t>(4 * m, 4)));
+  if (const mcl_status s = mcl_resample_targets(ctx, ctx->step, random_state_probability, total, first_slot, m, ctx->d_targets.ptr)) return s;
+  if (const mcl_status s = mcl_route_targets(ctx, ctx->d_targets.ptr, m, d_intervals, d_intervals + world, world, rank, ctx->d_send_targets.ptr,
+                                             ctx->d_route_order.ptr, reinterpret_cast<int64_t*>(d_counts))) return s;
+  if (const mcl_status s = comm_gather(ctx, d_counts, d_all_counts, world * sizeof(long long))) return s;  // counts[r][q]: r asks q
+  long long* h_counts = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + 9));
+  MCL_HIP(ctx, hipMemcpyAsync(h_counts, d_all_counts, world * world * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<uint64_t> send_requests(world), recv_requests(world), send_replies(world), recv_replies(world);
+  uint64_t incoming = 0;
+  for (uint32_t q = 0; q < world; ++q) {
+    const uint64_t out = static_cast<uint64_t>(h_counts[rank * world + q]), in = static_cast<uint64_t>(h_counts[q * world + rank]);
+    send_requests[q] = out * sizeof(double);
+    recv_requests[q] = in * sizeof(double);
+    send_replies[q] = in * 4 * sizeof(double);
+    recv_replies[q] = out * 4 * sizeof(double);
+    incoming += in;
+  }
+  MCL_HIP(ctx, ctx->d_requests_in.ensure(std::max<uint64_t>(incoming, 1)));
+  MCL_HIP(ctx, ctx->d_replies_out.ensure(std::max<uint64_t>(4 * incoming, 4)));
+  if (const mcl_status s = comm_exchange(ctx, ctx->d_send_targets.ptr, send_requests.data(), ctx->d_requests_in.ptr, recv_requests.data())) return s;
+  if (incoming) {
+    if (const mcl_status s = mcl_serve_requests(ctx, ctx->d_requests_in.ptr, incoming, ctx->d_replies_out.ptr)) return s;
+  }
+  return comm_exchange(ctx, ctx->d_replies_out.ptr, send_replies.data(), ctx->d_replies_in.ptr, recv_replies.data());
+}
+
+// views::sample | random_intersperse | take_while_kld | take(max) | actions::assign (amcl_core.hpp:188-196) over the shards:
+// candidates are drawn block by block (doubling), every rank drawing its slice of a block through the ancestor exchange;
+// the spatial hashes of the whole block are all-gathered so that every rank checks kld_condition over the GLOBAL candidate
+// stream (take_while_kld.hpp:72-88,112-137) and takes the same cut; the kept candidates [0, n_out) are then re-balanced into
+// contiguous shards of the new set.  Same candidate stream, same cut as the single-context filter.
+mcl_status sharded_resample_kld(mcl_ctx* ctx, double random_state_probability, double total, const double* d_intervals, uint64_t* n_out_total) {
+  const mcl_amcl_params& ap = ctx->cfg.amcl;
+  const uint32_t world = ctx->comm_world, rank = ctx->comm_rank;
+  const uint64_t max_p = ap.max_particles, min_p = ap.min_particles;
+  if (const mcl_status s = mcl_kld_begin(ctx)) return s;
+  struct Block { uint64_t pos, cnt, offset, mine; };  // offset: of this rank's slice in d_cand_states (particles)
+  std::vector<Block> blocks;
+  MCL_HIP(ctx, ctx->d_cand_states.ensure(4 * (max_p / world + 66)));
+  uint64_t pos = 0, block = std::max<uint64_t>(min_p + 1, 8192ull * world), held = 0, n_out = max_p;
+  while (pos < max_p) {
+    const uint64_t cnt = std::min(block, max_p - pos);
+    uint64_t lo, m;
+    shard_bounds(cnt, world, rank, &lo, &m);
+    if (const mcl_status s = sharded_draw(ctx, random_state_probability, total, d_intervals, pos + lo, m)) return s;
+    const uint64_t width = (cnt + world - 1) / world, rem = cnt % world;
+    MCL_HIP(ctx, ctx->d_cand_hashes.ensure(width));
+    MCL_HIP(ctx, ctx->d_block_hashes.ensure(2 * world * width));
+    if (m < width) MCL_HIP(ctx, hipMemsetAsync(ctx->d_cand_hashes.ptr + m, 0, (width - m) * sizeof(unsigned long long), ctx->stream));
+    if (const mcl_status s = mcl_finish_candidates(ctx, ctx->step, pos + lo, m, ctx->d_replies_in.ptr, ctx->d_route_order.ptr, ctx->d_targets.ptr,
+                                                   ctx->d_cand_states.ptr + 4 * held, reinterpret_cast<uint64_t*>(ctx->d_cand_hashes.ptr))) return s;
+    unsigned long long* gathered = ctx->d_block_hashes.ptr;
+    if (const mcl_status s = comm_gather(ctx, ctx->d_cand_hashes.ptr, gathered, width * sizeof(unsigned long long))) return s;
+    const unsigned long long* in_order = gathered;
+    if (rem) {  // ranks >= rem hold one candidate less: their rows lose the padding
+      unsigned long long* compact = gathered + static_cast<size_t>(world) * width;
+      uint64_t at = 0;
+      for (uint32_t r = 0; r < world; ++r) {
+        const uint64_t have = r < rem ? width : width - 1;
+        if (have) MCL_HIP(ctx, hipMemcpyAsync(compact + at, gathered + static_cast<size_t>(r) * width, have * sizeof(unsigned long long),
+                                              hipMemcpyDeviceToDevice, ctx->stream));
+        at += have;
+      }
+      in_order = compact;
+    }
+    blocks.push_back(Block{pos, cnt, held, m});
+    held += m;
+    uint64_t first_fail = ~0ull;
+    if (const mcl_status s = mcl_kld_feed(ctx, reinterpret_cast<const uint64_t*>(in_order), cnt, &first_fail)) return s;
+    if (first_fail != ~0ull) {
+      n_out = first_fail;  // the first candidate failing the predicate is dropped (take_while)
+      break;
+    }
+    pos += cnt;
+    block *= 2;
+  }
+  n_out = std::min(n_out, max_p);  // | take(max)
+  // re-balance: [0, n_out) becomes contiguous shards; what a rank receives from a block is one contiguous run of its new shard
+  uint64_t new_first, new_n;
+  shard_bounds(n_out, world, rank, &new_first, &new_n);
+  MCL_HIP(ctx, ctx->d_new_shard.ensure(std::max<uint64_t>(4 * new_n, 4)));
+  auto overlap = [](uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) {
+    const uint64_t lo = std::max(a0, b0), hi = std::min(a1, b1);
+    return hi > lo ? hi - lo : 0;
+  };
+  std::vector<uint64_t> send(world), recv(world);
+  for (const Block& b : blocks) {
+    if (b.pos >= n_out) break;
+    uint64_t received = 0;
+    for (uint32_t q = 0; q < world; ++q) {
+      uint64_t q_lo, q_m, span_first, span_n;
+      shard_bounds(b.cnt, world, q, &q_lo, &q_m);
+      shard_bounds(n_out, world, q, &span_first, &span_n);
+      uint64_t my_lo, my_m;
+      shard_bounds(b.cnt, world, rank, &my_lo, &my_m);
+      send[q] = overlap(b.pos + my_lo, std::min(b.pos + my_lo + my_m, n_out), span_first, span_first + span_n) * 4 * sizeof(double);
+      recv[q] = overlap(b.pos + q_lo, std::min(b.pos + q_lo + q_m, n_out), new_first, new_first + new_n) * 4 * sizeof(double);
+      received += recv[q];
+    }
+    const uint64_t out0 = std::max(b.pos, new_first) - new_first;
+    if (const mcl_status s = comm_exchange(ctx, ctx->d_cand_states.ptr + 4 * b.offset, send.data(),
+                                           ctx->d_new_shard.ptr + 4 * std::min(out0, new_n), recv.data())) return s;
+    (void)received;
+  }
+  if (const mcl_status s = mcl_load_shard(ctx, ctx->d_new_shard.ptr, new_n, new_first)) return s;
+  *n_out_total = n_out;
+  return MCL_OK;
+}
+
 // beluga::Amcl::update (amcl_core.hpp:165-201) over the sharded set; same statements as mcl_update, with the exchanges of
 // include/beluga_mcl.h ("Particle shards") between them.  Every rank takes the same decisions: they depend on the control
 // action (identical inputs) and on gathered sums (identical values, added in rank order everywhere).
@@ -1058,12 +1191,30 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
                           mcl_update_info* info) {
   const mcl_amcl_params& ap = ctx->cfg.amcl;
   const uint32_t world = ctx->comm_world, rank = ctx->comm_rank;
-  const uint64_t n_total = ap.max_particles;
-  if (ap.min_particles < ap.max_particles)
-    return fail(ctx, MCL_ERR_UNSUPPORTED, "sharded mcl_update handles a fixed particle count (min_particles >= max_particles); the KLD-adaptive "
-                                          "cut over shards goes through the stage-level entry points");
+  const bool adaptive = ap.min_particles < ap.max_particles;
+  if (adaptive && ap.max_particles >= 0xFFFFFFFFull) return fail(ctx, MCL_ERR_UNSUPPORTED, "max_particles too large for KLD resampling");
   if (ctx->estimate_kind != 0) return fail(ctx, MCL_ERR_UNSUPPORTED, "sharded mcl_update returns beluga::estimate");
   if (const mcl_status s = comm_scratch(ctx)) return s;
+  if (ctx->global_n_unknown) {  // shards loaded by the caller: total = sum of the counts, this shard starts behind the ranks before it
+    long long* d_counts = ctx->d_comm_i64.ptr;
+    long long mine = static_cast<long long>(ctx->n);
+    MCL_HIP(ctx, hipMemcpyAsync(d_counts, &mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (mine is a local)
+    if (const mcl_status s = comm_gather(ctx, d_counts, d_counts + world, sizeof(long long))) return s;
+    long long* h_counts = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + 9));
+    MCL_HIP(ctx, hipMemcpyAsync(h_counts, d_counts + world, world * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t sum = 0, before = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+      if (r < rank) before += static_cast<uint64_t>(h_counts[r]);
+      sum += static_cast<uint64_t>(h_counts[r]);
+    }
+    ctx->global_n = sum;
+    ctx->cfg.shard_offset = before;
+    ctx->global_n_unknown = false;
+  }
+  const uint64_t n_total = ctx->global_n ? ctx->global_n : ap.max_particles;  // particles over all shards before this cycle's resampling
+  if (n_total == 0) return MCL_OK;
   if (const mcl_status s = stage_points(ctx, points_xy, num_points)) return s;
   if (!ctx->have_window) {
     ctx->window0 = ctx->window1 = pose;
@@ -1078,8 +1229,6 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
   double* d_gather_stats = d_gather_sums + world;      // [world][3]
   double* d_intervals = d_gather_stats + 3 * world;    // ends[world], offsets[world]
   double* d_gather_est = d_intervals + 2 * world;      // [world][9]
-  long long* d_counts = ctx->d_comm_i64.ptr;           // [world]
-  long long* d_all_counts = d_counts + world;          // [world][world]
   double* h = ctx->h_comm;
 
   bool keys_ready = false;
@@ -1142,36 +1291,15 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
     }
     const double total = run;
     MCL_HIP(ctx, hipMemcpyAsync(d_intervals, up, 2 * world * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    const uint64_t m = ctx->n, first_slot = ctx->cfg.shard_offset;
-    MCL_HIP(ctx, ctx->d_targets.ensure(m));
-    MCL_HIP(ctx, ctx->d_send_targets.ensure(m));
-    MCL_HIP(ctx, ctx->d_route_order.ensure(m));
-    MCL_HIP(ctx, ctx->d_replies_in.ensure(4 * m));
-    if (const mcl_status s = mcl_resample_targets(ctx, ctx->step, random_state_probability, total, first_slot, m, ctx->d_targets.ptr)) return s;
-    if (const mcl_status s = mcl_route_targets(ctx, ctx->d_targets.ptr, m, d_intervals, d_intervals + world, world, rank, ctx->d_send_targets.ptr,
-                                               ctx->d_route_order.ptr, reinterpret_cast<int64_t*>(d_counts))) return s;
-    if (const mcl_status s = comm_gather(ctx, d_counts, d_all_counts, world * sizeof(long long))) return s;  // counts[r][q]: r asks q
-    long long* h_counts = reinterpret_cast<long long*>(up + 2 * world);
-    MCL_HIP(ctx, hipMemcpyAsync(h_counts, d_all_counts, world * world * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<uint64_t> send_requests(world), recv_requests(world), send_replies(world), recv_replies(world);
-    uint64_t incoming = 0;
-    for (uint32_t q = 0; q < world; ++q) {
-      const uint64_t out = static_cast<uint64_t>(h_counts[rank * world + q]), in = static_cast<uint64_t>(h_counts[q * world + rank]);
-      send_requests[q] = out * sizeof(double);
-      recv_requests[q] = in * sizeof(double);
-      send_replies[q] = in * 4 * sizeof(double);
-      recv_replies[q] = out * 4 * sizeof(double);
-      incoming += in;
+    if (adaptive) {
+      uint64_t kept = 0;
+      if (const mcl_status s = sharded_resample_kld(ctx, random_state_probability, total, d_intervals, &kept)) return s;
+      ctx->global_n = kept;
+    } else {
+      const uint64_t m = ctx->n, first_slot = ctx->cfg.shard_offset;
+      if (const mcl_status s = sharded_draw(ctx, random_state_probability, total, d_intervals, first_slot, m)) return s;
+      if (const mcl_status s = mcl_commit_routed(ctx, ctx->step, first_slot, m, ctx->d_replies_in.ptr, ctx->d_route_order.ptr, ctx->d_targets.ptr)) return s;
     }
-    MCL_HIP(ctx, ctx->d_requests_in.ensure(std::max<uint64_t>(incoming, 1)));
-    MCL_HIP(ctx, ctx->d_replies_out.ensure(std::max<uint64_t>(4 * incoming, 4)));
-    if (const mcl_status s = comm_exchange(ctx, ctx->d_send_targets.ptr, send_requests.data(), ctx->d_requests_in.ptr, recv_requests.data())) return s;
-    if (incoming) {
-      if (const mcl_status s = mcl_serve_requests(ctx, ctx->d_requests_in.ptr, incoming, ctx->d_replies_out.ptr)) return s;
-    }
-    if (const mcl_status s = comm_exchange(ctx, ctx->d_replies_out.ptr, send_replies.data(), ctx->d_replies_in.ptr, recv_replies.data())) return s;
-    if (const mcl_status s = mcl_commit_routed(ctx, ctx->step, first_slot, m, ctx->d_replies_in.ptr, ctx->d_route_order.ptr, ctx->d_targets.ptr)) return s;
     stage_end(ctx, MCL_STAGE_RESAMPLE);
   }
   ctx->force_update = false;  // :199
@@ -1200,7 +1328,7 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
   if (info) {
     info->updated = 1;
     info->resampled = do_resampling ? 1 : 0;
-    info->num_particles = n_total;
+    info->num_particles = ctx->global_n ? ctx->global_n : ap.max_particles;
     info->weight_sum = weight_sum;
     info->effective_sample_size = ess;
     info->random_state_probability = random_state_probability;
@@ -1424,6 +1552,10 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_replies_out.release();
   ctx->d_replies_in.release();
   ctx->d_route_order.release();
+  ctx->d_cand_states.release();
+  ctx->d_new_shard.release();
+  ctx->d_cand_hashes.release();
+  ctx->d_block_hashes.release();
   if (ctx->h_points) (void)hipHostFree(ctx->h_points);
   if (ctx->points_event) (void)hipEventDestroy(ctx->points_event);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
@@ -1532,6 +1664,8 @@ mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], con
   launch_init_normal(ctx->stream, ctx->cur(), n, mean_xytheta, T, ctx->cfg.seed, ctx->cfg.shard_offset);
   MCL_HIP(ctx, hipGetLastError());
   ctx->n = n;
+  ctx->global_n = 0;  // (shards: every rank holds its share of max_particles again)
+  ctx->global_n_unknown = false;
   ctx->force_update = true;  // amcl_core.hpp:136
   for (int k = 0; k < 3; ++k) {
     ctx->cloud_mean[k] = mean_xytheta[k];
@@ -1555,6 +1689,7 @@ mcl_status mcl_set_particles(mcl_ctx* ctx, const double* states, const double* w
     MCL_HIP(ctx, hipMemcpy(ctx->cur().w, weights, n * sizeof(double), hipMemcpyHostToDevice));
   }
   ctx->n = n;
+  ctx->global_n_unknown = ctx->have_comm && ctx->comm_world > 1;  // a shard loaded by the caller: the ranks compare notes first
   ctx->force_update = true;
   ctx->have_cloud_estimate = false;  // the ordering falls back to a bounding-box pass until the next estimate
   patch_totals(ctx, &ctx->patch_seen_planned, &ctx->patch_seen_through);  // (as in mcl_initialize_normal)
@@ -2120,6 +2255,8 @@ mcl_status mcl_initialize_from_map(mcl_ctx* ctx) {
                        FreeCells{ctx->d_free.ptr, ctx->n_free});
   MCL_HIP(ctx, hipGetLastError());
   ctx->n = n;
+  ctx->global_n = 0;
+  ctx->global_n_unknown = false;
   ctx->force_update = true;  // beluga_ros/include/beluga_ros/amcl.hpp:197
   // the set covers the map: centre of the grid, spans of its extent, every heading
   const double hx = 0.5 * ctx->W * ctx->resolution, hy = 0.5 * ctx->H * ctx->resolution;

@@ -261,8 +261,12 @@ mcl_status mcl_sample_particle_cloud(mcl_ctx* ctx, uint64_t size, uint32_t draw_
  * intervals of the global CDF; every output slot's draw u_j * total (same counter-based stream as on one GPU) is routed to the
  * shard that owns it, which answers with the ancestor's state (views::sample | random_intersperse | actions::assign,
  * amcl_core.hpp:188-196); the estimate's nine sums are gathered and added in rank order.  Results do not depend on the
- * number of ranks beyond the rounding of these sums.  Fixed particle count only (min_particles >= max_particles): the
- * KLD-adaptive cut over shards is driven through the stage-level entry points below (beluga_amd/sharded.py).
+ * number of ranks beyond the rounding of these sums.  With min_particles < max_particles the resampling is KLD-adaptive over
+ * the shards as well (views::take_while_kld over the GLOBAL candidate stream, take_while_kld.hpp:72-88,112-137): candidates are
+ * drawn block by block through the same exchange, the spatial hashes of every block are all-gathered, every rank takes the same
+ * cut, and the kept candidates are re-balanced into contiguous shards - each context's shard_capacity must hold its share of
+ * max_particles; mcl_update_info.num_particles is the count over all shards.  (The same steps are available one by one through
+ * the stage-level entry points below: beluga_amd/sharded.py drives them over torch.distributed.)
  *
  * The collectives go through a transport: RCCL over xGMI (mcl_comm_attach_rccl; librccl.so is loaded at run time, the
  * library has no link-time dependency on it), or caller-supplied functions (mcl_comm_attach: MPI, a shared-memory exchange

@@ -4,7 +4,9 @@
 // the exchange logic runs on a one-GPU box.  On a node with several GPUs the only change is device_id = rank and
 // mcl_comm_attach_rccl (or a peer-to-peer transport) in place of the host-staged one.
 // Prints the estimates of the sharded filter and of a single-context filter on the same inputs; tests/test_cpp_facade.py
-// compares them.  usage: sharded_demo [ranks = 2] [particles = 60000] [cycles = 6]
+// compares them.  usage: sharded_demo [ranks = 2] [particles = 60000] [cycles = 6] [min_particles = particles]
+// With min_particles < particles the filter is KLD-adaptive: the number of particles changes from cycle to cycle, every rank
+// reports the same count, and it equals the single-context filter's.
 #include <hip/hip_runtime_api.h>
 
 #include <cmath>
@@ -109,11 +111,20 @@ struct Scenario {
   }
 };
 
+uint64_t g_min_particles = 0;  // 0: fixed size
+
 mcl_config make_config(uint64_t n_total, uint64_t shard_offset, uint64_t shard_capacity) {
   mcl_config cfg;
   mcl_default_config(&cfg);
   cfg.seed = 77;
   cfg.amcl.min_particles = cfg.amcl.max_particles = n_total;
+  if (g_min_particles) {
+    cfg.amcl.min_particles = g_min_particles;
+    cfg.amcl.kld_epsilon = 0.05;
+    cfg.amcl.kld_z = 3.0;
+    cfg.amcl.spatial_resolution_x = cfg.amcl.spatial_resolution_y = 0.2;
+    cfg.amcl.spatial_resolution_theta = 0.1;
+  }
   cfg.motion = mcl_diffdrive_params{0.1, 0.05, 0.1, 0.05, 0.01};
   cfg.lf = mcl_lf_params{2.0, 100.0, 0.5, 0.5, 0.2, 1, 0};
   cfg.shard_offset = shard_offset;
@@ -121,7 +132,7 @@ mcl_config make_config(uint64_t n_total, uint64_t shard_offset, uint64_t shard_c
   return cfg;
 }
 
-bool run_filter(const Scenario& sc, mcl_ctx* ctx, std::vector<mcl_estimate>* out) {
+bool run_filter(const Scenario& sc, mcl_ctx* ctx, std::vector<mcl_estimate>* out, std::vector<uint64_t>* counts = nullptr) {
   const double origin[4] = {1.0, 0.0, -2.0, -3.0};
   const int8_t traits[3] = {0, -1, 100};
   if (mcl_set_map(ctx, sc.cells.data(), sc.W, sc.H, 0.05, origin, traits) != MCL_OK) return false;
@@ -136,6 +147,7 @@ bool run_filter(const Scenario& sc, mcl_ctx* ctx, std::vector<mcl_estimate>* out
     }
     if (!info.updated || !info.resampled) return false;
     out->push_back(est);
+    if (counts) counts->push_back(info.num_particles);
   }
   return true;
 }
@@ -146,6 +158,8 @@ int main(int argc, char** argv) {
   const int ranks = argc > 1 ? std::atoi(argv[1]) : 2;
   const uint64_t n_total = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 60000;
   const int cycles = argc > 3 ? std::atoi(argv[3]) : 6;
+  g_min_particles = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 0;
+  if (g_min_particles >= n_total) g_min_particles = 0;
   const Scenario sc(cycles);
 
   mcl_ctx* single = nullptr;
@@ -155,7 +169,8 @@ int main(int argc, char** argv) {
     return 3;
   }
   std::vector<mcl_estimate> reference;
-  if (!run_filter(sc, single, &reference)) return 4;
+  std::vector<uint64_t> reference_counts;
+  if (!run_filter(sc, single, &reference, &reference_counts)) return 4;
   std::vector<double> ref_states(4 * n_total), ref_weights(n_total);
   uint64_t got = 0;
   mcl_get_particles(single, ref_states.data(), ref_weights.data(), n_total, &got);
@@ -165,6 +180,7 @@ int main(int argc, char** argv) {
   std::vector<Endpoint> endpoints(ranks);
   std::vector<std::vector<mcl_estimate>> estimates(ranks);
   std::vector<std::vector<double>> shard_states(ranks);
+  std::vector<std::vector<uint64_t>> counts(ranks);
   std::vector<int> status(ranks, 0);
   std::vector<std::thread> threads;
   for (int r = 0; r < ranks; ++r) {
@@ -180,12 +196,14 @@ int main(int argc, char** argv) {
       }
       const mcl_transport transport{&endpoints[r], all_gather, all_to_all};
       if (mcl_comm_attach(ctx, static_cast<uint32_t>(r), static_cast<uint32_t>(ranks), &transport) != MCL_OK) status[r] = 2;
-      if (!status[r] && !run_filter(sc, ctx, &estimates[r])) status[r] = 3;
+      if (!status[r] && !run_filter(sc, ctx, &estimates[r], &counts[r])) status[r] = 3;
       if (!status[r]) {
-        shard_states[r].resize(4 * mine);
-        std::vector<double> w(mine);
+        uint64_t held = 0;
+        if (mcl_num_particles(ctx, &held) != MCL_OK || held > mine || (!g_min_particles && held != mine)) status[r] = 4;
+        shard_states[r].resize(4 * held);
+        std::vector<double> w(held);
         uint64_t n = 0;
-        if (mcl_get_particles(ctx, shard_states[r].data(), w.data(), mine, &n) != MCL_OK || n != mine) status[r] = 4;
+        if (!status[r] && (mcl_get_particles(ctx, shard_states[r].data(), w.data(), held, &n) != MCL_OK || n != held)) status[r] = 4;
       }
       mcl_destroy(ctx);
     });
@@ -207,6 +225,17 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 4; ++k) worst_pose = std::max(worst_pose, std::abs(estimates[0][c].pose[k] - reference[c].pose[k]));
     for (int k = 0; k < 9; ++k) worst_cov = std::max(worst_cov, std::abs(estimates[0][c].covariance[k] - reference[c].covariance[k]));
   }
+  // the particle counts (KLD-adaptive filters: an integer result, the same on every rank and in the single-context filter)
+  uint64_t count_mismatches = 0;
+  for (int c = 0; c < cycles; ++c)
+    for (int r = 0; r < ranks; ++r)
+      if (counts[r][c] != reference_counts[c]) ++count_mismatches;
+  uint64_t total_held = 0;
+  for (int r = 0; r < ranks; ++r) total_held += shard_states[r].size() / 4;
+  std::printf("particle_counts");
+  for (int c = 0; c < cycles; ++c) std::printf(" %llu", static_cast<unsigned long long>(reference_counts[c]));
+  std::printf("\ncount_mismatches %llu\nparticles_held %llu %llu\n", static_cast<unsigned long long>(count_mismatches),
+              static_cast<unsigned long long>(total_held), static_cast<unsigned long long>(got));
   // the sharded set, concatenated in rank order, against the single-context set
   uint64_t different = 0, at = 0;
   for (int r = 0; r < ranks; ++r)

@@ -74,6 +74,27 @@ def test_sharded_cycle_inside_the_library_matches_one_context(sharded_demo, rank
     assert int(kv["particles_that_differ"][0]) <= max(5, particles // 10000), out.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,max_particles,min_particles", [(2, 60000, 2000), (3, 100001, 500), (4, 40000, 39000)])
+def test_sharded_kld_cycle_inside_the_library_matches_one_context(sharded_demo, ranks, max_particles, min_particles):
+    """The KLD-adaptive cycle over R shards inside the library (candidate blocks drawn through the ancestor exchange, hashes of
+    every block all-gathered, the same take_while_kld cut on every rank, kept candidates re-balanced into contiguous shards):
+    the particle count of every cycle equals the single-context filter's on every rank (an integer result: exact), the
+    estimates agree up to the rounding of the gathered sums, the sets are the same particles up to CDF-boundary draws."""
+    out = subprocess.run([sharded_demo, str(ranks), str(max_particles), "6", str(min_particles)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    kv = {line.split()[0]: line.split()[1:] for line in out.stdout.splitlines()}
+    assert kv["count_mismatches"] == ["0"], out.stdout
+    counts = [int(v) for v in kv["particle_counts"]]
+    assert all(min_particles <= c <= max_particles for c in counts), out.stdout
+    assert len(set(counts)) > 1 or counts[0] == min_particles, out.stdout  # the cut moves, or sits at the floor
+    held, single = (int(v) for v in kv["particles_held"])
+    assert held == single == counts[-1], out.stdout
+    pose_diff, cov_diff = (float(v) for v in kv["estimate_max_abs_difference"])
+    assert pose_diff < 1e-9 and cov_diff < 1e-9, out.stdout
+    assert int(kv["particles_that_differ"][0]) <= max(5, max_particles // 10000), out.stdout
+
+
 def test_node_bodies_compile_and_fail_loudly_without_gpu(node_bodies):
     import torch
     if torch.cuda.is_available():
