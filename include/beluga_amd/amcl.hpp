@@ -259,6 +259,19 @@ class ValueGrid2 {
   double resolution_{1.0};
 };
 
+/// A contiguous shard of one logical filter's particles (include/beluga_mcl.h, "Particle shards"): one `Amcl` per GPU, every
+/// instance with its shard, the same map, control actions and scans; after `attach` / `attach_rccl`, `update()` runs the cycle
+/// over all shards (fixed-size and KLD-adaptive) and every instance returns the same estimate.  `particles()` is the shard.
+struct Shard {
+  std::uint64_t offset{0};    ///< global index of the shard's first particle
+  std::uint64_t capacity{0};  ///< particles the shard can hold (its share of max_particles); 0: not sharded
+  /// The balanced split the library itself uses when it re-balances: rank `rank` of `world`.
+  static Shard of(std::uint64_t max_particles, unsigned rank, unsigned world) {
+    const std::uint64_t base = max_particles / world, rem = max_particles % world;
+    return Shard{rank * base + (rank < rem ? rank : rem), base + (rank < rem ? 1u : 0u)};
+  }
+};
+
 class Amcl {
  public:
   using state_type = SE2d;
@@ -269,11 +282,13 @@ class Amcl {
   /// the likelihood field with the device's exact distance transform instead of the reference's wavefront on the host.
   Amcl(const OccupancyGridView& map, const MotionModelParam& motion, const SensorModelParam& sensor,
        const AmclParams& params = AmclParams{}, std::uint64_t seed = 0, int device = 0,
-       const std::vector<std::pair<std::string, std::int64_t>>& options = {}) {
+       const std::vector<std::pair<std::string, std::int64_t>>& options = {}, const Shard& shard = Shard{}) {
     mcl_config cfg;
     mcl_default_config(&cfg);
     cfg.device_id = device;
     cfg.seed = seed;
+    cfg.shard_offset = shard.offset;
+    cfg.shard_capacity = shard.capacity;
     cfg.amcl.update_min_d = params.update_min_d;
     cfg.amcl.update_min_a = params.update_min_a;
     cfg.amcl.resample_interval = params.resample_interval;
@@ -422,6 +437,20 @@ class Amcl {
 
   /// Force a manual update of the particles on the next iteration of the filter (amcl_core.hpp:204).
   void force_update() { check(mcl_force_update(ctx_)); }
+
+  /// Joins the communicator of a sharded filter (this instance was constructed with its `Shard`).  `transport`: the two
+  /// collectives of the exchange over device buffers (MPI, threads of one process, ...); copied, its `user` must outlive this.
+  void attach(unsigned rank, unsigned world, const mcl_transport& transport) { check(mcl_comm_attach(ctx_, rank, world, &transport)); }
+  /// The same over RCCL / xGMI (librccl.so is loaded at run time): rank 0 calls rccl_unique_id() and hands the 128 bytes to
+  /// the other ranks by whatever means the host has.
+  void attach_rccl(const std::array<std::uint8_t, 128>& id, unsigned rank, unsigned world) {
+    check(mcl_comm_attach_rccl(ctx_, id.data(), rank, world));
+  }
+  [[nodiscard]] static std::array<std::uint8_t, 128> rccl_unique_id() {
+    std::array<std::uint8_t, 128> id{};
+    if (mcl_comm_unique_id(id.data()) != MCL_OK) throw std::runtime_error(std::string("beluga_amd::Amcl: ") + mcl_last_error(nullptr));
+    return id;
+  }
 
   /// The pose sample behind beluga_ros::assign_particle_cloud(particles, size, PoseArray&)
   /// (beluga_ros/include/beluga_ros/particle_cloud.hpp:131-149): `size` states drawn with probability proportional to the

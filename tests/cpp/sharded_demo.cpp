@@ -18,6 +18,7 @@
 #include <thread>
 #include <vector>
 
+#include "beluga_amd/amcl.hpp"
 #include "beluga_mcl.h"
 
 namespace {
@@ -152,6 +153,69 @@ bool run_filter(const Scenario& sc, mcl_ctx* ctx, std::vector<mcl_estimate>* out
   return true;
 }
 
+// The same sharded filter through the C++ facade (include/beluga_amd/amcl.hpp): one beluga_amd::Amcl per rank, constructed with
+// its Shard, attached to the exchange; every rank's estimates, cycle by cycle.
+bool run_facade_shards(const Scenario& sc, int ranks, uint64_t n_total, std::vector<std::vector<mcl_estimate>>* out) {
+  using namespace beluga_amd;
+  Exchange exchange(ranks);
+  std::vector<Endpoint> endpoints(ranks);
+  std::vector<int> failed(ranks, 0);
+  std::vector<std::thread> threads;
+  out->assign(ranks, {});
+  for (int r = 0; r < ranks; ++r) {
+    endpoints[r] = Endpoint{&exchange, r};
+    threads.emplace_back([&, r] {
+      try {
+        OccupancyGridView map;
+        map.cells = sc.cells.data();
+        map.width = sc.W;
+        map.height = sc.H;
+        map.resolution = 0.05;
+        map.origin = SE2d{0.0, -2.0, -3.0};
+        AmclParams params;
+        params.min_particles = params.max_particles = n_total;
+        if (g_min_particles) {
+          params.min_particles = g_min_particles;
+          params.kld_epsilon = 0.05;
+          params.kld_z = 3.0;
+          params.spatial_resolution_x = params.spatial_resolution_y = 0.2;
+          params.spatial_resolution_theta = 0.1;
+        }
+        LikelihoodFieldModelParam lf;
+        lf.max_obstacle_distance = 2.0;
+        lf.max_laser_distance = 100.0;
+        lf.model_unknown_space = true;
+        Amcl filter{map, DifferentialDriveModelParam{0.1, 0.05, 0.1, 0.05}, lf, params, /*seed=*/77, /*device=*/0, {},
+                    Shard::of(n_total, static_cast<unsigned>(r), static_cast<unsigned>(ranks))};
+        filter.attach(static_cast<unsigned>(r), static_cast<unsigned>(ranks), mcl_transport{&endpoints[r], all_gather, all_to_all});
+        filter.initialize(SE2d{0.2, 1.0, 1.0}, Matrix3d{0.09, 0, 0, 0, 0.09, 0, 0, 0, 0.02});
+        for (size_t c = 0; c < sc.scans.size(); ++c) {
+          Amcl::measurement_type scan;
+          for (size_t b = 0; b + 1 < sc.scans[c].size(); b += 2) scan.emplace_back(sc.scans[c][b], sc.scans[c][b + 1]);
+          SE2d control;
+          std::memcpy(control.data(), sc.controls[c].data(), 4 * sizeof(double));
+          const auto est = filter.update(control, scan);
+          if (!est) {
+            failed[r] = 1;
+            return;
+          }
+          mcl_estimate e{};
+          std::memcpy(e.pose, est->first.data(), 4 * sizeof(double));
+          std::memcpy(e.covariance, est->second.data(), 9 * sizeof(double));
+          (*out)[r].push_back(e);
+        }
+      } catch (const std::exception& e) {
+        std::printf("facade_error %s\n", e.what());
+        failed[r] = 1;
+      }
+    });
+  }
+  for (auto& t : threads) t.join();
+  for (int r = 0; r < ranks; ++r)
+    if (failed[r]) return false;
+  return true;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -241,6 +305,16 @@ int main(int argc, char** argv) {
   for (int r = 0; r < ranks; ++r)
     for (size_t i = 0; i < shard_states[r].size() / 4; ++i, ++at)
       if (std::memcmp(&shard_states[r][4 * i], &ref_states[4 * at], 4 * sizeof(double)) != 0) ++different;
+  // the facade's shards against the C ABI's: the same library calls underneath, so the same bits
+  std::vector<std::vector<mcl_estimate>> facade;
+  if (!run_facade_shards(sc, ranks, n_total, &facade)) return 7;
+  uint64_t facade_mismatches = 0;
+  for (int c = 0; c < cycles; ++c)
+    for (int r = 0; r < ranks; ++r)
+      if (std::memcmp(facade[r][c].pose, estimates[0][c].pose, sizeof(estimates[0][c].pose)) != 0 ||
+          std::memcmp(facade[r][c].covariance, estimates[0][c].covariance, sizeof(estimates[0][c].covariance)) != 0)
+        ++facade_mismatches;
+  std::printf("facade_mismatches %llu\n", static_cast<unsigned long long>(facade_mismatches));
   std::printf("ranks %d particles %llu cycles %d\n", ranks, static_cast<unsigned long long>(n_total), cycles);
   std::printf("estimate_max_abs_difference %.3e %.3e\n", worst_pose, worst_cov);
   std::printf("particles_that_differ %llu\n", static_cast<unsigned long long>(different));

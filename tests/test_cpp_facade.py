@@ -72,6 +72,7 @@ def test_sharded_cycle_inside_the_library_matches_one_context(sharded_demo, rank
     pose_diff, cov_diff = (float(v) for v in kv["estimate_max_abs_difference"])
     assert pose_diff < 1e-9 and cov_diff < 1e-9, out.stdout
     assert int(kv["particles_that_differ"][0]) <= max(5, particles // 10000), out.stdout
+    assert kv["facade_mismatches"] == ["0"], out.stdout  # beluga_amd::Amcl with a Shard + attach(): the same bits
 
 
 @pytest.mark.gpu
@@ -93,6 +94,7 @@ def test_sharded_kld_cycle_inside_the_library_matches_one_context(sharded_demo, 
     pose_diff, cov_diff = (float(v) for v in kv["estimate_max_abs_difference"])
     assert pose_diff < 1e-9 and cov_diff < 1e-9, out.stdout
     assert int(kv["particles_that_differ"][0]) <= max(5, max_particles // 10000), out.stdout
+    assert kv["facade_mismatches"] == ["0"], out.stdout
 
 
 def test_node_bodies_compile_and_fail_loudly_without_gpu(node_bodies):
