@@ -656,8 +656,9 @@ void decide_lf_mode(mcl_ctx* ctx) {
 }
 
 bool wants_ordering(const mcl_ctx* ctx) {
-  if (ctx->n < static_cast<uint64_t>(ctx->tuning.sort_min_particles) || ctx->n >= (1ull << 32)) return false;
-  if (ctx->cfg.sensor_kind == MCL_SENSOR_BEAM) return true;
+  if (ctx->n >= (1ull << 32)) return false;
+  if (ctx->cfg.sensor_kind == MCL_SENSOR_BEAM) return ctx->n >= static_cast<uint64_t>(ctx->tuning.beam_sort_min_particles);
+  if (ctx->n < static_cast<uint64_t>(ctx->tuning.sort_min_particles)) return false;
   if (ctx->lf_mode.decided && ctx->lf_mode.beams) return false;
   return ctx->tuning.lf_variant == kLfSortedLanes && !(lf_set_is_small(ctx) && ctx->pal_count != 0 && ctx->tuning.lf_table == 0);
 }
@@ -1484,7 +1485,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "field_build"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2338,6 +2339,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "device_policy") t.device_policy = value ? 1 : 0;
   else if (key == "field_build") t.field_build = value ? 1 : 0;
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
+  else if (key == "beam_sort_min_particles") t.beam_sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "mcl_set_option: unknown option " + key);
   return MCL_OK;
 }

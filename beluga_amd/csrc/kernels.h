@@ -118,7 +118,9 @@ struct Tuning {
                                     // 1 = wave per particle / lane per beam (k_reweight_lf_beams, no ordering pass; measured
                                     // 20 % slower at 1M x 1080: profiles/r02_dispersed_study.txt)
   int device_policy = 1;            // recovery estimator on the device when the cycle has no host-side decision
-  int sort_min_particles = 16384;   // below this the ordering passes cost more than they save
+  int sort_min_particles = 16384;   // below this the ordering passes cost more than they save (likelihood-field models)
+  int beam_sort_min_particles = 16384;  // beam model: the ordered kernel (LDS bit window, scan segments) from here on; below, a wave per
+                                       // particle over the whole-grid maps (measured crossover: 12K particles at 180 beams, 28K at 1080)
   int lf_small_particles = 65536;   // likelihood-field sets below this: a wave per particle with the lanes over the beams, no ordering
                                     // (measured: 25 % faster than the ordered kernels at 20K particles, 10 % at 50K, 12 % slower at 100K)
   int field_build = 0;              // mcl_set_map: 0 = host wavefront (bit-identical to the reference), 1 = exact EDT on the device

@@ -1030,13 +1030,14 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
 }
 
 __global__ __launch_bounds__(kBlock) void k_lf_combine(double* __restrict__ w, uint64_t n, const uint32_t* __restrict__ perm,
-                                                       const double* __restrict__ partial, uint32_t segments, int prob) {
+                                                       const double* __restrict__ partial, uint32_t segments, int mode) {
+  // mode 0: w *= 1 + sum (likelihood field), 1: w *= exp(sum) (its log form), 2: w *= sum (beam model)
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (t >= n) return;
-  double acc = prob ? 0.0 : 1.0;
+  double acc = mode == 0 ? 1.0 : 0.0;
   for (uint32_t s = 0; s < segments; ++s) acc += partial[static_cast<size_t>(s) * n + t];
   const uint32_t i = perm[t];
-  w[i] = w[i] * (prob ? exp(acc) : acc);
+  w[i] = w[i] * (mode == 1 ? exp(acc) : acc);
 }
 
 // -- spatial ordering of the particles --------------------------------------------------------------
@@ -1867,6 +1868,22 @@ __device__ __forceinline__ double cast_ray_window(const GridView& g, const BitWi
   return walk_result(g, r, false, max_range, steps);
 }
 
+// The cast over the whole-grid maps alone (no LDS window): small sets, one wave per particle.
+__device__ __forceinline__ double cast_ray_grid(const GridView& g, const BlockMaps& grid_maps, int sx, int sy, int fx, int fy, double max_range,
+                                                unsigned long long& steps) {
+  RayWalk r = walk_begin(g, sx, sy, fx, fy);
+  int k = 0, hit_k = -1, error = r.error;
+  if (r.last >= 0) {
+    int gx = sx, gy = sy;
+    walk_blocks_any(grid_maps, r, gx, gy, error, k, hit_k, r.last);
+    if (hit_k >= 0) {
+      walk_seek(r, hit_k, 0);
+      return walk_result(g, r, true, max_range, steps);
+    }
+  }
+  return walk_result(g, r, false, max_range, steps);
+}
+
 // What beam_model.hpp:110-147 computes from the scan point alone (the same for every particle): the measured range, the
 // far end of the trace in the sensor frame (raycasting.hpp:78-88: bearing * max_range), and the terms of the mixture that do
 // not depend on the expected range.  The ordered kernel reads them from a table (k_beam_points), one entry per beam.
@@ -1924,7 +1941,7 @@ __device__ __forceinline__ double beam_term(const GridView& g, const BeamModel& 
 }
 
 // Variant A: one wavefront per particle, one lane per beam (small particle sets).
-__global__ __launch_bounds__(kBlock) void k_reweight_beam(Particles p, uint64_t n, GridView g, BeamModel m,
+__global__ __launch_bounds__(kBlock) void k_reweight_beam(Particles p, uint64_t n, GridView g, BeamModel m, NonFreeBits bits,
                                                           const double2* __restrict__ pts, uint32_t B, unsigned long long* d_steps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2* s_pts = reinterpret_cast<double2*>(smem);
@@ -1937,12 +1954,16 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam(Particles p, uint64_t 
   int sx, sy;
   cell_near(g, src.x, src.y, sx, sy);
   const double norm_hit = 1. / (sqrt(2. * kPi) * m.sigma_hit);
+  const BlockMaps grid_maps{bits.fine, static_cast<int>(bits.words_per_row), static_cast<int>(g.W) - 1, static_cast<int>(g.H) - 1, bits.rows,
+                            bits.columns, static_cast<int>(bits.row_words), static_cast<int>(bits.column_words), bits.dist,
+                            static_cast<int>(bits.dist_stride)};
   double acc = 0.0;
   unsigned long long steps = 0;
   for (uint32_t b = lane; b < B; b += kWave) {
     const double2 pt = s_pts[b];
-    acc += beam_term(g, m, norm_hit, src, beam_point(m, pt.x, pt.y),
-                     [&](int fx, int fy) { return cast_ray(g, sx, sy, fx, fy, m.beam_max_range, steps); });
+    acc += beam_term(g, m, norm_hit, src, beam_point(m, pt.x, pt.y), [&](int fx, int fy) {
+      return bits.fine ? cast_ray_grid(g, grid_maps, sx, sy, fx, fy, m.beam_max_range, steps) : cast_ray(g, sx, sy, fx, fy, m.beam_max_range, steps);
+    });
   }
   const double total = wave_sum_f64(acc);
   if (d_steps) {
@@ -1961,7 +1982,8 @@ constexpr int kBeamBlock = 1024;
 __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __restrict__ w, uint64_t n, GridView g, BeamModel m,
                                                                      NonFreeBits bits, const BeamPoint* __restrict__ pts,
                                                                      uint32_t B, const uint32_t* __restrict__ perm,
-                                                                     const double4* __restrict__ pose, unsigned long long* d_steps) {
+                                                                     const double4* __restrict__ pose, unsigned long long* d_steps,
+                                                                     double* __restrict__ partial, uint32_t beams_per_segment) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* win = reinterpret_cast<uint32_t*>(smem);
   const uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * kBeamBlock;
@@ -2017,10 +2039,15 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
       for (int q = 0; q < 32; ++q) bits |= ((coarse[(quarter * 32 + q) * kCoarseWords + (bx >> 5)] >> (bx & 31)) & 1u) << q;
       columns[cw] = bits;
     }
-    // block distance map of the window (blocks beyond it count as empty: the window walk never enters them)
+    // block distance map of the window: a copy of the whole grid's (the window's blocks are the grid's: x0 is a multiple of 32
+    // cells, y0 of 8); blocks outside the grid are never entered
     uint8_t* dist = reinterpret_cast<uint8_t*>(columns + kCoarse * kCoarseWords);
-    for (int blk = threadIdx.x; blk < kCoarse * kCoarse; blk += kBeamBlock)
-      dist[blk] = static_cast<uint8_t>(block_distance(coarse, kCoarseWords, kCoarse, blk % kCoarse, blk / kCoarse));
+    const int grid_block_columns = static_cast<int>((g.W + 7u) >> 3), grid_block_rows = static_cast<int>((g.H + 7u) >> 3);
+    for (int blk = threadIdx.x; blk < kCoarse * kCoarse; blk += kBeamBlock) {
+      const int gy = (bw.y0 >> 3) + blk / kCoarse, gx = (bw.x0 >> 3) + blk % kCoarse;
+      const bool inside = gy >= 0 && gy < grid_block_rows && gx >= 0 && gx < grid_block_columns;
+      dist[blk] = inside ? bits.dist[static_cast<size_t>(gy) * bits.dist_stride + gx] : static_cast<uint8_t>(kDistCap);
+    }
   }
   __syncthreads();
 
@@ -2031,7 +2058,11 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
   const double norm_hit = 1. / (sqrt(2. * kPi) * m.sigma_hit);
   double acc = 0.0;
   unsigned long long steps = 0;
-  for (uint32_t b = 0; b < B; ++b) {
+  // partial != nullptr (sets of fewer workgroups than CUs): blockIdx.y takes a contiguous segment of the scan, the segment's sum
+  // goes to partial[segment][t] and k_lf_combine adds the segments in order
+  const uint32_t b_begin = partial ? blockIdx.y * beams_per_segment : 0u;
+  const uint32_t b_end = partial ? (b_begin + beams_per_segment < B ? b_begin + beams_per_segment : B) : B;
+  for (uint32_t b = b_begin; b < b_end; ++b) {
     MCL_BEAM_STAT(0);  // a beam
     acc += beam_term(g, m, norm_hit, src, pts[b],
                      [&](int fx, int fy) { return cast_ray_window(g, bw, sx, sy, fx, fy, m.beam_max_range, steps); });
@@ -2041,7 +2072,10 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
     for (int o = 32; o > 0; o >>= 1) steps += __shfl_down(steps, o);
     if ((threadIdx.x & 63) == 0) atomicAdd(d_steps, steps);
   }
-  if (t < n) w[i] = w[i] * acc;
+  if (t < n) {
+    if (partial) partial[static_cast<size_t>(blockIdx.y) * n + t] = acc;
+    else w[i] = w[i] * acc;
+  }
 }
 
 // nonfree_bits: one bit per cell, row-major, words_per_row = ceil(W / 32) words per row.
@@ -3312,15 +3346,28 @@ void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, B
   if (n == 0 || B == 0) return;
   if (sorted && nonfree_bits) {
     const size_t lds = kBeamLds;
-    const dim3 grid(static_cast<unsigned>((n + kBeamBlock - 1) / kBeamBlock));
+    // One workgroup of 1024 particles per CU: below 256 workgroups the scan is split into segments (second grid dimension)
+    // until the chip is covered twice, and the segment sums are added in a second pass - same terms, fixed association.
+    const uint32_t groups = static_cast<uint32_t>((n + kBeamBlock - 1) / kBeamBlock);
+    uint32_t segments = 1;
+    if (sorted->partial && n < kLfSegmentedBelow && groups < 256) {
+      segments = std::min<uint32_t>((512 + groups - 1) / groups, kLfMaxSegments);
+      segments = std::max(1u, std::min(segments, B / 8));
+    }
+    const uint32_t per_segment = (B + segments - 1) / segments;
+    segments = (B + per_segment - 1) / per_segment;
+    double* partial = segments > 1 ? sorted->partial : nullptr;
     BeamPoint* table = reinterpret_cast<BeamPoint*>(d_beam_points);
     hipLaunchKernelGGL(k_beam_points, dim3(blocks_for(B)), dim3(kBlock), 0, st, d_points, B, m, table);
-    hipLaunchKernelGGL(k_reweight_beam_sorted, grid, dim3(kBeamBlock), lds, st, p.w, n, g, m,
-                       nonfree_layout(g.W, g.H, const_cast<uint32_t*>(nonfree_bits)), table, B, sorted->perm, p.pose, d_steps);
+    hipLaunchKernelGGL(k_reweight_beam_sorted, dim3(groups, segments), dim3(kBeamBlock), lds, st, p.w, n, g, m,
+                       nonfree_layout(g.W, g.H, const_cast<uint32_t*>(nonfree_bits)), table, B, sorted->perm, p.pose, d_steps, partial,
+                       per_segment);
+    if (segments > 1) hipLaunchKernelGGL(k_lf_combine, dim3(blocks_for(n)), dim3(kBlock), 0, st, p.w, n, sorted->perm, partial, segments, 2);
     return;
   }
   const dim3 grid(static_cast<unsigned>((n + (kBlock / kWave) - 1) / (kBlock / kWave)));
   hipLaunchKernelGGL(k_reweight_beam, grid, dim3(kBlock), static_cast<size_t>(B) * sizeof(double2), st, p, n, g, m,
+                     nonfree_bits ? nonfree_layout(g.W, g.H, const_cast<uint32_t*>(nonfree_bits)) : NonFreeBits{},
                      reinterpret_cast<const double2*>(d_points), B, d_steps);
 }
 

@@ -174,8 +174,10 @@ def test_reweight_lf_rotated_origin_and_empty_scan():
     f.close()
 
 
-@pytest.mark.parametrize("n,beams", [(777, 181), (20_001, 61)])  # wave-per-particle kernel / ordered-lanes kernel
+@pytest.mark.parametrize("n,beams", [(777, 181), (5_000, 181), (20_001, 61)])
 def test_reweight_beam_matches_oracle(n, beams):
+    """The wave-per-particle kernel over the whole-grid maps (777 particles), the ordered-lanes kernel with its scan split into
+    segments (5000 particles, forced below its threshold; 20 001 by default)."""
     grid = rooms_grid(300, 4)
     truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=2, clearance_cells=6)
     pts = make_scan(grid, truth, beams, max_range=10.0, fov=360.0)
@@ -183,6 +185,8 @@ def test_reweight_beam_matches_oracle(n, beams):
     states[:3, 2] += 50.0  # source cell outside the grid: no trace at all
     beam = BeamModelParam(beam_max_range=10.0)
     f = new_filter(grid, n, sensor=beam)
+    if n == 5_000:
+        f.set_option("beam_sort_min_particles", 0)
     f.set_particles(states, np.ones(n))
     f.reweight(pts)
     got = f.particles()[1]
@@ -234,6 +238,18 @@ def test_beam_walk_closed_forms_on_adversarial_maps(kind):
                                    threads=orc.max_threads(), return_steps=True)
     assert visited == steps
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-300)
+    f.close()
+    # the kernel of small sets (a wave per particle, the same closed forms over the whole-grid maps): the first 3000 particles
+    m = 3000
+    f = new_filter(grid, m, sensor=beam)
+    f.set_particles(states[:m], np.ones(m))
+    f.beam_cells_visited(reset=True)
+    f.reweight(pts)
+    got_small, visited_small = f.particles()[1], f.beam_cells_visited()
+    want_small, steps_small = orc.beam_weights(grid.cells, res, grid.origin, (0.5, 0.5, 0.05, 0.05, 0.2, 0.1, max_range), states[:m], pts,
+                                               threads=orc.max_threads(), return_steps=True)
+    assert visited_small == steps_small
+    np.testing.assert_allclose(got_small, want_small, rtol=1e-10, atol=1e-300)
     f.close()
 
 
