@@ -435,14 +435,16 @@ def main():
                 "avg_launch_ms": lf_avg_s * 1e3,
                 "launches": int(lf_count),
                 "launches_sampled_every": 4,
-                # What actually bounds it (profiles/r02_pmc_bench_1M.txt): 11 vector instructions per wave and beam - 4 v_fma_f64
-                # for the end-point, 1 for the exactness check, 2 for the LDS address, 2 to fetch and widen the palette address,
-                # 1 v_add_f64, the rest prologue - at 4 cycles each on 7 of the 8 waves of a workgroup (the eighth fetches the
-                # patches).  Groups of beams that do not fit a patch are gathered from global memory instead: those pay the
-                # texture-address pipe, 16 CU cycles per scattered 64-lane gather (profiles/r02_calib_gather_cost.txt).
-                "limiter": "vector instruction issue (VALU): ~11 instructions per wave-beam on 7/8 of the waves; gathered groups: texture-address pipe",
+                # What actually bounds it (profiles/r02_pmc_bench_1M.txt, r02_lf_series.txt): 10.2 vector instructions per wave and
+                # beam - 4 v_fma_f64 for the end-point, 1 for the exactness check, 2 for the LDS address, 1 v_add_f64, the rest
+                # prologue and gathered groups - at 4 cycles each on 7 of the 8 waves of a workgroup (the eighth fetches the
+                # patches).  Groups of beams that do not fit a patch are gathered from global memory instead: they pay the
+                # texture-address pipe (16 CU cycles per scattered 64-lane gather, profiles/r02_calib_gather_cost.txt) and their
+                # workgroup waits for them at its next barrier - 2.6x the cost of a patched group; the kernel's time follows
+                # their share (12-19 % in the first 20 cycles of a run, 2-4 % once the cloud has settled).
+                "limiter": "vector instruction issue (VALU): ~10 instructions per wave-beam on 7/8 of the waves; gathered groups (2.6x a patched one): texture-address pipe + barrier waits",
                 "groups_through_lds_patch": patch_fraction,
-                "valu_issue_floor_ms": n_local * BEAMS / 64 * 11 * 4 * (8 / 7) / (1024 * 2.4e9) * 1e3,
+                "valu_issue_floor_ms": n_local * BEAMS / 64 * 10.2 * 4 * (8 / 7) / (1024 * 2.4e9) * 1e3,
                 "ta_floor_ms_if_all_gathered": n_local * BEAMS / 64 * 16 / (256 * 2.4e9) * 1e3,
             },
         }
