@@ -295,6 +295,8 @@ struct mcl_ctx {
   uint64_t global_n{0};                     // particles of the logical filter over all shards (0: max_particles)
   bool global_n_unknown{false};             // the caller loaded this shard itself (mcl_set_particles): counts are gathered first
   double* h_comm{nullptr};                  // pinned staging for the exchange's host reads / uploads
+  unsigned char* h_cells{nullptr};          // cluster_based_estimate: the list of occupied cells in mapped pinned memory
+  unsigned char* hd_cells{nullptr};         // ... its device address
 
   // profiling: 0 = off, 1 = the sensor kernel only (two events per cycle), 2 = every stage
   int profile{0};
@@ -919,29 +921,69 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
   unsigned int* c_size = c_cluster + ctx->capacity;
   unsigned long long* c_key = ctx->d_cell_u64.ptr;
 
-  MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_keys.ptr, 0xFF, slots * sizeof(unsigned long long), ctx->stream));
-  MCL_HIP(ctx, hipMemsetAsync(ctx->d_table_first.ptr, 0xFF, slots * sizeof(unsigned int), ctx->stream));
-  MCL_HIP(ctx, hipMemsetAsync(t_wsum, 0, slots * sizeof(double), ctx->stream));
-  MCL_HIP(ctx, hipMemsetAsync(t_count, 0, slots * sizeof(unsigned int), ctx->stream));
-  MCL_HIP(ctx, hipMemsetAsync(t_cluster, 0xFF, slots * sizeof(unsigned int), ctx->stream));
-  MCL_HIP(ctx, hipMemsetAsync(c_size, 0, sizeof(unsigned int), ctx->stream));
+  // The occupied cells come to the host through a list in MAPPED pinned memory that the compaction kernel writes itself (a
+  // converged cloud has a few hundred cells): one synchronisation instead of seven.  A cloud with more cells than the list
+  // holds (global localisation) is compacted again into the device arrays and copied.
+  constexpr unsigned int kHostCells = 16384;
+  if (!ctx->h_cells) {
+    const size_t bytes = kHostCells * (sizeof(unsigned long long) + 5 * sizeof(double) + 4 * sizeof(unsigned int)) + 64;
+    MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_cells), bytes, hipHostMallocMapped));
+    MCL_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->hd_cells), ctx->h_cells, 0));
+  }
+  auto cell_views = [&](unsigned char* base, unsigned long long*& key, double*& wsum, double*& state, unsigned int*& first,
+                        unsigned int*& count, unsigned int*& slot, unsigned int*& cluster, unsigned int*& size) {
+    key = reinterpret_cast<unsigned long long*>(base);
+    wsum = reinterpret_cast<double*>(key + kHostCells);
+    state = wsum + kHostCells;
+    first = reinterpret_cast<unsigned int*>(state + 4 * kHostCells);
+    count = first + kHostCells;
+    slot = count + kHostCells;
+    cluster = slot + kHostCells;
+    size = cluster + kHostCells;
+  };
+  unsigned long long *hk, *dk;
+  double *hw, *hs, *dw, *ds;
+  unsigned int *hf, *hc, *hsl, *hcl, *hsize, *df, *dc, *dsl, *dcl, *dsize;
+  cell_views(ctx->h_cells, hk, hw, hs, hf, hc, hsl, hcl, hsize);
+  cell_views(ctx->hd_cells, dk, dw, ds, df, dc, dsl, dcl, dsize);
   const HashParams hp{cp.linear_hash_resolution, cp.linear_hash_resolution, cp.angular_hash_resolution};
   launch_cluster_cells(ctx->stream, ctx->cur(), n, hp, ctx->d_hashes.ptr, ctx->d_table_keys.ptr, ctx->d_table_first.ptr, t_wsum,
-                       t_count, t_cluster, slots, c_key, c_first, c_count, c_slot, c_wsum, c_state, c_size);
+                       t_count, t_cluster, slots, dk, df, dc, dsl, dw, ds, c_size, kHostCells);
   MCL_HIP(ctx, hipGetLastError());
-  unsigned int m = 0;
-  MCL_HIP(ctx, hipMemcpyAsync(&m, c_size, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
+  MCL_HIP(ctx, hipMemcpyAsync(hsize, c_size, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned int m = *hsize;
   MCL_REQUIRE(ctx, m >= 1 && m <= m_cap, "cell compaction failed");
-  std::vector<unsigned long long> key(m);
-  std::vector<unsigned int> first(m), count(m), slot(m);
-  std::vector<double> wsum(m), state(4 * static_cast<size_t>(m));
-  MCL_HIP(ctx, hipMemcpy(key.data(), c_key, m * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  MCL_HIP(ctx, hipMemcpy(first.data(), c_first, m * sizeof(unsigned int), hipMemcpyDeviceToHost));
-  MCL_HIP(ctx, hipMemcpy(count.data(), c_count, m * sizeof(unsigned int), hipMemcpyDeviceToHost));
-  MCL_HIP(ctx, hipMemcpy(slot.data(), c_slot, m * sizeof(unsigned int), hipMemcpyDeviceToHost));
-  MCL_HIP(ctx, hipMemcpy(wsum.data(), c_wsum, m * sizeof(double), hipMemcpyDeviceToHost));
-  MCL_HIP(ctx, hipMemcpy(state.data(), c_state, 4 * static_cast<size_t>(m) * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> key_big;
+  std::vector<unsigned int> first_big, count_big;
+  std::vector<double> wsum_big, state_big;
+  const unsigned long long* key = hk;
+  const unsigned int *first = hf, *count = hc, *slot_list = dsl;
+  const double *wsum = hw, *state = hs;
+  const bool on_host_list = m <= kHostCells;
+  if (!on_host_list) {
+    MCL_HIP(ctx, hipMemsetAsync(c_size, 0, sizeof(unsigned int), ctx->stream));
+    launch_cluster_cells(ctx->stream, ctx->cur(), n, hp, ctx->d_hashes.ptr, ctx->d_table_keys.ptr, ctx->d_table_first.ptr, t_wsum,
+                         t_count, t_cluster, slots, c_key, c_first, c_count, c_slot, c_wsum, c_state, c_size,
+                         static_cast<unsigned int>(std::min<uint64_t>(ctx->capacity, 0xFFFFFFFFull)), /*table_ready=*/true);
+    MCL_HIP(ctx, hipGetLastError());
+    key_big.resize(m);
+    first_big.resize(m);
+    count_big.resize(m);
+    wsum_big.resize(m);
+    state_big.resize(4 * static_cast<size_t>(m));
+    MCL_HIP(ctx, hipMemcpy(key_big.data(), c_key, m * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    MCL_HIP(ctx, hipMemcpy(first_big.data(), c_first, m * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    MCL_HIP(ctx, hipMemcpy(count_big.data(), c_count, m * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    MCL_HIP(ctx, hipMemcpy(wsum_big.data(), c_wsum, m * sizeof(double), hipMemcpyDeviceToHost));
+    MCL_HIP(ctx, hipMemcpy(state_big.data(), c_state, 4 * static_cast<size_t>(m) * sizeof(double), hipMemcpyDeviceToHost));
+    key = key_big.data();
+    first = first_big.data();
+    count = count_big.data();
+    wsum = wsum_big.data();
+    state = state_big.data();
+    slot_list = c_slot;
+  }
 
   // make_cluster_map :137-157 — cells enter the map in the order their first particle appears in the set.
   struct Cell {
@@ -1021,12 +1063,18 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
     if (const mcl_status s = do_estimate_sums(ctx, ctx->pivot, sums)) return s;
     return mcl_estimate_from_sums(sums, out);
   }
-  MCL_HIP(ctx, hipMemcpy(c_cluster, cluster_of.data(), m * sizeof(unsigned int), hipMemcpyHostToDevice));
-  launch_cell_set_cluster(ctx->stream, c_slot, c_cluster, m, t_cluster);
+  const unsigned int* cluster_list = c_cluster;
+  if (on_host_list) {  // the kernel reads the cluster ids from the mapped list
+    std::memcpy(hcl, cluster_of.data(), m * sizeof(unsigned int));
+    cluster_list = dcl;
+  } else {
+    MCL_HIP(ctx, hipMemcpy(c_cluster, cluster_of.data(), m * sizeof(unsigned int), hipMemcpyHostToDevice));
+  }
+  launch_cell_set_cluster(ctx->stream, slot_list, cluster_list, m, t_cluster);
   launch_estimate_sums_cluster(ctx->stream, ctx->cur(), n, ctx->d_hashes.ptr, ctx->d_table_keys.ptr, t_cluster, slots,
-                               static_cast<unsigned int>(best), ctx->pivot[0], ctx->pivot[1], ctx->chunk_row(0), ctx->d_scalars.ptr + 8);
+                               static_cast<unsigned int>(best), ctx->pivot[0], ctx->pivot[1], ctx->chunk_row(0), ctx->d_scalars.ptr + 8,
+                               ctx->hd_scalars + 8);
   MCL_HIP(ctx, hipGetLastError());
-  MCL_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, ctx->d_scalars.ptr + 8, 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int k = 0; k < 9; ++k) sums[k] = ctx->h_scalars[8 + k];
   sums[9] = ctx->pivot[0];
@@ -1545,6 +1593,7 @@ void mcl_destroy(mcl_ctx* ctx) {
     if (RcclApi* api = rccl_api(nullptr)) (void)api->CommDestroy(ctx->rccl_comm);
   }
   if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+  if (ctx->h_cells) (void)hipHostFree(ctx->h_cells);
   ctx->d_comm_f64.release();
   ctx->d_comm_i64.release();
   ctx->d_targets.release();

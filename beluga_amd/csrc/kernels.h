@@ -295,7 +295,8 @@ void launch_estimate_sums(hipStream_t st, Particles p, uint64_t n, double pivot_
 void launch_cluster_cells(hipStream_t st, Particles p, uint64_t n, HashParams hp, unsigned long long* d_hashes,
                           unsigned long long* t_keys, unsigned int* t_first, double* t_wsum, unsigned int* t_count,
                           unsigned int* t_cluster, uint64_t capacity, unsigned long long* c_key, unsigned int* c_first,
-                          unsigned int* c_count, unsigned int* c_slot, double* c_wsum, double* c_state, unsigned int* c_size);
+                          unsigned int* c_count, unsigned int* c_slot, double* c_wsum, double* c_state, unsigned int* c_size,
+                          unsigned int list_capacity, bool table_ready = false);
 void launch_cell_set_cluster(hipStream_t st, const unsigned int* d_slot, const unsigned int* d_cluster, uint32_t m,
                              unsigned int* t_cluster);
 void launch_estimate_sums_cluster(hipStream_t st, Particles p, uint64_t n, const unsigned long long* d_hashes,

@@ -2931,10 +2931,22 @@ struct CellList {  // compacted occupied cells, arbitrary order (the host sorts 
   unsigned int* size;
 };
 
-__global__ __launch_bounds__(kBlock) void k_cell_compact(CellTable t, Particles p, CellList out) {
+// One pass instead of six fills: the hash table's slots back to empty, the cell counter to zero.
+__global__ __launch_bounds__(kBlock) void k_cell_table_clear(CellTable t, unsigned int* __restrict__ list_size) {
+  const uint64_t s = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (s == 0) *list_size = 0u;
+  if (s >= t.capacity) return;
+  t.keys[s] = kEmptyKey;
+  t.first[s] = 0xFFFFFFFFu;
+  t.wsum[s] = 0.0;
+  t.count[s] = 0u;
+  t.cluster[s] = 0xFFFFFFFFu;
+}
+__global__ __launch_bounds__(kBlock) void k_cell_compact(CellTable t, Particles p, CellList out, unsigned int list_capacity) {
   const uint64_t s = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (s >= t.capacity || t.keys[s] == kEmptyKey) return;
   const unsigned int k = atomicAdd(out.size, 1u);
+  if (k >= list_capacity) return;  // counted, not stored: the caller sees size > capacity and compacts again into a larger list
   const unsigned int f = t.first[s];
   out.key[k] = t.keys[s];
   out.first[k] = f;
@@ -3568,13 +3580,17 @@ void launch_estimate_sums(hipStream_t st, Particles p, uint64_t n, double pivot_
 void launch_cluster_cells(hipStream_t st, Particles p, uint64_t n, HashParams hp, unsigned long long* d_hashes,
                           unsigned long long* t_keys, unsigned int* t_first, double* t_wsum, unsigned int* t_count,
                           unsigned int* t_cluster, uint64_t capacity, unsigned long long* c_key, unsigned int* c_first,
-                          unsigned int* c_count, unsigned int* c_slot, double* c_wsum, double* c_state, unsigned int* c_size) {
+                          unsigned int* c_count, unsigned int* c_slot, double* c_wsum, double* c_state, unsigned int* c_size,
+                          unsigned int list_capacity, bool table_ready) {
   if (n == 0) return;
   const CellTable t{t_keys, t_first, t_wsum, t_count, t_cluster, capacity};
-  hipLaunchKernelGGL(k_cluster_hash, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, hp, d_hashes);
-  hipLaunchKernelGGL(k_cell_aggregate, dim3(num_chunks(n)), dim3(kBlock), 0, st, d_hashes, p.w, n, t);
+  if (!table_ready) {  // clear, hash, aggregate; table_ready: only the compaction again (into a larger list)
+    hipLaunchKernelGGL(k_cell_table_clear, dim3(blocks_for(capacity)), dim3(kBlock), 0, st, t, c_size);
+    hipLaunchKernelGGL(k_cluster_hash, dim3(blocks_for(n)), dim3(kBlock), 0, st, p, n, hp, d_hashes);
+    hipLaunchKernelGGL(k_cell_aggregate, dim3(num_chunks(n)), dim3(kBlock), 0, st, d_hashes, p.w, n, t);
+  }
   const CellList out{c_key, c_first, c_count, c_slot, c_wsum, reinterpret_cast<double4*>(c_state), c_size};
-  hipLaunchKernelGGL(k_cell_compact, dim3(blocks_for(capacity)), dim3(kBlock), 0, st, t, p, out);
+  hipLaunchKernelGGL(k_cell_compact, dim3(blocks_for(capacity)), dim3(kBlock), 0, st, t, p, out, list_capacity);
 }
 void launch_cell_set_cluster(hipStream_t st, const unsigned int* d_slot, const unsigned int* d_cluster, uint32_t m,
                              unsigned int* t_cluster) {
