@@ -140,6 +140,15 @@ bool run_filter(const Scenario& sc, mcl_ctx* ctx, std::vector<mcl_estimate>* out
   const double mean[3] = {1.0, 1.0, 0.2}, cov[9] = {0.09, 0, 0, 0, 0.09, 0, 0, 0, 0.02};
   if (mcl_initialize_normal(ctx, mean, cov) != MCL_OK) return false;
   for (size_t c = 0; c < sc.scans.size(); ++c) {
+    if (c == 3) {
+      // the caller takes the set out and puts it back (what a host does to checkpoint / restore a filter): a sharded context
+      // then has to find out the size of the whole set and where its own shard starts from the other ranks
+      uint64_t held = 0, got = 0;
+      if (mcl_num_particles(ctx, &held) != MCL_OK) return false;
+      std::vector<double> states(4 * held), weights(held);
+      if (mcl_get_particles(ctx, states.data(), weights.data(), held, &got) != MCL_OK || got != held) return false;
+      if (mcl_set_particles(ctx, states.data(), weights.data(), held) != MCL_OK) return false;
+    }
     mcl_estimate est;
     mcl_update_info info;
     if (mcl_update(ctx, sc.controls[c].data(), sc.scans[c].data(), sc.scans[c].size() / 2, &est, &info) != MCL_OK) {
