@@ -202,6 +202,8 @@ __global__ __launch_bounds__(kWide) void k_propagate(Particles p, uint64_t n, Di
   }
 }
 
+// [lf-kernels-begin] (the HBM-traffic record of the LF kernel, profiles/lf_kernel_traffic.json, is keyed by the SHA-256 of
+// the source from here to [lf-kernels-end])
 // ---- K2 likelihood-field reweight ------------------------------------------------------------------
 // One beam end-point -> pz^3.  likelihood_field_model.hpp:82-88, dense_grid.hpp:92-96,127-129,
 // regular_grid.hpp:75-78, linear_grid.hpp:73-75.
@@ -1040,6 +1042,7 @@ __global__ __launch_bounds__(kBlock) void k_lf_combine(double* __restrict__ w, u
   w[i] = w[i] * (mode == 1 ? exp(acc) : acc);
 }
 
+// [lf-kernels-end]
 // -- spatial ordering of the particles --------------------------------------------------------------
 // A full least-significant-digit-first radix sort of (key, index) by the 20-bit ordering key, two passes of 10 bits:
 //   keys + block histograms of the low digit (inside k_propagate, or k_order_keys)  ->  row scan (+ digit totals)  ->

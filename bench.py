@@ -36,16 +36,26 @@ TRAFFIC_FILE = os.path.join(ROOT, "profiles", "lf_kernel_traffic.json")
 KERNEL_SOURCE = os.path.join(ROOT, "beluga_amd", "csrc", "kernels.hip")
 
 
+def lf_kernel_source_sha(path):
+    """SHA-256 of the likelihood-field kernels' source: the part of kernels.hip between the [lf-kernels-begin] and
+    [lf-kernels-end] markers (the whole file if they are missing)."""
+    import hashlib
+    with open(path, "rb") as fh:
+        text = fh.read()
+    a, b = text.find(b"[lf-kernels-begin]"), text.find(b"[lf-kernels-end]")
+    if 0 <= a < b:
+        text = text[a:b]
+    return hashlib.sha256(text).hexdigest()
+
+
 def measured_lf_traffic(n_particles: int):
     """HBM bytes per launch of the LF kernel from the PMC passes of tools/gpu_pmc_traffic.sh (2 x FETCH_SIZE + WRITE_SIZE, see
     profiles/r01_pmc_traffic_calibration.txt), valid only for the kernel source it was collected on: the file records the
-    SHA-256 of kernels.hip and the particle count; anything else gives None."""
-    import hashlib
+    SHA-256 of the LF kernels' source (lf_kernel_source_sha) and the particle count; anything else gives None."""
     try:
         with open(TRAFFIC_FILE) as fh:
             rec = json.load(fh)
-        with open(KERNEL_SOURCE, "rb") as fh:
-            sha = hashlib.sha256(fh.read()).hexdigest()
+        sha = lf_kernel_source_sha(KERNEL_SOURCE)
     except (OSError, ValueError):
         return None
     if rec.get("kernels_hip_sha256") != sha or rec.get("particles") != n_particles:
@@ -317,6 +327,7 @@ def main():
     filt.profile_enable(1)
     filt.profile_read(reset=True)
     sync_all()
+    patch_before = (filt.counter("lf_patch_groups_planned"), filt.counter("lf_patch_groups_through")) if hasattr(filt, "counter") else None
     t0 = time.perf_counter()
     for c in range(args.warmup, args.warmup + args.steps):
         est = filt.update(controls[c], scans[c])
@@ -328,6 +339,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = filt.profile_read(reset=True)
+    patch_after = (filt.counter("lf_patch_groups_planned"), filt.counter("lf_patch_groups_through")) if hasattr(filt, "counter") else None
     # Repeated windows of the same length right behind the timed region (same filter, the trajectory continues): the spread
     # says how much a single 20-step sample can be trusted.
     window_rates = []
@@ -378,10 +390,12 @@ def main():
         bytes_lf = lf_algorithmic_bytes(n_local, BEAMS)
         achieved = bytes_lf / lf_avg_s if lf_avg_s > 0 else 0.0
         traffic = measured_lf_traffic(n_local) if not use_sharded else None
-        patch_fraction = None
+        patch_fraction = patch_fraction_timed = None
         if hasattr(filt, "counter"):
             planned, through = filt.counter("lf_patch_groups_planned"), filt.counter("lf_patch_groups_through")
-            patch_fraction = through / planned if planned else None
+            patch_fraction = through / planned if planned else None  # over the whole run (the repeat windows included)
+            if patch_before and patch_after and patch_after[0] > patch_before[0]:
+                patch_fraction_timed = (patch_after[1] - patch_before[1]) / (patch_after[0] - patch_before[0])
         out = {
             "metric": "MCL update cycles/sec (motion+sensor+resample), N particles x 1080 beams",
             # whole-job aggregate: one unit = one update cycle of 1M particles x 1080 beams (the configuration the metric is
@@ -444,6 +458,7 @@ def main():
                 # their share (12-19 % in the first 20 cycles of a run, 2-4 % once the cloud has settled).
                 "limiter": "vector instruction issue (VALU): ~10 instructions per wave-beam on 7/8 of the waves; gathered groups (2.6x a patched one): texture-address pipe + barrier waits",
                 "groups_through_lds_patch": patch_fraction,
+                "groups_through_lds_patch_in_timed_region": patch_fraction_timed,
                 "valu_issue_floor_ms": n_local * BEAMS / 64 * 10.2 * 4 * (8 / 7) / (1024 * 2.4e9) * 1e3,
                 "ta_floor_ms_if_all_gathered": n_local * BEAMS / 64 * 16 / (256 * 2.4e9) * 1e3,
             },

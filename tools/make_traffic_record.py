@@ -15,8 +15,10 @@ def counter(db_path, name):
 
 kernel, fetch, n1 = counter(sys.argv[1], "FETCH_SIZE")
 _, write, n2 = counter(sys.argv[2], "WRITE_SIZE")
-with open(os.path.join(ROOT, "beluga_amd", "csrc", "kernels.hip"), "rb") as fh:
-    sha = hashlib.sha256(fh.read()).hexdigest()
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (the key of the record: SHA-256 of the LF kernels' source)
+
+sha = bench.lf_kernel_source_sha(os.path.join(ROOT, "beluga_amd", "csrc", "kernels.hip"))
 rec = {"kernel": kernel.replace("void ", "").replace("mcl::(anonymous namespace)::", "").split("(")[0], "particles": int(sys.argv[4]) if len(sys.argv) > 4 else 1_000_000,
        "fetch_size_kb": fetch, "write_size_kb": write, "launches_averaged": [n1, n2], "kernels_hip_sha256": sha,
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py`; HBM bytes per launch = "
