@@ -731,7 +731,8 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B), variant, &sort,
                        scan_is_short, ctx->tuning, use_patches,
                        PatchStats{reinterpret_cast<unsigned long long*>(ctx->d_scalars.ptr + 24),
-                                  reinterpret_cast<unsigned long long*>(ctx->hd_scalars + 28)});
+                                  reinterpret_cast<unsigned long long*>(ctx->hd_scalars + 28),
+                                  static_cast<uint32_t>(ctx->tuning.lf_loose_below)});
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
     if (variant == kLfSortedLanes && ctx->tuning.lf_fast != 0 && scan_is_short && ctx->W < 16384 && ctx->H < 16384 && ctx->pal_count &&
         ctx->tuning.lf_table == 0)
@@ -1532,7 +1533,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     MCL_HIP(ctx, hipEventCreateWithFlags(&ctx->points_event, hipEventDisableTiming));
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
-    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_small_particles", "device_policy",
+    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_loose_below", "lf_small_particles", "device_policy",
                              "sort_min_particles", "beam_sort_min_particles", "field_build"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
@@ -2381,6 +2382,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   Tuning& t = ctx->tuning;
   if (key == "lf_variant") t.lf_variant = value == 0 ? kLfWavePerParticle : (value == 1 ? kLfLanePerParticle : (value == 3 ? kLfBeamLanes : kLfSortedLanes));
   else if (key == "lf_dispersed") t.lf_dispersed = value ? 1 : 0;
+  else if (key == "lf_loose_below") t.lf_loose_below = static_cast<int>(std::clamp<int64_t>(value, 0, 257));
   else if (key == "lf_small_particles") t.lf_small_particles = value < 0 ? 0 : static_cast<int>(std::min<int64_t>(value, INT32_MAX));
   else if (key == "lf_fast") t.lf_fast = value < 0 ? -1 : (value ? 1 : 0);
   else if (key == "lf_table") t.lf_table = value ? 1 : 0;

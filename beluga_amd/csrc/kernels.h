@@ -114,6 +114,8 @@ struct Tuning {
   int lf_table = 0;                 // 0 = palette table when the field allows it, 1 = force the 8-byte cube table
   int lf_patch = 1;                 // index table through per-workgroup LDS patches: 1 = where the last launch found them useful,
                                     // 0 = never (per-lane gathers only), 2 = always
+  int lf_loose_below = 176;         // LF patch kernel: a workgroup with fewer than this many 256ths of its beam groups fitting a patch
+                                    // drops the patches (no producer, no barriers) and gathers every look-up
   int lf_dispersed = 0;             // a set the patch kernel reports as dispersed (lf_patch = 1): 0 = the ordered-lanes gather kernel,
                                     // 1 = wave per particle / lane per beam (k_reweight_lf_beams, no ordering pass; measured
                                     // 20 % slower at 1M x 1080: profiles/r02_dispersed_study.txt)
@@ -168,6 +170,7 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
 struct PatchStats {
   unsigned long long* device;  // [3]: groups planned, groups through a patch, workgroups reported (never reset)
   unsigned long long* mirror;  // [2]: mapped host copy of the first two, written by the last workgroup of a launch
+  uint32_t loose_below;        // a workgroup with fewer than loose_below / 256 of its groups fitting a patch gathers them all
 };
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats);

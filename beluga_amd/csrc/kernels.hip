@@ -830,7 +830,10 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     s_plan[threadIdx.x] = int2{x0, y0 | (fits ? 1 : 0)};
     mine_fits = fits;
   }
-  // A workgroup with (almost) no group through a patch - a dispersed set - drops the machinery: no producer, no barriers.
+  // A workgroup with too few of its groups through a patch drops the machinery: no producer, no barriers, every look-up a
+  // gather.  Not only dispersed sets: a gathered group INSIDE a patched workgroup costs 2.6x a patched one (the workgroup waits
+  // for the gathers at its next barrier), one of an all-gathering workgroup 1.3x, so mixing pays only above ~2/3 fitting
+  // (stats.loose_below, in 256ths: measured, profiles/r02_lf_series.txt).
   // (counted by hand: __syncthreads_count brings a static LDS variable with it, and this kernel addresses LDS from 0)
   uint32_t* s_count = reinterpret_cast<uint32_t*>(s_bound) + 24;  // behind the bound's [7][3]
   {
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   __syncthreads();
   uint32_t fitting = 0;
   for (uint32_t k = 0; k < kPalBlock / 64; ++k) fitting += s_count[k];
-  const bool loose = __builtin_amdgcn_readfirstlane(fitting) * 8u < groups;
+  const bool loose = __builtin_amdgcn_readfirstlane(fitting) * 256u < groups * stats.loose_below;
   auto plan_of = [&](uint32_t g, int& x0, int& y0) -> bool {  // g uniform; scalar results
     if (g >= kPatchPlanned) return false;
     const int2 e = s_plan[g];

@@ -11,6 +11,8 @@ grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIG
 controls = [se2_from_xytheta(*o) for o in odoms]
 n = 1_000_000
 f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF), AmclParams(min_particles=n, max_particles=n), seed=42)
+if os.environ.get("LOOSE"):
+    f.set_option("lf_loose_below", int(os.environ["LOOSE"]))
 f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
 f.profile_enable(2)
 p0 = t0 = 0
