@@ -42,7 +42,7 @@ def lf_kernel_source_sha(path):
     import hashlib
     with open(path, "rb") as fh:
         text = fh.read()
-    a, b = text.find(b"[lf-kernels-begin]"), text.find(b"[lf-kernels-end]")
+    a, b = text.find(b"[lf-kernels-begin]"), text.rfind(b"[lf-kernels-end]")  # (the begin marker's own comment names the end marker)
     if 0 <= a < b:
         text = text[a:b]
     return hashlib.sha256(text).hexdigest()
