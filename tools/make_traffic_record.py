@@ -22,7 +22,9 @@ sha = bench.lf_kernel_source_sha(os.path.join(ROOT, "beluga_amd", "csrc", "kerne
 rec = {"kernel": kernel.replace("void ", "").replace("mcl::(anonymous namespace)::", "").split("(")[0], "particles": int(sys.argv[4]) if len(sys.argv) > 4 else 1_000_000,
        "fetch_size_kb": fetch, "write_size_kb": write, "launches_averaged": [n1, n2], "kernels_hip_sha256": sha,
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py`; HBM bytes per launch = "
-               "2 x FETCH_SIZE + WRITE_SIZE (gfx950 reports half of every read: profiles/r01_pmc_traffic_calibration.txt)"}
+               "2 x FETCH_SIZE + WRITE_SIZE (gfx950 reports half of every read: profiles/r01_pmc_traffic_calibration.txt); "
+               "kernels_hip_sha256 = SHA-256 of the LF kernels' source, the part of kernels.hip between its [lf-kernels-begin] and "
+               "[lf-kernels-end] markers (bench.lf_kernel_source_sha)"}
 with open(sys.argv[3], "w") as fh:
     json.dump(rec, fh, indent=1)
 print(rec)
