@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of compile-time variants of the LF patch kernel: each argument is a string of extra compiler flags.
+# A/B of compile-time variants of a kernel: each argument is a string of extra compiler flags (-D...) for beluga_amd.build.
 # Per variant: rebuild, the patch == gather bit-for-bit test, a short bench (headline + windows + LF kernel time).
 set -u
 mkdir -p gpurun_out
