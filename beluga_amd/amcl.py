@@ -444,7 +444,8 @@ class Amcl:
         self._check(self._lib.mcl_comm_attach_rccl(self._ctx, unique_id, rank, world))
 
     def set_option(self, name: str, value: int):
-        """A/B switch of the library (include/beluga_mcl.h, mcl_set_option); no option changes a result."""
+        """A/B switch of the library (include/beluga_mcl.h, mcl_set_option); no option but field_build changes a result
+        beyond the rounding of a particle's sum over the scan."""
         self._check(self._lib.mcl_set_option(self._ctx, name.encode(), int(value)))
 
     def counter(self, name: str) -> int:

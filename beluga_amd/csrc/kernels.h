@@ -107,7 +107,8 @@ enum LfVariant : int {
   kLfBeamLanes = 3         // wave per particle, lanes = beams, palette table: dispersed sets (chosen by the cycle, or forced)
 };
 
-// Per-context switches for A/B measurements and tests (mcl_set_option); no switch changes a result.
+// Per-context switches for A/B measurements and tests (mcl_set_option); no switch changes a result beyond the rounding of a
+// particle's sum over the scan (scan order with a lane per particle, a fixed tree with a wave per particle).
 struct Tuning {
   int lf_variant = kLfSortedLanes;  // kernel family of the likelihood-field reweight
   int lf_fast = -1;                 // FMA variant with exact fallback: -1 / 1 = whenever its preconditions hold, 0 = never

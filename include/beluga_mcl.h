@@ -366,22 +366,34 @@ mcl_status mcl_profile_read(mcl_ctx* ctx, double ms[MCL_NUM_STAGES], uint64_t co
 /* Beam model only: grid cells visited by the ray walks since the last reset (cells/s). */
 mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
 
-/* ---- Switches and hooks for A/B measurements and tests; no option but field_build changes a result. -----------
+/* ---- Switches and hooks for A/B measurements and tests.  No option but field_build changes a result beyond the rounding of a
+ * particle's sum over the scan: the kernels with a lane per particle add the beams in scan order (the reference's order), the
+ * kernels with a wave per particle (lf_variant 0 / 3, small sets, lf_dispersed) in a fixed tree - 1e-16 relative. ------------
  * Options (defaults in parentheses; BELUGA_MCL_<NAME> in the environment sets the default at mcl_create):
- *   lf_variant (2)  likelihood-field kernel family: 2 = spatially ordered lanes, 1 = lane per particle, 0 = wave per particle
+ *   lf_variant (2)  likelihood-field kernel family: 2 = spatially ordered lanes (small sets: see lf_small_particles), 1 = lane
+ *                   per particle, 0 = wave per particle over the f32 field, 3 = wave per particle over the palette table
  *   lf_fast (-1)    FMA variant with exact fallback: nonzero = whenever its preconditions hold, 0 = never
  *   lf_table (0)    1 = force the 8-byte table instead of the palette
  *   lf_patch (1)    index table through per-workgroup LDS patches (dense sets): 1 = where the last launch found them useful
  *                   (a dispersed set - global localisation - has none, and is sent to the per-lane gathers, with a probe every
  *                   16th launch), 0 = never, 2 = always
+ *   lf_loose_below (176)  LDS-patch kernel: a workgroup with fewer than this many 256ths of its beam groups fitting a patch
+ *                   gathers every look-up (a gathered group inside a patched workgroup costs twice one of an all-gathering one)
+ *   lf_dispersed (0)  a set reported as dispersed: 0 = the ordered-lanes gather kernel, 1 = a wave per particle, lanes over the
+ *                   beams, no ordering pass (measured slower at 1M x 1080)
+ *   lf_small_particles (65536)  likelihood-field sets below this size: a wave per 1..16 particles, lanes over the beams, no
+ *                   ordering pass (the measured crossover to the ordered kernels)
  *   device_policy (1)  recovery estimator on the device when the cycle takes no host-side decision
- *   sort_min_particles (16384)  below this many particles the spatial ordering is skipped
+ *   sort_min_particles (16384)  below this many particles the spatial ordering is skipped (likelihood-field models)
+ *   beam_sort_min_particles (16384)  beam model: the ordered kernel from this size on; below it a wave per particle over the
+ *                   whole-grid bit maps (both skip empty space by the block distance map)
  *   field_build (0)  how the NEXT mcl_set_map builds the likelihood field: 0 = the reference's priority-queue wavefront on the
  *                    host (bit-identical field, seconds at 16 M cells), 1 = exact Euclidean distance transform on the device
  *                    (milliseconds; equal at all but the few cells where the wavefront does not find the nearest obstacle,
  *                    never farther from the truth; falls back to 0 when max_obstacle_distance spans more than 1024 cells).
  *                    This one DOES change the field where the two algorithms differ; everything downstream follows the field.
- * Counters: lf_fast_launches = launches of the FMA variant so far; lf_patch_launches = those of them sent to the LDS-patch
+ * Counters: lf_beams_launches = launches of the wave-per-particle LF kernel (small sets, lf_dispersed, lf_variant 3);
+ *   lf_fast_launches = launches of the FMA variant so far; lf_patch_launches = those of them sent to the LDS-patch
  *   kernel; lf_patch_groups_planned / lf_patch_groups_through = groups of 8 beams (per workgroup) that kernel has looked at /
  *   has read through a patch, running totals over a sample of the workgroups; field_built_on_device, field_build_us = the last mcl_set_map. */
 mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value);
