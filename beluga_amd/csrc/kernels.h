@@ -108,7 +108,7 @@ enum LfVariant : int {
 };
 
 // Per-context switches for A/B measurements and tests (mcl_set_option); no switch changes a result beyond the rounding of a
-// particle's sum over the scan (scan order with a lane per particle, a fixed tree with a wave per particle).
+// particle's sum over the scan (libstdc++'s transform_reduce order with a lane per particle, a fixed tree with a wave per particle).
 struct Tuning {
   int lf_variant = kLfSortedLanes;  // kernel family of the likelihood-field reweight
   int lf_fast = -1;                 // FMA variant with exact fallback: -1 / 1 = whenever its preconditions hold, 0 = never

@@ -58,6 +58,13 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// The order in which a particle's terms are added over the scan.  The reference calls std::transform_reduce
+// (likelihood_field_model.hpp:76, beam_model.hpp:108, likelihood_field_prob_model.hpp:77), whose association the standard leaves
+// open; libstdc++ (<numeric>, random-access overload: the reference's toolchain on Linux) adds blocks of four as
+// (f0 + f1) + (f2 + f3) to the running sum and the last B mod 4 terms one by one.  The kernels with a lane per particle do the
+// same, so their weights carry the same roundings as that build's (and the chain of dependent additions is a third as long).
+__device__ __forceinline__ double sum4(double a, double b, double c, double d) { return (a + b) + (c + d); }
+
 // Deterministic block reduction of K doubles per thread.  Result valid in thread 0.
 template <int K, int kThreads = kBlock>
 __device__ __forceinline__ void block_reduce(double (&v)[K], double* s_scratch /* [kThreads/64][K] */) {
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_wave(Particles p, uint64
 }
 
 // Variant B — one lane per particle, every lane walks the scan in order; the scan is read with scalar
-// loads (wave-uniform address), the sum is the reference's sequential `1 + sum pz^3` bit for bit.
+// loads (wave-uniform address), the sum `1 + sum pz^3` is added in the order of the reference's std::transform_reduce (sum4).
 template <bool kIdx32>
 __global__ __launch_bounds__(kBlock) void k_reweight_lf_lane(Particles p, uint64_t n, FieldView f, const double* __restrict__ pts,
                                                              uint32_t B) {
@@ -314,11 +321,15 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_lane(Particles p, uint64
   if (i < n) state = load_pose(p, i);
   const Pose2 T = pose_mul(f.world_to_field, state);
   double acc = f.prob ? 0.0 : 1.0;
-#pragma unroll 8
-  for (uint32_t b = 0; b < B; ++b) {
-    const double px = pts[2 * b], py = pts[2 * b + 1];
-    acc += lf_beam<kIdx32>(f, px, py, T.r.c, T.r.s, T.x, T.y);
+  uint32_t b = 0;
+#pragma unroll 2
+  for (; b + 4 <= B; b += 4) {
+    double t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = lf_beam<kIdx32>(f, pts[2 * (b + k)], pts[2 * (b + k) + 1], T.r.c, T.r.s, T.x, T.y);
+    acc += sum4(t[0], t[1], t[2], t[3]);
   }
+  for (; b < B; ++b) acc += lf_beam<kIdx32>(f, pts[2 * b], pts[2 * b + 1], T.r.c, T.r.s, T.x, T.y);
   if (i < n) p.w[i] = p.w[i] * (f.prob ? exp(acc) : acc);
 }
 
@@ -328,10 +339,10 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_lane(Particles p, uint64
 // instead of 64 and the working set of a CU stays in its 32 KB L1 (profiles/r01: variants A/B are bound by
 // the L1/L2 request rate, not by HBM).  The order in which particles are visited does not change any
 // result: each lane still accumulates `1 + sum pz^3` over the scan in the reference's order.
-// `partial` == nullptr: the whole scan per lane, weights updated in place (the sum is the reference's sequential sum).
+// `partial` == nullptr: the whole scan per lane, weights updated in place (the sum in the reference's order: sum4).
 // `partial` != nullptr (medium particle counts, where one lane per particle cannot fill 256 CUs): blockIdx.y selects a
 // contiguous segment of the scan; the segment's sum goes to partial[segment][t] and k_lf_combine adds the segments up in
-// order — same terms, fixed association, bit-reproducible, differs from the sequential sum only in rounding.
+// order — same terms, fixed association, bit-reproducible, differs from the whole-scan sum only in rounding.
 // The pose of the particle at a position of the spatial order, moved into the table's frame.  A 32-byte record gather
 // per lane, once per kernel (the ordering passes move 8 bytes per particle, not the poses).
 __device__ __forceinline__ Pose2 ordered_pose(const Pose2& to_frame, const double4* __restrict__ pose, uint32_t i) {
@@ -367,22 +378,35 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
         v[2 * k + 1] = (px * st + py * ct + yt) * f.inv_resolution;
       }
       floor_rd_16(v);
+      double t[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        acc += lf_cube_fetch(rsrc, f, row_bytes, unknown_offset, floor_rd_result(v[2 * k]), floor_rd_result(v[2 * k + 1]));
+        t[k] = lf_cube_fetch(rsrc, f, row_bytes, unknown_offset, floor_rd_result(v[2 * k]), floor_rd_result(v[2 * k + 1]));
+      acc += sum4(t[0], t[1], t[2], t[3]);
+      acc += sum4(t[4], t[5], t[6], t[7]);
     }
-    for (; b < b_end; ++b) {
-      const double px = pts[2 * b], py = pts[2 * b + 1];
+    auto term = [&](uint32_t at) {
+      const double px = pts[2 * at], py = pts[2 * at + 1];
       double vx = (px * ct - py * st + xt) * f.inv_resolution, vy = (px * st + py * ct + yt) * f.inv_resolution;
       floor_rd_2(vx, vy);
-      acc += lf_cube_fetch(rsrc, f, row_bytes, unknown_offset, floor_rd_result(vx), floor_rd_result(vy));
+      return lf_cube_fetch(rsrc, f, row_bytes, unknown_offset, floor_rd_result(vx), floor_rd_result(vy));
+    };
+    if (b + 4 <= b_end) {
+      const double t0 = term(b), t1 = term(b + 1), t2 = term(b + 2), t3 = term(b + 3);
+      acc += sum4(t0, t1, t2, t3);
+      b += 4;
     }
+    for (; b < b_end; ++b) acc += term(b);
   } else {
-#pragma unroll 8
-    for (uint32_t b = b_begin; b < b_end; ++b) {
-      const double px = pts[2 * b], py = pts[2 * b + 1];
-      acc += lf_beam<false>(f, px, py, ct, st, xt, yt);
+    uint32_t b = b_begin;
+#pragma unroll 2
+    for (; b + 4 <= b_end; b += 4) {
+      double t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = lf_beam<false>(f, pts[2 * (b + k)], pts[2 * (b + k) + 1], ct, st, xt, yt);
+      acc += sum4(t[0], t[1], t[2], t[3]);
     }
+    for (; b < b_end; ++b) acc += lf_beam<false>(f, pts[2 * b], pts[2 * b + 1], ct, st, xt, yt);
   }
   if (t < n) {
     if (partial) {
@@ -497,8 +521,11 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
     for (int k = 0; k < 8; ++k) e[k] = lf_palette_fetch(rsrc, f, floor_rd_result(v[2 * k]), floor_rd_result(v[2 * k + 1]), row_fix);
   };
   auto consume = [&](uint32_t (&e)[8], bool) {
+    double t[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc += lf_palette_value(e[k]);
+    for (int k = 0; k < 8; ++k) t[k] = lf_palette_value(e[k]);
+    acc += sum4(t[0], t[1], t[2], t[3]);
+    acc += sum4(t[4], t[5], t[6], t[7]);
   };
   uint32_t b = b_begin;
   uint32_t groups = (b_end - b_begin) / 8;
@@ -571,12 +598,18 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
       consume(ea, false);
     }
   }
-  for (; b < b_end; ++b) {
-    const double px = pts[2 * b], py = pts[2 * b + 1];
+  auto term = [&](uint32_t at) {
+    const double px = pts[2 * at], py = pts[2 * at + 1];
     double vx = (px * ct - py * st + xt) * f.inv_resolution, vy = (px * st + py * ct + yt) * f.inv_resolution;
     floor_rd_2(vx, vy);
-    acc += lf_palette_value(lf_palette_fetch(rsrc, f, floor_rd_result(vx), floor_rd_result(vy), row_fix));
+    return lf_palette_value(lf_palette_fetch(rsrc, f, floor_rd_result(vx), floor_rd_result(vy), row_fix));
+  };
+  if (b + 4 <= b_end) {
+    const double t0 = term(b), t1 = term(b + 1), t2 = term(b + 2), t3 = term(b + 3);
+    acc += sum4(t0, t1, t2, t3);
+    b += 4;
   }
+  for (; b < b_end; ++b) acc += term(b);
   if (t < n) {
     if (partial) {
       partial[static_cast<size_t>(blockIdx.y) * n + t] = acc;
@@ -600,7 +633,7 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
 // kernel gets out of that set (400 M) - but fewer of them hit in L2 (33 % vs 48 %), and the launch is bound by what the L2
 // misses pull in (33 GB per launch at 7.5 TB/s): 4.46 ms vs 3.72 ms.  Not chosen by default there.
 // End-points by the reference's separately rounded arithmetic; a lane adds its beams in scan order, the 64 lane sums are
-// added in a fixed tree (wave_sum_f64): the weight differs from the sequential sum of the other kernels in rounding only.
+// added in a fixed tree (wave_sum_f64): the weight differs from the sum of the lane-per-particle kernels in rounding only.
 // Workgroup memory as in k_reweight_lf_palette: [0, (H+2)*4) row offsets, [pal_base, ...) the palette; no other LDS.
 constexpr int kBeamsBlock = 256;
 __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, uint64_t n, FieldView f, const double2* __restrict__ pts,
@@ -943,21 +976,35 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   };
   // The separately rounded evaluation, beam by beam with plain gathers.
   auto add_exact = [&](uint32_t b0, uint32_t count) {
-#pragma unroll 1
-    for (uint32_t b = b0; b < b0 + count; ++b) {
-      const double px = pts[2 * b], py = pts[2 * b + 1];
+    auto term = [&](uint32_t at) {
+      const double px = pts[2 * at], py = pts[2 * at + 1];
       double vx = (px * ct - py * st + xt) * f.inv_resolution, vy = (px * st + py * ct + yt) * f.inv_resolution;
       floor_rd_2(vx, vy);
-      acc += lf_palette_value(lf_palette_fetch(rsrc, f, floor_rd_result(vx), floor_rd_result(vy), kFastBiasX));
+      return lf_palette_value(lf_palette_fetch(rsrc, f, floor_rd_result(vx), floor_rd_result(vy), kFastBiasX));
+    };
+    uint32_t b = b0;
+    const uint32_t end = b0 + count;
+#pragma unroll 1
+    for (; b + 4 <= end; b += 4) {  // (groups start at multiples of 8: the blocks of four are the scan's)
+      const double t0 = term(b), t1 = term(b + 1), t2 = term(b + 2), t3 = term(b + 3);
+      acc += sum4(t0, t1, t2, t3);
     }
+#pragma unroll 1
+    for (; b < end; ++b) acc += term(b);
   };
   auto consume = [&](const Lookups& e, uint32_t b0) {
     if (__builtin_amdgcn_readfirstlane(e.redo)) {
       add_exact(b0, 8);
       return;
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc += lf_palette_value(e.e[k]);
+    {
+      const double t0 = lf_palette_value(e.e[0]), t1 = lf_palette_value(e.e[1]), t2 = lf_palette_value(e.e[2]), t3 = lf_palette_value(e.e[3]);
+      acc += sum4(t0, t1, t2, t3);
+    }
+    {
+      const double t4 = lf_palette_value(e.e[4]), t5 = lf_palette_value(e.e[5]), t6 = lf_palette_value(e.e[6]), t7 = lf_palette_value(e.e[7]);
+      acc += sum4(t4, t5, t6, t7);
+    }
   };
   // One step: the end-points of group g, then the sum of the group before it (its gathers, if any, had the end-point
   // arithmetic to arrive), then the look-ups of group g.  `redo`: 1 if the group has to be added by add_exact instead.

@@ -367,8 +367,9 @@ mcl_status mcl_profile_read(mcl_ctx* ctx, double ms[MCL_NUM_STAGES], uint64_t co
 mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
 
 /* ---- Switches and hooks for A/B measurements and tests.  No option but field_build changes a result beyond the rounding of a
- * particle's sum over the scan: the kernels with a lane per particle add the beams in scan order (the reference's order), the
- * kernels with a wave per particle (lf_variant 0 / 3, small sets, lf_dispersed) in a fixed tree - 1e-16 relative. ------------
+ * particle's sum over the scan: the likelihood-field kernels with a lane per particle add the beams as libstdc++'s
+ * std::transform_reduce does (blocks of four; the reference's call, likelihood_field_model.hpp:76), the kernels with a wave per
+ * particle (lf_variant 0 / 3, small sets, lf_dispersed) in a fixed tree - 1e-16 relative. ------------------------------------
  * Options (defaults in parentheses; BELUGA_MCL_<NAME> in the environment sets the default at mcl_create):
  *   lf_variant (2)  likelihood-field kernel family: 2 = spatially ordered lanes (small sets: see lf_small_particles), 1 = lane
  *                   per particle, 0 = wave per particle over the f32 field, 3 = wave per particle over the palette table

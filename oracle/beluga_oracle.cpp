@@ -319,6 +319,11 @@ void make_likelihood_field(const Grid& g, const LfParams& p, float* out) {
   }
 }
 
+struct ScanPoint {  // std::pair<double, double> of the reference's measurement_type, over the caller's packed (x, y) doubles
+  double first, second;
+};
+static_assert(sizeof(ScanPoint) == 2 * sizeof(double), "ScanPoint must be two packed doubles");
+
 // sensor/likelihood_field_model.hpp:68-91 — ONE particle.
 inline double lf_weight(
     const float* field, int W, int H, double res, const SE2& world_to_field, double max_laser_distance, const SE2& state,
@@ -328,19 +333,20 @@ inline double lf_weight(
   const double cos_theta = transform.r.c, sin_theta = transform.r.s;
   const float unknown_space_occupancy_prob = static_cast<float>(1. / max_laser_distance);
   const double inv_resolution = 1. / res;  // regular_grid.hpp:76
-  double acc = 1.0;
-  for (size_t b = 0; b < B; ++b) {
-    const double px = pts[2 * b], py = pts[2 * b + 1];
-    const double x = px * cos_theta - py * sin_theta + x_offset;
-    const double y = px * sin_theta + py * cos_theta + y_offset;
+  // The reference calls std::transform_reduce over the points (:76), whose order of additions the standard leaves open; called
+  // here as well, over the same kind of range (random access), it associates as the reference's own standard library does -
+  // libstdc++: blocks of four, (f0 + f1) + (f2 + f3), added to the running sum, the rest one by one.
+  const ScanPoint* points = reinterpret_cast<const ScanPoint*>(pts);
+  return std::transform_reduce(points, points + B, 1.0, std::plus<>{}, [&](const ScanPoint& point) {
+    const double x = point.first * cos_theta - point.second * sin_theta + x_offset;
+    const double y = point.first * sin_theta + point.second * cos_theta + y_offset;
     const int xi = static_cast<int>(std::floor(x * inv_resolution));
     const int yi = static_cast<int>(std::floor(y * inv_resolution));
     float v = unknown_space_occupancy_prob;
     if (xi >= 0 && yi >= 0 && xi < W && yi < H) v = field[static_cast<size_t>(yi) * W + static_cast<size_t>(xi)];
     const double pz = static_cast<double>(v);
-    acc += pz * pz * pz;
-  }
-  return acc;
+    return pz * pz * pz;
+  });
 }
 
 // sensor/likelihood_field_prob_model.hpp:68-90 — ONE particle: exp(sum log pz).
@@ -352,18 +358,16 @@ inline double lf_prob_weight(
   const double cos_theta = transform.r.c, sin_theta = transform.r.s;
   const float unknown_space_occupancy_prob = static_cast<float>(1. / max_laser_distance);
   const double inv_resolution = 1. / res;
-  double acc = 0.0;
-  for (size_t b = 0; b < B; ++b) {
-    const double px = pts[2 * b], py = pts[2 * b + 1];
-    const double x = px * cos_theta - py * sin_theta + x_offset;
-    const double y = px * sin_theta + py * cos_theta + y_offset;
+  const ScanPoint* points = reinterpret_cast<const ScanPoint*>(pts);  // std::transform_reduce as in lf_weight (:77)
+  return std::exp(std::transform_reduce(points, points + B, 0.0, std::plus<>{}, [&](const ScanPoint& point) {
+    const double x = point.first * cos_theta - point.second * sin_theta + x_offset;
+    const double y = point.first * sin_theta + point.second * cos_theta + y_offset;
     const int xi = static_cast<int>(std::floor(x * inv_resolution));
     const int yi = static_cast<int>(std::floor(y * inv_resolution));
     float v = unknown_space_occupancy_prob;
     if (xi >= 0 && yi >= 0 && xi < W && yi < H) v = field[static_cast<size_t>(yi) * W + static_cast<size_t>(xi)];
-    acc += std::log(static_cast<double>(v));
-  }
-  return std::exp(acc);
+    return std::log(static_cast<double>(v));
+  }));
 }
 
 // algorithm/raycasting/bresenham.hpp:84-192, iterator restated as a small state machine.
@@ -481,9 +485,9 @@ struct BeamParams {  // sensor/beam_model.hpp:43-58
 inline double beam_weight(const Grid& g, const BeamParams& p, const SE2& state, const double* pts, size_t B, long* steps) {
   const Ray2d beam{g, state, p.beam_max_range};
   const double n = 1. / (std::sqrt(2. * M_PI) * p.sigma_hit);
-  double acc = 0.0;
-  for (size_t b = 0; b < B; ++b) {
-    const double px = pts[2 * b], py = pts[2 * b + 1];
+  const ScanPoint* points = reinterpret_cast<const ScanPoint*>(pts);  // std::transform_reduce as in lf_weight (:108)
+  return std::transform_reduce(points, points + B, 0.0, std::plus<>{}, [&](const ScanPoint& point) {
+    const double px = point.first, py = point.second;
     const double z = std::sqrt(px * px + py * py);
     SO2 bearing;
     bearing.c = px / z;
@@ -504,9 +508,8 @@ inline double beam_weight(const Grid& g, const BeamParams& p, const SE2& state, 
     } else {
       pz += p.z_max;
     }
-    acc += pz * pz * pz;
-  }
-  return acc;
+    return pz * pz * pz;
+  });
 }
 
 // motion/differential_drive_model.hpp:129-173
