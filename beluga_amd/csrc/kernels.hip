@@ -2027,8 +2027,8 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam(Particles p, uint64_t 
 }
 
 // Variant B (default above 16K particles): one lane per spatially ordered particle, every lane walks the same beam at
-// the same time.  Neighbouring lanes trace nearly the same line and finish together; the sum is the reference's
-// sequential sum.  Per-lane byte gathers top out at ~2 lanes/clk/CU on this chip (profiles/r01: the L1 handles a
+// the same time.  Neighbouring lanes trace nearly the same line and finish together; the sum is taken in scan order (the
+// reference's std::transform_reduce leaves the order open).  Per-lane byte gathers top out at ~2 lanes/clk/CU on this chip (profiles/r01: the L1 handles a
 // gather lane by lane even when the lanes share a line), so the occupancy the walks read is staged ONCE per workgroup
 // into LDS as a 1024 x 1024-cell bit window (132 KB) centred on the workgroup's particles; LDS serves 32 lanes/clk.
 constexpr int kBeamBlock = 1024;
