@@ -618,6 +618,42 @@ def test_full_size_kld_cut_10m_is_exact():
         f.close()
 
 
+def test_64m_particles_on_one_device_sampled_against_oracle():
+    """The whole 8-GPU job of config 4 (8M particles per GPU) on one device: 64M x 1080 beams (2.4 GB of states; indices stay
+    below 2^32, particle-beam products do not).  One full update cycle, then a reweight sampled against the oracle (first and
+    last particle included), the weight sum against a long-double host sum, and a resample that may only draw from the
+    particles with positive weight."""
+    size = 4000
+    cells = synth.make_rooms_map(size, size, seed=42)
+    grid = OccupancyGrid(cells, 0.05, origin=se2_from_xytheta(-100.0, -100.0, 0.0))
+    truth = synth.find_free_pose(cells, 0.05, (-100.0, -100.0), seed=1)
+    pts = make_scan(grid, truth, 1080, max_range=30.0)
+    n = 64_000_000
+    f = Amcl(grid, MOTION, LF, AmclParams(min_particles=n, max_particles=n), seed=3)
+    f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+    est = f.update(se2_from_xytheta(0.3, 0.0, 0.02), pts)
+    assert est is not None and np.all(np.isfinite(est[0])) and np.all(np.isfinite(est[1]))
+    assert f.last_info["resampled"] and f.last_info["num_particles"] == n
+    states, w0 = f.particles()
+    assert len(w0) == n and np.all(w0 == 1.0)
+    f.reweight(pts)
+    w = f.particles()[1]
+    sample = np.concatenate([np.random.Generator(np.random.MT19937(1)).choice(n, 2048, replace=False), [0, n - 1]])
+    want = orc.lf_weights(f.likelihood_field(), 0.05, grid.origin, 100.0, states[sample], pts, threads=orc.max_threads())
+    np.testing.assert_allclose(w[sample], want, rtol=RTOL)
+    assert abs(f.weight_sum() / float(np.sum(w, dtype=np.longdouble)) - 1.0) < 1e-12
+    # resample from a set whose particles left of the estimate weigh nothing: no survivor lies there
+    x_cut = est[0][2]
+    w[states[:, 2] < x_cut] = 0.0
+    assert 0 < np.count_nonzero(w) < n
+    f.set_particles(states, w)
+    assert f.resample(0.0, step=2) == n
+    got, gw = f.particles()
+    assert np.all(gw == 1.0) and np.all(got[:, 2] >= x_cut)
+    assert got[:, 2].max() <= states[:, 2].max()
+    f.close()
+
+
 def test_full_size_beam_model_1m_sample_against_oracle():
     """Config 5 shape: 1M particles x 1080 beams, BeamSensorModel on the 4000x4000 int8 grid.  A 256-particle sample of
     the full launch is checked against the oracle (each oracle particle walks ~3.5e5 cells), plus the cells-visited
