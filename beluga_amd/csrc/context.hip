@@ -192,6 +192,10 @@ struct mcl_ctx {
   DeviceBuffer<double> d_pal_val;
   DeviceBuffer<uint32_t> d_pal_keys;
   uint32_t pal_count{0}, pal_pitch{0}, pal_base{0}, pal_bytes{0};
+  DeviceBuffer<uint8_t> d_far_bits;   // FieldView::far_bits: tiles of d_pal_idx uniformly equal to the table's most common entry
+  DeviceBuffer<uint32_t> d_far_votes;
+  uint32_t far_row_bytes{0}, far_bytes{0}, far_entry{0};
+  uint64_t far_tiles{0};  // number of set bits' worth of tiles voted for far_entry (0 = no bitmap)
   DeviceBuffer<int8_t> d_cells;
   DeviceBuffer<uint32_t> d_nonfree_bits;  // beam model: 1 bit per cell
   DeviceBuffer<uint32_t> d_free;
@@ -273,6 +277,7 @@ struct mcl_ctx {
   // patches = the LDS-patch kernel; beams = a dispersed set goes to k_reweight_lf_beams (wave per particle, no ordering).
   struct LfMode { bool decided, patches, beams; } lf_mode{false, false, false};
   uint64_t lf_beams_launches{0};   // launches of k_reweight_lf_beams (mcl_get_counter)
+  uint64_t lf_far_launches{0};     // launches of the gather kernel with the far-tile bitmap (dispersed sets)
   // scratch of the spatial ordering
   DeviceBuffer<uint32_t> d_route_u32;           // scratch of mcl_route_targets
   DeviceBuffer<uint32_t> d_sort_u32;            // keys[cap] perm[cap] table[1024 * nblocks] totals[1024]
@@ -312,7 +317,8 @@ struct mcl_ctx {
   FieldView field_view() const {
     return FieldView{d_field.ptr, W, H, 1. / resolution, origin_inverse, static_cast<float>(1. / cfg.lf.max_laser_distance),
                      d_cube.ptr, cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD_PROB ? 1 : 0,
-                     pal_count ? d_pal_idx.ptr : nullptr, d_pal_val.ptr, pal_count, pal_pitch, pal_base, pal_bytes};
+                     pal_count ? d_pal_idx.ptr : nullptr, d_pal_val.ptr, pal_count, pal_pitch, pal_base, pal_bytes,
+                     pal_count && far_tiles ? d_far_bits.ptr : nullptr, far_row_bytes, far_bytes, far_entry};
   }
   SortScratch sort_scratch() {
     SortScratch s{};
@@ -479,6 +485,7 @@ mcl_status rebuild_cube(mcl_ctx* ctx, const float* h_field) {
   MCL_HIP(ctx, hipGetLastError());
   // Palette: the distinct values of the field (a distance map quantised to cell offsets has a few hundred).
   ctx->pal_count = 0;
+  ctx->far_tiles = 0;
   const uint64_t tiles_x = (ctx->W + 7) / 8 + 2, tiles_y = (ctx->H + 7) / 8 + 2;  // one border tile on every side
   const uint32_t pal_base = ((ctx->H + 2) * 4u + 7u) & ~7u;                       // the kernel's row-offset table comes first in LDS
   if (h_field && tiles_x * tiles_y * 128 < (1ull << 31) && ctx->W < (1u << 26) && pal_base + 8 <= 65536) {
@@ -513,6 +520,29 @@ mcl_status rebuild_cube(mcl_ctx* ctx, const float* h_field) {
       ctx->pal_pitch = static_cast<uint32_t>(tiles_x * 128);
       ctx->pal_base = pal_base;
       ctx->pal_bytes = static_cast<uint32_t>(tiles_x * tiles_y * 128);
+      // Far tiles: the entry most tiles are uniformly equal to, and the bitmap of those tiles (FieldView::far_bits).
+      ctx->far_tiles = 0;
+      const uint32_t row_bytes = static_cast<uint32_t>((tiles_x + 7) / 8);
+      const uint32_t far_bytes = static_cast<uint32_t>((static_cast<uint64_t>(row_bytes) * tiles_y + 15) & ~15ull);
+      if (tiles_x * tiles_y < (1ull << 31) && far_bytes <= 48 * 1024 && row_bytes < (1u << 13)) {
+        MCL_HIP(ctx, ctx->d_far_votes.ensure(keys.size()));
+        MCL_HIP(ctx, ctx->d_far_bits.ensure(far_bytes));
+        launch_far_tile_votes(ctx->stream, ctx->d_pal_idx.ptr, static_cast<uint32_t>(tiles_x * tiles_y), pal_base,
+                              static_cast<uint32_t>(keys.size()), ctx->d_far_votes.ptr);
+        std::vector<uint32_t> votes(keys.size());
+        MCL_HIP(ctx, hipMemcpyAsync(votes.data(), ctx->d_far_votes.ptr, votes.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t best = static_cast<size_t>(std::max_element(votes.begin(), votes.end()) - votes.begin());
+        if (votes[best] * 8ull >= tiles_x * tiles_y) {  // worth a test per look-up from one tile in eight
+          ctx->far_entry = pal_base + static_cast<uint32_t>(best) * 8u;
+          ctx->far_row_bytes = row_bytes;
+          ctx->far_bytes = far_bytes;
+          launch_far_tile_bits(ctx->stream, ctx->d_pal_idx.ptr, static_cast<uint32_t>(tiles_x), static_cast<uint32_t>(tiles_y), ctx->far_entry,
+                               row_bytes, far_bytes, ctx->d_far_bits.ptr);
+          MCL_HIP(ctx, hipGetLastError());
+          ctx->far_tiles = votes[best];
+        }
+      }
     }
   }
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -727,12 +757,16 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     const bool scan_is_short = ctx->scan_extent / ctx->resolution < 8192.0;
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
     const bool use_patches = mode.patches;
+    bool far_tiles_used = false;
     if (mode.beams) ctx->lf_beams_launches += 1;
     launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B), variant, &sort,
                        scan_is_short, ctx->tuning, use_patches,
                        PatchStats{reinterpret_cast<unsigned long long*>(ctx->d_scalars.ptr + 24),
                                   reinterpret_cast<unsigned long long*>(ctx->hd_scalars + 28),
-                                  static_cast<uint32_t>(ctx->tuning.lf_loose_below)});
+                                  static_cast<uint32_t>(ctx->tuning.lf_loose_below)},
+                       /*dispersed=*/!use_patches && (ctx->tuning.lf_far_tiles == 2 || (ctx->tuning.lf_patch == 1 && !ctx->patch_useful)),
+                       &far_tiles_used);
+    if (far_tiles_used) ctx->lf_far_launches += 1;
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
     if (variant == kLfSortedLanes && ctx->tuning.lf_fast != 0 && scan_is_short && ctx->W < 16384 && ctx->H < 16384 && ctx->pal_count &&
         ctx->tuning.lf_table == 0)
@@ -1533,7 +1567,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     MCL_HIP(ctx, hipEventCreateWithFlags(&ctx->points_event, hipEventDisableTiming));
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
-    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_loose_below", "lf_small_particles", "device_policy",
+    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "lf_loose_below", "lf_small_particles", "device_policy",
                              "sort_min_particles", "beam_sort_min_particles", "field_build"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
@@ -1563,6 +1597,8 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_field_scratch.release();
   ctx->d_cube.release();
   ctx->d_pal_idx.release();
+  ctx->d_far_bits.release();
+  ctx->d_far_votes.release();
   ctx->d_pal_val.release();
   ctx->d_pal_keys.release();
   ctx->d_cells.release();
@@ -2382,6 +2418,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   Tuning& t = ctx->tuning;
   if (key == "lf_variant") t.lf_variant = value == 0 ? kLfWavePerParticle : (value == 1 ? kLfLanePerParticle : (value == 3 ? kLfBeamLanes : kLfSortedLanes));
   else if (key == "lf_dispersed") t.lf_dispersed = value ? 1 : 0;
+  else if (key == "lf_far_tiles") t.lf_far_tiles = value < 0 ? 0 : static_cast<int>(std::min<int64_t>(value, 2));
   else if (key == "lf_loose_below") t.lf_loose_below = static_cast<int>(std::clamp<int64_t>(value, 0, 257));
   else if (key == "lf_small_particles") t.lf_small_particles = value < 0 ? 0 : static_cast<int>(std::min<int64_t>(value, INT32_MAX));
   else if (key == "lf_fast") t.lf_fast = value < 0 ? -1 : (value ? 1 : 0);
@@ -2401,6 +2438,8 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
   if (key == "lf_fast_launches") *value = ctx->lf_fast_launches;
   else if (key == "lf_patch_launches") *value = ctx->lf_patch_launches;
   else if (key == "lf_beams_launches") *value = ctx->lf_beams_launches;
+  else if (key == "lf_far_launches") *value = ctx->lf_far_launches;
+  else if (key == "lf_far_tiles") *value = ctx->far_tiles;
   else if (key == "lf_patch_groups_planned" || key == "lf_patch_groups_through") {
     if (const mcl_status s = bind_device(ctx)) return s;
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -44,6 +44,14 @@ struct FieldView {
   uint32_t pal_pitch;  // bytes per row of tiles (border included)
   uint32_t pal_base;   // LDS byte offset of the palette (after the row-offset table of H + 2 words)
   uint32_t pal_bytes;  // size of pal_idx in bytes
+  // Far tiles: one bit per 8x8 tile of pal_idx (border tiles included), set where all 64 cells hold the table's most common
+  // entry far_entry (free space beyond max_obstacle_distance of anything: more than half of a typical map).  Rows of
+  // far_row_bytes bytes, bit (tx & 7) of byte tx >> 3.  A look-up into such a tile needs no memory access at all; the gather
+  // kernel of DISPERSED sets keeps the bitmap in LDS (k_reweight_lf_palette<true, true>).  nullptr = none.
+  const uint8_t* far_bits;
+  uint32_t far_row_bytes;
+  uint32_t far_bytes;  // size of far_bits, a multiple of 16
+  uint32_t far_entry;  // LDS byte address of the common entry (as stored in pal_idx)
 };
 
 constexpr uint32_t kMaxPalette = 2048;
@@ -124,6 +132,8 @@ struct Tuning {
   int sort_min_particles = 16384;   // below this the ordering passes cost more than they save (likelihood-field models)
   int beam_sort_min_particles = 16384;  // beam model: the ordered kernel (LDS bit window, scan segments) from here on; below, a wave per
                                        // particle over the whole-grid maps (measured crossover: 12K particles at 180 beams, 28K at 1080)
+  int lf_far_tiles = 1;             // the gather kernel skips look-ups into far tiles (FieldView::far_bits): 1 = for sets reported as
+                                    // dispersed (lf_patch = 1), 0 = never, 2 = whenever it gathers
   int lf_small_particles = 65536;   // likelihood-field sets below this: a wave per particle with the lanes over the beams, no ordering
                                     // (measured: 25 % faster than the ordered kernels at 20K particles, 10 % at 50K, 12 % slower at 100K)
   int field_build = 0;              // mcl_set_map: 0 = host wavefront (bit-identical to the reference), 1 = exact EDT on the device
@@ -174,7 +184,8 @@ struct PatchStats {
   uint32_t loose_below;        // a workgroup with fewer than loose_below / 256 of its groups fitting a patch gathers them all
 };
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
-                        const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats);
+                        const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
+                        bool dispersed = false, bool* far_tiles_used = nullptr);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_order_particles first).
 // d_beam_points: scratch of kBeamPointDoubles * B doubles (per-beam terms shared by all particles; ordered variant only).
@@ -330,6 +341,11 @@ void launch_cube_table(hipStream_t st, const float* field, uint64_t cells, float
 // keys: the sorted bit patterns of the distinct field values (count entries, unknown_value among them)
 void launch_palette_table(hipStream_t st, const float* field, uint32_t W, uint32_t H, float unknown_value, const uint32_t* keys,
                           uint32_t count, int prob, uint16_t* idx, double* val, uint32_t pal_base);
+// Far tiles of a palette table (FieldView::far_bits).  votes[k] (count entries, zeroed here) = number of tiles uniformly equal
+// to entry k; the caller picks the entry and has launch_far_tile_bits write the bitmap (far_bytes bytes).
+void launch_far_tile_votes(hipStream_t st, const uint16_t* idx, uint32_t tiles, uint32_t pal_base, uint32_t count, uint32_t* votes);
+void launch_far_tile_bits(hipStream_t st, const uint16_t* idx, uint32_t tiles_x, uint32_t tiles_y, uint32_t entry, uint32_t row_bytes,
+                          uint32_t far_bytes, uint8_t* bits);
 // AoS (c,s,x,y) host layout <-> SoA device layout
 
 }  // namespace mcl

@@ -426,6 +426,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
 constexpr int kPalBlock = 512;
 typedef __attribute__((address_space(3))) const double lds_f64_t;
 typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) const uint8_t lds_u8_t;
 __device__ __forceinline__ int clamp_cell(int v, uint32_t hi) {  // max(-1, min(v, hi)) in one instruction
   int r;
   asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(v), "s"(hi));
@@ -479,12 +480,26 @@ __device__ __forceinline__ double lf_palette_value(uint32_t lds_address) {
 // holding a particle farther than 2^14 cells from the grid origin.  Clamps and offsets work on the biased high words.
 // 12 VALU ops per end-point instead of 17, same cells bit for bit; it pays where a wave's end-points fall into few
 // tiles (the gather costs a cycle per distinct line: profiles/r01_calib_gather_cost.txt), i.e. for dense particle sets.
-template <bool kFast>
+//
+// kFar (dispersed sets: global localisation, a kidnapped robot): neighbouring lanes are metres and radians apart, every look-up
+// is a cache line of its own, and the launch is bound by what the L2 misses pull in (profiles/r02_dispersed_study.txt).  But
+// more than half of a map is free space farther than max_obstacle_distance from anything, where the field holds one value:
+// the bitmap of such tiles (FieldView::far_bits, 32 KB for 4000^2 cells) sits in LDS at far_base, a look-up into a far tile
+// takes the common entry without touching memory (its buffer offset is pushed out of range, which returns 0 and moves
+// nothing), and only the look-ups near obstacles or outside the grid reach the table.  Same entries, same sums.
+template <bool kFast, bool kFar = false>
 __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __restrict__ w, uint64_t n, FieldView f,
                                                                    const double* __restrict__ pts, uint32_t B,
                                                                    const uint32_t* __restrict__ perm, const double4* __restrict__ pose,
-                                                                   double* __restrict__ partial, uint32_t beams_per_segment) {
+                                                                   double* __restrict__ partial, uint32_t beams_per_segment,
+                                                                   uint32_t far_base) {
+  static_assert(kFast || !kFar, "far tiles ride on the biased coordinates of the FMA variant");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if constexpr (kFar) {
+    const uint4* src = reinterpret_cast<const uint4*>(f.far_bits);
+    uint4* dst = reinterpret_cast<uint4*>(smem + far_base);
+    for (uint32_t j = threadIdx.x; j < f.far_bytes / 16; j += kPalBlock) dst[j] = src[j];
+  }
   {
     uint32_t* s_row = reinterpret_cast<uint32_t*>(smem);
     constexpr uint32_t row_fix_stored = kFast ? kFastBiasX : 0u;
@@ -548,8 +563,18 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
           near_integer = min3_u32(near_integer, static_cast<uint32_t>(bx), static_cast<uint32_t>(by));
           const int xc = med3_i32(static_cast<int>(bx >> 32), c_lo, x_hi), yc = med3_i32(static_cast<int>(by >> 32), c_lo, y_hi);
           const uint32_t row = *reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>((static_cast<uint32_t>(yc) << 2) + row_bias));
-          e[k] = static_cast<uint32_t>(
-              static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, (static_cast<uint32_t>(xc) << 4) + row, 0, 0)));
+          uint32_t offset = (static_cast<uint32_t>(xc) << 4) + row;
+          uint32_t common = 0u;
+          if constexpr (kFar) {
+            // tile of the clamped cell, border included: (coordinate - kFastBias + 8) >> 3; kFastBias has 19 zero low bits
+            const uint32_t tx8 = static_cast<uint32_t>(xc) + 8u, ty8 = static_cast<uint32_t>(yc) + 8u;
+            const uint32_t at = mad_u24(__builtin_amdgcn_ubfe(ty8, 3, 16), f.far_row_bytes, __builtin_amdgcn_ubfe(tx8, 6, 13)) + far_base;
+            const uint32_t byte = *reinterpret_cast<lds_u8_t*>(static_cast<uintptr_t>(at));
+            const bool far = __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(tx8, 3, 3), 1) != 0u;
+            offset = far ? 0xFFFFFFF0u : offset;
+            common = far ? f.far_entry : 0u;
+          }
+          e[k] = static_cast<uint32_t>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, offset, 0, 0))) | common;
         }
         if (__builtin_amdgcn_ballot_w64(near_integer == 0) != 0) issue(e, b0);  // an end-point on a cell boundary: exact path
       };
@@ -3229,6 +3254,46 @@ __global__ __launch_bounds__(kBlock) void k_palette_indices(const float* __restr
   if (x >= 0 && x < W && y >= 0 && y < H) v = field[static_cast<size_t>(y) * W + static_cast<size_t>(x)];
   idx[slot] = static_cast<uint16_t>(pal_base + palette_find(keys, count, __builtin_bit_cast(uint32_t, v)) * 8u);
 }
+// Far tiles (FieldView::far_bits).  A tile is 64 uint16 = 8 x uint4; votes[k] counts the tiles uniformly equal to entry k.
+__device__ __forceinline__ bool tile_is_uniform(const uint16_t* __restrict__ idx, uint64_t tile, uint32_t* entry) {
+  const uint4* t = reinterpret_cast<const uint4*>(idx) + tile * 8;
+  const uint4 first = t[0];
+  const uint32_t pair = first.x;
+  bool same = (pair >> 16) == (pair & 0xFFFFu) && first.y == pair && first.z == pair && first.w == pair;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    const uint4 v = t[k];
+    same = same && v.x == pair && v.y == pair && v.z == pair && v.w == pair;
+  }
+  *entry = pair & 0xFFFFu;
+  return same;
+}
+__global__ __launch_bounds__(kBlock) void k_far_tile_votes(const uint16_t* __restrict__ idx, uint32_t tiles, uint32_t pal_base,
+                                                           uint32_t count, uint32_t* __restrict__ votes) {
+  const uint32_t tile = blockIdx.x * kBlock + threadIdx.x;
+  if (tile >= tiles) return;
+  uint32_t entry;
+  if (!tile_is_uniform(idx, tile, &entry)) return;
+  const uint32_t k = (entry - pal_base) >> 3;
+  if (k < count) atomicAdd(votes + k, 1u);
+}
+// One thread per byte of the bitmap (8 tiles of one row of tiles).
+__global__ __launch_bounds__(kBlock) void k_far_tile_bits(const uint16_t* __restrict__ idx, uint32_t tiles_x, uint32_t tiles_y,
+                                                          uint32_t entry, uint32_t row_bytes, uint32_t far_bytes,
+                                                          uint8_t* __restrict__ bits) {
+  const uint32_t at = blockIdx.x * kBlock + threadIdx.x;
+  if (at >= far_bytes) return;
+  const uint32_t ty = at / row_bytes, bx = at % row_bytes;
+  uint32_t byte = 0;
+  if (ty < tiles_y) {
+    for (uint32_t k = 0; k < 8; ++k) {
+      const uint32_t tx = bx * 8 + k;
+      uint32_t found;
+      if (tx < tiles_x && tile_is_uniform(idx, static_cast<uint64_t>(ty) * tiles_x + tx, &found) && found == entry) byte |= 1u << k;
+    }
+  }
+  bits[at] = static_cast<uint8_t>(byte);
+}
 __global__ __launch_bounds__(kBlock) void k_fill(double* p, uint64_t n, double v) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i < n) p[i] = v;
@@ -3288,7 +3353,9 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
 }
 
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
-                        const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats) {
+                        const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
+                        bool dispersed, bool* far_tiles_used) {
+  if (far_tiles_used) *far_tiles_used = false;
   if (n == 0) return;
   const bool idx32 = static_cast<uint64_t>(f.W) * f.H < (1ull << 31);
   if (variant == kLfSortedLanes && sort && n < (1ull << 32)) {
@@ -3318,12 +3385,16 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
         hipLaunchKernelGGL(k_reweight_lf_patch, dim3(static_cast<unsigned>((n + kPatchParticles - 1) / kPatchParticles), segments),
                            dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial, per_segment, patch_base,
                            patch_stats);
-      else if (fast)
+      else if (fast && dispersed && tuning.lf_far_tiles != 0 && f.far_bits != nullptr && patch_base + f.far_bytes <= 65536) {
+        hipLaunchKernelGGL((k_reweight_lf_palette<true, true>), pgrid, dim3(kPalBlock), patch_base + f.far_bytes, st, p.w, n, f, d_points, B,
+                           sort->perm, p.pose, partial, per_segment, patch_base);
+        if (far_tiles_used) *far_tiles_used = true;
+      } else if (fast)
         hipLaunchKernelGGL(k_reweight_lf_palette<true>, pgrid, dim3(kPalBlock), pal_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose,
-                           partial, per_segment);
+                           partial, per_segment, 0u);
       else
         hipLaunchKernelGGL(k_reweight_lf_palette<false>, pgrid, dim3(kPalBlock), pal_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose,
-                           partial, per_segment);
+                           partial, per_segment, 0u);
     } else if (cube_ok) {
       hipLaunchKernelGGL(k_reweight_lf_sorted<true>, grid, dim3(kBlock), 0, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial,
                          per_segment);
@@ -3715,6 +3786,15 @@ void launch_palette_table(hipStream_t st, const float* field, uint32_t W, uint32
   const uint64_t slots = static_cast<uint64_t>(tiles_x) * tiles_y * 64;
   hipLaunchKernelGGL(k_palette_indices, dim3(blocks_for(slots)), dim3(kBlock), 0, st, field, W, H, tiles_x, tiles_y, unknown_value,
                      keys, count, pal_base, idx);
+}
+void launch_far_tile_votes(hipStream_t st, const uint16_t* idx, uint32_t tiles, uint32_t pal_base, uint32_t count, uint32_t* votes) {
+  (void)hipMemsetAsync(votes, 0, count * sizeof(uint32_t), st);
+  hipLaunchKernelGGL(k_far_tile_votes, dim3(blocks_for(tiles)), dim3(kBlock), 0, st, idx, tiles, pal_base, count, votes);
+}
+void launch_far_tile_bits(hipStream_t st, const uint16_t* idx, uint32_t tiles_x, uint32_t tiles_y, uint32_t entry, uint32_t row_bytes,
+                          uint32_t far_bytes, uint8_t* bits) {
+  hipLaunchKernelGGL(k_far_tile_bits, dim3(blocks_for(far_bytes)), dim3(kBlock), 0, st, idx, tiles_x, tiles_y, entry, row_bytes, far_bytes,
+                     bits);
 }
 void launch_fill(hipStream_t st, double* p, uint64_t n, double v) {
   if (n == 0) return;

@@ -158,6 +158,52 @@ def test_mid_size_sets_take_the_kernel_for_small_sets():
         f.close()
 
 
+@pytest.mark.parametrize("case", ["rooms", "rotated_ragged", "turtlebot", "unknown_space"])
+def test_far_tile_bitmap_changes_no_weight(case):
+    """The gather kernel with the bitmap of far tiles (8x8-cell tiles uniformly at the field's most common value; look-ups into
+    them skip the table) against the same kernel without it: bit for bit, on particles spread over and beyond the map with any
+    heading - grids whose sides are no multiples of 8, a rotated origin, the unknown-space overlay (where the common value
+    may be another one) - and against the oracle."""
+    sensor = LF
+    if case == "rooms":
+        grid = rooms_grid()
+    elif case == "rotated_ragged":
+        grid = OccupancyGrid(synth.make_rooms_map(203, 157, seed=9, n_rooms=5), 0.1, origin=se2_from_xytheta(3.0, -2.0, 0.7))
+    elif case == "turtlebot":
+        grid = turtlebot_grid()
+    else:
+        cells = synth.make_rooms_map(333, 250, seed=4, n_rooms=7).copy()
+        cells[:, 200:] = -1  # a third of the map unknown
+        grid = OccupancyGrid(cells, 0.05, origin=se2_from_xytheta(-4.0, 1.0, -0.3))
+        sensor = LikelihoodFieldModelParam(2.0, 100.0, 0.5, 0.5, 0.2, True)
+    H, W = grid.cells.shape
+    n = 20_000
+    rng = np.random.Generator(np.random.MT19937(17))
+    gx = rng.uniform(-0.15 * W, 1.15 * W, n) * grid.resolution  # in the grid frame, beyond its borders too
+    gy = rng.uniform(-0.15 * H, 1.15 * H, n) * grid.resolution
+    oc, os_, ox, oy = grid.origin
+    x, y = ox + oc * gx - os_ * gy, oy + os_ * gx + oc * gy
+    th = rng.uniform(-np.pi, np.pi, n)
+    states = np.stack([np.cos(th), np.sin(th), x, y], axis=1)
+    pts = synth.scan_points(rng.uniform(0.3, 9.0, 363), synth.lidar_angles(363, 300.0))
+    f = new_filter(grid, n, sensor=sensor)
+    f.set_option("lf_patch", 0)
+    f.set_option("lf_far_tiles", 0)
+    f.set_particles(states, np.ones(n))
+    f.reweight(pts)
+    plain = f.particles()[1]
+    assert f.counter("lf_far_launches") == 0 and f.counter("lf_fast_launches") == 1
+    f.set_option("lf_far_tiles", 2)
+    f.set_particles(states, np.ones(n))
+    f.reweight(pts)
+    assert f.counter("lf_far_tiles") > 0 and f.counter("lf_far_launches") == 1
+    assert np.array_equal(f.particles()[1], plain)
+    want = orc.lf_weights(f.likelihood_field(), grid.resolution, grid.origin, sensor.max_laser_distance, states, pts,
+                          threads=orc.max_threads())
+    np.testing.assert_allclose(plain, want, rtol=RTOL)
+    f.close()
+
+
 def test_reweight_lf_rotated_origin_and_empty_scan():
     cells = synth.make_rooms_map(200, 150, seed=9, n_rooms=6)
     grid = OccupancyGrid(cells, 0.1, origin=se2_from_xytheta(3.0, -2.0, 0.7))
@@ -1113,9 +1159,11 @@ def test_ten_million_particles_sampled_against_oracle():
 def test_dispersed_cloud_1m_sampled_against_oracle():
     """The worst case for the spatially ordered lanes: 1M particles from initialize_from_map on the 4000^2 map (global
     localisation; neighbours in any order are metres and radians apart).  initialize_from_map says so, and the reweight goes
-    straight to the ordered-lanes gather kernel; the LDS-patch kernel, tried on the same set, finds next to no group of beams
-    that fits a patch and reports it, which sends the launches after it to the gather kernel as well (option lf_patch = 1).
-    Same weights bit for bit; a 1024-particle sample against the oracle.  Option lf_dispersed = 1 sends such sets to
+    straight to the ordered-lanes gather kernel - in its far-tile form: look-ups into tiles of free space far from any
+    obstacle (a bitmap in LDS) take the field's common value without a memory access; the LDS-patch kernel, tried on the same
+    set, finds next to no group of beams that fits a patch and reports it, which sends the launches after it to the gather
+    kernel as well (option lf_patch = 1).  Same weights bit for bit with and without the bitmap (option lf_far_tiles) and from
+    the patch kernel; a 1024-particle sample against the oracle.  Option lf_dispersed = 1 sends such sets to
     k_reweight_lf_beams instead (wave per particle, lane per beam, no ordering pass: measured slower, kept as a switch); its
     lane sums are added in a tree: same weights up to rounding."""
     size = 4000
@@ -1130,7 +1178,18 @@ def test_dispersed_cloud_1m_sampled_against_oracle():
     assert np.all(w0 == 1.0)
     f.reweight(pts)
     assert f.counter("lf_beams_launches") == 0 and f.counter("lf_patch_launches") == 0 and f.counter("lf_fast_launches") == 1
+    tiles = (size // 8 + 2) ** 2
+    assert f.counter("lf_far_launches") == 1 and tiles // 4 < f.counter("lf_far_tiles") < tiles
     w = f.particles()[1]
+    # without the bitmap: every look-up goes to the table
+    f.set_option("lf_far_tiles", 0)
+    f.set_particles(states, w0)
+    f.set_option("lf_patch", 0)
+    f.reweight(pts)
+    assert f.counter("lf_far_launches") == 1 and f.counter("lf_fast_launches") == 2 and f.counter("lf_patch_launches") == 0
+    assert np.array_equal(f.particles()[1], w)
+    f.set_option("lf_far_tiles", 1)
+    f.set_option("lf_patch", 1)
     sample = np.random.Generator(np.random.MT19937(1)).choice(n, 1024, replace=False)
     want = orc.lf_weights(f.likelihood_field(), 0.05, grid.origin, 100.0, states[sample], pts, threads=orc.max_threads())
     np.testing.assert_allclose(w[sample], want, rtol=RTOL)
@@ -1140,9 +1199,9 @@ def test_dispersed_cloud_1m_sampled_against_oracle():
     planned, through = f.counter("lf_patch_groups_planned"), f.counter("lf_patch_groups_through")
     assert f.counter("lf_patch_launches") == 1 and planned >= (n // 448 // 16) * 135 and through * 4 < planned
     assert np.array_equal(f.particles()[1], w)
-    # ... and the launch after that report gathers again (the weights multiply)
+    # ... and the launch after that report gathers again, with the bitmap (the weights multiply)
     f.reweight(pts)
-    assert f.counter("lf_patch_launches") == 1 and f.counter("lf_beams_launches") == 0
+    assert f.counter("lf_patch_launches") == 1 and f.counter("lf_beams_launches") == 0 and f.counter("lf_far_launches") == 2
     assert np.array_equal(f.particles()[1], w * w)
     # option lf_dispersed = 1: the wave-per-particle kernel for sets reported as dispersed
     f.set_option("lf_dispersed", 1)

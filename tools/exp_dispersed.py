@@ -1,6 +1,6 @@
 """Dispersed 1M-particle set (initialize_from_map on the bench map): one LF reweight per kernel family, timed by the library's
 HIP events; run under rocprofv3 --pmc to see what each one asks of the memory system.
-Usage: python tools/exp_dispersed.py [variants...]   variants: beams gather patch lane wave"""
+Usage: python tools/exp_dispersed.py [variants...]   variants: beams gather far patch lane wave"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,8 @@ n = int(os.environ.get("N", 1_000_000))
 f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF), AmclParams(min_particles=n, max_particles=n), seed=42)
 f.initialize_from_map()
 states, w0 = f.particles()
-OPTS = {"beams": {"lf_variant": 3}, "gather": {"lf_variant": 2, "lf_patch": 0}, "patch": {"lf_variant": 2, "lf_patch": 2},
+OPTS = {"beams": {"lf_variant": 3}, "gather": {"lf_variant": 2, "lf_patch": 0, "lf_far_tiles": 0},
+        "far": {"lf_variant": 2, "lf_patch": 0, "lf_far_tiles": 2}, "patch": {"lf_variant": 2, "lf_patch": 2},
         "lane": {"lf_variant": 1}, "wave": {"lf_variant": 0}}
 ref = None
 for v in variants:
@@ -32,5 +33,5 @@ for v in variants:
     w = f.particles()[1]
     if ref is None:
         ref = w
-    print(v, "sensor_kernel_ms", [round(x, 3) for x in ms], "max rel diff vs first", float(np.max(np.abs(w - ref) / ref)), flush=True)
+    print(v, "far launches", f.counter("lf_far_launches"), "far tiles", f.counter("lf_far_tiles"), "sensor_kernel_ms", [round(x, 3) for x in ms], "max rel diff vs first", float(np.max(np.abs(w - ref) / ref)), flush=True)
 f.close()
