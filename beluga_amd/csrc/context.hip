@@ -591,7 +591,17 @@ void points_pulled(mcl_ctx* ctx, bool with_event) {
 
 // The frame of the ordering keys for the set as it will be AFTER this propagation: the last estimate moved by the mean
 // motion, spans widened by the motion noise.  Only the balance of the key's bins depends on it.
+// KeyFrame::layout of the next ordering: position-major for likelihood-field sets reported as dispersed (their gather kernel
+// walks the order region by region, kernels.hip: k_reweight_lf_palette<true, true>), heading-major otherwise.
+uint32_t key_layout(const mcl_ctx* ctx) {
+  if (ctx->tuning.key_layout >= 0) return ctx->tuning.key_layout ? 1u : 0u;
+  return ctx->cfg.sensor_kind != MCL_SENSOR_BEAM && ctx->tuning.lf_patch == 1 && !ctx->patch_useful && ctx->tuning.lf_far_tiles != 0 &&
+                 ctx->far_tiles != 0
+             ? 1u
+             : 0u;
+}
 bool predict_key_frame(const mcl_ctx* ctx, const DiffDriveSampler* motion, KeyFrame* out) {
+  out->layout = key_layout(ctx);
   if (!ctx->have_cloud_estimate) return false;
   double x = ctx->cloud_mean[0], y = ctx->cloud_mean[1], t = ctx->cloud_mean[2];
   double sx = ctx->cloud_sigma[0], sy = ctx->cloud_sigma[1], st = ctx->cloud_sigma[2];
@@ -611,14 +621,17 @@ bool predict_key_frame(const mcl_ctx* ctx, const DiffDriveSampler* motion, KeyFr
     st = std::sqrt(st * st + 0.02 * 0.02);
   }
   if (!(std::isfinite(x) && std::isfinite(y) && std::isfinite(t) && std::isfinite(sx) && std::isfinite(sy) && std::isfinite(st))) return false;
-  auto inverse_span = [](double sigma) { return sigma > 0.0 ? static_cast<float>(1.0 / (8.0 * sigma)) : 0.f; };  // +- 4 sigma
+  // +- 4 sigma; a dispersed set is closer to uniform than to normal: +- 2 sigma hold all of a uniform one
+  const double spans = out->layout ? 4.0 : 8.0;
+  auto inverse_span = [spans](double sigma) { return sigma > 0.0 ? static_cast<float>(1.0 / (spans * sigma)) : 0.f; };
+  auto sigma_span_t = [](double sigma) { return sigma > 0.0 ? static_cast<float>(1.0 / (8.0 * sigma)) : 0.f; };
   out->cx = x;
   out->cy = y;
   out->c0 = std::cos(t);
   out->s0 = std::sin(t);
   out->inv_x = inverse_span(sx);
   out->inv_y = inverse_span(sy);
-  out->inv_t = inverse_span(std::min(st, kPi / 4.0));  // the heading bins never span more than the circle
+  out->inv_t = sigma_span_t(std::min(st, kPi / 4.0));  // the heading bins never span more than the circle
   out->t_off = 0.f;
   return true;
 }
@@ -743,7 +756,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     KeyFrame frame{};
     // The ordering also serves the beam model: both kernels gather the pose records through sort.perm.
     const bool have_frame = !keys_ready && predict_key_frame(ctx, nullptr, &frame);
-    launch_order_particles(ctx->stream, ctx->cur(), ctx->n, &sort, have_frame ? &frame : nullptr, keys_ready);
+    launch_order_particles(ctx->stream, ctx->cur(), ctx->n, &sort, have_frame ? &frame : nullptr, keys_ready, frame.layout);
   }
   if (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM) {
     // Below a few thousand particles the ordering passes cost more than they save.
@@ -1567,7 +1580,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     MCL_HIP(ctx, hipEventCreateWithFlags(&ctx->points_event, hipEventDisableTiming));
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
-    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "lf_loose_below", "lf_small_particles", "device_policy",
+    for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
                              "sort_min_particles", "beam_sort_min_particles", "field_build"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
@@ -2418,6 +2431,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   Tuning& t = ctx->tuning;
   if (key == "lf_variant") t.lf_variant = value == 0 ? kLfWavePerParticle : (value == 1 ? kLfLanePerParticle : (value == 3 ? kLfBeamLanes : kLfSortedLanes));
   else if (key == "lf_dispersed") t.lf_dispersed = value ? 1 : 0;
+  else if (key == "key_layout") t.key_layout = value < 0 ? -1 : (value ? 1 : 0);
   else if (key == "lf_far_tiles") t.lf_far_tiles = value < 0 ? 0 : static_cast<int>(std::min<int64_t>(value, 2));
   else if (key == "lf_loose_below") t.lf_loose_below = static_cast<int>(std::clamp<int64_t>(value, 0, 257));
   else if (key == "lf_small_particles") t.lf_small_particles = value < 0 ? 0 : static_cast<int>(std::min<int64_t>(value, INT32_MAX));
@@ -2461,7 +2475,7 @@ mcl_status mcl_debug_order(mcl_ctx* ctx, uint32_t* perm, uint32_t* keys) {
   const SortScratch sort = ctx->sort_scratch();
   KeyFrame frame{};
   const bool have_frame = predict_key_frame(ctx, nullptr, &frame);
-  launch_order_particles(ctx->stream, ctx->cur(), ctx->n, &sort, have_frame ? &frame : nullptr, false);
+  launch_order_particles(ctx->stream, ctx->cur(), ctx->n, &sort, have_frame ? &frame : nullptr, false, frame.layout);
   MCL_HIP(ctx, hipGetLastError());
   MCL_HIP(ctx, hipMemcpyAsync(perm, sort.perm, ctx->n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   MCL_HIP(ctx, hipMemcpyAsync(keys, sort.keys, ctx->n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

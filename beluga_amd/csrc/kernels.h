@@ -134,6 +134,7 @@ struct Tuning {
                                        // particle over the whole-grid maps (measured crossover: 12K particles at 180 beams, 28K at 1080)
   int lf_far_tiles = 1;             // the gather kernel skips look-ups into far tiles (FieldView::far_bits): 1 = for sets reported as
                                     // dispersed (lf_patch = 1), 0 = never, 2 = whenever it gathers
+  int key_layout = -1;              // ordering key: -1 = position-major for dispersed likelihood-field sets, heading-major otherwise; 0 / 1 force
   int lf_small_particles = 65536;   // likelihood-field sets below this: a wave per particle with the lanes over the beams, no ordering
                                     // (measured: 25 % faster than the ordered kernels at 20K particles, 10 % at 50K, 12 % slower at 100K)
   int field_build = 0;              // mcl_set_map: 0 = host wavefront (bit-identical to the reference), 1 = exact EDT on the device
@@ -149,6 +150,8 @@ struct KeyFrame {
   double c0, s0;          // heading of the centre of the heading bins
   float inv_x, inv_y;     // 1 / span of the x / y bins (span = 8 sigma)
   float inv_t, t_off;     // heading bins: u = (delta - t_off) * inv_t + 0.5
+  uint32_t layout;        // 0: heading-major key (dense sets: a workgroup's poses fit an LDS patch), 1: position-major key
+                          // (dispersed sets: neighbours in the order share a region of the map, whatever their heading)
 };
 constexpr uint32_t kSortDigits = 1024;  // two least-significant-digit-first passes of 10 bits each
 struct SortScratch {
@@ -174,7 +177,9 @@ void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler 
 void launch_pull_scan(hipStream_t st, const double* scan_src, double* scan_dst, uint32_t scan_doubles);
 // Full sort of the particles by the ordering key -> sort->perm.  frame == nullptr: bounding-box pass + device-resident frame.
 // keys_ready: launch_propagate already wrote sort->keys and the first pass's block histograms.
-void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortScratch* sort, const KeyFrame* frame, bool keys_ready);
+// layout: KeyFrame::layout of the device-resident frame (a host frame carries its own).
+void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortScratch* sort, const KeyFrame* frame, bool keys_ready,
+                            uint32_t layout = 0);
 // K2  actions/reweight.hpp:53-60 + likelihood_field_model.hpp:68-91 (kLfSortedLanes needs launch_order_particles first)
 // scan_is_short: every scan point lies within 8192 cells of the sensor (precondition of the kernel's FMA variant)
 // use_patches: the LDS-patch kernel where its preconditions hold (dense sets); patch_stats: running totals it reports

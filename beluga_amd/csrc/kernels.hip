@@ -91,6 +91,10 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], double* s_scratch /
 // 20 bits: x, y in 64 bins each, heading in 256 bins over the key frame's span; the two top heading bits first, the
 // remaining 6 + 6 + 6 bits Morton-interleaved (heading, y, x).  Only locality depends on the key, never a result, so it
 // is evaluated in single precision.
+// KeyFrame::layout = 1 (sets reported as dispersed): 12 bits of (y, x) Morton-interleaved first, the 8 heading bits last.  Poses
+// metres apart share no cache line whatever their headings, but the end-points of a REGION's poses stay within max range of it:
+// with the order position-major and each XCD walking one contiguous eighth of it (k_reweight_lf_palette<true, true>), the part
+// of the table an XCD's L2 has to hold at any time is the neighbourhood of a block of the map instead of all of it.
 constexpr uint32_t kKeyBitsXY = 6, kKeyBitsTheta = 8, kKeyBits = 2 * kKeyBitsXY + kKeyBitsTheta;
 constexpr uint32_t kDigitBits = 10;
 static_assert((1u << kDigitBits) == kSortDigits && kKeyBits == 2 * kDigitBits, "two passes of one digit each");
@@ -100,6 +104,13 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // ...edcba -> ..e00d
   v = (v | (v << 8)) & 0x0300F00F;
   v = (v | (v << 4)) & 0x030C30C3;
   v = (v | (v << 2)) & 0x09249249;
+  return v;
+}
+__device__ __forceinline__ uint32_t spread2(uint32_t v) {  // ..fedcba -> .f0e0d0c0b0a
+  v &= 0x3F;
+  v = (v | (v << 4)) & 0x30F;
+  v = (v | (v << 2)) & 0x333;
+  v = (v | (v << 1)) & 0x555;
   return v;
 }
 __device__ __forceinline__ int unit_bin(float u, int bins) {  // u in [0, 1) inside the span; clamped outside (NaN -> 0)
@@ -115,6 +126,7 @@ __device__ __forceinline__ uint32_t order_key(const double4& q, const KeyFrame& 
   const float ut = (delta - kf.t_off) * kf.inv_t + 0.5f;
   const uint32_t bx = static_cast<uint32_t>(unit_bin(ux, 1 << kKeyBitsXY)), by = static_cast<uint32_t>(unit_bin(uy, 1 << kKeyBitsXY));
   const uint32_t bt = static_cast<uint32_t>(unit_bin(ut, 1 << kKeyBitsTheta));
+  if (kf.layout != 0) return ((spread2(bx) | (spread2(by) << 1)) << kKeyBitsTheta) | bt;
   return ((bt >> kKeyBitsXY) << (3 * kKeyBitsXY)) | spread3(bx) | (spread3(by) << 1) | (spread3(bt & ((1u << kKeyBitsXY) - 1)) << 2);
 }
 
@@ -487,6 +499,7 @@ __device__ __forceinline__ double lf_palette_value(uint32_t lds_address) {
 // the bitmap of such tiles (FieldView::far_bits, 32 KB for 4000^2 cells) sits in LDS at far_base, a look-up into a far tile
 // takes the common entry without touching memory (its buffer offset is pushed out of range, which returns 0 and moves
 // nothing), and only the look-ups near obstacles or outside the grid reach the table.  Same entries, same sums.
+__device__ __forceinline__ uint32_t far_block(uint32_t b, uint32_t blocks /* a multiple of 8 */) { return (b & 7u) * (blocks >> 3) + (b >> 3); }
 template <bool kFast, bool kFar = false>
 __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __restrict__ w, uint64_t n, FieldView f,
                                                                    const double* __restrict__ pts, uint32_t B,
@@ -496,6 +509,7 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
   static_assert(kFast || !kFar, "far tiles ride on the biased coordinates of the FMA variant");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if constexpr (kFar) {
+    if (static_cast<uint64_t>(far_block(blockIdx.x, gridDim.x)) * kPalBlock >= n) return;  // padding of the grid to 8 x
     const uint4* src = reinterpret_cast<const uint4*>(f.far_bits);
     uint4* dst = reinterpret_cast<uint4*>(smem + far_base);
     for (uint32_t j = threadIdx.x; j < f.far_bytes / 16; j += kPalBlock) dst[j] = src[j];
@@ -509,7 +523,10 @@ __global__ __launch_bounds__(kPalBlock) void k_reweight_lf_palette(double* __res
     for (uint32_t k = threadIdx.x; k < f.pal_count; k += kPalBlock) s_pal[k] = f.pal_val[k];
   }
   __syncthreads();
-  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kPalBlock + threadIdx.x;
+  // kFar: block b runs on XCD b % 8 (observed; nothing but speed depends on it) - XCD k takes the k-th contiguous eighth of the
+  // order, in order.  The grid is a multiple of 8 workgroups; the ones past the set have left above.
+  const uint32_t block = kFar ? far_block(blockIdx.x, gridDim.x) : blockIdx.x;
+  const uint64_t t = static_cast<uint64_t>(block) * kPalBlock + threadIdx.x;
   const uint64_t tt = t < n ? t : n - 1;
   const uint32_t i = perm[tt];
   const Pose2 T = ordered_pose(f.world_to_field, pose, i);  // likelihood_field_model.hpp:70
@@ -1173,7 +1190,8 @@ __global__ __launch_bounds__(kBlock) void k_bbox_partials(Particles p, uint64_t 
 
 // Also turns the box into the key frame of the ordering keys (bins over the box instead of +-4 sigma).
 __global__ __launch_bounds__(kBlock) void k_bbox_final(const double* __restrict__ partials, uint32_t count, uint32_t stride,
-                                                       double* __restrict__ out, Particles p, KeyFrame* __restrict__ frame) {
+                                                       double* __restrict__ out, Particles p, KeyFrame* __restrict__ frame,
+                                                       uint32_t layout) {
   __shared__ double scratch[(kBlock / 64) * 6];
   double v[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
   for (uint32_t b = threadIdx.x; b < count; b += kBlock)
@@ -1207,6 +1225,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final(const double* __restrict_
     kf.inv_y = inverse_span(v[2], v[3]);
     kf.inv_t = inverse_span(v[4], v[5]);
     kf.t_off = static_cast<float>(0.5 * (v[4] + v[5]));
+    kf.layout = layout;
     *frame = kf;
   }
 }
@@ -3329,7 +3348,8 @@ void launch_pull_scan(hipStream_t st, const double* scan_src, double* scan_dst, 
   hipLaunchKernelGGL(k_pull_scan, dim3(1), dim3(kBlock), 0, st, scan_src, scan_dst, scan_doubles);
 }
 
-void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortScratch* sort, const KeyFrame* frame, bool keys_ready) {
+void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortScratch* sort, const KeyFrame* frame, bool keys_ready,
+                            uint32_t layout) {
   if (n == 0 || !sort || n >= (1ull << 32)) return;
   const uint32_t nblocks = num_chunks(n);
   if (!keys_ready) {
@@ -3337,7 +3357,7 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
     if (!frame) {  // no estimate of the set on the host: bins over its bounding box
       double* partials = sort->bbox + 8;
       hipLaunchKernelGGL(k_bbox_partials, dim3(nblocks), dim3(kBlock), 0, st, p, n, partials, nblocks);
-      hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(kBlock), 0, st, partials, nblocks, nblocks, sort->bbox, p, sort->frame);
+      hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(kBlock), 0, st, partials, nblocks, nblocks, sort->bbox, p, sort->frame, layout);
       device_frame = sort->frame;
     }
     hipLaunchKernelGGL(k_order_keys, dim3(nblocks), dim3(kWide), 0, st, p, n, frame ? *frame : KeyFrame{}, device_frame, sort->keys,
@@ -3386,7 +3406,8 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
                            dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial, per_segment, patch_base,
                            patch_stats);
       else if (fast && dispersed && tuning.lf_far_tiles != 0 && f.far_bits != nullptr && patch_base + f.far_bytes <= 65536) {
-        hipLaunchKernelGGL((k_reweight_lf_palette<true, true>), pgrid, dim3(kPalBlock), patch_base + f.far_bytes, st, p.w, n, f, d_points, B,
+        const dim3 fgrid((pgrid.x + 7u) & ~7u, segments);
+        hipLaunchKernelGGL((k_reweight_lf_palette<true, true>), fgrid, dim3(kPalBlock), patch_base + f.far_bytes, st, p.w, n, f, d_points, B,
                            sort->perm, p.pose, partial, per_segment, patch_base);
         if (far_tiles_used) *far_tiles_used = true;
       } else if (fast)

@@ -386,6 +386,9 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                   field's most common value: free space beyond max_obstacle_distance of anything) and skips the memory access
  *                   of a look-up into one: 1 = for sets reported as dispersed, 0 = never, 2 = whenever that kernel runs.  Same
  *                   values, same sums (1M x 1080 dispersed over the 4000^2 map: 3.7 -> 1.9 ms per launch)
+ *   key_layout (-1)  spatial ordering key: -1 = position-major (y, x Morton-interleaved, heading last) for likelihood-field sets
+ *                   reported as dispersed - the far-tile gather kernel hands each XCD one contiguous eighth of that order, so an
+ *                   XCD's L2 serves the neighbourhood of one block of the map at a time - and heading-major otherwise; 0 / 1 force
  *   lf_small_particles (65536)  likelihood-field sets below this size: a wave per 1..16 particles, lanes over the beams, no
  *                   ordering pass (the measured crossover to the ordered kernels)
  *   device_policy (1)  recovery estimator on the device when the cycle takes no host-side decision

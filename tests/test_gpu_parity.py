@@ -163,7 +163,7 @@ def test_far_tile_bitmap_changes_no_weight(case):
     """The gather kernel with the bitmap of far tiles (8x8-cell tiles uniformly at the field's most common value; look-ups into
     them skip the table) against the same kernel without it: bit for bit, on particles spread over and beyond the map with any
     heading - grids whose sides are no multiples of 8, a rotated origin, the unknown-space overlay (where the common value
-    may be another one) - and against the oracle."""
+    may be another one) - and against the oracle.  The same under the position-major ordering key that dispersed sets get."""
     sensor = LF
     if case == "rooms":
         grid = rooms_grid()
@@ -177,7 +177,7 @@ def test_far_tile_bitmap_changes_no_weight(case):
         grid = OccupancyGrid(cells, 0.05, origin=se2_from_xytheta(-4.0, 1.0, -0.3))
         sensor = LikelihoodFieldModelParam(2.0, 100.0, 0.5, 0.5, 0.2, True)
     H, W = grid.cells.shape
-    n = 20_000
+    n = 21_013  # 42 workgroups of the gather kernel: its far-tile form pads the grid to 48 and hands each XCD a contiguous run
     rng = np.random.Generator(np.random.MT19937(17))
     gx = rng.uniform(-0.15 * W, 1.15 * W, n) * grid.resolution  # in the grid frame, beyond its borders too
     gy = rng.uniform(-0.15 * H, 1.15 * H, n) * grid.resolution
@@ -198,6 +198,13 @@ def test_far_tile_bitmap_changes_no_weight(case):
     f.reweight(pts)
     assert f.counter("lf_far_tiles") > 0 and f.counter("lf_far_launches") == 1
     assert np.array_equal(f.particles()[1], plain)
+    # the position-major ordering key of dispersed sets (forced here): another order of the lanes, the same weights
+    f.set_option("key_layout", 1)
+    f.set_particles(states, np.ones(n))
+    f.reweight(pts)
+    assert f.counter("lf_far_launches") == 2 and np.array_equal(f.particles()[1], plain)
+    perm, keys = f.debug_order()
+    assert np.array_equal(np.sort(perm), np.arange(n)) and np.all(np.diff(keys[perm].astype(np.int64)) >= 0)
     want = orc.lf_weights(f.likelihood_field(), grid.resolution, grid.origin, sensor.max_laser_distance, states, pts,
                           threads=orc.max_threads())
     np.testing.assert_allclose(plain, want, rtol=RTOL)

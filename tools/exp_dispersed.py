@@ -14,8 +14,10 @@ n = int(os.environ.get("N", 1_000_000))
 f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF), AmclParams(min_particles=n, max_particles=n), seed=42)
 f.initialize_from_map()
 states, w0 = f.particles()
-OPTS = {"beams": {"lf_variant": 3}, "gather": {"lf_variant": 2, "lf_patch": 0, "lf_far_tiles": 0},
-        "far": {"lf_variant": 2, "lf_patch": 0, "lf_far_tiles": 2}, "patch": {"lf_variant": 2, "lf_patch": 2},
+OPTS = {"beams": {"lf_variant": 3}, "gather": {"lf_variant": 2, "lf_patch": 0, "lf_far_tiles": 0, "key_layout": 0},
+        "far": {"lf_variant": 2, "lf_patch": 0, "lf_far_tiles": 2, "key_layout": 0},
+        "farpos": {"lf_variant": 2, "lf_patch": 0, "lf_far_tiles": 2, "key_layout": 1},
+        "gatherpos": {"lf_variant": 2, "lf_patch": 0, "lf_far_tiles": 0, "key_layout": 1}, "patch": {"lf_variant": 2, "lf_patch": 2},
         "lane": {"lf_variant": 1}, "wave": {"lf_variant": 0}}
 ref = None
 for v in variants:
