@@ -211,6 +211,45 @@ def test_far_tile_bitmap_changes_no_weight(case):
     f.close()
 
 
+def test_patch_probes_skip_hopelessly_sparse_sets():
+    """A set reported as dispersed is probed with the LDS-patch kernel every 16th launch (has it converged?) - unless the last
+    estimate says its poses are too sparse for any workgroup to fit a patch (the probe costs three far-tile launches)."""
+    grid = rooms_grid()
+    n = 40_000
+    pts = make_scan(grid, synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=2, clearance_cells=6),
+                    180, max_range=8.0)
+    # a wide cloud the library knows nothing about: the patch kernel runs, reports that next to nothing fits, the next 15
+    # launches gather (far-tile form), the 16th after the verdict is a probe
+    f = new_filter(grid, n)
+    f.set_particles(synth.normal_particles(n, (0.0, 0.0, 0.3), (3.0, 3.0, 1.5), seed=4), np.ones(n))
+    for _ in range(16):
+        f.reweight(pts)
+        f.sync()
+    assert f.counter("lf_patch_launches") == 1 and f.counter("lf_far_launches") == 15
+    f.reweight(pts)
+    assert f.counter("lf_patch_launches") == 2 and f.counter("lf_far_launches") == 15
+    f.close()
+    # initialize_from_map says what the set looks like (uniform over the map, every heading): too sparse here, never probed
+    f = new_filter(grid, n)
+    f.initialize_from_map()
+    for _ in range(20):
+        f.reweight(pts)
+    assert f.counter("lf_patch_launches") == 0 and f.counter("lf_far_launches") == 20
+    f.close()
+    # full cycles over a uniform set (no resampling, empty scans: the weights stay uniform): every estimate says "sparse"
+    f = new_filter(grid, n, resample_interval=1000, update_min_d=0.0, update_min_a=0.0)
+    f.initialize_from_map()
+    for c in range(20):
+        assert f.update(se2_from_xytheta(0.01 * c, 0.0, 0.0), np.zeros((0, 2))) is not None
+    assert f.counter("lf_patch_launches") == 0 and f.counter("lf_far_launches") == 20
+    # a dense set: the verdict is reset, the patch kernel runs and stays
+    f.set_particles(synth.normal_particles(n, (0.0, 0.0, 0.3), (0.3, 0.3, 0.1), seed=4), np.ones(n))
+    for c in range(3):
+        f.reweight(pts)
+    assert f.counter("lf_patch_launches") == 3
+    f.close()
+
+
 def test_reweight_lf_rotated_origin_and_empty_scan():
     cells = synth.make_rooms_map(200, 150, seed=9, n_rooms=6)
     grid = OccupancyGrid(cells, 0.1, origin=se2_from_xytheta(3.0, -2.0, 0.7))
