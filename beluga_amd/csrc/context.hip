@@ -607,10 +607,14 @@ bool predict_key_frame(const mcl_ctx* ctx, const DiffDriveSampler* motion, KeyFr
   double sx = ctx->cloud_sigma[0], sy = ctx->cloud_sigma[1], st = ctx->cloud_sigma[2];
   if (motion && motion->kind != MCL_MOTION_STATIONARY) {
     const double heading = t + (motion->kind == MCL_MOTION_DIFFERENTIAL ? motion->m1 : std::atan2(motion->first_s, motion->first_c));
-    x += motion->mt * std::cos(heading);
-    y += motion->mt * std::sin(heading);
+    // every pose moves along ITS heading: the set's mean moves by the translation times the mean resultant length of the headings
+    // (next to nothing for a set that points everywhere), and a heading error turns into a lateral one over the translation -
+    // mt * sigma_theta for a narrow set, at most mt / sqrt(2) per axis for headings all around
+    const double resultant = std::exp(-0.5 * st * st);
+    x += motion->mt * resultant * std::cos(heading);
+    y += motion->mt * resultant * std::sin(heading);
     t += motion->kind == MCL_MOTION_DIFFERENTIAL ? motion->m1 + motion->m2 : motion->m1;
-    const double lateral = motion->mt * st;  // a heading error turns into a lateral one over the translation
+    const double lateral = motion->mt * std::min(st, std::sqrt(0.5));
     const double noise2 = motion->st * motion->st + lateral * lateral + (motion->kind == MCL_MOTION_OMNIDIRECTIONAL ? motion->s2 * motion->s2 : 0.0);
     sx = std::sqrt(sx * sx + noise2);
     sy = std::sqrt(sy * sy + noise2);
