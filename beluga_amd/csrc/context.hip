@@ -246,6 +246,7 @@ struct mcl_ctx {
   DeviceBuffer<double> d_cell_f64;             // table wsum[cap_t] | list wsum[m_cap] | list state[4*m_cap]
   DeviceBuffer<unsigned int> d_cell_u32;       // table count[cap_t] cluster[cap_t] | list first,count,slot,cluster[m_cap] | size
   DeviceBuffer<unsigned long long> d_cell_u64; // list key[m_cap]
+  DeviceBuffer<double> d_cell_exchange;        // shards: this rank's cell records | the gathered records of all ranks
   int estimate_kind{0};
   mcl_cluster_params cluster_params{0.20, 0.524, 0.90};
 
@@ -654,10 +655,18 @@ void remember_cloud_estimate(mcl_ctx* ctx, const mcl_estimate& est) {
 // Whether the next LF launch goes to the LDS-patch kernel (where its other preconditions hold): by the verdict of the last
 // launch that has reported.  A dispersed set (global localisation) has no group that fits a patch, and the patch kernel's
 // workgroups carry a wave that would then do nothing.
-void patch_totals(const mcl_ctx* ctx, uint64_t* planned, uint64_t* through) {
+// synchronised: the stream is idle (the two 64-bit totals are consistent); otherwise the pair comes from the packed word the
+// kernel stores last (low 32 bits of each total in one 8-byte store: never torn; differences are taken modulo 2^32).
+void patch_totals(const mcl_ctx* ctx, uint64_t* planned, uint64_t* through, bool synchronised = false) {
   const volatile uint64_t* mirror = reinterpret_cast<const volatile uint64_t*>(ctx->h_scalars + 28);
-  *planned = mirror[0];
-  *through = mirror[1];
+  if (synchronised) {
+    *planned = mirror[0];
+    *through = mirror[1];
+    return;
+  }
+  const uint64_t packed = mirror[2];
+  *planned = packed & 0xFFFFFFFFull;
+  *through = packed >> 32;
 }
 // A workgroup of the patch kernel needs its 448 poses within a patch (64 x 64 cells less the margins) and within a few
 // hundredths of a radian.  From the last estimate's spread, taken as uniform (12 sigma_x sigma_y of area, sqrt(12) sigma_theta
@@ -676,8 +685,8 @@ bool wants_patches(mcl_ctx* ctx) {
   if (ctx->tuning.lf_patch != 1) return true;
   uint64_t planned, through;
   patch_totals(ctx, &planned, &through);
-  if (planned > ctx->patch_seen_planned) {  // a launch has reported since the last look
-    const uint64_t dp = planned - ctx->patch_seen_planned, dt = through - ctx->patch_seen_through;
+  if (planned != ctx->patch_seen_planned) {  // a launch has reported since the last look
+    const uint64_t dp = (planned - ctx->patch_seen_planned) & 0xFFFFFFFFull, dt = (through - ctx->patch_seen_through) & 0xFFFFFFFFull;
     ctx->patch_seen_planned = planned;
     ctx->patch_seen_through = through;
     ctx->patch_useful = 4 * dt >= dp;
@@ -749,6 +758,9 @@ mcl_status reweight_preconditions(mcl_ctx* ctx, uint64_t B) {
   MCL_REQUIRE(ctx, B <= 0x7FFFFFFFull, "too many points");
   if (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM)
     MCL_REQUIRE(ctx, B * sizeof(double2) <= 160 * 1024 || ctx->tuning.lf_variant != kLfWavePerParticle, "scan too large for LDS staging");
+  else if (!(ctx->n < (1ull << 32) && ctx->n >= static_cast<uint64_t>(ctx->tuning.beam_sort_min_particles)))
+    // the beam model's small-set kernel (a wave per particle) stages the scan in 64 KB of dynamic LDS
+    MCL_REQUIRE(ctx, B * sizeof(double2) <= 64 * 1024, "scan too large for the beam model's small-set kernel (4096 points)");
   return MCL_OK;
 }
 
@@ -942,6 +954,54 @@ mcl_status do_estimate_sums(mcl_ctx* ctx, const double pivot[2], double sums[12]
 }
 
 
+// ---- particle shards: the cycle over a communicator --------------------------------------------------------------------
+constexpr size_t kCommScalars = 16;  // d_comm_f64[0] local sum | [1] cdf total | [2] norm sum | [3] norm sumsq | [4] global sum | [5..14) estimate sums
+
+mcl_status comm_scratch(mcl_ctx* ctx) {
+  const size_t world = ctx->comm_world;
+  MCL_HIP(ctx, ctx->d_comm_f64.ensure(kCommScalars + world * (1 + 3 + 2 + 9)));
+  MCL_HIP(ctx, ctx->d_comm_i64.ensure(world + world * world));
+  if (!ctx->h_comm) MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_comm), (kCommScalars + 64 * (1 + 3 + 2 + 9) + 64 * 64 + 64) * sizeof(double)));
+  return MCL_OK;
+}
+mcl_status comm_gather(mcl_ctx* ctx, const void* d_send, void* d_recv, uint64_t bytes) {
+  if (ctx->transport.all_gather(ctx->transport.user, d_send, d_recv, bytes, ctx->stream) != 0)
+    return fail(ctx, MCL_ERR_HIP, "transport all_gather failed");
+  return MCL_OK;
+}
+mcl_status comm_exchange(mcl_ctx* ctx, const void* d_send, const uint64_t* send_bytes, void* d_recv, const uint64_t* recv_bytes) {
+  if (ctx->transport.all_to_all(ctx->transport.user, d_send, send_bytes, d_recv, recv_bytes, ctx->stream) != 0)
+    return fail(ctx, MCL_ERR_HIP, "transport all_to_all failed");
+  return MCL_OK;
+}
+
+// The nine estimate sums (estimation.hpp:436-475) over all shards: local sums - of the particles whose cell carries cluster id
+// wanted_plus_1 - 1 in t_cluster when t_cluster is given -, gathered, added in rank order by every rank.
+mcl_status sharded_estimate_sums(mcl_ctx* ctx, unsigned int* t_cluster, unsigned int wanted_plus_1, double sums[12], uint64_t slots = 0) {
+  if (const mcl_status s = comm_scratch(ctx)) return s;
+  const uint32_t world = ctx->comm_world;
+  double* d = ctx->d_comm_f64.ptr;
+  double* d_gather_est = d + kCommScalars + world * (1 + 3 + 2);  // [world][9]
+  if (ctx->n == 0) {
+    MCL_HIP(ctx, hipMemsetAsync(d + 5, 0, 9 * sizeof(double), ctx->stream));
+  } else if (t_cluster) {
+    launch_estimate_sums_cluster(ctx->stream, ctx->cur(), ctx->n, ctx->d_hashes.ptr, ctx->d_table_keys.ptr, t_cluster, slots, wanted_plus_1 - 1u,
+                                 ctx->pivot[0], ctx->pivot[1], ctx->chunk_row(0), d + 5);
+  } else {
+    launch_estimate_sums(ctx->stream, ctx->cur(), ctx->n, ctx->pivot[0], ctx->pivot[1], ctx->chunk_row(0), d + 5);
+  }
+  MCL_HIP(ctx, hipGetLastError());
+  if (const mcl_status s = comm_gather(ctx, d + 5, d_gather_est, 9 * sizeof(double))) return s;
+  launch_sum_rows(ctx->stream, d_gather_est, world, 9, ctx->d_scalars.ptr + 8, ctx->hd_scalars + 8);
+  MCL_HIP(ctx, hipGetLastError());
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 9; ++k) sums[k] = ctx->h_scalars[8 + k];
+  sums[9] = ctx->pivot[0];
+  sums[10] = ctx->pivot[1];
+  sums[11] = 0.0;
+  return MCL_OK;
+}
+
 // algorithm/spatial_hash.hpp:45-75,87-94,190-193 on the host (neighbour cells of the cluster flood fill).
 uint64_t host_floor_and_fibo_hash(double value, unsigned shift) {
   const int64_t sv = static_cast<int64_t>(std::floor(value));
@@ -958,7 +1018,8 @@ uint64_t host_spatial_hash(const Pose2& s, double res_xy, double res_theta) {
 // first-occurrence order so the containers evolve as they do in the reference.
 mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_estimate* out) {
   const uint64_t n = ctx->n;
-  if (n == 0) return fail(ctx, MCL_ERR_NOT_READY, "no particles");
+  const bool sharded = ctx->have_comm && ctx->comm_world > 1;
+  if (n == 0 && !sharded) return fail(ctx, MCL_ERR_NOT_READY, "no particles");  // (an empty shard still takes part in the exchange)
   MCL_REQUIRE(ctx, cp.linear_hash_resolution > 0 && cp.angular_hash_resolution > 0 && cp.weight_cap_percentile >= 0 &&
                        cp.weight_cap_percentile < 1.0, "bad cluster parameters");
   MCL_REQUIRE(ctx, n < 0xFFFFFFFFull, "too many particles");
@@ -1011,13 +1072,16 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
   cell_views(ctx->h_cells, hk, hw, hs, hf, hc, hsl, hcl, hsize);
   cell_views(ctx->hd_cells, dk, dw, ds, df, dc, dsl, dcl, dsize);
   const HashParams hp{cp.linear_hash_resolution, cp.linear_hash_resolution, cp.angular_hash_resolution};
-  launch_cluster_cells(ctx->stream, ctx->cur(), n, hp, ctx->d_hashes.ptr, ctx->d_table_keys.ptr, ctx->d_table_first.ptr, t_wsum,
-                       t_count, t_cluster, slots, dk, df, dc, dsl, dw, ds, c_size, kHostCells);
-  MCL_HIP(ctx, hipGetLastError());
-  MCL_HIP(ctx, hipMemcpyAsync(hsize, c_size, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  unsigned int m = *hsize;
-  MCL_REQUIRE(ctx, m >= 1 && m <= m_cap, "cell compaction failed");
+  unsigned int m = 0;
+  if (n) {
+    launch_cluster_cells(ctx->stream, ctx->cur(), n, hp, ctx->d_hashes.ptr, ctx->d_table_keys.ptr, ctx->d_table_first.ptr, t_wsum,
+                         t_count, t_cluster, slots, dk, df, dc, dsl, dw, ds, c_size, kHostCells);
+    MCL_HIP(ctx, hipGetLastError());
+    MCL_HIP(ctx, hipMemcpyAsync(hsize, c_size, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m = *hsize;
+    MCL_REQUIRE(ctx, m >= 1 && m <= m_cap, "cell compaction failed");
+  }
   std::vector<unsigned long long> key_big;
   std::vector<unsigned int> first_big, count_big;
   std::vector<double> wsum_big, state_big;
@@ -1036,11 +1100,13 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
     count_big.resize(m);
     wsum_big.resize(m);
     state_big.resize(4 * static_cast<size_t>(m));
-    MCL_HIP(ctx, hipMemcpy(key_big.data(), c_key, m * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    MCL_HIP(ctx, hipMemcpy(first_big.data(), c_first, m * sizeof(unsigned int), hipMemcpyDeviceToHost));
-    MCL_HIP(ctx, hipMemcpy(count_big.data(), c_count, m * sizeof(unsigned int), hipMemcpyDeviceToHost));
-    MCL_HIP(ctx, hipMemcpy(wsum_big.data(), c_wsum, m * sizeof(double), hipMemcpyDeviceToHost));
-    MCL_HIP(ctx, hipMemcpy(state_big.data(), c_state, 4 * static_cast<size_t>(m) * sizeof(double), hipMemcpyDeviceToHost));
+    // on the context's stream, behind the compaction (the stream does not synchronise with the null stream)
+    MCL_HIP(ctx, hipMemcpyAsync(key_big.data(), c_key, m * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    MCL_HIP(ctx, hipMemcpyAsync(first_big.data(), c_first, m * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    MCL_HIP(ctx, hipMemcpyAsync(count_big.data(), c_count, m * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    MCL_HIP(ctx, hipMemcpyAsync(wsum_big.data(), c_wsum, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MCL_HIP(ctx, hipMemcpyAsync(state_big.data(), c_state, 4 * static_cast<size_t>(m) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     key = key_big.data();
     first = first_big.data();
     count = count_big.data();
@@ -1049,23 +1115,102 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
     slot_list = c_slot;
   }
 
-  // make_cluster_map :137-157 — cells enter the map in the order their first particle appears in the set.
+  // The occupied cells in the order their first particle appears in the set (make_cluster_map :137-157 inserts them in that
+  // order).  Over shards: every rank's list in that order, gathered, and merged rank by rank - shards are contiguous pieces of
+  // the global index space, so rank order followed by local order IS the global first-occurrence order; a cell seen by
+  // several ranks keeps the state of its first particle and adds up weights and counts.
+  std::vector<uint32_t> order(m);
+  std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
+  std::vector<unsigned long long> g_key;
+  std::vector<double> g_wsum, g_state;
+  std::vector<uint64_t> g_count;
+  if (!sharded) {
+    g_key.resize(m);
+    g_wsum.resize(m);
+    g_count.resize(m);
+    g_state.resize(4 * static_cast<size_t>(m));
+    for (uint32_t j = 0; j < m; ++j) {
+      const uint32_t k = order[j];
+      g_key[j] = key[k];
+      g_wsum[j] = wsum[k];
+      g_count[j] = count[k];
+      std::memcpy(&g_state[4 * static_cast<size_t>(j)], state + 4 * static_cast<size_t>(k), 4 * sizeof(double));
+    }
+  } else {
+    if (const mcl_status s = comm_scratch(ctx)) return s;
+    const uint32_t world = ctx->comm_world;
+    constexpr size_t kRecord = 7;  // doubles per cell: key (bit pattern), weight sum, count (bit pattern), state[4]
+    long long* d_counts = ctx->d_comm_i64.ptr;
+    long long* h_counts = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + 9));
+    h_counts[0] = static_cast<long long>(m);
+    MCL_HIP(ctx, hipMemcpyAsync(d_counts, h_counts, sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+    if (const mcl_status s = comm_gather(ctx, d_counts, d_counts + world, sizeof(long long))) return s;
+    MCL_HIP(ctx, hipMemcpyAsync(h_counts, d_counts + world, world * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> m_of(world);
+    uint64_t widest = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+      m_of[r] = static_cast<uint64_t>(h_counts[r]);
+      widest = std::max(widest, m_of[r]);
+    }
+    std::vector<double> packed(kRecord * widest, 0.0);
+    for (uint32_t j = 0; j < m; ++j) {
+      const uint32_t k = order[j];
+      double* rec = &packed[kRecord * static_cast<size_t>(j)];
+      const unsigned long long cnt = count[k];
+      std::memcpy(rec + 0, &key[k], sizeof(double));
+      rec[1] = wsum[k];
+      std::memcpy(rec + 2, &cnt, sizeof(double));
+      std::memcpy(rec + 3, state + 4 * static_cast<size_t>(k), 4 * sizeof(double));
+    }
+    MCL_HIP(ctx, ctx->d_cell_exchange.ensure(kRecord * widest * (world + 1)));
+    double* d_send = ctx->d_cell_exchange.ptr;
+    double* d_recv = d_send + kRecord * widest;
+    MCL_HIP(ctx, hipMemcpyAsync(d_send, packed.data(), kRecord * widest * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (const mcl_status s = comm_gather(ctx, d_send, d_recv, kRecord * widest * sizeof(double))) return s;
+    std::vector<double> all(kRecord * widest * world);
+    MCL_HIP(ctx, hipMemcpyAsync(all.data(), d_recv, all.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::unordered_map<unsigned long long, size_t> seen;
+    for (uint32_t r = 0; r < world; ++r) {
+      for (uint64_t j = 0; j < m_of[r]; ++j) {
+        const double* rec = &all[kRecord * (static_cast<size_t>(r) * widest + j)];
+        unsigned long long k64, cnt;
+        std::memcpy(&k64, rec + 0, sizeof k64);
+        std::memcpy(&cnt, rec + 2, sizeof cnt);
+        const auto [it, fresh] = seen.try_emplace(k64, g_key.size());
+        if (fresh) {
+          g_key.push_back(k64);
+          g_wsum.push_back(rec[1]);
+          g_count.push_back(cnt);
+          g_state.insert(g_state.end(), rec + 3, rec + 7);
+        } else {
+          g_wsum[it->second] += rec[1];
+          g_count[it->second] += cnt;
+        }
+      }
+    }
+  }
+  const size_t cells = g_key.size();
+  if (cells == 0) return fail(ctx, MCL_ERR_NOT_READY, "no particles");
+  uint64_t n_global = 0;
+  for (const uint64_t c : g_count) n_global += c;
+
+  // make_cluster_map :137-157
   struct Cell {
     Pose2 representative_state;
     double weight;
     size_t num_particles;
     std::optional<size_t> cluster_id;
-    uint32_t k;
+    size_t k;
   };
-  std::vector<uint32_t> order(m);
-  std::iota(order.begin(), order.end(), 0u);
-  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
   std::unordered_map<size_t, Cell> map;
-  map.reserve(n / 5);
-  for (const uint32_t k : order) {
-    map.try_emplace(static_cast<size_t>(key[k]),
-                    Cell{Pose2{Rot2{state[4 * k], state[4 * k + 1]}, state[4 * k + 2], state[4 * k + 3]}, wsum[k], count[k],
-                         std::nullopt, k});
+  map.reserve(n_global / 5);
+  for (size_t k = 0; k < cells; ++k) {
+    map.try_emplace(static_cast<size_t>(g_key[k]),
+                    Cell{Pose2{Rot2{g_state[4 * k], g_state[4 * k + 1]}, g_state[4 * k + 2], g_state[4 * k + 3]}, g_wsum[k],
+                         static_cast<size_t>(g_count[k]), std::nullopt, k});
   }
   // normalize_and_cap_weights :173-189 (+ calculate_percentile_threshold :103-109)
   for (auto& kv : map) kv.second.weight /= static_cast<double>(kv.second.num_particles);
@@ -1110,31 +1255,43 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
   // estimate_clusters :345-411: clusters with more than one particle, the first one of maximum total weight
   std::vector<double> total_w(next_cluster_id, 0.0);
   std::vector<uint64_t> total_n(next_cluster_id, 0);
-  std::vector<unsigned int> cluster_of(m);
-  for (auto& kv : map) {
-    const Cell& c = kv.second;
-    cluster_of[c.k] = static_cast<unsigned int>(c.cluster_id.value());
-  }
-  for (const uint32_t k : order) {  // particle-order accumulation is not reproducible from cell sums; cell order is fixed
-    total_w[cluster_of[k]] += wsum[k];
-    total_n[cluster_of[k]] += count[k];
+  std::vector<unsigned int> cluster_of_cell(cells);
+  for (auto& kv : map) cluster_of_cell[kv.second.k] = static_cast<unsigned int>(kv.second.cluster_id.value());
+  for (size_t k = 0; k < cells; ++k) {  // particle-order accumulation is not reproducible from cell sums; cell order is fixed
+    total_w[cluster_of_cell[k]] += g_wsum[k];
+    total_n[cluster_of_cell[k]] += g_count[k];
   }
   long best = -1;
   for (size_t c = 0; c < next_cluster_id; ++c)
     if (total_n[c] > 1 && (best < 0 || total_w[static_cast<size_t>(best)] < total_w[c])) best = static_cast<long>(c);
   double sums[12];
   if (best < 0) {  // :424-427 no cluster: overall mean and covariance
-    if (const mcl_status s = do_estimate_sums(ctx, ctx->pivot, sums)) return s;
+    if (sharded) {
+      if (const mcl_status s = sharded_estimate_sums(ctx, nullptr, 0, sums)) return s;
+    } else if (const mcl_status s = do_estimate_sums(ctx, ctx->pivot, sums)) {
+      return s;
+    }
     return mcl_estimate_from_sums(sums, out);
+  }
+  // this rank's cells -> their clusters (list order, the order of slot_list)
+  std::vector<unsigned int> cluster_of(m);
+  for (uint32_t j = 0; j < m; ++j) {
+    const uint32_t k = order[j];
+    cluster_of[k] = sharded ? static_cast<unsigned int>(map[static_cast<size_t>(key[k])].cluster_id.value()) : cluster_of_cell[j];
   }
   const unsigned int* cluster_list = c_cluster;
   if (on_host_list) {  // the kernel reads the cluster ids from the mapped list
     std::memcpy(hcl, cluster_of.data(), m * sizeof(unsigned int));
     cluster_list = dcl;
   } else {
-    MCL_HIP(ctx, hipMemcpy(c_cluster, cluster_of.data(), m * sizeof(unsigned int), hipMemcpyHostToDevice));
+    MCL_HIP(ctx, hipMemcpyAsync(c_cluster, cluster_of.data(), m * sizeof(unsigned int), hipMemcpyHostToDevice, ctx->stream));
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (cluster_of is pageable host memory of this call)
   }
-  launch_cell_set_cluster(ctx->stream, slot_list, cluster_list, m, t_cluster);
+  if (m) launch_cell_set_cluster(ctx->stream, slot_list, cluster_list, m, t_cluster);
+  if (sharded) return [&] {
+    if (const mcl_status s = sharded_estimate_sums(ctx, t_cluster, static_cast<unsigned int>(best) + 1u, sums, slots)) return s;
+    return mcl_estimate_from_sums(sums, out);
+  }();
   launch_estimate_sums_cluster(ctx->stream, ctx->cur(), n, ctx->d_hashes.ptr, ctx->d_table_keys.ptr, t_cluster, slots,
                                static_cast<unsigned int>(best), ctx->pivot[0], ctx->pivot[1], ctx->chunk_row(0), ctx->d_scalars.ptr + 8,
                                ctx->hd_scalars + 8);
@@ -1147,27 +1304,6 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
   return mcl_estimate_from_sums(sums, out);
 }
 
-
-// ---- particle shards: the cycle over a communicator --------------------------------------------------------------------
-constexpr size_t kCommScalars = 16;  // d_comm_f64[0] local sum | [1] cdf total | [2] norm sum | [3] norm sumsq | [4] global sum | [5..14) estimate sums
-
-mcl_status comm_scratch(mcl_ctx* ctx) {
-  const size_t world = ctx->comm_world;
-  MCL_HIP(ctx, ctx->d_comm_f64.ensure(kCommScalars + world * (1 + 3 + 2 + 9)));
-  MCL_HIP(ctx, ctx->d_comm_i64.ensure(world + world * world));
-  if (!ctx->h_comm) MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_comm), (kCommScalars + 64 * (1 + 3 + 2 + 9) + 64 * 64 + 64) * sizeof(double)));
-  return MCL_OK;
-}
-mcl_status comm_gather(mcl_ctx* ctx, const void* d_send, void* d_recv, uint64_t bytes) {
-  if (ctx->transport.all_gather(ctx->transport.user, d_send, d_recv, bytes, ctx->stream) != 0)
-    return fail(ctx, MCL_ERR_HIP, "transport all_gather failed");
-  return MCL_OK;
-}
-mcl_status comm_exchange(mcl_ctx* ctx, const void* d_send, const uint64_t* send_bytes, void* d_recv, const uint64_t* recv_bytes) {
-  if (ctx->transport.all_to_all(ctx->transport.user, d_send, send_bytes, d_recv, recv_bytes, ctx->stream) != 0)
-    return fail(ctx, MCL_ERR_HIP, "transport all_to_all failed");
-  return MCL_OK;
-}
 
 // Contiguous, balanced split of [0, n_total) over the ranks.
 void shard_bounds(uint64_t n_total, uint32_t world, uint32_t rank, uint64_t* first, uint64_t* count) {
@@ -1297,6 +1433,14 @@ mcl_status sharded_resample_kld(mcl_ctx* ctx, double random_state_probability, d
   return MCL_OK;
 }
 
+// What can be refused without touching the filter's state (mcl_update checks it before the motion is consumed).
+mcl_status sharded_preconditions(mcl_ctx* ctx) {
+  const mcl_amcl_params& ap = ctx->cfg.amcl;
+  if (ap.min_particles < ap.max_particles && ap.max_particles >= 0xFFFFFFFFull)
+    return fail(ctx, MCL_ERR_UNSUPPORTED, "max_particles too large for KLD resampling");
+  return MCL_OK;
+}
+
 // beluga::Amcl::update (amcl_core.hpp:165-201) over the sharded set; same statements as mcl_update, with the exchanges of
 // include/beluga_mcl.h ("Particle shards") between them.  Every rank takes the same decisions: they depend on the control
 // action (identical inputs) and on gathered sums (identical values, added in rank order everywhere).
@@ -1305,8 +1449,6 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
   const mcl_amcl_params& ap = ctx->cfg.amcl;
   const uint32_t world = ctx->comm_world, rank = ctx->comm_rank;
   const bool adaptive = ap.min_particles < ap.max_particles;
-  if (adaptive && ap.max_particles >= 0xFFFFFFFFull) return fail(ctx, MCL_ERR_UNSUPPORTED, "max_particles too large for KLD resampling");
-  if (ctx->estimate_kind != 0) return fail(ctx, MCL_ERR_UNSUPPORTED, "sharded mcl_update returns beluga::estimate");
   if (const mcl_status s = comm_scratch(ctx)) return s;
   if (ctx->global_n_unknown) {  // shards loaded by the caller: total = sum of the counts, this shard starts behind the ranks before it
     long long* d_counts = ctx->d_comm_i64.ptr;
@@ -1340,8 +1482,7 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
   double* d = ctx->d_comm_f64.ptr;
   double* d_gather_sums = d + kCommScalars;            // [world]
   double* d_gather_stats = d_gather_sums + world;      // [world][3]
-  double* d_intervals = d_gather_stats + 3 * world;    // ends[world], offsets[world]
-  double* d_gather_est = d_intervals + 2 * world;      // [world][9]
+  double* d_intervals = d_gather_stats + 3 * world;    // ends[world], offsets[world]; behind them [world][9] estimate sums
   double* h = ctx->h_comm;
 
   bool keys_ready = false;
@@ -1416,22 +1557,21 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
     stage_end(ctx, MCL_STAGE_RESAMPLE);
   }
   ctx->force_update = false;  // :199
-  // :200 estimate: nine sums per shard, gathered, added in rank order
+  // :200 estimate: nine sums per shard, gathered, added in rank order; or cluster_based_estimate over the gathered cells
+  // (beluga_ros/src/amcl.cpp:125)
   stage_begin(ctx, MCL_STAGE_ESTIMATE);
-  launch_estimate_sums(ctx->stream, ctx->cur(), ctx->n, ctx->pivot[0], ctx->pivot[1], ctx->chunk_row(0), d + 5);
-  if (const mcl_status s = comm_gather(ctx, d + 5, d_gather_est, 9 * sizeof(double))) return s;
-  launch_sum_rows(ctx->stream, d_gather_est, world, 9, ctx->d_scalars.ptr + 8, ctx->hd_scalars + 8);
-  stage_end(ctx, MCL_STAGE_ESTIMATE);
-  MCL_HIP(ctx, hipGetLastError());
-  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  stage_collect(ctx);
-  double sums[12];
-  for (int k = 0; k < 9; ++k) sums[k] = ctx->h_scalars[8 + k];
-  sums[9] = ctx->pivot[0];
-  sums[10] = ctx->pivot[1];
-  sums[11] = 0.0;
   mcl_estimate est{};
-  if (const mcl_status s = mcl_estimate_from_sums(sums, &est)) return s;
+  if (ctx->estimate_kind == 1) {
+    if (const mcl_status s = do_cluster_estimate(ctx, ctx->cluster_params, &est)) return s;
+    stage_end(ctx, MCL_STAGE_ESTIMATE);
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    double sums[12];
+    if (const mcl_status s = sharded_estimate_sums(ctx, nullptr, 0, sums)) return s;
+    stage_end(ctx, MCL_STAGE_ESTIMATE);
+    if (const mcl_status s = mcl_estimate_from_sums(sums, &est)) return s;
+  }
+  stage_collect(ctx);
   if (std::isfinite(est.pose[2]) && std::isfinite(est.pose[3])) {
     ctx->pivot[0] = est.pose[2];
     ctx->pivot[1] = est.pose[3];
@@ -1587,6 +1727,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     MCL_HIP(ctx, ctx->d_scalars.ensure(32));
     MCL_HIP(ctx, hipMemsetAsync(ctx->d_scalars.ptr, 0, 32 * sizeof(double), ctx->stream));  // incl. the recovery filters
     MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalars), 32 * sizeof(double), hipHostMallocMapped));
+    std::memset(ctx->h_scalars, 0, 32 * sizeof(double));  // host mirrors are read before their first kernel has written them
     MCL_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->hd_scalars), ctx->h_scalars, 0));
     MCL_HIP(ctx, ctx->d_kld_scalars.ensure(8));
     MCL_HIP(ctx, hipMemsetAsync(ctx->d_kld_scalars.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
@@ -1653,6 +1794,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_cell_f64.release();
   ctx->d_cell_u32.release();
   ctx->d_cell_u64.release();
+  ctx->d_cell_exchange.release();
   ctx->d_sort_u64.release();
   ctx->d_sort_f64.release();
   if (ctx->rccl_comm) {
@@ -1973,7 +2115,14 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
     undo_policy();
     return s;
   }
-  if (ctx->have_comm && ctx->comm_world > 1) return sharded_update(ctx, pose, points_xy, num_points, estimate, info);
+  ctx->lf_mode.decided = false;  // whatever an earlier, failed cycle left behind
+  if (ctx->have_comm && ctx->comm_world > 1) {
+    if (const mcl_status s = sharded_preconditions(ctx)) {  // before any rank-local state moves: the ranks must not diverge
+      undo_policy();
+      return s;
+    }
+    return sharded_update(ctx, pose, points_xy, num_points, estimate, info);
+  }
   if (const mcl_status s = stage_points(ctx, points_xy, num_points)) {
     undo_policy();
     return s;
@@ -2477,7 +2626,7 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
     if (const mcl_status s = bind_device(ctx)) return s;
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t planned, through;
-    patch_totals(ctx, &planned, &through);
+    patch_totals(ctx, &planned, &through, /*synchronised=*/true);
     *value = key == "lf_patch_groups_planned" ? planned : through;
   }
   else if (key == "field_build_us") *value = static_cast<uint64_t>(ctx->field_build_ms * 1e3);  // kernels of the last device field build

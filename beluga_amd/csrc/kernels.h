@@ -185,7 +185,8 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
 // use_patches: the LDS-patch kernel where its preconditions hold (dense sets); patch_stats: running totals it reports
 struct PatchStats {
   unsigned long long* device;  // [3]: groups planned, groups through a patch, workgroups reported (never reset)
-  unsigned long long* mirror;  // [2]: mapped host copy of the first two, written by the last workgroup of a launch
+  unsigned long long* mirror;  // [3]: mapped host copy of the first two, written by the last workgroup of a launch, and their
+                               // low halves packed into one word (planned | through << 32: one store, read without synchronisation)
   uint32_t loose_below;        // a workgroup with fewer than loose_below / 256 of its groups fitting a patch gathers them all
 };
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,

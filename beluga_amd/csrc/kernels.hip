@@ -942,8 +942,11 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         const unsigned long long reporters = static_cast<unsigned long long>((gridDim.x + stride - 1) / stride) * gridDim.y;
         const unsigned long long ticket = atomicAdd(stats.device + 2, 1ull) + 1ull;
         if (ticket % reporters == 0 && stats.mirror) {
-          stats.mirror[0] = atomicAdd(stats.device + 0, 0ull);
-          stats.mirror[1] = atomicAdd(stats.device + 1, 0ull);
+          const unsigned long long planned = atomicAdd(stats.device + 0, 0ull), through = atomicAdd(stats.device + 1, 0ull);
+          stats.mirror[0] = planned;
+          stats.mirror[1] = through;
+          // the pair as ONE word (low halves) for the host's unsynchronised look between launches: never torn
+          stats.mirror[2] = (planned & 0xFFFFFFFFull) | (through << 32);
         }
       }
     };

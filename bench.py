@@ -32,8 +32,13 @@ if ROOT not in sys.path:
 
 HBM_PEAK = 8.0e12      # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_MEASURED = 6.29e12  # B/s, the float4-copy rate the same guide measures (79 % of spec)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "lf_kernel_traffic.json")
 KERNEL_SOURCE = os.path.join(ROOT, "beluga_amd", "csrc", "kernels.hip")
+PROFILES = os.path.join(ROOT, "profiles")
+# per-launch counters of the LF kernel (rocprofv3 --pmc passes of the default bench, tools/gpu_r3_profiles.sh) and the measured
+# issue cost of the instruction classes on this part (tools/calib_f64_rate.hip): what the VALU-issue roofline is computed from
+PMC_FILES = [os.path.join(PROFILES, "r03_pmc_bench_1M.txt"), os.path.join(PROFILES, "r02_pmc_bench_1M.txt")]
+CALIB_FILE = os.path.join(PROFILES, "r01_calib_f64_issue_rate.txt")
+SIMDS, CLOCK_HZ = 256 * 4, 2.4e9  # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz (the calibration quotes its cycles at this clock)
 
 
 def lf_kernel_source_sha(path):
@@ -48,19 +53,71 @@ def lf_kernel_source_sha(path):
     return hashlib.sha256(text).hexdigest()
 
 
-def measured_lf_traffic(n_particles: int):
-    """HBM bytes per launch of the LF kernel from the PMC passes of tools/gpu_pmc_traffic.sh (2 x FETCH_SIZE + WRITE_SIZE, see
-    profiles/r01_pmc_traffic_calibration.txt), valid only for the kernel source it was collected on: the file records the
-    SHA-256 of the LF kernels' source (lf_kernel_source_sha) and the particle count; anything else gives None."""
+def calibrated_issue_cycles():
+    """Cycles per wave64 instruction and SIMD by class, from profiles/r01_calib_f64_issue_rate.txt (measured with 8 waves per
+    SIMD and independent chains: the best the vector unit does, quoted at 2.4 GHz)."""
+    out = {}
+    with open(CALIB_FILE) as fh:
+        for line in fh:
+            parts = line.split()
+            if len(parts) >= 5 and parts[0].startswith("v_") and parts[3] == "->":
+                out[parts[0]] = float(parts[4])
+    return {"fma_f64": out["v_fma_f64"], "mul_f64": out["v_mul_f64"], "add_f64": out["v_add_f64"], "other": out["v_add_u32"]}
+
+
+def lf_kernel_counters(kernel="k_reweight_lf_patch"):
+    """Per-launch PMC averages of the LF kernel from the newest profile that has them: {counter: value}, the file, and whether the
+    file was collected on the LF kernels' current source (its header records the SHA-256 of that part of kernels.hip)."""
+    for path in PMC_FILES:
+        counters, sha = {}, None
+        try:
+            with open(path) as fh:
+                for line in fh:
+                    parts = line.split()
+                    if line.startswith("# lf_kernels_sha256") and len(parts) >= 3:
+                        sha = parts[2]
+                    if len(parts) >= 4 and parts[0] == "PMC" and parts[1] == kernel:
+                        counters[parts[2]] = float(parts[3])
+        except OSError:
+            continue
+        if "SQ_INSTS_VALU" in counters:
+            try:
+                current = sha == lf_kernel_source_sha(KERNEL_SOURCE)
+            except OSError:
+                current = False
+            return counters, os.path.relpath(path, ROOT), current
+    return None, None, False
+
+
+def valu_issue_floor_ms(n_particles: int):
+    """The time the LF kernel's vector instructions take to ISSUE at the measured rate of each class, all 1024 SIMDs busy:
+    sum over classes of (instructions per launch x cycles per instruction) / (SIMDs x clock).  Instruction counts by class from
+    SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 where the profile has them (the rest - integer, moves, conversions - at the 32-bit rate);
+    a profile with the total only prices everything at the nominal 4 cycles of a wave64 instruction."""
+    counters, source, current = lf_kernel_counters()
+    if counters is None:
+        return None
+    scale = n_particles / 1_000_000  # the profile is of the 1M-particle bench; the kernel's work is linear in the particles
+    total = counters["SQ_INSTS_VALU"] * scale
+    detail = {"source": source, "source_is_current_kernel": current, "valu_instructions_per_launch": total,
+              "valu_per_wave_beam": total / (n_particles * BEAMS / 64)}
     try:
-        with open(TRAFFIC_FILE) as fh:
-            rec = json.load(fh)
-        sha = lf_kernel_source_sha(KERNEL_SOURCE)
-    except (OSError, ValueError):
-        return None
-    if rec.get("kernels_hip_sha256") != sha or rec.get("particles") != n_particles:
-        return None
-    return int(2 * rec["fetch_size_kb"] * 1024 + rec["write_size_kb"] * 1024)
+        cyc = calibrated_issue_cycles()
+    except (OSError, KeyError):
+        cyc = None
+    classes = {k: counters.get(name) for k, name in (("fma_f64", "SQ_INSTS_VALU_FMA_F64"), ("mul_f64", "SQ_INSTS_VALU_MUL_F64"),
+                                                     ("add_f64", "SQ_INSTS_VALU_ADD_F64"))}
+    if cyc is not None and all(v is not None for v in classes.values()):
+        classes = {k: v * scale for k, v in classes.items()}
+        classes["other"] = max(total - sum(classes.values()), 0.0)
+        cycles = sum(classes[k] * cyc[k] for k in classes)
+        detail.update({"instructions_by_class": classes, "cycles_per_instruction": cyc, "pricing": "measured issue cost per class"})
+    else:
+        cycles = total * 4.0
+        detail.update({"pricing": "4 cycles per wave64 instruction (no class counters in the profile)"})
+    detail["issue_floor_ms"] = cycles / (SIMDS * CLOCK_HZ) * 1e3
+    detail["peak_winstr_per_s"] = total / (cycles / (SIMDS * CLOCK_HZ))  # instructions of this mix the chip can issue per second
+    return detail
 
 
 MAP_SIZE, RESOLUTION, ORIGIN = 4000, 0.05, (-100.0, -100.0)
@@ -90,38 +147,66 @@ def make_workload(steps_total: int):
         poses.append(pose)
         odoms.append(odom)
         scans.append(synth.scan_points(ranges, angles))
-    return cells, truth, odoms, scans
+    return cells, truth, odoms, scans, poses
 
 
-def cpu_baseline(cells, truth, odoms, scans, n_full: int, budget_s: float = 12.0):
-    """The oracle (CPU restatement of the reference path; kind 'port') on all host cores for the three loops the
-    reference parallelises, on a bounded particle sample of the same workload; extrapolated linearly in N."""
+def cpu_baseline(cells, truth, odoms, scans, n_full: int, budget_s: float = 14.0):
+    """The oracle (CPU restatement of the reference path; kind 'port') as BASELINE.md section 2 asks: built -O3 -march=native
+    (the timing build: oracle/Makefile `native`; the parity tests keep their -ffp-contract=off build), `seq` = one thread
+    (std::execution::seq) and `par` = all host threads on the three loops the reference parallelises (propagate, reweight,
+    the normalisation divide; the resampling is sequential in the reference whatever the policy: views/sample.hpp:128-136),
+    per-stage milliseconds, median over >= 5 full update cycles, on bounded particle samples of the same workload scaled
+    linearly in N."""
     from beluga_amd.amcl import se2_from_xytheta
     from oracle import binding as orc
-    threads = orc.max_threads()
-    sample_n = 32768 * max(1, threads // 8)
-    f = orc.Amcl(min_particles=sample_n, max_particles=sample_n, alphas=ALPHAS, seed=42, threads=threads,
-                 lf=(LF["max_obstacle_distance"], LF["max_laser_distance"], LF["z_hit"], LF["z_random"], LF["sigma_hit"]),
-                 lf_model_unknown_space=LF["model_unknown_space"])
-    f.set_map(cells, RESOLUTION, se2_from_xytheta(ORIGIN[0], ORIGIN[1], 0.0))
-    f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
-    f.update(se2_from_xytheta(*odoms[0]), scans[0])  # warm-up
-    t0 = time.perf_counter()
-    done = 0
-    for c in range(1, len(odoms)):
-        f.update(se2_from_xytheta(*odoms[c]), scans[c])
-        done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    cycles_per_s_sample = done / dt
+    flags = orc.use_timing_build(True)
+    try:
+        threads = orc.max_threads()
+
+        def run(n_sample, n_threads, share):
+            f = orc.Amcl(min_particles=n_sample, max_particles=n_sample, alphas=ALPHAS, seed=42, threads=n_threads,
+                         lf=(LF["max_obstacle_distance"], LF["max_laser_distance"], LF["z_hit"], LF["z_random"], LF["sigma_hit"]),
+                         lf_model_unknown_space=LF["model_unknown_space"])
+            f.set_map(cells, RESOLUTION, se2_from_xytheta(ORIGIN[0], ORIGIN[1], 0.0))
+            f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+            f.update(se2_from_xytheta(*odoms[0]), scans[0])  # warm-up
+            cycle_ms, stages = [], []
+            t_begin = time.perf_counter()
+            for c in range(1, len(odoms)):
+                t0 = time.perf_counter()
+                f.update(se2_from_xytheta(*odoms[c]), scans[c])
+                cycle_ms.append((time.perf_counter() - t0) * 1e3)
+                stages.append(f.stage_times())
+                if len(cycle_ms) >= 5 and time.perf_counter() - t_begin > budget_s * share:
+                    break
+            del f
+            med = float(np.median(cycle_ms))
+            return {
+                "threads": n_threads, "sample_particles": n_sample, "cycles_timed": len(cycle_ms), "ms_per_cycle_median": med,
+                "stage_ms_median": {k: float(np.median([st[k] for st in stages]) * 1e3) for k in stages[0]},
+                "ns_per_particle_beam": med * 1e6 / (n_sample * BEAMS),
+                "cycles_per_s_scaled": 1e3 / med * n_sample / n_full,
+            }
+
+        par = run(32768 * max(1, threads // 8), threads, 0.6)
+        seq = run(4096, 1, 0.4)
+    finally:
+        orc.use_timing_build(False)
     return {
-        "value": cycles_per_s_sample * sample_n / n_full,
+        "value": par["cycles_per_s_scaled"],
         "unit": "cycles/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{done} full update cycles of {sample_n} particles x {BEAMS} beams in {dt:.2f} s "
-                  f"({dt / done / sample_n / BEAMS * 1e9:.2f} ns per particle-beam), scaled linearly to {n_full} particles",
+        "build": flags,
+        "sample": f"par: {par['cycles_timed']} full update cycles of {par['sample_particles']} particles x {BEAMS} beams on {threads} threads "
+                  f"(median {par['ms_per_cycle_median']:.1f} ms, {par['ns_per_particle_beam']:.2f} ns per particle-beam); seq: "
+                  f"{seq['cycles_timed']} cycles of {seq['sample_particles']} particles on 1 thread (median {seq['ms_per_cycle_median']:.1f} ms); "
+                  f"both scaled linearly to {n_full} particles",
+        "par": par,
+        "seq": seq,
+        "note": "value = par.  The reference's resampling is sequential under either execution policy (views/sample.hpp:128-136; the "
+                "lazy sample view is materialised by actions::assign on one thread), so `par` carries a serial stage that grows "
+                "with N: see stage_ms_median.resample.",
     }
 
 
@@ -179,7 +264,7 @@ def other_configs(grid, cells, truth, controls, scans, main_filter, device):
             g.close()
             g = Amcl(grid, motion, LikelihoodFieldModelParam(**LF), AmclParams(min_particles=100_000, max_particles=n, selective_resampling=True),
                      seed=42, device=device)
-            first, counts = [], []
+            first, counts, fired_first = [], [], []
             for r in range(3):
                 g.initialize(truth, cov)
                 g.sync()
@@ -188,11 +273,19 @@ def other_configs(grid, cells, truth, controls, scans, main_filter, device):
                 g.sync()
                 first.append((time.perf_counter() - t0) * 1e3)
                 counts.append(g.last_info["num_particles"])
-            steady = _timed_cycles(g, controls, scans, 3, 8)
+                fired_first.append(bool(g.last_info["resampled"]))
+            cycles_after = []
+            for k in range(8):  # the trajectory continues from the third fresh set: the KLD cut, then cycles at N_out
+                n_in = g.last_info["num_particles"]
+                ms = _timed_cycles(g, controls, scans, 3 + k, 1)[0]
+                cycles_after.append({"N_in": n_in, "ms": ms, "resample_fires": bool(g.last_info["resampled"]),
+                                     "N_out": g.last_info["num_particles"]})
             out["3"] = {"what": "BASELINE configs[2]: max 10M / min 100k particles, KLD (eps .05, z 3) + selective resampling (ESS < N/2)",
-                        "first_cycle_ms_at_10M": first, "cycles_per_s_at_10M": 1e3 / float(np.median(first)),
-                        "particles_after_first_cycle": counts, "steady_state_ms_per_cycle": steady,
-                        "steady_state_particles": g.last_info["num_particles"]}
+                        "cycle_at_10M_resample_does_not_fire": {"ms": first, "cycles_per_s": 1e3 / float(np.median(first)),
+                                                                "N_out": counts, "resampled": fired_first},
+                        "cycles_after_it": cycles_after,
+                        "note": "from a fresh 10M-particle set the first cycle's ESS stays above N/2 (selective resampling: no "
+                                "resample, N stays 10M); the next cycle fires: KLD cut 10M -> N_out; then the filter runs at N_out"}
         g.close()
     # config 5
     n = 1_000_000
@@ -206,6 +299,34 @@ def other_configs(grid, cells, truth, controls, scans, main_filter, device):
                 "ms_per_cycle": ms, "cycles_per_s": 1e3 / float(np.median(ms)), "cells_visited_per_cycle": visited / 3,
                 "cells_per_s": visited / (sum(ms) * 1e-3)}
     b.close()
+    return out
+
+
+def verify_run(filt, grid, estimates, true_poses, scan, rank):
+    """What the timed run just did, checked (reported as `verified`, not timed): (1) the estimate of every timed cycle against
+    the workload's true pose (the filter has to be localising, not just running); (2) one more reweight on the set as the run
+    left it, 1024 sampled particles + the first and the last against the oracle (likelihood_field_model.hpp:68-91) at 1e-12."""
+    from oracle import binding as orc
+    out = {}
+    pos, ang = [], []
+    for est, truth in zip(estimates, true_poses):
+        pos.append(math.hypot(est[2] - truth[0], est[3] - truth[1]))
+        d = math.atan2(est[1], est[0]) - truth[2]
+        ang.append(abs(math.atan2(math.sin(d), math.cos(d))))
+    out["estimate_vs_true_pose"] = {"cycles": len(pos), "max_position_error_m": max(pos), "max_heading_error_rad": max(ang),
+                                    "ok": bool(max(pos) < 0.25 and max(ang) < 0.05)}
+    if hasattr(filt, "reweight") and hasattr(filt, "likelihood_field"):
+        states, w0 = filt.particles()
+        n = len(w0)
+        filt.reweight(scan)
+        w1 = filt.particles()[1]
+        pick = np.unique(np.concatenate([np.random.Generator(np.random.MT19937(7)).choice(n, min(1024, n), replace=False), [0, n - 1]]))
+        want = w0[pick] * orc.lf_weights(filt.likelihood_field(), RESOLUTION, grid.origin, LF["max_laser_distance"], states[pick],
+                                        scan, threads=orc.max_threads())
+        rel = float(np.max(np.abs(w1[pick] - want) / np.abs(want)))
+        out["reweight_sample_vs_oracle"] = {"particles": int(len(pick)), "beams": int(len(scan)), "max_relative_error": rel,
+                                            "tolerance": 1e-12, "ok": bool(rel <= 1e-12)}
+    out["ok"] = all(v["ok"] for v in out.values())
     return out
 
 
@@ -260,7 +381,7 @@ def main():
     from beluga_amd.amcl import AmclParams, DifferentialDriveModelParam, LikelihoodFieldModelParam, OccupancyGrid, se2_from_xytheta
 
     steps_total = args.warmup + args.steps * (1 + args.windows) + args.stage_steps
-    cells, truth, odoms, scans = make_workload(steps_total)
+    cells, truth, odoms, scans, true_poses = make_workload(steps_total)
     grid = OccupancyGrid(cells, RESOLUTION, origin=se2_from_xytheta(ORIGIN[0], ORIGIN[1], 0.0))
     n_local = args.particles
     n_total = n_local * world
@@ -330,10 +451,12 @@ def main():
     filt.profile_read(reset=True)
     sync_all()
     patch_before = (filt.counter("lf_patch_groups_planned"), filt.counter("lf_patch_groups_through")) if hasattr(filt, "counter") else None
+    timed_estimates = []
     t0 = time.perf_counter()
     for c in range(args.warmup, args.warmup + args.steps):
         est = filt.update(controls[c], scans[c])
         assert est is not None
+        timed_estimates.append(est[0])  # (a list append: checked against the true poses after the timed region)
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -363,6 +486,7 @@ def main():
     sync_all()
     stage_prof = filt.profile_read(reset=True)
     filt.profile_enable(0)
+    verified = verify_run(filt, grid, timed_estimates, true_poses[args.warmup:args.warmup + args.steps], scans[min(c, len(scans) - 1)], rank) if rank == 0 else None
 
     # BASELINE configs[3] with several ranks: 8M particles per GPU behind one logical filter (64M at 8 GPUs); cycles/s of
     # that filter, beside the metric.
@@ -390,20 +514,47 @@ def main():
         lf_ms, lf_count = prof["sensor_kernel"]
         lf_avg_s = (lf_ms / max(lf_count, 1)) * 1e-3
         bytes_lf = lf_algorithmic_bytes(n_local, BEAMS)
-        achieved = bytes_lf / lf_avg_s if lf_avg_s > 0 else 0.0
-        traffic = measured_lf_traffic(n_local) if not use_sharded else None
+        achieved_bytes = bytes_lf / lf_avg_s if lf_avg_s > 0 else 0.0
+        floor = valu_issue_floor_ms(n_local)
         patch_fraction = patch_fraction_timed = None
         if hasattr(filt, "counter"):
             planned, through = filt.counter("lf_patch_groups_planned"), filt.counter("lf_patch_groups_through")
             patch_fraction = through / planned if planned else None  # over the whole run (the repeat windows included)
             if patch_before and patch_after and patch_after[0] > patch_before[0]:
                 patch_fraction_timed = (patch_after[1] - patch_before[1]) / (patch_after[0] - patch_before[0])
+        # SURVEY 8(d)'s whole-cycle figure: algorithmic bytes of ONE cycle at the canonical element sizes over the cycle time
+        cycle_bytes = n_local * 4 * BEAMS + n_local * 44 + n_local * (4 * math.ceil(math.log2(max(n_local, 2))) + 44) + 8 * BEAMS
+        cycle_rate = cycle_bytes / (ms_per_step * 1e-3)
+        roofline = {
+            "kernel": "k_reweight_lf_patch (likelihood-field reweight; look-ups through per-workgroup LDS patches), 70 % of the cycle",
+            # What binds this kernel is vector-instruction issue, not HBM: its table is read through LDS patches and L2 (measured
+            # HBM traffic in profiles/: ~7 % of the algorithmic bytes), so the roofline reported is the issue rate of the kernel's own
+            # instruction mix.  achieved / peak are in wave64 vector instructions per second; frac = issue floor / launch time.
+            "bound": "valu",
+            "achieved": (floor["valu_instructions_per_launch"] / lf_avg_s / 1e9) if (floor and lf_avg_s > 0) else None,
+            "peak": (floor["peak_winstr_per_s"] / 1e9) if floor else None,
+            "unit": "G wave64-instr/s",
+            "frac": (floor["issue_floor_ms"] * 1e-3 / lf_avg_s) if (floor and lf_avg_s > 0) else None,
+            "traffic": None,  # HBM bytes are not measured inside this run (PMC passes: profiles/r03_pmc_bench_1M.txt, lf_kernel_traffic.json)
+            "avg_launch_ms": lf_avg_s * 1e3,
+            "launches": int(lf_count),
+            "launches_sampled_every": 4,
+            "valu_issue": floor,
+            # The contract's byte figure, kept beside it (NOT the binding roofline: above 1 where the table never leaves LDS / L2)
+            "algorithmic_bytes_per_launch": bytes_lf,
+            "algorithmic_GBps": achieved_bytes / 1e9,
+            "algorithmic_over_hbm_peak": achieved_bytes / HBM_PEAK,
+            "algorithmic_over_measured_copy_rate": achieved_bytes / HBM_MEASURED,
+            "whole_cycle": {"algorithmic_bytes_per_cycle": cycle_bytes, "GBps": cycle_rate / 1e9,
+                            "over_hbm_peak_8.0TBps": cycle_rate / HBM_PEAK, "over_measured_copy_rate_6.29TBps": cycle_rate / HBM_MEASURED},
+            "groups_through_lds_patch": patch_fraction,
+            "groups_through_lds_patch_in_timed_region": patch_fraction_timed,
+        }
         out = {
             "metric": "MCL update cycles/sec (motion+sensor+resample), N particles x 1080 beams",
-            # whole-job aggregate: one unit = one update cycle of 1M particles x 1080 beams (the configuration the metric is
-            # quoted on); with N GPUs (weak scaling, 1M particles per GPU) every cycle of the logical N x 1M filter moves N such
-            # units.  config.global_cycles_per_s is the rate of the logical filter itself.
-            "value": world * args.steps / elapsed,
+            # update cycles per second of the ONE logical filter the ranks run together (with N GPUs: N x particles_per_gpu
+            # particles behind it, weak scaling); config.particle_beam_evals_per_s is the aggregate work rate
+            "value": args.steps / elapsed,
             "unit": "cycles/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -425,45 +576,15 @@ def main():
                                                                     f"ancestors exchanged all-to-all (RCCL over xGMI, "
                                                                     f"{driver_used[0] or 'inside libbeluga_mcl.so'})",
                 "particle_beam_evals_per_s": n_total * BEAMS * args.steps / elapsed,
-                "global_cycles_per_s": args.steps / elapsed,
-                "unit_of_work": "one update cycle of 1M particles x 1080 beams; a global cycle over N GPUs = N units",
+                "units_of_1M_particle_cycles_per_s": world * args.steps / elapsed * (n_local / 1_000_000),
             },
             "timed_region_s": elapsed,
             "repeat_windows": {"steps_each": args.steps, "cycles_per_s": window_rates,
                                "min": min(window_rates) if window_rates else None,
                                "median": float(np.median(window_rates)) if window_rates else None},
             "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in stage_prof.items()},
-            "roofline": {
-                "kernel": "k_reweight_lf_patch (likelihood-field reweight; look-ups through per-workgroup LDS patches)",
-                # The contract's roofline: algorithmic bytes (4 B per particle-beam look-up + the particle's state and
-                # weight + the scan) over the kernel's HIP-event time, against the HBM peak.  It is a figure of merit, not HBM
-                # utilisation: the table is L2 / LDS resident (see `traffic`, `hbm_utilisation`); the kernel is bound by vector
-                # instruction issue (`limiter`).
-                "bound": "hbm",
-                "achieved": achieved / 1e9,
-                "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK,
-                "frac_of_measured_copy_rate": achieved / HBM_MEASURED,
-                "traffic": traffic,
-                "hbm_utilisation": (traffic / lf_avg_s / HBM_PEAK) if (traffic and lf_avg_s > 0) else None,
-                "algorithmic_bytes_per_launch": bytes_lf,
-                "avg_launch_ms": lf_avg_s * 1e3,
-                "launches": int(lf_count),
-                "launches_sampled_every": 4,
-                # What actually bounds it (profiles/r02_pmc_bench_1M.txt, r02_lf_series.txt): 10.2 vector instructions per wave and
-                # beam - 4 v_fma_f64 for the end-point, 1 for the exactness check, 2 for the LDS address, 1 v_add_f64, the rest
-                # prologue and gathered groups - at 4 cycles each on 7 of the 8 waves of a workgroup (the eighth fetches the
-                # patches).  Groups of beams that do not fit a patch are gathered from global memory instead: they pay the
-                # texture-address pipe (16 CU cycles per scattered 64-lane gather, profiles/r02_calib_gather_cost.txt) and their
-                # workgroup waits for them at its next barrier - 2.6x the cost of a patched group; the kernel's time follows
-                # their share (12-19 % in the first 20 cycles of a run, 2-4 % once the cloud has settled).
-                "limiter": "vector instruction issue (VALU): ~10 instructions per wave-beam on 7/8 of the waves; gathered groups (2.6x a patched one): texture-address pipe + barrier waits",
-                "groups_through_lds_patch": patch_fraction,
-                "groups_through_lds_patch_in_timed_region": patch_fraction_timed,
-                "valu_issue_floor_ms": n_local * BEAMS / 64 * 10.2 * 4 * (8 / 7) / (1024 * 2.4e9) * 1e3,
-                "ta_floor_ms_if_all_gathered": n_local * BEAMS / 64 * 16 / (256 * 2.4e9) * 1e3,
-            },
+            "roofline": roofline,
+            "verified": verified,
         }
         if not args.no_other_configs and world == 1 and n_local == 1_000_000:
             out["configs"] = other_configs(grid, cells, truth, controls, scans, filt, local_rank)

@@ -396,7 +396,16 @@ class Amcl {
     field_.reset();
   }
 
-  /// Update particles based on motion and sensor information (amcl_core.hpp:165-201).
+  /// The C ABI writes points as a flat double[2 m]; the measurement type is a vector of pairs (no aliasing between the two).
+  static measurement_type pairs_from(const std::vector<double>& flat, std::size_t m) {
+    measurement_type points;
+    points.reserve(m);
+    for (std::size_t i = 0; i < m; ++i) points.emplace_back(flat[2 * i], flat[2 * i + 1]);
+    return points;
+  }
+
+  /// Update particles based on motion and sensor information (amcl_core.hpp:165-201).  An empty particle set returns
+  /// std::nullopt before the motion policy sees the control action (:166-168; mcl_update checks it first).
   auto update(const SE2d& control_action, const measurement_type& measurement) -> std::optional<estimation_type> {
     static_assert(sizeof(std::pair<double, double>) == 2 * sizeof(double), "measurement points must be packed pairs");
     mcl_estimate est;
@@ -428,11 +437,10 @@ class Amcl {
     scan.max_beams = laser_scan.max_beams;
     scan.min_range = laser_scan.min_range;
     scan.max_range = laser_scan.max_range;
-    measurement_type points(std::min<std::size_t>(laser_scan.ranges.size(), laser_scan.max_beams) + 1);
+    std::vector<double> flat(2 * (std::min<std::size_t>(laser_scan.ranges.size(), laser_scan.max_beams) + 1));
     std::uint64_t m = 0;
-    check(mcl_prepare_laser_scan(&scan, &points.front().first, &m));
-    points.resize(m);
-    return update(base_pose_in_odom, points);
+    check(mcl_prepare_laser_scan(&scan, flat.data(), &m));
+    return update(base_pose_in_odom, pairs_from(flat, m));
   }
 
   /// Force a manual update of the particles on the next iteration of the filter (amcl_core.hpp:204).
@@ -519,10 +527,9 @@ class Amcl {
   /// points (3 floats each) in the sensor frame, `origin` the sensor pose in the base frame as Sophus::SE3d::data().
   auto update(const SE2d& base_pose_in_odom, const std::vector<float>& points_xyz, const std::array<double, 7>& origin)
       -> std::optional<estimation_type> {
-    measurement_type points(points_xyz.size() / 3 + 1);
-    check(mcl_project_point_cloud(points_xyz.data(), points_xyz.size() / 3, origin.data(), &points.front().first));
-    points.resize(points_xyz.size() / 3);
-    return update(base_pose_in_odom, points);
+    std::vector<double> flat(2 * (points_xyz.size() / 3 + 1));
+    check(mcl_project_point_cloud(points_xyz.data(), points_xyz.size() / 3, origin.data(), flat.data()));
+    return update(base_pose_in_odom, pairs_from(flat, points_xyz.size() / 3));
   }
 
   [[nodiscard]] const mcl_update_info& last_update_info() const { return last_info_; }

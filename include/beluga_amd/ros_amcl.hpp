@@ -192,10 +192,10 @@ class Amcl {
         xyz.push_back(static_cast<float>(p.y()));
         xyz.push_back(static_cast<float>(p.z()));
       }
-      measurement.resize(xyz.size() / 3 + 1);
-      if (mcl_project_point_cloud(xyz.data(), xyz.size() / 3, origin.data(), &measurement.front().first) != MCL_OK)
+      std::vector<double> flat(2 * (xyz.size() / 3 + 1));
+      if (mcl_project_point_cloud(xyz.data(), xyz.size() / 3, origin.data(), flat.data()) != MCL_OK)
         throw std::runtime_error("beluga_amd::ros::Amcl: bad point cloud");
-      measurement.resize(xyz.size() / 3);
+      measurement = beluga_amd::Amcl::pairs_from(flat, xyz.size() / 3);
     } else {
       const double qx = origin[0], qy = origin[1], qz = origin[2], qw = origin[3];
       for (const auto& p : points) {

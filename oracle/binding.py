@@ -61,37 +61,76 @@ class AmclConfig(C.Structure):
 
 
 _lib = None
+_libs = {}
+
+
+def _configure(L):
+    L.orc_so2_log.restype = C.c_double
+    L.orc_normalize.restype = C.c_double
+    L.orc_effective_sample_size.restype = C.c_double
+    L.orc_thrun.restype = C.c_double
+    L.orc_kld_target_size.restype = C.c_uint64
+    L.orc_kld_target_size.argtypes = [C.c_uint64, C.c_double, C.c_double]
+    L.orc_kld_take_while.restype = C.c_uint64
+    L.orc_kld_take_while.argtypes = [c_u64_p, C.c_uint64, C.c_uint64, C.c_double, C.c_double]
+    L.orc_spatial_hash.restype = C.c_uint64
+    L.orc_spatial_hash_xyt.restype = C.c_uint64
+    L.orc_spatial_hash_xyt.argtypes = [C.c_double, C.c_double, C.c_double, c_double_p]
+    L.orc_resample.restype = C.c_uint64
+    L.orc_amcl_create.restype = C.c_void_p
+    L.orc_amcl_num_free.restype = C.c_uint64
+    L.orc_amcl_num_particles.restype = C.c_uint64
+    L.orc_amcl_beam_steps.restype = C.c_int64
+    for name in (
+        "orc_amcl_destroy", "orc_amcl_set_map", "orc_amcl_set_field", "orc_amcl_get_field", "orc_amcl_num_free",
+        "orc_amcl_set_particles", "orc_amcl_num_particles", "orc_amcl_get_particles", "orc_amcl_init_normal", "orc_amcl_init_from_map",
+        "orc_amcl_force_update", "orc_amcl_stage_times", "orc_amcl_beam_steps", "orc_amcl_update",
+    ):
+        getattr(L, name).argtypes = None
+    return L
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_LIB_PATH)
-        L = _lib
-        L.orc_so2_log.restype = C.c_double
-        L.orc_normalize.restype = C.c_double
-        L.orc_effective_sample_size.restype = C.c_double
-        L.orc_thrun.restype = C.c_double
-        L.orc_kld_target_size.restype = C.c_uint64
-        L.orc_kld_target_size.argtypes = [C.c_uint64, C.c_double, C.c_double]
-        L.orc_kld_take_while.restype = C.c_uint64
-        L.orc_kld_take_while.argtypes = [c_u64_p, C.c_uint64, C.c_uint64, C.c_double, C.c_double]
-        L.orc_spatial_hash.restype = C.c_uint64
-        L.orc_spatial_hash_xyt.restype = C.c_uint64
-        L.orc_spatial_hash_xyt.argtypes = [C.c_double, C.c_double, C.c_double, c_double_p]
-        L.orc_resample.restype = C.c_uint64
-        L.orc_amcl_create.restype = C.c_void_p
-        L.orc_amcl_num_free.restype = C.c_uint64
-        L.orc_amcl_num_particles.restype = C.c_uint64
-        L.orc_amcl_beam_steps.restype = C.c_int64
-        for name in (
-            "orc_amcl_destroy", "orc_amcl_set_map", "orc_amcl_set_field", "orc_amcl_get_field", "orc_amcl_num_free",
-            "orc_amcl_set_particles", "orc_amcl_num_particles", "orc_amcl_get_particles", "orc_amcl_init_normal", "orc_amcl_init_from_map",
-            "orc_amcl_force_update", "orc_amcl_stage_times", "orc_amcl_beam_steps", "orc_amcl_update",
-        ):
-            getattr(L, name).argtypes = None
+        _libs["checker"] = _lib = _configure(C.CDLL(_LIB_PATH))
     return _lib
+
+
+def native_library_path() -> str:
+    """The timing build (-O3 -march=native) for THIS host: the file name carries a digest of the CPU's
+    model and flags, so a library built on another box is never loaded (it could hold instructions this CPU lacks)."""
+    import hashlib
+    ident = []
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith(("model name", "flags")):
+                    ident.append(line.strip())
+                    if len(ident) == 2:
+                        break
+    except OSError:
+        pass
+    return os.path.join(_HERE, "libbeluga_oracle_native_" + hashlib.sha256("|".join(ident).encode()).hexdigest()[:12] + ".so")
+
+
+def use_timing_build(on: bool) -> str:
+    """bench.py's cpu_baseline leg only: switches every call of this module between the checker (-O2 -ffp-contract=off, the
+    default) and the timing build.  Objects created under one build must be dropped before switching.  Returns the flags."""
+    global _lib
+    lib()
+    if not on:
+        _lib = _libs["checker"]
+        return "-O2 -ffp-contract=off -fopenmp"
+    if "native" not in _libs:
+        path = native_library_path()
+        src = os.path.join(_HERE, "beluga_oracle.cpp")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "native", "OUT=" + path])
+        _libs["native"] = _configure(C.CDLL(path))
+    _lib = _libs["native"]
+    return "-O3 -march=native -fopenmp"
 
 
 def _d(a):

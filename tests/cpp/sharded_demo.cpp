@@ -4,7 +4,8 @@
 // the exchange logic runs on a one-GPU box.  On a node with several GPUs the only change is device_id = rank and
 // mcl_comm_attach_rccl (or a peer-to-peer transport) in place of the host-staged one.
 // Prints the estimates of the sharded filter and of a single-context filter on the same inputs; tests/test_cpp_facade.py
-// compares them.  usage: sharded_demo [ranks = 2] [particles = 60000] [cycles = 6] [min_particles = particles]
+// compares them.  usage: sharded_demo [ranks = 2] [particles = 60000] [cycles = 6] [min_particles = particles] [estimate_kind = 0]
+// estimate_kind 1: every update returns beluga::cluster_based_estimate (what beluga_ros::Amcl returns), over the shards as well.
 // With min_particles < particles the filter is KLD-adaptive: the number of particles changes from cycle to cycle, every rank
 // reports the same count, and it equals the single-context filter's.
 #include <hip/hip_runtime_api.h>
@@ -113,6 +114,7 @@ struct Scenario {
 };
 
 uint64_t g_min_particles = 0;  // 0: fixed size
+int g_estimate_kind = 0;       // 1: cluster_based_estimate
 
 mcl_config make_config(uint64_t n_total, uint64_t shard_offset, uint64_t shard_capacity) {
   mcl_config cfg;
@@ -137,6 +139,7 @@ bool run_filter(const Scenario& sc, mcl_ctx* ctx, std::vector<mcl_estimate>* out
   const double origin[4] = {1.0, 0.0, -2.0, -3.0};
   const int8_t traits[3] = {0, -1, 100};
   if (mcl_set_map(ctx, sc.cells.data(), sc.W, sc.H, 0.05, origin, traits) != MCL_OK) return false;
+  if (g_estimate_kind && mcl_set_estimate_kind(ctx, g_estimate_kind, nullptr) != MCL_OK) return false;
   const double mean[3] = {1.0, 1.0, 0.2}, cov[9] = {0.09, 0, 0, 0, 0.09, 0, 0, 0, 0.02};
   if (mcl_initialize_normal(ctx, mean, cov) != MCL_OK) return false;
   for (size_t c = 0; c < sc.scans.size(); ++c) {
@@ -197,6 +200,7 @@ bool run_facade_shards(const Scenario& sc, int ranks, uint64_t n_total, std::vec
         Amcl filter{map, DifferentialDriveModelParam{0.1, 0.05, 0.1, 0.05}, lf, params, /*seed=*/77, /*device=*/0, {},
                     Shard::of(n_total, static_cast<unsigned>(r), static_cast<unsigned>(ranks))};
         filter.attach(static_cast<unsigned>(r), static_cast<unsigned>(ranks), mcl_transport{&endpoints[r], all_gather, all_to_all});
+        if (g_estimate_kind) filter.use_cluster_based_estimate(true);
         filter.initialize(SE2d{0.2, 1.0, 1.0}, Matrix3d{0.09, 0, 0, 0, 0.09, 0, 0, 0, 0.02});
         for (size_t c = 0; c < sc.scans.size(); ++c) {
           Amcl::measurement_type scan;
@@ -233,6 +237,7 @@ int main(int argc, char** argv) {
   const int cycles = argc > 3 ? std::atoi(argv[3]) : 6;
   g_min_particles = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 0;
   if (g_min_particles >= n_total) g_min_particles = 0;
+  g_estimate_kind = argc > 5 ? std::atoi(argv[5]) : 0;
   const Scenario sc(cycles);
 
   mcl_ctx* single = nullptr;

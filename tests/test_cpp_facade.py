@@ -97,6 +97,22 @@ def test_sharded_kld_cycle_inside_the_library_matches_one_context(sharded_demo, 
     assert kv["facade_mismatches"] == ["0"], out.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,max_particles,min_particles", [(2, 60000, 0), (3, 70001, 0), (4, 40000, 3000)])
+def test_sharded_cluster_based_estimate_matches_one_context(sharded_demo, ranks, max_particles, min_particles):
+    """beluga_ros::Amcl returns cluster_based_estimate from every update (beluga_ros/src/amcl.cpp:125); over shards the
+    occupied cells of every rank are gathered and merged in global first-occurrence order, every rank runs the same cluster
+    assignment, and the winning cluster's sums are gathered (cluster_based_estimation.hpp:345-433).  Fixed-size and
+    KLD-adaptive cycles against the single-context filter."""
+    out = subprocess.run([sharded_demo, str(ranks), str(max_particles), "6", str(min_particles), "1"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    kv = {line.split()[0]: line.split()[1:] for line in out.stdout.splitlines()}
+    assert kv["count_mismatches"] == ["0"], out.stdout
+    pose_diff, cov_diff = (float(v) for v in kv["estimate_max_abs_difference"])
+    assert pose_diff < 1e-9 and cov_diff < 1e-9, out.stdout
+    assert kv["facade_mismatches"] == ["0"], out.stdout
+
+
 def test_node_bodies_compile_and_fail_loudly_without_gpu(node_bodies):
     import torch
     if torch.cuda.is_available():

@@ -1,0 +1,111 @@
+"""End-to-end parity AT the headline workloads: full `Amcl::update` cycles (amcl_core.hpp:165-201) of BASELINE configs[1]
+(1M particles x 1080 beams, 4000x4000 @ 5 cm grid seed 42, resample every cycle - built by bench.py's own make_workload) and
+of configs[2] (10M particles, KLD eps .05 z 3 + selective resampling) on the GPU against the oracle, cycle by cycle.
+
+The stage tests of tests/test_gpu_parity.py check samples of full-size launches; these check the trajectory itself: the
+estimate of every cycle, the weight normaliser, the policy decisions, the particle counts (exact) and the particle set at the
+end.  Tolerances: estimates 1e-9 absolute (pose) / 1e-8 relative (covariance), normaliser 1e-11 relative; particle sets
+identical except for CDF-boundary draws (the one index result that depends on the association of a prefix sum): each such
+draw hands a slot another ancestor, whose descendants then differ - counted, bounded, and the estimate tolerance is widened by
+what that many differing particles can move a mean over N.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import bench
+from beluga_amd.amcl import (Amcl, AmclParams, DifferentialDriveModelParam, LikelihoodFieldModelParam, OccupancyGrid,
+                             se2_from_xytheta)
+from oracle import binding as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _filters(cells, params, seed=42):
+    grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
+    gpu = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF), params, seed=seed)
+    lf = bench.LF
+    cpu = orc.Amcl(min_particles=params.min_particles, max_particles=params.max_particles,
+                   selective_resampling=params.selective_resampling, alphas=bench.ALPHAS, seed=seed, threads=orc.max_threads(),
+                   lf=(lf["max_obstacle_distance"], lf["max_laser_distance"], lf["z_hit"], lf["z_random"], lf["sigma_hit"]),
+                   lf_model_unknown_space=lf["model_unknown_space"])
+    cpu.set_map(cells, bench.RESOLUTION, grid.origin)
+    return grid, gpu, cpu
+
+
+def _differing(gpu, cpu):
+    gs, gw = gpu.particles()
+    cs, cw = cpu.particles()
+    assert gs.shape == cs.shape
+    assert np.array_equal(gw, cw) or np.allclose(gw, cw, rtol=1e-12, atol=0.0)
+    return int(np.any(np.abs(gs - cs) > 1e-9, axis=1).sum())
+
+
+def _check_cycle(c, g, o, gi, oi, n, differing_so_far):
+    assert (g is None) == (o is None), f"cycle {c}: update / no-update decisions differ"
+    assert gi["resampled"] == oi["resampled"], f"cycle {c}: resample decisions differ"
+    assert gi["weight_sum"] == pytest.approx(oi["weight_sum"], rel=1e-11), f"cycle {c}"
+    # a differing particle sits within the cloud (metres at most): it moves a mean over n by less than 10 / n
+    slack = differing_so_far * 10.0 / n
+    np.testing.assert_allclose(g[0], o[0], atol=1e-9 + slack, err_msg=f"cycle {c}: pose")
+    np.testing.assert_allclose(g[1], o[1], rtol=1e-8, atol=1e-11 + slack, err_msg=f"cycle {c}: covariance")
+
+
+def test_headline_config_1m_x_1080_five_cycles_against_the_oracle():
+    """BASELINE configs[1] exactly as bench.py builds and times it: 1M particles, 1080 beams, 4000^2 map (seed 42), multinomial
+    resample every cycle, device-side recovery estimator, the LDS-patch kernel.  Five cycles."""
+    cycles, n = 5, 1_000_000
+    cells, truth, odoms, scans, _poses = bench.make_workload(cycles)
+    params = AmclParams(min_particles=n, max_particles=n)
+    grid, gpu, cpu = _filters(cells, params)
+    cov = np.diag([0.25, 0.25, 0.04])
+    gpu.initialize(truth, cov)
+    cpu.initialize(truth, cov)
+    differing = 0
+    for c in range(cycles):
+        ctrl = se2_from_xytheta(*odoms[c])
+        g = gpu.update(ctrl, scans[c])
+        o = cpu.update(ctrl, scans[c])
+        gi, oi = gpu.last_info, cpu.last_info
+        assert gi["num_particles"] == n == len(cpu.particles()[1])
+        differing = _differing(gpu, cpu)
+        assert differing <= 5 * (c + 1), f"cycle {c}: {differing} particles differ from the oracle's set"
+        _check_cycle(c, g, o, gi, oi, n, differing)
+        assert gi["random_state_probability"] == pytest.approx(oi["random_state_probability"], abs=1e-12)
+    # the kernel under test is the one the bench times
+    assert gpu.counter("lf_patch_launches") == cycles
+    # and the filter localises: the estimate follows the true pose of the workload
+    pose = _poses[cycles - 1]
+    assert math.hypot(g[0][2] - pose[0], g[0][3] - pose[1]) < 0.25
+    gpu.close()
+
+
+def test_config3_10m_kld_selective_cycles_against_the_oracle():
+    """BASELINE configs[2]: max 10M / min 100k particles, KLD (eps .05, z 3) + selective resampling (ESS < N/2), same map and
+    scans.  The first cycle keeps all 10M particles (ESS above N/2: no resampling), the second takes the KLD cut; the particle
+    count after every cycle is an integer result and must equal the oracle's."""
+    cycles, n_max, n_min = 4, 10_000_000, 100_000
+    cells, truth, odoms, scans, _poses = bench.make_workload(cycles)
+    params = AmclParams(min_particles=n_min, max_particles=n_max, selective_resampling=True)
+    grid, gpu, cpu = _filters(cells, params)
+    cov = np.diag([0.25, 0.25, 0.04])
+    gpu.initialize(truth, cov)
+    cpu.initialize(truth, cov)
+    counts, fired = [], []
+    for c in range(cycles):
+        ctrl = se2_from_xytheta(*odoms[c])
+        g = gpu.update(ctrl, scans[c])
+        o = cpu.update(ctrl, scans[c])
+        gi, oi = gpu.last_info, cpu.last_info
+        assert gi["num_particles"] == len(cpu.particles()[1]), f"cycle {c}: particle counts differ"
+        counts.append(gi["num_particles"])
+        fired.append(bool(gi["resampled"]))
+        differing = _differing(gpu, cpu)
+        assert differing <= 5 * (c + 1), f"cycle {c}: {differing} particles differ from the oracle's set"
+        _check_cycle(c, g, o, gi, oi, gi["num_particles"], differing)
+        if oi["ess"] >= 0:
+            assert gi["ess"] == pytest.approx(oi["ess"], rel=1e-10)
+    assert counts[0] == n_max and not fired[0], (counts, fired)  # what bench.py reports as the cycle that does not fire
+    assert any(fired) and n_min <= counts[-1] < n_max, (counts, fired)
+    gpu.close()

@@ -14,7 +14,7 @@ ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--particles5", type=int, default=1_000_000)
 ap.add_argument("--max3", type=int, default=10_000_000)
 args = ap.parse_args()
-cells, truth, odoms, scans = bench.make_workload(args.steps + 2)
+cells, truth, odoms, scans, _poses = bench.make_workload(args.steps + 2)
 grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
 controls = [se2_from_xytheta(*o) for o in odoms]
 motion = DifferentialDriveModelParam(*bench.ALPHAS)

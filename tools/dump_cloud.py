@@ -11,7 +11,7 @@ ap.add_argument("--particles", type=int, default=1_000_000)
 ap.add_argument("--cycles", type=int, default=6)
 ap.add_argument("--out", default="gpurun_out/cloud.npy")
 args = ap.parse_args()
-cells, truth, odoms, scans = bench.make_workload(args.cycles + 1)
+cells, truth, odoms, scans, _poses = bench.make_workload(args.cycles + 1)
 grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
 p = AmclParams(min_particles=args.particles, max_particles=args.particles)
 f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF), p, seed=42)

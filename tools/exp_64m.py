@@ -12,7 +12,7 @@ from beluga_amd.amcl import (Amcl, AmclParams, DifferentialDriveModelParam, Like
 from oracle import binding as orc  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64_000_000
-cells, truth, odoms, scans = bench.make_workload(6)
+cells, truth, odoms, scans, _poses = bench.make_workload(6)
 grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
 t0 = time.perf_counter()
 f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF),

@@ -8,7 +8,7 @@ import bench
 from beluga_amd.amcl import Amcl, AmclParams, DifferentialDriveModelParam, LikelihoodFieldModelParam, OccupancyGrid, se2_from_xytheta
 
 variants = sys.argv[1:] or ["beams", "gather", "lane", "wave"]
-cells, truth, odoms, scans = bench.make_workload(2)
+cells, truth, odoms, scans, _poses = bench.make_workload(2)
 grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
 n = int(os.environ.get("N", 1_000_000))
 f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF), AmclParams(min_particles=n, max_particles=n), seed=42)

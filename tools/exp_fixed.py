@@ -8,7 +8,7 @@ from beluga_amd.amcl import Amcl, AmclParams, DifferentialDriveModelParam, Likel
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(os.environ.get("N", 10_000_000))
-cells, truth, odoms, scans = bench.make_workload(steps + 1)
+cells, truth, odoms, scans, _poses = bench.make_workload(steps + 1)
 grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
 controls = [se2_from_xytheta(*o) for o in odoms]
 f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF), AmclParams(min_particles=n, max_particles=n), seed=42)

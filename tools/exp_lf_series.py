@@ -6,7 +6,7 @@ import bench
 from beluga_amd.amcl import Amcl, AmclParams, DifferentialDriveModelParam, LikelihoodFieldModelParam, OccupancyGrid, se2_from_xytheta
 
 steps = 40
-cells, truth, odoms, scans = bench.make_workload(steps)
+cells, truth, odoms, scans, _poses = bench.make_workload(steps)
 grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
 controls = [se2_from_xytheta(*o) for o in odoms]
 n = 1_000_000

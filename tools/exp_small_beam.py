@@ -6,7 +6,7 @@ import bench
 from beluga_amd.amcl import Amcl, AmclParams, BeamModelParam, DifferentialDriveModelParam, OccupancyGrid, se2_from_xytheta
 
 steps = 20
-cells, truth, odoms, scans = bench.make_workload(steps)
+cells, truth, odoms, scans, _poses = bench.make_workload(steps)
 grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
 controls = [se2_from_xytheta(*o) for o in odoms]
 for (n, beams) in [(2000, 60), (2000, 180), (2000, 1080), (10000, 180), (15000, 1080), (20000, 1080), (50000, 1080)]:
