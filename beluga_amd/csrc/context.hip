@@ -595,11 +595,13 @@ void points_pulled(mcl_ctx* ctx, bool with_event) {
 // KeyFrame::layout of the next ordering: position-major for likelihood-field sets reported as dispersed (their gather kernel
 // walks the order region by region, kernels.hip: k_reweight_lf_palette<true, true>), heading-major otherwise.
 uint32_t key_layout(const mcl_ctx* ctx) {
-  if (ctx->tuning.key_layout >= 0) return ctx->tuning.key_layout ? 1u : 0u;
-  return ctx->cfg.sensor_kind != MCL_SENSOR_BEAM && ctx->tuning.lf_patch == 1 && !ctx->patch_useful && ctx->tuning.lf_far_tiles != 0 &&
-                 ctx->far_tiles != 0
-             ? 1u
-             : 0u;
+  const uint32_t curve = ctx->tuning.key_curve ? 0u : 2u;  // heading-major keys: Hilbert curve (default) / Morton order
+  if (ctx->tuning.key_layout >= 0) return (ctx->tuning.key_layout ? 1u : 0u) | curve;
+  return (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM && ctx->tuning.lf_patch == 1 && !ctx->patch_useful && ctx->tuning.lf_far_tiles != 0 &&
+                  ctx->far_tiles != 0
+              ? 1u
+              : 0u) |
+         curve;
 }
 bool predict_key_frame(const mcl_ctx* ctx, const DiffDriveSampler* motion, KeyFrame* out) {
   out->layout = key_layout(ctx);
@@ -638,6 +640,24 @@ bool predict_key_frame(const mcl_ctx* ctx, const DiffDriveSampler* motion, KeyFr
   out->inv_y = inverse_span(sy);
   out->inv_t = sigma_span_t(std::min(st, kPi / 4.0));  // the heading bins never span more than the circle
   out->t_off = 0.f;
+  // How the 20 bits are split: a run of the curve is roughly a cube of bins, and what a workgroup's LDS patch has to absorb is
+  // its extent in x (or y) PLUS its extent in heading times the scan's reach - so the split that minimises the sum of the two
+  // bin sizes, in cells: 8 sigma_xy / res / 2^b  +  8 sigma_theta reach / res / 2^(20 - 2 b), b = 4 .. 6.
+  out->bits_xy = 6;
+  if (ctx->tuning.key_bits_xy >= 4 && ctx->tuning.key_bits_xy <= 6) {
+    out->bits_xy = static_cast<uint32_t>(ctx->tuning.key_bits_xy);
+  } else if (ctx->tuning.key_bits_xy == 0 && ctx->resolution > 0.0 && std::isfinite(ctx->scan_extent)) {
+    const double reach = 0.5 * ctx->scan_extent / ctx->resolution;  // cells; scan_extent = max |x| + |y| of the scan, ~ sqrt 2 the longest beam
+    const double span_xy = spans * std::max(sx, sy) / ctx->resolution, span_t = 8.0 * std::min(st, kPi / 4.0) * reach;
+    double best = std::numeric_limits<double>::infinity();
+    for (uint32_t b = 4; b <= 6; ++b) {
+      const double cost = std::ldexp(span_xy, -static_cast<int>(b)) + std::ldexp(span_t, -static_cast<int>(20 - 2 * b));
+      if (cost < best) {
+        best = cost;
+        out->bits_xy = b;
+      }
+    }
+  }
   return true;
 }
 void remember_cloud_estimate(mcl_ctx* ctx, const mcl_estimate& est) {
@@ -804,7 +824,8 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
                        scan_is_short, ctx->tuning, use_patches,
                        PatchStats{reinterpret_cast<unsigned long long*>(ctx->d_scalars.ptr + 24),
                                   reinterpret_cast<unsigned long long*>(ctx->hd_scalars + 28),
-                                  static_cast<uint32_t>(ctx->tuning.lf_loose_below)},
+                                  static_cast<uint32_t>(ctx->tuning.lf_loose_below), ctx->tuning.lf_margin ? 0u : 1u,
+                                  ctx->tuning.lf_split ? 1u : 0u},
                        /*dispersed=*/!use_patches && (ctx->tuning.lf_far_tiles == 2 || (ctx->tuning.lf_patch == 1 && !ctx->patch_useful)),
                        &far_tiles_used);
     if (far_tiles_used) ctx->lf_far_launches += 1;
@@ -1664,7 +1685,11 @@ int32_t rccl_all_to_all(void* user, const void* d_send, const uint64_t* send_byt
 
 extern "C" {
 
-const char* mcl_version(void) { return "beluga_mcl 0.1 (gfx950)"; }
+const char* mcl_version(void) { return "beluga_mcl 0.3 (gfx950)"; }
+
+uint32_t mcl_debug_curve_index(uint32_t heading_bin, uint32_t y_bin, uint32_t x_bin, uint32_t bits) {
+  if (bits < 1 || bits > 6) return 0xFFFFFFFFu;
+  return hilbert_index_3(heading_bin, y_bin, x_bin, bits); }
 
 void mcl_default_config(mcl_config* cfg) {
   std::memset(cfg, 0, sizeof(*cfg));
@@ -1738,7 +1763,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_bits_xy", "lf_margin", "lf_split"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2608,6 +2633,10 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "lf_patch") t.lf_patch = value < 0 || value > 2 ? 1 : static_cast<int>(value);
   else if (key == "device_policy") t.device_policy = value ? 1 : 0;
   else if (key == "field_build") t.field_build = value ? 1 : 0;
+  else if (key == "key_curve") t.key_curve = value ? 1 : 0;
+  else if (key == "key_bits_xy") t.key_bits_xy = (value >= 4 && value <= 6) ? static_cast<int>(value) : 0;
+  else if (key == "lf_margin") t.lf_margin = value ? 1 : 0;
+  else if (key == "lf_split") t.lf_split = value ? 1 : 0;
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else if (key == "beam_sort_min_particles") t.beam_sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "mcl_set_option: unknown option " + key);

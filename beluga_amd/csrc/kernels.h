@@ -138,6 +138,13 @@ struct Tuning {
   int lf_small_particles = 65536;   // likelihood-field sets below this: a wave per particle with the lanes over the beams, no ordering
                                     // (measured: 25 % faster than the ordered kernels at 20K particles, 10 % at 50K, 12 % slower at 100K)
   int field_build = 0;              // mcl_set_map: 0 = host wavefront (bit-identical to the reference), 1 = exact EDT on the device
+  int key_curve = 1;                // heading-major ordering key: 1 = Hilbert curve through (heading, y, x), 0 = Morton order
+  int key_bits_xy = 0;              // bits of the x / y bins of that key: 0 = chosen per cycle from the cloud's spread and the scan's
+                                    // reach (4 .. 6), otherwise forced; round 2: 6 (8 heading bits)
+  int lf_split = 1;                 // LDS-patch planner: a group of 8 beams that fits no whole 64 x 64 patch (a range discontinuity inside
+                                    // it) may go through two half patches (beams [0, k) and [k, 8): 32 x 64 or 64 x 32 cells each); 0 = never
+  int lf_margin = 1;                // LDS-patch planner, rotation part of the bound: 1 = per axis (|sin d| |q'y| + (1 - cos d) |q'x|),
+                                    // 0 = round 2's |R_p - R_ref| |q| on both axes
 };
 
 // Spatial ordering of the particles (kLfSortedLanes, ordered beam kernel): the 64 lanes of a wave should hold neighbouring
@@ -151,9 +158,51 @@ struct KeyFrame {
   float inv_x, inv_y;     // 1 / span of the x / y bins (span = 8 sigma)
   float inv_t, t_off;     // heading bins: u = (delta - t_off) * inv_t + 0.5
   uint32_t layout;        // 0: heading-major key (dense sets: a workgroup's poses fit an LDS patch), 1: position-major key
-                          // (dispersed sets: neighbours in the order share a region of the map, whatever their heading)
+                          // (dispersed sets: neighbours in the order share a region of the map, whatever their heading);
+                          // | 2: the heading-major key follows the Z (Morton) curve instead of the Hilbert curve (option key_curve)
+  uint32_t bits_xy;       // heading-major key: bits of the x and of the y bins (4 .. 6; 0 = 6); the heading takes the other 20 - 2 bits_xy
 };
 constexpr uint32_t kSortDigits = 1024;  // two least-significant-digit-first passes of 10 bits each
+// Position of the cell (a0, a1, a2), `bits` bits each (bits <= 6), along the 3-D Hilbert curve through the (2^bits)^3 cells
+// (Skilling's transpose form, "Programming the Hilbert curve", 2004: undo the excess work, Gray-encode, interleave with a0 most
+// significant).  Consecutive positions are face neighbours, so ANY run of the order is a connected, compact set of cells - a run
+// of the Morton order that crosses a high-level boundary of the Z curve is two pieces far apart, and the workgroup that holds it
+// (448 consecutive particles of the order, k_reweight_lf_patch) fits no LDS patch.  The curve enters at (0, 0, 0) and leaves at
+// (2^bits - 1, 0, 0): with the heading on axis 0, the slabs of the key's top heading bits chain into one continuous curve.
+__host__ __device__ inline uint32_t hilbert_index_3(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t bits) {
+  const uint32_t mask = (1u << bits) - 1u;
+  uint32_t x0 = a0 & mask, x1 = a1 & mask, x2 = a2 & mask;
+  for (uint32_t q = 1u << (bits - 1); q > 1; q >>= 1) {
+    const uint32_t p = q - 1;
+    x0 ^= (x0 & q) ? p : 0u;  // axis 0 against itself: invert or nothing
+    {
+      const uint32_t t = (x0 ^ x1) & p;
+      const bool inv = (x1 & q) != 0;
+      x0 ^= inv ? p : t;
+      x1 ^= inv ? 0u : t;
+    }
+    {
+      const uint32_t t = (x0 ^ x2) & p;
+      const bool inv = (x2 & q) != 0;
+      x0 ^= inv ? p : t;
+      x2 ^= inv ? 0u : t;
+    }
+  }
+  x1 ^= x0;
+  x2 ^= x1;
+  uint32_t t = 0;
+  for (uint32_t q = 1u << (bits - 1); q > 1; q >>= 1) t ^= (x2 & q) ? q - 1 : 0u;
+  x0 ^= t;
+  x1 ^= t;
+  x2 ^= t;
+  auto spread = [](uint32_t v) {  // ..fedcba -> f00e00d00c00b00a
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+  };
+  return (spread(x0) << 2) | (spread(x1) << 1) | spread(x2);
+}
 struct SortScratch {
   uint32_t* keys;                // [n] key of particle i
   uint32_t* perm;                // [n] sorted position -> particle index
@@ -188,6 +237,8 @@ struct PatchStats {
   unsigned long long* mirror;  // [3]: mapped host copy of the first two, written by the last workgroup of a launch, and their
                                // low halves packed into one word (planned | through << 32: one store, read without synchronisation)
   uint32_t loose_below;        // a workgroup with fewer than loose_below / 256 of its groups fitting a patch gathers them all
+  uint32_t isotropic_margin;   // 1: the rotation part of the bound as |R_p - R_ref| |q| on both axes (Tuning::lf_margin = 0)
+  uint32_t split_patches;      // 1: a group that fits no whole patch may go through two half patches (Tuning::lf_split)
 };
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,

@@ -124,10 +124,18 @@ __device__ __forceinline__ uint32_t order_key(const double4& q, const KeyFrame& 
   const float c0 = static_cast<float>(kf.c0), s0 = static_cast<float>(kf.s0);
   const float delta = atan2f(s * c0 - c * s0, c * c0 + s * s0);  // heading relative to the frame's, in (-pi, pi]
   const float ut = (delta - kf.t_off) * kf.inv_t + 0.5f;
-  const uint32_t bx = static_cast<uint32_t>(unit_bin(ux, 1 << kKeyBitsXY)), by = static_cast<uint32_t>(unit_bin(uy, 1 << kKeyBitsXY));
-  const uint32_t bt = static_cast<uint32_t>(unit_bin(ut, 1 << kKeyBitsTheta));
-  if (kf.layout != 0) return ((spread2(bx) | (spread2(by) << 1)) << kKeyBitsTheta) | bt;
-  return ((bt >> kKeyBitsXY) << (3 * kKeyBitsXY)) | spread3(bx) | (spread3(by) << 1) | (spread3(bt & ((1u << kKeyBitsXY) - 1)) << 2);
+  if (kf.layout & 1u) {
+    const uint32_t bx = static_cast<uint32_t>(unit_bin(ux, 1 << kKeyBitsXY)), by = static_cast<uint32_t>(unit_bin(uy, 1 << kKeyBitsXY));
+    const uint32_t bt = static_cast<uint32_t>(unit_bin(ut, 1 << kKeyBitsTheta));
+    return ((spread2(bx) | (spread2(by) << 1)) << kKeyBitsTheta) | bt;
+  }
+  // heading-major: the top heading bits select a slab, inside it the curve runs through cubes of bits_xy bits per axis
+  const uint32_t bits = kf.bits_xy ? kf.bits_xy : kKeyBitsXY, bits_t = kKeyBits - 2 * bits;
+  const uint32_t bx = static_cast<uint32_t>(unit_bin(ux, 1 << bits)), by = static_cast<uint32_t>(unit_bin(uy, 1 << bits));
+  const uint32_t bt = static_cast<uint32_t>(unit_bin(ut, 1 << bits_t));
+  const uint32_t slab = (bt >> bits) << (3 * bits), bt_in = bt & ((1u << bits) - 1);
+  if (kf.layout & 2u) return slab | spread3(bx) | (spread3(by) << 1) | (spread3(bt_in) << 2);
+  return slab | hilbert_index_3(bt_in, by, bx, bits);
 }
 
 // The cycle's scan, pulled from mapped pinned host memory by one workgroup (17 KB at 1080 beams): an asynchronous
@@ -460,9 +468,9 @@ __device__ __forceinline__ int med3_i32(int v, int lo /* in a VGPR: one scalar o
   asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "s"(hi));
   return r;
 }
-__device__ __forceinline__ uint32_t lshl_add_u32(uint32_t a, int shift /* constant */, uint32_t b) {  // (a << shift) + b, one instruction
+__device__ __forceinline__ uint32_t lshl_add_u32_uniform(uint32_t a, int shift /* constant */, uint32_t b /* uniform: a scalar register */) {
   uint32_t r;
-  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(shift), "v"(b));
+  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(shift), "s"(b));
   return r;
 }
 __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b /* uniform */, uint32_t c) {  // (a mod 2^24) * (b mod 2^24) + c
@@ -766,7 +774,7 @@ constexpr uint32_t kPatchPitch = kPatchH * 2 + 16;
 constexpr uint32_t kPatchBytes = kPatchW * kPatchPitch;
 constexpr uint32_t kPatchParticles = kPalBlock - 64;  // per workgroup
 constexpr uint32_t kPatchPlanned = 256;               // groups with a plan entry; the ones beyond are gathered
-constexpr uint32_t kPatchLds = 2 * kPatchBytes + kPatchPlanned * 8 + 48 * 4;  // two patches, the plan, the prologue's partial results
+constexpr uint32_t kPatchLds = 2 * kPatchBytes + kPatchPlanned * 16 + 48 * 4;  // two patches, the plan, the prologue's partial results
 constexpr double kPatchMagic = 1572864.0 + 4.656612873077392578125e-10;     // 1.5 * 2^20 + 2^-31
 // 6 waves per SIMD = three workgroups per CU: at most 80 registers
 __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reweight_lf_patch(double* __restrict__ w, uint64_t n, FieldView f,
@@ -783,9 +791,14 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     double* s_pal = reinterpret_cast<double*>(smem + f.pal_base);
     for (uint32_t k = threadIdx.x; k < f.pal_count; k += kPalBlock) s_pal[k] = f.pal_val[k];
   }
-  // plan entry of group g: biased x0; biased y0 (a multiple of 8) | 1 if the group goes through a patch
-  int2* s_plan = reinterpret_cast<int2*>(smem + patch_base + 2 * kPatchBytes);
-  float* s_bound = reinterpret_cast<float*>(smem + patch_base + 2 * kPatchBytes + kPatchPlanned * 8);  // [7][6]
+  // plan entry of group g: {x0A, y0A | flags, x0B, y0B | first beam of half B} - biased origins, y0 multiples of 8;
+  // flags: 1 = the group goes through a patch, 2 = split into two halves side by side (32 x 64 cells each), 4 = split into two
+  // halves one above the other (64 x 32 cells each).  A group whose 8 end-points straddle a range discontinuity fits no single
+  // patch however tight the cloud (3 - 5 % of the groups of an indoor scan); its beams [0, k) and [k, 8) almost always fit two
+  // half patches, which share the buffer of one whole patch: the consumers' addressing does not change, only the constant K
+  // differs between the two halves (a scalar select per beam).
+  int4* s_plan = reinterpret_cast<int4*>(smem + patch_base + 2 * kPatchBytes);
+  float* s_bound = reinterpret_cast<float*>(smem + patch_base + 2 * kPatchBytes + kPatchPlanned * 16);  // [7][6]
   const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPalBlock / 64 - 1);  // a scalar branch: the roles
                                                                                                   // run different loops
   const uint32_t lane = threadIdx.x & 63;
@@ -806,7 +819,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
 
   // ---- the reference pose: the middle of the workgroup's box in x and y, its mean heading (any pose would do: the bound
   // below is taken against whatever is chosen here; a central one makes it small).  In cells, like ixt, iyt.
-  float* s_part = s_bound;  // [7][6] partial results, then [7][3]
+  float* s_part = s_bound;  // [7][6] partial results, then [7][4]
   if (!producer) {
     float lo_x = static_cast<float>(ixt), hi_x = lo_x, lo_y = static_cast<float>(iyt), hi_y = lo_y;
     float sum_c = static_cast<float>(ct), sum_s = static_cast<float>(st);
@@ -850,67 +863,115 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   const double rxm = ref_x + kPatchMagic, rym = ref_y + kPatchMagic;
   __syncthreads();  // the partial results are read; their place takes the next ones
   // ---- the bound: every wave's lanes against the reference pose, then the workgroup's maxima
+  // Rotation part: with M the reference's (c, s) as a matrix (a rotation up to the rounding of its float entries) and q' = M q / res
+  // the reference end-point relative to the reference position - what the planner below evaluates anyway -, the particle's end-point
+  // is off by (R_p M^-1 - I) q' = (A q'x - B q'y, B q'x + A q'y),  A = (c_p c + s_p s) / |M|^2 - 1,  B = (s_p c - c_p s) / |M|^2:
+  // |B| = |sin d| and |A| = 1 - cos d for a heading difference d, so a beam along x moves in y only (to first order), and the
+  // margin is taken per axis: max|A| max|q'x| + max|B| max|q'y| in x, max|B| max|q'x| + max|A| max|q'y| in y.
+  // (stats.isotropic_margin: round 2's bound, |R_p - M| |q| on both axes, for A/B measurements.)
   if (!producer) {
     const double dc = ct - ref_c, ds = st - ref_s;
     float dx = static_cast<float>(fabs(ixt - ref_x)), dy = static_cast<float>(fabs(iyt - ref_y));
-    float dr = static_cast<float>(sqrt(dc * dc + ds * ds));
-    if (!(lane_small && dx < 1e6f && dy < 1e6f && dr < 4.f)) dx = dy = dr = INFINITY;  // a far or non-finite particle: no patches
+    float da, db;
+    if (stats.isotropic_margin) {
+      da = db = static_cast<float>(sqrt(dc * dc + ds * ds));
+    } else {
+      const double norm2 = ref_c * ref_c + ref_s * ref_s;
+      da = static_cast<float>(fabs((ct * ref_c + st * ref_s) / norm2 - 1.0));
+      db = static_cast<float>(fabs((st * ref_c - ct * ref_s) / norm2));
+    }
+    if (!(lane_small && dx < 1e6f && dy < 1e6f && da < 4.f && db < 4.f)) dx = dy = da = db = INFINITY;  // a far or non-finite particle: no patches
     for (int o = 32; o > 0; o >>= 1) {
       dx = fmaxf(dx, __shfl_xor(dx, o));
       dy = fmaxf(dy, __shfl_xor(dy, o));
-      dr = fmaxf(dr, __shfl_xor(dr, o));
+      da = fmaxf(da, __shfl_xor(da, o));
+      db = fmaxf(db, __shfl_xor(db, o));
     }
     if (lane == 0) {
-      float* mine = s_bound + 3 * (threadIdx.x >> 6);
+      float* mine = s_bound + 4 * (threadIdx.x >> 6);
       mine[0] = dx;
       mine[1] = dy;
-      mine[2] = dr;
+      mine[2] = da;
+      mine[3] = db;
     }
   }
   __syncthreads();
   // ---- the plan: thread g looks at group g through the reference pose
   bool mine_fits = false;
   if (threadIdx.x < groups && threadIdx.x < kPatchPlanned) {
-    float Dx = 0.f, Dy = 0.f, Drot = 0.f;
+    float Dx = 0.f, Dy = 0.f, Da = 0.f, Db = 0.f;
     for (uint32_t k = 0; k < kPalBlock / 64 - 1; ++k) {
-      Dx = fmaxf(Dx, s_bound[3 * k]);
-      Dy = fmaxf(Dy, s_bound[3 * k + 1]);
-      Drot = fmaxf(Drot, s_bound[3 * k + 2]);
+      Dx = fmaxf(Dx, s_bound[4 * k]);
+      Dy = fmaxf(Dy, s_bound[4 * k + 1]);
+      Da = fmaxf(Da, s_bound[4 * k + 2]);
+      Db = fmaxf(Db, s_bound[4 * k + 3]);
     }
     // every float operation below may round down: scaled up by 1 + 2^-10 where it matters, and two cells of slack
     Dx = Dx * 1.001f + 2.f;
     Dy = Dy * 1.001f + 2.f;
-    int lo_x = INT_MAX, hi_x = INT_MIN, lo_y = INT_MAX, hi_y = INT_MIN;
-    float reach2 = 0.f;
     const double2* q = reinterpret_cast<const double2*>(pts) + (b_begin + 8 * threadIdx.x);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const double2 p = q[k];
-      const double sx = __builtin_fma(p.x, rc, __builtin_fma(-p.y, rs, rxm));
-      const double sy = __builtin_fma(p.x, rs, __builtin_fma(p.y, rc, rym));
-      const int cx = static_cast<int>(__builtin_bit_cast(uint64_t, sx) >> 32), cy = static_cast<int>(__builtin_bit_cast(uint64_t, sy) >> 32);
-      lo_x = min(lo_x, cx);
-      hi_x = max(hi_x, cx);
-      lo_y = min(lo_y, cy);
-      hi_y = max(hi_y, cy);
-      const float qx = static_cast<float>(p.x), qy = static_cast<float>(p.y);
-      reach2 = fmaxf(reach2, qx * qx + qy * qy);
+    // Do the beams [from, to) of this group fit a patch of PW x PH cells?  -> its origin.  (The end-points are evaluated anew
+    // for every question - a few hundred operations for the 1 thread in 4 that plans, once per workgroup - rather than held
+    // in registers: the kernel's 80 registers belong to the main loop.)
+    auto try_fit = [&](int from, int to, int PW, int PH, int& x0, int& y0) -> bool {
+      int lo_x = INT_MAX, hi_x = INT_MIN, lo_y = INT_MAX, hi_y = INT_MIN;
+      float reach_x = 0.f, reach_y = 0.f;  // of q' = M q / res (cells), per axis
+#pragma unroll 1
+      for (int k = from; k < to; ++k) {
+        const double2 p = q[k];
+        const double sx = __builtin_fma(p.x, rc, __builtin_fma(-p.y, rs, rxm));
+        const double sy = __builtin_fma(p.x, rs, __builtin_fma(p.y, rc, rym));
+        const int cx = static_cast<int>(__builtin_bit_cast(uint64_t, sx) >> 32), cy = static_cast<int>(__builtin_bit_cast(uint64_t, sy) >> 32);
+        lo_x = min(lo_x, cx);
+        hi_x = max(hi_x, cx);
+        lo_y = min(lo_y, cy);
+        hi_y = max(hi_y, cy);
+        reach_x = fmaxf(reach_x, static_cast<float>(fabs(p.x * rc - p.y * rs)));
+        reach_y = fmaxf(reach_y, static_cast<float>(fabs(p.x * rs + p.y * rc)));
+      }
+      float turn_x, turn_y;  // cells
+      if (stats.isotropic_margin) {  // |q'| <= sqrt(max q'x^2 + max q'y^2)
+        turn_x = turn_y = sqrtf(reach_x * reach_x + reach_y * reach_y) * 1.002f * (Da * 1.001f);
+      } else {
+        const float A = Da * 1.001f, Bv = Db * 1.001f, qx = reach_x * 1.001f, qy = reach_y * 1.001f;
+        turn_x = (A * qx + Bv * qy) * 1.001f;
+        turn_y = (Bv * qx + A * qy) * 1.001f;
+      }
+      const float mx = ceilf(Dx + turn_x), my = ceilf(Dy + turn_y);
+      bool fits = mx < 64.f && my < 64.f;  // false for NaN and infinity
+      const int margin_x = fits ? static_cast<int>(mx) : 0, margin_y = fits ? static_cast<int>(my) : 0;
+      x0 = lo_x - margin_x;
+      y0 = (lo_y - margin_y) & ~7;
+      return fits && hi_x + margin_x - x0 < PW && hi_y + margin_y - y0 < PH;
+    };
+    int x0a = 0, y0a = 0, x0b = 0, y0b = 0;
+    uint32_t flags = 0u, first_b = 0u;
+    if (try_fit(0, 8, kPatchW, kPatchH, x0a, y0a)) {
+      flags = 1u;
+    } else if (stats.split_patches) {
+#pragma unroll 1
+      for (int k = 1; k < 8 && !flags; ++k) {
+        int xa, ya, xb, yb;
+        if (try_fit(0, k, kPatchW / 2, kPatchH, xa, ya) && try_fit(k, 8, kPatchW / 2, kPatchH, xb, yb)) flags = 1u | 2u;
+        else if (try_fit(0, k, kPatchW, kPatchH / 2, xa, ya) && try_fit(k, 8, kPatchW, kPatchH / 2, xb, yb)) flags = 1u | 4u;
+        if (flags) {
+          x0a = xa;
+          y0a = ya;
+          x0b = xb;
+          y0b = yb;
+          first_b = static_cast<uint32_t>(k);
+        }
+      }
     }
-    const float turn = sqrtf(reach2) * 1.001f * (static_cast<float>(f.inv_resolution) * 1.001f) * (Drot * 1.001f);  // cells
-    const float mx = ceilf(Dx + turn), my = ceilf(Dy + turn);
-    bool fits = mx < 64.f && my < 64.f;  // false for NaN and infinity
-    const int margin_x = fits ? static_cast<int>(mx) : 0, margin_y = fits ? static_cast<int>(my) : 0;
-    const int x0 = lo_x - margin_x, y0 = (lo_y - margin_y) & ~7;
-    fits = fits && hi_x + margin_x - x0 < kPatchW && hi_y + margin_y - y0 < kPatchH;
-    s_plan[threadIdx.x] = int2{x0, y0 | (fits ? 1 : 0)};
-    mine_fits = fits;
+    s_plan[threadIdx.x] = int4{x0a, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
+    mine_fits = flags != 0u;
   }
   // A workgroup with too few of its groups through a patch drops the machinery: no producer, no barriers, every look-up a
   // gather.  Not only dispersed sets: a gathered group INSIDE a patched workgroup costs 2.6x a patched one (the workgroup waits
   // for the gathers at its next barrier), one of an all-gathering workgroup 1.3x, so mixing pays only above ~2/3 fitting
   // (stats.loose_below, in 256ths: measured, profiles/r02_lf_series.txt).
   // (counted by hand: __syncthreads_count brings a static LDS variable with it, and this kernel addresses LDS from 0)
-  uint32_t* s_count = reinterpret_cast<uint32_t*>(s_bound) + 24;  // behind the bound's [7][3]
+  uint32_t* s_count = reinterpret_cast<uint32_t*>(s_bound) + 28;  // behind the bound's [7][4]
   {
     const uint32_t in_wave = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine_fits)));
     if (lane == 0) s_count[threadIdx.x >> 6] = in_wave;
@@ -919,13 +980,22 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   uint32_t fitting = 0;
   for (uint32_t k = 0; k < kPalBlock / 64; ++k) fitting += s_count[k];
   const bool loose = __builtin_amdgcn_readfirstlane(fitting) * 256u < groups * stats.loose_below;
-  auto plan_of = [&](uint32_t g, int& x0, int& y0) -> bool {  // g uniform; scalar results
+  struct Plan {  // scalars
+    int x0a, y0a, x0b, y0b;
+    uint32_t flags, first_b;
+  };
+  auto plan_of = [&](uint32_t g, Plan& plan) -> bool {  // g uniform; scalar results
+    plan = Plan{0, 0, 0, 0, 0u, 8u};
     if (g >= kPatchPlanned) return false;
-    const int2 e = s_plan[g];
-    x0 = __builtin_amdgcn_readfirstlane(e.x);
-    const int y = __builtin_amdgcn_readfirstlane(e.y);
-    y0 = y & ~7;
-    return (y & 1) != 0;
+    const int4 e = s_plan[g];
+    const int ya = __builtin_amdgcn_readfirstlane(e.y), yb = __builtin_amdgcn_readfirstlane(e.w);
+    plan.x0a = __builtin_amdgcn_readfirstlane(e.x);
+    plan.y0a = ya & ~7;
+    plan.x0b = __builtin_amdgcn_readfirstlane(e.z);
+    plan.y0b = yb & ~7;
+    plan.flags = static_cast<uint32_t>(ya & 7);
+    plan.first_b = (plan.flags & 6u) ? static_cast<uint32_t>(yb & 7) : 8u;
+    return (plan.flags & 1u) != 0;
   };
 
   if (producer) {
@@ -962,23 +1032,27 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     // Fetches and stores are unconditional (a group without a patch, or past the last one, moves a patch nobody reads):
     // straight-line code lets the compiler count the loads in flight exactly, so that a store waits for ITS fetch only.
     const uint32_t last_planned = (groups < kPatchPlanned ? groups : kPatchPlanned) - 1u;
-    auto origin_of = [&](uint32_t g, int& x0, int& y0) {
-      const int2 e = s_plan[g < last_planned ? g : last_planned];
-      x0 = __builtin_amdgcn_readfirstlane(e.x);
-      y0 = __builtin_amdgcn_readfirstlane(e.y) & ~7;
-    };
+    // A whole patch: this lane's column x0A + lane, tile rows from y0A.  Halves side by side (flags & 2): the lanes from 32 on
+    // fetch columns x0B + lane - 32, rows from y0B.  Halves one above the other (flags & 4): the pieces from 4 on come from
+    // rows y0B + 8 (r - 4).
     auto fetch = [&](uint32_t g, Pieces& piece) {
-      int x0, y0;
-      origin_of(g, x0, y0);
-      const int xu = x0 + static_cast<int>(lane) - static_cast<int>(kFastBias);
+      const int4 e = s_plan[g < last_planned ? g : last_planned];
+      const int ya = __builtin_amdgcn_readfirstlane(e.y), yb = __builtin_amdgcn_readfirstlane(e.w);
+      const int x0a = __builtin_amdgcn_readfirstlane(e.x), x0b = __builtin_amdgcn_readfirstlane(e.z);
+      const int y0a = ya & ~7, y0b = yb & ~7;
+      const bool side_by_side = (ya & 2) != 0, stacked = (ya & 4) != 0;  // scalar
+      const bool half_b = side_by_side && lane >= static_cast<uint32_t>(kPatchW / 2);
+      const int xu = (half_b ? x0b + static_cast<int>(lane) - kPatchW / 2 : x0a + static_cast<int>(lane)) - static_cast<int>(kFastBias);
       // + 8: the border tile's share of palette_row_offset goes here, so that the vector offset - the one the buffer's
       // range check looks at - is never negative
       const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W)) + 8) << 4;
 #pragma unroll
       for (int r = 0; r < kPatchH / 8; ++r) {
-        const int yu = y0 + 8 * r - static_cast<int>(kFastBias);
-        const int yc = min(max(yu, -8), y_last);  // scalar
-        piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, column, palette_row_offset(yc, f.pal_pitch) - 128u, 0));
+        const int yu_a = ((stacked && r >= kPatchH / 16) ? y0b + 8 * (r - kPatchH / 16) : y0a + 8 * r) - static_cast<int>(kFastBias);
+        const int yu_b = y0b + 8 * r - static_cast<int>(kFastBias);
+        const uint32_t row_a = palette_row_offset(min(max(yu_a, -8), y_last), f.pal_pitch) - 128u;  // scalar
+        const uint32_t row_b = palette_row_offset(min(max(yu_b, -8), y_last), f.pal_pitch) - 128u;  // scalar
+        piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, column + (half_b ? row_b : row_a), 0, 0));
       }
     };
     auto store = [&](uint32_t g, const Pieces& piece) {
@@ -1019,8 +1093,26 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     uint32_t e[8];  // palette addresses (LDS byte addresses of the f64 terms)
     uint32_t redo;  // 1: the group is added by add_exact instead
   };
-  // The separately rounded evaluation, beam by beam with plain gathers.
+  // The separately rounded evaluation, beam by beam with plain gathers.  It needs the pose as the reference holds it (not
+  // pre-multiplied by 1 / res); this path runs for 4 in 2^32 end-points, so the pose is fetched again here rather than kept
+  // alive - or parked in scratch memory: 16 bytes per lane written by every launch - across the main loop.  (The pointers go
+  // through an empty asm statement so that the compiler does not fold the second fetch into the first.)
+  // Likewise the lane's position in the order and its particle index: derived again where they are needed (the cold path,
+  // the final store) instead of occupying three registers - or scratch - through the main loop.
+  auto particle_again = [&](uint64_t& position) -> uint32_t {
+    uint32_t zero = 0;
+    const uint32_t* perm_again = perm;
+    asm volatile("" : "+v"(zero), "+s"(perm_again));
+    position = static_cast<uint64_t>(blockIdx.x) * kPatchParticles + (threadIdx.x + zero);
+    return perm_again[position < n ? position : n - 1];
+  };
   auto add_exact = [&](uint32_t b0, uint32_t count) {
+    if (count == 0) return;
+    const double4* pose_again = pose;
+    asm volatile("" : "+s"(pose_again));
+    uint64_t position;
+    const Pose2 T_again = ordered_pose(f.world_to_field, pose_again, particle_again(position));
+    const double ct = T_again.r.c, st = T_again.r.s, xt = T_again.x, yt = T_again.y;
     auto term = [&](uint32_t at) {
       const double px = pts[2 * at], py = pts[2 * at + 1];
       double vx = (px * ct - py * st + xt) * f.inv_resolution, vy = (px * st + py * ct + yt) * f.inv_resolution;
@@ -1056,10 +1148,14 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   auto step = [&](auto is_loose, auto add_before, uint32_t g_any, Lookups& now, const Lookups& before) {
     const uint32_t g = __builtin_amdgcn_readfirstlane(g_any);  // uniform anyway; this keeps the scan reads on the scalar unit
     const uint32_t b0 = b_begin + 8 * g;
-    int x0 = 0, y0 = 0;
+    Plan plan{0, 0, 0, 0, 0u, 8u};
     bool in_patch = false;
-    if constexpr (!decltype(is_loose)::value) in_patch = plan_of(g, x0, y0);
-    const uint32_t K = patch_base + (g & 1) * kPatchBytes - (static_cast<uint32_t>(x0) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0) << 1);
+    if constexpr (!decltype(is_loose)::value) in_patch = plan_of(g, plan);
+    const uint32_t buffer = patch_base + (g & 1) * kPatchBytes;
+    const uint32_t KA = buffer - (static_cast<uint32_t>(plan.x0a) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(plan.y0a) << 1);
+    // half B lives in columns 32 .. 63 (side by side) or in rows 32 .. 63 (stacked) of the same buffer
+    const uint32_t KB = buffer + ((plan.flags & 2u) ? (kPatchW / 2) * kPatchPitch : kPatchH) - (static_cast<uint32_t>(plan.x0b) & 0xFFFFFFu) * kPatchPitch -
+                        (static_cast<uint32_t>(plan.y0b) << 1);
     if constexpr (!decltype(is_loose)::value) __syncthreads();
     now.redo = 1u;
     if (!fast) {
@@ -1082,9 +1178,11 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
     if (in_patch) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t K = static_cast<uint32_t>(k) < plan.first_b ? KA : KB;  // scalar: goes into the add as a scalar operand
         now.e[k] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(
-            static_cast<uintptr_t>(mad_u24(static_cast<uint32_t>(cx[k]), kPatchPitch, lshl_add_u32(static_cast<uint32_t>(cy[k]), 1, K)))));
+            static_cast<uintptr_t>(mad_u24(static_cast<uint32_t>(cx[k]), kPatchPitch, lshl_add_u32_uniform(static_cast<uint32_t>(cy[k]), 1, K)))));
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -1117,11 +1215,13 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     else run(std::false_type{});
   }
   add_exact(b_begin + 8 * groups, b_end - (b_begin + 8 * groups));
-  if (t < n) {
+  uint64_t t_end;
+  const uint32_t i_end = particle_again(t_end);
+  if (t_end < n) {
     if (partial) {
-      partial[static_cast<size_t>(blockIdx.y) * n + t] = acc;
+      partial[static_cast<size_t>(blockIdx.y) * n + t_end] = acc;
     } else {
-      w[i] = w[i] * (f.prob ? exp(acc) : acc);
+      w[i_end] = w[i_end] * (f.prob ? exp(acc) : acc);
     }
   }
 }
@@ -1229,6 +1329,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_final(const double* __restrict_
     kf.inv_t = inverse_span(v[4], v[5]);
     kf.t_off = static_cast<float>(0.5 * (v[4] + v[5]));
     kf.layout = layout;
+    kf.bits_xy = 0;  // (the default split: 6 + 6 + 8)
     *frame = kf;
   }
 }

@@ -395,6 +395,16 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *   sort_min_particles (16384)  below this many particles the spatial ordering is skipped (likelihood-field models)
  *   beam_sort_min_particles (16384)  beam model: the ordered kernel from this size on; below it a wave per particle over the
  *                   whole-grid bit maps (both skip empty space by the block distance map)
+ *   key_curve (1)   heading-major ordering key: 1 = along the Hilbert curve through the (heading, y, x) bins - any run of the
+ *                   order is a compact, connected set of bins -, 0 = Morton order (round 2: a run that crosses a high-level boundary
+ *                   of the Z curve is two pieces far apart, and its workgroup fits no LDS patch)
+ *   key_bits_xy (0) bits of the x and of the y bins of that key (the heading gets the other 20 - 2 b): 0 = chosen every cycle from
+ *                   the cloud's spread and the scan's reach (4 .. 6), 4 / 5 / 6 = forced (round 2: 6)
+ *   lf_split (1)    LDS-patch planner: a group of 8 beams that fits no whole 64 x 64-cell patch (its end-points straddle a range
+ *                   discontinuity: 3 - 5 % of the groups of an indoor scan, whatever the cloud) goes through two half patches -
+ *                   beams [0, k) and [k, 8), 32 x 64 or 64 x 32 cells each, in the buffer of one whole patch; 0 = such groups are gathered
+ *   lf_margin (1)   LDS-patch planner, the rotation part of the bound on a workgroup's end-points: 1 = per axis
+ *                   ((1 - cos d) |q'x| + |sin d| |q'y| in x, the transpose in y), 0 = |R_p - R_ref| |q| on both axes (round 2)
  *   field_build (0)  how the NEXT mcl_set_map builds the likelihood field: 0 = the reference's priority-queue wavefront on the
  *                    host (bit-identical field, seconds at 16 M cells), 1 = exact Euclidean distance transform on the device
  *                    (milliseconds; equal at all but the few cells where the wavefront does not find the nearest obstacle,
@@ -410,6 +420,10 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value);
 /* Runs the spatial ordering on the current set and returns it: perm[t] = particle at position t, keys[i] = ordering key
  * of particle i (n entries each, host memory).  keys[perm[t]] is non-decreasing in t. */
 mcl_status mcl_debug_order(mcl_ctx* ctx, uint32_t* perm, uint32_t* keys);
+
+/* Position of the cell (heading, y, x), `bits` bits each, along the 3-D Hilbert curve the heading-major ordering key follows
+ * (kernels.h hilbert_index_3; pure host arithmetic, no device needed): consecutive positions are face neighbours. */
+uint32_t mcl_debug_curve_index(uint32_t heading_bin, uint32_t y_bin, uint32_t x_bin, uint32_t bits /* per axis, 1 .. 6 */);
 
 const char* mcl_version(void);
 

@@ -114,3 +114,33 @@ def test_laser_scan_preparation_matches_oracle(lib):
         want = orc.prepare_laser_scan(ranges, -2.356, 0.004363, 0.1, 30.0, origin_se3=q, max_beams=min(max_beams, 2 ** 63), min_range=0.2,
                                       max_range=25.0)
         assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("bits", [4, 5, 6])
+def test_ordering_curve_is_a_hilbert_curve(lib, bits):
+    """The heading-major ordering key follows a 3-D Hilbert curve through the (2^bits)^3 (heading, y, x) bins (kernels.h
+    hilbert_index_3; pure host arithmetic through the C ABI): a bijection onto [0, 2^(3 bits)), consecutive positions are face
+    neighbours (so any run of the spatial order is a connected set of bins - the property the LDS-patch kernel's workgroups
+    rely on), it enters at (0, 0, 0) and leaves at (max, 0, 0) so that the slabs of the key's top heading bits chain."""
+    import numpy as np
+    n = 1 << bits
+    index = np.empty((n, n, n), dtype=np.int64)
+    for t in range(n):
+        for y in range(n):
+            for x in range(n):
+                index[t, y, x] = lib.mcl_debug_curve_index(t, y, x, bits)
+    flat = index.ravel()
+    assert flat.min() == 0 and flat.max() == n ** 3 - 1 and len(np.unique(flat)) == n ** 3
+    cell_of = np.empty((n ** 3, 3), dtype=np.int64)
+    t, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    cell_of[flat] = np.stack([t.ravel(), y.ravel(), x.ravel()], axis=1)
+    steps = np.abs(np.diff(cell_of, axis=0))
+    assert np.all(steps.sum(axis=1) == 1), "consecutive positions of the curve must be face neighbours"
+    assert tuple(cell_of[0]) == (0, 0, 0) and tuple(cell_of[-1]) == (n - 1, 0, 0)
+    # locality of runs: the bounding box of ANY 512 consecutive positions stays within 16 bins per axis (a Morton run that
+    # crosses the middle of the cube spans all of it)
+    worst = 0
+    for start in range(0, n ** 3 - 512, 97):
+        run = cell_of[start:start + 512]
+        worst = max(worst, int((run.max(axis=0) - run.min(axis=0)).max()) + 1)
+    assert worst <= 16, worst
