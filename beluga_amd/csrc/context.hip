@@ -825,7 +825,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
                        PatchStats{reinterpret_cast<unsigned long long*>(ctx->d_scalars.ptr + 24),
                                   reinterpret_cast<unsigned long long*>(ctx->hd_scalars + 28),
                                   static_cast<uint32_t>(ctx->tuning.lf_loose_below), ctx->tuning.lf_margin ? 0u : 1u,
-                                  ctx->tuning.lf_split ? 1u : 0u},
+                                  static_cast<uint32_t>(ctx->tuning.lf_split)},
                        /*dispersed=*/!use_patches && (ctx->tuning.lf_far_tiles == 2 || (ctx->tuning.lf_patch == 1 && !ctx->patch_useful)),
                        &far_tiles_used);
     if (far_tiles_used) ctx->lf_far_launches += 1;
@@ -2636,7 +2636,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "key_curve") t.key_curve = value ? 1 : 0;
   else if (key == "key_bits_xy") t.key_bits_xy = (value >= 4 && value <= 6) ? static_cast<int>(value) : 0;
   else if (key == "lf_margin") t.lf_margin = value ? 1 : 0;
-  else if (key == "lf_split") t.lf_split = value ? 1 : 0;
+  else if (key == "lf_split") t.lf_split = static_cast<int>(value & 3);  // 1: side by side only, 2: stacked only, 3: both
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else if (key == "beam_sort_min_particles") t.beam_sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "mcl_set_option: unknown option " + key);

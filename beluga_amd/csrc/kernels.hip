@@ -774,7 +774,7 @@ constexpr uint32_t kPatchPitch = kPatchH * 2 + 16;
 constexpr uint32_t kPatchBytes = kPatchW * kPatchPitch;
 constexpr uint32_t kPatchParticles = kPalBlock - 64;  // per workgroup
 constexpr uint32_t kPatchPlanned = 256;               // groups with a plan entry; the ones beyond are gathered
-constexpr uint32_t kPatchLds = 2 * kPatchBytes + kPatchPlanned * 16 + 48 * 4;  // two patches, the plan, the prologue's partial results
+constexpr uint32_t kPatchLds = 2 * kPatchBytes + kPatchPlanned * 32 + 48 * 4;  // two patches, the two plans, the prologue's partial results
 constexpr double kPatchMagic = 1572864.0 + 4.656612873077392578125e-10;     // 1.5 * 2^20 + 2^-31
 // 6 waves per SIMD = three workgroups per CU: at most 80 registers
 __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reweight_lf_patch(double* __restrict__ w, uint64_t n, FieldView f,
@@ -797,8 +797,20 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   // patch however tight the cloud (3 - 5 % of the groups of an indoor scan); its beams [0, k) and [k, 8) almost always fit two
   // half patches, which share the buffer of one whole patch: the consumers' addressing does not change, only the constant K
   // differs between the two halves (a scalar select per beam).
+  // The consumers read a second entry per group: {KA', meta, KB', -}: the constants of the two halves' LDS addresses less the
+  // buffer's base (cell (cx, cy) sits at cx * pitch + cy * 2 + K), meta = 0: gathered, 8: one whole patch, k = 1 .. 7: two halves,
+  // the second one from beam k on.
   int4* s_plan = reinterpret_cast<int4*>(smem + patch_base + 2 * kPatchBytes);
-  float* s_bound = reinterpret_cast<float*>(smem + patch_base + 2 * kPatchBytes + kPatchPlanned * 16);  // [7][6]
+  int4* s_plan_k = s_plan + kPatchPlanned;
+  float* s_bound = reinterpret_cast<float*>(smem + patch_base + 2 * kPatchBytes + kPatchPlanned * 32);  // [7][6]
+  // The scan itself, for the planner's threads (they walk their group's points again and again): staged in the patch buffers,
+  // which nothing else uses before the main loop, if it fits there.
+  const bool scan_staged = static_cast<size_t>(B) * sizeof(double2) <= 2 * kPatchBytes;
+  if (scan_staged) {
+    double2* s_scan = reinterpret_cast<double2*>(smem + patch_base);
+    const double2* scan = reinterpret_cast<const double2*>(pts);
+    for (uint32_t k = threadIdx.x; k < B; k += kPalBlock) s_scan[k] = scan[k];
+  }
   const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPalBlock / 64 - 1);  // a scalar branch: the roles
                                                                                                   // run different loops
   const uint32_t lane = threadIdx.x & 63;
@@ -909,16 +921,27 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     // every float operation below may round down: scaled up by 1 + 2^-10 where it matters, and two cells of slack
     Dx = Dx * 1.001f + 2.f;
     Dy = Dy * 1.001f + 2.f;
-    const double2* q = reinterpret_cast<const double2*>(pts) + (b_begin + 8 * threadIdx.x);
+    const uint32_t q0 = b_begin + 8 * threadIdx.x;
+    const double2* q = reinterpret_cast<const double2*>(pts) + q0;
+    lds_f64_t* q_staged = reinterpret_cast<lds_f64_t*>(static_cast<uintptr_t>(patch_base)) + 2 * q0;
     // Do the beams [from, to) of this group fit a patch of PW x PH cells?  -> its origin.  (The end-points are evaluated anew
     // for every question - a few hundred operations for the 1 thread in 4 that plans, once per workgroup - rather than held
     // in registers: the kernel's 80 registers belong to the main loop.)
+    int widest_jump = 0, jump_at = 4;  // the largest step between the end-points of consecutive beams of the last range asked about
     auto try_fit = [&](int from, int to, int PW, int PH, int& x0, int& y0) -> bool {
       int lo_x = INT_MAX, hi_x = INT_MIN, lo_y = INT_MAX, hi_y = INT_MIN;
       float reach_x = 0.f, reach_y = 0.f;  // of q' = M q / res (cells), per axis
+      int last_x = 0, last_y = 0;
+      widest_jump = -1;
 #pragma unroll 1
       for (int k = from; k < to; ++k) {
-        const double2 p = q[k];
+        double2 p;
+        if (scan_staged) {
+          p.x = q_staged[2 * k];
+          p.y = q_staged[2 * k + 1];
+        } else {
+          p = q[k];
+        }
         const double sx = __builtin_fma(p.x, rc, __builtin_fma(-p.y, rs, rxm));
         const double sy = __builtin_fma(p.x, rs, __builtin_fma(p.y, rc, rym));
         const int cx = static_cast<int>(__builtin_bit_cast(uint64_t, sx) >> 32), cy = static_cast<int>(__builtin_bit_cast(uint64_t, sy) >> 32);
@@ -928,6 +951,13 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         hi_y = max(hi_y, cy);
         reach_x = fmaxf(reach_x, static_cast<float>(fabs(p.x * rc - p.y * rs)));
         reach_y = fmaxf(reach_y, static_cast<float>(fabs(p.x * rs + p.y * rc)));
+        const int jump = k > from ? max(abs(cx - last_x), abs(cy - last_y)) : -1;
+        if (jump > widest_jump) {
+          widest_jump = jump;
+          jump_at = k;
+        }
+        last_x = cx;
+        last_y = cy;
       }
       float turn_x, turn_y;  // cells
       if (stats.isotropic_margin) {  // |q'| <= sqrt(max q'x^2 + max q'y^2)
@@ -949,21 +979,28 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     if (try_fit(0, 8, kPatchW, kPatchH, x0a, y0a)) {
       flags = 1u;
     } else if (stats.split_patches) {
-#pragma unroll 1
-      for (int k = 1; k < 8 && !flags; ++k) {
-        int xa, ya, xb, yb;
-        if (try_fit(0, k, kPatchW / 2, kPatchH, xa, ya) && try_fit(k, 8, kPatchW / 2, kPatchH, xb, yb)) flags = 1u | 2u;
-        else if (try_fit(0, k, kPatchW, kPatchH / 2, xa, ya) && try_fit(k, 8, kPatchW, kPatchH / 2, xb, yb)) flags = 1u | 4u;
-        if (flags) {
-          x0a = xa;
-          y0a = ya;
-          x0b = xb;
-          y0b = yb;
-          first_b = static_cast<uint32_t>(k);
-        }
+      // split where the scan jumps: between the two consecutive beams whose end-points lie farthest apart (the pass above found it)
+      const int k = jump_at;
+      int xa, ya, xb, yb;
+      if ((stats.split_patches & 1u) && try_fit(0, k, kPatchW / 2, kPatchH, xa, ya) && try_fit(k, 8, kPatchW / 2, kPatchH, xb, yb)) flags = 1u | 2u;
+      else if ((stats.split_patches & 2u) && try_fit(0, k, kPatchW, kPatchH / 2, xa, ya) && try_fit(k, 8, kPatchW, kPatchH / 2, xb, yb)) flags = 1u | 4u;
+      if (flags) {
+        x0a = xa;
+        y0a = ya;
+        x0b = xb;
+        y0b = yb;
+        first_b = static_cast<uint32_t>(k);
       }
     }
     s_plan[threadIdx.x] = int4{x0a, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
+    {
+      const uint32_t ka = 0u - (static_cast<uint32_t>(x0a) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0a) << 1);
+      // half B lives in columns 32 .. 63 (side by side) or in rows 32 .. 63 (stacked) of the same buffer
+      const uint32_t kb = ((flags & 2u) ? (kPatchW / 2) * kPatchPitch : static_cast<uint32_t>(kPatchH)) -
+                          (static_cast<uint32_t>(x0b) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0b) << 1);
+      const uint32_t meta = flags == 0u ? 0u : ((flags & 6u) ? first_b : 8u);
+      s_plan_k[threadIdx.x] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), 0};
+    }
     mine_fits = flags != 0u;
   }
   // A workgroup with too few of its groups through a patch drops the machinery: no producer, no barriers, every look-up a
@@ -981,21 +1018,15 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   for (uint32_t k = 0; k < kPalBlock / 64; ++k) fitting += s_count[k];
   const bool loose = __builtin_amdgcn_readfirstlane(fitting) * 256u < groups * stats.loose_below;
   struct Plan {  // scalars
-    int x0a, y0a, x0b, y0b;
-    uint32_t flags, first_b;
+    uint32_t ka;    // less the buffer's base
+    uint32_t meta;  // 0: gathered, 8: one whole patch, 1 .. 7: two halves, the second one from this beam on
   };
-  auto plan_of = [&](uint32_t g, Plan& plan) -> bool {  // g uniform; scalar results
-    plan = Plan{0, 0, 0, 0, 0u, 8u};
-    if (g >= kPatchPlanned) return false;
-    const int4 e = s_plan[g];
-    const int ya = __builtin_amdgcn_readfirstlane(e.y), yb = __builtin_amdgcn_readfirstlane(e.w);
-    plan.x0a = __builtin_amdgcn_readfirstlane(e.x);
-    plan.y0a = ya & ~7;
-    plan.x0b = __builtin_amdgcn_readfirstlane(e.z);
-    plan.y0b = yb & ~7;
-    plan.flags = static_cast<uint32_t>(ya & 7);
-    plan.first_b = (plan.flags & 6u) ? static_cast<uint32_t>(yb & 7) : 8u;
-    return (plan.flags & 1u) != 0;
+  auto plan_of = [&](uint32_t g, Plan& plan) {  // g uniform; scalar results
+    plan = Plan{0u, 0u};
+    if (g >= kPatchPlanned) return;
+    const int2 e = *reinterpret_cast<const int2*>(s_plan_k + g);
+    plan.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.x));
+    plan.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
   };
 
   if (producer) {
@@ -1037,22 +1068,39 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     // rows y0B + 8 (r - 4).
     auto fetch = [&](uint32_t g, Pieces& piece) {
       const int4 e = s_plan[g < last_planned ? g : last_planned];
-      const int ya = __builtin_amdgcn_readfirstlane(e.y), yb = __builtin_amdgcn_readfirstlane(e.w);
-      const int x0a = __builtin_amdgcn_readfirstlane(e.x), x0b = __builtin_amdgcn_readfirstlane(e.z);
-      const int y0a = ya & ~7, y0b = yb & ~7;
+      const int ya = __builtin_amdgcn_readfirstlane(e.y);
+      const int x0a = __builtin_amdgcn_readfirstlane(e.x), y0a = ya & ~7;
+      if ((ya & 6) == 0) {  // one whole patch (or none: then nobody reads it): this lane's column, scalar row offsets
+        const int xu = x0a + static_cast<int>(lane) - static_cast<int>(kFastBias);
+        // + 8: the border tile's share of palette_row_offset goes here, so that the vector offset - the one the buffer's
+        // range check looks at - is never negative
+        const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W)) + 8) << 4;
+#pragma unroll
+        for (int r = 0; r < kPatchH / 8; ++r) {
+          const int yu = y0a + 8 * r - static_cast<int>(kFastBias);
+          const int yc = min(max(yu, -8), y_last);  // scalar
+          piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, column, palette_row_offset(yc, f.pal_pitch) - 128u, 0));
+        }
+        return;
+      }
+      const int yb = __builtin_amdgcn_readfirstlane(e.w), x0b = __builtin_amdgcn_readfirstlane(e.z), y0b = yb & ~7;
       const bool side_by_side = (ya & 2) != 0, stacked = (ya & 4) != 0;  // scalar
       const bool half_b = side_by_side && lane >= static_cast<uint32_t>(kPatchW / 2);
       const int xu = (half_b ? x0b + static_cast<int>(lane) - kPatchW / 2 : x0a + static_cast<int>(lane)) - static_cast<int>(kFastBias);
       // + 8: the border tile's share of palette_row_offset goes here, so that the vector offset - the one the buffer's
       // range check looks at - is never negative
       const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W)) + 8) << 4;
+      // stacked halves: the lower half of the buffer (pieces 4 .. 7) holds the columns from x0B on
+      const int xu_low = (stacked ? x0b : x0a) + static_cast<int>(lane) - static_cast<int>(kFastBias);
+      const uint32_t column_low = stacked ? static_cast<uint32_t>(min(max(xu_low, -1), static_cast<int>(f.W)) + 8) << 4 : column;
 #pragma unroll
       for (int r = 0; r < kPatchH / 8; ++r) {
-        const int yu_a = ((stacked && r >= kPatchH / 16) ? y0b + 8 * (r - kPatchH / 16) : y0a + 8 * r) - static_cast<int>(kFastBias);
+        const bool low = r >= kPatchH / 16;
+        const int yu_a = ((stacked && low) ? y0b + 8 * (r - kPatchH / 16) : y0a + 8 * r) - static_cast<int>(kFastBias);
         const int yu_b = y0b + 8 * r - static_cast<int>(kFastBias);
         const uint32_t row_a = palette_row_offset(min(max(yu_a, -8), y_last), f.pal_pitch) - 128u;  // scalar
         const uint32_t row_b = palette_row_offset(min(max(yu_b, -8), y_last), f.pal_pitch) - 128u;  // scalar
-        piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, column + (half_b ? row_b : row_a), 0, 0));
+        piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (low ? column_low : column) + (half_b ? row_b : row_a), 0, 0));
       }
     };
     auto store = [&](uint32_t g, const Pieces& piece) {
@@ -1148,14 +1196,9 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   auto step = [&](auto is_loose, auto add_before, uint32_t g_any, Lookups& now, const Lookups& before) {
     const uint32_t g = __builtin_amdgcn_readfirstlane(g_any);  // uniform anyway; this keeps the scan reads on the scalar unit
     const uint32_t b0 = b_begin + 8 * g;
-    Plan plan{0, 0, 0, 0, 0u, 8u};
-    bool in_patch = false;
-    if constexpr (!decltype(is_loose)::value) in_patch = plan_of(g, plan);
+    Plan plan{0u, 0u};
+    if constexpr (!decltype(is_loose)::value) plan_of(g, plan);
     const uint32_t buffer = patch_base + (g & 1) * kPatchBytes;
-    const uint32_t KA = buffer - (static_cast<uint32_t>(plan.x0a) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(plan.y0a) << 1);
-    // half B lives in columns 32 .. 63 (side by side) or in rows 32 .. 63 (stacked) of the same buffer
-    const uint32_t KB = buffer + ((plan.flags & 2u) ? (kPatchW / 2) * kPatchPitch : kPatchH) - (static_cast<uint32_t>(plan.x0b) & 0xFFFFFFu) * kPatchPitch -
-                        (static_cast<uint32_t>(plan.y0b) << 1);
     if constexpr (!decltype(is_loose)::value) __syncthreads();
     now.redo = 1u;
     if (!fast) {
@@ -1176,10 +1219,17 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       cy[k] = static_cast<int>(by >> 32);
     }
     if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
-    if (in_patch) {
+    if (plan.meta == 8u) {  // one whole patch (19 groups in 20): one constant for the eight look-ups
+      const uint32_t K = buffer + plan.ka;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        now.e[k] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(
+            static_cast<uintptr_t>(mad_u24(static_cast<uint32_t>(cx[k]), kPatchPitch, lshl_add_u32_uniform(static_cast<uint32_t>(cy[k]), 1, K)))));
+    } else if (plan.meta != 0u) {  // two halves: the beams from plan.meta on read the second one
+      const uint32_t KA = buffer + plan.ka, KB = buffer + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_plan_k[g].z));
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const uint32_t K = static_cast<uint32_t>(k) < plan.first_b ? KA : KB;  // scalar: goes into the add as a scalar operand
+        const uint32_t K = static_cast<uint32_t>(k) < plan.meta ? KA : KB;  // scalar: goes into the add as a scalar operand
         now.e[k] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(
             static_cast<uintptr_t>(mad_u24(static_cast<uint32_t>(cx[k]), kPatchPitch, lshl_add_u32_uniform(static_cast<uint32_t>(cy[k]), 1, K)))));
       }
