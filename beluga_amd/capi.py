@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbeluga_mcl.so")
+# BELUGA_MCL_LIB: another build of the same library (measurement variants: tools/build_variant.sh)
+LIB_PATH = os.environ.get("BELUGA_MCL_LIB") or os.path.join(_HERE, "lib", "libbeluga_mcl.so")
 
 MCL_OK = 0
 MCL_ERR_INVALID_ARGUMENT = -1

@@ -1763,7 +1763,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_bits_xy", "lf_margin", "lf_split"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_bits_xy", "lf_margin", "lf_split", "lf_producer"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2636,6 +2636,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "key_curve") t.key_curve = value ? 1 : 0;
   else if (key == "key_bits_xy") t.key_bits_xy = (value >= 4 && value <= 6) ? static_cast<int>(value) : 0;
   else if (key == "lf_margin") t.lf_margin = value ? 1 : 0;
+  else if (key == "lf_producer") t.lf_producer = value ? 1 : 0;
   else if (key == "lf_split") t.lf_split = static_cast<int>(value & 3);  // 1: side by side only, 2: stacked only, 3: both
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else if (key == "beam_sort_min_particles") t.beam_sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));

@@ -141,6 +141,9 @@ struct Tuning {
   int key_curve = 1;                // heading-major ordering key: 1 = Hilbert curve through (heading, y, x), 0 = Morton order
   int key_bits_xy = 0;              // bits of the x / y bins of that key: 0 = chosen per cycle from the cloud's spread and the scan's
                                     // reach (4 .. 6), otherwise forced; round 2: 6 (8 heading bits)
+  int lf_producer = 1;              // LDS-patch kernel: 1 = seven waves of particles + a producer wave (the form that knows half patches and
+                                    // patches clamped at the table's border), 0 = every wave holds particles and fetches its share of the
+                                    // patches straight into LDS (buffer_load ... lds); measured 5 % slower on the bench
   int lf_split = 3;                 // LDS-patch planner: a group of 8 beams that fits no whole 64 x 64 patch (a range discontinuity inside
                                     // it) may go through two half patches (beams [0, k) and [k, 8): 32 x 64 or 64 x 32 cells each); 0 = never
   int lf_margin = 1;                // LDS-patch planner, rotation part of the bound: 1 = per axis (|sin d| |q'y| + (1 - cos d) |q'x|),

@@ -767,16 +767,32 @@ __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, 
 // either its integer part is I (high word = kFastBias + I, whatever the low word) or it carried and its low word is below 4.
 // A group with a low word below 4 (4 in 2^32 end-points) is added by the exact evaluation, beam by beam, and so is every
 // group of a wave holding a particle farther than 2^14 cells from the grid origin.  4 VALU operations per end-point.
+// Measurement builds only (tools/build_variant.sh, never the product library): -DMCL_ABLATE=<bits> removes one ingredient of
+// the patch kernel's main loop at a time to see what it costs (the results are then wrong): 1 = the barriers, 2 = the palette
+// value reads, 4 = the look-ups in the patch, 16 = the producer's fetches and stores.
+#ifndef MCL_ABLATE
+#define MCL_ABLATE 0
+#endif
 constexpr int kPatchW = 64, kPatchH = 64;  // cells
 // Bytes per patch column: the 128 of its cells + 16, so that the bank of a cell is (4 x + y / 2) mod 32 - neighbouring
 // columns on different banks (with 128, every column of a row pair would share one).
 constexpr uint32_t kPatchPitch = kPatchH * 2 + 16;
 constexpr uint32_t kPatchBytes = kPatchW * kPatchPitch;
-constexpr uint32_t kPatchParticles = kPalBlock - 64;  // per workgroup
+constexpr uint32_t kPatchParticles = kPalBlock - 64;  // per workgroup, with a producer wave (k_reweight_lf_patch<false>)
+constexpr uint32_t kPatchParticlesAll = kPalBlock;    // per workgroup when every wave holds particles (k_reweight_lf_patch<true>)
 constexpr uint32_t kPatchPlanned = 256;               // groups with a plan entry; the ones beyond are gathered
-constexpr uint32_t kPatchLds = 2 * kPatchBytes + kPatchPlanned * 32 + 48 * 4;  // two patches, the two plans, the prologue's partial results
+constexpr uint32_t kPatchLds = 2 * kPatchBytes + kPatchPlanned * 32 + 48 * 4 + kPalBlock * 8;  // two patches, the two plans, the prologue's
+                                                                                               // partial results, the lanes' shares of a fetch (kShared)
 constexpr double kPatchMagic = 1572864.0 + 4.656612873077392578125e-10;     // 1.5 * 2^20 + 2^-31
+// kShared: no producer wave.  All eight waves hold particles, and each fetches an eighth of the next group's patch itself with
+// buffer_load_dwordx4 ... lds (global memory -> LDS without passing through registers: lane i's 16 bytes land at M0 + 16 i,
+// tools/calib_lds_direct.hip): the patch's 576 16-byte pieces (64 columns x 8 tile rows + one piece of padding per column) are
+// dealt out 72 to a wave, a full instruction and one of 8 lanes.  Every lane's share of the address is a constant (column x 16
+// + tile row x pitch), the group's share a scalar: no vector instruction and no register per fetch.  The seven-consumer form
+// leaves one wave in eight without arithmetic; this one has none idle.  (Half patches and patches that need clamping at the
+// table's border are left to the producer form: here such groups are gathered.)
 // 6 waves per SIMD = three workgroups per CU: at most 80 registers
+template <bool kShared>
 __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reweight_lf_patch(double* __restrict__ w, uint64_t n, FieldView f,
                                                                  const double* __restrict__ pts, uint32_t B,
                                                                  const uint32_t* __restrict__ perm, const double4* __restrict__ pose,
@@ -797,7 +813,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   // patch however tight the cloud (3 - 5 % of the groups of an indoor scan); its beams [0, k) and [k, 8) almost always fit two
   // half patches, which share the buffer of one whole patch: the consumers' addressing does not change, only the constant K
   // differs between the two halves (a scalar select per beam).
-  // The consumers read a second entry per group: {KA', meta, KB', -}: the constants of the two halves' LDS addresses less the
+  // The consumers read a second entry per group: {KA', meta, KB', the group's fetch offset (kShared)}: the constants of the two halves' LDS addresses less the
   // buffer's base (cell (cx, cy) sits at cx * pitch + cy * 2 + K), meta = 0: gathered, 8: one whole patch, k = 1 .. 7: two halves,
   // the second one from beam k on.
   int4* s_plan = reinterpret_cast<int4*>(smem + patch_base + 2 * kPatchBytes);
@@ -811,10 +827,12 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     const double2* scan = reinterpret_cast<const double2*>(pts);
     for (uint32_t k = threadIdx.x; k < B; k += kPalBlock) s_scan[k] = scan[k];
   }
-  const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPalBlock / 64 - 1);  // a scalar branch: the roles
-                                                                                                  // run different loops
+  constexpr uint32_t kConsumers = kShared ? kPalBlock / 64 : kPalBlock / 64 - 1;  // waves that hold particles
+  constexpr uint32_t kParticles = kConsumers * 64;
+  const bool producer = !kShared && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPalBlock / 64 - 1);  // a scalar branch: the roles
+                                                                                                              // run different loops
   const uint32_t lane = threadIdx.x & 63;
-  const uint64_t first = static_cast<uint64_t>(blockIdx.x) * kPatchParticles;
+  const uint64_t first = static_cast<uint64_t>(blockIdx.x) * kParticles;
   const uint64_t t = producer ? first : first + threadIdx.x;  // (the producer holds no particle; it reads a valid one)
   const uint64_t tt = t < n ? t : n - 1;
   const uint32_t i = perm[tt];
@@ -857,7 +875,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   double ref_c, ref_s, ref_x, ref_y;
   {
     float lo_x = s_part[0], hi_x = s_part[1], lo_y = s_part[2], hi_y = s_part[3], sum_c = s_part[4], sum_s = s_part[5];
-    for (uint32_t k = 1; k < kPalBlock / 64 - 1; ++k) {
+    for (uint32_t k = 1; k < kConsumers; ++k) {
       lo_x = fminf(lo_x, s_part[6 * k]);
       hi_x = fmaxf(hi_x, s_part[6 * k + 1]);
       lo_y = fminf(lo_y, s_part[6 * k + 2]);
@@ -912,7 +930,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   bool mine_fits = false;
   if (threadIdx.x < groups && threadIdx.x < kPatchPlanned) {
     float Dx = 0.f, Dy = 0.f, Da = 0.f, Db = 0.f;
-    for (uint32_t k = 0; k < kPalBlock / 64 - 1; ++k) {
+    for (uint32_t k = 0; k < kConsumers; ++k) {
       Dx = fmaxf(Dx, s_bound[4 * k]);
       Dy = fmaxf(Dy, s_bound[4 * k + 1]);
       Da = fmaxf(Da, s_bound[4 * k + 2]);
@@ -976,9 +994,20 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     };
     int x0a = 0, y0a = 0, x0b = 0, y0b = 0;
     uint32_t flags = 0u, first_b = 0u;
+    uint32_t fetch_offset = 0u;  // kShared: the group's share of every piece's byte offset in the table
     if (try_fit(0, 8, kPatchW, kPatchH, x0a, y0a)) {
       flags = 1u;
-    } else if (stats.split_patches) {
+      if constexpr (kShared) {
+        // all 64 x 64 cells inside the bordered table (its border tiles hold the unknown entry: what a clamped fetch would
+        // read as well); a patch that reaches beyond them is left to the gathers
+        const int xu = x0a - static_cast<int>(kFastBias), yu = y0a - static_cast<int>(kFastBias);
+        const int x_last = static_cast<int>((f.W + 7u) & ~7u) + 7, y_last_cell = static_cast<int>((f.H + 7u) & ~7u) + 7;
+        if (xu >= -8 && xu + kPatchW - 1 <= x_last && yu >= -8 && yu + kPatchH - 1 <= y_last_cell)
+          fetch_offset = (static_cast<uint32_t>(xu + 8) << 4) + (static_cast<uint32_t>(yu + 8) >> 3) * f.pal_pitch;
+        else
+          flags = 0u;
+      }
+    } else if (!kShared && stats.split_patches) {
       // split where the scan jumps: between the two consecutive beams whose end-points lie farthest apart (the pass above found it)
       const int k = jump_at;
       int xa, ya, xb, yb;
@@ -999,7 +1028,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       const uint32_t kb = ((flags & 2u) ? (kPatchW / 2) * kPatchPitch : static_cast<uint32_t>(kPatchH)) -
                           (static_cast<uint32_t>(x0b) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0b) << 1);
       const uint32_t meta = flags == 0u ? 0u : ((flags & 6u) ? first_b : 8u);
-      s_plan_k[threadIdx.x] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), 0};
+      s_plan_k[threadIdx.x] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), static_cast<int>(fetch_offset)};
     }
     mine_fits = flags != 0u;
   }
@@ -1008,7 +1037,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   // for the gathers at its next barrier), one of an all-gathering workgroup 1.3x, so mixing pays only above ~2/3 fitting
   // (stats.loose_below, in 256ths: measured, profiles/r02_lf_series.txt).
   // (counted by hand: __syncthreads_count brings a static LDS variable with it, and this kernel addresses LDS from 0)
-  uint32_t* s_count = reinterpret_cast<uint32_t*>(s_bound) + 28;  // behind the bound's [7][4]
+  uint32_t* s_count = reinterpret_cast<uint32_t*>(s_bound) + 4 * kConsumers;  // behind the bound's [7 or 8][4]
   {
     const uint32_t in_wave = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine_fits)));
     if (lane == 0) s_count[threadIdx.x >> 6] = in_wave;
@@ -1029,12 +1058,50 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     plan.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
   };
 
-  if (producer) {
-    // The launch's statistics (what the host picks the next launch's kernel by): groups planned and groups through a
-    // patch, summed over a sample of the workgroups - every 16th of a large launch: thousands of atomic operations on one
-    // address would cost more than the kernel's other work - ; the last one to report copies the running totals to the
-    // host's mirror.
-    auto report = [&]() {
+  // kShared: this wave's 72 pieces of a patch.  Piece c = 9 x + r (column x, tile row r; r = 8 is the column's padding, which
+  // nobody fetches) lies at byte 16 c of the buffer: lane i of the full instruction takes piece 72 wave + i, lanes 0 .. 7 of
+  // the second one piece 72 wave + 64 + i.  The lane's share of the table offset never changes.
+  // (kept in LDS, one 8-byte read per fetch: the main loop has no two registers to spare for them)
+  uint2* s_piece = reinterpret_cast<uint2*>(smem + patch_base + 2 * kPatchBytes + kPatchPlanned * 32 + 48 * 4);
+  if constexpr (kShared) {
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t ca = 72u * wave + lane, cb = 72u * wave + 64u + lane;
+    uint32_t piece_a = 0xFFFFFFFFu, piece_b = 0xFFFFFFFFu;
+    if (ca % 9u != 8u) piece_a = (ca / 9u) * 16u + (ca % 9u) * f.pal_pitch;
+    if (lane < 8u && cb % 9u != 8u) piece_b = (cb / 9u) * 16u + (cb % 9u) * f.pal_pitch;
+    s_piece[threadIdx.x] = uint2{piece_a, piece_b};  // (read back by the same thread only)
+  }
+  typedef int rsrc_words_t __attribute__((ext_vector_type(4)));
+  const rsrc_words_t rsrc_words = {static_cast<int>(reinterpret_cast<uintptr_t>(f.pal_idx) & 0xFFFFFFFFull),
+                                   static_cast<int>((reinterpret_cast<uintptr_t>(f.pal_idx) >> 32) & 0xFFFFull), static_cast<int>(f.pal_bytes), 0x00020000};
+  auto fetch_shared = [&](uint32_t g) {  // g uniform
+    if constexpr (kShared) {
+      if (g >= groups || g >= kPatchPlanned) return;
+      const int4 e = s_plan_k[g];
+      if (__builtin_amdgcn_readfirstlane(e.y) != 8) return;  // no patch for this group
+      const uint32_t offset = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.w));
+      const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+      const uint32_t to = patch_base + (g & 1) * kPatchBytes + wave * (72u * 16u);
+      const uint2 mine = s_piece[threadIdx.x];
+      const uint32_t piece_a = mine.x, piece_b = mine.y;
+      // In assembly rather than through __builtin_amdgcn_raw_ptr_buffer_load_lds: the compiler makes every LDS read behind such a
+      // load wait for it (it cannot tell the patch buffer from the tables), i.e. stalls the wave for a memory latency once per
+      // group.  These loads are waited for where their data is needed: s_waitcnt vmcnt(0) in front of the next group's barrier.
+      if (piece_a != 0xFFFFFFFFu)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(to), "v"(piece_a), "s"(rsrc_words), "s"(offset) : "memory");
+      if (piece_b != 0xFFFFFFFFu)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(to + 64u * 16u), "v"(piece_b), "s"(rsrc_words), "s"(offset) : "memory");
+    }
+  };
+  if constexpr (kShared) {
+    if (!loose) fetch_shared(0);  // lands before the first group's barrier (a workgroup barrier waits for the wave's own fetches)
+  }
+
+  // The launch's statistics (what the host picks the next launch's kernel by): groups planned and groups through a
+  // patch, summed over a sample of the workgroups - every 16th of a large launch: thousands of atomic operations on one
+  // address would cost more than the kernel's other work - ; the last one to report copies the running totals to the
+  // host's mirror.  Called by the workgroup's last wave (the producer, if there is one).
+  auto report = [&]() {
       const uint32_t stride = gridDim.x >= 256 ? 16u : 1u;
       if (stats.device && lane == 0 && blockIdx.x % stride == 0) {
         atomicAdd(stats.device + 0, static_cast<unsigned long long>(groups));
@@ -1050,7 +1117,8 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
           stats.mirror[2] = (planned & 0xFFFFFFFFull) | (through << 32);
         }
       }
-    };
+  };
+  if (producer) {
     if (loose) {
       report();
       return;
@@ -1117,14 +1185,19 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     fetch(2, even);
     uint32_t g = 0;
     for (; g + 1 < groups; g += 2) {
-      __syncthreads();  // the consumers are done with group g - 1: its buffer takes the patch of g + 1
-      store(g + 1, odd);
-      fetch(g + 3, odd);
-      __syncthreads();
-      store(g + 2, even);
-      fetch(g + 4, even);
+      if constexpr (!(MCL_ABLATE & 1)) __syncthreads();  // the consumers are done with group g - 1: its buffer takes the patch of g + 1
+      if constexpr (!(MCL_ABLATE & 16)) {
+        store(g + 1, odd);
+        fetch(g + 3, odd);
+      }
+      if constexpr (!(MCL_ABLATE & 1)) __syncthreads();
+      if constexpr (!(MCL_ABLATE & 16)) {
+        store(g + 2, even);
+        fetch(g + 4, even);
+      }
     }
-    if (g < groups) __syncthreads();
+    if constexpr (!(MCL_ABLATE & 1))
+      if (g < groups) __syncthreads();
     report();  // off the consumers' path: they are still at their last group
     return;
   }
@@ -1151,7 +1224,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     uint32_t zero = 0;
     const uint32_t* perm_again = perm;
     asm volatile("" : "+v"(zero), "+s"(perm_again));
-    position = static_cast<uint64_t>(blockIdx.x) * kPatchParticles + (threadIdx.x + zero);
+    position = static_cast<uint64_t>(blockIdx.x) * kParticles + (threadIdx.x + zero);
     return perm_again[position < n ? position : n - 1];
   };
   auto add_exact = [&](uint32_t b0, uint32_t count) {
@@ -1182,6 +1255,12 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       add_exact(b0, 8);
       return;
     }
+    if constexpr (MCL_ABLATE & 2) {
+      auto fake = [](uint32_t a) { return __hiloint2double(0x3F000000, static_cast<int>(a)); };
+      acc += sum4(fake(e.e[0]), fake(e.e[1]), fake(e.e[2]), fake(e.e[3]));
+      acc += sum4(fake(e.e[4]), fake(e.e[5]), fake(e.e[6]), fake(e.e[7]));
+      return;
+    }
     {
       const double t0 = lf_palette_value(e.e[0]), t1 = lf_palette_value(e.e[1]), t2 = lf_palette_value(e.e[2]), t3 = lf_palette_value(e.e[3]);
       acc += sum4(t0, t1, t2, t3);
@@ -1199,7 +1278,11 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     Plan plan{0u, 0u};
     if constexpr (!decltype(is_loose)::value) plan_of(g, plan);
     const uint32_t buffer = patch_base + (g & 1) * kPatchBytes;
-    if constexpr (!decltype(is_loose)::value) __syncthreads();
+    if constexpr (kShared && !decltype(is_loose)::value) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of group g's patch are in LDS
+    if constexpr (!decltype(is_loose)::value && !(MCL_ABLATE & 1)) __syncthreads();
+    // kShared: behind this barrier every wave is done with the buffer of group g - 1, which takes the patch of group g + 1; the
+    // fetch issued here lands before the next barrier (one group of arithmetic, ~3 us, against ~1 us of L2 latency)
+    if constexpr (kShared && !decltype(is_loose)::value) fetch_shared(g + 1);
     now.redo = 1u;
     if (!fast) {
       if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
@@ -1222,9 +1305,11 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     if (plan.meta == 8u) {  // one whole patch (19 groups in 20): one constant for the eight look-ups
       const uint32_t K = buffer + plan.ka;
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        now.e[k] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(
-            static_cast<uintptr_t>(mad_u24(static_cast<uint32_t>(cx[k]), kPatchPitch, lshl_add_u32_uniform(static_cast<uint32_t>(cy[k]), 1, K)))));
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t at = mad_u24(static_cast<uint32_t>(cx[k]), kPatchPitch, lshl_add_u32_uniform(static_cast<uint32_t>(cy[k]), 1, K));
+        if constexpr (MCL_ABLATE & 4) now.e[k] = f.pal_base + (at & 0x3F8u);
+        else now.e[k] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(static_cast<uintptr_t>(at)));
+      }
     } else if (plan.meta != 0u) {  // two halves: the beams from plan.meta on read the second one
       const uint32_t KA = buffer + plan.ka, KB = buffer + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_plan_k[g].z));
 #pragma unroll
@@ -1273,6 +1358,9 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     } else {
       w[i_end] = w[i_end] * (f.prob ? exp(acc) : acc);
     }
+  }
+  if constexpr (kShared) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == kPalBlock / 64 - 1) report();
   }
 }
 
@@ -3563,10 +3651,16 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
       const bool fast = tuning.lf_fast != 0 && scan_is_short && f.W < 16384 && f.H < 16384;
       const uint32_t patch_base = (static_cast<uint32_t>(pal_lds) + 15u) & ~15u;
       const size_t patch_lds = patch_base + kPatchLds;
-      if (fast && use_patches && patch_lds <= 65536)
-        hipLaunchKernelGGL(k_reweight_lf_patch, dim3(static_cast<unsigned>((n + kPatchParticles - 1) / kPatchParticles), segments),
-                           dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial, per_segment, patch_base,
-                           patch_stats);
+      if (fast && use_patches && patch_lds <= 65536) {
+        if (tuning.lf_producer == 0)
+          hipLaunchKernelGGL(k_reweight_lf_patch<true>, dim3(static_cast<unsigned>((n + kPatchParticlesAll - 1) / kPatchParticlesAll), segments),
+                             dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial, per_segment, patch_base,
+                             patch_stats);
+        else
+          hipLaunchKernelGGL(k_reweight_lf_patch<false>, dim3(static_cast<unsigned>((n + kPatchParticles - 1) / kPatchParticles), segments),
+                             dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial, per_segment, patch_base,
+                             patch_stats);
+      }
       else if (fast && dispersed && tuning.lf_far_tiles != 0 && f.far_bits != nullptr && patch_base + f.far_bytes <= 65536) {
         const dim3 fgrid((pgrid.x + 7u) & ~7u, segments);
         hipLaunchKernelGGL((k_reweight_lf_palette<true, true>), fgrid, dim3(kPalBlock), patch_base + f.far_bytes, st, p.w, n, f, d_points, B,

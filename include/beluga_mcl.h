@@ -400,9 +400,13 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                   of the Z curve is two pieces far apart, and its workgroup fits no LDS patch)
  *   key_bits_xy (0) bits of the x and of the y bins of that key (the heading gets the other 20 - 2 b): 0 = chosen every cycle from
  *                   the cloud's spread and the scan's reach (4 .. 6), 4 / 5 / 6 = forced (round 2: 6)
- *   lf_split (1)    LDS-patch planner: a group of 8 beams that fits no whole 64 x 64-cell patch (its end-points straddle a range
+ *   lf_producer (1) LDS-patch kernel: 1 = seven waves of particles and a producer wave per workgroup, 0 = eight waves of particles,
+ *                   each fetching its share of the patches straight into LDS (buffer_load ... lds; no half patches, no patches
+ *                   clamped at the table's border: such groups are gathered)
+ *   lf_split (3)    LDS-patch planner: a group of 8 beams that fits no whole 64 x 64-cell patch (its end-points straddle a range
  *                   discontinuity: 3 - 5 % of the groups of an indoor scan, whatever the cloud) goes through two half patches -
- *                   beams [0, k) and [k, 8), 32 x 64 or 64 x 32 cells each, in the buffer of one whole patch; 0 = such groups are gathered
+ *                   beams [0, k) and [k, 8), 32 x 64 (bit 0) or 64 x 32 (bit 1) cells each, in the buffer of one whole patch; 0 = such
+ *                   groups are gathered
  *   lf_margin (1)   LDS-patch planner, the rotation part of the bound on a workgroup's end-points: 1 = per axis
  *                   ((1 - cos d) |q'x| + |sin d| |q'y| in x, the transpose in y), 0 = |R_p - R_ref| |q| on both axes (round 2)
  *   field_build (0)  how the NEXT mcl_set_map builds the likelihood field: 0 = the reference's priority-queue wavefront on the

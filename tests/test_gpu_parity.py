@@ -1088,6 +1088,40 @@ def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n):
         assert np.array_equal(weights[0], weights[1]), (n, beams, int((weights[0] != weights[1]).sum()))
 
 
+@pytest.mark.parametrize("options", [
+    dict(lf_producer=1, lf_split=3, lf_margin=1, key_curve=1),  # the defaults
+    dict(lf_producer=1, lf_split=1), dict(lf_producer=1, lf_split=2), dict(lf_producer=1, lf_split=0, lf_margin=0, key_curve=0, key_bits_xy=6),
+    dict(lf_producer=0), dict(lf_producer=0, lf_margin=0, key_bits_xy=4), dict(lf_producer=1, key_bits_xy=5),
+])
+def test_reweight_lf_patch_planner_options_change_no_weight(options):
+    """What the LDS-patch kernel's planner and the ordering decide - whole patches, half patches side by side / stacked for groups
+    that straddle a range discontinuity, the per-axis or isotropic bound, Hilbert or Morton keys and their bit split, a producer
+    wave or fetches shared by all waves (buffer_load ... lds) - changes where a look-up is read from, never its value: the
+    weights equal the gather kernel's bit for bit, on a cloud wide enough to put patches across the grid's edges, and on a
+    tight one where nearly every group goes through a patch (and the planner's statistics say so)."""
+    cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
+    grid = OccupancyGrid(cells=cells, resolution=0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
+    truth = synth.find_free_pose(cells, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
+    pts = make_scan(grid, truth, 1080, max_range=12.0)
+    n = 200_000
+    for sigma in ((0.5, 0.5, 0.2), (0.1, 0.1, 0.03)):
+        weights, shares = [], []
+        for patch in (2, 0):
+            f = new_filter(grid, n)
+            f.set_option("lf_patch", patch)
+            for k, v in options.items():
+                f.set_option(k, v)
+            f.initialize(truth, np.diag([s * s for s in sigma]))
+            f.reweight(pts)
+            weights.append(f.particles()[1].copy())
+            if patch == 2:
+                shares.append(f.counter("lf_patch_groups_through") / max(f.counter("lf_patch_groups_planned"), 1))
+            f.close()
+        assert np.array_equal(weights[0], weights[1]), (options, sigma, int((weights[0] != weights[1]).sum()))
+        if sigma[0] < 0.2 and options.get("lf_producer", 1) == 1:
+            assert shares[0] > 0.9, (options, shares)
+
+
 def test_spatial_order_is_a_sorted_permutation():
     """The ordering pass (two-pass radix sort of the 20-bit keys, the second pass stable): perm is a permutation and
     keys[perm] is non-decreasing — with the key frame from the host's estimate, from a bounding-box pass (set_particles

@@ -11,7 +11,7 @@ cells, truth, odoms, scans, _poses = bench.make_workload(2)
 grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
 n = int(os.environ.get("N", 1_000_000))
 f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF), AmclParams(min_particles=n, max_particles=n), seed=42)
-for sig in [(0.15, 0.15, 0.05), (0.05, 0.05, 0.02)]:
+for sig in [(0.33, 0.14, 0.11), (0.1, 0.2, 0.107), (0.05, 0.05, 0.02)]:
     states = synth.normal_particles(n, truth, sig, seed=9)
     w0 = np.ones(n)
     ms = []

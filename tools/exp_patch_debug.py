@@ -13,7 +13,7 @@ pts = synth.scan_points(ranges, angles)
 LF = LikelihoodFieldModelParam(2.0, 100.0, 0.5, 0.5, 0.2, True)
 n = 200_000
 ref = None
-for split, margin, curve in itertools.product((0, 1, 2, 3), (0, 1), (1,)):
+for split, margin, curve in itertools.product((0, 3), (1,), (1,)):
     ws = []
     for patch in (2, 0):
         f = Amcl(grid, DifferentialDriveModelParam(0.1, 0.05, 0.1, 0.05), LF, AmclParams(min_particles=n, max_particles=n), seed=11)
