@@ -226,6 +226,8 @@ struct mcl_ctx {
   DeviceBuffer<double> d_est_partials;  // [9][ceil(n / 256)] estimate sums left by the draw kernel
   DeviceBuffer<double> d_cloud_w;
   DeviceBuffer<double> d_cdf_tree;  // sampled levels of the 16-ary search tree over d_cdf (CdfTree)
+  DeviceBuffer<double> d_lf_wsum;   // sums of the new weights per workgroup of the LF patch kernel (PatchStats::weight_sums)
+  uint32_t lf_wsum_count{0};        // how many the last reweight left (0: none; consumed by the normalisation right behind it)
   CdfTree cdf_tree() const { return make_cdf_tree(d_cdf.ptr, d_cdf_tree.ptr, n); }
 
   // KLD
@@ -401,6 +403,7 @@ mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
   MCL_HIP(ctx, ctx->d_chunk.ensure(static_cast<size_t>(12) * chunks));
   MCL_HIP(ctx, ctx->d_cdf.ensure(cap));
   MCL_HIP(ctx, ctx->d_cdf_tree.ensure(cdf_tree_doubles(cap)));
+  MCL_HIP(ctx, ctx->d_lf_wsum.ensure(cap / 448 + 2));
   ctx->capacity = cap;
   {
     static_assert(sizeof(KeyFrame) <= 8 * sizeof(double), "the key frame sits in the first 8 doubles of d_sort_f64");
@@ -640,6 +643,7 @@ bool predict_key_frame(const mcl_ctx* ctx, const DiffDriveSampler* motion, KeyFr
   out->inv_y = inverse_span(sy);
   out->inv_t = sigma_span_t(std::min(st, kPi / 4.0));  // the heading bins never span more than the circle
   out->t_off = 0.f;
+  if (ctx->tuning.key_warp && !(out->layout & 1u) && spans == 8.0) out->layout |= 4u;  // bins of equal mass over the +-4 sigma
   // How the 20 bits are split: a run of the curve is roughly a cube of bins, and what a workgroup's LDS patch has to absorb is
   // its extent in x (or y) PLUS its extent in heading times the scan's reach - so the split that minimises the sum of the two
   // bin sizes, in cells: 8 sigma_xy / res / 2^b  +  8 sigma_theta reach / res / 2^(20 - 2 b), b = 4 .. 6.
@@ -785,7 +789,11 @@ mcl_status reweight_preconditions(mcl_ctx* ctx, uint64_t B) {
 }
 
 // points_staged: stage_points + the pull already happened (mcl_update); keys_ready: k_propagate emitted the ordering keys.
-mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_staged = false, bool keys_ready = false) {
+// want_weight_sums: the normalisation follows at once (mcl_update): the LF patch kernel leaves the sums of its workgroups' new
+// weights in d_lf_wsum (ctx->lf_wsum_count of them; 0 if another kernel ran).
+mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_staged = false, bool keys_ready = false,
+                       bool want_weight_sums = false) {
+  ctx->lf_wsum_count = 0;
   if (const mcl_status s = reweight_preconditions(ctx, B)) return s;
   if (!points_staged) {
     if (const mcl_status s = stage_points(ctx, pts, B)) return s;
@@ -825,9 +833,9 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
                        PatchStats{reinterpret_cast<unsigned long long*>(ctx->d_scalars.ptr + 24),
                                   reinterpret_cast<unsigned long long*>(ctx->hd_scalars + 28),
                                   static_cast<uint32_t>(ctx->tuning.lf_loose_below), ctx->tuning.lf_margin ? 0u : 1u,
-                                  static_cast<uint32_t>(ctx->tuning.lf_split)},
+                                  static_cast<uint32_t>(ctx->tuning.lf_split), want_weight_sums ? ctx->d_lf_wsum.ptr : nullptr},
                        /*dispersed=*/!use_patches && (ctx->tuning.lf_far_tiles == 2 || (ctx->tuning.lf_patch == 1 && !ctx->patch_useful)),
-                       &far_tiles_used);
+                       &far_tiles_used, &ctx->lf_wsum_count);
     if (far_tiles_used) ctx->lf_far_launches += 1;
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
     if (variant == kLfSortedLanes && ctx->tuning.lf_fast != 0 && scan_is_short && ctx->W < 16384 && ctx->H < 16384 && ctx->pal_count &&
@@ -858,7 +866,9 @@ mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats, bo
   stage_begin(ctx, MCL_STAGE_NORMALIZE);
   if (std::isnan(factor)) {  // by the set's own total
     launch_sum_and_normalize(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->chunk_row(1), ctx->chunk_row(2),
-                             ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0, finalize);
+                             ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0, finalize, ctx->lf_wsum_count ? ctx->d_lf_wsum.ptr : nullptr,
+                             ctx->lf_wsum_count);
+    ctx->lf_wsum_count = 0;  // (they described the weights as the reweight left them)
   } else {
     launch_weight_sum(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0);
     ctx->h_scalars[3] = factor;
@@ -1763,7 +1773,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_bits_xy", "lf_margin", "lf_split", "lf_producer"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_weight_sums"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -1805,6 +1815,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_scalars.release();
   ctx->d_cdf.release();
   ctx->d_cdf_tree.release();
+  ctx->d_lf_wsum.release();
   ctx->d_cloud.release();
   ctx->d_est_partials.release();
   ctx->d_cloud_w.release();
@@ -2165,17 +2176,18 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
 
   bool keys_ready = false;
   if (const mcl_status s = do_propagate(ctx, ctx->window0, ctx->window1, ctx->step, num_points, &keys_ready)) return s;  // :174-175
-  if (const mcl_status s = do_reweight(ctx, points_xy, num_points, true, keys_ready)) return s;                         // :176
-  mcl_weight_stats stats{};
-  double random_state_probability = 0.0;
-  double ess = -1.0;
-  bool do_resampling = false;
-  bool estimate_enqueued = false;  // the estimate sums of the resampled set came out of the draw kernel
   // With a fixed particle count and no selective resampling nothing in the cycle depends on a host-side decision: the
   // recovery estimator runs on the device as well and the cycle synchronises once, at the estimate.
   const mcl_amcl_params& ap = ctx->cfg.amcl;
   const bool device_policy = !ap.selective_resampling && ap.min_particles >= std::min<uint64_t>(ap.max_particles, ctx->capacity) &&
                              ctx->tuning.device_policy != 0;
+  // (the normalisation follows at once: the LF kernel leaves the sums it is built on)
+  if (const mcl_status s = do_reweight(ctx, points_xy, num_points, true, keys_ready, /*want_weight_sums=*/ctx->tuning.lf_weight_sums != 0)) return s;  // :176
+  mcl_weight_stats stats{};
+  double random_state_probability = 0.0;
+  double ess = -1.0;
+  bool do_resampling = false;
+  bool estimate_enqueued = false;  // the estimate sums of the resampled set came out of the draw kernel
   constexpr int kPolicySlot = 20;  // d_scalars[20..23) = {slow, fast, p}
   if (device_policy) {
     // :177; the totals of the normalised weights and the recovery estimator (:179, :184-186) ride on the next kernel
@@ -2634,9 +2646,11 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "device_policy") t.device_policy = value ? 1 : 0;
   else if (key == "field_build") t.field_build = value ? 1 : 0;
   else if (key == "key_curve") t.key_curve = value ? 1 : 0;
+  else if (key == "key_warp") t.key_warp = value ? 1 : 0;
   else if (key == "key_bits_xy") t.key_bits_xy = (value >= 4 && value <= 6) ? static_cast<int>(value) : 0;
   else if (key == "lf_margin") t.lf_margin = value ? 1 : 0;
   else if (key == "lf_producer") t.lf_producer = value ? 1 : 0;
+  else if (key == "lf_weight_sums") t.lf_weight_sums = value ? 1 : 0;
   else if (key == "lf_split") t.lf_split = static_cast<int>(value & 3);  // 1: side by side only, 2: stacked only, 3: both
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else if (key == "beam_sort_min_particles") t.beam_sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));

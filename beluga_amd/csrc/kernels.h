@@ -139,11 +139,15 @@ struct Tuning {
                                     // (measured: 25 % faster than the ordered kernels at 20K particles, 10 % at 50K, 12 % slower at 100K)
   int field_build = 0;              // mcl_set_map: 0 = host wavefront (bit-identical to the reference), 1 = exact EDT on the device
   int key_curve = 1;                // heading-major ordering key: 1 = Hilbert curve through (heading, y, x), 0 = Morton order
+  int key_warp = 1;                 // heading-major key: 1 = bins of equal mass (the frame's +-4 sigma mapped through the normal distribution
+                                    // function) when the frame comes from an estimate of the set, 0 = bins of equal width
   int key_bits_xy = 0;              // bits of the x / y bins of that key: 0 = chosen per cycle from the cloud's spread and the scan's
                                     // reach (4 .. 6), otherwise forced; round 2: 6 (8 heading bits)
   int lf_producer = 1;              // LDS-patch kernel: 1 = seven waves of particles + a producer wave (the form that knows half patches and
                                     // patches clamped at the table's border), 0 = every wave holds particles and fetches its share of the
                                     // patches straight into LDS (buffer_load ... lds); measured 5 % slower on the bench
+  int lf_weight_sums = 1;           // fixed-size cycle: the normalisation factor is added up from the LF patch kernel's workgroup sums of the
+                                    // new weights (no k_chunk_sum pass); 0 = from chunk sums of the weights
   int lf_split = 3;                 // LDS-patch planner: a group of 8 beams that fits no whole 64 x 64 patch (a range discontinuity inside
                                     // it) may go through two half patches (beams [0, k) and [k, 8): 32 x 64 or 64 x 32 cells each); 0 = never
   int lf_margin = 1;                // LDS-patch planner, rotation part of the bound: 1 = per axis (|sin d| |q'y| + (1 - cos d) |q'x|),
@@ -163,6 +167,7 @@ struct KeyFrame {
   uint32_t layout;        // 0: heading-major key (dense sets: a workgroup's poses fit an LDS patch), 1: position-major key
                           // (dispersed sets: neighbours in the order share a region of the map, whatever their heading);
                           // | 2: the heading-major key follows the Z (Morton) curve instead of the Hilbert curve (option key_curve)
+                          // | 4: heading-major key over bins of equal mass of a normal set instead of equal width (option key_warp)
   uint32_t bits_xy;       // heading-major key: bits of the x and of the y bins (4 .. 6; 0 = 6); the heading takes the other 20 - 2 bits_xy
 };
 constexpr uint32_t kSortDigits = 1024;  // two least-significant-digit-first passes of 10 bits each
@@ -172,9 +177,11 @@ constexpr uint32_t kSortDigits = 1024;  // two least-significant-digit-first pas
 // of the Morton order that crosses a high-level boundary of the Z curve is two pieces far apart, and the workgroup that holds it
 // (448 consecutive particles of the order, k_reweight_lf_patch) fits no LDS patch.  The curve enters at (0, 0, 0) and leaves at
 // (2^bits - 1, 0, 0): with the heading on axis 0, the slabs of the key's top heading bits chain into one continuous curve.
-__host__ __device__ inline uint32_t hilbert_index_3(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t bits) {
+template <uint32_t bits>
+__host__ __device__ inline uint32_t hilbert_index_3_fixed(uint32_t a0, uint32_t a1, uint32_t a2) {
   const uint32_t mask = (1u << bits) - 1u;
   uint32_t x0 = a0 & mask, x1 = a1 & mask, x2 = a2 & mask;
+#pragma unroll
   for (uint32_t q = 1u << (bits - 1); q > 1; q >>= 1) {
     const uint32_t p = q - 1;
     x0 ^= (x0 & q) ? p : 0u;  // axis 0 against itself: invert or nothing
@@ -194,6 +201,7 @@ __host__ __device__ inline uint32_t hilbert_index_3(uint32_t a0, uint32_t a1, ui
   x1 ^= x0;
   x2 ^= x1;
   uint32_t t = 0;
+#pragma unroll
   for (uint32_t q = 1u << (bits - 1); q > 1; q >>= 1) t ^= (x2 & q) ? q - 1 : 0u;
   x0 ^= t;
   x1 ^= t;
@@ -205,6 +213,16 @@ __host__ __device__ inline uint32_t hilbert_index_3(uint32_t a0, uint32_t a1, ui
     return v;
   };
   return (spread(x0) << 2) | (spread(x1) << 1) | spread(x2);
+}
+__host__ __device__ inline uint32_t hilbert_index_3(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t bits) {  // straight-line code per width
+  switch (bits) {
+    case 1: return hilbert_index_3_fixed<1>(a0, a1, a2);
+    case 2: return hilbert_index_3_fixed<2>(a0, a1, a2);
+    case 3: return hilbert_index_3_fixed<3>(a0, a1, a2);
+    case 4: return hilbert_index_3_fixed<4>(a0, a1, a2);
+    case 5: return hilbert_index_3_fixed<5>(a0, a1, a2);
+    default: return hilbert_index_3_fixed<6>(a0, a1, a2);
+  }
 }
 struct SortScratch {
   uint32_t* keys;                // [n] key of particle i
@@ -242,10 +260,14 @@ struct PatchStats {
   uint32_t loose_below;        // a workgroup with fewer than loose_below / 256 of its groups fitting a patch gathers them all
   uint32_t isotropic_margin;   // 1: the rotation part of the bound as |R_p - R_ref| |q| on both axes (Tuning::lf_margin = 0)
   uint32_t split_patches;      // 1: a group that fits no whole patch may go through two half patches (Tuning::lf_split)
+  double* weight_sums;         // optional: [workgroups] sums of the new weights, one per workgroup of the patch kernel (the
+                               // normalisation's input: launch_sum_and_normalize); only written by single-segment launches
 };
+// *weight_sums_written (optional): how many workgroup sums of the new weights the launch left in patch_stats.weight_sums (0: none -
+// another kernel ran, or the launch was segmented)
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
-                        bool dispersed = false, bool* far_tiles_used = nullptr);
+                        bool dispersed = false, bool* far_tiles_used = nullptr, uint32_t* weight_sums_written = nullptr);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_order_particles first).
 // d_beam_points: scratch of kBeamPointDoubles * B doubles (per-beam terms shared by all particles; ordered variant only).
@@ -280,8 +302,10 @@ void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_pa
 //      d_out[0] = total of new w, d_out[1] = total of squares.
 void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_factor, double* d_chunk_sum, double* d_chunk_sumsq,
                       double* d_out, double* host_mirror = nullptr);
+// known_partials (optional): `known_count` sums whose total is the normalisation factor (PatchStats::weight_sums) - k_chunk_sum is skipped
 void launch_sum_and_normalize(hipStream_t st, double* w, uint64_t n, double* d_partials, double* d_chunk_sum, double* d_chunk_sumsq,
-                              double* d_sums, double* host_mirror, bool finalize = true);
+                              double* d_sums, double* host_mirror, bool finalize = true, const double* known_partials = nullptr,
+                              uint32_t known_count = 0);
 // ThrunRecoveryProbabilityEstimator (thrun_recovery_probability_estimator.hpp:69-89, exponential_filter.hpp:32-44) evaluated
 // on the device so that a cycle without host-side decisions needs no mid-cycle read-back: d_policy = {slow, fast, p}.
 // It rides on the workgroup that adds up the totals of the normalised weights (launch_cdf / launch_norm_finalize).

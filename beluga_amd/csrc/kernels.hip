@@ -131,8 +131,19 @@ __device__ __forceinline__ uint32_t order_key(const double4& q, const KeyFrame& 
   }
   // heading-major: the top heading bits select a slab, inside it the curve runs through cubes of bits_xy bits per axis
   const uint32_t bits = kf.bits_xy ? kf.bits_xy : kKeyBitsXY, bits_t = kKeyBits - 2 * bits;
-  const uint32_t bx = static_cast<uint32_t>(unit_bin(ux, 1 << bits)), by = static_cast<uint32_t>(unit_bin(uy, 1 << bits));
-  const uint32_t bt = static_cast<uint32_t>(unit_bin(ut, 1 << bits_t));
+  float vx = ux, vy = uy, vt = ut;
+  if (kf.layout & 4u) {
+    // Bins of equal MASS instead of equal width: the frame's span is +-4 sigma of a set that is close to normal, so u -> the
+    // normal distribution function of 8 (u - 1/2).  The 1024 buckets of the ordering's first pass (the key's high digit) then
+    // hold about the same number of particles - with bins of equal width the bucket at the centre of the cloud held ten times the
+    // average, and its workgroup was the second pass's critical path - and the cells are small where the particles are.
+    auto mass = [](float u) { return 0.5f + 0.5f * erff((u - 0.5f) * 5.65685425f); };  // 8 / sqrt 2
+    vx = mass(ux);
+    vy = mass(uy);
+    vt = mass(ut);
+  }
+  const uint32_t bx = static_cast<uint32_t>(unit_bin(vx, 1 << bits)), by = static_cast<uint32_t>(unit_bin(vy, 1 << bits));
+  const uint32_t bt = static_cast<uint32_t>(unit_bin(vt, 1 << bits_t));
   const uint32_t slab = (bt >> bits) << (3 * bits), bt_in = bt & ((1u << bits) - 1);
   if (kf.layout & 2u) return slab | spread3(bx) | (spread3(by) << 1) | (spread3(bt_in) << 2);
   return slab | hilbert_index_3(bt_in, by, bx, bits);
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(kWide) void k_propagate(Particles p, uint64_t n, Di
     if (kKeys) {
       const uint32_t key = order_key(double4{out.r.c, out.r.s, out.x, out.y}, kf);
       keys[i] = key;
-      atomicAdd(&hist[key & (kSortDigits - 1)], 1u);
+      atomicAdd(&hist[key >> kDigitBits], 1u);  // the ordering's first pass goes by the HIGH digit
     }
   }
   if (kKeys) {
@@ -780,9 +791,20 @@ constexpr uint32_t kPatchPitch = kPatchH * 2 + 16;
 constexpr uint32_t kPatchBytes = kPatchW * kPatchPitch;
 constexpr uint32_t kPatchParticles = kPalBlock - 64;  // per workgroup, with a producer wave (k_reweight_lf_patch<false>)
 constexpr uint32_t kPatchParticlesAll = kPalBlock;    // per workgroup when every wave holds particles (k_reweight_lf_patch<true>)
-constexpr uint32_t kPatchPlanned = 256;               // groups with a plan entry; the ones beyond are gathered
-constexpr uint32_t kPatchLds = 2 * kPatchBytes + kPatchPlanned * 32 + 48 * 4 + kPalBlock * 8;  // two patches, the two plans, the prologue's
-                                                                                               // partial results, the lanes' shares of a fetch (kShared)
+constexpr uint32_t kPatchPlanned = 192;               // groups with a plan entry (scans of up to 1536 points); the ones beyond are gathered
+// Patch buffers: THREE with a producer wave, so that the consumers need no wait at a group's barrier - the look-ups of group g
+// (issued at the end of step g, used in step g + 1) have returned long before the buffer of group g is written again behind
+// barrier g + 2, whereas with two buffers every wave had to sit out its outstanding LDS reads in front of each barrier - ; two when
+// the fetches are shared by all waves.  Behind them: the two plans, the prologue's partial results, and (shared fetches) the lanes'
+// constant shares of a fetch.
+#ifndef MCL_PATCH_BUFFERS
+#define MCL_PATCH_BUFFERS 3
+#endif
+#ifndef MCL_BARE_BARRIER
+#define MCL_BARE_BARRIER 1
+#endif
+constexpr uint32_t patch_buffers(bool shared) { return shared ? 2u : MCL_PATCH_BUFFERS; }
+constexpr uint32_t patch_lds_bytes(bool shared) { return patch_buffers(shared) * kPatchBytes + kPatchPlanned * 32 + 48 * 4 + (shared ? kPalBlock * 8 : 0u); }
 constexpr double kPatchMagic = 1572864.0 + 4.656612873077392578125e-10;     // 1.5 * 2^20 + 2^-31
 // kShared: no producer wave.  All eight waves hold particles, and each fetches an eighth of the next group's patch itself with
 // buffer_load_dwordx4 ... lds (global memory -> LDS without passing through registers: lane i's 16 bytes land at M0 + 16 i,
@@ -816,12 +838,17 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   // The consumers read a second entry per group: {KA', meta, KB', the group's fetch offset (kShared)}: the constants of the two halves' LDS addresses less the
   // buffer's base (cell (cx, cy) sits at cx * pitch + cy * 2 + K), meta = 0: gathered, 8: one whole patch, k = 1 .. 7: two halves,
   // the second one from beam k on.
-  int4* s_plan = reinterpret_cast<int4*>(smem + patch_base + 2 * kPatchBytes);
+  constexpr uint32_t kBuffers = patch_buffers(kShared);
+  auto buffer_of = [&](uint32_t g) -> uint32_t {  // LDS byte address of the buffer that holds the patch of group g (g uniform, < 2^16)
+    const uint32_t slot = kBuffers == 2 ? (g & 1u) : g - 3u * ((g * 0xAAABu) >> 17);
+    return patch_base + slot * kPatchBytes;
+  };
+  int4* s_plan = reinterpret_cast<int4*>(smem + patch_base + kBuffers * kPatchBytes);
   int4* s_plan_k = s_plan + kPatchPlanned;
-  float* s_bound = reinterpret_cast<float*>(smem + patch_base + 2 * kPatchBytes + kPatchPlanned * 32);  // [7][6]
+  float* s_bound = reinterpret_cast<float*>(smem + patch_base + kBuffers * kPatchBytes + kPatchPlanned * 32);  // [7][6]
   // The scan itself, for the planner's threads (they walk their group's points again and again): staged in the patch buffers,
   // which nothing else uses before the main loop, if it fits there.
-  const bool scan_staged = static_cast<size_t>(B) * sizeof(double2) <= 2 * kPatchBytes;
+  const bool scan_staged = static_cast<size_t>(B) * sizeof(double2) <= kBuffers * kPatchBytes;
   if (scan_staged) {
     double2* s_scan = reinterpret_cast<double2*>(smem + patch_base);
     const double2* scan = reinterpret_cast<const double2*>(pts);
@@ -1062,7 +1089,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   // nobody fetches) lies at byte 16 c of the buffer: lane i of the full instruction takes piece 72 wave + i, lanes 0 .. 7 of
   // the second one piece 72 wave + 64 + i.  The lane's share of the table offset never changes.
   // (kept in LDS, one 8-byte read per fetch: the main loop has no two registers to spare for them)
-  uint2* s_piece = reinterpret_cast<uint2*>(smem + patch_base + 2 * kPatchBytes + kPatchPlanned * 32 + 48 * 4);
+  uint2* s_piece = reinterpret_cast<uint2*>(smem + patch_base + kBuffers * kPatchBytes + kPatchPlanned * 32 + 48 * 4);
   if constexpr (kShared) {
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t ca = 72u * wave + lane, cb = 72u * wave + 64u + lane;
@@ -1081,7 +1108,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       if (__builtin_amdgcn_readfirstlane(e.y) != 8) return;  // no patch for this group
       const uint32_t offset = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.w));
       const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-      const uint32_t to = patch_base + (g & 1) * kPatchBytes + wave * (72u * 16u);
+      const uint32_t to = buffer_of(g) + wave * (72u * 16u);
       const uint2 mine = s_piece[threadIdx.x];
       const uint32_t piece_a = mine.x, piece_b = mine.y;
       // In assembly rather than through __builtin_amdgcn_raw_ptr_buffer_load_lds: the compiler makes every LDS read behind such a
@@ -1172,7 +1199,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       }
     };
     auto store = [&](uint32_t g, const Pieces& piece) {
-      unsigned char* dst = smem + patch_base + (g & 1) * kPatchBytes + lane * kPatchPitch;
+      unsigned char* dst = smem + buffer_of(g) + lane * kPatchPitch;
 #pragma unroll
       for (int r = 0; r < kPatchH / 8; ++r) *reinterpret_cast<uint4*>(dst + r * 16) = piece[r];
     };
@@ -1277,9 +1304,20 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     const uint32_t b0 = b_begin + 8 * g;
     Plan plan{0u, 0u};
     if constexpr (!decltype(is_loose)::value) plan_of(g, plan);
-    const uint32_t buffer = patch_base + (g & 1) * kPatchBytes;
+    const uint32_t buffer = buffer_of(g);
     if constexpr (kShared && !decltype(is_loose)::value) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of group g's patch are in LDS
-    if constexpr (!decltype(is_loose)::value && !(MCL_ABLATE & 1)) __syncthreads();
+    if constexpr (!decltype(is_loose)::value && !(MCL_ABLATE & 1)) {
+      if constexpr (kShared || !MCL_BARE_BARRIER) {
+        __syncthreads();
+      } else {
+        // A bare barrier: no wait for this wave's outstanding LDS reads (see patch_buffers).  What it orders: the producer's stores
+        // of patch g (complete before ITS barrier: it keeps the fence) against the look-ups below.  The empty asm statements keep
+        // the compiler from moving memory operations across it.
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
     // kShared: behind this barrier every wave is done with the buffer of group g - 1, which takes the patch of group g + 1; the
     // fetch issued here lands before the next barrier (one group of arithmetic, ~3 us, against ~1 us of L2 latency)
     if constexpr (kShared && !decltype(is_loose)::value) fetch_shared(g + 1);
@@ -1352,11 +1390,27 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   add_exact(b_begin + 8 * groups, b_end - (b_begin + 8 * groups));
   uint64_t t_end;
   const uint32_t i_end = particle_again(t_end);
+  double new_weight = 0.0;
   if (t_end < n) {
     if (partial) {
       partial[static_cast<size_t>(blockIdx.y) * n + t_end] = acc;
     } else {
-      w[i_end] = w[i_end] * (f.prob ? exp(acc) : acc);
+      new_weight = w[i_end] * (f.prob ? exp(acc) : acc);
+      w[i_end] = new_weight;
+    }
+  }
+  // The sum of the workgroup's new weights (fixed order: lanes, then waves), for the normalisation that follows: the weights
+  // need no pass of their own to be added up (actions/normalize.hpp:70).  The producer, if any, has left: the barrier counts
+  // the waves that are still there.
+  if (stats.weight_sums) {
+    double* s_sum = reinterpret_cast<double*>(s_bound);
+    const double wave_total = wave_sum_f64(new_weight);
+    if (lane == 0) s_sum[threadIdx.x >> 6] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double total = s_sum[0];
+      for (uint32_t k = 1; k < kConsumers; ++k) total += s_sum[k];
+      stats.weight_sums[blockIdx.x] = total;
     }
   }
   if constexpr (kShared) {
@@ -1377,12 +1431,15 @@ __global__ __launch_bounds__(kBlock) void k_lf_combine(double* __restrict__ w, u
 
 // [lf-kernels-end]
 // -- spatial ordering of the particles --------------------------------------------------------------
-// A full least-significant-digit-first radix sort of (key, index) by the 20-bit ordering key, two passes of 10 bits:
-//   keys + block histograms of the low digit (inside k_propagate, or k_order_keys)  ->  row scan (+ digit totals)  ->
-//   scatter by the low digit (order inside a digit irrelevant; digit bases scanned per workgroup)  ->  block histograms of
-//   the high digit  ->  row scan  ->  STABLE scatter by the high digit  ->  perm.     5 launches behind the keys.
+// A full sort of (key, index) by the 20-bit ordering key, most significant digit first, two digits of 10 bits:
+//   keys + block histograms of the HIGH digit (inside k_propagate, or k_order_keys)  ->  row scan (+ digit totals)  ->
+//   stable scatter by the high digit into 1024 buckets (digit bases scanned per workgroup)  ->  every bucket sorted by the low
+//   digit in LDS-resident counters, stable  ->  perm.     3 launches behind the keys (round 2's least-significant-digit-first
+//   sort took 5: a bucket's low-digit pass needs no second table of block histograms and no second row scan).
+// The order is the one by (key, particle index): identical in every run, so what depends on the ORDER of the lanes (the
+// LF kernel's workgroup sums of the new weights) is reproducible bit for bit.
 // Global atomics are slow on this part (~6 per ns, device scope resolves at the memory side), so there are none: block
-// histograms in LDS, [digit][block] offset tables, LDS cursors.  Only 8 bytes per particle move; the kernels that
+// histograms in LDS, [digit][block] offset tables, per-wave counters.  Only 8 bytes per particle move; the kernels that
 // consume the order gather the pose records through perm.
 __device__ __forceinline__ double heading_delta(double c, double s, double c0, double s0) {
   return atan2(s * c0 - c * s0, c * c0 + s * s0);  // angle of (c,s) relative to (c0,s0), in (-pi, pi]
@@ -1486,7 +1543,7 @@ __global__ __launch_bounds__(kWide) void k_order_keys(Particles p, uint64_t n, K
     if (i < n) {
       const uint32_t key = order_key(p.pose[i], kf);
       keys[i] = key;
-      atomicAdd(&hist[key & (kSortDigits - 1)], 1u);
+      atomicAdd(&hist[key >> kDigitBits], 1u);
     }
   }
   __syncthreads();
@@ -1543,48 +1600,29 @@ __device__ __forceinline__ void digit_bases(const uint32_t* __restrict__ totals,
   __syncthreads();
 }
 
-// First pass: by the low digit.  Elements of one digit may land in any order (LDS cursors); the second pass orders
-// them by the high digit anyway and two particles with the same 20-bit key are interchangeable for locality.
-__global__ __launch_bounds__(kWide) void k_sort_scatter_low(const uint32_t* __restrict__ keys, uint64_t n,
-                                                             const uint32_t* __restrict__ table, uint32_t nblocks,
-                                                             const uint32_t* __restrict__ totals, unsigned long long* __restrict__ out) {
-  __shared__ uint32_t cursor[kSortDigits], base_of[kSortDigits], wave_sums[kWide / 64];
-  digit_bases<kWide>(totals, base_of, wave_sums);
-  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) cursor[d] = base_of[d] + table[static_cast<size_t>(d) * nblocks + blockIdx.x];
-  __syncthreads();
-  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+// The lanes of a wave that hold the same digit find each other with ten ballots: -> the mask of those lanes (for an invalid
+// lane: the mask of the invalid ones, which nobody uses).
+__device__ __forceinline__ unsigned long long same_digit_lanes(uint32_t digit, bool valid) {
+  unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
+  same = valid ? same : ~same;
 #pragma unroll
-  for (int k = 0; k < kChunk / kWide; ++k) {
-    const uint64_t i = base + k * kWide + threadIdx.x;
-    if (i < n) {
-      const uint32_t key = keys[i];
-      const uint32_t dest = atomicAdd(&cursor[key & (kSortDigits - 1)], 1u);
-      out[dest] = (static_cast<unsigned long long>(key >> kDigitBits) << 32) | static_cast<uint32_t>(i);
-    }
+  for (uint32_t bit = 0; bit < kDigitBits; ++bit) {
+    const bool set = (digit >> bit) & 1u;
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(set);
+    same &= set ? b : ~b;
   }
+  return same;
 }
-__global__ __launch_bounds__(kWide) void k_sort_hist_high(const unsigned long long* __restrict__ in, uint64_t n,
-                                                           uint32_t* __restrict__ table, uint32_t nblocks) {
-  __shared__ uint32_t hist[kSortDigits];
-  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) hist[d] = 0;
-  __syncthreads();
-  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
-#pragma unroll
-  for (int k = 0; k < kChunk / kWide; ++k) {
-    const uint64_t e = base + k * kWide + threadIdx.x;
-    if (e < n) atomicAdd(&hist[static_cast<uint32_t>(in[e] >> 32) & (kSortDigits - 1)], 1u);
-  }
-  __syncthreads();
-  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
-}
-// Second pass: by the high digit, stable.  Every wave owns a contiguous quarter of the block and walks it 64 elements at a
-// time: the lanes holding the same digit find each other with ten ballots (rank inside the group = lanes below with
-// the same digit), the wave's running count per digit lives in LDS; the four waves' counts are then chained in wave order
-// behind the block's offset of that digit.  No cross-wave step until every wave has ranked its quarter.
+
+// First pass: by the HIGH digit, stable, straight from the keys.  Every wave owns a contiguous eighth of the block and walks
+// it 64 elements at a time: rank inside the group of equal digits = lanes below with the same digit, the wave's running count
+// per digit lives in LDS; the waves' counts are then chained in wave order behind the block's offset of that digit.  No
+// cross-wave step until every wave has ranked its part.  Out: (low digit << 32 | particle) at the element's place in its
+// bucket - the buckets hold their particles in index order.
 constexpr int kStable = 512;  // 8 waves x 256 elements: 48 KB of LDS counters per workgroup
-__global__ __launch_bounds__(kStable) void k_sort_scatter_high(const unsigned long long* __restrict__ in, uint64_t n,
+__global__ __launch_bounds__(kStable) void k_sort_scatter_high(const uint32_t* __restrict__ keys, uint64_t n,
                                                               const uint32_t* __restrict__ table, uint32_t nblocks,
-                                                              const uint32_t* __restrict__ totals, uint32_t* __restrict__ perm) {
+                                                              const uint32_t* __restrict__ totals, unsigned long long* __restrict__ out) {
   constexpr int kWaves = kStable / 64, kRounds = kChunk / kStable;
   __shared__ uint16_t wave_count[kWaves][kSortDigits];
   __shared__ uint32_t wave_base[kWaves][kSortDigits];
@@ -1595,27 +1633,20 @@ __global__ __launch_bounds__(kStable) void k_sort_scatter_high(const unsigned lo
   __syncthreads();
   volatile uint16_t* mine = wave_count[wave];
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + static_cast<uint64_t>(wave) * (kChunk / kWaves);
-  uint32_t index[kRounds], digit[kRounds], rank[kRounds];
+  uint32_t key[kRounds], rank[kRounds];
 #pragma unroll
   for (int k = 0; k < kRounds; ++k) {
     const uint64_t e = base + static_cast<uint64_t>(k) * 64 + lane;
     const bool valid = e < n;
-    const unsigned long long v = valid ? in[e] : 0ull;
-    index[k] = static_cast<uint32_t>(v);
-    digit[k] = static_cast<uint32_t>(v >> 32) & (kSortDigits - 1);
-    unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
-#pragma unroll
-    for (uint32_t bit = 0; bit < kDigitBits; ++bit) {
-      const bool set = (digit[k] >> bit) & 1u;
-      const unsigned long long b = __builtin_amdgcn_ballot_w64(set);
-      same &= set ? b : ~b;
-    }
+    key[k] = valid ? keys[e] : 0u;
+    const uint32_t digit = key[k] >> kDigitBits;
+    const unsigned long long same = same_digit_lanes(digit, valid);
     const uint32_t below = static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
     const uint32_t count = static_cast<uint32_t>(__popcll(same));
-    const uint32_t before = valid ? mine[digit[k]] : 0u;
+    const uint32_t before = valid ? mine[digit] : 0u;
     rank[k] = before + below;
     __builtin_amdgcn_wave_barrier();
-    if (valid && below == 0) mine[digit[k]] = static_cast<uint16_t>(before + count);
+    if (valid && below == 0) mine[digit] = static_cast<uint16_t>(before + count);
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
@@ -1631,7 +1662,104 @@ __global__ __launch_bounds__(kStable) void k_sort_scatter_high(const unsigned lo
 #pragma unroll
   for (int k = 0; k < kRounds; ++k) {
     const uint64_t e = base + static_cast<uint64_t>(k) * 64 + lane;
-    if (e < n) perm[wave_base[wave][digit[k]] + rank[k]] = index[k];
+    if (e < n)
+      out[wave_base[wave][key[k] >> kDigitBits] + rank[k]] =
+          (static_cast<unsigned long long>(key[k] & (kSortDigits - 1)) << 32) | static_cast<uint32_t>(e);
+  }
+}
+
+// Second pass: one workgroup per bucket (= high digit) sorts the bucket's particles by the low digit, stable: the order is the
+// sort by (key, particle index), the same in every run.  Two walks over the bucket, each wave over a contiguous eighth of it:
+// the first counts the digits per wave (ballots, as above), a scan turns the counts into every wave's first destination per
+// digit, the second walk ranks again and writes.  Buckets of any size (a degenerate set is one bucket); an average one holds a
+// thousand particles.
+__global__ __launch_bounds__(kStable) void k_sort_buckets(const unsigned long long* __restrict__ in, const uint32_t* __restrict__ totals,
+                                                         uint32_t* __restrict__ perm) {
+  constexpr int kWaves = kStable / 64;
+  __shared__ uint32_t run[kWaves][kSortDigits];
+  __shared__ uint32_t base_of[kSortDigits], wave_sums[kWaves];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  digit_bases<kStable>(totals, base_of, wave_sums);
+  const uint32_t begin = base_of[blockIdx.x], size = totals[blockIdx.x];
+  if (size == 0) return;  // (uniform)
+  for (uint32_t d = threadIdx.x; d < kWaves * kSortDigits; d += kStable) (&run[0][0])[d] = 0;
+  __syncthreads();
+  const uint32_t per_wave = ((size + kWaves - 1) / kWaves + 63u) & ~63u;
+  const uint32_t first = min(wave * per_wave, size), last = min(first + per_wave, size);
+  volatile uint32_t* mine = run[wave];
+  // (four rounds' loads in flight at a time: a round by itself would wait out a memory latency for 64 elements)
+  for (uint32_t at0 = first; at0 < last; at0 += 256) {
+    uint32_t digit4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t at = at0 + 64u * r;
+      digit4[r] = at + lane < last ? static_cast<uint32_t>(in[begin + at + lane] >> 32) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t at = at0 + 64u * r;
+      if (at >= last) break;  // (uniform)
+      const bool valid = at + lane < last;
+      const unsigned long long same = same_digit_lanes(digit4[r], valid);
+      if (valid && (same & ((1ull << lane) - 1ull)) == 0) mine[digit4[r]] = mine[digit4[r]] + static_cast<uint32_t>(__popcll(same));
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  // counts -> first destinations: digits in order, inside a digit the waves in order
+  {
+    constexpr int kPer = kSortDigits / kStable;
+    uint32_t total[kPer], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      total[k] = 0;
+      for (int q = 0; q < kWaves; ++q) total[k] += run[q][threadIdx.x * kPer + k];
+      sum += total[k];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o);
+      if (lane >= static_cast<uint32_t>(o)) incl += up;
+    }
+    __syncthreads();  // (wave_sums was read by digit_bases)
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t prefix = begin + incl - sum;
+    for (uint32_t q = 0; q < wave; ++q) prefix += wave_sums[q];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      uint32_t at = prefix;
+      for (int q = 0; q < kWaves; ++q) {
+        const uint32_t c = run[q][threadIdx.x * kPer + k];
+        run[q][threadIdx.x * kPer + k] = at;
+        at += c;
+      }
+      prefix += total[k];
+    }
+  }
+  __syncthreads();
+  for (uint32_t at0 = first; at0 < last; at0 += 256) {
+    unsigned long long v4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t at = at0 + 64u * r;
+      v4[r] = at + lane < last ? in[begin + at + lane] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t at = at0 + 64u * r;
+      if (at >= last) break;  // (uniform)
+      const bool valid = at + lane < last;
+      const uint32_t digit = static_cast<uint32_t>(v4[r] >> 32);
+      const unsigned long long same = same_digit_lanes(digit, valid);
+      const uint32_t below = static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
+      const uint32_t to = valid ? mine[digit] : 0u;
+      if (valid) perm[to + below] = static_cast<uint32_t>(v4[r]);
+      __builtin_amdgcn_wave_barrier();
+      if (valid && below == 0) mine[digit] = to + static_cast<uint32_t>(__popcll(same));
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
@@ -3615,16 +3743,15 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
   }
   const dim3 rows(kSortDigits / (kBlock / 64));
   hipLaunchKernelGGL(k_row_scan, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
-  hipLaunchKernelGGL(k_sort_scatter_low, dim3(nblocks), dim3(kWide), 0, st, sort->keys, n, sort->table, nblocks, sort->totals, sort->keyidx);
-  hipLaunchKernelGGL(k_sort_hist_high, dim3(nblocks), dim3(kWide), 0, st, sort->keyidx, n, sort->table, nblocks);
-  hipLaunchKernelGGL(k_row_scan, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
-  hipLaunchKernelGGL(k_sort_scatter_high, dim3(nblocks), dim3(kStable), 0, st, sort->keyidx, n, sort->table, nblocks, sort->totals,
-                     sort->perm);
+  hipLaunchKernelGGL(k_sort_scatter_high, dim3(nblocks), dim3(kStable), 0, st, sort->keys, n, sort->table, nblocks, sort->totals,
+                     sort->keyidx);
+  hipLaunchKernelGGL(k_sort_buckets, dim3(kSortDigits), dim3(kStable), 0, st, sort->keyidx, sort->totals, sort->perm);
 }
 
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
-                        bool dispersed, bool* far_tiles_used) {
+                        bool dispersed, bool* far_tiles_used, uint32_t* weight_sums_written) {
+  if (weight_sums_written) *weight_sums_written = 0;
   if (far_tiles_used) *far_tiles_used = false;
   if (n == 0) return;
   const bool idx32 = static_cast<uint64_t>(f.W) * f.H < (1ull << 31);
@@ -3650,16 +3777,18 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
       // fallback handles everything else inside the kernel); tuning.lf_fast = 0 forces the separately rounded arithmetic.
       const bool fast = tuning.lf_fast != 0 && scan_is_short && f.W < 16384 && f.H < 16384;
       const uint32_t patch_base = (static_cast<uint32_t>(pal_lds) + 15u) & ~15u;
-      const size_t patch_lds = patch_base + kPatchLds;
+      const size_t patch_lds = patch_base + patch_lds_bytes(tuning.lf_producer == 0);
       if (fast && use_patches && patch_lds <= 65536) {
+        const uint32_t per_group = tuning.lf_producer == 0 ? kPatchParticlesAll : kPatchParticles;
+        const unsigned groups_x = static_cast<unsigned>((n + per_group - 1) / per_group);
+        if (segments > 1) patch_stats.weight_sums = nullptr;  // the segments' sums are combined by k_lf_combine
         if (tuning.lf_producer == 0)
-          hipLaunchKernelGGL(k_reweight_lf_patch<true>, dim3(static_cast<unsigned>((n + kPatchParticlesAll - 1) / kPatchParticlesAll), segments),
-                             dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial, per_segment, patch_base,
-                             patch_stats);
+          hipLaunchKernelGGL(k_reweight_lf_patch<true>, dim3(groups_x, segments), dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B,
+                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats);
         else
-          hipLaunchKernelGGL(k_reweight_lf_patch<false>, dim3(static_cast<unsigned>((n + kPatchParticles - 1) / kPatchParticles), segments),
-                             dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B, sort->perm, p.pose, partial, per_segment, patch_base,
-                             patch_stats);
+          hipLaunchKernelGGL(k_reweight_lf_patch<false>, dim3(groups_x, segments), dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B,
+                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats);
+        if (weight_sums_written && patch_stats.weight_sums) *weight_sums_written = groups_x;
       }
       else if (fast && dispersed && tuning.lf_far_tiles != 0 && f.far_bits != nullptr && patch_base + f.far_bytes <= 65536) {
         const dim3 fgrid((pgrid.x + 7u) & ~7u, segments);
@@ -3806,12 +3935,14 @@ void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_fac
 // finalize == false: the totals after (and the recovery estimator) are left to the kernel that follows — launch_cdf with its
 // finalize arguments, or launch_norm_finalize.
 void launch_sum_and_normalize(hipStream_t st, double* w, uint64_t n, double* d_partials, double* d_chunk_sum, double* d_chunk_sumsq,
-                              double* d_sums, double* host_mirror, bool finalize) {
+                              double* d_sums, double* host_mirror, bool finalize, const double* known_partials, uint32_t known_count) {
   const uint32_t chunks = num_chunks(n);
   if (chunks) {
-    hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_partials);
+    // known_partials: sums whose total is the factor already exist (the LF kernel's workgroup sums): no pass to add the weights up
+    if (!known_partials) hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_partials);
     hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, static_cast<const double*>(nullptr), d_chunk_sum,
-                       d_chunk_sumsq, d_partials, chunks, d_sums, host_mirror);
+                       d_chunk_sumsq, known_partials ? known_partials : d_partials, known_partials ? known_count : chunks, d_sums,
+                       host_mirror);
   } else {
     hipLaunchKernelGGL(k_final_rows, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_sums, host_mirror);
   }

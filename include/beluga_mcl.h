@@ -391,6 +391,9 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                   XCD's L2 serves the neighbourhood of one block of the map at a time - and heading-major otherwise; 0 / 1 force
  *   lf_small_particles (65536)  likelihood-field sets below this size: a wave per 1..16 particles, lanes over the beams, no
  *                   ordering pass (the measured crossover to the ordered kernels)
+ *   lf_weight_sums (1)  the whole cycle's normalisation factor is added up from the likelihood-field kernel's workgroup sums of the
+ *                   new weights (fixed order: the spatial order is the sort by (key, index), the same in every run); 0 = a pass of
+ *                   its own over the weights (k_chunk_sum)
  *   device_policy (1)  recovery estimator on the device when the cycle takes no host-side decision
  *   sort_min_particles (16384)  below this many particles the spatial ordering is skipped (likelihood-field models)
  *   beam_sort_min_particles (16384)  beam model: the ordered kernel from this size on; below it a wave per particle over the
@@ -398,6 +401,9 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *   key_curve (1)   heading-major ordering key: 1 = along the Hilbert curve through the (heading, y, x) bins - any run of the
  *                   order is a compact, connected set of bins -, 0 = Morton order (round 2: a run that crosses a high-level boundary
  *                   of the Z curve is two pieces far apart, and its workgroup fits no LDS patch)
+ *   key_warp (1)    heading-major ordering key over bins of equal MASS of a normal set (the key frame's +-4 sigma mapped through the
+ *                   normal distribution function) instead of equal width: the ordering's 1024 first-pass buckets then hold about the
+ *                   same number of particles; 0 = equal width (round 2)
  *   key_bits_xy (0) bits of the x and of the y bins of that key (the heading gets the other 20 - 2 b): 0 = chosen every cycle from
  *                   the cloud's spread and the scan's reach (4 .. 6), 4 / 5 / 6 = forced (round 2: 6)
  *   lf_producer (1) LDS-patch kernel: 1 = seven waves of particles and a producer wave per workgroup, 0 = eight waves of particles,
