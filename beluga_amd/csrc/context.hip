@@ -1346,8 +1346,9 @@ void shard_bounds(uint64_t n_total, uint32_t world, uint32_t rank, uint64_t* fir
 // The ancestor exchange for the output slots [first_slot, first_slot + m) of views::sample | random_intersperse: every
 // slot's point of the global CDF goes to the shard that owns it, which answers with the state.  Leaves the targets in
 // d_targets, the replies (request order) in d_replies_in and the slot of every request in d_route_order.
+// d_plan (optional): {total, random state probability} on the device (launch_shard_plan) instead of the two values.
 mcl_status sharded_draw(mcl_ctx* ctx, double random_state_probability, double total, const double* d_intervals, uint64_t first_slot,
-                        uint64_t m) {
+                        uint64_t m, const double* d_plan = nullptr) {
   const uint32_t world = ctx->comm_world, rank = ctx->comm_rank;
   long long* d_counts = ctx->d_comm_i64.ptr;   // [world]
   long long* d_all_counts = d_counts + world;  // [world][world]
@@ -1355,7 +1356,9 @@ mcl_status sharded_draw(mcl_ctx* ctx, double random_state_probability, double to
   MCL_HIP(ctx, ctx->d_send_targets.ensure(std::max<uint64_t>(m, 1)));
   MCL_HIP(ctx, ctx->d_route_order.ensure(std::max<uint64_t>(m, 1)));
   MCL_HIP(ctx, ctx->d_replies_in.ensure(std::max<uint64_t>(4 * m, 4)));
-  if (const mcl_status s = mcl_resample_targets(ctx, ctx->step, random_state_probability, total, first_slot, m, ctx->d_targets.ptr)) return s;
+  launch_resample_targets(ctx->stream, ctx->cfg.seed, ctx->step, random_state_probability, total, first_slot, m, ctx->have_map ? ctx->n_free : 0,
+                          ctx->d_targets.ptr, d_plan);
+  MCL_HIP(ctx, hipGetLastError());
   if (const mcl_status s = mcl_route_targets(ctx, ctx->d_targets.ptr, m, d_intervals, d_intervals + world, world, rank, ctx->d_send_targets.ptr,
                                              ctx->d_route_order.ptr, reinterpret_cast<int64_t*>(d_counts))) return s;
   if (const mcl_status s = comm_gather(ctx, d_counts, d_all_counts, world * sizeof(long long))) return s;  // counts[r][q]: r asks q
@@ -1536,6 +1539,54 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
   }
   MCL_HIP(ctx, hipGetLastError());
   if (const mcl_status s = comm_gather(ctx, d + 1, d_gather_stats, 3 * sizeof(double))) return s;
+  // A fixed-size cycle without selective resampling takes no decision that depends on the gathered numbers: the CDF intervals,
+  // the totals and the recovery estimator are derived on the device by every rank (launch_shard_plan), the draw reads them
+  // there, and the host reads them back with the estimate.  The cycle then has ONE host round trip before its end: the request
+  // counts of the ancestor exchange (a collective's send / receive counts are host values).
+  if (!adaptive && !ap.selective_resampling && ctx->tuning.device_policy != 0) {
+    constexpr int kPolicySlot = 20;  // d_scalars[20..23) = {slow, fast, p}, as in the single-context cycle
+    const RecoveryPolicy policy{ap.alpha_slow, ap.alpha_fast, fires ? 1 : 0, ctx->d_scalars.ptr + kPolicySlot, ctx->hd_scalars + kPolicySlot};
+    double* d_plan = d + 14;  // {total, p}
+    launch_shard_plan(ctx->stream, d_gather_stats, world, n_total, ctx->d_scalars.ptr + 1, ctx->hd_scalars + 1, policy, d_intervals, d_plan);
+    launch_sum_rows(ctx->stream, d + 4, 1, 1, ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0);  // the global weight sum, for the info
+    MCL_HIP(ctx, hipGetLastError());
+    if (fires) {
+      stage_begin(ctx, MCL_STAGE_RESAMPLE);
+      const uint64_t m = ctx->n, first_slot = ctx->cfg.shard_offset;
+      if (const mcl_status s = sharded_draw(ctx, 0.0, 0.0, d_intervals, first_slot, m, d_plan)) return s;
+      if (const mcl_status s = mcl_commit_routed(ctx, ctx->step, first_slot, m, ctx->d_replies_in.ptr, ctx->d_route_order.ptr, ctx->d_targets.ptr)) return s;
+      stage_end(ctx, MCL_STAGE_RESAMPLE);
+    }
+    ctx->force_update = false;  // :199
+    stage_begin(ctx, MCL_STAGE_ESTIMATE);
+    mcl_estimate est{};
+    if (ctx->estimate_kind == 1) {
+      if (const mcl_status s = do_cluster_estimate(ctx, ctx->cluster_params, &est)) return s;
+      stage_end(ctx, MCL_STAGE_ESTIMATE);
+      MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+      double sums[12];
+      if (const mcl_status s = sharded_estimate_sums(ctx, nullptr, 0, sums)) return s;
+      stage_end(ctx, MCL_STAGE_ESTIMATE);
+      if (const mcl_status s = mcl_estimate_from_sums(sums, &est)) return s;
+    }
+    stage_collect(ctx);
+    if (std::isfinite(est.pose[2]) && std::isfinite(est.pose[3])) {
+      ctx->pivot[0] = est.pose[2];
+      ctx->pivot[1] = est.pose[3];
+    }
+    remember_cloud_estimate(ctx, est);
+    if (estimate) *estimate = est;
+    if (info) {
+      info->updated = 1;
+      info->resampled = fires ? 1 : 0;
+      info->num_particles = n_total;
+      info->weight_sum = ctx->h_scalars[0];
+      info->effective_sample_size = -1.0;
+      info->random_state_probability = ctx->h_scalars[kPolicySlot + 2];
+    }
+    return MCL_OK;
+  }
   MCL_HIP(ctx, hipMemcpyAsync(h, d + 4, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MCL_HIP(ctx, hipMemcpyAsync(h + 1, d_gather_stats, 3 * world * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -362,7 +362,12 @@ void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cd
 // Sharded variant: targets given, no RNG (mcl_gather_by_cdf).
 // Sharded resampling helpers (mcl_resample_targets / mcl_commit_resampled).
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
-                             uint64_t count, uint64_t n_free, double* d_targets);
+                             uint64_t count, uint64_t n_free, double* d_targets, const double* d_plan = nullptr);
+// Sharded fixed-size cycle: CDF intervals, global total, totals of the normalised weights and the recovery estimator from the
+// gathered shard statistics, on the device (d_plan = {total, random state probability}; d_intervals = ends[world], offsets[world]).
+struct RecoveryPolicy;
+void launch_shard_plan(hipStream_t st, const double* d_stats, uint32_t world, uint64_t n_total, double* d_sums, double* sums_mirror,
+                       const RecoveryPolicy& policy, double* d_intervals, double* d_plan);
 // Counting sort of resample targets by owning shard; d_block_hist needs world * num_chunks(count) words.
 void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t count, const double* d_ends, const double* d_offsets,
                           uint32_t world, uint32_t self_rank, uint8_t* d_dest, uint32_t* d_block_hist, uint32_t* d_chunk_sum,

@@ -3038,10 +3038,16 @@ __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(8, 8
 
 // -- sharded resampling (one context per GPU; the exchange between them is done by the caller) -----------
 // targets[t] = u_j * total for output slot j = first_slot + t, NaN where the slot takes an injected random state.
+// d_plan (optional): {total of the global CDF, random state probability} in device memory (k_shard_plan) instead of p / total
 __global__ __launch_bounds__(kBlock) void k_resample_targets(uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
-                                                             uint64_t count, uint64_t n_free, double* __restrict__ targets) {
+                                                             uint64_t count, uint64_t n_free, double* __restrict__ targets,
+                                                             const double* __restrict__ d_plan) {
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (t >= count) return;
+  if (d_plan) {
+    total = d_plan[0];
+    p = d_plan[1];
+  }
   const uint64_t j = first_slot + t;
   const RngWords r = rng_draw(seed, step, kRngResample, j);
   targets[t] = intersperse_here(r, j, p, n_free) ? __builtin_nan("") : rng_uniform53(r.w[0], r.w[1]) * total;
@@ -4037,10 +4043,51 @@ void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cd
 }
 
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
-                             uint64_t count, uint64_t n_free, double* d_targets) {
+                             uint64_t count, uint64_t n_free, double* d_targets, const double* d_plan) {
   if (count == 0) return;
   hipLaunchKernelGGL(k_resample_targets, dim3(blocks_for(count)), dim3(kBlock), 0, st, seed, step, p, total, first_slot, count, n_free,
-                     d_targets);
+                     d_targets, d_plan);
+}
+
+// What every rank derives from the gathered shard statistics [world][3] = {shard CDF total, sum and sum of squares of the
+// shard's normalised weights}, in rank order, without a host round trip (fixed-size cycles): the intervals of the global CDF
+// (ends[r], offsets[r]), d_plan = {global total, random state probability}, the totals of the normalised weights, and one step
+// of the recovery estimator on their average (thrun_recovery_probability_estimator.hpp:69-89; reset when the cycle resamples
+// with p > 0: amcl_core.hpp:184-186).  Same additions in the same order on every rank.
+__global__ void k_shard_plan(const double* __restrict__ stats, uint32_t world, NormFinalize fin, double* __restrict__ intervals,
+                             double* __restrict__ d_plan) {
+  if (threadIdx.x != 0) return;
+  double run = 0.0, norm_sum = 0.0, norm_sumsq = 0.0;
+  for (uint32_t r = 0; r < world; ++r) {
+    intervals[world + r] = run;
+    run += stats[3 * r];
+    intervals[r] = run;
+    norm_sum += stats[3 * r + 1];
+    norm_sumsq += stats[3 * r + 2];
+  }
+  fin.d_sums[0] = norm_sum;
+  fin.d_sums[1] = norm_sumsq;
+  if (fin.sums_mirror) {
+    fin.sums_mirror[0] = norm_sum;
+    fin.sums_mirror[1] = norm_sumsq;
+  }
+  recovery_policy_step(norm_sum, fin);
+  d_plan[0] = run;
+  d_plan[1] = fin.d_policy[2];
+}
+void launch_shard_plan(hipStream_t st, const double* d_stats, uint32_t world, uint64_t n_total, double* d_sums, double* sums_mirror,
+                       const RecoveryPolicy& policy, double* d_intervals, double* d_plan) {
+  NormFinalize fin{};
+  fin.d_sums = d_sums;
+  fin.sums_mirror = sums_mirror;
+  fin.n = n_total;
+  fin.policy = 1;
+  fin.alpha_slow = policy.alpha_slow;
+  fin.alpha_fast = policy.alpha_fast;
+  fin.resampling = policy.resampling;
+  fin.d_policy = policy.d_policy;
+  fin.policy_mirror = policy.host_mirror;
+  hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(64), 0, st, d_stats, world, fin, d_intervals, d_plan);
 }
 
 void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t count, const double* d_ends, const double* d_offsets,

@@ -191,3 +191,27 @@ def test_library_rccl_transport_world_one():
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     plain.close()
     sharded.close()
+
+
+def test_bench_multi_rank_flow_dry_run_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), here with both ranks on the
+    GPU at hand and gloo between them (BELUGA_BENCH_BACKEND=gloo: the timings mean nothing): the multi-rank flow - rendezvous,
+    sharded filter, timed region with barriers, max over ranks, ONE JSON line from rank 0 - must not fall over unseen on the
+    first 8-GPU node it meets.  The line's contract fields are checked, and the filter still localises."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BELUGA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--particles", "20000", "--windows", "1",
+           "--stage-steps", "2", "--no-cpu-baseline", "--no-other-configs"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 2 and line["unit"] == "cycles/s" and line["scaling"] == "weak"
+    assert line["config"]["particles_total"] == 40000 and line["config"]["particles_per_gpu"] == 20000
+    assert line["value"] == pytest.approx(4 / line["timed_region_s"], rel=1e-9)  # cycles/s of the logical filter, not x ranks
+    assert line["verified"]["estimate_vs_true_pose"]["ok"], line["verified"]
