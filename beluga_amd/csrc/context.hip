@@ -208,6 +208,8 @@ struct mcl_ctx {
   // scan: staged in mapped pinned host memory and pulled into d_points by a kernel of the cycle (no copy-engine hand-off)
   DeviceBuffer<double> d_points;
   DeviceBuffer<double> d_beam_points;  // beam model: per-beam terms (kBeamPointDoubles per beam)
+  DeviceBuffer<double> d_beam_table;   // beam model: 4 doubles per squared cell distance of a hit (launch_beam_table), built by mcl_set_map
+  uint32_t beam_table_count{0};
   double* h_points{nullptr};   // pinned, mapped
   double* hd_points{nullptr};  // the same memory as the device sees it
   double scan_extent{0.0};     // max |x| + |y| of the uploaded scan points (NaN if any is NaN)
@@ -850,7 +852,8 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     launch_reweight_beam(ctx->stream, ctx->cur(), ctx->n, ctx->grid_view(),
                          BeamModel{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range},
                          ctx->d_points.ptr, static_cast<uint32_t>(B), ctx->d_kld_scalars.ptr + 1, ordered ? &sort : nullptr,
-                         ctx->d_nonfree_bits.ptr, ctx->d_beam_points.ptr);
+                         ctx->d_nonfree_bits.ptr, ctx->d_beam_points.ptr, ctx->tuning.beam_table ? ctx->d_beam_table.ptr : nullptr,
+                         ctx->tuning.beam_table ? ctx->beam_table_count : 0u);
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
   }
   stage_end(ctx, MCL_STAGE_REWEIGHT);
@@ -1824,7 +1827,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_weight_sums"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_weight_sums", "beam_table"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -1862,6 +1865,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_free.release();
   ctx->d_points.release();
   ctx->d_beam_points.release();
+  ctx->d_beam_table.release();
   ctx->d_chunk.release();
   ctx->d_scalars.release();
   ctx->d_cdf.release();
@@ -1939,6 +1943,16 @@ mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32
     MCL_HIP(ctx, ctx->d_nonfree_bits.ensure(nonfree_words(width, height)));
     launch_pack_nonfree(ctx->stream, ctx->d_cells.ptr, width, height, ctx->traits.free_value, ctx->d_nonfree_bits.ptr);
     MCL_HIP(ctx, hipGetLastError());
+    {
+      const mcl_beam_params& b = ctx->cfg.beam;
+      ctx->beam_table_count = beam_table_entries(b.beam_max_range, resolution);
+      if (ctx->beam_table_count) {
+        MCL_HIP(ctx, ctx->d_beam_table.ensure(4 * static_cast<size_t>(ctx->beam_table_count)));
+        launch_beam_table(ctx->stream, BeamModel{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range}, resolution,
+                          ctx->beam_table_count, ctx->d_beam_table.ptr);
+        MCL_HIP(ctx, hipGetLastError());
+      }
+    }
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   if (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM) {
@@ -2701,6 +2715,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "key_bits_xy") t.key_bits_xy = (value >= 4 && value <= 6) ? static_cast<int>(value) : 0;
   else if (key == "lf_margin") t.lf_margin = value ? 1 : 0;
   else if (key == "lf_producer") t.lf_producer = value ? 1 : 0;
+  else if (key == "beam_table") t.beam_table = value ? 1 : 0;
   else if (key == "lf_weight_sums") t.lf_weight_sums = value ? 1 : 0;
   else if (key == "lf_split") t.lf_split = static_cast<int>(value & 3);  // 1: side by side only, 2: stacked only, 3: both
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));

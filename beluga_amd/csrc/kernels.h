@@ -146,6 +146,8 @@ struct Tuning {
   int lf_producer = 1;              // LDS-patch kernel: 1 = seven waves of particles + a producer wave (the form that knows half patches and
                                     // patches clamped at the table's border), 0 = every wave holds particles and fetches its share of the
                                     // patches straight into LDS (buffer_load ... lds); measured 5 % slower on the bench
+  int beam_table = 1;               // beam model, ordered kernel: the terms that depend on the expected range alone from a table over the hit's
+                                    // squared cell distance (built at mcl_set_map); 0 = evaluated per beam
   int lf_weight_sums = 1;           // fixed-size cycle: the normalisation factor is added up from the LF patch kernel's workgroup sums of the
                                     // new weights (no k_chunk_sum pass); 0 = from chunk sums of the weights
   int lf_split = 3;                 // LDS-patch planner: a group of 8 beams that fits no whole 64 x 64 patch (a range discontinuity inside
@@ -272,8 +274,15 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_order_particles first).
 // d_beam_points: scratch of kBeamPointDoubles * B doubles (per-beam terms shared by all particles; ordered variant only).
 constexpr uint32_t kBeamPointDoubles = 5;
+// d_beam_table (optional, ordered variant): launch_beam_table's output, beam_table_count entries of 4 doubles
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
-                          unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points);
+                          unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points,
+                          const double* d_beam_table = nullptr, uint32_t beam_table_count = 0);
+// The beam model's terms that depend on the expected range alone, tabulated over the squared cell distance of the hit (kernels.hip
+// BeamTable): entries = beam_table_entries(...) (0: the range spans too many cells for a table), 4 doubles each.
+constexpr double kBeamTableMaxCells = 2046.0;
+uint32_t beam_table_entries(double beam_max_range, double resolution);
+void launch_beam_table(hipStream_t st, BeamModel m, double resolution, uint32_t entries, double* table);
 // The occupancy the ray walks read, in one buffer of nonfree_words(W, H) words: one bit per cell (1 = not free), ceil(W/32)
 // words per row, followed by two coarse bitmaps — one bit per 8 x 8-cell block, "any cell not free" — row-major and column-major —
 // and the block distance map (one byte per block).

@@ -1949,8 +1949,20 @@ __device__ __forceinline__ bool walk_until(RayWalk& r, int upto, Fetch&& occupie
   return false;
 }
 
-__device__ __forceinline__ double walk_result(const GridView& g, const RayWalk& r, bool hit, double max_range,
-                                              unsigned long long& steps) {
+// kCell: instead of the range, the hit cell (x << 32 | y, both below 2^31) or kNoHitCell - the ordered beam kernel looks the
+// range's terms up in a table over the squared cell distance (BeamTable).
+constexpr long long kNoHitCell = -1;
+__device__ __forceinline__ double walk_range(const GridView& g, const RayWalk& r, bool hit, double max_range, unsigned long long& steps);
+template <bool kCell = false>
+__device__ __forceinline__ auto walk_result(const GridView& g, const RayWalk& r, bool hit, double max_range, unsigned long long& steps) {
+  if constexpr (kCell) {
+    steps += static_cast<unsigned long long>((hit ? r.k : r.last) + 1);
+    return hit ? ((static_cast<long long>(r.x) << 32) | static_cast<long long>(static_cast<uint32_t>(r.y))) : kNoHitCell;
+  } else {
+    return walk_range(g, r, hit, max_range, steps);
+  }
+}
+__device__ __forceinline__ double walk_range(const GridView& g, const RayWalk& r, bool hit, double max_range, unsigned long long& steps) {
   if (!hit) {
     steps += static_cast<unsigned long long>(r.last + 1);
     return max_range;  // std::nullopt -> value_or(max_range)
@@ -2297,8 +2309,9 @@ __device__ __forceinline__ void walk_blocks_any(const BlockMaps& maps, const Ray
   }
 }
 
-__device__ __forceinline__ double cast_ray_window(const GridView& g, const BitWindow& w, int sx, int sy, int fx, int fy,
-                                                  double max_range, unsigned long long& steps) {
+template <bool kCell = false>
+__device__ __forceinline__ auto cast_ray_window(const GridView& g, const BitWindow& w, int sx, int sy, int fx, int fy,
+                                                double max_range, unsigned long long& steps) {
   RayWalk r = walk_begin<false>(g, sx, sy, fx, fy);
   // Cells inside the grid AND the window (a box): one closed-form bound.  The grid's own bound is only needed by a ray that
   // leaves the window without a hit.
@@ -2317,7 +2330,7 @@ __device__ __forceinline__ double cast_ray_window(const GridView& g, const BitWi
     walk_blocks_any(lds_maps, r, lx, ly, error, k, hit_k, upto);
     if (hit_k >= 0) {
       walk_seek(r, hit_k, 0);
-      return walk_result(g, r, true, max_range, steps);
+      return walk_result<kCell>(g, r, true, max_range, steps);
     }
   }
   // Cells beyond the window (long rays near its edge): the same walk over the whole-grid maps in global memory.
@@ -2329,15 +2342,16 @@ __device__ __forceinline__ double cast_ray_window(const GridView& g, const BitWi
     walk_blocks_any(w.grid_maps, r, gx, gy, error, k, hit_k, r.last);
     if (hit_k >= 0) {
       walk_seek(r, hit_k, 0);
-      return walk_result(g, r, true, max_range, steps);
+      return walk_result<kCell>(g, r, true, max_range, steps);
     }
   }
-  return walk_result(g, r, false, max_range, steps);
+  return walk_result<kCell>(g, r, false, max_range, steps);
 }
 
 // The cast over the whole-grid maps alone (no LDS window): small sets, one wave per particle.
-__device__ __forceinline__ double cast_ray_grid(const GridView& g, const BlockMaps& grid_maps, int sx, int sy, int fx, int fy, double max_range,
-                                                unsigned long long& steps) {
+template <bool kCell = false>
+__device__ __forceinline__ auto cast_ray_grid(const GridView& g, const BlockMaps& grid_maps, int sx, int sy, int fx, int fy, double max_range,
+                                              unsigned long long& steps) {
   RayWalk r = walk_begin(g, sx, sy, fx, fy);
   int k = 0, hit_k = -1, error = r.error;
   if (r.last >= 0) {
@@ -2345,10 +2359,10 @@ __device__ __forceinline__ double cast_ray_grid(const GridView& g, const BlockMa
     walk_blocks_any(grid_maps, r, gx, gy, error, k, hit_k, r.last);
     if (hit_k >= 0) {
       walk_seek(r, hit_k, 0);
-      return walk_result(g, r, true, max_range, steps);
+      return walk_result<kCell>(g, r, true, max_range, steps);
     }
   }
-  return walk_result(g, r, false, max_range, steps);
+  return walk_result<kCell>(g, r, false, max_range, steps);
 }
 
 // What beam_model.hpp:110-147 computes from the scan point alone (the same for every particle): the measured range, the
@@ -2379,15 +2393,70 @@ __global__ __launch_bounds__(kBlock) void k_beam_points(const double* __restrict
 // erf saturates: for |x| >= 6.5 it is +-1 to the last bit (erfc(6.5) < 4e-20), so when the expected range is more than
 // 6.5 * sqrt(2) * sigma_hit away from both 0 and max_range — nearly every beam — the normaliser eta_hit is exactly 2 / 2
 // and neither erf is evaluated (a wave takes the general path only if one of its lanes needs it).
-template <class Cast>
+// What depends on the expected range alone, tabulated over the squared cell distance r2 between the hit and the source (an
+// integer the walk produces anyway): {z = min(sqrt(r2) * resolution, max_range), z_hit * eta_hit(z) * norm_hit,
+// z_short * lambda_short * eta_short(z), -}, built on the device at mcl_set_map by the expressions of beam_term below (same
+// functions, same order of operations); the last entry is the ray that hits nothing (z = max_range).  The table's z is the
+// distance of the cell centres up to the rounding of (x + 0.5) * resolution - a relative 1e-16 - which the mixture's terms do not
+// feel (the parity bar of the beam model's weights is 1e-10).  Per beam it replaces a square root, the short-return normaliser's
+// exp and division and, near the ends of the range, two erf by one 32-byte look-up.
+struct BeamTable {
+  const double4* entries;  // nullptr: no table (max_range spans more than kBeamTableMaxCells cells)
+  uint32_t no_hit;         // index of the last entry
+};
+__device__ __forceinline__ double4 beam_table_entry(const BeamModel& m, double resolution, double norm_hit, uint32_t r2, bool no_hit) {
+  const double z_mean = no_hit ? m.beam_max_range : fmin(sqrt(static_cast<double>(r2)) * resolution, m.beam_max_range);
+  const double scale = sqrt(2.) * m.sigma_hit;
+  const double hi = (m.beam_max_range - z_mean) / scale, lo = -z_mean / scale;
+  const bool saturated = m.beam_max_range - z_mean >= 6.6 * scale && z_mean >= 6.6 * scale;  // erf is +-1 to the last bit there
+  const double eta_hit = saturated ? 1.0 : 2. / (erf(hi) - erf(lo));
+  const double eta_short = 1. / (1. - exp(-m.lambda_short * z_mean));
+  return double4{z_mean, m.z_hit * eta_hit * norm_hit, m.z_short * m.lambda_short * eta_short, 0.0};
+}
+__global__ __launch_bounds__(kBlock) void k_beam_table(BeamModel m, double resolution, uint32_t entries, double4* __restrict__ out) {
+  const uint32_t r2 = blockIdx.x * kBlock + threadIdx.x;
+  if (r2 >= entries) return;
+  const double norm_hit = 1. / (sqrt(2. * kPi) * m.sigma_hit);
+  out[r2] = beam_table_entry(m, resolution, norm_hit, r2, r2 == entries - 1);
+}
+
+// kTable: `cast` returns the hit cell (walk_result<true>) instead of the range; (sx, sy) is the source cell.
+template <bool kTable, class Cast>
 __device__ __forceinline__ double beam_term(const GridView& g, const BeamModel& m, double norm_hit, const Pose2& src, const BeamPoint& q,
-                                            Cast&& cast) {
+                                            const BeamTable& table, int sx, int sy, Cast&& cast) {
   double ex, ey;  // trace(): raycasting.hpp:78-88
   rot_apply(src.r, q.ux, q.uy, ex, ey);
   ex += src.x;
   ey += src.y;
   int fx, fy;
   cell_near(g, ex, ey, fx, fy);
+  if constexpr (kTable) {
+    const long long hit = cast(fx, fy);
+    const int hx = static_cast<int>(hit >> 32), hy = static_cast<int>(static_cast<uint32_t>(hit));
+    uint32_t at = table.no_hit;
+    if (hit != kNoHitCell) {
+      const int cx = hx - sx, cy = hy - sy;
+      const uint32_t r2 = static_cast<uint32_t>(cx * cx + cy * cy);
+      at = r2 < table.no_hit ? r2 : table.no_hit;  // (beyond the table: at least max_range away - the same entry)
+    }
+    const double4 e = table.entries[at];
+    double z_mean = e.x;
+    // The one place where the last bits of the expected range decide something: `measured < expected` below.  A measured range
+    // within 1e-9 m of the table's value takes the reference's own expression - the distance of the two cell centres
+    // (raycasting.hpp:97-107) - so that a tie falls as it does there.
+    const bool tie = hit != kNoHitCell && fabs(q.z - z_mean) < 1e-9;
+    if (__builtin_amdgcn_ballot_w64(tie) != 0 && tie) {
+      const double ax = (static_cast<double>(sx) + 0.5) * g.resolution, ay = (static_cast<double>(sy) + 0.5) * g.resolution;
+      const double bx = (static_cast<double>(hx) + 0.5) * g.resolution, by = (static_cast<double>(hy) + 0.5) * g.resolution;
+      const double dx = bx - ax, dy = by - ay;
+      z_mean = fmin(sqrt(dx * dx + dy * dy), m.beam_max_range);
+    }
+    const double d = (q.z - z_mean) / m.sigma_hit;
+    double pz = e.y * exp(-(d * d) / 2.);
+    if (q.z < z_mean) pz += e.z * q.short_e;
+    pz += q.tail;
+    return pz * pz * pz;
+  }
   const double z_mean = cast(fx, fy);
   const double scale = sqrt(2.) * m.sigma_hit;
   double eta_hit = 1.0;
@@ -2428,7 +2497,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam(Particles p, uint64_t 
   unsigned long long steps = 0;
   for (uint32_t b = lane; b < B; b += kWave) {
     const double2 pt = s_pts[b];
-    acc += beam_term(g, m, norm_hit, src, beam_point(m, pt.x, pt.y), [&](int fx, int fy) {
+    acc += beam_term<false>(g, m, norm_hit, src, beam_point(m, pt.x, pt.y), BeamTable{nullptr, 0u}, sx, sy, [&](int fx, int fy) {
       return bits.fine ? cast_ray_grid(g, grid_maps, sx, sy, fx, fy, m.beam_max_range, steps) : cast_ray(g, sx, sy, fx, fy, m.beam_max_range, steps);
     });
   }
@@ -2446,11 +2515,13 @@ __global__ __launch_bounds__(kBlock) void k_reweight_beam(Particles p, uint64_t 
 // gather lane by lane even when the lanes share a line), so the occupancy the walks read is staged ONCE per workgroup
 // into LDS as a 1024 x 1024-cell bit window (132 KB) centred on the workgroup's particles; LDS serves 32 lanes/clk.
 constexpr int kBeamBlock = 1024;
+template <bool kTable>
 __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __restrict__ w, uint64_t n, GridView g, BeamModel m,
                                                                      NonFreeBits bits, const BeamPoint* __restrict__ pts,
                                                                      uint32_t B, const uint32_t* __restrict__ perm,
                                                                      const double4* __restrict__ pose, unsigned long long* d_steps,
-                                                                     double* __restrict__ partial, uint32_t beams_per_segment) {
+                                                                     double* __restrict__ partial, uint32_t beams_per_segment,
+                                                                     BeamTable table) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* win = reinterpret_cast<uint32_t*>(smem);
   const uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * kBeamBlock;
@@ -2531,8 +2602,9 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
   const uint32_t b_end = partial ? (b_begin + beams_per_segment < B ? b_begin + beams_per_segment : B) : B;
   for (uint32_t b = b_begin; b < b_end; ++b) {
     MCL_BEAM_STAT(0);  // a beam
-    acc += beam_term(g, m, norm_hit, src, pts[b],
-                     [&](int fx, int fy) { return cast_ray_window(g, bw, sx, sy, fx, fy, m.beam_max_range, steps); });
+    acc += beam_term<kTable>(g, m, norm_hit, src, pts[b], table, sx, sy, [&](int fx, int fy) {
+      return cast_ray_window<kTable>(g, bw, sx, sy, fx, fy, m.beam_max_range, steps);
+    });
   }
   if (d_steps) {
     if (t >= n) steps = 0;
@@ -3885,12 +3957,25 @@ namespace mcl {
 // hipFuncSetAttribute is per device: contexts on several GPUs of one process each opt in (mcl_create calls this).
 void configure_device_kernels() {
   const size_t lds = kBeamLds;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_beam_sorted), hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_beam_sorted<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_beam_sorted<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(lds));
 }
 
+uint32_t beam_table_entries(double beam_max_range, double resolution) {
+  const double reach = std::ceil(beam_max_range / resolution) + 3.0;  // cells between the source and the far end of a trace, with slack
+  if (!(reach > 0.0) || reach > kBeamTableMaxCells) return 0;
+  const uint32_t r = static_cast<uint32_t>(reach);
+  return r * r + 1u;  // squared distances below reach^2, + the entry of the ray that hits nothing
+}
+void launch_beam_table(hipStream_t st, BeamModel m, double resolution, uint32_t entries, double* table) {
+  if (entries) hipLaunchKernelGGL(k_beam_table, dim3(blocks_for(entries)), dim3(kBlock), 0, st, m, resolution, entries, reinterpret_cast<double4*>(table));
+}
+
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
-                          unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points) {
+                          unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points,
+                          const double* d_beam_table, uint32_t beam_table_count) {
   if (n == 0 || B == 0) return;
   if (sorted && nonfree_bits) {
     const size_t lds = kBeamLds;
@@ -3907,9 +3992,14 @@ void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, B
     double* partial = segments > 1 ? sorted->partial : nullptr;
     BeamPoint* table = reinterpret_cast<BeamPoint*>(d_beam_points);
     hipLaunchKernelGGL(k_beam_points, dim3(blocks_for(B)), dim3(kBlock), 0, st, d_points, B, m, table);
-    hipLaunchKernelGGL(k_reweight_beam_sorted, dim3(groups, segments), dim3(kBeamBlock), lds, st, p.w, n, g, m,
-                       nonfree_layout(g.W, g.H, const_cast<uint32_t*>(nonfree_bits)), table, B, sorted->perm, p.pose, d_steps, partial,
-                       per_segment);
+    if (d_beam_table && beam_table_count)
+      hipLaunchKernelGGL(k_reweight_beam_sorted<true>, dim3(groups, segments), dim3(kBeamBlock), lds, st, p.w, n, g, m,
+                         nonfree_layout(g.W, g.H, const_cast<uint32_t*>(nonfree_bits)), table, B, sorted->perm, p.pose, d_steps, partial,
+                         per_segment, BeamTable{reinterpret_cast<const double4*>(d_beam_table), beam_table_count - 1u});
+    else
+      hipLaunchKernelGGL(k_reweight_beam_sorted<false>, dim3(groups, segments), dim3(kBeamBlock), lds, st, p.w, n, g, m,
+                         nonfree_layout(g.W, g.H, const_cast<uint32_t*>(nonfree_bits)), table, B, sorted->perm, p.pose, d_steps, partial,
+                         per_segment, BeamTable{nullptr, 0u});
     if (segments > 1) hipLaunchKernelGGL(k_lf_combine, dim3(blocks_for(n)), dim3(kBlock), 0, st, p.w, n, sorted->perm, partial, segments, 2);
     return;
   }

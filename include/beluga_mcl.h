@@ -391,6 +391,9 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                   XCD's L2 serves the neighbourhood of one block of the map at a time - and heading-major otherwise; 0 / 1 force
  *   lf_small_particles (65536)  likelihood-field sets below this size: a wave per 1..16 particles, lanes over the beams, no
  *                   ordering pass (the measured crossover to the ordered kernels)
+ *   beam_table (1)  beam model, ordered kernel: what depends on a beam's EXPECTED range alone (the range itself, the hit normaliser
+ *                   with its two erf, the short-return normaliser with its exp) comes from a table over the squared cell distance
+ *                   between the hit and the source, built on the device at mcl_set_map with the same expressions; 0 = per beam
  *   lf_weight_sums (1)  the whole cycle's normalisation factor is added up from the likelihood-field kernel's workgroup sums of the
  *                   new weights (fixed order: the spatial order is the sort by (key, index), the same in every run); 0 = a pass of
  *                   its own over the weights (k_chunk_sum)

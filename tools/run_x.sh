@@ -1,2 +1,3 @@
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_headline.py -q -x 2>&1 | tail -3
-for i in 1 2; do python bench.py --steps 20 --warmup 5 --no-other-configs --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench', round(d['value']), round(d['repeat_windows']['median']), {k: round(v,4) for k,v in d['stage_ms'].items()}, d['verified']['ok'])"; done
+python tools/exp_beam_table_debug.py 2>&1 | head -2
+timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "beam" 2>&1 | tail -3
+python tools/bench_configs.py 5 --steps 3 2>&1 | tail -2
