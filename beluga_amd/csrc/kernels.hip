@@ -117,12 +117,25 @@ __device__ __forceinline__ int unit_bin(float u, int bins) {  // u in [0, 1) ins
   const int b = static_cast<int>(u * static_cast<float>(bins));
   return min(max(b, 0), bins - 1);
 }
+// atan2 to ~1e-4 rad, monotone in the angle (a cubic in min / max of |x|, |y| - Rajan et al.'s approximation - folded back into
+// the octants): the ordering key needs the BIN of a heading, and nothing but locality depends on which side of a bin's edge a
+// particle falls.  A dozen instructions instead of libm's forty-odd.
+__device__ __forceinline__ float fast_atan2f(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
+  const float t = hi > 0.f ? lo * __builtin_amdgcn_rcpf(hi) : 0.f;
+  const float t2 = t * t;
+  float a = t * (0.99997726f + t2 * (-0.33262347f + t2 * (0.19354346f + t2 * (-0.11643287f + t2 * (0.05265332f + t2 * -0.01172120f)))));
+  a = ay > ax ? 1.57079633f - a : a;
+  a = x < 0.f ? 3.14159265f - a : a;
+  return y < 0.f ? -a : a;
+}
 __device__ __forceinline__ uint32_t order_key(const double4& q, const KeyFrame& kf) {
   const float ux = static_cast<float>(q.z - kf.cx) * kf.inv_x + 0.5f;
   const float uy = static_cast<float>(q.w - kf.cy) * kf.inv_y + 0.5f;
   const float c = static_cast<float>(q.x), s = static_cast<float>(q.y);
   const float c0 = static_cast<float>(kf.c0), s0 = static_cast<float>(kf.s0);
-  const float delta = atan2f(s * c0 - c * s0, c * c0 + s * s0);  // heading relative to the frame's, in (-pi, pi]
+  const float delta = fast_atan2f(s * c0 - c * s0, c * c0 + s * s0);  // heading relative to the frame's, in (-pi, pi]
   const float ut = (delta - kf.t_off) * kf.inv_t + 0.5f;
   if (kf.layout & 1u) {
     const uint32_t bx = static_cast<uint32_t>(unit_bin(ux, 1 << kKeyBitsXY)), by = static_cast<uint32_t>(unit_bin(uy, 1 << kKeyBitsXY));
@@ -137,7 +150,8 @@ __device__ __forceinline__ uint32_t order_key(const double4& q, const KeyFrame& 
     // normal distribution function of 8 (u - 1/2).  The 1024 buckets of the ordering's first pass (the key's high digit) then
     // hold about the same number of particles - with bins of equal width the bucket at the centre of the cloud held ten times the
     // average, and its workgroup was the second pass's critical path - and the cells are small where the particles are.
-    auto mass = [](float u) { return 0.5f + 0.5f * erff((u - 0.5f) * 5.65685425f); };  // 8 / sqrt 2
+    // (the logistic curve 1 / (1 + exp(-1.702 z)) is within 0.01 of the normal distribution function: a bin's mass is equal to 1 %)
+    auto mass = [](float u) { return __builtin_amdgcn_rcpf(1.f + __expf(-13.616f * (u - 0.5f))); };  // z = 8 (u - 1/2)
     vx = mass(ux);
     vy = mass(uy);
     vt = mass(ut);
@@ -3046,10 +3060,13 @@ __device__ __forceinline__ bool intersperse_here(const RngWords& r, uint64_t j, 
 // way out — est_partials[k][workgroup] — so that the estimate needs no pass of its own over the particles it just wrote.
 // Workgroups of 1024 outputs share an LDS copy of the upper levels of the search tree (staged doubles from level
 // first_staged on; dynamic shared memory).
+#ifndef MCL_DRAW_WAVES
+#define MCL_DRAW_WAVES 8
+#endif
 constexpr int kDrawBlock = 1024;
 constexpr uint32_t kDrawStageMax = 4608;  // doubles (36 KB): two workgroups per CU (which also takes 8 waves per SIMD: 64 registers)
 template <bool kEstimate>
-__global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
+__global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(MCL_DRAW_WAVES, MCL_DRAW_WAVES))) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
                                                               Particles dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
                                                               unsigned long long* __restrict__ hashes, double pivot_x, double pivot_y,
                                                               double* __restrict__ est_partials, uint32_t est_stride, int first_staged,

@@ -76,7 +76,7 @@ def lf_kernel_counters(kernel="k_reweight_lf_patch"):
                     parts = line.split()
                     if line.startswith("# lf_kernels_sha256") and len(parts) >= 3:
                         sha = parts[2]
-                    if len(parts) >= 4 and parts[0] == "PMC" and parts[1] == kernel:
+                    if len(parts) >= 4 and parts[0] == "PMC" and parts[1].split("<")[0] == kernel:
                         counters[parts[2]] = float(parts[3])
         except OSError:
             continue
