@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <cctype>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -226,6 +228,14 @@ struct mcl_ctx {
   DeviceBuffer<double> d_cdf;
   DeviceBuffer<double4> d_cloud;    // mcl_sample_particle_cloud staging
   DeviceBuffer<double> d_est_partials;  // [9][ceil(n / 256)] estimate sums left by the draw kernel
+  // The fixed-size cycle's completion word (Completion): ticket in d_scalars[27], word in h_scalars[31]; done_seq counts the
+  // cycles that armed it, done_armed: this cycle's last kernel carries it.
+  uint64_t done_seq{0};
+  bool done_armed{false};
+  // Host time of mcl_update on the one-synchronisation path, running totals in ns (mcl_get_counter host_ns_*): entry -> first
+  // kernel enqueued, -> last kernel enqueued, the wait for the cycle, the rest until the return; host_cycles counts them.
+  uint64_t host_ns[4]{0, 0, 0, 0};
+  uint64_t host_cycles{0};
   DeviceBuffer<double> d_cloud_w;
   DeviceBuffer<double> d_cdf_tree;  // sampled levels of the 16-ary search tree over d_cdf (CdfTree)
   DeviceBuffer<double> d_lf_wsum;   // sums of the new weights per workgroup of the LF patch kernel (PatchStats::weight_sums)
@@ -396,6 +406,31 @@ void stage_collect(mcl_ctx* ctx) {
     }
     ctx->ev_pending[s] = false;
   }
+}
+
+// The end of a cycle whose last kernel is the draw's k_final_rows.  Armed (done_armed): that kernel stores the cycle's number
+// to a word of mapped host memory behind everything the cycle mirrored there; the host watches the word - the kernel's own
+// store arrives a few microseconds before the stream's completion signal has been raised and noticed.  The stream is in order:
+// everything before that kernel is complete too, and later calls that need the stream itself idle still synchronise it.  Not
+// armed (profiling on, another path), or the word does not show up within 20 ms: hipStreamSynchronize.
+mcl_status wait_for_cycle(mcl_ctx* ctx) {
+  if (ctx->done_armed) {
+    ctx->done_armed = false;
+    const volatile uint64_t* word = reinterpret_cast<const volatile uint64_t*>(ctx->h_scalars + 31);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 1;; ++spins) {
+      if (*word == ctx->done_seq) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        // (now and then the runtime gets to see an idle stream all the same: it retires its bookkeeping of finished commands there)
+        if ((ctx->done_seq & 0xFFu) == 0) break;
+        return MCL_OK;
+      }
+      __builtin_ia32_pause();
+      if ((spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+  }
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MCL_OK;
 }
 
 mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
@@ -935,9 +970,16 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
     ra.out_offset = 0;
     if (with_estimate) {
       MCL_HIP(ctx, ctx->d_est_partials.ensure(static_cast<size_t>(9) * ((max_p + 1023) / 1024)));
+      Completion done{};
+      ctx->done_armed = ctx->tuning.cycle_spin && !ctx->profile && estimate_enqueued;
+      if (ctx->done_armed) {
+        done.d_ticket = reinterpret_cast<unsigned long long*>(ctx->d_scalars.ptr + 27);
+        done.host_flag = reinterpret_cast<unsigned long long*>(ctx->hd_scalars + 31);
+        done.seq = ++ctx->done_seq;
+      }
       launch_resample_draw_and_estimate(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp,
                                         ctx->pivot[0], ctx->pivot[1], ctx->d_est_partials.ptr, ctx->d_scalars.ptr + 8,
-                                        ctx->hd_scalars + 8);
+                                        ctx->hd_scalars + 8, ctx->done_armed ? &done : nullptr);
       if (estimate_enqueued) *estimate_enqueued = true;
     } else {
       launch_resample_draw(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp, nullptr);
@@ -1827,7 +1869,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_weight_sums", "beam_table"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_weight_sums", "beam_table", "cycle_spin"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2180,6 +2222,7 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
                       mcl_estimate* estimate, mcl_update_info* info) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
   MCL_REQUIRE(ctx, control_pose && (num_points == 0 || points_xy), "null argument");
+  const auto t_entry = std::chrono::steady_clock::now();
   if (info) {
     std::memset(info, 0, sizeof(*info));
     info->effective_sample_size = -1.0;
@@ -2241,6 +2284,7 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
 
   bool keys_ready = false;
   if (const mcl_status s = do_propagate(ctx, ctx->window0, ctx->window1, ctx->step, num_points, &keys_ready)) return s;  // :174-175
+  const auto t_first = std::chrono::steady_clock::now();
   // With a fixed particle count and no selective resampling nothing in the cycle depends on a host-side decision: the
   // recovery estimator runs on the device as well and the cycle synchronises once, at the estimate.
   const mcl_amcl_params& ap = ctx->cfg.amcl;
@@ -2297,6 +2341,8 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   }
   ctx->force_update = false;  // :199
   mcl_estimate est{};
+  auto t_enqueued = t_first, t_waited = t_first;
+  bool host_timed = false;
   if (ctx->estimate_kind == 1) {  // beluga_ros::Amcl returns cluster_based_estimate (beluga_ros/src/amcl.cpp:125)
     if (const mcl_status s = mcl_cluster_based_estimate(ctx, &ctx->cluster_params, &est)) return s;
     if (std::isfinite(est.pose[2]) && std::isfinite(est.pose[3])) {
@@ -2306,7 +2352,10 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   } else if (estimate_enqueued) {  // :200, sums already produced by the draw kernel
     stage_begin(ctx, MCL_STAGE_ESTIMATE);
     stage_end(ctx, MCL_STAGE_ESTIMATE);
-    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    t_enqueued = std::chrono::steady_clock::now();
+    if (const mcl_status s = wait_for_cycle(ctx)) return s;
+    t_waited = std::chrono::steady_clock::now();
+    host_timed = true;
     stage_collect(ctx);
     double sums[12];
     for (int k = 0; k < 9; ++k) sums[k] = ctx->h_scalars[8 + k];
@@ -2336,6 +2385,14 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
     info->weight_sum = stats.sum;
     info->effective_sample_size = ess;
     info->random_state_probability = random_state_probability;
+  }
+  if (host_timed) {
+    const auto ns = [](auto a, auto b) { return static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count()); };
+    ctx->host_ns[0] += ns(t_entry, t_first);
+    ctx->host_ns[1] += ns(t_first, t_enqueued);
+    ctx->host_ns[2] += ns(t_enqueued, t_waited);
+    ctx->host_ns[3] += ns(t_waited, std::chrono::steady_clock::now());
+    ctx->host_cycles += 1;
   }
   return MCL_OK;
 }
@@ -2715,6 +2772,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "key_bits_xy") t.key_bits_xy = (value >= 4 && value <= 6) ? static_cast<int>(value) : 0;
   else if (key == "lf_margin") t.lf_margin = value ? 1 : 0;
   else if (key == "lf_producer") t.lf_producer = value ? 1 : 0;
+  else if (key == "cycle_spin") t.cycle_spin = value ? 1 : 0;
   else if (key == "beam_table") t.beam_table = value ? 1 : 0;
   else if (key == "lf_weight_sums") t.lf_weight_sums = value ? 1 : 0;
   else if (key == "lf_split") t.lf_split = static_cast<int>(value & 3);  // 1: side by side only, 2: stacked only, 3: both
@@ -2739,6 +2797,11 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
     patch_totals(ctx, &planned, &through, /*synchronised=*/true);
     *value = key == "lf_patch_groups_planned" ? planned : through;
   }
+  else if (key == "host_ns_to_first_launch") *value = ctx->host_ns[0];
+  else if (key == "host_ns_other_launches") *value = ctx->host_ns[1];
+  else if (key == "host_ns_wait") *value = ctx->host_ns[2];
+  else if (key == "host_ns_after_wait") *value = ctx->host_ns[3];
+  else if (key == "host_cycles") *value = ctx->host_cycles;
   else if (key == "field_build_us") *value = static_cast<uint64_t>(ctx->field_build_ms * 1e3);  // kernels of the last device field build
   else if (key == "field_built_on_device") *value = ctx->field_built_on_device ? 1 : 0;
   else return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "mcl_get_counter: unknown counter " + key);

@@ -146,6 +146,8 @@ struct Tuning {
   int lf_producer = 1;              // LDS-patch kernel: 1 = seven waves of particles + a producer wave (the form that knows half patches and
                                     // patches clamped at the table's border), 0 = every wave holds particles and fetches its share of the
                                     // patches straight into LDS (buffer_load ... lds); measured 5 % slower on the bench
+  int cycle_spin = 1;               // fixed-size cycles: 1 = the host waits for the cycle's own completion word (written to mapped host memory
+                                    // by the last kernel, Completion) instead of the stream's completion signal; 0 = hipStreamSynchronize
   int beam_table = 1;               // beam model, ordered kernel: the terms that depend on the expected range alone from a table over the hit's
                                     // squared cell distance (built at mcl_set_map); 0 = evaluated per beam
   int lf_weight_sums = 1;           // fixed-size cycle: the normalisation factor is added up from the LF patch kernel's workgroup sums of the
@@ -331,6 +333,13 @@ void launch_norm_finalize(hipStream_t st, const double* d_chunk_sum, const doubl
 // 16-ary search tree over the cdf: level l (l = 1 .. depth) keeps every 16^l-th cumulative sum (the last of each group
 // of 16 entries of the level below, one 128-byte line per group), so that std::lower_bound touches one line per level.
 // Pure comparisons: the result is exactly cdf_lower_bound's.
+// A launch's own completion word (k_final_rows): d_ticket counts its workgroups (never reset), host_flag is a word of mapped host
+// memory that receives seq when the last of them is done, behind everything the launch mirrored to the host.
+struct Completion {
+  unsigned long long* d_ticket{nullptr};
+  unsigned long long* host_flag{nullptr};
+  unsigned long long seq{0};
+};
 constexpr int kCdfTreeMaxDepth = 8;
 struct CdfTree {
   const double* cdf;
@@ -367,7 +376,7 @@ void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const doub
                           ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes);
 void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst, ResampleArgs a,
                                        GridView g, FreeCells fc, HashParams hp, double pivot_x, double pivot_y, double* d_partials,
-                                       double* d_sums, double* host_mirror);
+                                       double* d_sums, double* host_mirror, const Completion* done = nullptr);
 // Sharded variant: targets given, no RNG (mcl_gather_by_cdf).
 // Sharded resampling helpers (mcl_resample_targets / mcl_commit_resampled).
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,

@@ -795,6 +795,20 @@ __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, 
 // Measurement builds only (tools/build_variant.sh, never the product library): -DMCL_ABLATE=<bits> removes one ingredient of
 // the patch kernel's main loop at a time to see what it costs (the results are then wrong): 1 = the barriers, 2 = the palette
 // value reads, 4 = the look-ups in the patch, 16 = the producer's fetches and stores.
+// -DMCL_LF_TIMING (tools/exp_lf_timing.py): cycles (s_memtime) the waves of k_reweight_lf_patch spend in total and waiting at
+// their workgroup barriers.  g_lf_timing: [0] consumer waves, [1] their cycles, [2] of which at barriers, [3] producer waves,
+// [4] their cycles, [5] of which at barriers, [6] consumer cycles before the main loop (planning), [7] producer cycles waiting for its loads.  Compiled out of the product.
+#ifdef MCL_LF_TIMING
+__device__ unsigned long long g_lf_timing[8];
+#define MCL_LF_BARRIER(statement)                         \
+  do {                                                    \
+    const long long t_b = __builtin_readcyclecounter();   \
+    statement;                                            \
+    lf_barrier_cycles += __builtin_readcyclecounter() - t_b; \
+  } while (0)
+#else
+#define MCL_LF_BARRIER(statement) statement
+#endif
 #ifndef MCL_ABLATE
 #define MCL_ABLATE 0
 #endif
@@ -836,6 +850,10 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
                                                                  uint32_t patch_base /* LDS byte offset, 16-aligned */,
                                                                  PatchStats stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef MCL_LF_TIMING
+  const long long lf_t0 = __builtin_readcyclecounter();
+  long long lf_barrier_cycles = 0, lf_t_main = lf_t0, lf_load_wait = 0;
+#endif
   {
     uint32_t* s_row = reinterpret_cast<uint32_t*>(smem);
     for (uint32_t j = threadIdx.x; j < f.H + 2; j += kPalBlock)
@@ -1164,6 +1182,9 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       report();
       return;
     }
+#ifdef MCL_PRODUCER_PRIO
+    __builtin_amdgcn_s_setprio(MCL_PRODUCER_PRIO);
+#endif
     const int y_last = static_cast<int>((f.H + 7u) & ~7u);  // first row of the bottom border tiles
     // The patch of group g, clamped into the bordered table (whatever lies outside the grid reads the unknown entry, like
     // a clamped gather): this lane's column, tile row by tile row.  While the consumers work on group g the patch of g + 1
@@ -1214,6 +1235,13 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     };
     auto store = [&](uint32_t g, const Pieces& piece) {
       unsigned char* dst = smem + buffer_of(g) + lane * kPatchPitch;
+#ifdef MCL_LF_TIMING
+      {  // the wait for this set's loads (the other set's eight, issued later, may still be out: vmcnt(8))
+        const long long t_w = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_waitcnt(0x0F78);
+        lf_load_wait += __builtin_readcyclecounter() - t_w;
+      }
+#endif
 #pragma unroll
       for (int r = 0; r < kPatchH / 8; ++r) *reinterpret_cast<uint4*>(dst + r * 16) = piece[r];
     };
@@ -1226,19 +1254,27 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     fetch(2, even);
     uint32_t g = 0;
     for (; g + 1 < groups; g += 2) {
-      if constexpr (!(MCL_ABLATE & 1)) __syncthreads();  // the consumers are done with group g - 1: its buffer takes the patch of g + 1
+      if constexpr (!(MCL_ABLATE & 1)) MCL_LF_BARRIER(__syncthreads());  // the consumers are done with group g - 1: its buffer takes the patch of g + 1
       if constexpr (!(MCL_ABLATE & 16)) {
         store(g + 1, odd);
         fetch(g + 3, odd);
       }
-      if constexpr (!(MCL_ABLATE & 1)) __syncthreads();
+      if constexpr (!(MCL_ABLATE & 1)) MCL_LF_BARRIER(__syncthreads());
       if constexpr (!(MCL_ABLATE & 16)) {
         store(g + 2, even);
         fetch(g + 4, even);
       }
     }
     if constexpr (!(MCL_ABLATE & 1))
-      if (g < groups) __syncthreads();
+      if (g < groups) MCL_LF_BARRIER(__syncthreads());
+#ifdef MCL_LF_TIMING
+    if (lane == 0) {
+      atomicAdd(&g_lf_timing[3], 1ull);
+      atomicAdd(&g_lf_timing[4], static_cast<unsigned long long>(__builtin_readcyclecounter() - lf_t0));
+      atomicAdd(&g_lf_timing[5], static_cast<unsigned long long>(lf_barrier_cycles));
+      atomicAdd(&g_lf_timing[7], static_cast<unsigned long long>(lf_load_wait));
+    }
+#endif
     report();  // off the consumers' path: they are still at their last group
     return;
   }
@@ -1322,13 +1358,13 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     if constexpr (kShared && !decltype(is_loose)::value) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of group g's patch are in LDS
     if constexpr (!decltype(is_loose)::value && !(MCL_ABLATE & 1)) {
       if constexpr (kShared || !MCL_BARE_BARRIER) {
-        __syncthreads();
+        MCL_LF_BARRIER(__syncthreads());
       } else {
         // A bare barrier: no wait for this wave's outstanding LDS reads (see patch_buffers).  What it orders: the producer's stores
         // of patch g (complete before ITS barrier: it keeps the fence) against the look-ups below.  The empty asm statements keep
         // the compiler from moving memory operations across it.
         asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        MCL_LF_BARRIER(__builtin_amdgcn_s_barrier());
         asm volatile("" ::: "memory");
       }
     }
@@ -1397,11 +1433,22 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     }
     consume(a, b_begin + 8 * groups - 8);
   };
+#ifdef MCL_LF_TIMING
+  lf_t_main = __builtin_readcyclecounter();
+#endif
   if (groups) {
     if (loose) run(std::true_type{});
     else run(std::false_type{});
   }
   add_exact(b_begin + 8 * groups, b_end - (b_begin + 8 * groups));
+#ifdef MCL_LF_TIMING
+  if (lane == 0) {
+    atomicAdd(&g_lf_timing[0], 1ull);
+    atomicAdd(&g_lf_timing[1], static_cast<unsigned long long>(__builtin_readcyclecounter() - lf_t0));
+    atomicAdd(&g_lf_timing[2], static_cast<unsigned long long>(lf_barrier_cycles));
+    atomicAdd(&g_lf_timing[6], static_cast<unsigned long long>(lf_t_main - lf_t0));
+  }
+#endif
   uint64_t t_end;
   const uint32_t i_end = particle_again(t_end);
   double new_weight = 0.0;
@@ -2692,15 +2739,71 @@ __global__ __launch_bounds__(kBlock) void k_block_distances(const uint32_t* __re
 // Each workgroup owns chunk b = [b*kChunk, (b+1)*kChunk): thread t holds elements t*8 .. t*8+7.
 constexpr int kItems = kChunk / kBlock;  // 8
 
+// A chunk between global memory and the threads' items, through LDS.  A thread reading its own eight consecutive doubles asks
+// the vector-memory pipe for 64 different lines per instruction (one per lane, eight instructions per line: measured 1.1 TB/s at
+// 10M particles); here the global side moves 16 bytes per lane with consecutive lanes on consecutive addresses, and the items
+// are read back from an LDS copy padded by one double per eight (stride 9 doubles = 18 banks: conflict free for the 32 lanes
+// of a b64 pass).  Which thread adds which elements in which order - and with it every bit of the sums and of the CDF - is
+// unchanged.  Elements beyond n read as 0.
+constexpr int kChunkPadded = kChunk + kChunk / kItems;
+__device__ __forceinline__ int chunk_slot(int e) { return e + (e >> 3); }
+__device__ __forceinline__ void chunk_items_load(const double* __restrict__ a, uint64_t n, double* lds, double (&x)[kItems]) {
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+  if ((reinterpret_cast<uintptr_t>(a) & 15u) == 0) {
+#pragma unroll
+    for (int k = 0; k < kChunk / 2 / kBlock; ++k) {
+      const int e = 2 * (k * kBlock + static_cast<int>(threadIdx.x));
+      const uint64_t i = base + e;
+      double2 v{0.0, 0.0};
+      if (i + 1 < n) v = *reinterpret_cast<const double2*>(a + i);
+      else if (i < n) v.x = a[i];
+      lds[chunk_slot(e)] = v.x;  // e is even: e + 1 lies in the same group of eight
+      lds[chunk_slot(e) + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      const int e = k * kBlock + static_cast<int>(threadIdx.x);
+      lds[chunk_slot(e)] = base + e < n ? a[base + e] : 0.0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) x[k] = lds[threadIdx.x * (kItems + 1) + k];
+}
+// The way back: the threads' items to a[chunk] (elements below n only).  The LDS copy may be the one chunk_items_load filled: a
+// thread overwrites the slots it read itself.
+__device__ __forceinline__ void chunk_items_store(double* __restrict__ a, uint64_t n, double* lds, const double (&x)[kItems]) {
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) lds[threadIdx.x * (kItems + 1) + k] = x[k];
+  __syncthreads();
+  if ((reinterpret_cast<uintptr_t>(a) & 15u) == 0) {
+#pragma unroll
+    for (int k = 0; k < kChunk / 2 / kBlock; ++k) {
+      const int e = 2 * (k * kBlock + static_cast<int>(threadIdx.x));
+      const uint64_t i = base + e;
+      const double2 v{lds[chunk_slot(e)], lds[chunk_slot(e) + 1]};
+      if (i + 1 < n) *reinterpret_cast<double2*>(a + i) = v;
+      else if (i < n) a[i] = v.x;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      const int e = k * kBlock + static_cast<int>(threadIdx.x);
+      if (base + e < n) a[base + e] = lds[chunk_slot(e)];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_chunk_sum(const double* __restrict__ w, uint64_t n, double* __restrict__ partials) {
   __shared__ double scratch[kBlock / 64];
-  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
+  __shared__ double s_items[kChunkPadded];
+  double x[kItems];
+  chunk_items_load(w, n, s_items, x);
   double v[1] = {0.0};
 #pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    const uint64_t i = base + k;
-    if (i < n) v[0] += w[i];
-  }
+  for (int k = 0; k < kItems; ++k) v[0] += x[k];  // (an element beyond n adds + 0.0: the sum keeps its bits)
   block_reduce<1>(v, scratch);
   if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
 }
@@ -2714,14 +2817,24 @@ __device__ __forceinline__ double row_total(const double* __restrict__ row, uint
   block_reduce<1>(v, scratch);
   return v[0];  // valid in thread 0
 }
+// done (optional, Completion): the launch's last workgroup to finish stores done.seq to a word of mapped host memory, behind
+// everything the launch mirrored - the host can wait for that word instead of the stream's completion signal.
 __global__ __launch_bounds__(kBlock) void k_final_rows(const double* __restrict__ partials, uint32_t count, uint32_t stride,
-                                                       double* __restrict__ out, double* __restrict__ host_mirror) {
+                                                       double* __restrict__ out, double* __restrict__ host_mirror, Completion done) {
   __shared__ double scratch[kBlock / 64];
   const uint32_t k = blockIdx.x;
   const double total = row_total(partials + static_cast<size_t>(k) * stride, count, scratch);
   if (threadIdx.x == 0) {
     out[k] = total;
     if (host_mirror) host_mirror[k] = total;
+    if (done.host_flag) {
+      __threadfence_system();  // this workgroup's mirrored value is visible to the host before its ticket counts
+      const unsigned long long ticket = atomicAdd(done.d_ticket, 1ull);
+      if (ticket % gridDim.x == gridDim.x - 1) {
+        __threadfence_system();
+        __hip_atomic_store(done.host_flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -2749,21 +2862,17 @@ __global__ __launch_bounds__(kBlock) void k_normalize(double* __restrict__ w, ui
   }
   const double factor = sum_partials ? s_factor : *d_factor;
   const bool skip = fabs(factor - 1.0) < DBL_EPSILON;  // normalize.hpp:73
-  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
+  __shared__ double s_items[kChunkPadded];
+  double x[kItems];
+  chunk_items_load(w, n, s_items, x);
   double v[2] = {0.0, 0.0};
 #pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    const uint64_t i = base + k;
-    if (i < n) {
-      double x = w[i];
-      if (!skip) {
-        x = x / factor;
-        w[i] = x;
-      }
-      v[0] += x;
-      v[1] += x * x;
-    }
+  for (int k = 0; k < kItems; ++k) {  // (an element beyond n is 0: 0 / factor = 0 adds nothing)
+    if (!skip) x[k] = x[k] / factor;
+    v[0] += x[k];
+    v[1] += x[k] * x[k];
   }
+  if (!skip) chunk_items_store(w, n, s_items, x);
   block_reduce<2>(v, scratch);
   if (threadIdx.x == 0) {
     chunk_sum[blockIdx.x] = v[0];
@@ -2898,12 +3007,13 @@ __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, ui
   const double my_offset = chunk_sum_to_scan ? chunk_offset_replay(chunk_sum_to_scan, chunk_count, blockIdx.x) : chunk_offset[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk + threadIdx.x * kItems;
+  __shared__ double s_items[kChunkPadded];
   double loc[kItems];
+  chunk_items_load(w, n, s_items, loc);
   double run = 0.0;
 #pragma unroll
   for (int k = 0; k < kItems; ++k) {
-    const uint64_t i = base + k;
-    run += (i < n) ? w[i] : 0.0;
+    run += loc[k];
     loc[k] = run;
   }
   double incl = run;
@@ -2918,11 +3028,13 @@ __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, ui
   for (int q = 0; q < wave; ++q) prefix += s_wave[q];
   prefix += incl - run;
 #pragma unroll
+  for (int k = 0; k < kItems; ++k) loc[k] = prefix + loc[k];
+  chunk_items_store(cdf, n, s_items, loc);
+#pragma unroll
   for (int k = 0; k < kItems; ++k) {
     const uint64_t i = base + k;
     if (i < n) {
-      const double v = prefix + loc[k];
-      cdf[i] = v;
+      const double v = loc[k];
       if (levels) {
         uint64_t q = i + 1;
         for (int l = 0; l < tree.depth && (q & 15) == 0; ++l) {
@@ -3959,6 +4071,18 @@ void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32
                      block_rows, b.row_words, block_columns, b.dist_stride, const_cast<uint8_t*>(b.dist));
 }
 
+#ifdef MCL_LF_TIMING
+}  // namespace mcl
+extern "C" int mcl_debug_lf_timing(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mcl::g_lf_timing), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    static const unsigned long long zeros[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mcl::g_lf_timing), zeros, sizeof(zeros)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+namespace mcl {
+#endif
 #ifdef MCL_BEAM_STATS
 }  // namespace mcl
 extern "C" int mcl_debug_beam_stats(unsigned long long* out32, int reset) {
@@ -4029,7 +4153,7 @@ void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, B
 void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_partials, double* d_out, double* host_mirror) {
   const uint32_t chunks = num_chunks(n);
   if (chunks) hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_partials);
-  hipLaunchKernelGGL(k_final_rows, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror);
+  hipLaunchKernelGGL(k_final_rows, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror, Completion{});
 }
 
 void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_factor, double* d_chunk_sum, double* d_chunk_sumsq,
@@ -4040,7 +4164,7 @@ void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_fac
                        static_cast<const double*>(nullptr), 0u, static_cast<double*>(nullptr), static_cast<double*>(nullptr));
   // d_chunk_sum and d_chunk_sumsq are adjacent rows of one [2][stride] buffer (see context.hip)
   hipLaunchKernelGGL(k_final_rows, dim3(2), dim3(kBlock), 0, st, d_chunk_sum, chunks, static_cast<uint32_t>(d_chunk_sumsq - d_chunk_sum),
-                     d_out, host_mirror);
+                     d_out, host_mirror, Completion{});
 }
 
 // actions::normalize by the set's own total (normalize.hpp:70): weight chunk sums, then the division with the total added
@@ -4053,15 +4177,24 @@ void launch_sum_and_normalize(hipStream_t st, double* w, uint64_t n, double* d_p
   if (chunks) {
     // known_partials: sums whose total is the factor already exist (the LF kernel's workgroup sums): no pass to add the weights up
     if (!known_partials) hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_partials);
-    hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, static_cast<const double*>(nullptr), d_chunk_sum,
-                       d_chunk_sumsq, known_partials ? known_partials : d_partials, known_partials ? known_count : chunks, d_sums,
-                       host_mirror);
+    const double* partials = known_partials ? known_partials : d_partials;
+    const uint32_t count = known_partials ? known_count : chunks;
+    // Every workgroup adding the partial sums up for itself saves a launch while they are few (2232 at 1M particles); at 10M particles (22k sums x
+    // 4.9k workgroups) it was most of the kernel's time: then one workgroup adds them up first (same order, same bits).
+    if (count > 4096u) {
+      hipLaunchKernelGGL(k_final_rows, dim3(1), dim3(kBlock), 0, st, partials, count, count, d_sums, host_mirror, Completion{});
+      hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, static_cast<const double*>(d_sums), d_chunk_sum, d_chunk_sumsq,
+                         static_cast<const double*>(nullptr), 0u, static_cast<double*>(nullptr), static_cast<double*>(nullptr));
+    } else {
+      hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, static_cast<const double*>(nullptr), d_chunk_sum,
+                         d_chunk_sumsq, partials, count, d_sums, host_mirror);
+    }
   } else {
-    hipLaunchKernelGGL(k_final_rows, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_sums, host_mirror);
+    hipLaunchKernelGGL(k_final_rows, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_sums, host_mirror, Completion{});
   }
   if (finalize)
     hipLaunchKernelGGL(k_final_rows, dim3(2), dim3(kBlock), 0, st, d_chunk_sum, chunks, static_cast<uint32_t>(d_chunk_sumsq - d_chunk_sum),
-                       d_sums + 1, host_mirror ? host_mirror + 1 : nullptr);
+                       d_sums + 1, host_mirror ? host_mirror + 1 : nullptr, Completion{});
 }
 
 namespace {
@@ -4138,7 +4271,7 @@ void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const doub
 // The draw plus the estimate sums of the set it produces: d_partials needs 9 * ceil(count / 1024) doubles.
 void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst, ResampleArgs a,
                                        GridView g, FreeCells fc, HashParams hp, double pivot_x, double pivot_y, double* d_partials,
-                                       double* d_sums, double* host_mirror) {
+                                       double* d_sums, double* host_mirror, const Completion* done) {
   int first;
   uint32_t doubles;
   draw_staging(cdf, first, doubles);
@@ -4146,7 +4279,7 @@ void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cd
   if (blocks)
     hipLaunchKernelGGL(k_resample_draw<true>, dim3(blocks), dim3(kDrawBlock), doubles * sizeof(double), st, src, cdf, d_total, dst, a, g,
                        fc, hp, static_cast<unsigned long long*>(nullptr), pivot_x, pivot_y, d_partials, blocks, first, doubles);
-  hipLaunchKernelGGL(k_final_rows, dim3(9), dim3(kBlock), 0, st, d_partials, blocks, blocks, d_sums, host_mirror);
+  hipLaunchKernelGGL(k_final_rows, dim3(9), dim3(kBlock), 0, st, d_partials, blocks, blocks, d_sums, host_mirror, done ? *done : Completion{});
 }
 
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,
@@ -4260,7 +4393,7 @@ void launch_estimate_sums(hipStream_t st, Particles p, uint64_t n, double pivot_
                           double* d_out, double* host_mirror) {
   const uint32_t chunks = num_chunks(n);
   if (chunks) hipLaunchKernelGGL(k_estimate_partials, dim3(chunks), dim3(kBlock), 0, st, p, n, pivot_x, pivot_y, d_partials, chunks);
-  hipLaunchKernelGGL(k_final_rows, dim3(kEstK), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror);
+  hipLaunchKernelGGL(k_final_rows, dim3(kEstK), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror, Completion{});
 }
 
 void launch_cluster_cells(hipStream_t st, Particles p, uint64_t n, HashParams hp, unsigned long long* d_hashes,
@@ -4291,7 +4424,7 @@ void launch_estimate_sums_cluster(hipStream_t st, Particles p, uint64_t n, const
   if (chunks)
     hipLaunchKernelGGL(k_estimate_partials_cluster, dim3(chunks), dim3(kBlock), 0, st, p, n, d_hashes, t, wanted, pivot_x, pivot_y,
                        d_partials, chunks);
-  hipLaunchKernelGGL(k_final_rows, dim3(kEstK), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror);
+  hipLaunchKernelGGL(k_final_rows, dim3(kEstK), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_out, host_mirror, Completion{});
 }
 
 void launch_init_normal(hipStream_t st, Particles p, uint64_t n, const double mean[3], const double T[9], uint64_t seed,

@@ -48,3 +48,8 @@ for c in range(ncycles):
         print(f"  {n:44s} start {(s - t0) / 1e3:9.1f}  dur {(e - s) / 1e3:8.1f}  gap {gap:7.1f}")
         prev_end = e
     print(f"  kernel time {busy:.1f} us, last end at {(prev_end - t0) / 1e3:.1f} us")
+
+# every launch of the dominant kernel in order: shows how its duration moves as the set converges
+lf = [(e - s) / 1e3 for n, s, e in rows if n.startswith("k_reweight_lf") or n.startswith("k_reweight_beam")]
+if lf:
+    print("sensor kernel, every launch in order (us):", " ".join(f"{v:.0f}" for v in lf))
