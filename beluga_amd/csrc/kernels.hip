@@ -854,7 +854,11 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   const long long lf_t0 = __builtin_readcyclecounter();
   long long lf_barrier_cycles = 0, lf_t_main = lf_t0, lf_load_wait = 0;
 #endif
-  {
+  if constexpr ((MCL_ABLATE & 512) != 0) {  // timing only: what launching the workgroups costs
+    if (n == 0xFFFFFFFFFFFFull) w[threadIdx.x] = smem[threadIdx.x];
+    return;
+  }
+  if constexpr (!(MCL_ABLATE & 64)) {
     uint32_t* s_row = reinterpret_cast<uint32_t*>(smem);
     for (uint32_t j = threadIdx.x; j < f.H + 2; j += kPalBlock)
       s_row[j] = palette_row_offset(static_cast<int32_t>(j) - 1, f.pal_pitch) - kFastBiasX;
@@ -880,12 +884,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   float* s_bound = reinterpret_cast<float*>(smem + patch_base + kBuffers * kPatchBytes + kPatchPlanned * 32);  // [7][6]
   // The scan itself, for the planner's threads (they walk their group's points again and again): staged in the patch buffers,
   // which nothing else uses before the main loop, if it fits there.
-  const bool scan_staged = static_cast<size_t>(B) * sizeof(double2) <= kBuffers * kPatchBytes;
-  if (scan_staged) {
-    double2* s_scan = reinterpret_cast<double2*>(smem + patch_base);
-    const double2* scan = reinterpret_cast<const double2*>(pts);
-    for (uint32_t k = threadIdx.x; k < B; k += kPalBlock) s_scan[k] = scan[k];
-  }
+  const bool scan_staged = false;  // (the planner's fallback for long scans reads global memory; see beam_records below)
   constexpr uint32_t kConsumers = kShared ? kPalBlock / 64 : kPalBlock / 64 - 1;  // waves that hold particles
   constexpr uint32_t kParticles = kConsumers * 64;
   const bool producer = !kShared && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPalBlock / 64 - 1);  // a scalar branch: the roles
@@ -984,10 +983,145 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       mine[3] = db;
     }
   }
+  // ---- the scan through the reference pose, a beam per thread (every wave, the producer's too): end-point cell and reach per
+  // axis of each beam of the planned groups, 16 bytes per beam in the patch buffers (nothing else uses them before the main
+  // loop).  The plan below then works on these records: the double precision arithmetic of a workgroup's 1080 beams runs once,
+  // 512 wide, instead of once per question a group's thread asks about its 8 beams, one beam after the other (the planner was
+  // 18 us of the kernel's 450, none of it hidden behind other workgroups: they all plan at the same time).
+  const uint32_t planned = groups < kPatchPlanned ? groups : kPatchPlanned;
+  const bool beam_records = static_cast<size_t>(planned) * 8 * sizeof(int4) <= kBuffers * kPatchBytes;
+  int4* s_beam = reinterpret_cast<int4*>(smem + patch_base);
+  if (beam_records) {
+    const double2* scan = reinterpret_cast<const double2*>(pts) + b_begin;
+#pragma unroll
+    for (uint32_t pass = 0; pass < (kBuffers * kPatchBytes / sizeof(int4) + kPalBlock - 1) / kPalBlock; ++pass) {
+      const uint32_t b = pass * kPalBlock + threadIdx.x;
+      if (b < planned * 8) {
+        const double2 p = scan[b];
+        const double sx = __builtin_fma(p.x, rc, __builtin_fma(-p.y, rs, rxm));
+        const double sy = __builtin_fma(p.x, rs, __builtin_fma(p.y, rc, rym));
+        const int cx = static_cast<int>(__builtin_bit_cast(uint64_t, sx) >> 32), cy = static_cast<int>(__builtin_bit_cast(uint64_t, sy) >> 32);
+        const float reach_x = static_cast<float>(fabs(p.x * rc - p.y * rs)), reach_y = static_cast<float>(fabs(p.x * rs + p.y * rc));
+        s_beam[b] = int4{cx, cy, __builtin_bit_cast(int, reach_x), __builtin_bit_cast(int, reach_y)};
+      }
+    }
+  }
   __syncthreads();
   // ---- the plan: thread g looks at group g through the reference pose
   bool mine_fits = false;
-  if (threadIdx.x < groups && threadIdx.x < kPatchPlanned) {
+#pragma unroll 1
+  for (int plan_rep = 0; plan_rep < ((MCL_ABLATE & 1024) ? 2 : 1); ++plan_rep) {  // (twice: timing only - is the plan's time hidden?)
+  if constexpr ((MCL_ABLATE & 1024) != 0) asm volatile("" ::: "memory");
+  if (threadIdx.x < planned && beam_records) {
+    float Dx = 0.f, Dy = 0.f, Da = 0.f, Db = 0.f;
+    for (uint32_t k = 0; k < kConsumers; ++k) {
+      Dx = fmaxf(Dx, s_bound[4 * k]);
+      Dy = fmaxf(Dy, s_bound[4 * k + 1]);
+      Da = fmaxf(Da, s_bound[4 * k + 2]);
+      Db = fmaxf(Db, s_bound[4 * k + 3]);
+    }
+    // every float operation below may round down: scaled up by 1 + 2^-10 where it matters, and two cells of slack
+    Dx = Dx * 1.001f + 2.f;
+    Dy = Dy * 1.001f + 2.f;
+    int4 rec[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rec[k] = s_beam[8 * threadIdx.x + k];
+    struct Range {
+      int lo_x, hi_x, lo_y, hi_y;
+      float reach_x, reach_y;
+    };
+    auto range_of = [&](int from, int to) {  // beams [from, to) of this group
+      Range r{INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k >= from && k < to) {
+          r.lo_x = min(r.lo_x, rec[k].x);
+          r.hi_x = max(r.hi_x, rec[k].x);
+          r.lo_y = min(r.lo_y, rec[k].y);
+          r.hi_y = max(r.hi_y, rec[k].y);
+          r.reach_x = fmaxf(r.reach_x, __builtin_bit_cast(float, rec[k].z));
+          r.reach_y = fmaxf(r.reach_y, __builtin_bit_cast(float, rec[k].w));
+        }
+      }
+      return r;
+    };
+    // Does the range fit a patch of PW x PH cells?  -> its origin
+    auto fits_patch = [&](const Range& r, int PW, int PH, int& x0, int& y0) -> bool {
+      float turn_x, turn_y;  // cells
+      if (stats.isotropic_margin) {  // |q'| <= sqrt(max q'x^2 + max q'y^2)
+        turn_x = turn_y = sqrtf(r.reach_x * r.reach_x + r.reach_y * r.reach_y) * 1.002f * (Da * 1.001f);
+      } else {
+        const float A = Da * 1.001f, Bv = Db * 1.001f, qx = r.reach_x * 1.001f, qy = r.reach_y * 1.001f;
+        turn_x = (A * qx + Bv * qy) * 1.001f;
+        turn_y = (Bv * qx + A * qy) * 1.001f;
+      }
+      const float mx = ceilf(Dx + turn_x), my = ceilf(Dy + turn_y);
+      const bool fits = mx < 64.f && my < 64.f;  // false for NaN and infinity
+      const int margin_x = fits ? static_cast<int>(mx) : 0, margin_y = fits ? static_cast<int>(my) : 0;
+      x0 = r.lo_x - margin_x;
+      y0 = (r.lo_y - margin_y) & ~7;
+      return fits && r.hi_x + margin_x - x0 < PW && r.hi_y + margin_y - y0 < PH;
+    };
+    int x0a = 0, y0a = 0, x0b = 0, y0b = 0;
+    uint32_t flags = 0u, first_b = 0u;
+    uint32_t fetch_offset = 0u;  // kShared: the group's share of every piece's byte offset in the table
+    if ((MCL_ABLATE & 256) != 0) {
+    } else if (fits_patch(range_of(0, 8), kPatchW, kPatchH, x0a, y0a)) {
+      flags = 1u;
+      if constexpr (kShared) {
+        // all 64 x 64 cells inside the bordered table (its border tiles hold the unknown entry: what a clamped fetch would
+        // read as well); a patch that reaches beyond them is left to the gathers
+        const int xu = x0a - static_cast<int>(kFastBias), yu = y0a - static_cast<int>(kFastBias);
+        const int x_last = static_cast<int>((f.W + 7u) & ~7u) + 7, y_last_cell = static_cast<int>((f.H + 7u) & ~7u) + 7;
+        if (xu >= -8 && xu + kPatchW - 1 <= x_last && yu >= -8 && yu + kPatchH - 1 <= y_last_cell)
+          fetch_offset = (static_cast<uint32_t>(xu + 8) << 4) + (static_cast<uint32_t>(yu + 8) >> 3) * f.pal_pitch;
+        else
+          flags = 0u;
+      }
+    } else if (!kShared && stats.split_patches) {
+      // split where the scan jumps: between the two consecutive beams whose end-points lie farthest apart (the first such pair)
+      int widest_jump = -1, k_split = 4;
+#pragma unroll
+      for (int k = 1; k < 8; ++k) {
+        const int jump = max(abs(rec[k].x - rec[k - 1].x), abs(rec[k].y - rec[k - 1].y));
+        if (jump > widest_jump) {
+          widest_jump = jump;
+          k_split = k;
+        }
+      }
+      Range ra{INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0.f, 0.f}, rb = ra;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {  // (k_split is a run-time value: both halves in one pass)
+        Range& r = k < k_split ? ra : rb;
+        r.lo_x = min(r.lo_x, rec[k].x);
+        r.hi_x = max(r.hi_x, rec[k].x);
+        r.lo_y = min(r.lo_y, rec[k].y);
+        r.hi_y = max(r.hi_y, rec[k].y);
+        r.reach_x = fmaxf(r.reach_x, __builtin_bit_cast(float, rec[k].z));
+        r.reach_y = fmaxf(r.reach_y, __builtin_bit_cast(float, rec[k].w));
+      }
+      int xa, ya, xb, yb;
+      if ((stats.split_patches & 1u) && fits_patch(ra, kPatchW / 2, kPatchH, xa, ya) && fits_patch(rb, kPatchW / 2, kPatchH, xb, yb)) flags = 1u | 2u;
+      else if ((stats.split_patches & 2u) && fits_patch(ra, kPatchW, kPatchH / 2, xa, ya) && fits_patch(rb, kPatchW, kPatchH / 2, xb, yb)) flags = 1u | 4u;
+      if (flags) {
+        x0a = xa;
+        y0a = ya;
+        x0b = xb;
+        y0b = yb;
+        first_b = static_cast<uint32_t>(k_split);
+      }
+    }
+    s_plan[threadIdx.x] = int4{x0a, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
+    {
+      const uint32_t ka = 0u - (static_cast<uint32_t>(x0a) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0a) << 1);
+      // half B lives in columns 32 .. 63 (side by side) or in rows 32 .. 63 (stacked) of the same buffer
+      const uint32_t kb = ((flags & 2u) ? (kPatchW / 2) * kPatchPitch : static_cast<uint32_t>(kPatchH)) -
+                          (static_cast<uint32_t>(x0b) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0b) << 1);
+      const uint32_t meta = flags == 0u ? 0u : ((flags & 6u) ? first_b : 8u);
+      s_plan_k[threadIdx.x] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), static_cast<int>(fetch_offset)};
+    }
+    mine_fits = flags != 0u;
+  } else if (threadIdx.x < planned) {  // (a scan too long for the records: the plan straight from global memory, a beam after the other)
     float Dx = 0.f, Dy = 0.f, Da = 0.f, Db = 0.f;
     for (uint32_t k = 0; k < kConsumers; ++k) {
       Dx = fmaxf(Dx, s_bound[4 * k]);
@@ -1054,7 +1188,8 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     int x0a = 0, y0a = 0, x0b = 0, y0b = 0;
     uint32_t flags = 0u, first_b = 0u;
     uint32_t fetch_offset = 0u;  // kShared: the group's share of every piece's byte offset in the table
-    if (try_fit(0, 8, kPatchW, kPatchH, x0a, y0a)) {
+    if ((MCL_ABLATE & 256) != 0) {
+    } else if (try_fit(0, 8, kPatchW, kPatchH, x0a, y0a)) {
       flags = 1u;
       if constexpr (kShared) {
         // all 64 x 64 cells inside the bordered table (its border tiles hold the unknown entry: what a clamped fetch would
@@ -1090,6 +1225,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       s_plan_k[threadIdx.x] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), static_cast<int>(fetch_offset)};
     }
     mine_fits = flags != 0u;
+  }
   }
   // A workgroup with too few of its groups through a patch drops the machinery: no producer, no barriers, every look-up a
   // gather.  Not only dispersed sets: a gathered group INSIDE a patched workgroup costs 2.6x a patched one (the workgroup waits
@@ -1177,6 +1313,10 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         }
       }
   };
+  if constexpr ((MCL_ABLATE & 32) != 0) {  // timing only: the prologue (tables, poses, bound, plan) and nothing else
+    if (threadIdx.x == 0 && fitting == 0xFFFFFFFFu) w[0] = ixm + iym;
+    return;
+  }
   if (producer) {
     if (loose) {
       report();
