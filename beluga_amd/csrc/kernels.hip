@@ -188,29 +188,108 @@ __global__ __launch_bounds__(kBlock) void k_pull_scan(const double* __restrict__
 // One workgroup per chunk of kChunk particles (coalesced 32-byte records).  kKeys: the ordering key of the NEW pose and the
 // chunk's histogram of the key's low digit come out of the same pass (the poses are in registers here).
 // One particle through the motion model (the body of actions::propagate for the three models).
+// The propagation's own forms of the shared helpers (se2.h, rng.h: library sin / cos / hypot and two divisions per
+// normalisation - 1150 vector instructions per particle, four fifths of them in eight trigonometric calls and six normalisations).
+// Same expressions, evaluated another way; each within 2 ulp of the shared form (the parity tests' tolerance for a propagated
+// state is 1e-11 relative):
+//  * sin and cos of one argument together: Cody-Waite reduction by pi/2 in two fused steps (the product k * pi/2_hi is exact
+//    inside the FMA; |theta| < 1e6, anything else - NaN included - goes to the library), fdlibm's kernel polynomials on
+//    [-pi/4, pi/4] (k_sin.c, k_cos.c: 1.1e-16 / 1.4e-16 absolute against long double, checked over 2M points);
+//  * z / |z| as z * rsqrt(|z|^2): v_rsq_f64 and two Newton steps instead of hypot and two divisions.
+__device__ __forceinline__ void sincos_fast(double theta, double& s, double& c) {
+  if (!(fabs(theta) < 1.0e6)) {
+    s = sin(theta);
+    c = cos(theta);
+    return;
+  }
+  const double kd = __builtin_rint(theta * 0x1.45f306dc9c883p-1);  // theta * 2 / pi
+  const int k = static_cast<int>(kd);
+  double r = __builtin_fma(-kd, 0x1.921fb54442d18p+0, theta);  // pi / 2 = hi + lo
+  r = __builtin_fma(-kd, 0x1.1a62633145c07p-54, r);
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10, pc = -1.13596475577881948265e-11;
+  ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+  pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+  ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+  const double sr = __builtin_fma(r * z, ps, r);
+  const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+  // theta = r + k pi/2: (sin, cos) = (sr, cr), (cr, -sr), (-sr, -cr), (-cr, sr) for k mod 4 = 0 .. 3
+  const double s0 = (k & 1) ? cr : sr, c0 = (k & 1) ? sr : cr;
+  s = (k & 2) ? -s0 : s0;
+  c = ((k + 1) & 2) ? -c0 : c0;
+}
+__device__ __forceinline__ Rot2 rot_from_complex_fast(double re, double im) {  // se2.h rot_from_complex: z / hypot(z)
+  const double n2 = __builtin_fma(re, re, im * im);
+  double y = __builtin_amdgcn_rsq(n2);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {  // y <- y + y (1/2 - n2 y^2 / 2)
+    const double e = __builtin_fma(-n2 * y, 0.5 * y, 0.5);
+    y = __builtin_fma(y, e, y);
+  }
+  return Rot2{re * y, im * y};  // (|z| = 0: 0 * inf = NaN, as 0 / 0 there)
+}
+__device__ __forceinline__ Rot2 rot_exp_fast(double theta) {
+  double sn, cs;
+  sincos_fast(theta, sn, cs);
+  return rot_from_complex_fast(cs, sn);
+}
+__device__ __forceinline__ Rot2 rot_mul_fast(const Rot2& a, const Rot2& b) {  // se2.h rot_mul
+  double re = a.c * b.c - a.s * b.s;
+  double im = a.c * b.s + a.s * b.c;
+  const double n2 = re * re + im * im;
+  if (n2 != 1.0) {
+    const double scale = 2.0 / (1.0 + n2);
+    re = re * scale;
+    im = im * scale;
+  }
+  return rot_from_complex_fast(re, im);
+}
+__device__ __forceinline__ Pose2 pose_mul_fast(const Pose2& a, const Pose2& b) {  // se2.h pose_mul
+  Pose2 o;
+  o.r = rot_mul_fast(a.r, b.r);
+  double tx, ty;
+  rot_apply(a.r, b.x, b.y, tx, ty);
+  o.x = a.x + tx;
+  o.y = a.y + ty;
+  return o;
+}
+__device__ __forceinline__ void box_muller_fast(double u1, double u2, double& z0, double& z1) {  // rng.h rng_box_muller
+  const double r = sqrt(-2.0 * log(1.0 - u1));
+  double sn, cs;
+  sincos_fast(2.0 * kPi * u2, sn, cs);
+  z0 = r * cs;
+  z1 = r * sn;
+}
 __device__ __forceinline__ Pose2 propagate_one(const Pose2& state, const DiffDriveSampler& smp, uint64_t seed, uint32_t step, uint64_t index) {
   const RngWords a = rng_draw(seed, step, kRngPropagateA, index);
   const RngWords b = rng_draw(seed, step, kRngPropagateB, index);
   double z0, z1, z2, z3;
-  rng_box_muller(rng_uniform53(a.w[0], a.w[1]), rng_uniform53(a.w[2], a.w[3]), z0, z1);
-  rng_box_muller(rng_uniform53(b.w[0], b.w[1]), rng_uniform53(b.w[2], b.w[3]), z2, z3);
+  box_muller_fast(rng_uniform53(a.w[0], a.w[1]), rng_uniform53(a.w[2], a.w[3]), z0, z1);
+  box_muller_fast(rng_uniform53(b.w[0], b.w[1]), rng_uniform53(b.w[2], b.w[3]), z2, z3);
   if (smp.kind == 1) {
     // omnidirectional_drive_model.hpp:133-144 — draws in source order: rotation, translation, strafe
     const Rot2 first{smp.first_c, smp.first_s};
-    const Rot2 second = rot_mul(rot_exp(z0 * smp.s1 + smp.m1), rot_inverse(first));
+    const Rot2 second = rot_mul_fast(rot_exp_fast(z0 * smp.s1 + smp.m1), rot_inverse(first));
     const double t = z1 * smp.st + smp.mt;
     const double strafe = z2 * smp.s2 + 0.0;
-    return pose_mul(pose_mul(state, Pose2{first, 0.0, 0.0}), Pose2{second, t, -strafe});
+    return pose_mul_fast(pose_mul_fast(state, Pose2{first, 0.0, 0.0}), Pose2{second, t, -strafe});
   }
   if (smp.kind == 2) {
     // stationary_model.hpp:55-61 — N(0, 0.02) on heading, x, y
-    return pose_mul(state, Pose2{rot_exp(z0 * 0.02 + 0.0), z1 * 0.02 + 0.0, z2 * 0.02 + 0.0});
+    return pose_mul_fast(state, Pose2{rot_exp_fast(z0 * 0.02 + 0.0), z1 * 0.02 + 0.0, z2 * 0.02 + 0.0});
   }
   // differential_drive_model.hpp:156-163
   const double r1 = z0 * smp.s1 + smp.m1;
   const double t = z1 * smp.st + smp.mt;
   const double r2 = z2 * smp.s2 + smp.m2;
-  return pose_mul(pose_mul(state, Pose2{rot_exp(r1), 0.0, 0.0}), Pose2{rot_exp(r2), t, 0.0});
+  return pose_mul_fast(pose_mul_fast(state, Pose2{rot_exp_fast(r1), 0.0, 0.0}), Pose2{rot_exp_fast(r2), t, 0.0});
 }
 
 // Small sets (no ordering keys): one particle per lane, 256 per workgroup - 2000 particles are 8 workgroups on 8 CUs, a wave

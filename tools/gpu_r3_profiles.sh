@@ -50,6 +50,17 @@ for pmc in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY S
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof/b$i
 done
 cd $GRAFT_REPO_ROOT
+# fixed 10M: kernel trace + timeline
+cd /tmp
+N=10000000 timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof/tf -o trace -- python $GRAFT_REPO_ROOT/tools/exp_fixed.py 8 2>/dev/null | grep "^N " > $O/fixed_10M.log
+cd $GRAFT_REPO_ROOT
+python tools/rocpd_summary.py gpurun_out/prof/tf/trace_results.db | head -14 > $O/kernel_trace_fixed_10M.txt
+python tools/timeline.py gpurun_out/prof/tf/trace_results.db 1 >> $O/kernel_trace_fixed_10M.txt
+rm -rf gpurun_out/prof/tf
+python tools/exp_host_time.py 2>/dev/null | tail -n 1 > $O/host_time_per_cycle.txt
+python tools/exp_lf_converge.py 2>/dev/null > $O/lf_converge.txt
+[ -x build/calib_mfma_f64 ] && timeout 60 ./build/calib_mfma_f64 > $O/calib_mfma_f64.txt 2>/dev/null
+[ -x build/calib_lds_residency ] && timeout 60 ./build/calib_lds_residency > $O/calib_lds_residency.txt 2>/dev/null
 timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench.err > $O/bench_1M.json
 python tools/exp_lf_ab.py 40 2>/dev/null | grep -A2 "^all (defaults)" > $O/lf_series.txt
 python tools/exp_small.py 2>/dev/null > $O/small_filters.txt
