@@ -1071,7 +1071,9 @@ def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n):
     cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
     grid = OccupancyGrid(cells=cells, resolution=0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
     truth = synth.find_free_pose(cells, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
-    for beams in (57, 360, 1080):
+    # 1300 and 1700 beams (200 000 particles: one segment): more groups than the per-beam records of the planner hold (its
+    # fallback walks global memory), and more than there are plan entries (the groups beyond them are gathered)
+    for beams in (57, 360, 1080) + ((1300, 1700) if n == 200_000 else ()):
         pts = make_scan(grid, truth, beams, max_range=12.0)
         weights = []
         for patch in (2, 0):  # always / never
