@@ -3415,10 +3415,19 @@ __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(MCL_
   // The search reads global memory a wave at a time: every lane goes through it, the ones with nothing to draw (beyond
   // the count, or taking an injected random state) with a target of zero.
   const uint64_t j = a.first_candidate + t;
+#ifdef MCL_DRAW_ABLATE
+  const RngWords r = (MCL_DRAW_ABLATE & 4) ? RngWords{{static_cast<uint32_t>(j * 2654435761u), static_cast<uint32_t>(j), 1u << 31, 0u}} : rng_draw(a.seed, a.step, kRngResample, j);
+#else
   const RngWords r = rng_draw(a.seed, a.step, kRngResample, j);
+#endif
   const double p_random = a.d_random_state_probability ? *a.d_random_state_probability : a.random_state_probability;
   const bool intersperse = t < a.count && intersperse_here(r, j, p_random, fc.count);
   uint64_t idx = 0;
+#ifdef MCL_DRAW_ABLATE  // timing only (tools/build_variant.sh): 1 = no search, 2 = no estimate sums, 4 = no generator
+  if (MCL_DRAW_ABLATE & 1) {
+    idx = (static_cast<uint64_t>(r.w[0]) * a.n_in) >> 32;
+  } else
+#endif
   if (a.n_in >= 2) {
     const double target = (t < a.count && !intersperse) ? rng_uniform53(r.w[0], r.w[1]) * (*d_total) : 0.0;
     idx = cdf_tree_lower_bound_staged(cdf, staged, first_staged, target);
@@ -3447,6 +3456,11 @@ __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(MCL_
       v[8] = dy * dy;
     }
   }
+#ifdef MCL_DRAW_ABLATE
+  if (kEstimate && (MCL_DRAW_ABLATE & 2)) {
+    if (threadIdx.x == 0) for (int k = 0; k < 9; ++k) est_partials[static_cast<size_t>(k) * est_stride + blockIdx.x] = v[k];
+  } else
+#endif
   if (kEstimate) {
     block_reduce<9, kDrawBlock>(v, scratch);
     if (threadIdx.x == 0) {

@@ -1,7 +1,12 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|Error" | tail -n 5
-bash tools/gpu_r3_trace.sh 2>&1 | sed -n 1,6p
-timeout 300 python bench.py --steps 20 --warmup 5 --windows 3 --stage-steps 0 --no-cpu-baseline --no-other-configs 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['verified'], d['repeat_windows']['cycles_per_s'])"
-N=10000000 python tools/exp_fixed.py 8 | tail -n 1
+mkdir -p gpurun_out/prof
+for v in da1 da2 da4 da7 ""; do
+  if [ -z "$v" ]; then unset BELUGA_MCL_LIB; echo "== product"; else export BELUGA_MCL_LIB=$GRAFT_REPO_ROOT/build/variants/$v/libbeluga_mcl.so; echo "== $v"; fi
+  cd /tmp; rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof/tr
+  timeout 200 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof/tr -o trace -- python $GRAFT_REPO_ROOT/tools/exp_fixed.py 6 > /dev/null 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/rocpd_summary.py gpurun_out/prof/tr/trace_results.db | grep "resample_draw"
+done
+rm -rf gpurun_out/prof/tr
