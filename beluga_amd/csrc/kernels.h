@@ -146,8 +146,10 @@ struct Tuning {
   int lf_producer = 1;              // LDS-patch kernel: 1 = seven waves of particles + a producer wave (the form that knows half patches and
                                     // patches clamped at the table's border), 0 = every wave holds particles and fetches its share of the
                                     // patches straight into LDS (buffer_load ... lds); measured 5 % slower on the bench
-  int cycle_spin = 1;               // fixed-size cycles: 1 = the host waits for the cycle's own completion word (written to mapped host memory
-                                    // by the last kernel, Completion) instead of the stream's completion signal; 0 = hipStreamSynchronize
+  int cycle_spin = 0;               // fixed-size cycles: 1 = the host waits for the cycle's own completion word (written to mapped host memory
+                                    // by the last kernel, Completion) instead of the stream's completion signal; 0 = hipStreamSynchronize.
+                                    // Measured: nothing at 1M particles (1489 / 1492 vs 1482 / 1496 cycles/s), 4 us per cycle SLOWER at
+                                    // 2000 particles (the launches behind an unsynchronised stream cost the host more) - off
   int beam_table = 1;               // beam model, ordered kernel: the terms that depend on the expected range alone from a table over the hit's
                                     // squared cell distance (built at mcl_set_map); 0 = evaluated per beam
   int lf_weight_sums = 1;           // fixed-size cycle: the normalisation factor is added up from the LF patch kernel's workgroup sums of the

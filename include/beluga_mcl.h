@@ -412,9 +412,10 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *   lf_producer (1) LDS-patch kernel: 1 = seven waves of particles and a producer wave per workgroup, 0 = eight waves of particles,
  *                   each fetching its share of the patches straight into LDS (buffer_load ... lds; no half patches, no patches
  *                   clamped at the table's border: such groups are gathered)
- *   cycle_spin (1)  fixed-size cycles (resample every cycle, mean / covariance estimate): the host waits for a completion word the
- *                   cycle's last kernel stores to mapped host memory instead of the stream's completion signal (a few microseconds
- *                   per cycle); 0 = hipStreamSynchronize.  Off while stage profiling is enabled.
+ *   cycle_spin (0)  fixed-size cycles (resample every cycle, mean / covariance estimate): 1 = the host waits for a completion word the
+ *                   cycle's last kernel stores to mapped host memory instead of the stream's completion signal; 0 = hipStreamSynchronize.
+ *                   Measured: no gain at 1M particles, 4 us per cycle slower at 2000 - off by default.  Never while stage
+ *                   profiling is enabled.
  *   lf_split (3)    LDS-patch planner: a group of 8 beams that fits no whole 64 x 64-cell patch (its end-points straddle a range
  *                   discontinuity: 3 - 5 % of the groups of an indoor scan, whatever the cloud) goes through two half patches -
  *                   beams [0, k) and [k, 8), 32 x 64 (bit 0) or 64 x 32 (bit 1) cells each, in the buffer of one whole patch; 0 = such
