@@ -961,9 +961,6 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   int4* s_plan = reinterpret_cast<int4*>(smem + patch_base + kBuffers * kPatchBytes);
   int4* s_plan_k = s_plan + kPatchPlanned;
   float* s_bound = reinterpret_cast<float*>(smem + patch_base + kBuffers * kPatchBytes + kPatchPlanned * 32);  // [7][6]
-  // The scan itself, for the planner's threads (they walk their group's points again and again): staged in the patch buffers,
-  // which nothing else uses before the main loop, if it fits there.
-  const bool scan_staged = false;  // (the planner's fallback for long scans reads global memory; see beam_records below)
   constexpr uint32_t kConsumers = kShared ? kPalBlock / 64 : kPalBlock / 64 - 1;  // waves that hold particles
   constexpr uint32_t kParticles = kConsumers * 64;
   const bool producer = !kShared && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPalBlock / 64 - 1);  // a scalar branch: the roles
@@ -1213,7 +1210,6 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     Dy = Dy * 1.001f + 2.f;
     const uint32_t q0 = b_begin + 8 * threadIdx.x;
     const double2* q = reinterpret_cast<const double2*>(pts) + q0;
-    lds_f64_t* q_staged = reinterpret_cast<lds_f64_t*>(static_cast<uintptr_t>(patch_base)) + 2 * q0;
     // Do the beams [from, to) of this group fit a patch of PW x PH cells?  -> its origin.  (The end-points are evaluated anew
     // for every question - a few hundred operations for the 1 thread in 4 that plans, once per workgroup - rather than held
     // in registers: the kernel's 80 registers belong to the main loop.)
@@ -1225,13 +1221,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       widest_jump = -1;
 #pragma unroll 1
       for (int k = from; k < to; ++k) {
-        double2 p;
-        if (scan_staged) {
-          p.x = q_staged[2 * k];
-          p.y = q_staged[2 * k + 1];
-        } else {
-          p = q[k];
-        }
+        const double2 p = q[k];
         const double sx = __builtin_fma(p.x, rc, __builtin_fma(-p.y, rs, rxm));
         const double sy = __builtin_fma(p.x, rs, __builtin_fma(p.y, rc, rym));
         const int cx = static_cast<int>(__builtin_bit_cast(uint64_t, sx) >> 32), cy = static_cast<int>(__builtin_bit_cast(uint64_t, sy) >> 32);
