@@ -123,7 +123,7 @@ struct Tuning {
   int lf_table = 0;                 // 0 = palette table when the field allows it, 1 = force the 8-byte cube table
   int lf_patch = 1;                 // index table through per-workgroup LDS patches: 1 = where the last launch found them useful,
                                     // 0 = never (per-lane gathers only), 2 = always
-  int lf_loose_below = 176;         // LF patch kernel: a workgroup with fewer than this many 256ths of its beam groups fitting a patch
+  int lf_loose_below = 224;         // LF patch kernel: a workgroup with fewer than this many 256ths of its beam groups fitting a patch
                                     // drops the patches (no producer, no barriers) and gathers every look-up
   int lf_dispersed = 0;             // a set the patch kernel reports as dispersed (lf_patch = 1): 0 = the ordered-lanes gather kernel,
                                     // 1 = wave per particle / lane per beam (k_reweight_lf_beams, no ordering pass; measured

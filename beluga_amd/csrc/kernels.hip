@@ -3395,6 +3395,9 @@ __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(MCL_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* staged = reinterpret_cast<double*>(smem);
   __shared__ double scratch[kEstimate ? (kDrawBlock / 64) * 9 : 1];
+#ifdef MCL_DRAW_ABLATE
+  if (!(MCL_DRAW_ABLATE & 8))
+#endif
   if (first_staged < cdf.depth) {
     const double* from = cdf.levels + cdf.offset[first_staged];
     for (uint32_t k = threadIdx.x; k < staged_doubles; k += kDrawBlock) staged[k] = from[k];

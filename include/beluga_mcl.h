@@ -378,7 +378,7 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *   lf_patch (1)    index table through per-workgroup LDS patches (dense sets): 1 = where the last launch found them useful
  *                   (a dispersed set - global localisation - has none, and is sent to the per-lane gathers, with a probe every
  *                   16th launch), 0 = never, 2 = always
- *   lf_loose_below (176)  LDS-patch kernel: a workgroup with fewer than this many 256ths of its beam groups fitting a patch
+ *   lf_loose_below (224)  LDS-patch kernel: a workgroup with fewer than this many 256ths of its beam groups fitting a patch
  *                   gathers every look-up (a gathered group inside a patched workgroup costs twice one of an all-gathering one)
  *   lf_dispersed (0)  a set reported as dispersed: 0 = the ordered-lanes gather kernel, 1 = a wave per particle, lanes over the
  *                   beams, no ordering pass (measured slower at 1M x 1080)
