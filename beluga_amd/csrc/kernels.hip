@@ -1489,6 +1489,9 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   }
 
   double acc = (f.prob || partial) ? 0.0 : 1.0;
+#if (MCL_ABLATE & 8192)
+  float lf_dummy = static_cast<float>(threadIdx.x);
+#endif
   const bool fast = __builtin_amdgcn_ballot_w64(!lane_small) == 0;  // per wave: a far particle sends its wave through the exact code
   const int c_lo = static_cast<int>(kFastBias) - 1, x_hi = static_cast<int>(kFastBias + f.W), y_hi = static_cast<int>(kFastBias + f.H);
   const uint32_t row_bias = 4u - (kFastBias << 2);  // LDS byte address of the row entry = (biased y << 2) + row_bias
@@ -1591,6 +1594,9 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const double px = q[2 * k], py = q[2 * k + 1];
+#if (MCL_ABLATE & 8192)  // timing only: two more vector instructions per beam (the kernel's sensitivity to their number)
+      asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %0, %0, %0, %0" : "+v"(lf_dummy));
+#endif
       const double sx = __builtin_fma(px, ict, __builtin_fma(-py, ist, ixm));
       const double sy = __builtin_fma(px, ist, __builtin_fma(py, ict, iym));
       const uint64_t bx = __builtin_bit_cast(uint64_t, sx), by = __builtin_bit_cast(uint64_t, sy);
@@ -1650,6 +1656,9 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     else run(std::false_type{});
   }
   add_exact(b_begin + 8 * groups, b_end - (b_begin + 8 * groups));
+#if (MCL_ABLATE & 8192)
+  if (lf_dummy == 12345.f) acc += 1.0;
+#endif
 #ifdef MCL_LF_TIMING
   if (lane == 0) {
     atomicAdd(&g_lf_timing[0], 1ull);
