@@ -590,7 +590,7 @@ def main():
             out["configs"] = other_configs(grid, cells, truth, controls, scans, filt, local_rank)
         if config4 is not None:
             out["configs"] = {"4": config4}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: the other ranks would sit in a barrier behind it)
             out["cpu_baseline"] = cpu_baseline(cells, truth, odoms, scans, n_total)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
