@@ -205,6 +205,7 @@ struct mcl_ctx {
   std::vector<float> h_field;
   DeviceBuffer<uint32_t> d_field_scratch;  // device field build: uint16 column distances + int16 offsets per cell
   bool field_built_on_device{false};
+  uint64_t cluster_cells{0};  // occupied cells of the last cluster_based_estimate on this context (before the merge over shards)
   double field_build_ms{0.0};
 
   // scan: staged in mapped pinned host memory and pulled into d_points by a kernel of the cycle (no copy-engine hand-off)
@@ -1158,6 +1159,7 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
     m = *hsize;
     MCL_REQUIRE(ctx, m >= 1 && m <= m_cap, "cell compaction failed");
   }
+  ctx->cluster_cells = m;
   std::vector<unsigned long long> key_big;
   std::vector<unsigned int> first_big, count_big;
   std::vector<double> wsum_big, state_big;
@@ -2804,6 +2806,7 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
   else if (key == "host_cycles") *value = ctx->host_cycles;
   else if (key == "field_build_us") *value = static_cast<uint64_t>(ctx->field_build_ms * 1e3);  // kernels of the last device field build
   else if (key == "field_built_on_device") *value = ctx->field_built_on_device ? 1 : 0;
+  else if (key == "cluster_cells") *value = ctx->cluster_cells;
   else return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "mcl_get_counter: unknown counter " + key);
   return MCL_OK;
 }

@@ -944,6 +944,123 @@ def test_cluster_based_estimate_bimodal_cloud_and_update_path():
     f.close()
 
 
+def test_cluster_based_estimate_beyond_the_host_cell_list():
+    """Global localisation on the headline map: 200 000 particles from initialize_from_map() spread over the 4000 x 4000 grid
+    occupy far more hash cells than the mapped host list holds (16 384): the estimate then goes through the second compaction
+    into device arrays and the stream-ordered copies (context.hip, do_cluster_estimate) - the path a round-2 ordering bug sat
+    in.  It is what beluga_ros::Amcl returns while the robot is lost (beluga_ros/src/amcl.cpp:125,
+    cluster_based_estimation.hpp:415-433).  Three sets: uniform weights straight after the initialisation, random weights on
+    the same states, and the set an update() leaves (estimate_kind = cluster based, i.e. the ROS facade's update)."""
+    import bench
+    cells, truth, odoms, scans, _poses = bench.make_workload(2)
+    grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
+    n = 200_000
+    f = new_filter(grid, n)
+    f.initialize_from_map()
+    states, w = f.particles()
+    assert len(w) == n
+    pose, cov = f.cluster_based_estimate()
+    cells_uniform = f.counter("cluster_cells")
+    assert cells_uniform > 16_384, cells_uniform
+    want_pose, want_cov = orc.cluster_based_estimate(states, w)
+    np.testing.assert_allclose(pose, want_pose, atol=1e-9)
+    np.testing.assert_allclose(cov, want_cov, rtol=1e-8, atol=1e-10)
+    # random weights: the cells' priorities differ, the flood fill takes another order
+    w2 = np.random.Generator(np.random.MT19937(8)).gamma(2.0, 1.0, n)
+    f.set_particles(states, w2)
+    pose, cov = f.cluster_based_estimate()
+    assert f.counter("cluster_cells") > 16_384
+    want_pose, want_cov = orc.cluster_based_estimate(states, w2)
+    np.testing.assert_allclose(pose, want_pose, atol=1e-9)
+    np.testing.assert_allclose(cov, want_cov, rtol=1e-8, atol=1e-10)
+    # the update() path with selective resampling (no resampling while the ESS stays above N / 2: the set stays spread out)
+    f.close()
+    params = AmclParams(min_particles=n, max_particles=n, selective_resampling=True)
+    f = Amcl(grid, MOTION, LF, params, seed=11)
+    f.set_estimate_kind(True)
+    f.initialize_from_map()
+    est = f.update(se2_from_xytheta(*odoms[0]), scans[0][::6])
+    assert est is not None
+    s3, w3 = f.particles()
+    if not f.last_info["resampled"]:
+        assert f.counter("cluster_cells") > 16_384
+    want_pose, want_cov = orc.cluster_based_estimate(s3, w3)
+    np.testing.assert_allclose(est[0], want_pose, atol=1e-9)
+    np.testing.assert_allclose(est[1], want_cov, rtol=1e-8, atol=1e-10)
+    f.close()
+
+
+def _free_in_both(grid_a, grid_b, seed, clearance=8):
+    """A pose on a free cell (with clearance) of both maps; both grids share the world frame region around it."""
+    for k in range(200):
+        pose = synth.find_free_pose(grid_a.cells, grid_a.resolution, (grid_a.origin[2], grid_a.origin[3]), seed=seed + k,
+                                    clearance_cells=clearance)
+        bx = int(math.floor((pose[0] - grid_b.origin[2]) / grid_b.resolution))
+        by = int(math.floor((pose[1] - grid_b.origin[3]) / grid_b.resolution))
+        H, W = grid_b.cells.shape
+        if clearance <= bx < W - clearance and clearance <= by < H - clearance and \
+                np.all(grid_b.cells[by - clearance:by + clearance + 1, bx - clearance:bx + clearance + 1] == 0):
+            return pose
+    raise AssertionError("no pose free in both maps")
+
+
+@pytest.mark.parametrize("model", ["likelihood_field", "beam"])
+@pytest.mark.parametrize("n", [3_000, 40_000])
+def test_update_map_on_a_live_filter_follows_the_oracle(model, n):
+    """Amcl::update_map (amcl_core.hpp:150 -> likelihood_field_model_base.hpp:113-116 / beam_model.hpp:154): five cycles, a
+    DIFFERENT map (other obstacles, other size, other origin) on the live filter, five more cycles.  mcl_set_map rebuilds the
+    field, the palette, the far tiles, the bit maps and the beam table; the particles stay.  Every estimate, before and after,
+    against the oracle that takes the same call."""
+    grid_a = rooms_grid(400, 3)
+    cells_b = synth.make_rooms_map(440, 360, seed=9, n_rooms=10)
+    grid_b = OccupancyGrid(cells=cells_b, resolution=0.05, origin=se2_from_xytheta(-11.5, -8.0, 0.0))
+    truth = _free_in_both(grid_a, grid_b, seed=4)
+    if model == "beam":
+        sensor, okw, beams, max_range, tol = BeamModelParam(beam_max_range=10.0), dict(sensor="beam", beam=(0.5, 0.5, 0.05, 0.05, 0.2, 0.1, 10.0)), 60, 10.0, 1e-8
+    else:
+        sensor, okw, beams, max_range, tol = LF, dict(lf=LF_T, lf_model_unknown_space=True), 180, 12.0, 1e-9
+    params = AmclParams(min_particles=n, max_particles=n)
+    gpu = Amcl(grid_a, MOTION, sensor, params, seed=5)
+    gpu.set_option("lf_small_particles", 16_384)
+    cpu = orc.Amcl(min_particles=n, max_particles=n, alphas=MOTION_T, seed=5, **okw)
+    cpu.set_map(grid_a.cells, grid_a.resolution, grid_a.origin)
+    cov = np.diag([0.04, 0.04, 0.01])
+    gpu.initialize(truth, cov)
+    cpu.initialize(truth, cov)
+    pose, odom = truth, (0.0, 0.0, 0.0)
+    grid = grid_a
+    compared = 0
+    for c in range(10):
+        if c == 5:
+            gpu.update_map(grid_b)
+            cpu.set_map(grid_b.cells, grid_b.resolution, grid_b.origin)
+            grid = grid_b
+            if model == "likelihood_field":
+                want = orc.make_likelihood_field(grid_b.cells, grid_b.resolution, LF_T, True, False)
+                assert np.array_equal(gpu.likelihood_field().view(np.uint32), want.view(np.uint32))
+        step = 0.26 if c % 2 == 0 else -0.26  # back and forth (beyond update_min_d each time): stays inside the free region of both maps
+        pose = synth.odometry_step(pose, step, 0.21)
+        odom = synth.odometry_step(odom, step, 0.21)
+        pts = make_scan(grid, pose, beams, max_range=max_range, seed=300 + c)
+        ctrl = se2_from_xytheta(*odom)
+        g = gpu.update(ctrl, pts)
+        o = cpu.update(ctrl, pts)
+        assert (g is None) == (o is None), f"cycle {c}"
+        if g is None:
+            continue
+        gi, oi = gpu.last_info, cpu.last_info
+        assert gi["resampled"] == oi["resampled"] and gi["num_particles"] == len(cpu.particles()[1])
+        assert gi["weight_sum"] == pytest.approx(oi["weight_sum"], rel=1e-9), f"cycle {c}"
+        np.testing.assert_allclose(g[0], o[0], atol=tol, err_msg=f"cycle {c}: pose")
+        np.testing.assert_allclose(g[1], o[1], rtol=1e-7, atol=1e-10, err_msg=f"cycle {c}: covariance")
+        compared += 1
+    assert compared >= 8
+    gs, _ = gpu.particles()
+    os_, _ = cpu.particles()
+    assert int(np.any(np.abs(gs - os_) > 1e-9, axis=1).sum()) <= 3
+    gpu.close()
+
+
 # ---- the two table forms of the default kernel ---------------------------------------------------------------------
 @pytest.mark.parametrize("table", ["palette", "cube"])
 @pytest.mark.parametrize("field_kind", ["distance_map", "arbitrary"])
