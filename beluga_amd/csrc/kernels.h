@@ -158,6 +158,9 @@ struct Tuning {
                                     // it) may go through two half patches (beams [0, k) and [k, 8): 32 x 64 or 64 x 32 cells each); 0 = never
   int lf_margin = 1;                // LDS-patch planner, rotation part of the bound: 1 = per axis (|sin d| |q'y| + (1 - cos d) |q'x|),
                                     // 0 = round 2's |R_p - R_ref| |q| on both axes
+  int lf_pipe = 1;                  // LDS-patch kernel: 1 = persistent workgroups whose producer wave also runs the next block's prologue and
+                                    // the previous block's epilogue (k_reweight_lf_pipe) where it applies, 0 = one workgroup per block
+  int lf_pipe_grid = 0;             // its workgroups: 0 = three per CU, otherwise this many (tests: few workgroups, many blocks each)
 };
 
 // Spatial ordering of the particles (kLfSortedLanes, ordered beam kernel): the 64 lanes of a wave should hold neighbouring
@@ -268,12 +271,14 @@ struct PatchStats {
   uint32_t split_patches;      // 1: a group that fits no whole patch may go through two half patches (Tuning::lf_split)
   double* weight_sums;         // optional: [workgroups] sums of the new weights, one per workgroup of the patch kernel (the
                                // normalisation's input: launch_sum_and_normalize); only written by single-segment launches
+  unsigned int* arrivals;      // k_reweight_lf_pipe: its workgroups count themselves here (wraps at the grid's size: 0 between launches)
 };
 // *weight_sums_written (optional): how many workgroup sums of the new weights the launch left in patch_stats.weight_sums (0: none -
 // another kernel ran, or the launch was segmented)
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
-                        bool dispersed = false, bool* far_tiles_used = nullptr, uint32_t* weight_sums_written = nullptr);
+                        bool dispersed = false, bool* far_tiles_used = nullptr, uint32_t* weight_sums_written = nullptr,
+                        bool* pipe_used = nullptr);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_order_particles first).
 // d_beam_points: scratch of kBeamPointDoubles * B doubles (per-beam terms shared by all particles; ordered variant only).

@@ -1233,6 +1233,67 @@ def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n):
         assert np.array_equal(weights[0], weights[1]), (n, beams, int((weights[0] != weights[1]).sum()))
 
 
+@pytest.mark.parametrize("n,grid_wgs", [(300_000, 0), (300_000, 7), (300_000, 64), (1_000_003, 0), (1_000_003, 96)])
+def test_reweight_lf_pipelined_patch_kernel_equals_the_gather_kernel_bit_for_bit(n, grid_wgs):
+    """k_reweight_lf_pipe: persistent workgroups whose producer wave runs the next block's prologue and the previous block's
+    epilogue beside the patches, which it fetches straight into LDS (the default form of the patch kernel from 262 144 particles
+    on: one scan segment).  Same cells, same sums as the gather kernel: the weights are identical bit for bit - with the
+    default grid (three workgroups per CU: one block each at 300 000 particles, two at a million) and with a few workgroups that
+    take dozens of blocks each (option lf_pipe_grid), over wide clouds (blocks that gather everything, patches clamped at the
+    grid's edges, half patches) and tight ones, scans with a tail of beams (57, 1095), the shortest scan with a group (8) and
+    the longest the plan holds (1095; one more beam goes to k_reweight_lf_patch); the launch's statistics reach the host."""
+    cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
+    grid = OccupancyGrid(cells=cells, resolution=0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
+    truth = synth.find_free_pose(cells, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
+    cases = [(1080, (0.5, 0.5, 0.2)), (1080, (0.1, 0.1, 0.03)), (57, (0.3, 0.3, 0.1)), (1095, (0.1, 0.1, 0.03)), (8, (0.1, 0.1, 0.03)),
+             (1096, (0.1, 0.1, 0.03))]
+    if n > 500_000:
+        cases = cases[:2]
+    for beams, sigma in cases:
+        pts = make_scan(grid, truth, beams, max_range=12.0)
+        weights = []
+        for patch in (2, 0):  # always / never
+            f = new_filter(grid, n)
+            f.set_option("lf_patch", patch)
+            f.set_option("lf_pipe_grid", grid_wgs)
+            f.initialize(truth, np.diag([s * s for s in sigma]))
+            f.reweight(pts)
+            weights.append(f.particles()[1].copy())
+            if patch == 2:
+                assert f.counter("lf_pipe_launches") == (1 if beams <= 1095 else 0), (beams, n)
+                planned, through = f.counter("lf_patch_groups_planned"), f.counter("lf_patch_groups_through")
+                assert planned > 0 and through <= planned
+                if sigma[0] <= 0.1 and beams >= 57:
+                    assert through > 0.8 * planned, (beams, sigma, through, planned)
+            f.close()
+        assert np.array_equal(weights[0], weights[1]), (n, beams, sigma, int((weights[0] != weights[1]).sum()))
+
+
+def test_pipelined_patch_kernel_leaves_the_same_cycle_as_the_block_per_workgroup_form():
+    """Whole cycles (the fused mcl_update: the LF kernel's per-block sums of the new weights feed the normalisation) with
+    k_reweight_lf_pipe and with k_reweight_lf_patch (option lf_pipe = 0): estimates, weights and particle sets are identical
+    bit for bit - the blocks' sums are added in the same tree by either kernel.  A million particles: three blocks per workgroup."""
+    import bench
+    cells, truth, odoms, scans, _poses = bench.make_workload(4)
+    grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
+    n = 1_000_000
+    outs = []
+    for pipe in (1, 0):
+        f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF),
+                 AmclParams(min_particles=n, max_particles=n), seed=42)
+        f.set_option("lf_pipe", pipe)
+        f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+        est = []
+        for c in range(4):
+            e = f.update(se2_from_xytheta(*odoms[c]), scans[c])
+            est.append(np.concatenate([e[0], e[1].ravel(), [f.last_info["weight_sum"]]]))
+        assert f.counter("lf_pipe_launches") == (4 if pipe else 0)
+        outs.append((np.asarray(est), f.particles()))
+        f.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1][0], outs[1][1][0]) and np.array_equal(outs[0][1][1], outs[1][1][1])
+
+
 @pytest.mark.parametrize("options", [
     dict(lf_producer=1, lf_split=3, lf_margin=1, key_curve=1),  # the defaults
     dict(lf_producer=1, lf_split=1), dict(lf_producer=1, lf_split=2), dict(lf_producer=1, lf_split=0, lf_margin=0, key_curve=0, key_bits_xy=6),

@@ -14,7 +14,7 @@ grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIG
 f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF), AmclParams(min_particles=n, max_particles=n), seed=42)
 f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
 lib = capi.load()
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 f.profile_enable(2)
 for c in range(cycles):
     if c in (5, cycles - 1):
@@ -30,5 +30,6 @@ for c in range(cycles):
         ms = p["sensor_kernel"][0] / max(p["sensor_kernel"][1], 1)
         cw, cc, cb, pw, pc, pb, pre, plw = v[:8]
         print(f"cycle {c}: kernel {ms * 1e3:.1f} us; consumer waves {cw}: {cc / cw:.0f} cycles each, {100 * cb / cc:.1f} % at barriers, "
-              f"{100 * pre / cc:.1f} % before the main loop; producer waves {pw}: {pc / max(pw, 1):.0f} cycles each, {100 * pb / max(pc, 1):.1f} % at barriers, {100 * plw / max(pc, 1):.1f} % waiting for loads", flush=True)
+              f"{100 * pre / cc:.1f} % before the main loop; producer waves {pw}: {pc / max(pw, 1):.0f} cycles each, {100 * pb / max(pc, 1):.1f} % at barriers, {100 * plw / max(pc, 1):.1f} % waiting for loads"
+              + (f"; pipe producer: {v[10]} steps, {v[8] / max(v[10], 1):.0f} cycles per step issuing patches, {v[9] / max(v[10], 1):.0f} in slices, {pb / max(v[10], 1):.0f} at barriers, {plw / max(v[10], 1):.0f} waiting for loads; consumers {v[6] / max(cw, 1):.0f} cycles at block starts" if v[10] else ""), flush=True)
 f.close()
