@@ -158,8 +158,9 @@ struct Tuning {
                                     // it) may go through two half patches (beams [0, k) and [k, 8): 32 x 64 or 64 x 32 cells each); 0 = never
   int lf_margin = 1;                // LDS-patch planner, rotation part of the bound: 1 = per axis (|sin d| |q'y| + (1 - cos d) |q'x|),
                                     // 0 = round 2's |R_p - R_ref| |q| on both axes
-  int lf_pipe = 1;                  // LDS-patch kernel: 1 = persistent workgroups whose producer wave also runs the next block's prologue and
-                                    // the previous block's epilogue (k_reweight_lf_pipe) where it applies, 0 = one workgroup per block
+  int lf_pipe = 0;                  // LDS-patch kernel: 1 = persistent workgroups whose producer wave also fetches the next block's poses and
+                                    // writes the previous block's weights (k_reweight_lf_pipe) where it applies, 0 = one workgroup per block.
+                                    // Bit-identical; measured SLOWER (0.51 vs 0.44 ms at 1M x 1080, profiles/r04_lf_pipe_study.txt): off
   int lf_pipe_grid = 0;             // its workgroups: 0 = three per CU, otherwise this many (tests: few workgroups, many blocks each)
 };
 

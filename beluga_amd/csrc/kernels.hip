@@ -879,12 +879,16 @@ __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, 
 // [4] their cycles, [5] of which at barriers, [6] consumer cycles before the main loop (planning), [7] producer cycles waiting for its loads.  Compiled out of the product.
 #ifdef MCL_LF_TIMING
 __device__ unsigned long long g_lf_timing[16];
+#ifdef MCL_LF_TIMING_COARSE  // (no timer around the barriers of the main loop: they distort it 2x)
+#define MCL_LF_BARRIER(statement) statement
+#else
 #define MCL_LF_BARRIER(statement)                         \
   do {                                                    \
     const long long t_b = __builtin_readcyclecounter();   \
     statement;                                            \
     lf_barrier_cycles += __builtin_readcyclecounter() - t_b; \
   } while (0)
+#endif
 #else
 #define MCL_LF_BARRIER(statement) statement
 #endif
@@ -1700,116 +1704,47 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   }
 }
 
-// ---- the patch kernel, persistent and pipelined ------------------------------------------------------------------------
+// ---- the patch kernel, persistent ---------------------------------------------------------------------------------------
 // k_reweight_lf_patch runs 2232 workgroups on 768 slots in three lock-step rounds: every workgroup of a round plans at the same
-// time and writes its weights at the same time, so nothing hides a workgroup's prologue (perm -> pose -> reference pose -> bound ->
-// plan: ~14 us) or its epilogue (perm -> old weight -> product -> scattered store: ~7 us) behind its neighbours' main loops - 60 of
-// the kernel's 450 - 480 us at 1M particles, and the same share at 10M (29 rounds).  Here a workgroup stays resident and takes
-// blocks b, b + gridDim.x, ...; its PRODUCER wave does, while the seven consumer waves run the main loop of block k,
-//   * the epilogue of block k - 1 (the consumers park their sums in LDS and go on),
-//   * the prologue of block k + 1: the 448 poses of the order moved into the table's frame and parked in LDS (the consumers pick
-//     theirs up at the block's first barrier: no dependent global loads on their path), the reference pose, the bound, the plan,
-//   * the patches, as before - but fetched STRAIGHT INTO LDS (buffer_load_dwordx4 ... lds: lane i's 16 bytes land at M0 + 16 i,
-//     tools/calib_lds_direct.hip; a patch is 9 such instructions, its 576 pieces of 16 bytes in buffer order), which leaves the
-//     wave's registers to the side work (the register-staged fetch of k_reweight_lf_patch holds two sets of 32).
-// Only the first prologue and the last epilogue of a workgroup are exposed.  The side work is cut into slices, one per group
-// step, none of which waits for a load it has issued itself (issue in one slice, use in the next).
-// Same plan rule, same patches, same look-ups, same order of additions as k_reweight_lf_patch: the weights are its weights bit
-// for bit (tests/test_gpu_parity.py), and the sums of a block's new weights are added in the same tree.
+// time and writes its weights at the same time, so nothing hides a workgroup's prologue (tables -> perm -> pose -> reference
+// pose -> bound -> plan: ~14 us) or its epilogue (perm -> old weight -> product -> scattered store: ~7 us) behind its neighbours'
+// main loops - 60 of the kernel's 450 - 480 us at 1M particles, and the same share at 10M (29 rounds).  Here a workgroup stays
+// resident and takes blocks b, b + gridDim.x, ...; what its producer wave does beside the patches, while the seven consumer
+// waves run the main loop of block k, is everything of the next block's prologue and of the previous block's epilogue that
+// WAITS FOR MEMORY:
+//   * block k + 1's 448 indices of the order and then their pose records go from global memory straight into LDS (buffer_load ...
+//     lds: no register holds them; lane i's bytes land at M0 + 4 i / 16 i, tools/calib_lds_direct.hip), where the consumers pick
+//     them up at the block's first barrier - no dependent global loads on their path -;
+//   * block k - 1's sums, which the consumers park in the same slots and go on: indices and old weights come the same way, the
+//     products are stored, and the block's sum of new weights is added in k_reweight_lf_patch's order.
+// The arithmetic of the prologue (frame change, reference pose, bound, per-beam records, plan: k_reweight_lf_patch's, a beam or a
+// group per thread) stays with all eight waves at the block's start, and the patches go through the producer's registers two
+// groups ahead as there.  [Built and measured first: ALL of the prologue on the producer wave and the patches fetched straight
+// into LDS - the producer's instruction stream is the workgroup's critical path (every consumer waits for it at each group's
+// barrier): 130 instructions per group made the kernel 2.6 x slower, 40 still 1.2 x, with three LDS buffers a patch has one
+// group's time to arrive, not three (profiles/r04_lf_pipe_study.txt).]
+// Side work is cut into slices of a few dozen instructions, one per group step, none of which waits for a load it has issued
+// itself (issue in one slice, use in a later one).  Only the first block's loads and the last block's epilogue are exposed.
+// Same plan rule, same look-ups, same order of additions as k_reweight_lf_patch: the weights are its weights bit for bit, and so
+// are the blocks' sums of new weights (tests/test_gpu_parity.py).
 // Workgroup memory: no row-offset table (a gathered look-up computes its row: + 4 instructions on the few per cent of the beams
 // that gather) - its 16 KB at 4000 rows hold the parked poses instead; the palette stays at f.pal_base (the table's entries ARE
-// LDS addresses); three patch buffers; two plans (this block's, the next one's).
-// Barriers of a workgroup, per block: A (the block's plan, poses and first patch are visible; the producer is done with the
-// slots' previous contents), B (the consumers have taken their poses and parked the previous block's sums), then one per group
-// from the second group on (none in a block that gathers everything); A and B once more behind the last block, for its sums.
-// Both roles count the same.
-constexpr uint32_t kPipePlanned = 136;                      // groups with a plan entry: scans of up to 1095 points
-constexpr uint32_t kPipePlanBytes = 32 + kPipePlanned * 16;  // header {loose, fitting, groups, -}, then an entry per group: {x0A, y0A | flags, x0B, y0B | first beam of
-                                                             // half B} as in k_reweight_lf_patch; the consumers derive their constants from it on the scalar unit
+// LDS addresses); three patch buffers (the per-beam records of the plan live there before a block's main loop); one plan.
+// A slot = the 64 particles of consumer wave j: 2048 bytes at park + 2048 j, two halves of 16 bytes per lane:
+//   half 0 (+ 16 lane): {c, s} of the parked pose (as the set holds it); its first 8 bytes take the consumer's sum at the block's end
+//   half 1 (+ 1024 + 16 lane): {x, y}; behind barrier B it is four planes of 4 bytes per lane for the epilogue: the particle's
+//   index (+ 0), its old weight (+ 256, + 512), and the next block's index (+ 768).
+// Barriers of a workgroup, per block: A (the block's poses are in their slots; the producer is done with the slots' previous
+// contents), B (the consumers have taken their poses and parked the previous block's sums), the prologue's five, then one per
+// group (none in a block that gathers everything); A and B once more behind the last block, for its sums.  All eight waves
+// count the same.
+constexpr uint32_t kPipePlanned = 136;  // groups with a plan entry: scans of up to 1095 points
 constexpr uint32_t kPipeParkBytes = kPatchParticles * 32;
-constexpr int kPipeSlices = 13;
+constexpr int kPipeSlices = 23;
 struct PipeLds {  // absolute LDS byte addresses, 16-aligned
-  uint32_t patch, plan0, plan1, park, pieces, total;
+  uint32_t patch, plan, park, total;
 };
-constexpr uint32_t kPipePieceBytes = 9 * 64 * 4;  // the lanes' shares of a whole patch's byte offsets, one plane of 64 words per instruction
-struct PipeGroupPlan {
-  int x0a, y0a, x0b, y0b;
-  uint32_t flags, first_b;
-};
-// The plan of one group of 8 beams from its records {cell x, cell y, reach x, reach y} through the reference pose (the rule of
-// k_reweight_lf_patch, see there): a whole 64 x 64 patch, else two halves split at the scan's widest jump, else gathered.
-__device__ __forceinline__ PipeGroupPlan pipe_plan_group(const int4 (&rec)[8], float Dx, float Dy, float Da, float Db, uint32_t isotropic,
-                                                        uint32_t split_patches) {
-  struct Range {
-    int lo_x, hi_x, lo_y, hi_y;
-    float reach_x, reach_y;
-  };
-  auto fits_patch = [&](const Range& r, int PW, int PH, int& x0, int& y0) -> bool {
-    float turn_x, turn_y;  // cells
-    if (isotropic) {
-      turn_x = turn_y = sqrtf(r.reach_x * r.reach_x + r.reach_y * r.reach_y) * 1.002f * (Da * 1.001f);
-    } else {
-      const float A = Da * 1.001f, Bv = Db * 1.001f, qx = r.reach_x * 1.001f, qy = r.reach_y * 1.001f;
-      turn_x = (A * qx + Bv * qy) * 1.001f;
-      turn_y = (Bv * qx + A * qy) * 1.001f;
-    }
-    const float mx = ceilf(Dx + turn_x), my = ceilf(Dy + turn_y);
-    const bool fits = mx < 64.f && my < 64.f;  // false for NaN and infinity
-    const int margin_x = fits ? static_cast<int>(mx) : 0, margin_y = fits ? static_cast<int>(my) : 0;
-    x0 = r.lo_x - margin_x;
-    y0 = (r.lo_y - margin_y) & ~7;
-    return fits && r.hi_x + margin_x - x0 < PW && r.hi_y + margin_y - y0 < PH;
-  };
-  PipeGroupPlan out{0, 0, 0, 0, 0u, 0u};
-  Range all{INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    all.lo_x = min(all.lo_x, rec[k].x);
-    all.hi_x = max(all.hi_x, rec[k].x);
-    all.lo_y = min(all.lo_y, rec[k].y);
-    all.hi_y = max(all.hi_y, rec[k].y);
-    all.reach_x = fmaxf(all.reach_x, __builtin_bit_cast(float, rec[k].z));
-    all.reach_y = fmaxf(all.reach_y, __builtin_bit_cast(float, rec[k].w));
-  }
-  if (fits_patch(all, kPatchW, kPatchH, out.x0a, out.y0a)) {
-    out.flags = 1u;
-    return out;
-  }
-  if (!split_patches) return out;
-  int widest_jump = -1, k_split = 4;
-#pragma unroll
-  for (int k = 1; k < 8; ++k) {
-    const int jump = max(abs(rec[k].x - rec[k - 1].x), abs(rec[k].y - rec[k - 1].y));
-    if (jump > widest_jump) {
-      widest_jump = jump;
-      k_split = k;
-    }
-  }
-  Range ra{INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0.f, 0.f}, rb = ra;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    Range& r = k < k_split ? ra : rb;
-    r.lo_x = min(r.lo_x, rec[k].x);
-    r.hi_x = max(r.hi_x, rec[k].x);
-    r.lo_y = min(r.lo_y, rec[k].y);
-    r.hi_y = max(r.hi_y, rec[k].y);
-    r.reach_x = fmaxf(r.reach_x, __builtin_bit_cast(float, rec[k].z));
-    r.reach_y = fmaxf(r.reach_y, __builtin_bit_cast(float, rec[k].w));
-  }
-  int xa, ya, xb, yb;
-  uint32_t flags = 0u;
-  if ((split_patches & 1u) && fits_patch(ra, kPatchW / 2, kPatchH, xa, ya) && fits_patch(rb, kPatchW / 2, kPatchH, xb, yb)) flags = 1u | 2u;
-  else if ((split_patches & 2u) && fits_patch(ra, kPatchW, kPatchH / 2, xa, ya) && fits_patch(rb, kPatchW, kPatchH / 2, xb, yb)) flags = 1u | 4u;
-  if (flags) {
-    out.x0a = xa;
-    out.y0a = ya;
-    out.x0b = xb;
-    out.y0b = yb;
-    out.flags = flags;
-    out.first_b = static_cast<uint32_t>(k_split);
-  }
-  return out;
-}
+constexpr uint32_t kPipePlanBytes = kPipePlanned * 32 + 64 * 4;  // producer entries, consumer entries, the prologue's partial results
 // A gathered look-up without the row-offset table: the byte offset of the clamped, biased cell (xc, yc) less kFastBiasX's share
 __device__ __forceinline__ uint32_t pipe_gather_offset(uint32_t xc /* biased */, uint32_t yc /* biased */, uint32_t pitch) {
   const uint32_t py = yc + (8u - kFastBias);  // the cell's row + 8 (the border tile), 0 .. H + 8
@@ -1824,6 +1759,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     double* s_pal = reinterpret_cast<double*>(smem + f.pal_base);
     for (uint32_t k = threadIdx.x; k < f.pal_count; k += kPalBlock) s_pal[k] = f.pal_val[k];
   }
+  constexpr uint32_t kConsumers = kPalBlock / 64 - 1;
   constexpr uint32_t kParticles = kPatchParticles;  // 448: seven waves of particles
   const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPalBlock / 64 - 1);
   const uint32_t lane = threadIdx.x & 63;
@@ -1831,457 +1767,447 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   const uint32_t my_blocks = (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x;  // blocks blockIdx.x + k gridDim.x, k < my_blocks (>= 1)
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(f.pal_idx), 0, static_cast<int>(f.pal_bytes), 0x00020000);
-  auto plan_base = [&](uint32_t k) -> uint32_t { return (k & 1u) ? L.plan1 : L.plan0; };  // LDS address of block k's plan
-  auto buffer_of = [&](uint32_t pg) -> uint32_t { return L.patch + (pg - 3u * ((pg * 0xAAABu) >> 17)) * kPatchBytes; };  // (mod 3; pg < 2^16: kept below 3 + 2 groups)
-  auto lds_i4 = [&](uint32_t address) -> int4& { return *reinterpret_cast<int4*>(smem + address); };
+  auto buffer_of = [&](uint32_t g) -> uint32_t { return L.patch + (g - 3u * ((g * 0xAAABu) >> 17)) * kPatchBytes; };  // (g < 2^16) mod 3
+  int4* s_plan = reinterpret_cast<int4*>(smem + L.plan);  // as in k_reweight_lf_patch: {x0A, y0A | flags, x0B, y0B | first beam of half B}
+  int4* s_plan_k = s_plan + kPipePlanned;                 // {KA', meta, KB', -}
+  float* s_bound = reinterpret_cast<float*>(smem + L.plan + kPipePlanned * 32);  // [7][6] partial results, then [7][4], then the counts
+  auto slot = [&](uint32_t j) -> uint32_t { return L.park + 2048u * j; };
+  auto lds_u32 = [&](uint32_t address) -> uint32_t& { return *reinterpret_cast<uint32_t*>(smem + address); };
+  auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-  if (producer) {
-    // =================================================================== the producer ===================================
-    typedef int rsrc_words_t __attribute__((ext_vector_type(4)));
-    const rsrc_words_t rsrc_words = {__builtin_amdgcn_readfirstlane(static_cast<int>(reinterpret_cast<uintptr_t>(f.pal_idx) & 0xFFFFFFFFull)),
-                                     __builtin_amdgcn_readfirstlane(static_cast<int>((reinterpret_cast<uintptr_t>(f.pal_idx) >> 32) & 0xFFFFull)),
-                                     __builtin_amdgcn_readfirstlane(static_cast<int>(f.pal_bytes)), 0x00020000};
-    const int y_last = static_cast<int>((f.H + 7u) & ~7u);  // first row of the bottom border tiles
-#if !(MCL_PIPE_ABLATE & 8)
-    __builtin_amdgcn_s_setprio(3);  // the one wave every other wave of the workgroup waits for at each barrier
-#endif
-    // The patch of group g of the block whose plan sits at `plan`, into `buffer`: piece c = 9 x + r (column x, tile row r; r = 8 is
-    // the column's padding) lies at byte 16 c; instruction i moves pieces 64 i + lane.  Clamped into the bordered table like a
-    // clamped gather; halves as in k_reweight_lf_patch (side by side: columns 32 .. 63 from the second origin; stacked: tile rows 4 .. 7).
-    // This lane's share of a whole patch's byte offsets: instruction i moves piece c = 64 i + lane = 9 x + r -> (x << 4) + r * pitch
-    // (the padding pieces, r = 8, fetch whatever lies there - or nothing beyond the table's end -: nobody reads them).  Kept in
-    // LDS, three reads per group: in registers the side work's slices push them out to scratch memory, and a reload in front of
-    // every fetch waits for the fetch before it (vmcnt counts both) - nine L2 round trips per group (measured: 2.6 x the kernel's
-    // time); derived from the lane's number at every use they cost 130 instructions per group on the one wave whose instruction
-    // stream is the workgroup's critical path (every consumer waits for it at the next barrier).
-#pragma unroll
-    for (uint32_t i = 0; i < 9; ++i) {
-      const uint32_t c = 64u * i + lane;
-      const uint32_t x = (c * 7282u) >> 16, r = c - 9u * x;  // c / 9, c % 9 (c < 576)
-      *reinterpret_cast<uint32_t*>(smem + L.pieces + 256u * i + 4u * lane) = (x << 4) + r * f.pal_pitch;
-    }
-    auto issue_patch = [&](uint32_t plan, uint32_t g, uint32_t buffer) __attribute__((always_inline)) {
-      const int4 e = lds_i4(plan + 32 + 16 * g);
-      const int ya = __builtin_amdgcn_readfirstlane(e.y);
-      if ((ya & 1) == 0) return;  // a gathered group
-      const int x0a = __builtin_amdgcn_readfirstlane(e.x), y0a = ya & ~7;
-      const int xu0 = x0a - static_cast<int>(kFastBias), yu0 = y0a - static_cast<int>(kFastBias);
-      if ((ya & 6) == 0 && xu0 >= -1 && xu0 + kPatchW - 1 <= static_cast<int>(f.W) && yu0 >= -8 && yu0 + kPatchH - 8 <= y_last) {
-        // A whole patch inside the bordered table (19 groups in 20): the group's share of every offset is a scalar, the lane's
-        // a constant - no vector instruction per fetch (the producer's own instructions are the workgroup's critical path:
-        // every consumer waits for it at the next barrier).
-        const uint32_t base = (static_cast<uint32_t>(xu0 + 8) << 4) + (static_cast<uint32_t>(yu0 + 8) >> 3) * f.pal_pitch;
-        uint32_t piece[9];
-#pragma unroll
-        for (uint32_t i = 0; i < 9; ++i) piece[i] = *reinterpret_cast<const uint32_t*>(smem + L.pieces + 256u * i + 4u * lane);
-#pragma unroll
-        for (uint32_t i = 0; i < 9; ++i) {
-          const uint32_t to = __builtin_amdgcn_readfirstlane(buffer + 1024u * i);
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(to), "v"(piece[i]), "s"(rsrc_words), "s"(base) : "memory");
-        }
-        return;
-      }
-      const int yb = __builtin_amdgcn_readfirstlane(e.w), x0b = __builtin_amdgcn_readfirstlane(e.z), y0b = yb & ~7;
-      const bool side_by_side = (ya & 2) != 0, stacked = (ya & 4) != 0;  // scalar
-#pragma unroll 1
-      for (uint32_t i = 0; i < 9; ++i) {
-        const uint32_t c = 64u * i + lane;
-        const uint32_t x = (c * 7282u) >> 16, r = c - 9u * x;  // c / 9, c % 9 (c < 576)
-        int xu = x0a + static_cast<int>(x), yu = y0a + 8 * static_cast<int>(r);
-        if (side_by_side && x >= static_cast<uint32_t>(kPatchW / 2)) {
-          xu = x0b + static_cast<int>(x) - kPatchW / 2;
-          yu = y0b + 8 * static_cast<int>(r);
-        }
-        if (stacked && r >= static_cast<uint32_t>(kPatchH / 16)) {
-          xu = x0b + static_cast<int>(x);
-          yu = y0b + 8 * (static_cast<int>(r) - kPatchH / 16);
-        }
-        xu -= static_cast<int>(kFastBias);
-        yu -= static_cast<int>(kFastBias);
-        // + 8: the border tile's share of palette_row_offset goes into the column, so that no part of the offset is negative
-        const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W)) + 8) << 4;
-        const uint32_t row = (static_cast<uint32_t>(min(max(yu, -8), y_last) + 8) >> 3) * f.pal_pitch;  // palette_row_offset(yc) - 128 (yc a multiple of 8)
-        const uint32_t offset = column + row;
-        const uint32_t to = __builtin_amdgcn_readfirstlane(buffer + 1024u * i);
-        if (r != 8u)
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(to), "v"(offset), "s"(rsrc_words) : "memory");
-      }
+  // ---- the producer's side work (declared for every wave: its lambdas are only called by the producer)
+  typedef int rsrc_words_t __attribute__((ext_vector_type(4)));
+  auto words_of = [&](const void* base, uint64_t bytes) -> rsrc_words_t {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+    const uint32_t size = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(bytes);
+    return rsrc_words_t{__builtin_amdgcn_readfirstlane(static_cast<int>(a & 0xFFFFFFFFull)),
+                        __builtin_amdgcn_readfirstlane(static_cast<int>((a >> 32) & 0xFFFFull)), __builtin_amdgcn_readfirstlane(static_cast<int>(size)), 0x00020000};
+  };
+  auto to_lds_b32 = [&](uint32_t lds, uint32_t offset, const rsrc_words_t& words) __attribute__((always_inline)) {  // lane i's 4 bytes land at lds + 4 i
+    const uint32_t to = __builtin_amdgcn_readfirstlane(lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" : : "s"(to), "v"(offset), "s"(words) : "memory");
+  };
+  auto to_lds_b128 = [&](uint32_t lds, uint32_t offset, const rsrc_words_t& words) __attribute__((always_inline)) {  // lane i's 16 bytes land at lds + 16 i
+    const uint32_t to = __builtin_amdgcn_readfirstlane(lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(to), "v"(offset), "s"(words) : "memory");
+  };
+  auto position_of = [&](uint32_t blk, uint32_t j) -> uint64_t { return static_cast<uint64_t>(blk) * kParticles + 64u * j + lane; };
+  auto index_offset = [&](uint32_t blk, uint32_t j) -> uint32_t {  // byte offset of the particle's entry of perm (the last one's beyond the set)
+    const uint64_t t = position_of(blk, j);
+    return static_cast<uint32_t>(t < n ? t : n - 1) << 2;
+  };
+  uint32_t ep_blk = 0, st_blk = 0;
+  bool ep_on = false, st_on = false;
+  double ep_total = 0.0;
+  // slices 0 .. 6: epilogue indices, 7 .. 13: old weights, 14 .. 20: the products and their sum, 21: staging indices, 22: staging poses
+  // `paced`: called once per group step of a patched block, behind the step's patch fetch (8 loads): what an earlier slice has
+  // asked for is in LDS when all but the 8 youngest loads have returned (vmcnt counts them in order) - waiting for everything would
+  // drain the producer's fetches two groups ahead, a full memory latency in front of the next barrier (measured: + 20 us per block).
+  auto slice = [&](int s, bool paced) __attribute__((always_inline)) {
+    auto landed = [&]() {
+      if (paced) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    auto patches_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-
-    // ---- side work: the epilogue of block `ep_blk` (if any) and the staging of block `st_blk` (if any), in slices
-    // The 80 registers of the kernel belong to the consumers' main loop; the side work keeps a handful of uniform values across
-    // its slices and nothing per particle: indices, pose records and old weights go from global memory STRAIGHT INTO the parked
-    // slots (buffer_load ... lds again), are read back from there by the slice that needs them, and the results overwrite them.
-    // A slot = the 64 particles of consumer wave j: 2048 bytes at park + 2048 j, two halves of 16 bytes per lane:
-    //   half 0 (+ 16 lane): {c, s} of the parked pose (as the set holds it); its first 8 bytes take the consumer's sum at the block's end
-    //   half 1 (+ 1024 + 16 lane): {x, y}; behind barrier B it is four planes of 4 bytes per lane for the epilogue:
-    //   the particle's index (+ 0), its old weight (+ 256, + 512), and the next block's index (+ 768).
-    uint32_t ep_blk = 0, st_blk = 0, st_plan = 0;
-    bool ep_on = false, st_on = false;
-    bool all_small = true;
-    float ref_cf = 1.f, ref_sf = 0.f, ref_xf = 0.f, ref_yf = 0.f;  // the reference pose (uniform; floats by construction)
-    float Dx = 0.f, Dy = 0.f, Da = 0.f, Db = 0.f;
-    uint32_t fitting = 0;
-    auto words_of = [&](const void* base, uint64_t bytes) -> rsrc_words_t {
-      const uintptr_t a = reinterpret_cast<uintptr_t>(base);
-      const uint32_t size = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(bytes);
-      return rsrc_words_t{__builtin_amdgcn_readfirstlane(static_cast<int>(a & 0xFFFFFFFFull)),
-                          __builtin_amdgcn_readfirstlane(static_cast<int>((a >> 32) & 0xFFFFull)), __builtin_amdgcn_readfirstlane(static_cast<int>(size)), 0x00020000};
-    };
-    const bool small_set = n < (1ull << 27);  // byte offsets of the pose records fit 32 bits (the launcher's precondition)
-    (void)small_set;
     const rsrc_words_t perm_words = words_of(perm, n * 4), w_words = words_of(w, n * 8), pose_words = words_of(pose, n * 32);
-    auto to_lds_b32 = [&](uint32_t lds, uint32_t offset, const rsrc_words_t& words) __attribute__((always_inline)) {  // lane i's 4 bytes land at lds + 4 i
-      const uint32_t to = __builtin_amdgcn_readfirstlane(lds);
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" : : "s"(to), "v"(offset), "s"(words) : "memory");
-    };
-    auto to_lds_b128 = [&](uint32_t lds, uint32_t offset, const rsrc_words_t& words) __attribute__((always_inline)) {  // lane i's 16 bytes land at lds + 16 i
-      const uint32_t to = __builtin_amdgcn_readfirstlane(lds);
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(to), "v"(offset), "s"(words) : "memory");
-    };
-    auto slot = [&](uint32_t j) -> uint32_t { return L.park + 2048u * j; };
-    auto lds_u32 = [&](uint32_t address) -> uint32_t& { return *reinterpret_cast<uint32_t*>(smem + address); };
-    auto lds_f64x2 = [&](uint32_t address) -> double2& { return *reinterpret_cast<double2*>(smem + address); };
-    auto position_of = [&](uint32_t blk, uint32_t j) -> uint64_t { return static_cast<uint64_t>(blk) * kParticles + 64u * j + lane; };
-    auto index_offset = [&](uint32_t blk, uint32_t j) -> uint32_t {  // byte offset of the particle's entry of perm (the last one's beyond the set)
-      const uint64_t t = position_of(blk, j);
-      return static_cast<uint32_t>(t < n ? t : n - 1) << 2;
-    };
-    // The parked pose stays as the set holds it (the consumers move it into the table's frame themselves, with the shared
-    // arithmetic: their end-points must be the gather kernel's bit for bit).  The plan needs the poses in the table's frame to
-    // a small fraction of a cell only (its bound carries two cells of slack and factors of 1 + 2^-10): the plain complex product,
-    // without Sophus' renormalisation (1e-16 relative), 10 operations instead of 300.
-    auto frame_pose = [&](uint32_t j, double& c, double& sn, double& x, double& y) __attribute__((always_inline)) {
-      const double2 cs = lds_f64x2(slot(j) + 16u * lane), xy = lds_f64x2(slot(j) + 1024u + 16u * lane);
-      const Pose2& a = f.world_to_field;
-      c = a.r.c * cs.x - a.r.s * cs.y;
-      sn = a.r.c * cs.y + a.r.s * cs.x;
-      x = (a.x + (a.r.c * xy.x - a.r.s * xy.y)) * f.inv_resolution;
-      y = (a.y + (a.r.s * xy.x + a.r.c * xy.y)) * f.inv_resolution;
-    };
-    auto uniform_f32 = [](float v) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-    auto slice = [&](int s) __attribute__((always_inline)) {
-      switch (s) {
-        case 0:  // epilogue: the particles' indices
-          if (ep_on) {
-#pragma unroll 1
-            for (uint32_t j = 0; j < 7; ++j) to_lds_b32(slot(j) + 1024u, index_offset(ep_blk, j), perm_words);
-          }
-          break;
-        case 1:  // their old weights
-          if (ep_on) {
-            patches_landed();
-#pragma unroll 1
-            for (uint32_t j = 0; j < 7; ++j) {
-              const uint32_t at = lds_u32(slot(j) + 1024u + 4u * lane) << 3;
-              to_lds_b32(slot(j) + 1024u + 256u, at, w_words);
-              to_lds_b32(slot(j) + 1024u + 512u, at + 4u, w_words);
-            }
-          }
-          break;
-        case 2:  // the new weights; their sum in the order of k_reweight_lf_patch (the lanes of a wave in wave_sum_f64's tree, then the waves)
-          if (ep_on) {
-            patches_landed();
-            double total = 0.0;
-#pragma unroll 1
-            for (uint32_t j = 0; j < 7; ++j) {
-              const uint64_t t = position_of(ep_blk, j);
-              const double acc = *reinterpret_cast<const double*>(smem + slot(j) + 16u * lane);
-              const uint32_t i = lds_u32(slot(j) + 1024u + 4u * lane);
-              const double old_weight = __hiloint2double(static_cast<int>(lds_u32(slot(j) + 1024u + 512u + 4u * lane)),
-                                                         static_cast<int>(lds_u32(slot(j) + 1024u + 256u + 4u * lane)));
-              double new_weight = 0.0;
-              if (t < n) {
-                new_weight = old_weight * (f.prob ? exp(acc) : acc);
-                w[i] = new_weight;
-              }
-              const double wave_total = wave_sum_f64(new_weight);
-              total = j == 0 ? wave_total : total + wave_total;
-            }
-            if (stats.weight_sums && lane == 0) stats.weight_sums[ep_blk] = total;
-          }
-          break;
-        case 3:  // staging: the particles' indices
-          if (st_on) {
-#pragma unroll 1
-            for (uint32_t j = 0; j < 7; ++j) to_lds_b32(slot(j) + 1024u + 768u, index_offset(st_blk, j), perm_words);
-          }
-          break;
-        case 4:  // their pose records (the two halves of a record overwrite the slot, the index plane - read first - included)
-          if (st_on) {
-            patches_landed();
-#pragma unroll 1
-            for (uint32_t j = 0; j < 7; ++j) {
-              const uint32_t at = lds_u32(slot(j) + 1024u + 768u + 4u * lane) << 5;
-              to_lds_b128(slot(j), at, pose_words);
-              to_lds_b128(slot(j) + 1024u, at + 16u, pose_words);
-            }
-          }
-          break;
-        case 5:  // the reference pose: the middle of the block's box, its mean heading (any pose would do, see k_reweight_lf_patch)
-          if (st_on) {
-            patches_landed();
-            float lo_x = 0.f, hi_x = 0.f, lo_y = 0.f, hi_y = 0.f, sum_c = 0.f, sum_s = 0.f;
-            bool small = true;
-#pragma unroll 1
-            for (uint32_t j = 0; j < 7; ++j) {
-              double c, sn, x, y;
-              frame_pose(j, c, sn, x, y);
-              const float fx = static_cast<float>(x), fy = static_cast<float>(y), fc = static_cast<float>(c), fs = static_cast<float>(sn);
-              lo_x = j == 0 ? fx : fminf(lo_x, fx);
-              hi_x = j == 0 ? fx : fmaxf(hi_x, fx);
-              lo_y = j == 0 ? fy : fminf(lo_y, fy);
-              hi_y = j == 0 ? fy : fmaxf(hi_y, fy);
-              sum_c = j == 0 ? fc : sum_c + fc;
-              sum_s = j == 0 ? fs : sum_s + fs;
-              small = small && fabs(x) < 16000.0 && fabs(y) < 16000.0;  // false for NaN as well (the consumers test 16384 on their own values)
-            }
-            for (int o = 32; o > 0; o >>= 1) {
-              lo_x = fminf(lo_x, __shfl_xor(lo_x, o));
-              hi_x = fmaxf(hi_x, __shfl_xor(hi_x, o));
-              lo_y = fminf(lo_y, __shfl_xor(lo_y, o));
-              hi_y = fmaxf(hi_y, __shfl_xor(hi_y, o));
-              sum_c += __shfl_xor(sum_c, o);
-              sum_s += __shfl_xor(sum_s, o);
-            }
-            const float len = sqrtf(sum_c * sum_c + sum_s * sum_s);
-            ref_cf = uniform_f32(len > 0.f ? sum_c / len : 1.f);  // a NaN stays one, and switches the patches off below
-            ref_sf = uniform_f32(len > 0.f ? sum_s / len : 0.f);
-            ref_xf = uniform_f32(0.5f * (lo_x + hi_x));
-            ref_yf = uniform_f32(0.5f * (lo_y + hi_y));
-            all_small = __builtin_amdgcn_ballot_w64(!small) == 0;
-          }
-          break;
-        case 6:
-        case 7:
-          break;
-        case 8:  // the bound: every particle against the reference pose
-          if (st_on) {
-            const double ref_c = ref_cf, ref_s = ref_sf, ref_x = ref_xf, ref_y = ref_yf;
-            float dx = 0.f, dy = 0.f, da = 0.f, db = 0.f;
-            const double norm2 = ref_c * ref_c + ref_s * ref_s;
-#pragma unroll 1
-            for (uint32_t j = 0; j < 7; ++j) {
-              double ct, st;
-              double2 xy;
-              frame_pose(j, ct, st, xy.x, xy.y);
-              dx = fmaxf(dx, static_cast<float>(fabs(xy.x - ref_x)));
-              dy = fmaxf(dy, static_cast<float>(fabs(xy.y - ref_y)));
-              float a, b;
-              if (stats.isotropic_margin) {
-                const double dc = ct - ref_c, ds = st - ref_s;
-                a = b = static_cast<float>(sqrt(dc * dc + ds * ds));
-              } else {
-                a = static_cast<float>(fabs((ct * ref_c + st * ref_s) / norm2 - 1.0));
-                b = static_cast<float>(fabs((st * ref_c - ct * ref_s) / norm2));
-              }
-              da = fmaxf(da, a);
-              db = fmaxf(db, b);
-            }
-            if (!(all_small && dx < 1e6f && dy < 1e6f && da < 4.f && db < 4.f)) dx = dy = da = db = INFINITY;  // a far or non-finite particle: no patches
-            for (int o = 32; o > 0; o >>= 1) {
-              dx = fmaxf(dx, __shfl_xor(dx, o));
-              dy = fmaxf(dy, __shfl_xor(dy, o));
-              da = fmaxf(da, __shfl_xor(da, o));
-              db = fmaxf(db, __shfl_xor(db, o));
-            }
-            // every float operation of the plan may round down: scaled up by 1 + 2^-10 where it matters, and two cells of slack
-            Dx = uniform_f32(dx * 1.001f + 2.25f);  // (+ 1/4 cell for the plain product above)
-            Dy = uniform_f32(dy * 1.001f + 2.25f);
-            Da = uniform_f32(da);
-            Db = uniform_f32(db);
-            fitting = 0;
-          }
-          break;
-        case 9:
-        case 10:
-        case 11:  // the plan: this lane's group of the slice, through the reference pose
-          if (st_on) {
-            const uint32_t g = 64u * static_cast<uint32_t>(s - 9) + lane;
-            bool fits = false;
-            if (g < groups) {
-              const double rc = static_cast<double>(ref_cf) * f.inv_resolution, rs = static_cast<double>(ref_sf) * f.inv_resolution;
-              const double rxm = static_cast<double>(ref_xf) + kPatchMagic, rym = static_cast<double>(ref_yf) + kPatchMagic;
-              const double2* scan = reinterpret_cast<const double2*>(pts) + 8u * g;
-              int4 rec[8];
-#pragma unroll
-              for (int k = 0; k < 8; ++k) {
-                const double2 q = scan[k];
-                const double sx = __builtin_fma(q.x, rc, __builtin_fma(-q.y, rs, rxm));
-                const double sy = __builtin_fma(q.x, rs, __builtin_fma(q.y, rc, rym));
-                const int cx = static_cast<int>(__builtin_bit_cast(uint64_t, sx) >> 32), cy = static_cast<int>(__builtin_bit_cast(uint64_t, sy) >> 32);
-                const float reach_x = static_cast<float>(fabs(q.x * rc - q.y * rs)), reach_y = static_cast<float>(fabs(q.x * rs + q.y * rc));
-                rec[k] = int4{cx, cy, __builtin_bit_cast(int, reach_x), __builtin_bit_cast(int, reach_y)};
-              }
-              const PipeGroupPlan gp = pipe_plan_group(rec, Dx, Dy, Da, Db, stats.isotropic_margin, stats.split_patches);
-              lds_i4(st_plan + 32 + 16 * g) = int4{gp.x0a, gp.y0a | static_cast<int>(gp.flags), gp.x0b, gp.y0b | static_cast<int>(gp.first_b)};
-              fits = gp.flags != 0u;
-            }
-            fitting += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(fits)));
-          }
-          break;
-        case 12:  // a block with too few of its groups through a patch gathers everything (see k_reweight_lf_patch); the launch's statistics
-          if (st_on) {
-            const bool loose = fitting * 256u < groups * stats.loose_below;
-            if (lane == 0) lds_i4(st_plan) = int4{loose ? 1 : 0, static_cast<int>(fitting), static_cast<int>(groups), 0};
-            // the launch's statistics (what the host picks the next launch's kernel by), from a sample of the blocks
-            const uint32_t stride = nblocks >= 256 ? 16u : 1u;
-            if (stats.device && lane == 0 && st_blk % stride == 0) {
-              atomicAdd(stats.device + 0, static_cast<unsigned long long>(groups));
-              atomicAdd(stats.device + 1, static_cast<unsigned long long>(loose ? 0u : fitting));
-            }
-          }
-          break;
-        default:
-          break;
+    if (s < 7) {
+      if (ep_on) to_lds_b32(slot(s) + 1024u, index_offset(ep_blk, s), perm_words);
+    } else if (s < 14) {
+      if (ep_on) {
+        const uint32_t j = static_cast<uint32_t>(s - 7);
+        landed();
+        const uint32_t at = lds_u32(slot(j) + 1024u + 4u * lane) << 3;
+        to_lds_b32(slot(j) + 1024u + 256u, at, w_words);
+        to_lds_b32(slot(j) + 1024u + 512u, at + 4u, w_words);
       }
-    };
-    // One loop over the workgroup's blocks with a virtual block in front (k = -1: the first block's prologue, all of it, while the
-    // consumers wait at barrier A) and one behind (k = my_blocks: the last block's epilogue), so that the slices have ONE call
-    // site (the compiler keeps the side work's state in registers only if it can inline them).
-    uint32_t pg = 0;  // patched groups so far, over all blocks: the patch of a group goes to buffer pg mod 3
-#ifdef MCL_LF_TIMING
-    const long long lf_t0 = __builtin_readcyclecounter();
-    long long lf_barrier_cycles = 0, lf_load_wait = 0, lf_issue = 0, lf_slices = 0, lf_steps = 0;
-#endif
-#pragma unroll 1
-    for (int k = -1; k <= static_cast<int>(my_blocks); ++k) {
-      const bool real = k >= 0 && k < static_cast<int>(my_blocks);
-      const uint32_t blk = blockIdx.x + static_cast<uint32_t>(k) * gridDim.x;
-      const uint32_t plan = plan_base(static_cast<uint32_t>(k));
-      bool loose = true;
-      if (k >= 0) {
-        __syncthreads();  // A: the side work of the block before (its epilogue's reads of the slots, the staging) is done
-        if (real) loose = __builtin_amdgcn_readfirstlane(lds_i4(plan).x) != 0;
-        __syncthreads();  // B: the poses are taken, the previous block's sums parked (behind the last block: its sums)
-      }
-      ep_on = k > 0;
-      ep_blk = blk - gridDim.x;
-      st_on = k + 1 < static_cast<int>(my_blocks);
-      st_blk = blk + gridDim.x;
-      st_plan = plan_base(static_cast<uint32_t>(k + 1));
-      // behind barrier B the patch of group 0 is visible; behind barrier g that of group g, and the buffer of group g - 2 is free
-      const uint32_t steps = loose ? 1u : groups;
-      int next = 0;
-#pragma unroll 1
-      for (uint32_t g = 0; g < steps; ++g) {
-        if (g > 0) MCL_LF_BARRIER(__syncthreads());
-        const bool last = g + 1 == steps;
-#ifdef MCL_LF_TIMING
-        const long long lf_ti = __builtin_readcyclecounter();
-#endif
-#if (MCL_PIPE_ABLATE & 2)
-        if (!last && g + 1 == 0xFFFFFFu)
-#else
-        if (!last)
-#endif
-          issue_patch(plan, g + 1, buffer_of(pg + g + 1));
-#ifdef MCL_LF_TIMING
-        const long long lf_ts = __builtin_readcyclecounter();
-        lf_issue += lf_ts - lf_ti;
-        lf_steps += 1;
-#endif
-        do {  // one slice per step; whatever is left in the block's last step (the next block's plan must be complete there)
-#if (MCL_PIPE_ABLATE & 4)
-          if (last && next < kPipeSlices) slice(next);
-          if (last) ++next;
-#else
-          if (next < kPipeSlices) slice(next);
-          ++next;
-#endif
-        } while (last && next < kPipeSlices);
-        if (last && st_on) {
-          const uint32_t pg_next = loose ? pg : pg + groups;
-          if (__builtin_amdgcn_readfirstlane(lds_i4(st_plan).x) == 0) issue_patch(st_plan, 0, buffer_of(pg_next));
+    } else if (s < 21) {  // the new weights; their sum in the order of k_reweight_lf_patch (the lanes of a wave in wave_sum_f64's tree, then the waves)
+      if (ep_on) {
+        const uint32_t j = static_cast<uint32_t>(s - 14);
+        landed();
+        const uint64_t t = position_of(ep_blk, j);
+        const double acc = *reinterpret_cast<const double*>(smem + slot(j) + 16u * lane);
+        const uint32_t i = lds_u32(slot(j) + 1024u + 4u * lane);
+        const double old_weight = __hiloint2double(static_cast<int>(lds_u32(slot(j) + 1024u + 512u + 4u * lane)),
+                                                   static_cast<int>(lds_u32(slot(j) + 1024u + 256u + 4u * lane)));
+        double new_weight = 0.0;
+        if (t < n) {
+          new_weight = old_weight * (f.prob ? exp(acc) : acc);
+          w[i] = new_weight;
         }
-#ifdef MCL_LF_TIMING
-        const long long lf_tw = __builtin_readcyclecounter();
-        lf_slices += lf_tw - lf_ts;
-#endif
-#if (MCL_PIPE_ABLATE & 1)
-        if (last)
-#endif
-        patches_landed();
-#ifdef MCL_LF_TIMING
-        lf_load_wait += __builtin_readcyclecounter() - lf_tw;
-#endif
+        const double wave_total = wave_sum_f64(new_weight);
+        ep_total = j == 0 ? wave_total : ep_total + wave_total;
+        if (j == 6 && stats.weight_sums && lane == 0) stats.weight_sums[ep_blk] = ep_total;
       }
-      if (!loose) pg = (pg + groups) % 3u;
-    }
-#ifdef MCL_LF_TIMING
-    if (lane == 0) {
-      atomicAdd(&g_lf_timing[3], 1ull);
-      atomicAdd(&g_lf_timing[4], static_cast<unsigned long long>(__builtin_readcyclecounter() - lf_t0));
-      atomicAdd(&g_lf_timing[5], static_cast<unsigned long long>(lf_barrier_cycles));
-      atomicAdd(&g_lf_timing[7], static_cast<unsigned long long>(lf_load_wait));
-      atomicAdd(&g_lf_timing[8], static_cast<unsigned long long>(lf_issue));
-      atomicAdd(&g_lf_timing[9], static_cast<unsigned long long>(lf_slices));
-      atomicAdd(&g_lf_timing[10], static_cast<unsigned long long>(lf_steps));
-    }
-#endif
-    // The last workgroup to get here copies the running totals of the launch's statistics to the host's mirror.
-    if (stats.device && lane == 0) {
-      __threadfence();
-      // the last workgroup of THIS launch to arrive (a counter that wraps at the grid's size: no state carried between launches)
-      if (atomicInc(stats.arrivals, gridDim.x - 1u) == gridDim.x - 1u && stats.mirror) {
-        const unsigned long long planned = atomicAdd(stats.device + 0, 0ull), through = atomicAdd(stats.device + 1, 0ull);
-        stats.mirror[0] = planned;
-        stats.mirror[1] = through;
-        stats.mirror[2] = (planned & 0xFFFFFFFFull) | (through << 32);  // the pair as ONE word: never torn
+    } else if (s == 21) {  // staging: the particles' indices (the epilogue is done with the slots)
+      if (st_on) {
+#pragma unroll 1
+        for (uint32_t j = 0; j < 7; ++j) to_lds_b32(slot(j) + 1024u + 768u, index_offset(st_blk, j), perm_words);
+      }
+    } else if (s == 22) {  // their pose records (the two halves of a record overwrite the slot, the index plane - read first - included)
+      if (st_on) {
+        landed();
+#pragma unroll 1
+        for (uint32_t j = 0; j < 7; ++j) {
+          const uint32_t at = lds_u32(slot(j) + 1024u + 768u + 4u * lane) << 5;
+          to_lds_b128(slot(j), at, pose_words);
+          to_lds_b128(slot(j) + 1024u, at + 16u, pose_words);
+        }
       }
     }
-    return;
-  }
+  };
 
-  // ===================================================================== the consumers ====================================
+  if (producer) {  // the first block's poses, while the others wait at barrier A
+    st_on = true;
+    st_blk = blockIdx.x;
+    slice(21, false);
+    slice(22, false);
+    landed();
+  }
   const uint32_t opaque_zero = f.pal_bytes >> 31;  // (see k_reweight_lf_patch: keeps the palette addresses 32 bits wide)
   const int c_lo = static_cast<int>(kFastBias) - 1, x_hi = static_cast<int>(kFastBias + f.W), y_hi = static_cast<int>(kFastBias + f.H);
-  uint32_t pg = 0;
   double acc = 0.0;
 #ifdef MCL_LF_TIMING
   const long long lf_t0 = __builtin_readcyclecounter();
-  long long lf_barrier_cycles = 0, lf_block_start = 0;
+  long long lf_barrier_cycles = 0, lf_block_start = 0, lf_slices = 0, lf_steps = 0;
 #endif
 #pragma unroll 1
   for (uint32_t k = 0; k < my_blocks; ++k) {
     const uint32_t blk = blockIdx.x + k * gridDim.x;
-    const uint32_t plan = plan_base(k);
 #ifdef MCL_LF_TIMING
     const long long lf_tb = __builtin_readcyclecounter();
 #endif
-    __syncthreads();  // A: this block's plan, poses and first patch are visible
-    const bool loose = __builtin_amdgcn_readfirstlane(lds_i4(plan).x) != 0;
-    // the parked pose: wave j's slot at park + 2048 j, {c, s} / resolution in its first half, {x, y} / resolution in the second
+    __syncthreads();  // A: this block's poses are in their slots
+    // the parked pose -> the table's frame (likelihood_field_model.hpp:70: the arithmetic of ordered_pose, as the gather kernel does it)
     const uint32_t my_slot = L.park + 2048u * (threadIdx.x >> 6) + 16u * lane;
-    const double2 q_cs = *reinterpret_cast<const double2*>(smem + my_slot), q_xy = *reinterpret_cast<const double2*>(smem + my_slot + 1024u);
-    if (k > 0) *reinterpret_cast<double*>(smem + my_slot) = acc;  // the previous block's sum, for the producer's epilogue
+    Pose2 T = pose_identity();
+    if (!producer) {
+      const double2 q_cs = *reinterpret_cast<const double2*>(smem + my_slot), q_xy = *reinterpret_cast<const double2*>(smem + my_slot + 1024u);
+      if (k > 0) *reinterpret_cast<double*>(smem + my_slot) = acc;  // the previous block's sum, for the producer's epilogue
+      T = pose_mul(f.world_to_field, Pose2{Rot2{q_cs.x, q_cs.y}, q_xy.x, q_xy.y});
+    }
     __syncthreads();  // B
-    const Pose2 T = pose_mul(f.world_to_field, Pose2{Rot2{q_cs.x, q_cs.y}, q_xy.x, q_xy.y});  // likelihood_field_model.hpp:70 (ordered_pose)
-    const double ict = T.r.c * f.inv_resolution, ist = T.r.s * f.inv_resolution, ixt = T.x * f.inv_resolution, iyt = T.y * f.inv_resolution;
+    const double ct = T.r.c, st = T.r.s;
+    const double ict = ct * f.inv_resolution, ist = st * f.inv_resolution, ixt = T.x * f.inv_resolution, iyt = T.y * f.inv_resolution;
     const double ixm = ixt + kPatchMagic, iym = iyt + kPatchMagic;
     const bool lane_small = fabs(ixt) < 16384.0 && fabs(iyt) < 16384.0;  // false for NaN as well
-    const bool fast = __builtin_amdgcn_ballot_w64(!lane_small) == 0;  // per wave: a far particle sends its wave through the exact code
-    acc = f.prob ? 0.0 : 1.0;
+
+    // ---- the prologue's arithmetic, all eight waves (k_reweight_lf_patch: reference pose, bound, per-beam records, plan)
+    float* s_part = s_bound;
+    if (!producer) {
+      float lo_x = static_cast<float>(ixt), hi_x = lo_x, lo_y = static_cast<float>(iyt), hi_y = lo_y;
+      float sum_c = static_cast<float>(ct), sum_s = static_cast<float>(st);
+      for (int o = 32; o > 0; o >>= 1) {
+        lo_x = fminf(lo_x, __shfl_xor(lo_x, o));
+        hi_x = fmaxf(hi_x, __shfl_xor(hi_x, o));
+        lo_y = fminf(lo_y, __shfl_xor(lo_y, o));
+        hi_y = fmaxf(hi_y, __shfl_xor(hi_y, o));
+        sum_c += __shfl_xor(sum_c, o);
+        sum_s += __shfl_xor(sum_s, o);
+      }
+      if (lane == 0) {
+        float* mine = s_part + 6 * (threadIdx.x >> 6);
+        mine[0] = lo_x;
+        mine[1] = hi_x;
+        mine[2] = lo_y;
+        mine[3] = hi_y;
+        mine[4] = sum_c;
+        mine[5] = sum_s;
+      }
+    }
+    __syncthreads();
+    double ref_c, ref_s, ref_x, ref_y;
+    {
+      float lo_x = s_part[0], hi_x = s_part[1], lo_y = s_part[2], hi_y = s_part[3], sum_c = s_part[4], sum_s = s_part[5];
+      for (uint32_t q = 1; q < kConsumers; ++q) {
+        lo_x = fminf(lo_x, s_part[6 * q]);
+        hi_x = fmaxf(hi_x, s_part[6 * q + 1]);
+        lo_y = fminf(lo_y, s_part[6 * q + 2]);
+        hi_y = fmaxf(hi_y, s_part[6 * q + 3]);
+        sum_c += s_part[6 * q + 4];
+        sum_s += s_part[6 * q + 5];
+      }
+      const float len = sqrtf(sum_c * sum_c + sum_s * sum_s);
+      ref_c = len > 0.f ? static_cast<double>(sum_c / len) : 1.0;  // a NaN stays one, and switches the patches off below
+      ref_s = len > 0.f ? static_cast<double>(sum_s / len) : 0.0;
+      ref_x = static_cast<double>(0.5f * (lo_x + hi_x));
+      ref_y = static_cast<double>(0.5f * (lo_y + hi_y));
+    }
+    const double rc = ref_c * f.inv_resolution, rs = ref_s * f.inv_resolution;
+    const double rxm = ref_x + kPatchMagic, rym = ref_y + kPatchMagic;
+    __syncthreads();  // the partial results are read; their place takes the next ones
+    if (!producer) {
+      const double dc = ct - ref_c, ds = st - ref_s;
+      float dx = static_cast<float>(fabs(ixt - ref_x)), dy = static_cast<float>(fabs(iyt - ref_y));
+      float da, db;
+      if (stats.isotropic_margin) {
+        da = db = static_cast<float>(sqrt(dc * dc + ds * ds));
+      } else {
+        const double norm2 = ref_c * ref_c + ref_s * ref_s;
+        da = static_cast<float>(fabs((ct * ref_c + st * ref_s) / norm2 - 1.0));
+        db = static_cast<float>(fabs((st * ref_c - ct * ref_s) / norm2));
+      }
+      if (!(lane_small && dx < 1e6f && dy < 1e6f && da < 4.f && db < 4.f)) dx = dy = da = db = INFINITY;  // a far or non-finite particle: no patches
+      for (int o = 32; o > 0; o >>= 1) {
+        dx = fmaxf(dx, __shfl_xor(dx, o));
+        dy = fmaxf(dy, __shfl_xor(dy, o));
+        da = fmaxf(da, __shfl_xor(da, o));
+        db = fmaxf(db, __shfl_xor(db, o));
+      }
+      if (lane == 0) {
+        float* mine = s_bound + 4 * (threadIdx.x >> 6);
+        mine[0] = dx;
+        mine[1] = dy;
+        mine[2] = da;
+        mine[3] = db;
+      }
+    }
+    // the scan through the reference pose, a beam per thread: 16-byte records in the patch buffers (idle before the main loop)
+    int4* s_beam = reinterpret_cast<int4*>(smem + L.patch);
+    {
+      const double2* scan = reinterpret_cast<const double2*>(pts);
+#pragma unroll
+      for (uint32_t pass = 0; pass < (kPipePlanned * 8 + kPalBlock - 1) / kPalBlock; ++pass) {
+        const uint32_t b = pass * kPalBlock + threadIdx.x;
+        if (b < groups * 8) {
+          const double2 p = scan[b];
+          const double sx = __builtin_fma(p.x, rc, __builtin_fma(-p.y, rs, rxm));
+          const double sy = __builtin_fma(p.x, rs, __builtin_fma(p.y, rc, rym));
+          const int cx = static_cast<int>(__builtin_bit_cast(uint64_t, sx) >> 32), cy = static_cast<int>(__builtin_bit_cast(uint64_t, sy) >> 32);
+          const float reach_x = static_cast<float>(fabs(p.x * rc - p.y * rs)), reach_y = static_cast<float>(fabs(p.x * rs + p.y * rc));
+          s_beam[b] = int4{cx, cy, __builtin_bit_cast(int, reach_x), __builtin_bit_cast(int, reach_y)};
+        }
+      }
+    }
+    __syncthreads();
+    bool mine_fits = false;
+    if (threadIdx.x < groups) {  // the plan: thread g looks at group g through the reference pose
+      float Dx = 0.f, Dy = 0.f, Da = 0.f, Db = 0.f;
+      for (uint32_t q = 0; q < kConsumers; ++q) {
+        Dx = fmaxf(Dx, s_bound[4 * q]);
+        Dy = fmaxf(Dy, s_bound[4 * q + 1]);
+        Da = fmaxf(Da, s_bound[4 * q + 2]);
+        Db = fmaxf(Db, s_bound[4 * q + 3]);
+      }
+      // every float operation below may round down: scaled up by 1 + 2^-10 where it matters, and two cells of slack
+      Dx = Dx * 1.001f + 2.f;
+      Dy = Dy * 1.001f + 2.f;
+      int4 rec[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rec[q] = s_beam[8 * threadIdx.x + q];
+      struct Range {
+        int lo_x, hi_x, lo_y, hi_y;
+        float reach_x, reach_y;
+      };
+      auto fits_patch = [&](const Range& r, int PW, int PH, int& x0, int& y0) -> bool {
+        float turn_x, turn_y;  // cells
+        if (stats.isotropic_margin) {  // |q'| <= sqrt(max q'x^2 + max q'y^2)
+          turn_x = turn_y = sqrtf(r.reach_x * r.reach_x + r.reach_y * r.reach_y) * 1.002f * (Da * 1.001f);
+        } else {
+          const float A = Da * 1.001f, Bv = Db * 1.001f, qx = r.reach_x * 1.001f, qy = r.reach_y * 1.001f;
+          turn_x = (A * qx + Bv * qy) * 1.001f;
+          turn_y = (Bv * qx + A * qy) * 1.001f;
+        }
+        const float mx = ceilf(Dx + turn_x), my = ceilf(Dy + turn_y);
+        const bool fits = mx < 64.f && my < 64.f;  // false for NaN and infinity
+        const int margin_x = fits ? static_cast<int>(mx) : 0, margin_y = fits ? static_cast<int>(my) : 0;
+        x0 = r.lo_x - margin_x;
+        y0 = (r.lo_y - margin_y) & ~7;
+        return fits && r.hi_x + margin_x - x0 < PW && r.hi_y + margin_y - y0 < PH;
+      };
+      Range all{INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        all.lo_x = min(all.lo_x, rec[q].x);
+        all.hi_x = max(all.hi_x, rec[q].x);
+        all.lo_y = min(all.lo_y, rec[q].y);
+        all.hi_y = max(all.hi_y, rec[q].y);
+        all.reach_x = fmaxf(all.reach_x, __builtin_bit_cast(float, rec[q].z));
+        all.reach_y = fmaxf(all.reach_y, __builtin_bit_cast(float, rec[q].w));
+      }
+      int x0a = 0, y0a = 0, x0b = 0, y0b = 0;
+      uint32_t flags = 0u, first_b = 0u;
+      if (fits_patch(all, kPatchW, kPatchH, x0a, y0a)) {
+        flags = 1u;
+      } else if (stats.split_patches) {
+        // split where the scan jumps: between the two consecutive beams whose end-points lie farthest apart (the first such pair)
+        int widest_jump = -1, k_split = 4;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+          const int jump = max(abs(rec[q].x - rec[q - 1].x), abs(rec[q].y - rec[q - 1].y));
+          if (jump > widest_jump) {
+            widest_jump = jump;
+            k_split = q;
+          }
+        }
+        Range ra{INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0.f, 0.f}, rb = ra;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {  // (k_split is a run-time value: both halves in one pass)
+          Range& r = q < k_split ? ra : rb;
+          r.lo_x = min(r.lo_x, rec[q].x);
+          r.hi_x = max(r.hi_x, rec[q].x);
+          r.lo_y = min(r.lo_y, rec[q].y);
+          r.hi_y = max(r.hi_y, rec[q].y);
+          r.reach_x = fmaxf(r.reach_x, __builtin_bit_cast(float, rec[q].z));
+          r.reach_y = fmaxf(r.reach_y, __builtin_bit_cast(float, rec[q].w));
+        }
+        int xa, ya, xb, yb;
+        if ((stats.split_patches & 1u) && fits_patch(ra, kPatchW / 2, kPatchH, xa, ya) && fits_patch(rb, kPatchW / 2, kPatchH, xb, yb)) flags = 1u | 2u;
+        else if ((stats.split_patches & 2u) && fits_patch(ra, kPatchW, kPatchH / 2, xa, ya) && fits_patch(rb, kPatchW, kPatchH / 2, xb, yb)) flags = 1u | 4u;
+        if (flags) {
+          x0a = xa;
+          y0a = ya;
+          x0b = xb;
+          y0b = yb;
+          first_b = static_cast<uint32_t>(k_split);
+        }
+      }
+      s_plan[threadIdx.x] = int4{x0a, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
+      {
+        const uint32_t ka = 0u - (static_cast<uint32_t>(x0a) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0a) << 1);
+        // half B lives in columns 32 .. 63 (side by side) or in rows 32 .. 63 (stacked) of the same buffer
+        const uint32_t kb = ((flags & 2u) ? (kPatchW / 2) * kPatchPitch : static_cast<uint32_t>(kPatchH)) -
+                            (static_cast<uint32_t>(x0b) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0b) << 1);
+        const uint32_t meta = flags == 0u ? 0u : ((flags & 6u) ? first_b : 8u);
+        s_plan_k[threadIdx.x] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), 0};
+      }
+      mine_fits = flags != 0u;
+    }
+    // a block with too few of its groups through a patch drops the machinery (see k_reweight_lf_patch)
+    uint32_t* s_count = reinterpret_cast<uint32_t*>(s_bound) + 4 * kConsumers;  // behind the bound's [7][4]
+    {
+      const uint32_t in_wave = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine_fits)));
+      if (lane == 0) s_count[threadIdx.x >> 6] = in_wave;
+    }
+    __syncthreads();
+    uint32_t fitting = 0;
+    for (uint32_t q = 0; q < kPalBlock / 64; ++q) fitting += s_count[q];
+    const bool loose = __builtin_amdgcn_readfirstlane(fitting) * 256u < groups * stats.loose_below;
 #ifdef MCL_LF_TIMING
     lf_block_start += __builtin_readcyclecounter() - lf_tb;
 #endif
+
+    if (producer) {
+      // ============================================================== the producer's main loop ==========================
+      // the launch's statistics (what the host picks the next launch's kernel by), from a sample of the blocks
+      {
+        const uint32_t stride = nblocks >= 256 ? 16u : 1u;
+        if (stats.device && lane == 0 && blk % stride == 0) {
+          atomicAdd(stats.device + 0, static_cast<unsigned long long>(groups));
+          atomicAdd(stats.device + 1, static_cast<unsigned long long>(loose ? 0u : fitting));
+        }
+      }
+      ep_on = k > 0;
+      ep_blk = blk - gridDim.x;
+      st_on = k + 1 < my_blocks;
+      st_blk = blk + gridDim.x;
+      int next = 0;
+#if (MCL_PIPE_ABLATE & 16)
+      __builtin_amdgcn_s_setprio(3);
+#endif
+      if (!loose) {
+        const int y_last = static_cast<int>((f.H + 7u) & ~7u);  // first row of the bottom border tiles
+        using Pieces = uint4[kPatchH / 8];
+        const uint32_t last_planned = groups - 1u;
+        auto fetch = [&](uint32_t g, Pieces& piece) {  // (k_reweight_lf_patch)
+          const int4 e = s_plan[g < last_planned ? g : last_planned];
+          const int ya = __builtin_amdgcn_readfirstlane(e.y);
+          const int x0a = __builtin_amdgcn_readfirstlane(e.x), y0a = ya & ~7;
+          if ((ya & 6) == 0) {  // one whole patch (or none: then nobody reads it): this lane's column, scalar row offsets
+            const int xu = x0a + static_cast<int>(lane) - static_cast<int>(kFastBias);
+            const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W)) + 8) << 4;
+#pragma unroll
+            for (int r = 0; r < kPatchH / 8; ++r) {
+              const int yu = y0a + 8 * r - static_cast<int>(kFastBias);
+              const int yc = min(max(yu, -8), y_last);  // scalar
+              piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, column, palette_row_offset(yc, f.pal_pitch) - 128u, 0));
+            }
+            return;
+          }
+          const int yb = __builtin_amdgcn_readfirstlane(e.w), x0b = __builtin_amdgcn_readfirstlane(e.z), y0b = yb & ~7;
+          const bool side_by_side = (ya & 2) != 0, stacked = (ya & 4) != 0;  // scalar
+          const bool half_b = side_by_side && lane >= static_cast<uint32_t>(kPatchW / 2);
+          const int xu = (half_b ? x0b + static_cast<int>(lane) - kPatchW / 2 : x0a + static_cast<int>(lane)) - static_cast<int>(kFastBias);
+          const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W)) + 8) << 4;
+          const int xu_low = (stacked ? x0b : x0a) + static_cast<int>(lane) - static_cast<int>(kFastBias);
+          const uint32_t column_low = stacked ? static_cast<uint32_t>(min(max(xu_low, -1), static_cast<int>(f.W)) + 8) << 4 : column;
+#pragma unroll
+          for (int r = 0; r < kPatchH / 8; ++r) {
+            const bool low = r >= kPatchH / 16;
+            const int yu_a = ((stacked && low) ? y0b + 8 * (r - kPatchH / 16) : y0a + 8 * r) - static_cast<int>(kFastBias);
+            const int yu_b = y0b + 8 * r - static_cast<int>(kFastBias);
+            const uint32_t row_a = palette_row_offset(min(max(yu_a, -8), y_last), f.pal_pitch) - 128u;  // scalar
+            const uint32_t row_b = palette_row_offset(min(max(yu_b, -8), y_last), f.pal_pitch) - 128u;  // scalar
+            piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (low ? column_low : column) + (half_b ? row_b : row_a), 0, 0));
+          }
+        };
+        auto store = [&](uint32_t g, const Pieces& piece) {
+          unsigned char* dst = smem + buffer_of(g) + lane * kPatchPitch;
+#pragma unroll
+          for (int r = 0; r < kPatchH / 8; ++r) *reinterpret_cast<uint4*>(dst + r * 16) = piece[r];
+        };
+        Pieces even, odd;
+        fetch(0, even);
+        store(0, even);
+        fetch(1, odd);
+        fetch(2, even);
+        uint32_t g = 0;
+        for (; g + 1 < groups; g += 2) {
+          MCL_LF_BARRIER(__syncthreads());  // the consumers are done with group g - 1: its buffer takes the patch of g + 1
+          store(g + 1, odd);
+          fetch(g + 3, odd);
+#ifdef MCL_LF_TIMING
+          const long long lf_ts0 = __builtin_readcyclecounter();
+#endif
+#if !(MCL_PIPE_ABLATE & 4)
+          if (next < kPipeSlices) slice(next, true);
+          ++next;
+#endif
+#ifdef MCL_LF_TIMING
+          lf_slices += __builtin_readcyclecounter() - lf_ts0;
+          lf_steps += 2;
+#endif
+          MCL_LF_BARRIER(__syncthreads());
+          store(g + 2, even);
+          fetch(g + 4, even);
+#ifdef MCL_LF_TIMING
+          const long long lf_ts1 = __builtin_readcyclecounter();
+#endif
+#if !(MCL_PIPE_ABLATE & 4)
+          if (next < kPipeSlices) slice(next, true);
+          ++next;
+#endif
+#ifdef MCL_LF_TIMING
+          lf_slices += __builtin_readcyclecounter() - lf_ts1;
+#endif
+        }
+        if (g < groups) __syncthreads();
+      }
+#pragma unroll 1
+      for (; next < kPipeSlices; ++next) slice(next, false);  // whatever the block's steps have left (a short scan; a block that gathers everything)
+      landed();
+      continue;
+    }
+
+    // ================================================================ the consumers' main loop ============================
+    acc = f.prob ? 0.0 : 1.0;
+    const bool fast = __builtin_amdgcn_ballot_w64(!lane_small) == 0;  // per wave: a far particle sends its wave through the exact code
+    struct Plan {  // scalars
+      uint32_t ka;    // less the buffer's base
+      uint32_t meta;  // 0: gathered, 8: one whole patch, 1 .. 7: two halves, the second one from this beam on
+    };
     struct Lookups {
       uint32_t e[8];  // palette addresses (LDS byte addresses of the f64 terms)
       uint32_t redo;  // 1: the group is added by add_exact instead
-    };
-    auto particle_again = [&](uint64_t& position) -> uint32_t {  // (the cold path fetches what it needs: the consumers never saw perm or pose)
-      position = static_cast<uint64_t>(blk) * kParticles + threadIdx.x;
-      return perm[position < n ? position : n - 1];
     };
     auto exact_fetch = [&](int xi, int yi) -> uint32_t {  // lf_palette_fetch without the row-offset table
       const uint32_t xc = static_cast<uint32_t>(clamp_cell(xi, f.W)) + kFastBias, yc = static_cast<uint32_t>(clamp_cell(yi, f.H)) + kFastBias;
       return static_cast<uint32_t>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, pipe_gather_offset(xc, yc, f.pal_pitch), 0, 0)));
     };
+    // The separately rounded evaluation, beam by beam with plain gathers (4 in 2^32 end-points; the tail of the scan).  It needs
+    // the pose as the reference holds it (not pre-multiplied by 1 / res): fetched again here, from global memory, rather than kept.
     auto add_exact = [&](uint32_t b0, uint32_t count) {
       if (count == 0) return;
-      uint64_t position;
-      const Pose2 T_again = ordered_pose(f.world_to_field, pose, particle_again(position));
+      const uint64_t position = static_cast<uint64_t>(blk) * kParticles + threadIdx.x;
+      const Pose2 T_again = ordered_pose(f.world_to_field, pose, perm[position < n ? position : n - 1]);
       const double ct = T_again.r.c, st = T_again.r.s, xt = T_again.x, yt = T_again.y;
       auto term = [&](uint32_t at) {
         const double px = pts[2 * at], py = pts[2 * at + 1];
@@ -2317,22 +2243,17 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     auto step = [&](auto is_loose, auto add_before, uint32_t g_any, Lookups& now, const Lookups& before) {
       const uint32_t g = __builtin_amdgcn_readfirstlane(g_any);
       const uint32_t b0 = 8 * g;
-      uint32_t ka = 0u, meta = 0u;
+      Plan plan{0u, 0u};
       if constexpr (!decltype(is_loose)::value) {
-        // the group's plan entry; its constants (cell (cx, cy) of the patch sits at cx * pitch + cy * 2 + K) on the scalar unit
-        const int2 e = *reinterpret_cast<const int2*>(smem + plan + 32 + 16 * g);
-        const uint32_t x0a = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.x)), ya = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
-        ka = 0u - (x0a & 0xFFFFFFu) * kPatchPitch - ((ya & ~7u) << 1);
-        const uint32_t flags = ya & 7u;
-        meta = flags == 0u ? 0u : ((flags & 6u) ? 9u : 8u);  // 9: two halves (the split point is read with the second origin)
+        const int2 e = *reinterpret_cast<const int2*>(s_plan_k + g);
+        plan.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.x));
+        plan.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
       }
-      const uint32_t buffer = buffer_of(pg + g);
-      if constexpr (!decltype(is_loose)::value) {
-        if (g > 0) {  // (group 0: barrier B)  a bare barrier, see k_reweight_lf_patch: the producer's side keeps the fence
-          asm volatile("" ::: "memory");
-          MCL_LF_BARRIER(__builtin_amdgcn_s_barrier());
-          asm volatile("" ::: "memory");
-        }
+      const uint32_t buffer = buffer_of(g);
+      if constexpr (!decltype(is_loose)::value) {  // a bare barrier, see k_reweight_lf_patch: the producer's side keeps the fence
+        asm volatile("" ::: "memory");
+        MCL_LF_BARRIER(__builtin_amdgcn_s_barrier());
+        asm volatile("" ::: "memory");
       }
       now.redo = 1u;
       if (!fast) {
@@ -2353,24 +2274,18 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         cy[kk] = static_cast<int>(by >> 32);
       }
       if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
-      if (meta == 8u) {  // one whole patch (19 groups in 20): one constant for the eight look-ups
-        const uint32_t K = buffer + ka;
+      if (plan.meta == 8u) {  // one whole patch (19 groups in 20): one constant for the eight look-ups
+        const uint32_t K = buffer + plan.ka;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
           const uint32_t at = mad_u24(static_cast<uint32_t>(cx[kk]), kPatchPitch, lshl_add_u32_uniform(static_cast<uint32_t>(cy[kk]), 1, K));
           now.e[kk] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(static_cast<uintptr_t>(at)));
         }
-      } else if (meta != 0u) {  // two halves: the beams from the split point on read the second one
-        const int4 e = lds_i4(plan + 32 + 16 * g);
-        const uint32_t ya = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
-        const uint32_t x0b = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.z)), yb = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.w));
-        const uint32_t first_b = yb & 7u;
-        // half B lives in columns 32 .. 63 (side by side) or in rows 32 .. 63 (stacked) of the same buffer
-        const uint32_t kb = ((ya & 2u) ? (kPatchW / 2) * kPatchPitch : static_cast<uint32_t>(kPatchH)) - (x0b & 0xFFFFFFu) * kPatchPitch - ((yb & ~7u) << 1);
-        const uint32_t KA = buffer + ka, KB = buffer + kb;
+      } else if (plan.meta != 0u) {  // two halves: the beams from plan.meta on read the second one
+        const uint32_t KA = buffer + plan.ka, KB = buffer + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_plan_k[g].z));
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-          const uint32_t K = static_cast<uint32_t>(kk) < first_b ? KA : KB;  // scalar
+          const uint32_t K = static_cast<uint32_t>(kk) < plan.meta ? KA : KB;  // scalar
           now.e[kk] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(
               static_cast<uintptr_t>(mad_u24(static_cast<uint32_t>(cx[kk]), kPatchPitch, lshl_add_u32_uniform(static_cast<uint32_t>(cy[kk]), 1, K)))));
         }
@@ -2400,25 +2315,63 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       }
       consume(a, 8 * groups - 8);
     };
-    if (loose) {
-      run(std::true_type{});
-    } else {
-      run(std::false_type{});
-      pg = (pg + groups) % 3u;
-    }
+    if (loose) run(std::true_type{});
+    else run(std::false_type{});
     add_exact(8 * groups, B - 8 * groups);
   }
 #ifdef MCL_LF_TIMING
   if (lane == 0) {
-    atomicAdd(&g_lf_timing[0], 1ull);
-    atomicAdd(&g_lf_timing[1], static_cast<unsigned long long>(__builtin_readcyclecounter() - lf_t0));
-    atomicAdd(&g_lf_timing[2], static_cast<unsigned long long>(lf_barrier_cycles));
-    atomicAdd(&g_lf_timing[6], static_cast<unsigned long long>(lf_block_start));
+    const int o = producer ? 3 : 0;
+    atomicAdd(&g_lf_timing[o], 1ull);
+    atomicAdd(&g_lf_timing[o + 1], static_cast<unsigned long long>(__builtin_readcyclecounter() - lf_t0));
+    atomicAdd(&g_lf_timing[o + 2], static_cast<unsigned long long>(lf_barrier_cycles));
+    if (producer) {
+      atomicAdd(&g_lf_timing[9], static_cast<unsigned long long>(lf_slices));
+      atomicAdd(&g_lf_timing[10], static_cast<unsigned long long>(lf_steps));
+      atomicAdd(&g_lf_timing[11], static_cast<unsigned long long>(lf_block_start));
+    } else {
+      atomicAdd(&g_lf_timing[6], static_cast<unsigned long long>(lf_block_start));
+    }
   }
 #endif
-  __syncthreads();  // A: the producer has read the sums of the block before the last one out of the slots
-  *reinterpret_cast<double*>(smem + L.park + 2048u * (threadIdx.x >> 6) + 16u * lane) = acc;
-  __syncthreads();  // B: the last block's sums are parked
+  // ---- behind the last block: its epilogue by the consumers themselves, all lanes at once (k_reweight_lf_patch's; on the producer
+  // alone it is seven dependent rounds of loads with nothing to hide them behind)
+  {
+    const uint32_t blk = blockIdx.x + (my_blocks - 1) * gridDim.x;
+    double new_weight = 0.0;
+    if (!producer) {
+      const uint64_t t = static_cast<uint64_t>(blk) * kParticles + threadIdx.x;
+      if (t < n) {
+        const uint32_t i = perm[t];
+        new_weight = w[i] * (f.prob ? exp(acc) : acc);
+        w[i] = new_weight;
+      }
+    }
+    __syncthreads();  // (the plan's memory is free: every wave is out of the main loop)
+    if (stats.weight_sums) {
+      double* s_sum = reinterpret_cast<double*>(smem + L.plan);
+      const double wave_total = wave_sum_f64(new_weight);
+      if (!producer && lane == 0) s_sum[threadIdx.x >> 6] = wave_total;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double total = s_sum[0];
+        for (uint32_t q = 1; q < kConsumers; ++q) total += s_sum[q];
+        stats.weight_sums[blk] = total;
+      }
+    }
+  }
+  if (!producer) return;
+  // The last workgroup to get here copies the running totals of the launch's statistics to the host's mirror.
+  if (stats.device && lane == 0) {
+    __threadfence();
+    // the last workgroup of THIS launch to arrive (a counter that wraps at the grid's size: no state carried between launches)
+    if (atomicInc(stats.arrivals, gridDim.x - 1u) == gridDim.x - 1u && stats.mirror) {
+      const unsigned long long planned = atomicAdd(stats.device + 0, 0ull), through = atomicAdd(stats.device + 1, 0ull);
+      stats.mirror[0] = planned;
+      stats.mirror[1] = through;
+      stats.mirror[2] = (planned & 0xFFFFFFFFull) | (through << 32);  // the pair as ONE word: never torn
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_lf_combine(double* __restrict__ w, uint64_t n, const uint32_t* __restrict__ perm,
@@ -4965,9 +4918,7 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
         };
         pipe.park = place(kPipeParkBytes);
         pipe.patch = place(3 * kPatchBytes);
-        pipe.plan0 = place(kPipePlanBytes);
-        pipe.plan1 = place(kPipePlanBytes);
-        pipe.pieces = place(kPipePieceBytes);
+        pipe.plan = place(kPipePlanBytes);
         pipe.total = high;
         pipe_ok = pipe.total <= 53248;  // three workgroups per CU (tools/calib_lds_residency.hip)
       }

@@ -1235,9 +1235,9 @@ def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n):
 
 @pytest.mark.parametrize("n,grid_wgs", [(300_000, 0), (300_000, 7), (300_000, 64), (1_000_003, 0), (1_000_003, 96)])
 def test_reweight_lf_pipelined_patch_kernel_equals_the_gather_kernel_bit_for_bit(n, grid_wgs):
-    """k_reweight_lf_pipe: persistent workgroups whose producer wave runs the next block's prologue and the previous block's
-    epilogue beside the patches, which it fetches straight into LDS (the default form of the patch kernel from 262 144 particles
-    on: one scan segment).  Same cells, same sums as the gather kernel: the weights are identical bit for bit - with the
+    """k_reweight_lf_pipe (option lf_pipe = 1): persistent workgroups whose producer wave fetches the next block's poses straight
+    into LDS and writes the previous block's weights beside the patches (from 262 144 particles on: one scan segment).  Same
+    cells, same sums as the gather kernel: the weights are identical bit for bit - with the
     default grid (three workgroups per CU: one block each at 300 000 particles, two at a million) and with a few workgroups that
     take dozens of blocks each (option lf_pipe_grid), over wide clouds (blocks that gather everything, patches clamped at the
     grid's edges, half patches) and tight ones, scans with a tail of beams (57, 1095), the shortest scan with a group (8) and
@@ -1255,6 +1255,7 @@ def test_reweight_lf_pipelined_patch_kernel_equals_the_gather_kernel_bit_for_bit
         for patch in (2, 0):  # always / never
             f = new_filter(grid, n)
             f.set_option("lf_patch", patch)
+            f.set_option("lf_pipe", 1)  # (an option: measured slower than the block-per-workgroup form, profiles/r04_lf_pipe_study.txt)
             f.set_option("lf_pipe_grid", grid_wgs)
             f.initialize(truth, np.diag([s * s for s in sigma]))
             f.reweight(pts)

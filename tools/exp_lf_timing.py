@@ -31,5 +31,5 @@ for c in range(cycles):
         cw, cc, cb, pw, pc, pb, pre, plw = v[:8]
         print(f"cycle {c}: kernel {ms * 1e3:.1f} us; consumer waves {cw}: {cc / cw:.0f} cycles each, {100 * cb / cc:.1f} % at barriers, "
               f"{100 * pre / cc:.1f} % before the main loop; producer waves {pw}: {pc / max(pw, 1):.0f} cycles each, {100 * pb / max(pc, 1):.1f} % at barriers, {100 * plw / max(pc, 1):.1f} % waiting for loads"
-              + (f"; pipe producer: {v[10]} steps, {v[8] / max(v[10], 1):.0f} cycles per step issuing patches, {v[9] / max(v[10], 1):.0f} in slices, {pb / max(v[10], 1):.0f} at barriers, {plw / max(v[10], 1):.0f} waiting for loads; consumers {v[6] / max(cw, 1):.0f} cycles at block starts" if v[10] else ""), flush=True)
+              + (f"; pipe producer: {v[10]} steps, {v[9] / max(v[10], 1):.0f} cycles per step in slices, {pb / max(v[10], 1):.0f} at barriers, {v[11] / max(pw, 1):.0f} cycles at block starts; consumers {v[6] / max(cw, 1):.0f} cycles at block starts" if v[10] else ""), flush=True)
 f.close()
