@@ -36,8 +36,11 @@ KERNEL_SOURCE = os.path.join(ROOT, "beluga_amd", "csrc", "kernels.hip")
 PROFILES = os.path.join(ROOT, "profiles")
 # per-launch counters of the LF kernel (rocprofv3 --pmc passes of the default bench, tools/gpu_r3_profiles.sh) and the measured
 # issue cost of the instruction classes on this part (tools/calib_f64_rate.hip): what the VALU-issue roofline is computed from
-PMC_FILES = [os.path.join(PROFILES, "r03_pmc_bench_1M.txt"), os.path.join(PROFILES, "r02_pmc_bench_1M.txt")]
+PMC_FILES = [os.path.join(PROFILES, "r04_pmc_bench_1M.txt"), os.path.join(PROFILES, "r03_pmc_bench_1M.txt"), os.path.join(PROFILES, "r02_pmc_bench_1M.txt")]
+TRAFFIC_FILES = [os.path.join(PROFILES, "r04_lf_kernel_traffic.json"), os.path.join(PROFILES, "r03_lf_kernel_traffic.json")]
 CALIB_FILE = os.path.join(PROFILES, "r01_calib_f64_issue_rate.txt")
+# the datasheet's issue rates (MI355X_MICROARCH.md, "Wave scheduling"): a wave64 instruction takes 2 passes of a SIMD-32, f64 at half rate 4
+SPEC_CYCLES = {"fma_f64": 4.0, "mul_f64": 4.0, "add_f64": 4.0, "other": 2.0}
 SIMDS, CLOCK_HZ = 256 * 4, 2.4e9  # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz (the calibration quotes its cycles at this clock)
 
 
@@ -65,9 +68,15 @@ def calibrated_issue_cycles():
     return {"fma_f64": out["v_fma_f64"], "mul_f64": out["v_mul_f64"], "add_f64": out["v_add_f64"], "other": out["v_add_u32"]}
 
 
+IN_RUN_COUNTERS = {}  # filled by collect_in_run_counters(): {counter: per-launch average of the LF kernel}, measured by this very run
+
+
 def lf_kernel_counters(kernel="k_reweight_lf_patch"):
-    """Per-launch PMC averages of the LF kernel from the newest profile that has them: {counter: value}, the file, and whether the
-    file was collected on the LF kernels' current source (its header records the SHA-256 of that part of kernels.hip)."""
+    """Per-launch PMC averages of the LF kernel: measured by this run if it could (collect_in_run_counters), otherwise from the newest
+    tracked profile that has them: {counter: value}, the source, and whether it was collected on the LF kernels' current source (a
+    tracked file's header records the SHA-256 of that part of kernels.hip)."""
+    if "SQ_INSTS_VALU" in IN_RUN_COUNTERS:
+        return dict(IN_RUN_COUNTERS), "in-run rocprofv3 --pmc pass of this bench.py (--pmc-child)", True
     for path in PMC_FILES:
         counters, sha = {}, None
         try:
@@ -117,7 +126,68 @@ def valu_issue_floor_ms(n_particles: int):
         detail.update({"pricing": "4 cycles per wave64 instruction (no class counters in the profile)"})
     detail["issue_floor_ms"] = cycles / (SIMDS * CLOCK_HZ) * 1e3
     detail["peak_winstr_per_s"] = total / (cycles / (SIMDS * CLOCK_HZ))  # instructions of this mix the chip can issue per second
+    # the same mix at the datasheet's rates (the calibration above absorbs the clock this load sustains, ~1.65 GHz of the nominal 2.4)
+    if isinstance(classes, dict) and "other" in classes:
+        spec_cycles = sum(classes[k] * SPEC_CYCLES[k] for k in classes)
+    else:
+        spec_cycles = total * 2.0
+    detail["issue_floor_ms_spec_rates"] = spec_cycles / (SIMDS * CLOCK_HZ) * 1e3
     return detail
+
+
+def collect_in_run_counters(timeout_s=150):
+    """Three more short runs of the headline workload (--pmc-child: 5 + 8 cycles) under `rocprofv3 --kernel-trace --pmc ...`, one per
+    counter set as the guide prescribes (the SQ instruction counters; FETCH_SIZE; WRITE_SIZE): the LF kernel's per-launch averages
+    land in IN_RUN_COUNTERS.  Returns a short status string; on any failure the line falls back to the tracked profiles and says so."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if tool is None:
+        return "rocprofv3 not found"
+    passes = ["SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT32", "FETCH_SIZE", "WRITE_SIZE"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    got = {}
+    try:
+        for counters in passes:
+            with tempfile.TemporaryDirectory(dir="/tmp") as out:
+                cmd = [tool, "--kernel-trace", "--pmc"] + counters.split() + ["-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+                db_path = None
+                for root, _dirs, files in os.walk(out):
+                    for name in files:
+                        if name.endswith("_results.db"):
+                            db_path = os.path.join(root, name)
+                if r.returncode != 0 or db_path is None:
+                    return f"rocprofv3 pass '{counters}' failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-200:]}"
+                db = sqlite3.connect(db_path)
+                rows = db.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name").fetchall()
+                db.close()
+                for kernel, counter, value, launches in rows:
+                    if "k_reweight_lf_patch" in kernel:
+                        got[counter] = float(value)
+                        got["launches"] = int(launches)
+    except Exception as exc:  # a profiler that hangs or a database of another layout: the tracked profiles serve
+        return f"in-run counters failed: {exc!r}"
+    if "SQ_INSTS_VALU" not in got:
+        return "no LF kernel rows in the profiler's database"
+    IN_RUN_COUNTERS.update(got)
+    return "ok"
+
+
+def pmc_child():
+    """What collect_in_run_counters profiles: the headline filter, 5 cycles of warm-up and 8 more (the same kernels as the timed region)."""
+    from beluga_amd.amcl import Amcl, AmclParams, DifferentialDriveModelParam, LikelihoodFieldModelParam, OccupancyGrid, se2_from_xytheta
+    cells, truth, odoms, scans, _poses = make_workload(13)
+    grid = OccupancyGrid(cells, RESOLUTION, origin=se2_from_xytheta(ORIGIN[0], ORIGIN[1], 0.0))
+    n = 1_000_000
+    f = Amcl(grid, DifferentialDriveModelParam(*ALPHAS), LikelihoodFieldModelParam(**LF), AmclParams(min_particles=n, max_particles=n), seed=42)
+    f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+    for c in range(13):
+        assert f.update(se2_from_xytheta(*odoms[c]), scans[c]) is not None
+    f.sync()
+    f.close()
 
 
 MAP_SIZE, RESOLUTION, ORIGIN = 4000, 0.05, (-100.0, -100.0)
@@ -341,7 +411,12 @@ def main():
     ap.add_argument("--windows", type=int, default=5, help="repeated timing windows of --steps cycles behind the timed region")
     ap.add_argument("--stage-steps", type=int, default=6, help="cycles of the per-stage breakdown pass")
     ap.add_argument("--sharded", action="store_true", help="use the sharded driver even with one GPU (measures its overhead)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes behind the timed region (the line then quotes the tracked profiles)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child()
+        return
 
     import torch
     import torch.distributed as dist
@@ -510,12 +585,31 @@ def main():
         big.close()
 
     if rank == 0:
+        pmc_status = "skipped (--no-pmc)" if args.no_pmc else ("skipped (several ranks or another set size)" if (world != 1 or n_local != 1_000_000) else None)
+        if pmc_status is None:
+            filt.sync()
+            pmc_status = collect_in_run_counters()
         ms_per_step = elapsed / args.steps * 1e3
         lf_ms, lf_count = prof["sensor_kernel"]
         lf_avg_s = (lf_ms / max(lf_count, 1)) * 1e-3
         bytes_lf = lf_algorithmic_bytes(n_local, BEAMS)
         achieved_bytes = bytes_lf / lf_avg_s if lf_avg_s > 0 else 0.0
         floor = valu_issue_floor_ms(n_local)
+        traffic_bytes, traffic_source = None, None
+        if "FETCH_SIZE" in IN_RUN_COUNTERS and "WRITE_SIZE" in IN_RUN_COUNTERS:
+            traffic_bytes = (2.0 * IN_RUN_COUNTERS["FETCH_SIZE"] + IN_RUN_COUNTERS["WRITE_SIZE"]) * 1024.0
+            traffic_source = "in-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench.py (--pmc-child), per launch of the LF kernel"
+        else:
+            for path in TRAFFIC_FILES:
+                try:
+                    with open(path) as fh:
+                        rec = json.load(fh)
+                    traffic_bytes = (2.0 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1024.0 * (n_local / rec.get("particles", 1_000_000))
+                    traffic_source = os.path.relpath(path, ROOT) + (" (collected on the LF kernels' current source)" if rec.get("kernels_hip_sha256") == lf_kernel_source_sha(KERNEL_SOURCE)
+                                                                     else " (collected on an EARLIER version of the LF kernels' source)")
+                    break
+                except (OSError, KeyError, ValueError):
+                    continue
         patch_fraction = patch_fraction_timed = None
         if hasattr(filt, "counter"):
             planned, through = filt.counter("lf_patch_groups_planned"), filt.counter("lf_patch_groups_through")
@@ -535,7 +629,11 @@ def main():
             "peak": (floor["peak_winstr_per_s"] / 1e9) if floor else None,
             "unit": "G wave64-instr/s",
             "frac": (floor["issue_floor_ms"] * 1e-3 / lf_avg_s) if (floor and lf_avg_s > 0) else None,
-            "traffic": None,  # HBM bytes are not measured inside this run (PMC passes: profiles/r03_pmc_bench_1M.txt, lf_kernel_traffic.json)
+            # the same instructions priced at the datasheet's issue rates (2 cycles per wave64 instruction, 4 for f64) at the nominal 2.4 GHz
+            "frac_spec": (floor["issue_floor_ms_spec_rates"] * 1e-3 / lf_avg_s) if (floor and lf_avg_s > 0) else None,
+            "traffic": traffic_bytes,  # HBM bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies a read at half its size), see traffic_source
+            "traffic_source": traffic_source,
+            "in_run_counters": pmc_status,
             "avg_launch_ms": lf_avg_s * 1e3,
             "launches": int(lf_count),
             "launches_sampled_every": 4,
