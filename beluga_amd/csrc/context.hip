@@ -11,6 +11,7 @@
 #include <cctype>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -213,6 +214,7 @@ struct mcl_ctx {
   DeviceBuffer<double> d_beam_points;  // beam model: per-beam terms (kBeamPointDoubles per beam)
   DeviceBuffer<double> d_beam_table;   // beam model: 4 doubles per squared cell distance of a hit (launch_beam_table), built by mcl_set_map
   uint32_t beam_table_count{0};
+  bool beam_table_ready{false};        // d_beam_table holds the table of the current map (built lazily: do_reweight)
   double* h_points{nullptr};   // pinned, mapped
   double* hd_points{nullptr};  // the same memory as the device sees it
   double scan_extent{0.0};     // max |x| + |y| of the uploaded scan points (NaN if any is NaN)
@@ -427,7 +429,13 @@ mcl_status wait_for_cycle(mcl_ctx* ctx) {
         if ((ctx->done_seq & 0xFFu) == 0) break;
         return MCL_OK;
       }
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#elif defined(__aarch64__)
+      asm volatile("yield" ::: "memory");
+#else
+      std::this_thread::yield();
+#endif
       if ((spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
     }
   }
@@ -887,17 +895,27 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     }
   } else {
     const mcl_beam_params& b = ctx->cfg.beam;
+    const BeamModel model{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range};
+    const bool use_table = ordered && ctx->tuning.beam_table != 0 && ctx->beam_table_count != 0;  // (only the ordered kernel reads it)
+    if (use_table && !ctx->beam_table_ready) {
+      MCL_HIP(ctx, ctx->d_beam_table.ensure(4 * static_cast<size_t>(ctx->beam_table_count)));
+      launch_beam_table(ctx->stream, model, ctx->resolution, ctx->beam_table_count, ctx->d_beam_table.ptr);
+      MCL_HIP(ctx, hipGetLastError());
+      ctx->beam_table_ready = true;
+    }
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
-    launch_reweight_beam(ctx->stream, ctx->cur(), ctx->n, ctx->grid_view(),
-                         BeamModel{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range},
+    launch_reweight_beam(ctx->stream, ctx->cur(), ctx->n, ctx->grid_view(), model,
                          ctx->d_points.ptr, static_cast<uint32_t>(B), ctx->d_kld_scalars.ptr + 1, ordered ? &sort : nullptr,
-                         ctx->d_nonfree_bits.ptr, ctx->d_beam_points.ptr, ctx->tuning.beam_table ? ctx->d_beam_table.ptr : nullptr,
-                         ctx->tuning.beam_table ? ctx->beam_table_count : 0u);
+                         ctx->d_nonfree_bits.ptr, ctx->d_beam_points.ptr, use_table ? ctx->d_beam_table.ptr : nullptr,
+                         use_table ? ctx->beam_table_count : 0u);
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
   }
   stage_end(ctx, MCL_STAGE_REWEIGHT);
   ctx->profile_tick += 1;
-  MCL_HIP(ctx, hipGetLastError());
+  if (const hipError_t e = hipGetLastError(); e != hipSuccess) {
+    ctx->lf_wsum_count = 0;  // (sums that no longer describe the weights must not reach a later normalisation)
+    return fail(ctx, MCL_ERR_HIP, std::string("reweight: ") + hipGetErrorString(e));
+  }
   return MCL_OK;
 }
 
@@ -954,6 +972,7 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
                        bool finalize_norm = false) {
   const mcl_amcl_params& a = ctx->cfg.amcl;
   MCL_REQUIRE(ctx, ctx->n > 0, "mcl_resample: empty particle set");
+  ctx->lf_wsum_count = 0;  // (the set changes: workgroup sums of an earlier reweight describe another one)
   const uint64_t max_p = std::min<uint64_t>(a.max_particles, ctx->capacity);
   stage_begin(ctx, MCL_STAGE_RESAMPLE);
   if (const mcl_status s = do_build_cdf(ctx, normalized_just_now, policy, finalize_norm)) return s;
@@ -1055,6 +1074,61 @@ mcl_status comm_exchange(mcl_ctx* ctx, const void* d_send, const uint64_t* send_
   return MCL_OK;
 }
 
+// What selects the SEQUENCE of collectives a sharded cycle runs (fixed-size or KLD-adaptive, selective resampling, the recovery
+// estimator on the device or on the host, the plain or the cluster-based estimate, the resampling interval) has to be the same on
+// every rank, or the ranks block in different collectives for ever.  Part of it comes from each process's own environment
+// (BELUGA_MCL_DEVICE_POLICY) or from calls made after the communicator exists: the word below is all-gathered and compared when
+// the communicator is attached and whenever one of those calls changes it (they are then collective calls: every rank makes them).
+uint64_t comm_path_word(const mcl_ctx* ctx) {
+  const mcl_amcl_params& ap = ctx->cfg.amcl;
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&h](uint64_t v) {
+    for (int k = 0; k < 8; ++k) {
+      h ^= (v >> (8 * k)) & 0xFFu;
+      h *= 1099511628211ull;
+    }
+  };
+  mix(ap.min_particles);
+  mix(ap.max_particles);
+  mix(static_cast<uint64_t>(ap.resample_interval));
+  mix(ap.selective_resampling ? 1u : 0u);
+  mix(static_cast<uint64_t>(ctx->cfg.sensor_kind));
+  mix(static_cast<uint64_t>(ctx->cfg.motion_kind));
+  mix(ctx->cfg.seed);
+  mix(static_cast<uint64_t>(ctx->tuning.device_policy != 0));
+  mix(static_cast<uint64_t>(ctx->estimate_kind));
+  for (const double v : {ctx->cluster_params.linear_hash_resolution, ctx->cluster_params.angular_hash_resolution, ctx->cluster_params.weight_cap_percentile}) {
+    uint64_t bits;
+    std::memcpy(&bits, &v, sizeof bits);
+    mix(bits);
+  }
+  mix(static_cast<uint64_t>(ctx->comm_world));
+  return h;
+}
+mcl_status comm_agree(mcl_ctx* ctx, const char* where) {
+  if (!ctx->have_comm || ctx->comm_world <= 1) return MCL_OK;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  if (const mcl_status s = comm_scratch(ctx)) return s;
+  const uint32_t world = ctx->comm_world;
+  long long* d_words = ctx->d_comm_i64.ptr;
+  long long* h_words = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + 9));
+  const uint64_t mine = comm_path_word(ctx);
+  std::memcpy(h_words, &mine, sizeof(mine));
+  MCL_HIP(ctx, hipMemcpyAsync(d_words, h_words, sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+  if (const mcl_status s = comm_gather(ctx, d_words, d_words + world, sizeof(long long))) return s;
+  MCL_HIP(ctx, hipMemcpyAsync(h_words, d_words + world, world * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t r = 0; r < world; ++r) {
+    uint64_t theirs;
+    std::memcpy(&theirs, h_words + r, sizeof(theirs));
+    if (theirs != mine)
+      return fail(ctx, MCL_ERR_INVALID_ARGUMENT,
+                  std::string(where) + ": rank " + std::to_string(r) + " runs another configuration (particle bounds, resampling policy, models, seed, "
+                  "device_policy, estimate kind): every shard of a filter must be created and switched alike");
+  }
+  return MCL_OK;
+}
+
 // The nine estimate sums (estimation.hpp:436-475) over all shards: local sums - of the particles whose cell carries cluster id
 // wanted_plus_1 - 1 in t_cluster when t_cluster is given -, gathered, added in rank order by every rank.
 mcl_status sharded_estimate_sums(mcl_ctx* ctx, unsigned int* t_cluster, unsigned int wanted_plus_1, double sums[12], uint64_t slots = 0) {
@@ -1153,6 +1227,7 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
   cell_views(ctx->hd_cells, dk, dw, ds, df, dc, dsl, dcl, dsize);
   const HashParams hp{cp.linear_hash_resolution, cp.linear_hash_resolution, cp.angular_hash_resolution};
   unsigned int m = 0;
+  bool local_failure = false;  // (sharded: reported to the peers with the count, so that every rank leaves together)
   if (n) {
     launch_cluster_cells(ctx->stream, ctx->cur(), n, hp, ctx->d_hashes.ptr, ctx->d_table_keys.ptr, ctx->d_table_first.ptr, t_wsum,
                          t_count, t_cluster, slots, dk, df, dc, dsl, dw, ds, c_size, kHostCells);
@@ -1160,7 +1235,11 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
     MCL_HIP(ctx, hipMemcpyAsync(hsize, c_size, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     m = *hsize;
-    MCL_REQUIRE(ctx, m >= 1 && m <= m_cap, "cell compaction failed");
+    if (!(m >= 1 && m <= m_cap)) {
+      if (!sharded) return fail(ctx, MCL_ERR_HIP, "cell compaction failed");
+      local_failure = true;
+      m = 0;
+    }
   }
   ctx->cluster_cells = m;
   std::vector<unsigned long long> key_big;
@@ -1224,7 +1303,7 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
     constexpr size_t kRecord = 7;  // doubles per cell: key (bit pattern), weight sum, count (bit pattern), state[4]
     long long* d_counts = ctx->d_comm_i64.ptr;
     long long* h_counts = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + 9));
-    h_counts[0] = static_cast<long long>(m);
+    h_counts[0] = local_failure ? -1 : static_cast<long long>(m);  // -1: this rank's compaction failed
     MCL_HIP(ctx, hipMemcpyAsync(d_counts, h_counts, sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
     if (const mcl_status s = comm_gather(ctx, d_counts, d_counts + world, sizeof(long long))) return s;
     MCL_HIP(ctx, hipMemcpyAsync(h_counts, d_counts + world, world * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -1232,6 +1311,8 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
     std::vector<uint64_t> m_of(world);
     uint64_t widest = 0;
     for (uint32_t r = 0; r < world; ++r) {
+      if (h_counts[r] < 0)  // every rank sees it behind the same collective and returns here: nobody is left in the next one
+        return fail(ctx, MCL_ERR_HIP, "cluster_based_estimate: cell compaction failed on rank " + std::to_string(r));
       m_of[r] = static_cast<uint64_t>(h_counts[r]);
       widest = std::max(widest, m_of[r]);
     }
@@ -1992,13 +2073,10 @@ mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32
     MCL_HIP(ctx, hipGetLastError());
     {
       const mcl_beam_params& b = ctx->cfg.beam;
+      // (the table itself - 32 bytes per squared cell distance up to the range, 46 MB at 60 m / 5 cm - is built by the first
+      // launch of the ordered kernel that wants it: the usual 2000-particle filter never does; do_reweight)
       ctx->beam_table_count = beam_table_entries(b.beam_max_range, resolution);
-      if (ctx->beam_table_count) {
-        MCL_HIP(ctx, ctx->d_beam_table.ensure(4 * static_cast<size_t>(ctx->beam_table_count)));
-        launch_beam_table(ctx->stream, BeamModel{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range}, resolution,
-                          ctx->beam_table_count, ctx->d_beam_table.ptr);
-        MCL_HIP(ctx, hipGetLastError());
-      }
+      ctx->beam_table_ready = false;
     }
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
@@ -2062,6 +2140,7 @@ mcl_status mcl_set_likelihood_field(mcl_ctx* ctx, const float* field) {
 
 mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], const double cov[9]) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  ctx->lf_wsum_count = 0;  // (workgroup sums of an earlier reweight describe another set)
   MCL_REQUIRE(ctx, mean_xytheta && cov, "null argument");
   double T[9];
   if (!covariance_to_transform(cov, T)) return fail(ctx, MCL_ERR_BAD_COVARIANCE, "Invalid covariance matrix");
@@ -2086,6 +2165,7 @@ mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], con
 
 mcl_status mcl_set_particles(mcl_ctx* ctx, const double* states, const double* weights, uint64_t n) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  ctx->lf_wsum_count = 0;  // (workgroup sums of an earlier reweight describe another set)
   MCL_REQUIRE(ctx, n == 0 || (states && weights), "null argument");
   MCL_REQUIRE(ctx, n <= ctx->capacity, "mcl_set_particles: n exceeds capacity");
   if (const mcl_status s = bind_device(ctx)) return s;
@@ -2462,8 +2542,11 @@ mcl_status mcl_cluster_based_estimate(mcl_ctx* ctx, const mcl_cluster_params* pa
 mcl_status mcl_set_estimate_kind(mcl_ctx* ctx, int32_t kind, const mcl_cluster_params* params) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
   MCL_REQUIRE(ctx, kind == 0 || kind == 1, "estimate kind must be 0 (estimate) or 1 (cluster_based_estimate)");
+  const bool changed = ctx->estimate_kind != kind;
   ctx->estimate_kind = kind;
   if (params) ctx->cluster_params = *params;
+  // on a sharded filter the estimate's kind selects the cycle's collectives: a collective call (every rank, the same kind)
+  if (changed || params) return comm_agree(ctx, "mcl_set_estimate_kind");
   return MCL_OK;
 }
 
@@ -2505,6 +2588,7 @@ mcl_status mcl_get_device_view(mcl_ctx* ctx, mcl_device_view* view) {
 
 mcl_status mcl_set_num_particles(mcl_ctx* ctx, uint64_t n) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  ctx->lf_wsum_count = 0;  // (workgroup sums of an earlier reweight describe another set)
   MCL_REQUIRE(ctx, n <= ctx->capacity, "n exceeds capacity");
   ctx->n = n;
   return MCL_OK;
@@ -2622,6 +2706,7 @@ mcl_status mcl_kld_feed(mcl_ctx* ctx, const uint64_t* d_hashes, uint64_t count, 
 
 mcl_status mcl_load_shard(mcl_ctx* ctx, const double* d_states, uint64_t n, uint64_t shard_offset) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  ctx->lf_wsum_count = 0;
   MCL_REQUIRE(ctx, n <= ctx->capacity, "n exceeds shard capacity");
   MCL_REQUIRE(ctx, n == 0 || d_states, "null states");
   if (const mcl_status s = bind_device(ctx)) return s;
@@ -2676,6 +2761,7 @@ mcl_status mcl_estimate_sums_device(mcl_ctx* ctx, const double pivot_xy[2], doub
 
 mcl_status mcl_initialize_from_map(mcl_ctx* ctx) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  ctx->lf_wsum_count = 0;  // (workgroup sums of an earlier reweight describe another set)
   if (!ctx->have_map) return fail(ctx, MCL_ERR_NOT_READY, "mcl_initialize_from_map: no map set");
   MCL_REQUIRE(ctx, ctx->n_free > 0, "mcl_initialize_from_map: the map has no free cell");  // the reference asserts (:136)
   if (const mcl_status s = bind_device(ctx)) return s;
@@ -2770,7 +2856,12 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "lf_fast") t.lf_fast = value < 0 ? -1 : (value ? 1 : 0);
   else if (key == "lf_table") t.lf_table = value ? 1 : 0;
   else if (key == "lf_patch") t.lf_patch = value < 0 || value > 2 ? 1 : static_cast<int>(value);
-  else if (key == "device_policy") t.device_policy = value ? 1 : 0;
+  else if (key == "device_policy") {
+    const int before = t.device_policy;
+    t.device_policy = value ? 1 : 0;
+    // on a sharded filter it selects the cycle's collectives: a collective call (every rank, the same value)
+    if (before != t.device_policy) return comm_agree(ctx, "mcl_set_option(device_policy)");
+  }
   else if (key == "field_build") t.field_build = value ? 1 : 0;
   else if (key == "key_curve") t.key_curve = value ? 1 : 0;
   else if (key == "key_warp") t.key_warp = value ? 1 : 0;
@@ -2780,7 +2871,15 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "lf_pipe") t.lf_pipe = value ? 1 : 0;
   else if (key == "lf_pipe_grid") t.lf_pipe_grid = static_cast<int>(std::clamp<int64_t>(value, 0, 1 << 20));
   else if (key == "cycle_spin") t.cycle_spin = value ? 1 : 0;
-  else if (key == "beam_table") t.beam_table = value ? 1 : 0;
+  else if (key == "beam_table") {
+    t.beam_table = value ? 1 : 0;
+    if (!t.beam_table && ctx->beam_table_ready) {  // its memory goes back at once
+      if (hipStreamSynchronize(ctx->stream) == hipSuccess) {
+        ctx->d_beam_table.release();
+        ctx->beam_table_ready = false;
+      }
+    }
+  }
   else if (key == "lf_weight_sums") t.lf_weight_sums = value ? 1 : 0;
   else if (key == "lf_split") t.lf_split = static_cast<int>(value & 3);  // 1: side by side only, 2: stacked only, 3: both
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
@@ -2842,6 +2941,12 @@ mcl_status mcl_comm_attach(mcl_ctx* ctx, uint32_t rank, uint32_t world, const mc
   ctx->comm_world = world;
   ctx->transport = transport ? *transport : mcl_transport{};
   ctx->have_comm = true;
+  // the first collective of the communicator: do the ranks run the same filter?  (a rank with another
+  // BELUGA_MCL_DEVICE_POLICY would otherwise take another sequence of collectives and block its peers for ever)
+  if (const mcl_status s = comm_agree(ctx, "mcl_comm_attach")) {
+    ctx->have_comm = false;
+    return s;
+  }
   return MCL_OK;
 }
 

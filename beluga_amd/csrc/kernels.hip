@@ -2636,8 +2636,28 @@ __global__ __launch_bounds__(kStable) void k_sort_buckets(const unsigned long lo
   __shared__ uint32_t base_of[kSortDigits], wave_sums[kWaves];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   digit_bases<kStable>(totals, base_of, wave_sums);
+  // A bucket far beyond the average (a degenerate set: identical poses, a zero-covariance initialisation - all of a million
+  // particles in ONE bucket, which one workgroup would walk twice on its own: milliseconds) is not sorted by its low digit at
+  // all: it keeps the first pass's order (by particle index), and every workgroup of the launch copies a slice of it.  Only
+  // locality depends on the order, never a result; the order stays a pure function of the keys (deterministic).
+  constexpr uint32_t kHugeBucket = 65536;
+  {
+    constexpr int kPer = kSortDigits / kStable;
+    bool huge = false;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) huge = huge || totals[threadIdx.x * kPer + k] > kHugeBucket;
+    if (__syncthreads_or(huge)) {
+#pragma unroll 1
+      for (uint32_t d = 0; d < kSortDigits; ++d) {
+        const uint32_t count = totals[d];
+        if (count <= kHugeBucket) continue;  // (uniform)
+        const uint32_t from = base_of[d];
+        for (uint32_t e = blockIdx.x * kStable + threadIdx.x; e < count; e += gridDim.x * kStable) perm[from + e] = static_cast<uint32_t>(in[from + e]);
+      }
+    }
+  }
   const uint32_t begin = base_of[blockIdx.x], size = totals[blockIdx.x];
-  if (size == 0) return;  // (uniform)
+  if (size == 0 || size > kHugeBucket) return;  // (uniform)
   for (uint32_t d = threadIdx.x; d < kWaves * kSortDigits; d += kStable) (&run[0][0])[d] = 0;
   __syncthreads();
   const uint32_t per_wave = ((size + kWaves - 1) / kWaves + 63u) & ~63u;
@@ -5022,6 +5042,17 @@ void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32
                      block_rows, b.row_words, block_columns, b.dist_stride, const_cast<uint8_t*>(b.dist));
 }
 
+}  // namespace mcl
+// Nonzero for a measurement build of the kernels (tools/build_variant.sh: ablations compute nonsense by design, timing builds
+// distort): beluga_amd/capi.py refuses to load one as the product library unless told so.
+extern "C" int mcl_measurement_build(void) {
+#if MCL_ABLATE || MCL_PIPE_ABLATE || defined(MCL_LF_TIMING) || defined(MCL_BEAM_STATS) || defined(MCL_DRAW_ABLATE)
+  return 1;
+#else
+  return 0;
+#endif
+}
+namespace mcl {
 #ifdef MCL_LF_TIMING
 }  // namespace mcl
 extern "C" int mcl_debug_lf_timing(unsigned long long* out16, int reset) {

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -238,7 +239,37 @@ int main(int argc, char** argv) {
   g_min_particles = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 0;
   if (g_min_particles >= n_total) g_min_particles = 0;
   g_estimate_kind = argc > 5 ? std::atoi(argv[5]) : 0;
+  const bool mismatch = argc > 6 && std::string(argv[6]) == "mismatch";
   const Scenario sc(cycles);
+  if (mismatch) {
+    // One rank runs another configuration (what a stray BELUGA_MCL_DEVICE_POLICY in one process's environment does): the
+    // communicator's first collective compares the ranks' configurations, and EVERY rank's attach fails - none is left waiting
+    // in a collective the others never enter.
+    Exchange exchange(ranks);
+    std::vector<Endpoint> endpoints(ranks);
+    std::vector<int> refused(ranks, 0);
+    std::vector<std::thread> threads;
+    for (int r = 0; r < ranks; ++r) {
+      endpoints[r] = Endpoint{&exchange, r};
+      threads.emplace_back([&, r] {
+        const uint64_t base = n_total / ranks, rem = n_total % ranks;
+        const uint64_t first = r * base + std::min<uint64_t>(r, rem), mine = base + (static_cast<uint64_t>(r) < rem ? 1 : 0);
+        mcl_ctx* ctx = nullptr;
+        const mcl_config cfg = make_config(n_total, first, mine);
+        if (mcl_create(&cfg, &ctx) != MCL_OK) return;
+        if (r == 1) mcl_set_option(ctx, "device_policy", 0);
+        const mcl_transport transport{&endpoints[r], all_gather, all_to_all};
+        const mcl_status st = mcl_comm_attach(ctx, static_cast<uint32_t>(r), static_cast<uint32_t>(ranks), &transport);
+        refused[r] = st == MCL_ERR_INVALID_ARGUMENT && std::string(mcl_last_error(ctx)).find("another configuration") != std::string::npos;
+        mcl_destroy(ctx);
+      });
+    }
+    for (auto& t : threads) t.join();
+    int total = 0;
+    for (int r = 0; r < ranks; ++r) total += refused[r];
+    std::printf("attach_refused %d of %d\n", total, ranks);
+    return total == ranks ? 0 : 8;
+  }
 
   mcl_ctx* single = nullptr;
   const mcl_config whole = make_config(n_total, 0, 0);

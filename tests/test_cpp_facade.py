@@ -98,6 +98,17 @@ def test_sharded_kld_cycle_inside_the_library_matches_one_context(sharded_demo, 
 
 
 @pytest.mark.gpu
+def test_ranks_with_different_configurations_are_refused_together(sharded_demo):
+    """A rank whose path-selecting configuration differs (here device_policy, which a stray BELUGA_MCL_DEVICE_POLICY in one
+    process's environment sets) would run another SEQUENCE of collectives and leave its peers blocked for ever: the
+    communicator's first collective (mcl_comm_attach) compares a word of the ranks' configurations, and every rank's attach
+    fails with the same message.  (mcl_set_option(device_policy) and mcl_set_estimate_kind on an attached filter repeat it.)"""
+    out = subprocess.run([sharded_demo, "3", "30000", "1", "0", "0", "mismatch"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "attach_refused 3 of 3" in out.stdout
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ranks,max_particles,min_particles", [(2, 60000, 0), (3, 70001, 0), (4, 40000, 3000)])
 def test_sharded_cluster_based_estimate_matches_one_context(sharded_demo, ranks, max_particles, min_particles):
     """beluga_ros::Amcl returns cluster_based_estimate from every update (beluga_ros/src/amcl.cpp:125); over shards the

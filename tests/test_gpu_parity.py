@@ -1329,6 +1329,39 @@ def test_reweight_lf_patch_planner_options_change_no_weight(options):
             assert shares[0] > 0.9, (options, shares)
 
 
+def test_degenerate_set_of_identical_poses_is_ordered_in_bounded_time():
+    """A million particles on ONE pose (mcl_set_particles with copies; a zero-spread cloud): all keys are equal, the ordering's
+    first pass puts the whole set into one of its 1024 buckets, and one workgroup used to walk it twice on its own.  Such a
+    bucket keeps the first pass's order (by particle index) and every workgroup copies a slice of it; the weights are the
+    oracle's, and the reweight (ordering + kernel) stays within a few milliseconds."""
+    import time
+    grid = rooms_grid(400, 3)
+    truth = synth.find_free_pose(grid.cells, grid.resolution, (grid.origin[2], grid.origin[3]), seed=4, clearance_cells=8)
+    pts = make_scan(grid, truth, 360, max_range=12.0)
+    n = 1_000_000
+    states = np.tile(se2_from_xytheta(*truth), (n, 1))
+    states[n // 2:, 2] += 1e-3  # (two poses a millimetre apart: still one bucket)
+    w0 = np.ones(n)
+    f = new_filter(grid, n)
+    f.set_particles(states, w0)
+    f.reweight(pts)  # (first launch: allocations)
+    f.set_particles(states, w0)
+    f.sync()
+    t0 = time.perf_counter()
+    f.reweight(pts)
+    f.sync()
+    elapsed = time.perf_counter() - t0
+    perm, _keys = f.debug_order()
+    assert np.array_equal(np.sort(np.asarray(perm)), np.arange(n))  # still a permutation
+    got = f.particles()[1]
+    pick = np.array([0, 1, n // 2 - 1, n // 2, n - 1])
+    want = orc.lf_weights(f.likelihood_field(), grid.resolution, grid.origin, LF.max_laser_distance, states[pick], pts)
+    np.testing.assert_allclose(got[pick], want, rtol=RTOL, atol=0)
+    assert np.all(got[:n // 2] == got[0]) and np.all(got[n // 2:] == got[n - 1])
+    assert elapsed < 0.02, elapsed  # (0.3 ms of ordering + the kernel on a healthy set; the single-workgroup walk took milliseconds per pass)
+    f.close()
+
+
 def test_spatial_order_is_a_sorted_permutation():
     """The ordering pass (two-pass radix sort of the 20-bit keys, the second pass stable): perm is a permutation and
     keys[perm] is non-decreasing — with the key frame from the host's estimate, from a bounding-box pass (set_particles
