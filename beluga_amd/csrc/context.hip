@@ -206,6 +206,10 @@ struct mcl_ctx {
   std::vector<float> h_field;
   DeviceBuffer<uint32_t> d_field_scratch;  // device field build: uint16 column distances + int16 offsets per cell
   bool field_built_on_device{false};
+  uint64_t comm_bytes_out{0};   // bytes this rank has handed to the transport (all-gather contributions + all-to-all sends), cumulative
+  uint64_t comm_collectives{0}; // collectives called, cumulative
+  uint64_t comm_ranks_seen{0};  // ranks the communicator reports (ncclCommCount), or the attached world size
+  int comm_backend{0};          // 0 none, 1 caller's transport, 2 RCCL inside the library
   uint64_t cluster_cells{0};  // occupied cells of the last cluster_based_estimate on this context (before the merge over shards)
   double field_build_ms{0.0};
 
@@ -1064,11 +1068,16 @@ mcl_status comm_scratch(mcl_ctx* ctx) {
   return MCL_OK;
 }
 mcl_status comm_gather(mcl_ctx* ctx, const void* d_send, void* d_recv, uint64_t bytes) {
+  ctx->comm_bytes_out += bytes;
+  ctx->comm_collectives += 1;
   if (ctx->transport.all_gather(ctx->transport.user, d_send, d_recv, bytes, ctx->stream) != 0)
     return fail(ctx, MCL_ERR_HIP, "transport all_gather failed");
   return MCL_OK;
 }
 mcl_status comm_exchange(mcl_ctx* ctx, const void* d_send, const uint64_t* send_bytes, void* d_recv, const uint64_t* recv_bytes) {
+  for (uint32_t q = 0; q < ctx->comm_world; ++q)
+    if (q != ctx->comm_rank) ctx->comm_bytes_out += send_bytes[q];
+  ctx->comm_collectives += 1;
   if (ctx->transport.all_to_all(ctx->transport.user, d_send, send_bytes, d_recv, recv_bytes, ctx->stream) != 0)
     return fail(ctx, MCL_ERR_HIP, "transport all_to_all failed");
   return MCL_OK;
@@ -1816,6 +1825,7 @@ struct RcclApi {
   int (*Recv)(void*, size_t, int, int, void*, hipStream_t){nullptr};
   int (*GroupStart)(){nullptr};
   int (*GroupEnd)(){nullptr};
+  int (*CommCount)(void*, int*){nullptr};  // optional: how many ranks the communicator itself says it has
 };
 RcclApi* rccl_api(std::string* error) {
   static RcclApi api;
@@ -1841,6 +1851,7 @@ RcclApi* rccl_api(std::string* error) {
       api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
       api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
       api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+      api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
       if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
         load_error = "librccl.so lacks an expected symbol";
     }
@@ -2912,6 +2923,10 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
   else if (key == "field_build_us") *value = static_cast<uint64_t>(ctx->field_build_ms * 1e3);  // kernels of the last device field build
   else if (key == "field_built_on_device") *value = ctx->field_built_on_device ? 1 : 0;
   else if (key == "cluster_cells") *value = ctx->cluster_cells;
+  else if (key == "comm_bytes_out") *value = ctx->comm_bytes_out;
+  else if (key == "comm_collectives") *value = ctx->comm_collectives;
+  else if (key == "comm_ranks_seen") *value = ctx->comm_ranks_seen;
+  else if (key == "comm_backend") *value = static_cast<uint64_t>(ctx->comm_backend);
   else return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "mcl_get_counter: unknown counter " + key);
   return MCL_OK;
 }
@@ -2941,6 +2956,10 @@ mcl_status mcl_comm_attach(mcl_ctx* ctx, uint32_t rank, uint32_t world, const mc
   ctx->comm_world = world;
   ctx->transport = transport ? *transport : mcl_transport{};
   ctx->have_comm = true;
+  if (ctx->comm_backend != 2) {
+    ctx->comm_backend = world > 1 ? 1 : 0;
+    ctx->comm_ranks_seen = world;
+  }
   // the first collective of the communicator: do the ranks run the same filter?  (a rank with another
   // BELUGA_MCL_DEVICE_POLICY would otherwise take another sequence of collectives and block its peers for ever)
   if (const mcl_status s = comm_agree(ctx, "mcl_comm_attach")) {
@@ -2975,6 +2994,12 @@ mcl_status mcl_comm_attach_rccl(mcl_ctx* ctx, const uint8_t id[128], uint32_t ra
     return fail(ctx, MCL_ERR_HIP, "ncclCommInitRank failed");
   ctx->rccl_comm = comm;
   ctx->rccl_user = mcl_ctx::RcclUserStorage{comm, rank, world};
+  ctx->comm_backend = 2;
+  ctx->comm_ranks_seen = world;
+  if (api->CommCount) {  // what the communicator itself says (the driver's check that RCCL saw every rank)
+    int count = 0;
+    if (api->CommCount(comm, &count) == 0 && count > 0) ctx->comm_ranks_seen = static_cast<uint64_t>(count);
+  }
   const mcl_transport t{&ctx->rccl_user, rccl_all_gather, rccl_all_to_all};
   return mcl_comm_attach(ctx, rank, world, &t);
 }

@@ -526,6 +526,8 @@ def main():
     filt.profile_read(reset=True)
     sync_all()
     patch_before = (filt.counter("lf_patch_groups_planned"), filt.counter("lf_patch_groups_through")) if hasattr(filt, "counter") else None
+    library_comm = use_sharded and type(filt).__name__ == "Amcl"  # (the torch.distributed driver is beluga_amd.sharded.ShardedAmcl)
+    comm_before = (filt.counter("comm_bytes_out"), filt.counter("comm_collectives")) if library_comm else None
     timed_estimates = []
     t0 = time.perf_counter()
     for c in range(args.warmup, args.warmup + args.steps):
@@ -539,6 +541,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = filt.profile_read(reset=True)
+    collective = None
+    if comm_before is not None:
+        # what the communicator moved in the timed region, from the library's own counters: the driver's check that RCCL ran over
+        # all ranks (ranks_seen = ncclCommCount of the library's communicator) has a field to read
+        backend_name = {0: "none (one rank)", 1: "caller's transport", 2: "RCCL inside libbeluga_mcl.so (ncclAllGather + grouped ncclSend / ncclRecv)"}
+        collective = {"backend": backend_name.get(filt.counter("comm_backend"), "?"), "ranks_seen": filt.counter("comm_ranks_seen"),
+                      "bytes_out_per_rank_per_cycle": (filt.counter("comm_bytes_out") - comm_before[0]) / args.steps,
+                      "collectives_per_cycle": (filt.counter("comm_collectives") - comm_before[1]) / args.steps,
+                      "host_synchronisations_per_cycle": 2 if world > 1 else 1}
+    elif use_sharded:
+        collective = {"backend": f"torch.distributed ({backend}) driver, beluga_amd/sharded.py", "ranks_seen": dist.get_world_size(),
+                      "bytes_out_per_rank_per_cycle": None}
     patch_after = (filt.counter("lf_patch_groups_planned"), filt.counter("lf_patch_groups_through")) if hasattr(filt, "counter") else None
     # Repeated windows of the same length right behind the timed region (same filter, the trajectory continues): the spread
     # says how much a single 20-step sample can be trusted.
@@ -673,6 +687,7 @@ def main():
                 "parallelism": "1 GPU" if not use_sharded else f"particle shards x{world}: shard sums / CDF intervals / estimate sums all-gathered, "
                                                                     f"ancestors exchanged all-to-all (RCCL over xGMI, "
                                                                     f"{driver_used[0] or 'inside libbeluga_mcl.so'})",
+                "collective": collective,
                 "particle_beam_evals_per_s": n_total * BEAMS * args.steps / elapsed,
                 "units_of_1M_particle_cycles_per_s": world * args.steps / elapsed * (n_local / 1_000_000),
             },
