@@ -1,8 +1,10 @@
 // map_build.cpp — see map_build.h.
 #include "map_build.h"
 
+#include <algorithm>
 #include <cmath>
 #include <queue>
+#include <thread>
 
 namespace mcl {
 namespace {
@@ -40,6 +42,24 @@ inline float squared_distance(uint32_t W, double res, uint32_t a, uint32_t b) {
   return static_cast<float>(dx * dx + dy * dy);
 }
 
+// Rows [first, last) of a pass whose cells do not depend on one another, on all cores (any split gives the same bits).
+template <class Fn>
+void parallel_rows(uint32_t rows, Fn&& fn) {
+  unsigned workers = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+  if (rows < 512) workers = 1;
+  if (workers <= 1) {
+    fn(0u, rows);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const uint32_t per = (rows + workers - 1) / workers;
+  for (unsigned k = 0; k < workers; ++k) {
+    const uint32_t a = std::min(rows, k * per), b = std::min(rows, a + per);
+    if (a < b) pool.emplace_back([&fn, a, b] { fn(a, b); });
+  }
+  for (auto& t : pool) t.join();
+}
+
 }  // namespace
 
 void build_likelihood_field(const int8_t* cells, uint32_t W, uint32_t H, double resolution, const OccupancyTraits& traits,
@@ -50,19 +70,29 @@ void build_likelihood_field(const int8_t* cells, uint32_t W, uint32_t H, double 
 
   // distance_map.hpp:55-98.  The wavefront pops the closest frontier cell and labels its unvisited
   // 4-neighbours (+x, +y, -x, -y: linear_grid.hpp:113-130) with the distance to the PARENT's obstacle.
+  // Only the wavefront itself depends on an order (the pop order of the reference's std::priority_queue decides which neighbour
+  // labels a cell: it is kept as it is, 85 % of the build's time at 16 M cells); the seed mask before it and the passes behind
+  // it go row by row on all cores, with the same bits.
   std::vector<float>& dist = field;
-  dist.assign(n, max_sq);
+  dist.resize(n);
+  std::vector<uint8_t> seed_mask(n);
+  parallel_rows(H, [&](uint32_t y0, uint32_t y1) {
+    for (size_t i = static_cast<size_t>(y0) * W; i < static_cast<size_t>(y1) * W; ++i) {
+      const bool seed = p.only_obstacle_boundaries ? g.obstacle_edge(i) : g.occupied(i);
+      seed_mask[i] = seed ? 1 : 0;
+      dist[i] = seed ? 0.f : max_sq;
+    }
+  });
   std::vector<bool> visited(n, false);
   auto farther = [&dist](const Entry& a, const Entry& b) { return dist[a.index] > dist[b.index]; };
   std::priority_queue<Entry, std::vector<Entry>, decltype(farther)> frontier(farther);
-  for (size_t i = 0; i < n; ++i) {
-    const bool seed = p.only_obstacle_boundaries ? g.obstacle_edge(i) : g.occupied(i);
-    if (seed) {
+  for (size_t i = 0; i < n; ++i) {  // in index order, like the reference's enumerate (distance_map.hpp:74-80)
+    if (seed_mask[i]) {
       visited[i] = true;
-      dist[i] = 0;
       frontier.push(Entry{static_cast<uint32_t>(i), static_cast<uint32_t>(i)});
     }
   }
+  std::vector<uint8_t>().swap(seed_mask);
   auto relax = [&](const Entry& parent, size_t index) {
     if (visited[index]) return;
     visited[index] = true;
@@ -87,18 +117,22 @@ void build_likelihood_field(const int8_t* cells, uint32_t W, uint32_t H, double 
   const double amplitude = p.z_hit / (p.sigma_hit * std::sqrt(2 * kPiD));
   const double offset = p.z_random / p.max_laser_distance;
 
+  float overlay = 0.f;
   if (p.model_unknown_space) {  // :160-179
     const double inverse_max_distance = 1 / p.max_laser_distance;
     const double squared_background_distance = -two_squared_sigma * std::log((inverse_max_distance - offset) / amplitude);
-    const float overlay = std::min(max_sq, static_cast<float>(squared_background_distance));
-    for (size_t i = 0; i < n; ++i) {
-      const bool masked = p.only_obstacle_boundaries ? (g.unknown(i) || (g.occupied(i) && !g.obstacle_edge(i))) : g.unknown(i);
-      if (masked) dist[i] = overlay;
+    overlay = std::min(max_sq, static_cast<float>(squared_background_distance));
+  }
+  parallel_rows(H, [&](uint32_t y0, uint32_t y1) {
+    for (size_t i = static_cast<size_t>(y0) * W; i < static_cast<size_t>(y1) * W; ++i) {
+      if (p.model_unknown_space) {
+        const bool masked = p.only_obstacle_boundaries ? (g.unknown(i) || (g.occupied(i) && !g.obstacle_edge(i))) : g.unknown(i);
+        if (masked) dist[i] = overlay;
+      }
+      // :181-182, in place on the float map
+      field[i] = static_cast<float>(amplitude * std::exp(-static_cast<double>(dist[i]) / two_squared_sigma) + offset);
     }
-  }
-  for (size_t i = 0; i < n; ++i) {  // :181-182, in place on the float map
-    field[i] = static_cast<float>(amplitude * std::exp(-static_cast<double>(dist[i]) / two_squared_sigma) + offset);
-  }
+  });
 }
 
 void collect_free_cells(const int8_t* cells, uint32_t W, uint32_t H, const OccupancyTraits& traits, std::vector<uint32_t>& out) {
