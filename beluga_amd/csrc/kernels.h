@@ -158,6 +158,8 @@ struct Tuning {
                                     // it) may go through two half patches (beams [0, k) and [k, 8): 32 x 64 or 64 x 32 cells each); 0 = never
   int lf_margin = 1;                // LDS-patch planner, rotation part of the bound: 1 = per axis (|sin d| |q'y| + (1 - cos d) |q'x|),
                                     // 0 = round 2's |R_p - R_ref| |q| on both axes
+  int beam_free_ahead = 1;          // beam model, ordered kernel: a workgroup's lanes pass the cells its middle ray's clearance proves free in one
+                                    // closed-form step (per beam and workgroup); 0 = block-distance skips only
   int lf_pipe = 0;                  // LDS-patch kernel: 1 = persistent workgroups whose producer wave also fetches the next block's poses and
                                     // writes the previous block's weights (k_reweight_lf_pipe) where it applies, 0 = one workgroup per block.
                                     // Bit-identical; measured SLOWER (0.51 vs 0.44 ms at 1M x 1080, profiles/r04_lf_pipe_study.txt): off
@@ -287,7 +289,7 @@ constexpr uint32_t kBeamPointDoubles = 5;
 // d_beam_table (optional, ordered variant): launch_beam_table's output, beam_table_count entries of 4 doubles
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
                           unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points,
-                          const double* d_beam_table = nullptr, uint32_t beam_table_count = 0);
+                          const double* d_beam_table = nullptr, uint32_t beam_table_count = 0, bool free_ahead = true);
 // The beam model's terms that depend on the expected range alone, tabulated over the squared cell distance of the hit (kernels.hip
 // BeamTable): entries = beam_table_entries(...) (0: the range spans too many cells for a table), 4 doubles each.
 constexpr double kBeamTableMaxCells = 2046.0;

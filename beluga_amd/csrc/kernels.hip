@@ -2992,7 +2992,9 @@ __device__ __forceinline__ void walk_seek(RayWalk& r, int k, int error) {
 constexpr int kRuntimeStep = 0x7FFFFFFF;
 constexpr int kCoarse = kWin / 8, kCoarseWords = kCoarse / 32;  // 128 x 128 blocks, 4 words per row of blocks
 // LDS of the ordered beam kernel: the bit window, its two coarse bitmaps, the block distance map
-constexpr size_t kBeamLds = (static_cast<size_t>(kWin) * kWinStride + 2 * kCoarse * kCoarseWords) * sizeof(uint32_t) + kCoarse * kCoarse;
+constexpr uint32_t kBeamCertified = 2048;  // beams with a "free ahead" entry (2 bytes each) behind the maps; 64 floats of scratch behind them
+constexpr size_t kBeamLds = (static_cast<size_t>(kWin) * kWinStride + 2 * kCoarse * kCoarseWords) * sizeof(uint32_t) + kCoarse * kCoarse +
+                            kBeamCertified * sizeof(uint16_t) + 64 * sizeof(float);
 
 // Cells u = 0 .. count-1 (count <= 8) from (lx, ly, error): their words are fetched together (where they lie does not depend
 // on what they hold) and examined in order.  Returns the index of the first non-free one or -1; `advance` also moves
@@ -3137,9 +3139,11 @@ __device__ __forceinline__ int examine_column(const BlockMaps& maps, int major, 
   return hits ? __builtin_ctz(hits) : -1;
 }
 
+// k_start: that many cells from the current one on are known to be free (the ordered beam kernel's per-beam certificate, see
+// k_reweight_beam_sorted): they are passed in one closed-form step.
 template <int STEEP, int MAJ, int MIN>
 __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int& ly, int& error, int& k, int& hit_k, int upto, int dminor,
-                                            int dmajor, bool r_steep, int r_major_step, int r_minor_step) {
+                                            int dmajor, bool r_steep, int r_major_step, int r_minor_step, int k_start = 0) {
   const bool steep = STEEP == kRuntimeStep ? r_steep : (STEEP != 0);
   const int major_step = MAJ == kRuntimeStep ? r_major_step : MAJ, minor_step = MIN == kRuntimeStep ? r_minor_step : MIN;
   if (k > upto) return;
@@ -3165,6 +3169,13 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
     if (steep) ly += j * major_step;
     else lx += j * major_step;
   };
+  if (k_start > 0 && closed_forms) {
+    MCL_BEAM_STAT(10);  // a certified start
+    const int j = min(k_start, upto - k + 1);
+    advance_free(j);
+    k += j;
+    if (k > upto) return;
+  }
   // 1. up to the end of the first block column
   {
     const int major = steep ? ly : lx;
@@ -3274,20 +3285,21 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
 // instance with a compile-time major axis; the step directions stay run-time values (one instance per octant made the kernel
 // outgrow the instruction cache).
 __device__ __forceinline__ void walk_blocks_any(const BlockMaps& maps, const RayWalk& r, int& lx, int& ly, int& error, int& k, int& hit_k,
-                                                int upto) {
+                                                int upto, int k_start = 0) {
   const int wave_steep = __builtin_amdgcn_readfirstlane(r.steep ? 1 : 0);
   if (__builtin_amdgcn_ballot_w64((r.steep ? 1 : 0) != wave_steep) == 0) {
-    if (wave_steep) walk_blocks<1, kRuntimeStep, kRuntimeStep>(maps, lx, ly, error, k, hit_k, upto, r.dminor, r.dmajor, true, r.major_step, r.minor_step);
-    else walk_blocks<0, kRuntimeStep, kRuntimeStep>(maps, lx, ly, error, k, hit_k, upto, r.dminor, r.dmajor, false, r.major_step, r.minor_step);
+    if (wave_steep) walk_blocks<1, kRuntimeStep, kRuntimeStep>(maps, lx, ly, error, k, hit_k, upto, r.dminor, r.dmajor, true, r.major_step, r.minor_step, k_start);
+    else walk_blocks<0, kRuntimeStep, kRuntimeStep>(maps, lx, ly, error, k, hit_k, upto, r.dminor, r.dmajor, false, r.major_step, r.minor_step, k_start);
   } else {
     walk_blocks<kRuntimeStep, kRuntimeStep, kRuntimeStep>(maps, lx, ly, error, k, hit_k, upto, r.dminor, r.dmajor, r.steep, r.major_step,
-                                                          r.minor_step);
+                                                          r.minor_step, k_start);
   }
 }
 
+// free_ahead: cells of Euclidean distance from the source up to which every cell of this lane's trace is known to be free (0: nothing known)
 template <bool kCell = false>
 __device__ __forceinline__ auto cast_ray_window(const GridView& g, const BitWindow& w, int sx, int sy, int fx, int fy,
-                                                double max_range, unsigned long long& steps) {
+                                                double max_range, unsigned long long& steps, float free_ahead = 0.f) {
   RayWalk r = walk_begin<false>(g, sx, sy, fx, fy);
   // Cells inside the grid AND the window (a box): one closed-form bound.  The grid's own bound is only needed by a ray that
   // leaves the window without a hit.
@@ -3303,7 +3315,14 @@ __device__ __forceinline__ auto cast_ray_window(const GridView& g, const BitWind
     const BlockMaps lds_maps{w.lds, kWinStride, kWin - 1, kWin - 1, rows, rows + kCoarse * kCoarseWords, kCoarseWords, kCoarseWords,
                              reinterpret_cast<const uint8_t*>(rows + 2 * kCoarse * kCoarseWords), kCoarse};
     MCL_BEAM_STAT(7);  // a walk inside the LDS window
-    walk_blocks_any(lds_maps, r, lx, ly, error, k, hit_k, upto);
+    // cell k of the trace lies k * |line| / major_span from the source (within a cell): the cells below free_ahead, less two for the roundings
+    int k_start = 0;
+    if (free_ahead > 0.f) {
+      const float dxs = static_cast<float>(fx - sx), dys = static_cast<float>(fy - sy);
+      const float length = sqrtf(dxs * dxs + dys * dys);
+      k_start = length > 0.f ? static_cast<int>(free_ahead * static_cast<float>(r.major_span) * __builtin_amdgcn_rcpf(length) * 0.999f) - 2 : 0;
+    }
+    walk_blocks_any(lds_maps, r, lx, ly, error, k, hit_k, upto, k_start);
     if (hit_k >= 0) {
       walk_seek(r, hit_k, 0);
       return walk_result<kCell>(g, r, true, max_range, steps);
@@ -3497,7 +3516,7 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
                                                                      uint32_t B, const uint32_t* __restrict__ perm,
                                                                      const double4* __restrict__ pose, unsigned long long* d_steps,
                                                                      double* __restrict__ partial, uint32_t beams_per_segment,
-                                                                     BeamTable table) {
+                                                                     BeamTable table, uint32_t free_ahead_on) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* win = reinterpret_cast<uint32_t*>(smem);
   const uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * kBeamBlock;
@@ -3576,10 +3595,72 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
   // goes to partial[segment][t] and k_lf_combine adds the segments in order
   const uint32_t b_begin = partial ? blockIdx.y * beams_per_segment : 0u;
   const uint32_t b_end = partial ? (b_begin + beams_per_segment < B ? b_begin + beams_per_segment : B) : B;
+  // "Free ahead", per beam and workgroup: the workgroup's 1024 poses are neighbours of the spatial order, so their traces of one
+  // beam run side by side - a lane's point at distance t along its ray is within  D + t R  of the middle particle's point at the same
+  // distance (D: the largest distance of a pose from the middle one, R: the largest |R_p - R_middle| = chord of the heading
+  // difference), plus a cell for each of the roundings involved (cell centres for poses, the integer line for the ray, Bresenham's
+  // half cell).  Where the middle particle's ray sits in a block whose Chebyshev distance c to the nearest block holding a non-free
+  // cell (the block distance map) leaves that much room - every cell within 8 (c - 1) cells of any cell of the block is free -,
+  // all the lanes' cells up to there are free: one thread per beam walks the middle ray block by block and leaves the distance, and
+  // every lane passes its share of it in ONE closed-form step instead of five or six block-distance skips (which then only
+  // serve the rest of the trace).  Free cells stay free: the first non-free cell, hence Ray2d::cast's result and the count of
+  // cells visited (raycasting.hpp:97-107, bresenham.hpp:122-160), do not change.
+  uint16_t* s_free_ahead = reinterpret_cast<uint16_t*>(smem + (static_cast<size_t>(kWin) * kWinStride + 2 * kCoarse * kCoarseWords) * sizeof(uint32_t) +
+                                                       kCoarse * kCoarse);
+  float* s_spread = reinterpret_cast<float*>(s_free_ahead + kBeamCertified);
+  const bool certified = free_ahead_on != 0u && b_end - b_begin <= kBeamCertified && m.beam_max_range / g.resolution < 4096.0;
+  if (certified) {
+    const Pose2 middle = ordered_pose(g.origin_inverse, pose, perm[tm]);
+    const float inv_res = static_cast<float>(1.0 / g.resolution);
+    float d_pos = sqrtf(static_cast<float>((src.x - middle.x) * (src.x - middle.x) + (src.y - middle.y) * (src.y - middle.y))) * inv_res;
+    float d_rot = sqrtf(static_cast<float>((src.r.c - middle.r.c) * (src.r.c - middle.r.c) + (src.r.s - middle.r.s) * (src.r.s - middle.r.s)));
+    if (!(d_pos < 1e6f && d_rot < 4.f)) d_pos = d_rot = INFINITY;  // (a non-finite pose: no certificate)
+    for (int o = 32; o > 0; o >>= 1) {
+      d_pos = fmaxf(d_pos, __shfl_xor(d_pos, o));
+      d_rot = fmaxf(d_rot, __shfl_xor(d_rot, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_spread[2 * (threadIdx.x >> 6)] = d_pos;
+      s_spread[2 * (threadIdx.x >> 6) + 1] = d_rot;
+    }
+    __syncthreads();
+    float D = 0.f, R = 0.f;
+    for (int q = 0; q < kBeamBlock / 64; ++q) {
+      D = fmaxf(D, s_spread[2 * q]);
+      R = fmaxf(R, s_spread[2 * q + 1]);
+    }
+    D = D * 1.001f + 3.f;  // + the cells of the roundings
+    R = R * 1.001f;
+    const uint8_t* dist = reinterpret_cast<const uint8_t*>(win + kWin * kWinStride + 2 * kCoarse * kCoarseWords);
+    const float wx = static_cast<float>(middle.x) * inv_res - static_cast<float>(bw.x0), wy = static_cast<float>(middle.y) * inv_res - static_cast<float>(bw.y0);
+    const float reach = static_cast<float>(m.beam_max_range) * inv_res;
+    for (uint32_t b = b_begin + threadIdx.x; b < b_end; b += kBeamBlock) {
+      const BeamPoint q = pts[b];
+      double ex, ey;
+      rot_apply(middle.r, q.ux, q.uy, ex, ey);
+      const float dx = static_cast<float>(ex / m.beam_max_range), dy = static_cast<float>(ey / m.beam_max_range);  // the middle ray's direction
+      float t = 0.f;
+#pragma unroll 1
+      for (; t < reach; t += 8.f) {
+        const float px = wx + t * dx, py = wy + t * dy;
+        if (!(px >= 0.f && py >= 0.f && px < static_cast<float>(kWin) && py < static_cast<float>(kWin))) break;  // (NaN: no certificate)
+        // (the window's distance map says nothing about blocks beyond the grid)
+        if (!(px + static_cast<float>(bw.x0) >= 0.f && py + static_cast<float>(bw.y0) >= 0.f && px + static_cast<float>(bw.x0) < static_cast<float>(g.W) &&
+              py + static_cast<float>(bw.y0) < static_cast<float>(g.H)))
+          break;
+        const int c = dist[(static_cast<int>(py) >> 3) * kCoarse + (static_cast<int>(px) >> 3)];
+        // the points of [t, t + 8) lie within 8 cells of this one
+        if (!(D + (t + 8.f) * R + 8.f <= static_cast<float>(8 * (c - 1)))) break;
+      }
+      s_free_ahead[b - b_begin] = static_cast<uint16_t>(t);
+    }
+    __syncthreads();
+  }
   for (uint32_t b = b_begin; b < b_end; ++b) {
     MCL_BEAM_STAT(0);  // a beam
+    const float free_ahead = certified ? static_cast<float>(s_free_ahead[b - b_begin]) : 0.f;
     acc += beam_term<kTable>(g, m, norm_hit, src, pts[b], table, sx, sy, [&](int fx, int fy) {
-      return cast_ray_window<kTable>(g, bw, sx, sy, fx, fy, m.beam_max_range, steps);
+      return cast_ray_window<kTable>(g, bw, sx, sy, fx, fy, m.beam_max_range, steps, free_ahead);
     });
   }
   if (d_steps) {
@@ -5098,7 +5179,7 @@ void launch_beam_table(hipStream_t st, BeamModel m, double resolution, uint32_t 
 
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
                           unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points,
-                          const double* d_beam_table, uint32_t beam_table_count) {
+                          const double* d_beam_table, uint32_t beam_table_count, bool free_ahead) {
   if (n == 0 || B == 0) return;
   if (sorted && nonfree_bits) {
     const size_t lds = kBeamLds;
@@ -5118,11 +5199,11 @@ void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, B
     if (d_beam_table && beam_table_count)
       hipLaunchKernelGGL(k_reweight_beam_sorted<true>, dim3(groups, segments), dim3(kBeamBlock), lds, st, p.w, n, g, m,
                          nonfree_layout(g.W, g.H, const_cast<uint32_t*>(nonfree_bits)), table, B, sorted->perm, p.pose, d_steps, partial,
-                         per_segment, BeamTable{reinterpret_cast<const double4*>(d_beam_table), beam_table_count - 1u});
+                         per_segment, BeamTable{reinterpret_cast<const double4*>(d_beam_table), beam_table_count - 1u}, free_ahead ? 1u : 0u);
     else
       hipLaunchKernelGGL(k_reweight_beam_sorted<false>, dim3(groups, segments), dim3(kBeamBlock), lds, st, p.w, n, g, m,
                          nonfree_layout(g.W, g.H, const_cast<uint32_t*>(nonfree_bits)), table, B, sorted->perm, p.pose, d_steps, partial,
-                         per_segment, BeamTable{nullptr, 0u});
+                         per_segment, BeamTable{nullptr, 0u}, free_ahead ? 1u : 0u);
     if (segments > 1) hipLaunchKernelGGL(k_lf_combine, dim3(blocks_for(n)), dim3(kBlock), 0, st, p.w, n, sorted->perm, partial, segments, 2);
     return;
   }

@@ -45,5 +45,5 @@ if "5" in args.configs:
     n = args.particles5
     p = AmclParams(min_particles=n, max_particles=n)
     f = Amcl(grid, motion, BeamModelParam(beam_max_range=30.0), p, seed=42)
-    run("config5", f, min(args.steps, 4))
+    run("config5", f, args.steps if os.environ.get("CONFIG5_ALL_STEPS") else min(args.steps, 4))
     f.close()
