@@ -293,6 +293,7 @@ struct mcl_ctx {
   // with a probe every 16th launch (option lf_patch = 1).
   uint64_t lf_patch_launches{0};
   uint64_t lf_pipe_launches{0};  // of which by the persistent, pipelined form (k_reweight_lf_pipe)
+  uint64_t lf_queue_launches{0};  // of which by resident workgroups that take their blocks from a queue (k_reweight_lf_patch<false, true>)
   uint64_t patch_seen_planned{0}, patch_seen_through{0};
   bool patch_useful{true};
   int patch_probe_in{0};
@@ -877,7 +878,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     const bool scan_is_short = ctx->scan_extent / ctx->resolution < 8192.0;
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
     const bool use_patches = mode.patches;
-    bool far_tiles_used = false, pipe_used = false;
+    bool far_tiles_used = false, pipe_used = false, queue_used = false;
     if (mode.beams) ctx->lf_beams_launches += 1;
     launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B), variant, &sort,
                        scan_is_short, ctx->tuning, use_patches,
@@ -887,9 +888,10 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
                                   static_cast<uint32_t>(ctx->tuning.lf_split), want_weight_sums ? ctx->d_lf_wsum.ptr : nullptr,
                                   reinterpret_cast<unsigned int*>(ctx->d_scalars.ptr + 30)},
                        /*dispersed=*/!use_patches && (ctx->tuning.lf_far_tiles == 2 || (ctx->tuning.lf_patch == 1 && !ctx->patch_useful)),
-                       &far_tiles_used, &ctx->lf_wsum_count, &pipe_used);
+                       &far_tiles_used, &ctx->lf_wsum_count, &pipe_used, &queue_used);
     if (far_tiles_used) ctx->lf_far_launches += 1;
     if (pipe_used) ctx->lf_pipe_launches += 1;
+    if (queue_used) ctx->lf_queue_launches += 1;
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
     if (variant == kLfSortedLanes && ctx->tuning.lf_fast != 0 && scan_is_short && ctx->W < 16384 && ctx->H < 16384 && ctx->pal_count &&
         ctx->tuning.lf_table == 0)
@@ -1966,7 +1968,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_pipe", "lf_pipe_grid", "beam_free_ahead", "lf_weight_sums", "beam_table", "cycle_spin"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_pipe", "lf_pipe_grid", "lf_queue", "beam_free_ahead", "lf_weight_sums", "beam_table", "cycle_spin"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2880,6 +2882,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "lf_margin") t.lf_margin = value ? 1 : 0;
   else if (key == "lf_producer") t.lf_producer = value ? 1 : 0;
   else if (key == "lf_pipe") t.lf_pipe = value ? 1 : 0;
+  else if (key == "lf_queue") t.lf_queue = value ? 1 : 0;
   else if (key == "beam_free_ahead") t.beam_free_ahead = value ? 1 : 0;
   else if (key == "lf_pipe_grid") t.lf_pipe_grid = static_cast<int>(std::clamp<int64_t>(value, 0, 1 << 20));
   else if (key == "cycle_spin") t.cycle_spin = value ? 1 : 0;
@@ -2906,6 +2909,7 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
   if (key == "lf_fast_launches") *value = ctx->lf_fast_launches;
   else if (key == "lf_patch_launches") *value = ctx->lf_patch_launches;
   else if (key == "lf_pipe_launches") *value = ctx->lf_pipe_launches;
+  else if (key == "lf_queue_launches") *value = ctx->lf_queue_launches;
   else if (key == "lf_beams_launches") *value = ctx->lf_beams_launches;
   else if (key == "lf_far_launches") *value = ctx->lf_far_launches;
   else if (key == "lf_far_tiles") *value = ctx->far_tiles;

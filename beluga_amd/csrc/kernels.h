@@ -164,6 +164,8 @@ struct Tuning {
                                     // writes the previous block's weights (k_reweight_lf_pipe) where it applies, 0 = one workgroup per block.
                                     // Bit-identical; measured SLOWER (0.51 vs 0.44 ms at 1M x 1080, profiles/r04_lf_pipe_study.txt): off
   int lf_pipe_grid = 0;             // its workgroups: 0 = three per CU, otherwise this many (tests: few workgroups, many blocks each)
+  int lf_queue = 1;                 // LDS-patch kernel: 1 = as many workgroups as stay resident (lf_pipe_grid) take the blocks from a queue where
+                                    // there are more blocks than that (k_reweight_lf_patch<false, true>), 0 = one workgroup per block.  Bit-identical.
 };
 
 // Spatial ordering of the particles (kLfSortedLanes, ordered beam kernel): the 64 lanes of a wave should hold neighbouring
@@ -281,7 +283,7 @@ struct PatchStats {
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
                         bool dispersed = false, bool* far_tiles_used = nullptr, uint32_t* weight_sums_written = nullptr,
-                        bool* pipe_used = nullptr);
+                        bool* pipe_used = nullptr, bool* queue_used = nullptr);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_order_particles first).
 // d_beam_points: scratch of kBeamPointDoubles * B doubles (per-beam terms shared by all particles; ordered variant only).

@@ -879,6 +879,8 @@ __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, 
 // [4] their cycles, [5] of which at barriers, [6] consumer cycles before the main loop (planning), [7] producer cycles waiting for its loads.  Compiled out of the product.
 #ifdef MCL_LF_TIMING
 __device__ unsigned long long g_lf_timing[16];
+// per workgroup of k_reweight_lf_patch (tools/exp_lf_workgroups.py): {start, end (s_memrealtime, 100 MHz), groups | fitting << 16 | loose << 31, HW_ID}
+__device__ unsigned long long g_lf_wg[4 * 8192];
 #ifdef MCL_LF_TIMING_COARSE  // (no timer around the barriers of the main loop: they distort it 2x)
 #define MCL_LF_BARRIER(statement) statement
 #else
@@ -903,8 +905,18 @@ constexpr int kPatchW = 64, kPatchH = 64;  // cells
 // columns on different banks (with 128, every column of a row pair would share one).
 constexpr uint32_t kPatchPitch = kPatchH * 2 + 16;
 constexpr uint32_t kPatchBytes = kPatchW * kPatchPitch;
-constexpr uint32_t kPatchParticles = kPalBlock - 64;  // per workgroup, with a producer wave (k_reweight_lf_patch<false>)
-constexpr uint32_t kPatchParticlesAll = kPalBlock;    // per workgroup when every wave holds particles (k_reweight_lf_patch<true>)
+#ifndef MCL_PATCH_BLOCK
+#define MCL_PATCH_BLOCK 512
+#endif
+#ifndef MCL_PATCH_LDS_PAD  // measurement builds: unused workgroup memory, so that fewer workgroups share a CU
+#define MCL_PATCH_LDS_PAD 0
+#endif
+#ifndef MCL_PATCH_WAVES
+#define MCL_PATCH_WAVES 6
+#endif
+constexpr int kPatchBlock = MCL_PATCH_BLOCK;  // threads of k_reweight_lf_patch: the waves that hold particles and, without kShared, the producer
+constexpr uint32_t kPatchParticles = kPatchBlock - 64;  // per workgroup, with a producer wave (k_reweight_lf_patch<false>)
+constexpr uint32_t kPatchParticlesAll = kPatchBlock;    // per workgroup when every wave holds particles (k_reweight_lf_patch<true>)
 constexpr uint32_t kPatchPlanned = 192;               // groups with a plan entry (scans of up to 1536 points); the ones beyond are gathered
 // Patch buffers: THREE with a producer wave, so that the consumers need no wait at a group's barrier - the look-ups of group g
 // (issued at the end of step g, used in step g + 1) have returned long before the buffer of group g is written again behind
@@ -918,7 +930,7 @@ constexpr uint32_t kPatchPlanned = 192;               // groups with a plan entr
 #define MCL_BARE_BARRIER 1
 #endif
 constexpr uint32_t patch_buffers(bool shared) { return shared ? 2u : MCL_PATCH_BUFFERS; }
-constexpr uint32_t patch_lds_bytes(bool shared) { return patch_buffers(shared) * kPatchBytes + kPatchPlanned * 32 + 48 * 4 + (shared ? kPalBlock * 8 : 0u); }
+constexpr uint32_t patch_lds_bytes(bool shared) { return patch_buffers(shared) * kPatchBytes + kPatchPlanned * 32 + 48 * 4 + (shared ? kPatchBlock * 8 : 0u); }
 constexpr double kPatchMagic = 1572864.0 + 4.656612873077392578125e-10;     // 1.5 * 2^20 + 2^-31
 // kShared: no producer wave.  All eight waves hold particles, and each fetches an eighth of the next group's patch itself with
 // buffer_load_dwordx4 ... lds (global memory -> LDS without passing through registers: lane i's 16 bytes land at M0 + 16 i,
@@ -928,16 +940,39 @@ constexpr double kPatchMagic = 1572864.0 + 4.656612873077392578125e-10;     // 1
 // leaves one wave in eight without arithmetic; this one has none idle.  (Half patches and patches that need clamping at the
 // table's border are left to the producer form: here such groups are gathered.)
 // 6 waves per SIMD = three workgroups per CU: at most 80 registers
-template <bool kShared>
-__global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reweight_lf_patch(double* __restrict__ w, uint64_t n, FieldView f,
-                                                                 const double* __restrict__ pts, uint32_t B,
-                                                                 const uint32_t* __restrict__ perm, const double4* __restrict__ pose,
-                                                                 double* __restrict__ partial, uint32_t beams_per_segment,
-                                                                 uint32_t patch_base /* LDS byte offset, 16-aligned */,
-                                                                 PatchStats stats) {
+// The kernel's arguments as one structure: it is the kernel argument segment, byte for byte.
+struct PatchArgs {
+  double* w;
+  uint64_t n;
+  FieldView f;
+  const double* pts;
+  uint32_t B;
+  const uint32_t* perm;
+  const double4* pose;
+  double* partial;
+  uint32_t beams_per_segment;
+  uint32_t patch_base;  // LDS byte offset, 16-aligned
+  PatchStats stats;
+  uint32_t nblocks;
+};
+template <bool kShared, bool kQueue = false>
+__global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL_PATCH_WAVES, MCL_PATCH_WAVES))) void k_reweight_lf_patch(PatchArgs args) {
+  // The arguments are read from the kernel argument segment at the start of every block (scalar loads), its address through an empty asm
+  // statement so that the loads are not hoisted out of the queue's loop (kQueue): held in registers from the kernel's entry on they would all
+  // stay alive around that loop - 90 scalar registers spilled.
+  typedef const __attribute__((address_space(4))) unsigned char* kernarg_bytes_t;
+  const kernarg_bytes_t kernarg = (kernarg_bytes_t)(__builtin_amdgcn_kernarg_segment_ptr());
+  const PatchArgs* ka = (const PatchArgs*)(kernarg);
+  double* const w = ka->w;
+  const uint64_t n = ka->n;
+  const FieldView& f = ka->f;  // (used once, in front of the loop)
+  const uint32_t patch_base = ka->patch_base;
+  const PatchStats& stats = ka->stats;
+  const uint32_t nblocks = ka->nblocks;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef MCL_LF_TIMING
   const long long lf_t0 = __builtin_readcyclecounter();
+  unsigned long long lf_wall0 = __builtin_amdgcn_s_memrealtime();
   long long lf_barrier_cycles = 0, lf_t_main = lf_t0, lf_load_wait = 0;
 #endif
   if constexpr ((MCL_ABLATE & 512) != 0) {  // timing only: what launching the workgroups costs
@@ -946,10 +981,10 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   }
   if constexpr (!(MCL_ABLATE & 64)) {
     uint32_t* s_row = reinterpret_cast<uint32_t*>(smem);
-    for (uint32_t j = threadIdx.x; j < f.H + 2; j += kPalBlock)
+    for (uint32_t j = threadIdx.x; j < f.H + 2; j += kPatchBlock)
       s_row[j] = palette_row_offset(static_cast<int32_t>(j) - 1, f.pal_pitch) - kFastBiasX;
     double* s_pal = reinterpret_cast<double*>(smem + f.pal_base);
-    for (uint32_t k = threadIdx.x; k < f.pal_count; k += kPalBlock) s_pal[k] = f.pal_val[k];
+    for (uint32_t k = threadIdx.x; k < f.pal_count; k += kPatchBlock) s_pal[k] = f.pal_val[k];
   }
   // plan entry of group g: {x0A, y0A | flags, x0B, y0B | first beam of half B} - biased origins, y0 multiples of 8;
   // flags: 1 = the group goes through a patch, 2 = split into two halves side by side (32 x 64 cells each), 4 = split into two
@@ -968,13 +1003,49 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   int4* s_plan = reinterpret_cast<int4*>(smem + patch_base + kBuffers * kPatchBytes);
   int4* s_plan_k = s_plan + kPatchPlanned;
   float* s_bound = reinterpret_cast<float*>(smem + patch_base + kBuffers * kPatchBytes + kPatchPlanned * 32);  // [7][6]
-  constexpr uint32_t kConsumers = kShared ? kPalBlock / 64 : kPalBlock / 64 - 1;  // waves that hold particles
+  constexpr uint32_t kConsumers = kShared ? kPatchBlock / 64 : kPatchBlock / 64 - 1;  // waves that hold particles
   constexpr uint32_t kParticles = kConsumers * 64;
-  const bool producer = !kShared && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPalBlock / 64 - 1);  // a scalar branch: the roles
+  const bool producer = !kShared && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPatchBlock / 64 - 1);  // a scalar branch: the roles
                                                                                                               // run different loops
-  const uint32_t lane = threadIdx.x & 63;
-  const uint64_t first = static_cast<uint64_t>(blockIdx.x) * kParticles;
-  const uint64_t t = producer ? first : first + threadIdx.x;  // (the producer holds no particle; it reads a valid one)
+  // kQueue: the launch holds as many workgroups as the device keeps resident, and each takes blocks of the order from a counter until
+  // none is left (stats.arrivals: nblocks + gridDim.x fetches per launch, the last of which wraps it to zero for the next one).  The
+  // hardware deals the workgroups of a grid out to the XCDs in turn, the same number to each whatever their speed - and under this
+  // kernel's load the XCDs of one device differ by 10 - 20 % (tools/exp_lf_workgroups.py): with the queue a faster one takes more blocks.
+  uint32_t* s_next = reinterpret_cast<uint32_t*>(s_bound) + 46;
+#pragma unroll 1
+  for (;;) {
+  uint32_t tid = threadIdx.x;  // (through an empty asm statement in the queue's loop: what derives from it is not kept across the blocks)
+  if constexpr (kQueue) asm volatile("" : "+v"(tid));
+  const uint32_t lane = tid & 63;
+  uint32_t kernarg_offset = 0;
+  if constexpr (kQueue) asm volatile("" : "+s"(kernarg_offset));
+  const PatchArgs* kb = (const PatchArgs*)(kernarg + kernarg_offset);
+  // References: read where they are used (again behind a barrier), which keeps what only the block's start, its end and the rare exact
+  // path need out of the main loop's registers.  Copies: what the main loop reads.
+  double* const& w = kb->w;
+  const uint64_t& n = kb->n;
+  const FieldView& f = kb->f;
+  const double* const pts = kb->pts;
+  const uint32_t B = kb->B;
+  const uint32_t* const& perm = kb->perm;
+  const double4* const& pose = kb->pose;
+  double* const& partial = kb->partial;
+  const uint32_t beams_per_segment = kb->beams_per_segment;
+  const PatchStats& stats = kb->stats;
+  const uint32_t nblocks = kb->nblocks;
+  uint32_t block = blockIdx.x;
+  if constexpr (kQueue) {
+    __syncthreads();  // the block before is done with the workgroup's memory
+    if (tid == 0) *s_next = atomicInc(stats.arrivals, nblocks + gridDim.x - 1u);
+    __syncthreads();
+    block = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(*s_next));
+    if (block >= nblocks) break;
+#ifdef MCL_LF_TIMING
+    lf_wall0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  }
+  const uint64_t first = static_cast<uint64_t>(block) * kParticles;
+  const uint64_t t = producer ? first : first + tid;  // (the producer holds no particle; it reads a valid one)
   const uint64_t tt = t < n ? t : n - 1;
   const uint32_t i = perm[tt];
   const Pose2 T = ordered_pose(f.world_to_field, pose, i);  // likelihood_field_model.hpp:70
@@ -1003,7 +1074,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       sum_s += __shfl_xor(sum_s, o);
     }
     if (lane == 0) {
-      float* mine = s_part + 6 * (threadIdx.x >> 6);
+      float* mine = s_part + 6 * (tid >> 6);
       mine[0] = lo_x;
       mine[1] = hi_x;
       mine[2] = lo_y;
@@ -1059,7 +1130,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       db = fmaxf(db, __shfl_xor(db, o));
     }
     if (lane == 0) {
-      float* mine = s_bound + 4 * (threadIdx.x >> 6);
+      float* mine = s_bound + 4 * (tid >> 6);
       mine[0] = dx;
       mine[1] = dy;
       mine[2] = da;
@@ -1077,8 +1148,8 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   if (beam_records) {
     const double2* scan = reinterpret_cast<const double2*>(pts) + b_begin;
 #pragma unroll
-    for (uint32_t pass = 0; pass < (kBuffers * kPatchBytes / sizeof(int4) + kPalBlock - 1) / kPalBlock; ++pass) {
-      const uint32_t b = pass * kPalBlock + threadIdx.x;
+    for (uint32_t pass = 0; pass < (kBuffers * kPatchBytes / sizeof(int4) + kPatchBlock - 1) / kPatchBlock; ++pass) {
+      const uint32_t b = pass * kPatchBlock + tid;
       if (b < planned * 8) {
         const double2 p = scan[b];
         const double sx = __builtin_fma(p.x, rc, __builtin_fma(-p.y, rs, rxm));
@@ -1095,7 +1166,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
 #pragma unroll 1
   for (int plan_rep = 0; plan_rep < ((MCL_ABLATE & 1024) ? 2 : 1); ++plan_rep) {  // (twice: timing only - is the plan's time hidden?)
   if constexpr ((MCL_ABLATE & 1024) != 0) asm volatile("" ::: "memory");
-  if (threadIdx.x < planned && beam_records) {
+  if (tid < planned && beam_records) {
     float Dx = 0.f, Dy = 0.f, Da = 0.f, Db = 0.f;
     for (uint32_t k = 0; k < kConsumers; ++k) {
       Dx = fmaxf(Dx, s_bound[4 * k]);
@@ -1108,7 +1179,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     Dy = Dy * 1.001f + 2.f;
     int4 rec[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rec[k] = s_beam[8 * threadIdx.x + k];
+    for (int k = 0; k < 8; ++k) rec[k] = s_beam[8 * tid + k];
     struct Range {
       int lo_x, hi_x, lo_y, hi_y;
       float reach_x, reach_y;
@@ -1194,17 +1265,17 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         first_b = static_cast<uint32_t>(k_split);
       }
     }
-    s_plan[threadIdx.x] = int4{x0a, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
+    s_plan[tid] = int4{x0a, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
     {
       const uint32_t ka = 0u - (static_cast<uint32_t>(x0a) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0a) << 1);
       // half B lives in columns 32 .. 63 (side by side) or in rows 32 .. 63 (stacked) of the same buffer
       const uint32_t kb = ((flags & 2u) ? (kPatchW / 2) * kPatchPitch : static_cast<uint32_t>(kPatchH)) -
                           (static_cast<uint32_t>(x0b) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0b) << 1);
       const uint32_t meta = flags == 0u ? 0u : ((flags & 6u) ? first_b : 8u);
-      s_plan_k[threadIdx.x] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), static_cast<int>(fetch_offset)};
+      s_plan_k[tid] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), static_cast<int>(fetch_offset)};
     }
     mine_fits = flags != 0u;
-  } else if (threadIdx.x < planned) {  // (a scan too long for the records: the plan straight from global memory, a beam after the other)
+  } else if (tid < planned) {  // (a scan too long for the records: the plan straight from global memory, a beam after the other)
     float Dx = 0.f, Dy = 0.f, Da = 0.f, Db = 0.f;
     for (uint32_t k = 0; k < kConsumers; ++k) {
       Dx = fmaxf(Dx, s_bound[4 * k]);
@@ -1215,7 +1286,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     // every float operation below may round down: scaled up by 1 + 2^-10 where it matters, and two cells of slack
     Dx = Dx * 1.001f + 2.f;
     Dy = Dy * 1.001f + 2.f;
-    const uint32_t q0 = b_begin + 8 * threadIdx.x;
+    const uint32_t q0 = b_begin + 8 * tid;
     const double2* q = reinterpret_cast<const double2*>(pts) + q0;
     // Do the beams [from, to) of this group fit a patch of PW x PH cells?  -> its origin.  (The end-points are evaluated anew
     // for every question - a few hundred operations for the 1 thread in 4 that plans, once per workgroup - rather than held
@@ -1291,14 +1362,14 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
         first_b = static_cast<uint32_t>(k);
       }
     }
-    s_plan[threadIdx.x] = int4{x0a, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
+    s_plan[tid] = int4{x0a, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
     {
       const uint32_t ka = 0u - (static_cast<uint32_t>(x0a) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0a) << 1);
       // half B lives in columns 32 .. 63 (side by side) or in rows 32 .. 63 (stacked) of the same buffer
       const uint32_t kb = ((flags & 2u) ? (kPatchW / 2) * kPatchPitch : static_cast<uint32_t>(kPatchH)) -
                           (static_cast<uint32_t>(x0b) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0b) << 1);
       const uint32_t meta = flags == 0u ? 0u : ((flags & 6u) ? first_b : 8u);
-      s_plan_k[threadIdx.x] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), static_cast<int>(fetch_offset)};
+      s_plan_k[tid] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), static_cast<int>(fetch_offset)};
     }
     mine_fits = flags != 0u;
   }
@@ -1311,11 +1382,11 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   uint32_t* s_count = reinterpret_cast<uint32_t*>(s_bound) + 4 * kConsumers;  // behind the bound's [7 or 8][4]
   {
     const uint32_t in_wave = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine_fits)));
-    if (lane == 0) s_count[threadIdx.x >> 6] = in_wave;
+    if (lane == 0) s_count[tid >> 6] = in_wave;
   }
   __syncthreads();
   uint32_t fitting = 0;
-  for (uint32_t k = 0; k < kPalBlock / 64; ++k) fitting += s_count[k];
+  for (uint32_t k = 0; k < kPatchBlock / 64; ++k) fitting += s_count[k];
   const bool loose = __builtin_amdgcn_readfirstlane(fitting) * 256u < groups * stats.loose_below;
   struct Plan {  // scalars
     uint32_t ka;    // less the buffer's base
@@ -1335,12 +1406,12 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   // (kept in LDS, one 8-byte read per fetch: the main loop has no two registers to spare for them)
   uint2* s_piece = reinterpret_cast<uint2*>(smem + patch_base + kBuffers * kPatchBytes + kPatchPlanned * 32 + 48 * 4);
   if constexpr (kShared) {
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = tid >> 6;
     const uint32_t ca = 72u * wave + lane, cb = 72u * wave + 64u + lane;
     uint32_t piece_a = 0xFFFFFFFFu, piece_b = 0xFFFFFFFFu;
     if (ca % 9u != 8u) piece_a = (ca / 9u) * 16u + (ca % 9u) * f.pal_pitch;
     if (lane < 8u && cb % 9u != 8u) piece_b = (cb / 9u) * 16u + (cb % 9u) * f.pal_pitch;
-    s_piece[threadIdx.x] = uint2{piece_a, piece_b};  // (read back by the same thread only)
+    s_piece[tid] = uint2{piece_a, piece_b};  // (read back by the same thread only)
   }
   typedef int rsrc_words_t __attribute__((ext_vector_type(4)));
   const rsrc_words_t rsrc_words = {static_cast<int>(reinterpret_cast<uintptr_t>(f.pal_idx) & 0xFFFFFFFFull),
@@ -1351,9 +1422,9 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       const int4 e = s_plan_k[g];
       if (__builtin_amdgcn_readfirstlane(e.y) != 8) return;  // no patch for this group
       const uint32_t offset = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.w));
-      const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+      const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
       const uint32_t to = buffer_of(g) + wave * (72u * 16u);
-      const uint2 mine = s_piece[threadIdx.x];
+      const uint2 mine = s_piece[tid];
       const uint32_t piece_a = mine.x, piece_b = mine.y;
       // In assembly rather than through __builtin_amdgcn_raw_ptr_buffer_load_lds: the compiler makes every LDS read behind such a
       // load wait for it (it cannot tell the patch buffer from the tables), i.e. stalls the wave for a memory latency once per
@@ -1373,12 +1444,12 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   // address would cost more than the kernel's other work - ; the last one to report copies the running totals to the
   // host's mirror.  Called by the workgroup's last wave (the producer, if there is one).
   auto report = [&]() {
-      const uint32_t stride = gridDim.x >= 256 ? 16u : 1u;
-      if (stats.device && lane == 0 && blockIdx.x % stride == 0) {
+      const uint32_t stride = nblocks >= 256 ? 16u : 1u;
+      if (stats.device && lane == 0 && block % stride == 0) {
         atomicAdd(stats.device + 0, static_cast<unsigned long long>(groups));
         atomicAdd(stats.device + 1, static_cast<unsigned long long>(loose ? 0u : fitting));
         __threadfence();
-        const unsigned long long reporters = static_cast<unsigned long long>((gridDim.x + stride - 1) / stride) * gridDim.y;
+        const unsigned long long reporters = static_cast<unsigned long long>((nblocks + stride - 1) / stride) * gridDim.y;
         const unsigned long long ticket = atomicAdd(stats.device + 2, 1ull) + 1ull;
         if (ticket % reporters == 0 && stats.mirror) {
           const unsigned long long planned = atomicAdd(stats.device + 0, 0ull), through = atomicAdd(stats.device + 1, 0ull);
@@ -1390,12 +1461,16 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       }
   };
   if constexpr ((MCL_ABLATE & 32) != 0) {  // timing only: the prologue (tables, poses, bound, plan) and nothing else
-    if (threadIdx.x == 0 && fitting == 0xFFFFFFFFu) w[0] = ixm + iym;
+    if (tid == 0 && fitting == 0xFFFFFFFFu) w[0] = ixm + iym;
     return;
   }
   if (producer) {
     if (loose) {
       report();
+      if constexpr (kQueue) {
+        if (stats.weight_sums) __syncthreads();  // (the consumers' barrier around the block's sum)
+        continue;
+      }
       return;
     }
 #ifdef MCL_PRODUCER_PRIO
@@ -1492,12 +1567,16 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     }
 #endif
     report();  // off the consumers' path: they are still at their last group
+    if constexpr (kQueue) {
+      if (stats.weight_sums) __syncthreads();  // (the consumers' barrier around the block's sum)
+      continue;
+    }
     return;
   }
 
   double acc = (f.prob || partial) ? 0.0 : 1.0;
 #if (MCL_ABLATE & 8192)
-  float lf_dummy = static_cast<float>(threadIdx.x);
+  float lf_dummy = static_cast<float>(tid);
 #endif
   const bool fast = __builtin_amdgcn_ballot_w64(!lane_small) == 0;  // per wave: a far particle sends its wave through the exact code
   const int c_lo = static_cast<int>(kFastBias) - 1, x_hi = static_cast<int>(kFastBias + f.W), y_hi = static_cast<int>(kFastBias + f.H);
@@ -1520,7 +1599,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     uint32_t zero = 0;
     const uint32_t* perm_again = perm;
     asm volatile("" : "+v"(zero), "+s"(perm_again));
-    position = static_cast<uint64_t>(blockIdx.x) * kParticles + (threadIdx.x + zero);
+    position = static_cast<uint64_t>(block) * kParticles + (tid + zero);
     return perm_again[position < n ? position : n - 1];
   };
   auto add_exact = [&](uint32_t b0, uint32_t count) {
@@ -1595,7 +1674,8 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
       if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
       return;
     }
-    const double* q = pts + 2 * b0;
+    // (the constant address space: scalar loads - `pts` is no kernel argument any more, of which the compiler knows that nobody writes there)
+    const __attribute__((address_space(4))) double* q = (const __attribute__((address_space(4))) double*)(pts + 2 * b0);
     int cx[8], cy[8];
     uint32_t lowest = 0xFFFFFFFFu;
 #pragma unroll
@@ -1673,6 +1753,14 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     atomicAdd(&g_lf_timing[2], static_cast<unsigned long long>(lf_barrier_cycles));
     atomicAdd(&g_lf_timing[6], static_cast<unsigned long long>(lf_t_main - lf_t0));
   }
+  if (tid == 0 && block < 8192 && blockIdx.y == 0) {
+    unsigned long long* rec = g_lf_wg + 4 * block;
+    rec[0] = lf_wall0;
+    rec[1] = __builtin_amdgcn_s_memrealtime();
+    rec[2] = groups | (loose ? 0u : fitting) << 16 | (loose ? 1u : 0u) << 31;
+    rec[3] = static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(4 /* HW_ID */ | (0 << 6) | (31 << 11))) |
+             static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(20 /* XCC_ID */ | (0 << 6) | (3 << 11))) << 32;
+  }
 #endif
   uint64_t t_end;
   const uint32_t i_end = particle_again(t_end);
@@ -1691,17 +1779,19 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
   if (stats.weight_sums) {
     double* s_sum = reinterpret_cast<double*>(s_bound);
     const double wave_total = wave_sum_f64(new_weight);
-    if (lane == 0) s_sum[threadIdx.x >> 6] = wave_total;
+    if (lane == 0) s_sum[tid >> 6] = wave_total;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       double total = s_sum[0];
       for (uint32_t k = 1; k < kConsumers; ++k) total += s_sum[k];
-      stats.weight_sums[blockIdx.x] = total;
+      stats.weight_sums[block] = total;
     }
   }
   if constexpr (kShared) {
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == kPalBlock / 64 - 1) report();
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) == kPatchBlock / 64 - 1) report();
   }
+  if constexpr (!kQueue) break;
+  }  // the next block of the queue
 }
 
 // ---- the patch kernel, persistent ---------------------------------------------------------------------------------------
@@ -1739,7 +1829,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
 // group (none in a block that gathers everything); A and B once more behind the last block, for its sums.  All eight waves
 // count the same.
 constexpr uint32_t kPipePlanned = 136;  // groups with a plan entry: scans of up to 1095 points
-constexpr uint32_t kPipeParkBytes = kPatchParticles * 32;
+constexpr uint32_t kPipeParkBytes = (kPalBlock - 64) * 32;
 constexpr int kPipeSlices = 23;
 struct PipeLds {  // absolute LDS byte addresses, 16-aligned
   uint32_t patch, plan, park, total;
@@ -1760,7 +1850,7 @@ __global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6)
     for (uint32_t k = threadIdx.x; k < f.pal_count; k += kPalBlock) s_pal[k] = f.pal_val[k];
   }
   constexpr uint32_t kConsumers = kPalBlock / 64 - 1;
-  constexpr uint32_t kParticles = kPatchParticles;  // 448: seven waves of particles
+  constexpr uint32_t kParticles = kPalBlock - 64;  // 448: seven waves of particles
   const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPalBlock / 64 - 1);
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t groups = B / 8;  // 1 .. kPipePlanned (the launcher's precondition)
@@ -4970,7 +5060,7 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
 
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
-                        bool dispersed, bool* far_tiles_used, uint32_t* weight_sums_written, bool* pipe_used) {
+                        bool dispersed, bool* far_tiles_used, uint32_t* weight_sums_written, bool* pipe_used, bool* queue_used) {
   if (weight_sums_written) *weight_sums_written = 0;
   if (far_tiles_used) *far_tiles_used = false;
   if (pipe_used) *pipe_used = false;
@@ -5023,14 +5113,14 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
         pipe.total = high;
         pipe_ok = pipe.total <= 53248;  // three workgroups per CU (tools/calib_lds_residency.hip)
       }
+      static int cus = 0;
+      if (cus == 0) {
+        int device = 0, count = 0;
+        if (hipGetDevice(&device) != hipSuccess || hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || count <= 0) count = 256;
+        cus = count;
+      }
       if (pipe_ok) {
-        static int cus = 0;
-        if (cus == 0) {
-          int device = 0, count = 0;
-          if (hipGetDevice(&device) != hipSuccess || hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || count <= 0) count = 256;
-          cus = count;
-        }
-        const uint32_t nblocks = static_cast<uint32_t>((n + kPatchParticles - 1) / kPatchParticles);
+        const uint32_t nblocks = static_cast<uint32_t>((n + (kPalBlock - 64u) - 1) / (kPalBlock - 64u));
         const uint32_t resident = tuning.lf_pipe_grid > 0 ? static_cast<uint32_t>(tuning.lf_pipe_grid) : 3u * static_cast<uint32_t>(cus);
         const unsigned grid_x = std::min(nblocks, resident);
         hipLaunchKernelGGL(k_reweight_lf_pipe, dim3(grid_x), dim3(kPalBlock), pipe.total, st, p.w, n, f, d_points, B, sort->perm, p.pose, pipe,
@@ -5041,12 +5131,19 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
         const uint32_t per_group = tuning.lf_producer == 0 ? kPatchParticlesAll : kPatchParticles;
         const unsigned groups_x = static_cast<unsigned>((n + per_group - 1) / per_group);
         if (segments > 1) patch_stats.weight_sums = nullptr;  // the segments' sums are combined by k_lf_combine
+        // A queue of blocks and as many workgroups as stay resident (three per CU) instead of a workgroup per block, where the launch
+        // has more blocks than that: see k_reweight_lf_patch.
+        const uint32_t resident = tuning.lf_pipe_grid > 0 ? static_cast<uint32_t>(tuning.lf_pipe_grid) : 3u * static_cast<uint32_t>(cus);
         if (tuning.lf_producer == 0)
-          hipLaunchKernelGGL(k_reweight_lf_patch<true>, dim3(groups_x, segments), dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B,
-                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats);
-        else
-          hipLaunchKernelGGL(k_reweight_lf_patch<false>, dim3(groups_x, segments), dim3(kPalBlock), patch_lds, st, p.w, n, f, d_points, B,
-                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats);
+          hipLaunchKernelGGL(k_reweight_lf_patch<true>, dim3(groups_x, segments), dim3(kPatchBlock), patch_lds, st, PatchArgs{p.w, n, f, d_points, B,
+                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x});
+        else if (tuning.lf_queue != 0 && segments == 1 && patch_stats.arrivals != nullptr && groups_x > resident) {
+          if (queue_used) *queue_used = true;
+          hipLaunchKernelGGL((k_reweight_lf_patch<false, true>), dim3(resident), dim3(kPatchBlock), patch_lds + MCL_PATCH_LDS_PAD, st, PatchArgs{p.w, n, f, d_points, B,
+                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x});
+        } else
+          hipLaunchKernelGGL(k_reweight_lf_patch<false>, dim3(groups_x, segments), dim3(kPatchBlock), patch_lds + MCL_PATCH_LDS_PAD, st, PatchArgs{p.w, n, f, d_points, B,
+                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x});
         if (weight_sums_written && patch_stats.weight_sums) *weight_sums_written = groups_x;
       }
       else if (fast && dispersed && tuning.lf_far_tiles != 0 && f.far_bits != nullptr && patch_base + f.far_bytes <= 65536) {
@@ -5127,7 +5224,7 @@ void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32
 // Nonzero for a measurement build of the kernels (tools/build_variant.sh: ablations compute nonsense by design, timing builds
 // distort): beluga_amd/capi.py refuses to load one as the product library unless told so.
 extern "C" int mcl_measurement_build(void) {
-#if MCL_ABLATE || MCL_PIPE_ABLATE || defined(MCL_LF_TIMING) || defined(MCL_BEAM_STATS) || defined(MCL_DRAW_ABLATE)
+#if MCL_ABLATE || MCL_PIPE_ABLATE || MCL_PATCH_LDS_PAD || defined(MCL_LF_TIMING) || defined(MCL_BEAM_STATS) || defined(MCL_DRAW_ABLATE)
   return 1;
 #else
   return 0;
@@ -5136,6 +5233,9 @@ extern "C" int mcl_measurement_build(void) {
 namespace mcl {
 #ifdef MCL_LF_TIMING
 }  // namespace mcl
+extern "C" int mcl_debug_lf_workgroups(unsigned long long* out, unsigned int workgroups) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mcl::g_lf_wg), 4 * sizeof(unsigned long long) * (workgroups < 8192u ? workgroups : 8192u)) != hipSuccess;
+}
 extern "C" int mcl_debug_lf_timing(unsigned long long* out16, int reset) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mcl::g_lf_timing), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
   if (reset) {
@@ -5161,6 +5261,9 @@ namespace mcl {
 // hipFuncSetAttribute is per device: contexts on several GPUs of one process each opt in (mcl_create calls this).
 void configure_device_kernels() {
   const size_t lds = kBeamLds;
+#if MCL_PATCH_LDS_PAD
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_lf_patch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_beam_sorted<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(lds));
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_beam_sorted<true>), hipFuncAttributeMaxDynamicSharedMemorySize,

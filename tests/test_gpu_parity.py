@@ -1270,6 +1270,65 @@ def test_reweight_lf_pipelined_patch_kernel_equals_the_gather_kernel_bit_for_bit
         assert np.array_equal(weights[0], weights[1]), (n, beams, sigma, int((weights[0] != weights[1]).sum()))
 
 
+@pytest.mark.parametrize("n,grid_wgs", [(300_000, 7), (300_000, 64), (300_000, 669), (1_000_003, 0), (1_000_003, 96)])
+def test_reweight_lf_patch_kernel_with_a_queue_of_blocks_equals_the_gather_kernel_bit_for_bit(n, grid_wgs):
+    """k_reweight_lf_patch<false, true> (option lf_queue = 1, the default where a launch has more blocks than the device keeps workgroups
+    resident): the workgroups of the launch take their blocks from a counter instead of one block each - which workgroup computes a
+    block changes nothing in it.  Weights identical to the gather kernel's bit for bit, with the default number of workgroups (three
+    per CU) and with a few that take dozens of blocks each (option lf_pipe_grid; 669 = one block short of a workgroup per block),
+    over wide and tight clouds and scans with a tail of beams; launch after launch (the counter wraps to zero by itself)."""
+    cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
+    grid = OccupancyGrid(cells=cells, resolution=0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
+    truth = synth.find_free_pose(cells, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
+    cases = [(1080, (0.5, 0.5, 0.2)), (1080, (0.1, 0.1, 0.03)), (57, (0.3, 0.3, 0.1)), (1543, (0.1, 0.1, 0.03)), (8, (0.1, 0.1, 0.03))]
+    if n > 500_000:
+        cases = cases[:2]
+    for beams, sigma in cases:
+        pts = make_scan(grid, truth, beams, max_range=12.0)
+        weights = []
+        for patch in (2, 0):  # always / never
+            f = new_filter(grid, n)
+            f.set_option("lf_patch", patch)
+            f.set_option("lf_queue", 1)
+            f.set_option("lf_pipe_grid", grid_wgs)
+            f.initialize(truth, np.diag([s * s for s in sigma]))
+            f.reweight(pts)
+            f.reweight(pts)  # a second launch finds the counter where the first one left it: at zero
+            weights.append(f.particles()[1].copy())
+            if patch == 2:
+                assert f.counter("lf_queue_launches") == 2, (beams, n)
+                planned, through = f.counter("lf_patch_groups_planned"), f.counter("lf_patch_groups_through")
+                assert planned > 0 and through <= planned
+                if sigma[0] <= 0.1 and beams >= 57:
+                    assert through > 0.8 * planned, (beams, sigma, through, planned)
+            f.close()
+        assert np.array_equal(weights[0], weights[1]), (n, beams, sigma, int((weights[0] != weights[1]).sum()))
+
+
+def test_queue_of_blocks_leaves_the_same_cycle_as_a_workgroup_per_block():
+    """Whole cycles (the fused mcl_update: the LF kernel's per-block sums of the new weights feed the normalisation) with the queue of
+    blocks and with a workgroup per block (option lf_queue = 0): estimates, weights and particle sets identical bit for bit."""
+    import bench
+    cells, truth, odoms, scans, _poses = bench.make_workload(4)
+    grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
+    n = 1_000_000
+    outs = []
+    for queue in (1, 0):
+        f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF),
+                 AmclParams(min_particles=n, max_particles=n), seed=42)
+        f.set_option("lf_queue", queue)
+        f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+        est = []
+        for c in range(4):
+            e = f.update(se2_from_xytheta(*odoms[c]), scans[c])
+            est.append(np.concatenate([e[0], e[1].ravel(), [f.last_info["weight_sum"]]]))
+        assert f.counter("lf_queue_launches") == (4 if queue else 0)
+        outs.append((np.asarray(est), f.particles()))
+        f.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1][0], outs[1][1][0]) and np.array_equal(outs[0][1][1], outs[1][1][1])
+
+
 def test_pipelined_patch_kernel_leaves_the_same_cycle_as_the_block_per_workgroup_form():
     """Whole cycles (the fused mcl_update: the LF kernel's per-block sums of the new weights feed the normalisation) with
     k_reweight_lf_pipe and with k_reweight_lf_patch (option lf_pipe = 0): estimates, weights and particle sets are identical
