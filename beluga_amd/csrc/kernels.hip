@@ -940,6 +940,9 @@ constexpr double kPatchMagic = 1572864.0 + 4.656612873077392578125e-10;     // 1
 // leaves one wave in eight without arithmetic; this one has none idle.  (Half patches and patches that need clamping at the
 // table's border are left to the producer form: here such groups are gathered.)
 // 6 waves per SIMD = three workgroups per CU: at most 80 registers
+// exp() as a call: inlined into the queue's loop, its dozen polynomial coefficients are hoisted out of the loop into registers and from
+// there into scratch memory (likelihood_field_prob_model.hpp:89 - once per particle and launch, and not at all for the plain model).
+__device__ __attribute__((noinline)) double exp_out_of_line(double x) { return exp(x); }
 // The kernel's arguments as one structure: it is the kernel argument segment, byte for byte.
 struct PatchArgs {
   double* w;
@@ -1769,7 +1772,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
     if (partial) {
       partial[static_cast<size_t>(blockIdx.y) * n + t_end] = acc;
     } else {
-      new_weight = w[i_end] * (f.prob ? exp(acc) : acc);
+      new_weight = w[i_end] * (f.prob ? exp_out_of_line(acc) : acc);
       w[i_end] = new_weight;
     }
   }
