@@ -168,6 +168,7 @@ _SIGNATURES = {
     "mcl_debug_order": (C.c_int32, [_ctx, c_u32_p, c_u32_p]),
     "mcl_debug_curve_index": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mcl_version": (C.c_char_p, []),
+    "mcl_measurement_build": (C.c_int, []),
 }
 
 _lib = None

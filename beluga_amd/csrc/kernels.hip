@@ -1012,8 +1012,9 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
                                                                                                               // run different loops
   // kQueue: the launch holds as many workgroups as the device keeps resident, and each takes blocks of the order from a counter until
   // none is left (stats.arrivals: nblocks + gridDim.x fetches per launch, the last of which wraps it to zero for the next one).  The
-  // hardware deals the workgroups of a grid out to the XCDs in turn, the same number to each whatever their speed - and under this
-  // kernel's load the XCDs of one device differ by 10 - 20 % (tools/exp_lf_workgroups.py): with the queue a faster one takes more blocks.
+  // hardware deals the workgroups of a grid out to the XCDs in turn, the same number to each - at 1M particles 279 blocks for 96 slots,
+  // and the XCDs are done with these equal shares 10 - 20 % apart (tools/exp_lf_workgroups.py, profiles/r04_lf_workgroup_timeline.txt);
+  // with the queue an XCD that is ahead takes more blocks (256 .. 318 each): 2 - 4 % of the kernel at 1M, 1.3 % at 10M.
   uint32_t* s_next = reinterpret_cast<uint32_t*>(s_bound) + 46;
 #pragma unroll 1
   for (;;) {
@@ -1798,10 +1799,11 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
 }
 
 // ---- the patch kernel, persistent ---------------------------------------------------------------------------------------
-// k_reweight_lf_patch runs 2232 workgroups on 768 slots in three lock-step rounds: every workgroup of a round plans at the same
-// time and writes its weights at the same time, so nothing hides a workgroup's prologue (tables -> perm -> pose -> reference
-// pose -> bound -> plan: ~14 us) or its epilogue (perm -> old weight -> product -> scattered store: ~7 us) behind its neighbours'
-// main loops - 60 of the kernel's 450 - 480 us at 1M particles, and the same share at 10M (29 rounds).  Here a workgroup stays
+// (Option lf_pipe, off: measured slower.  Its premise - 2232 workgroups on 768 slots in three lock-step rounds, every workgroup of a
+// round planning at the same time, so that nothing hides a workgroup's prologue (tables -> perm -> pose -> reference pose -> bound ->
+// plan: ~14 us) or its epilogue (perm -> old weight -> product -> scattered store: ~7 us) - did not survive the launch's timeline
+// (tools/exp_lf_workgroups.py, profiles/r04_lf_workgroup_timeline.txt): the CU serves its oldest waves first, three workgroups that
+// start together end one after the other, and from then on the workgroups of a CU are out of step by themselves.)  Here a workgroup stays
 // resident and takes blocks b, b + gridDim.x, ...; what its producer wave does beside the patches, while the seven consumer
 // waves run the main loop of block k, is everything of the next block's prologue and of the previous block's epilogue that
 // WAITS FOR MEMORY:

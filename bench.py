@@ -82,7 +82,7 @@ def lf_kernel_counters(kernel="k_reweight_lf_patch"):
         try:
             with open(path) as fh:
                 for line in fh:
-                    parts = line.split()
+                    parts = line.replace(", ", ",").split()  # (a template argument list is part of the kernel's name)
                     if line.startswith("# lf_kernels_sha256") and len(parts) >= 3:
                         sha = parts[2]
                     if len(parts) >= 4 and parts[0] == "PMC" and parts[1].split("<")[0] == kernel:

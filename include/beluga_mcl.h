@@ -412,6 +412,14 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *   lf_producer (1) LDS-patch kernel: 1 = seven waves of particles and a producer wave per workgroup, 0 = eight waves of particles,
  *                   each fetching its share of the patches straight into LDS (buffer_load ... lds; no half patches, no patches
  *                   clamped at the table's border: such groups are gathered)
+ *   lf_queue (1)    LDS-patch kernel, launches with more blocks of 448 particles than the device keeps workgroups resident (three per
+ *                   CU): 1 = that many workgroups, each taking blocks from a counter until none is left (an XCD that is ahead takes more:
+ *                   2 - 4 % off the kernel at 1M particles), 0 = one workgroup per block.  Which workgroup computes a block changes
+ *                   nothing in it.  lf_pipe_grid (0): the number of resident workgroups, 0 = three per CU (tests: a few workgroups)
+ *   lf_pipe (0)     LDS-patch kernel: 1 = persistent workgroups whose producer wave also fetches the next block's poses straight into LDS
+ *                   and writes the previous block's weights (bit-identical; measured slower: off)
+ *   beam_free_ahead (1)  beam model, ordered kernel: per workgroup and beam, the cells the middle particle's ray clearance proves free for
+ *                   every lane are passed in one closed-form step before a lane's own walk (same cells visited, same weights)
  *   cycle_spin (0)  fixed-size cycles (resample every cycle, mean / covariance estimate): 1 = the host waits for a completion word the
  *                   cycle's last kernel stores to mapped host memory instead of the stream's completion signal; 0 = hipStreamSynchronize.
  *                   Measured: no gain at 1M particles, 4 us per cycle slower at 2000 - off by default.  Never while stage
@@ -431,7 +439,10 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *   lf_far_launches = those of the gather kernel with the far-tile bitmap, lf_far_tiles = tiles in the bitmap (0 = none built);
  *   lf_fast_launches = launches of the FMA variant so far; lf_patch_launches = those of them sent to the LDS-patch
  *   kernel; lf_patch_groups_planned / lf_patch_groups_through = groups of 8 beams (per workgroup) that kernel has looked at /
- *   has read through a patch, running totals over a sample of the workgroups; field_built_on_device, field_build_us = the last mcl_set_map. */
+ *   has read through a patch, running totals over a sample of the workgroups; lf_queue_launches / lf_pipe_launches = launches of the
+ *   LDS-patch kernel with the queue of blocks / in its pipelined form; field_built_on_device, field_build_us = the last mcl_set_map;
+ *   cluster_cells = occupied cells of the last cluster_based_estimate; comm_ranks_seen (ncclCommCount of the library's communicator, 0
+ *   without one), comm_collectives, comm_bytes_out (running totals of this rank), comm_backend (0 = none, 1 = the caller's transport, 2 = RCCL inside the library). */
 mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value);
 mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value);
 /* Runs the spatial ordering on the current set and returns it: perm[t] = particle at position t, keys[i] = ordering key
@@ -443,6 +454,9 @@ mcl_status mcl_debug_order(mcl_ctx* ctx, uint32_t* perm, uint32_t* keys);
 uint32_t mcl_debug_curve_index(uint32_t heading_bin, uint32_t y_bin, uint32_t x_bin, uint32_t bits /* per axis, 1 .. 6 */);
 
 const char* mcl_version(void);
+/* Nonzero for a measurement build of the kernels (tools/build_variant.sh: ablations compute nonsense by design, timing builds distort):
+ * beluga_amd/capi.py refuses to load one as the product library unless BELUGA_MCL_ALLOW_MEASUREMENT_BUILD=1. */
+int mcl_measurement_build(void);
 
 #ifdef __cplusplus
 }

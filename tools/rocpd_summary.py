@@ -11,5 +11,5 @@ for name, calls, total, avg, pct in rows:
 if len(sys.argv) > 2:
     for (kernel, counter, value, n) in db.execute(
             "select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name"):
-        short = kernel.replace("mcl::(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        short = kernel.replace("mcl::(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace(", ", ",")  # (one field: no blanks)
         print(f"PMC {short:60s} {counter:36s} {value:18.1f} (n={n})")
