@@ -22,11 +22,13 @@ for case in range(cases):
     angles = synth.lidar_angles(beams, float(rng.choice([270.0, 360.0, 180.0])))
     ranges = synth.cast_scan(cells, res, origin, truth, angles, max_range, 0.01, int(rng.integers(1, 100)))
     pts = synth.scan_points(ranges, angles)
-    n = int(rng.choice([16_384, 20_000, 66_667, 131_072, 250_000]))
+    n = int(rng.choice([16_384, 20_000, 66_667, 131_072, 250_000, 300_000, 524_288]))  # (from 262 144 on: one scan segment, the queue applies)
     sig = (float(rng.choice([0.02, 0.1, 0.3, 0.8])), float(rng.choice([0.02, 0.1, 0.3, 0.8])), float(rng.choice([0.01, 0.05, 0.15, 0.5])))
     opts = dict(lf_split=int(rng.integers(0, 4)), lf_margin=int(rng.integers(0, 2)), key_curve=int(rng.integers(0, 2)),
                 key_warp=int(rng.integers(0, 2)), key_bits_xy=int(rng.choice([0, 4, 5, 6])), lf_producer=int(rng.integers(0, 2)),
-                lf_loose_below=int(rng.choice([0, 128, 224, 257])))
+                lf_loose_below=int(rng.choice([0, 128, 224, 257])),
+                # the queue of blocks, with few resident workgroups so that every one takes many blocks (0 = three per CU: a workgroup per block here)
+                lf_queue=int(rng.integers(0, 2)), lf_pipe_grid=int(rng.choice([0, 1, 5, 37, 200])))
     ws = []
     for patch in (2, 0):
         f = Amcl(grid, DifferentialDriveModelParam(0.1, 0.05, 0.1, 0.05), LF, AmclParams(min_particles=n, max_particles=n), seed=11)
@@ -39,10 +41,11 @@ for case in range(cases):
         ws.append(f.particles()[1].copy())
         if patch == 2:
             share = f.counter("lf_patch_groups_through") / max(f.counter("lf_patch_groups_planned"), 1)
+            queued = f.counter("lf_queue_launches")
         f.close()
     ok = np.array_equal(ws[0], ws[1])
     bad += not ok
-    print(f"case {case}: map {size} @ {res}, {beams} beams to {max_range} m, n {n}, sigma {sig}, {opts}: through a patch {share:.3f} "
+    print(f"case {case}: map {size} @ {res}, {beams} beams to {max_range} m, n {n}, sigma {sig}, {opts}: through a patch {share:.3f}{' (queue)' if queued else ''} "
           f"{'ok' if ok else 'MISMATCH ' + str(int((ws[0] != ws[1]).sum()))}", flush=True)
 print("mismatching cases:", bad)
 sys.exit(1 if bad else 0)
