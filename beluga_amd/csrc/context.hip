@@ -913,7 +913,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     launch_reweight_beam(ctx->stream, ctx->cur(), ctx->n, ctx->grid_view(), model,
                          ctx->d_points.ptr, static_cast<uint32_t>(B), ctx->d_kld_scalars.ptr + 1, ordered ? &sort : nullptr,
                          ctx->d_nonfree_bits.ptr, ctx->d_beam_points.ptr, use_table ? ctx->d_beam_table.ptr : nullptr,
-                         use_table ? ctx->beam_table_count : 0u, ctx->tuning.beam_free_ahead != 0);
+                         use_table ? ctx->beam_table_count : 0u, ctx->tuning.beam_free_ahead != 0, ctx->tuning.beam_sectors != 0);
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
   }
   stage_end(ctx, MCL_STAGE_REWEIGHT);
@@ -1968,7 +1968,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_pipe", "lf_pipe_grid", "lf_queue", "beam_free_ahead", "lf_weight_sums", "beam_table", "cycle_spin"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_pipe", "lf_pipe_grid", "lf_queue", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2884,6 +2884,8 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "lf_pipe") t.lf_pipe = value ? 1 : 0;
   else if (key == "lf_queue") t.lf_queue = value ? 1 : 0;
   else if (key == "beam_free_ahead") t.beam_free_ahead = value ? 1 : 0;
+  else if (key == "beam_sectors") t.beam_sectors = value ? 1 : 0;
+  else if (key == "beam_sectors") t.beam_sectors = value ? 1 : 0;
   else if (key == "lf_pipe_grid") t.lf_pipe_grid = static_cast<int>(std::clamp<int64_t>(value, 0, 1 << 20));
   else if (key == "cycle_spin") t.cycle_spin = value ? 1 : 0;
   else if (key == "beam_table") {

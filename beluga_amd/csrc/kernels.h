@@ -164,6 +164,8 @@ struct Tuning {
                                     // writes the previous block's weights (k_reweight_lf_pipe) where it applies, 0 = one workgroup per block.
                                     // Bit-identical; measured SLOWER (0.51 vs 0.44 ms at 1M x 1080, profiles/r04_lf_pipe_study.txt): off
   int lf_pipe_grid = 0;             // its workgroups: 0 = three per CU, otherwise this many (tests: few workgroups, many blocks each)
+  int beam_sectors = 1;             // beam model, ordered kernel, scanners that reach beyond half the LDS window: the scan in four sectors, each with
+                                    // a window of its own that holds its rays (0 = one centred window; the rays that leave it go on in global memory)
   int lf_queue = 1;                 // LDS-patch kernel: 1 = as many workgroups as stay resident (lf_pipe_grid) take the blocks from a queue where
                                     // there are more blocks than that (k_reweight_lf_patch<false, true>), 0 = one workgroup per block.  Bit-identical.
 };
@@ -291,7 +293,7 @@ constexpr uint32_t kBeamPointDoubles = 5;
 // d_beam_table (optional, ordered variant): launch_beam_table's output, beam_table_count entries of 4 doubles
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
                           unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points,
-                          const double* d_beam_table = nullptr, uint32_t beam_table_count = 0, bool free_ahead = true);
+                          const double* d_beam_table = nullptr, uint32_t beam_table_count = 0, bool free_ahead = true, bool sectors = true);
 // The beam model's terms that depend on the expected range alone, tabulated over the squared cell distance of the hit (kernels.hip
 // BeamTable): entries = beam_table_entries(...) (0: the range spans too many cells for a table), 4 doubles each.
 constexpr double kBeamTableMaxCells = 2046.0;

@@ -3425,6 +3425,9 @@ __device__ __forceinline__ auto cast_ray_window(const GridView& g, const BitWind
   }
   // Cells beyond the window (long rays near its edge): the same walk over the whole-grid maps in global memory.
   r.last = walk_room_in_grid(g, r);
+#ifdef MCL_BEAM_ABLATE  // timing only (1: rays that leave the window end there): what the walks over the whole-grid maps cost
+  if (MCL_BEAM_ABLATE & 1) r.last = -1;
+#endif
   if (k <= r.last) {
     MCL_BEAM_STAT(8);  // a walk over the whole-grid maps (the ray left the window)
     walk_seek(r, k, error);
@@ -3611,38 +3614,36 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
                                                                      uint32_t B, const uint32_t* __restrict__ perm,
                                                                      const double4* __restrict__ pose, unsigned long long* d_steps,
                                                                      double* __restrict__ partial, uint32_t beams_per_segment,
-                                                                     BeamTable table, uint32_t free_ahead_on) {
+                                                                     BeamTable table, uint32_t free_ahead_on, uint32_t sectors_on) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* win = reinterpret_cast<uint32_t*>(smem);
   const uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * kBeamBlock;
   const uint64_t t = t0 + threadIdx.x;
   const uint64_t tt = t < n ? t : n - 1;
-  // window centred on the middle particle of the workgroup (they are spatial neighbours after the ordering pass)
+  // window around the middle particle of the workgroup (they are spatial neighbours after the ordering pass)
   const uint64_t tm = t0 + kBeamBlock / 2 < n ? t0 + kBeamBlock / 2 : n - 1;
+  const Pose2 middle = ordered_pose(g.origin_inverse, pose, perm[tm]);
   int cx, cy;
-  {
-    const Pose2 middle = ordered_pose(g.origin_inverse, pose, perm[tm]);
-    cell_near(g, middle.x, middle.y, cx, cy);
-  }
+  cell_near(g, middle.x, middle.y, cx, cy);
   BitWindow bw;
-  bw.x0 = ((cx - kWin / 2) >> 5) << 5;
-  bw.y0 = ((cy - kWin / 2) >> 3) << 3;  // block rows of the coarse bitmap start on multiples of 8 cells
   bw.lds = win;
   bw.grid_maps = BlockMaps{bits.fine, static_cast<int>(bits.words_per_row), static_cast<int>(g.W) - 1, static_cast<int>(g.H) - 1, bits.rows,
                            bits.columns, static_cast<int>(bits.row_words), static_cast<int>(bits.column_words), bits.dist,
                            static_cast<int>(bits.dist_stride)};
   const uint32_t* nonfree_bits = bits.fine;
   const uint32_t words_per_row = bits.words_per_row;
-  for (int i = threadIdx.x; i < kWin * kWinWords; i += kBeamBlock) {
-    const int row = i >> 5, col = i & 31;
-    const int gy = bw.y0 + row, gw = (bw.x0 >> 5) + col;
-    uint32_t v = 0;
-    if (gy >= 0 && gy < static_cast<int>(g.H) && gw >= 0 && gw < static_cast<int>(words_per_row))
-      v = nonfree_bits[static_cast<size_t>(gy) * words_per_row + gw];
-    win[row * kWinStride + col] = v;
-  }
-  __syncthreads();
-  {  // coarse bitmap behind the window: bit (bx, by) = any cell of block (bx, by) not free
+  // The window at (bw.x0, bw.y0) - x0 a multiple of 32 cells, y0 of 8 - with its coarse bitmaps and block distances behind it.
+  auto stage_window = [&]() {
+    for (int i = threadIdx.x; i < kWin * kWinWords; i += kBeamBlock) {
+      const int row = i >> 5, col = i & 31;
+      const int gy = bw.y0 + row, gw = (bw.x0 >> 5) + col;
+      uint32_t v = 0;
+      if (gy >= 0 && gy < static_cast<int>(g.H) && gw >= 0 && gw < static_cast<int>(words_per_row))
+        v = nonfree_bits[static_cast<size_t>(gy) * words_per_row + gw];
+      win[row * kWinStride + col] = v;
+    }
+    __syncthreads();
+    // coarse bitmap behind the window: bit (bx, by) = any cell of block (bx, by) not free
     uint32_t* coarse = win + kWin * kWinStride;
     for (int cw = threadIdx.x; cw < kCoarse * kCoarseWords; cw += kBeamBlock) {
       const int by = cw / kCoarseWords, quarter = cw % kCoarseWords;
@@ -3676,8 +3677,8 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
       const bool inside = gy >= 0 && gy < grid_block_rows && gx >= 0 && gx < grid_block_columns;
       dist[blk] = inside ? bits.dist[static_cast<size_t>(gy) * bits.dist_stride + gx] : static_cast<uint8_t>(kDistCap);
     }
-  }
-  __syncthreads();
+    __syncthreads();
+  };
 
   const uint32_t i = perm[tt];
   const Pose2 src = ordered_pose(g.origin_inverse, pose, i);  // Ray2d ctor: raycasting.hpp:69
@@ -3703,10 +3704,12 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
   uint16_t* s_free_ahead = reinterpret_cast<uint16_t*>(smem + (static_cast<size_t>(kWin) * kWinStride + 2 * kCoarse * kCoarseWords) * sizeof(uint32_t) +
                                                        kCoarse * kCoarse);
   float* s_spread = reinterpret_cast<float*>(s_free_ahead + kBeamCertified);
-  const bool certified = free_ahead_on != 0u && b_end - b_begin <= kBeamCertified && m.beam_max_range / g.resolution < 4096.0;
+  const float inv_res = static_cast<float>(1.0 / g.resolution);
+  const float reach = static_cast<float>(m.beam_max_range) * inv_res;
+  const bool per_beam_entries = b_end - b_begin <= kBeamCertified && reach < 4096.f;
+  const bool certified = free_ahead_on != 0u && per_beam_entries;
+  float D = 0.f, R = 0.f;
   if (certified) {
-    const Pose2 middle = ordered_pose(g.origin_inverse, pose, perm[tm]);
-    const float inv_res = static_cast<float>(1.0 / g.resolution);
     float d_pos = sqrtf(static_cast<float>((src.x - middle.x) * (src.x - middle.x) + (src.y - middle.y) * (src.y - middle.y))) * inv_res;
     float d_rot = sqrtf(static_cast<float>((src.r.c - middle.r.c) * (src.r.c - middle.r.c) + (src.r.s - middle.r.s) * (src.r.s - middle.r.s)));
     if (!(d_pos < 1e6f && d_rot < 4.f)) d_pos = d_rot = INFINITY;  // (a non-finite pose: no certificate)
@@ -3719,44 +3722,75 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
       s_spread[2 * (threadIdx.x >> 6) + 1] = d_rot;
     }
     __syncthreads();
-    float D = 0.f, R = 0.f;
     for (int q = 0; q < kBeamBlock / 64; ++q) {
       D = fmaxf(D, s_spread[2 * q]);
       R = fmaxf(R, s_spread[2 * q + 1]);
     }
     D = D * 1.001f + 3.f;  // + the cells of the roundings
     R = R * 1.001f;
-    const uint8_t* dist = reinterpret_cast<const uint8_t*>(win + kWin * kWinStride + 2 * kCoarse * kCoarseWords);
-    const float wx = static_cast<float>(middle.x) * inv_res - static_cast<float>(bw.x0), wy = static_cast<float>(middle.y) * inv_res - static_cast<float>(bw.y0);
-    const float reach = static_cast<float>(m.beam_max_range) * inv_res;
-    for (uint32_t b = b_begin + threadIdx.x; b < b_end; b += kBeamBlock) {
-      const BeamPoint q = pts[b];
-      double ex, ey;
-      rot_apply(middle.r, q.ux, q.uy, ex, ey);
-      const float dx = static_cast<float>(ex / m.beam_max_range), dy = static_cast<float>(ey / m.beam_max_range);  // the middle ray's direction
-      float t = 0.f;
-#pragma unroll 1
-      for (; t < reach; t += 8.f) {
-        const float px = wx + t * dx, py = wy + t * dy;
-        if (!(px >= 0.f && py >= 0.f && px < static_cast<float>(kWin) && py < static_cast<float>(kWin))) break;  // (NaN: no certificate)
-        // (the window's distance map says nothing about blocks beyond the grid)
-        if (!(px + static_cast<float>(bw.x0) >= 0.f && py + static_cast<float>(bw.y0) >= 0.f && px + static_cast<float>(bw.x0) < static_cast<float>(g.W) &&
-              py + static_cast<float>(bw.y0) < static_cast<float>(g.H)))
-          break;
-        const int c = dist[(static_cast<int>(py) >> 3) * kCoarse + (static_cast<int>(px) >> 3)];
-        // the points of [t, t + 8) lie within 8 cells of this one
-        if (!(D + (t + 8.f) * R + 8.f <= static_cast<float>(8 * (c - 1)))) break;
-      }
-      s_free_ahead[b - b_begin] = static_cast<uint16_t>(t);
-    }
-    __syncthreads();
   }
-  for (uint32_t b = b_begin; b < b_end; ++b) {
-    MCL_BEAM_STAT(0);  // a beam
-    const float free_ahead = certified ? static_cast<float>(s_free_ahead[b - b_begin]) : 0.f;
-    acc += beam_term<kTable>(g, m, norm_hit, src, pts[b], table, sx, sy, [&](int fx, int fy) {
-      return cast_ray_window<kTable>(g, bw, sx, sy, fx, fy, m.beam_max_range, steps, free_ahead);
-    });
+  // One window centred on the workgroup's particles holds every ray of up to ~kWin / 2 cells.  Longer ones (a 30 m scanner on a 5 cm
+  // grid reaches 600 cells) left it and went on over the whole-grid maps in global memory: a fifth of this kernel's time for three
+  // wave-beams in ten.  They stay in workgroup memory if the scan is taken in FOUR SECTORS - the quadrant the middle particle's ray of a
+  // beam points into -, each with a window of its own that has the particles near the corner the rays leave from (kWin - reach cells
+  // of room, shared between the two sides): four stagings of the window per workgroup instead of one (each ~0.1 % of the workgroup's
+  // time).  A lane's ray that still leaves its window (a pose far from the middle one) goes on over the whole-grid maps as before.
+  // The sum over the beams is then taken sector by sector (the reference's std::transform_reduce leaves the order open).
+  const uint32_t sectors = (sectors_on != 0u && per_beam_entries && reach > static_cast<float>(kWin / 2 - 64) && reach < static_cast<float>(kWin - 128)) ? 4u : 1u;
+  const int room = sectors > 1 ? (kWin - static_cast<int>(reach)) / 2 : kWin / 2;
+#pragma unroll 1
+  for (uint32_t sector = 0; sector < sectors; ++sector) {
+    // sector 0: rays towards +x +y, 1: -x +y, 2: -x -y, 3: +x -y
+    const bool to_left = sector == 1 || sector == 2, down = sector >= 2;
+    bw.x0 = ((sectors > 1 ? (to_left ? cx + room - (kWin - 1) : cx - room) : cx - kWin / 2) >> 5) << 5;
+    bw.y0 = ((sectors > 1 ? (down ? cy + room - (kWin - 1) : cy - room) : cy - kWin / 2) >> 3) << 3;  // block rows start on multiples of 8 cells
+    if (sector > 0) __syncthreads();  // every lane is done with the window before
+    stage_window();
+    if (certified || sectors > 1) {
+      // s_free_ahead[beam]: bit 15 = the beam belongs to this sector, bits 0 .. 14 = its certificate in cells
+      const uint8_t* dist = reinterpret_cast<const uint8_t*>(win + kWin * kWinStride + 2 * kCoarse * kCoarseWords);
+      const float wx = static_cast<float>(middle.x) * inv_res - static_cast<float>(bw.x0), wy = static_cast<float>(middle.y) * inv_res - static_cast<float>(bw.y0);
+      for (uint32_t b = b_begin + threadIdx.x; b < b_end; b += kBeamBlock) {
+        const BeamPoint q = pts[b];
+        double ex, ey;
+        rot_apply(middle.r, q.ux, q.uy, ex, ey);
+        const uint32_t its_sector = ex >= 0.0 ? (ey >= 0.0 ? 0u : 3u) : (ey >= 0.0 ? 1u : 2u);
+        if (sectors > 1 && its_sector != sector) {
+          s_free_ahead[b - b_begin] = 0;
+          continue;
+        }
+        float t = 0.f;
+        if (certified) {
+          const float dx = static_cast<float>(ex / m.beam_max_range), dy = static_cast<float>(ey / m.beam_max_range);  // the middle ray's direction
+#pragma unroll 1
+          for (; t < reach; t += 8.f) {
+            const float px = wx + t * dx, py = wy + t * dy;
+            if (!(px >= 0.f && py >= 0.f && px < static_cast<float>(kWin) && py < static_cast<float>(kWin))) break;  // (NaN: no certificate)
+            // (the window's distance map says nothing about blocks beyond the grid)
+            if (!(px + static_cast<float>(bw.x0) >= 0.f && py + static_cast<float>(bw.y0) >= 0.f && px + static_cast<float>(bw.x0) < static_cast<float>(g.W) &&
+                  py + static_cast<float>(bw.y0) < static_cast<float>(g.H)))
+              break;
+            const int c = dist[(static_cast<int>(py) >> 3) * kCoarse + (static_cast<int>(px) >> 3)];
+            // the points of [t, t + 8) lie within 8 cells of this one
+            if (!(D + (t + 8.f) * R + 8.f <= static_cast<float>(8 * (c - 1)))) break;
+          }
+        }
+        s_free_ahead[b - b_begin] = static_cast<uint16_t>(0x8000u | static_cast<uint32_t>(t));
+      }
+      __syncthreads();
+    }
+    for (uint32_t b = b_begin; b < b_end; ++b) {
+      float free_ahead = 0.f;
+      if (certified || sectors > 1) {
+        const uint32_t entry = s_free_ahead[b - b_begin];  // (the same for every lane: a scalar branch)
+        if (!(entry & 0x8000u)) continue;
+        free_ahead = static_cast<float>(entry & 0x7FFFu);
+      }
+      MCL_BEAM_STAT(0);  // a beam
+      acc += beam_term<kTable>(g, m, norm_hit, src, pts[b], table, sx, sy, [&](int fx, int fy) {
+        return cast_ray_window<kTable>(g, bw, sx, sy, fx, fy, m.beam_max_range, steps, free_ahead);
+      });
+    }
   }
   if (d_steps) {
     if (t >= n) steps = 0;
@@ -5229,7 +5263,7 @@ void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32
 // Nonzero for a measurement build of the kernels (tools/build_variant.sh: ablations compute nonsense by design, timing builds
 // distort): beluga_amd/capi.py refuses to load one as the product library unless told so.
 extern "C" int mcl_measurement_build(void) {
-#if MCL_ABLATE || MCL_PIPE_ABLATE || MCL_PATCH_LDS_PAD || defined(MCL_LF_TIMING) || defined(MCL_BEAM_STATS) || defined(MCL_DRAW_ABLATE)
+#if MCL_ABLATE || MCL_PIPE_ABLATE || MCL_PATCH_LDS_PAD || defined(MCL_LF_TIMING) || defined(MCL_BEAM_STATS) || defined(MCL_BEAM_ABLATE) || defined(MCL_DRAW_ABLATE)
   return 1;
 #else
   return 0;
@@ -5287,7 +5321,7 @@ void launch_beam_table(hipStream_t st, BeamModel m, double resolution, uint32_t 
 
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
                           unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points,
-                          const double* d_beam_table, uint32_t beam_table_count, bool free_ahead) {
+                          const double* d_beam_table, uint32_t beam_table_count, bool free_ahead, bool sectors) {
   if (n == 0 || B == 0) return;
   if (sorted && nonfree_bits) {
     const size_t lds = kBeamLds;
@@ -5307,11 +5341,11 @@ void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, B
     if (d_beam_table && beam_table_count)
       hipLaunchKernelGGL(k_reweight_beam_sorted<true>, dim3(groups, segments), dim3(kBeamBlock), lds, st, p.w, n, g, m,
                          nonfree_layout(g.W, g.H, const_cast<uint32_t*>(nonfree_bits)), table, B, sorted->perm, p.pose, d_steps, partial,
-                         per_segment, BeamTable{reinterpret_cast<const double4*>(d_beam_table), beam_table_count - 1u}, free_ahead ? 1u : 0u);
+                         per_segment, BeamTable{reinterpret_cast<const double4*>(d_beam_table), beam_table_count - 1u}, free_ahead ? 1u : 0u, sectors ? 1u : 0u);
     else
       hipLaunchKernelGGL(k_reweight_beam_sorted<false>, dim3(groups, segments), dim3(kBeamBlock), lds, st, p.w, n, g, m,
                          nonfree_layout(g.W, g.H, const_cast<uint32_t*>(nonfree_bits)), table, B, sorted->perm, p.pose, d_steps, partial,
-                         per_segment, BeamTable{nullptr, 0u}, free_ahead ? 1u : 0u);
+                         per_segment, BeamTable{nullptr, 0u}, free_ahead ? 1u : 0u, sectors ? 1u : 0u);
     if (segments > 1) hipLaunchKernelGGL(k_lf_combine, dim3(blocks_for(n)), dim3(kBlock), 0, st, p.w, n, sorted->perm, partial, segments, 2);
     return;
   }
