@@ -418,6 +418,9 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                   nothing in it.  lf_pipe_grid (0): the number of resident workgroups, 0 = three per CU (tests: a few workgroups)
  *   lf_pipe (0)     LDS-patch kernel: 1 = persistent workgroups whose producer wave also fetches the next block's poses straight into LDS
  *                   and writes the previous block's weights (bit-identical; measured slower: off)
+ *   beam_sectors (1)  beam model, ordered kernel, scanners that reach beyond half the 1024-cell LDS window (448 .. 896 cells): the scan is taken
+ *                   in four sectors, each with a window that holds its rays; 0 = one centred window, rays that leave it go on over the
+ *                   whole-grid maps in global memory (same cells visited either way)
  *   beam_free_ahead (1)  beam model, ordered kernel: per workgroup and beam, the cells the middle particle's ray clearance proves free for
  *                   every lane are passed in one closed-form step before a lane's own walk (same cells visited, same weights)
  *   cycle_spin (0)  fixed-size cycles (resample every cycle, mean / covariance estimate): 1 = the host waits for a completion word the
