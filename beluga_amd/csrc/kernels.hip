@@ -3303,6 +3303,9 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   const uint32_t* bitmap = steep ? maps.rows : maps.columns;
   const int bitmap_words = steep ? maps.row_words : maps.column_words;
   int major = steep ? ly : lx, minor = steep ? lx : ly;
+#ifdef MCL_BEAM_STATS
+  bool stat_after_skip = k_start > 0;
+#endif
   while (k + 8 <= upto) {  // cells k .. k+7 and the cell behind them are inside
     {
       // Empty space in closed form: d = block distance from the block of cell k to the nearest block holding anything.  The next
@@ -3315,6 +3318,11 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
         const uint32_t room = static_cast<uint32_t>(upto - k) >> 3;  // >= 1
         const int s_columns = static_cast<int>(min(d - 1u, room));
         MCL_BEAM_STAT(9);  // a skip
+#ifdef MCL_BEAM_STATS
+        if (stat_after_skip) beam_stat(11);  // ... straight behind another skip (or the certified start)
+        if (s_columns >= 15) beam_stat(12);  // ... of the longest kind (the distance map's cap)
+        stat_after_skip = true;
+#endif
         const int cells = 8 * s_columns;
         const int total = error + cells * dminor;  // <= 129 dmajor, far below 2^24
         int trips = static_cast<int>(static_cast<float>(total - 1) * inv_dmajor);
@@ -3337,6 +3345,9 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
     const int b0 = minor >> 3, b1 = minor_next >> 3;
     const uint32_t occupied = ((row[b0 >> 5] >> (b0 & 31)) | (row[b1 >> 5] >> (b1 & 31))) & 1u;
     MCL_BEAM_STAT(3);  // a whole block column
+#ifdef MCL_BEAM_STATS
+    stat_after_skip = false;
+#endif
     if (occupied) {
       MCL_BEAM_STAT(4);  // ... examined cell by cell
       int first;
@@ -3417,6 +3428,10 @@ __device__ __forceinline__ auto cast_ray_window(const GridView& g, const BitWind
       const float length = sqrtf(dxs * dxs + dys * dys);
       k_start = length > 0.f ? static_cast<int>(free_ahead * static_cast<float>(r.major_span) * __builtin_amdgcn_rcpf(length) * 0.999f) - 2 : 0;
     }
+#ifdef MCL_BEAM_ABLATE  // timing only (2: no walk - a hit half way to the window's edge): what everything but the walk costs
+    if (MCL_BEAM_ABLATE & 2) hit_k = upto >> 1;
+    else
+#endif
     walk_blocks_any(lds_maps, r, lx, ly, error, k, hit_k, upto, k_start);
     if (hit_k >= 0) {
       walk_seek(r, hit_k, 0);

@@ -21,7 +21,7 @@ for c in range(1):
     v = list(out)
     beams_w = max(v[0], 1)
     names = ["beams", "walks, shared axis", "walks, mixed axes", "block columns", "columns examined", "columns with a hit", "tail groups",
-             "window walks", "grid walks", "skips", "certified starts", "skips of 2 columns", "skips of 4 columns", "skips of 8 columns", "head cells examined", "tail cells examined"]
+             "window walks", "grid walks", "skips", "certified starts", "skips behind a skip", "skips of 15+ columns", "-", "head cells examined", "tail cells examined"]
     print(f"cycle {c}:")
     for i, name in enumerate(names):
         if v[2 * i] == 0:
