@@ -966,12 +966,10 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
   typedef const __attribute__((address_space(4))) unsigned char* kernarg_bytes_t;
   const kernarg_bytes_t kernarg = (kernarg_bytes_t)(__builtin_amdgcn_kernarg_segment_ptr());
   const PatchArgs* ka = (const PatchArgs*)(kernarg);
-  double* const w = ka->w;
-  const uint64_t n = ka->n;
+  [[maybe_unused]] double* const w = ka->w;  // (these two in front of the loop: a timing build only)
+  [[maybe_unused]] const uint64_t n = ka->n;
   const FieldView& f = ka->f;  // (used once, in front of the loop)
   const uint32_t patch_base = ka->patch_base;
-  const PatchStats& stats = ka->stats;
-  const uint32_t nblocks = ka->nblocks;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef MCL_LF_TIMING
   const long long lf_t0 = __builtin_readcyclecounter();
