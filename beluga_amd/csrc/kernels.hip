@@ -3232,6 +3232,24 @@ __device__ __forceinline__ int examine_column(const BlockMaps& maps, int major, 
   return hits ? __builtin_ctz(hits) : -1;
 }
 
+// j cells along a stretch known to be free, in closed form: error + j dminor brought back into (0, dmajor], one trip per dmajor taken off (a
+// float quotient and a +-1 correction: the operands are far below 2^24).
+__device__ __forceinline__ void walk_advance_free(int j, int dminor, int dmajor, float inv_dmajor, bool steep, int major_step, int minor_step,
+                                                  int& lx, int& ly, int& error) {
+  if (dmajor > 0) {
+    const int total = error + j * dminor;
+    int trips = static_cast<int>(static_cast<float>(total - 1) * inv_dmajor);
+    int rem = total - trips * dmajor;
+    const int up = rem > dmajor ? 1 : 0, down = rem <= 0 ? 1 : 0;
+    trips += up - down;
+    rem -= (up - down) * dmajor;
+    error = rem;
+    if (steep) lx += trips * minor_step;
+    else ly += trips * minor_step;
+  }
+  if (steep) ly += j * major_step;
+  else lx += j * major_step;
+}
 // k_start: that many cells from the current one on are known to be free (the ordered beam kernel's per-beam certificate, see
 // k_reweight_beam_sorted): they are passed in one closed-form step.
 template <int STEEP, int MAJ, int MIN>
@@ -3246,22 +3264,13 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   // taken off (a float quotient and a +-1 correction: the operands are far below 2^24).
   const float inv_dmajor = dmajor > 0 ? __builtin_amdgcn_rcpf(static_cast<float>(dmajor)) : 0.f;  // (quotients below 2^8: one ulp is plenty)
   const bool closed_forms = dmajor < (1 << 16);  // (lines of 32K cells and more walk block column by block column)
-  auto clear_ahead = [&](int cx, int cy) { return closed_forms && maps.dist[(cy >> 3) * maps.dist_stride + (cx >> 3)] >= 2; };
-  auto advance_free = [&](int j) {
-    if (dmajor > 0) {
-      const int total = error + j * dminor;
-      int trips = static_cast<int>(static_cast<float>(total - 1) * inv_dmajor);
-      int rem = total - trips * dmajor;
-      const int up = rem > dmajor ? 1 : 0, down = rem <= 0 ? 1 : 0;
-      trips += up - down;
-      rem -= (up - down) * dmajor;
-      error = rem;
-      if (steep) lx += trips * minor_step;
-      else ly += trips * minor_step;
-    }
-    if (steep) ly += j * major_step;
-    else lx += j * major_step;
+  // (plain functions, not lambdas that capture by reference: the closure object of such a lambda - seven pointers to the walk's position,
+  // error term and constants - outlives the inlining as a dead store, the variables it points to count as escaped and live in scratch
+  // memory through the loops below: 18 stack slots and their loads and stores in every iteration)
+  auto clear_ahead = [closed_forms, &maps](int cx, int cy) __attribute__((always_inline)) {
+    return closed_forms && maps.dist[(cy >> 3) * maps.dist_stride + (cx >> 3)] >= 2;
   };
+#define advance_free(j) walk_advance_free((j), dminor, dmajor, inv_dmajor, steep, major_step, minor_step, lx, ly, error)
   if (k_start > 0 && closed_forms) {
     MCL_BEAM_STAT(10);  // a certified start
     const int j = min(k_start, upto - k + 1);
@@ -3385,6 +3394,7 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
     k += j;
   }
 }
+#undef advance_free
 // Dispatch on the line's orientation: a wave whose lanes agree on it (they follow one beam from neighbouring poses) runs the
 // instance with a compile-time major axis; the step directions stay run-time values (one instance per octant made the kernel
 // outgrow the instruction cache).
