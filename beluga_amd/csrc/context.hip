@@ -1968,7 +1968,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     configure_device_kernels();
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_pipe", "lf_pipe_grid", "lf_queue", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_pipe", "lf_pipe_grid", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2883,6 +2883,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "lf_producer") t.lf_producer = value ? 1 : 0;
   else if (key == "lf_pipe") t.lf_pipe = value ? 1 : 0;
   else if (key == "lf_queue") t.lf_queue = value ? 1 : 0;
+  else if (key == "lf_ends_first") t.lf_ends_first = value ? 1 : 0;
   else if (key == "beam_free_ahead") t.beam_free_ahead = value ? 1 : 0;
   else if (key == "beam_sectors") t.beam_sectors = value ? 1 : 0;
   else if (key == "beam_sectors") t.beam_sectors = value ? 1 : 0;

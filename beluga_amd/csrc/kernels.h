@@ -164,6 +164,7 @@ struct Tuning {
                                     // writes the previous block's weights (k_reweight_lf_pipe) where it applies, 0 = one workgroup per block.
                                     // Bit-identical; measured SLOWER (0.51 vs 0.44 ms at 1M x 1080, profiles/r04_lf_pipe_study.txt): off
   int lf_pipe_grid = 0;             // its workgroups: 0 = three per CU, otherwise this many (tests: few workgroups, many blocks each)
+  int lf_ends_first = 1;            // LDS-patch kernel: the blocks are taken from both ends of the order inwards (the fringe's slow blocks first)
   int beam_sectors = 1;             // beam model, ordered kernel, scanners that reach beyond half the LDS window: the scan in four sectors, each with
                                     // a window of its own that holds its rays (0 = one centred window; the rays that leave it go on in global memory)
   int lf_queue = 1;                 // LDS-patch kernel: 1 = as many workgroups as stay resident (lf_pipe_grid) take the blocks from a queue where

@@ -957,6 +957,7 @@ struct PatchArgs {
   uint32_t patch_base;  // LDS byte offset, 16-aligned
   PatchStats stats;
   uint32_t nblocks;
+  uint32_t ends_first;  // 1: the blocks are taken from both ends of the order inwards
 };
 template <bool kShared, bool kQueue = false>
 __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL_PATCH_WAVES, MCL_PATCH_WAVES))) void k_reweight_lf_patch(PatchArgs args) {
@@ -1035,6 +1036,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
   const uint32_t beams_per_segment = kb->beams_per_segment;
   const PatchStats& stats = kb->stats;
   const uint32_t nblocks = kb->nblocks;
+  const bool ends_first = kb->ends_first != 0u;
   uint32_t block = blockIdx.x;
   if constexpr (kQueue) {
     __syncthreads();  // the block before is done with the workgroup's memory
@@ -1046,6 +1048,10 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
     lf_wall0 = __builtin_amdgcn_s_memrealtime();
 #endif
   }
+  // The blocks are taken from both ends of the order inwards: 0, N - 1, 1, N - 2, ...  The ends of the heading-major order are the cloud's
+  // fringe - the blocks that gather everything, twice as slow as the others, sit in its first and last tenth (tools/exp_lf_workgroups.py) -
+  // and taken in order the slowest blocks were the launch's last; this way its end is made of the compact blocks of the middle.
+  if (ends_first) block = (block & 1u) ? nblocks - 1u - (block >> 1) : (block >> 1);
   const uint64_t first = static_cast<uint64_t>(block) * kParticles;
   const uint64_t t = producer ? first : first + tid;  // (the producer holds no particle; it reads a valid one)
   const uint64_t tt = t < n ? t : n - 1;
@@ -5198,14 +5204,14 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
         const uint32_t resident = tuning.lf_pipe_grid > 0 ? static_cast<uint32_t>(tuning.lf_pipe_grid) : 3u * static_cast<uint32_t>(cus);
         if (tuning.lf_producer == 0)
           hipLaunchKernelGGL(k_reweight_lf_patch<true>, dim3(groups_x, segments), dim3(kPatchBlock), patch_lds, st, PatchArgs{p.w, n, f, d_points, B,
-                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x});
+                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x, tuning.lf_ends_first != 0 ? 1u : 0u});
         else if (tuning.lf_queue != 0 && segments == 1 && patch_stats.arrivals != nullptr && groups_x > resident) {
           if (queue_used) *queue_used = true;
           hipLaunchKernelGGL((k_reweight_lf_patch<false, true>), dim3(resident), dim3(kPatchBlock), patch_lds + MCL_PATCH_LDS_PAD, st, PatchArgs{p.w, n, f, d_points, B,
-                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x});
+                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x, tuning.lf_ends_first != 0 ? 1u : 0u});
         } else
           hipLaunchKernelGGL(k_reweight_lf_patch<false>, dim3(groups_x, segments), dim3(kPatchBlock), patch_lds + MCL_PATCH_LDS_PAD, st, PatchArgs{p.w, n, f, d_points, B,
-                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x});
+                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x, tuning.lf_ends_first != 0 ? 1u : 0u});
         if (weight_sums_written && patch_stats.weight_sums) *weight_sums_written = groups_x;
       }
       else if (fast && dispersed && tuning.lf_far_tiles != 0 && f.far_bits != nullptr && patch_base + f.far_bytes <= 65536) {

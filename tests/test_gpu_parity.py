@@ -1276,7 +1276,8 @@ def test_reweight_lf_patch_kernel_with_a_queue_of_blocks_equals_the_gather_kerne
     resident): the workgroups of the launch take their blocks from a counter instead of one block each - which workgroup computes a
     block changes nothing in it.  Weights identical to the gather kernel's bit for bit, with the default number of workgroups (three
     per CU) and with a few that take dozens of blocks each (option lf_pipe_grid; 669 = one block short of a workgroup per block),
-    over wide and tight clouds and scans with a tail of beams; launch after launch (the counter wraps to zero by itself)."""
+    over wide and tight clouds and scans with a tail of beams; launch after launch (the counter wraps to zero by itself); the blocks taken
+    in order or from both ends of the order inwards (option lf_ends_first)."""
     cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
     grid = OccupancyGrid(cells=cells, resolution=0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
     truth = synth.find_free_pose(cells, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
@@ -1291,6 +1292,7 @@ def test_reweight_lf_patch_kernel_with_a_queue_of_blocks_equals_the_gather_kerne
             f.set_option("lf_patch", patch)
             f.set_option("lf_queue", 1)
             f.set_option("lf_pipe_grid", grid_wgs)
+            f.set_option("lf_ends_first", 0 if grid_wgs == 64 else 1)  # the blocks in order / from both ends of the order inwards (the default)
             f.initialize(truth, np.diag([s * s for s in sigma]))
             f.reweight(pts)
             f.reweight(pts)  # a second launch finds the counter where the first one left it: at zero
