@@ -416,6 +416,9 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                   CU): 1 = that many workgroups, each taking blocks from a counter until none is left (an XCD that is ahead takes more:
  *                   2 - 4 % off the kernel at 1M particles), 0 = one workgroup per block.  Which workgroup computes a block changes
  *                   nothing in it.  lf_pipe_grid (0): the number of resident workgroups, 0 = three per CU (tests: a few workgroups)
+ *   lf_ends_first (1)  LDS-patch kernel: the blocks are taken from both ends of the spatial order inwards (0, N - 1, 1, N - 2, ...): the ends
+ *                   are the cloud's fringe, whose blocks gather every look-up and take twice as long - taken first they are not the launch's
+ *                   last; 0 = in order
  *   lf_pipe (0)     LDS-patch kernel: 1 = persistent workgroups whose producer wave also fetches the next block's poses straight into LDS
  *                   and writes the previous block's weights (bit-identical; measured slower: off)
  *   beam_sectors (1)  beam model, ordered kernel, scanners that reach beyond half the 1024-cell LDS window (448 .. 896 cells): the scan is taken
