@@ -3646,7 +3646,10 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
                                                                      BeamTable table, uint32_t free_ahead_on, uint32_t sectors_on) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* win = reinterpret_cast<uint32_t*>(smem);
-  const uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * kBeamBlock;
+  // (the workgroups take the blocks of the order from both ends inwards - 0, N - 1, 1, N - 2, ... -: the ends are the cloud's fringe, whose rays
+  // run less alongside one another; see k_reweight_lf_patch)
+  const uint32_t block = (blockIdx.x & 1u) ? gridDim.x - 1u - (blockIdx.x >> 1) : (blockIdx.x >> 1);
+  const uint64_t t0 = static_cast<uint64_t>(block) * kBeamBlock;
   const uint64_t t = t0 + threadIdx.x;
   const uint64_t tt = t < n ? t : n - 1;
   // window around the middle particle of the workgroup (they are spatial neighbours after the ordering pass)
