@@ -364,7 +364,8 @@ class Amcl:
         return np.array(est.pose), np.array(est.covariance).reshape(3, 3)
 
     def set_estimate_kind(self, cluster_based: bool, **cluster_params):
-        """What update() returns: beluga::estimate (beluga::Amcl) or cluster_based_estimate (beluga_ros::Amcl)."""
+        """What update() returns: beluga::estimate (beluga::Amcl) or cluster_based_estimate (beluga_ros::Amcl).
+        On a sharded filter (comm_attach_rccl) a COLLECTIVE call: every rank makes it, concurrently, with the same arguments."""
         cp = capi.ClusterParams(cluster_params.get("linear_hash_resolution", 0.20), cluster_params.get("angular_hash_resolution", 0.524),
                                 cluster_params.get("weight_cap_percentile", 0.90))
         self._check(self._lib.mcl_set_estimate_kind(self._ctx, int(cluster_based), C.byref(cp)))
@@ -439,7 +440,9 @@ class Amcl:
 
     def comm_attach_rccl(self, unique_id: bytes, rank: int, world: int):
         """Joins the RCCL communicator of a sharded filter (include/beluga_mcl.h, "Particle shards"): this context must have been
-        created with its shard_offset / shard_capacity; update() then runs the cycle over all shards."""
+        created with its shard_offset / shard_capacity; update() then runs the cycle over all shards.  COLLECTIVE for world > 1: the
+        ranks attach concurrently (they exchange a word of their configuration and fail alike on a mismatch); set_option("device_policy")
+        and set_estimate_kind are collective on an attached filter as well."""
         assert len(unique_id) == 128
         self._check(self._lib.mcl_comm_attach_rccl(self._ctx, unique_id, rank, world))
 

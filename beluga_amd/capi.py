@@ -171,6 +171,7 @@ _SIGNATURES = {
     "mcl_measurement_build": (C.c_int, []),
 }
 
+_OPTIONAL = {"mcl_measurement_build"}  # symbols a library may lack and still load
 _lib = None
 
 
@@ -184,19 +185,21 @@ def load():
                 "beluga_amd has no CPU fallback.")
         lib = C.CDLL(LIB_PATH)
         if os.environ.get("BELUGA_MCL_LIB"):
-            # Another build stands in for the product library: say so, and refuse a measurement build (tools/build_variant.sh:
-            # ablations compute nonsense by design) unless the caller asks for exactly that.
             import sys
             print(f"[beluga_amd] BELUGA_MCL_LIB: loading {LIB_PATH} instead of the package's own library", file=sys.stderr)
-            try:
-                lib.mcl_measurement_build.restype = C.c_int
-                measurement = bool(lib.mcl_measurement_build())
-            except AttributeError:  # a build from before the tag existed
-                measurement = False
-            if measurement and os.environ.get("BELUGA_MCL_ALLOW_MEASUREMENT_BUILD") != "1":
-                raise ImportError(f"{LIB_PATH} is a measurement build of the kernels (timing hooks / ablations): its results are not "
-                                  "the product's.  Set BELUGA_MCL_ALLOW_MEASUREMENT_BUILD=1 to load it anyway (tools/ only).")
+        # A measurement build of the kernels (tools/build_variant.sh: ablations compute nonsense by design) is refused as the product
+        # library - wherever it was loaded from, the package's own path included - unless the caller asks for exactly that.
+        try:
+            lib.mcl_measurement_build.restype = C.c_int
+            measurement = bool(lib.mcl_measurement_build())
+        except AttributeError:  # a build from before the tag existed
+            measurement = False
+        if measurement and os.environ.get("BELUGA_MCL_ALLOW_MEASUREMENT_BUILD") != "1":
+            raise ImportError(f"{LIB_PATH} is a measurement build of the kernels (timing hooks / ablations): its results are not "
+                              "the product's.  Set BELUGA_MCL_ALLOW_MEASUREMENT_BUILD=1 to load it anyway (tools/ only).")
         for name, (res, args) in _SIGNATURES.items():
+            if name in _OPTIONAL and not hasattr(lib, name):
+                continue  # (an older build named by BELUGA_MCL_LIB)
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

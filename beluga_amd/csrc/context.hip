@@ -292,8 +292,7 @@ struct mcl_ctx {
   // d_scalars[24..27), mirrored to h_scalars[28..30)); a launch that found few sends the next ones to the gather kernel,
   // with a probe every 16th launch (option lf_patch = 1).
   uint64_t lf_patch_launches{0};
-  uint64_t lf_pipe_launches{0};  // of which by the persistent, pipelined form (k_reweight_lf_pipe)
-  uint64_t lf_queue_launches{0};  // of which by resident workgroups that take their blocks from a queue (k_reweight_lf_patch<false, true>)
+  uint64_t lf_queue_launches{0};  // of which by resident workgroups that take their blocks from a queue (k_reweight_lf_patch<*, true>)
   uint64_t patch_seen_planned{0}, patch_seen_through{0};
   bool patch_useful{true};
   int patch_probe_in{0};
@@ -878,7 +877,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     const bool scan_is_short = ctx->scan_extent / ctx->resolution < 8192.0;
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
     const bool use_patches = mode.patches;
-    bool far_tiles_used = false, pipe_used = false, queue_used = false;
+    bool far_tiles_used = false, queue_used = false;
     if (mode.beams) ctx->lf_beams_launches += 1;
     launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B), variant, &sort,
                        scan_is_short, ctx->tuning, use_patches,
@@ -888,9 +887,8 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
                                   static_cast<uint32_t>(ctx->tuning.lf_split), want_weight_sums ? ctx->d_lf_wsum.ptr : nullptr,
                                   reinterpret_cast<unsigned int*>(ctx->d_scalars.ptr + 30)},
                        /*dispersed=*/!use_patches && (ctx->tuning.lf_far_tiles == 2 || (ctx->tuning.lf_patch == 1 && !ctx->patch_useful)),
-                       &far_tiles_used, &ctx->lf_wsum_count, &pipe_used, &queue_used);
+                       &far_tiles_used, &ctx->lf_wsum_count, &queue_used);
     if (far_tiles_used) ctx->lf_far_launches += 1;
-    if (pipe_used) ctx->lf_pipe_launches += 1;
     if (queue_used) ctx->lf_queue_launches += 1;
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
     if (variant == kLfSortedLanes && ctx->tuning.lf_fast != 0 && scan_is_short && ctx->W < 16384 && ctx->H < 16384 && ctx->pal_count &&
@@ -904,9 +902,15 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     const BeamModel model{b.z_hit, b.z_short, b.z_max, b.z_rand, b.sigma_hit, b.lambda_short, b.beam_max_range};
     const bool use_table = ordered && ctx->tuning.beam_table != 0 && ctx->beam_table_count != 0;  // (only the ordered kernel reads it)
     if (use_table && !ctx->beam_table_ready) {
-      MCL_HIP(ctx, ctx->d_beam_table.ensure(4 * static_cast<size_t>(ctx->beam_table_count)));
-      launch_beam_table(ctx->stream, model, ctx->resolution, ctx->beam_table_count, ctx->d_beam_table.ptr);
-      MCL_HIP(ctx, hipGetLastError());
+      hipError_t e = ctx->d_beam_table.ensure(4 * static_cast<size_t>(ctx->beam_table_count));
+      if (e == hipSuccess) {
+        launch_beam_table(ctx->stream, model, ctx->resolution, ctx->beam_table_count, ctx->d_beam_table.ptr);
+        e = hipGetLastError();
+      }
+      if (e != hipSuccess) {
+        stage_end(ctx, MCL_STAGE_REWEIGHT);  // (the stage opened above is closed on this way out as well)
+        return fail(ctx, MCL_ERR_HIP, std::string("reweight (beam table): ") + hipGetErrorString(e));
+      }
       ctx->beam_table_ready = true;
     }
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
@@ -1108,7 +1112,11 @@ uint64_t comm_path_word(const mcl_ctx* ctx) {
   mix(ctx->cfg.seed);
   mix(static_cast<uint64_t>(ctx->tuning.device_policy != 0));
   mix(static_cast<uint64_t>(ctx->estimate_kind));
-  for (const double v : {ctx->cluster_params.linear_hash_resolution, ctx->cluster_params.angular_hash_resolution, ctx->cluster_params.weight_cap_percentile}) {
+  // (the thresholds decide update / no update, the recovery alphas whether a cycle injects, the KLD parameters where a cut falls:
+  // each of them changes which collectives a cycle reaches)
+  for (const double v : {ap.update_min_d, ap.update_min_a, ap.alpha_slow, ap.alpha_fast, ap.kld_epsilon, ap.kld_z, ap.spatial_resolution_x,
+                         ap.spatial_resolution_y, ap.spatial_resolution_theta, ctx->cluster_params.linear_hash_resolution,
+                         ctx->cluster_params.angular_hash_resolution, ctx->cluster_params.weight_cap_percentile}) {
     uint64_t bits;
     std::memcpy(&bits, &v, sizeof bits);
     mix(bits);
@@ -1966,9 +1974,14 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
       for (auto& e : pair) MCL_HIP(ctx, hipEventCreate(&e));
     MCL_HIP(ctx, hipEventCreateWithFlags(&ctx->points_event, hipEventDisableTiming));
     configure_device_kernels();
+    {  // the device's compute units: the queue form of the LF patch kernel launches three workgroups per CU
+      int count = 0;
+      if (hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || count <= 0) count = 256;
+      ctx->tuning.device_cus = count;
+    }
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_pipe", "lf_pipe_grid", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_queue_grid", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2555,11 +2568,17 @@ mcl_status mcl_cluster_based_estimate(mcl_ctx* ctx, const mcl_cluster_params* pa
 mcl_status mcl_set_estimate_kind(mcl_ctx* ctx, int32_t kind, const mcl_cluster_params* params) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
   MCL_REQUIRE(ctx, kind == 0 || kind == 1, "estimate kind must be 0 (estimate) or 1 (cluster_based_estimate)");
-  const bool changed = ctx->estimate_kind != kind;
+  const int32_t kind_before = ctx->estimate_kind;
+  const mcl_cluster_params params_before = ctx->cluster_params;
   ctx->estimate_kind = kind;
   if (params) ctx->cluster_params = *params;
-  // on a sharded filter the estimate's kind selects the cycle's collectives: a collective call (every rank, the same kind)
-  if (changed || params) return comm_agree(ctx, "mcl_set_estimate_kind");
+  // On a sharded filter the estimate's kind selects the cycle's collectives: a COLLECTIVE call there (every rank, concurrently, the
+  // same kind and parameters - entered whatever this rank's state was before); a mismatch leaves kind and parameters as they were.
+  if (const mcl_status s = comm_agree(ctx, "mcl_set_estimate_kind")) {
+    ctx->estimate_kind = kind_before;
+    ctx->cluster_params = params_before;
+    return s;
+  }
   return MCL_OK;
 }
 
@@ -2872,8 +2891,13 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "device_policy") {
     const int before = t.device_policy;
     t.device_policy = value ? 1 : 0;
-    // on a sharded filter it selects the cycle's collectives: a collective call (every rank, the same value)
-    if (before != t.device_policy) return comm_agree(ctx, "mcl_set_option(device_policy)");
+    // On a sharded filter it selects the cycle's collectives: a COLLECTIVE call there - every rank makes it, concurrently, with the
+    // same value, whatever its value was before (a rank that skipped the exchange because nothing changed for IT would leave the
+    // others waiting).  A mismatch leaves the option as it was.
+    if (const mcl_status s = comm_agree(ctx, "mcl_set_option(device_policy)")) {
+      t.device_policy = before;
+      return s;
+    }
   }
   else if (key == "field_build") t.field_build = value ? 1 : 0;
   else if (key == "key_curve") t.key_curve = value ? 1 : 0;
@@ -2881,18 +2905,16 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "key_bits_xy") t.key_bits_xy = (value >= 4 && value <= 6) ? static_cast<int>(value) : 0;
   else if (key == "lf_margin") t.lf_margin = value ? 1 : 0;
   else if (key == "lf_producer") t.lf_producer = value ? 1 : 0;
-  else if (key == "lf_pipe") t.lf_pipe = value ? 1 : 0;
   else if (key == "lf_queue") t.lf_queue = value ? 1 : 0;
   else if (key == "lf_ends_first") t.lf_ends_first = value ? 1 : 0;
   else if (key == "beam_free_ahead") t.beam_free_ahead = value ? 1 : 0;
   else if (key == "beam_sectors") t.beam_sectors = value ? 1 : 0;
-  else if (key == "beam_sectors") t.beam_sectors = value ? 1 : 0;
-  else if (key == "lf_pipe_grid") t.lf_pipe_grid = static_cast<int>(std::clamp<int64_t>(value, 0, 1 << 20));
+  else if (key == "lf_queue_grid") t.lf_queue_grid = static_cast<int>(std::clamp<int64_t>(value, 0, 1 << 20));
   else if (key == "cycle_spin") t.cycle_spin = value ? 1 : 0;
   else if (key == "beam_table") {
     t.beam_table = value ? 1 : 0;
     if (!t.beam_table && ctx->beam_table_ready) {  // its memory goes back at once
-      if (hipStreamSynchronize(ctx->stream) == hipSuccess) {
+      if (bind_device(ctx) == MCL_OK && hipStreamSynchronize(ctx->stream) == hipSuccess) {
         ctx->d_beam_table.release();
         ctx->beam_table_ready = false;
       }
@@ -2911,7 +2933,6 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
   const std::string key(name);
   if (key == "lf_fast_launches") *value = ctx->lf_fast_launches;
   else if (key == "lf_patch_launches") *value = ctx->lf_patch_launches;
-  else if (key == "lf_pipe_launches") *value = ctx->lf_pipe_launches;
   else if (key == "lf_queue_launches") *value = ctx->lf_queue_launches;
   else if (key == "lf_beams_launches") *value = ctx->lf_beams_launches;
   else if (key == "lf_far_launches") *value = ctx->lf_far_launches;

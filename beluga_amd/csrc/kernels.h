@@ -109,8 +109,8 @@ struct ResampleArgs {
 };
 
 enum LfVariant : int {
-  kLfWavePerParticle = 0,  // wave per particle over the f32 field (small sets)
-  kLfLanePerParticle = 1,
+  kLfWavePerParticle = 0,  // (rounds 1 - 4: a wave per particle over the f32 field; now the same kernel as 1)
+  kLfLanePerParticle = 1,  // a lane per particle in index order over the f32 field (no ordering pass, no palette)
   kLfSortedLanes = 2,      // default: lanes = spatial neighbours (ordering pass), palette table, LDS patches
   kLfBeamLanes = 3         // wave per particle, lanes = beams, palette table: dispersed sets (chosen by the cycle, or forced)
 };
@@ -143,9 +143,8 @@ struct Tuning {
                                     // function) when the frame comes from an estimate of the set, 0 = bins of equal width
   int key_bits_xy = 0;              // bits of the x / y bins of that key: 0 = chosen per cycle from the cloud's spread and the scan's
                                     // reach (4 .. 6), otherwise forced; round 2: 6 (8 heading bits)
-  int lf_producer = 1;              // LDS-patch kernel: 1 = seven waves of particles + a producer wave (the form that knows half patches and
-                                    // patches clamped at the table's border), 0 = every wave holds particles and fetches its share of the
-                                    // patches straight into LDS (buffer_load ... lds); measured 5 % slower on the bench
+  int lf_producer = 1;              // LDS-patch kernel: 1 = seven waves of particles + a producer wave that copies the patches, 0 = every wave
+                                    // holds particles and copies one tile row of each patch through its registers (k_reweight_lf_patch<true>)
   int cycle_spin = 0;               // fixed-size cycles: 1 = the host waits for the cycle's own completion word (written to mapped host memory
                                     // by the last kernel, Completion) instead of the stream's completion signal; 0 = hipStreamSynchronize.
                                     // Measured: nothing at 1M particles (1489 / 1492 vs 1482 / 1496 cycles/s), 4 us per cycle SLOWER at
@@ -160,15 +159,14 @@ struct Tuning {
                                     // 0 = round 2's |R_p - R_ref| |q| on both axes
   int beam_free_ahead = 1;          // beam model, ordered kernel: a workgroup's lanes pass the cells its middle ray's clearance proves free in one
                                     // closed-form step (per beam and workgroup); 0 = block-distance skips only
-  int lf_pipe = 0;                  // LDS-patch kernel: 1 = persistent workgroups whose producer wave also fetches the next block's poses and
-                                    // writes the previous block's weights (k_reweight_lf_pipe) where it applies, 0 = one workgroup per block.
-                                    // Bit-identical; measured SLOWER (0.51 vs 0.44 ms at 1M x 1080, profiles/r04_lf_pipe_study.txt): off
-  int lf_pipe_grid = 0;             // its workgroups: 0 = three per CU, otherwise this many (tests: few workgroups, many blocks each)
+  int lf_queue_grid = 0;            // workgroups of the queue form (lf_queue): 0 = three per CU, otherwise this many (tests: few workgroups, many
+                                    // blocks each)
+  int device_cus = 0;               // compute units of the context's device (filled in by mcl_create; 0 = assume 256)
   int lf_ends_first = 1;            // LDS-patch kernel: the blocks are taken from both ends of the order inwards (the fringe's slow blocks first)
   int beam_sectors = 1;             // beam model, ordered kernel, scanners that reach beyond half the LDS window: the scan in four sectors, each with
                                     // a window of its own that holds its rays (0 = one centred window; the rays that leave it go on in global memory)
-  int lf_queue = 1;                 // LDS-patch kernel: 1 = as many workgroups as stay resident (lf_pipe_grid) take the blocks from a queue where
-                                    // there are more blocks than that (k_reweight_lf_patch<false, true>), 0 = one workgroup per block.  Bit-identical.
+  int lf_queue = 1;                 // LDS-patch kernel: 1 = as many workgroups as stay resident (lf_queue_grid) take the blocks from a queue where
+                                    // there are more blocks than that (k_reweight_lf_patch<*, true>), 0 = one workgroup per block.  Bit-identical.
 };
 
 // Spatial ordering of the particles (kLfSortedLanes, ordered beam kernel): the 64 lanes of a wave should hold neighbouring
@@ -279,14 +277,14 @@ struct PatchStats {
   uint32_t split_patches;      // 1: a group that fits no whole patch may go through two half patches (Tuning::lf_split)
   double* weight_sums;         // optional: [workgroups] sums of the new weights, one per workgroup of the patch kernel (the
                                // normalisation's input: launch_sum_and_normalize); only written by single-segment launches
-  unsigned int* arrivals;      // k_reweight_lf_pipe: its workgroups count themselves here (wraps at the grid's size: 0 between launches)
+  unsigned int* arrivals;      // the queue of blocks (k_reweight_lf_patch<*, true>): the next block to take; wraps to 0 behind a launch's last fetch
 };
 // *weight_sums_written (optional): how many workgroup sums of the new weights the launch left in patch_stats.weight_sums (0: none -
 // another kernel ran, or the launch was segmented)
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
                         bool dispersed = false, bool* far_tiles_used = nullptr, uint32_t* weight_sums_written = nullptr,
-                        bool* pipe_used = nullptr, bool* queue_used = nullptr);
+                        bool* queue_used = nullptr);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_order_particles first).
 // d_beam_points: scratch of kBeamPointDoubles * B doubles (per-beam terms shared by all particles; ordered variant only).

@@ -338,7 +338,6 @@ __global__ __launch_bounds__(kWide) void k_propagate(Particles p, uint64_t n, Di
 // ---- K2 likelihood-field reweight ------------------------------------------------------------------
 // One beam end-point -> pz^3.  likelihood_field_model.hpp:82-88, dense_grid.hpp:92-96,127-129,
 // regular_grid.hpp:75-78, linear_grid.hpp:73-75.
-template <bool kIdx32>
 __device__ __forceinline__ double lf_beam(const FieldView& f, double px, double py, double ct, double st, double xt, double yt) {
   const double x = px * ct - py * st + xt;
   const double y = px * st + py * ct + yt;
@@ -347,14 +346,8 @@ __device__ __forceinline__ double lf_beam(const FieldView& f, double px, double 
   // Branch-free: out-of-grid lanes read cell 0 and discard it, so the gathers of an unrolled group
   // of beams can all be in flight together instead of sitting behind one exec-mask branch each.
   const bool inside = static_cast<unsigned>(xi) < f.W && static_cast<unsigned>(yi) < f.H;
-  float v;
-  if (kIdx32) {
-    const unsigned idx = inside ? static_cast<unsigned>(yi) * f.W + static_cast<unsigned>(xi) : 0u;
-    v = f.data[idx];
-  } else {
-    const size_t idx = inside ? static_cast<size_t>(yi) * f.W + static_cast<size_t>(xi) : size_t{0};
-    v = f.data[idx];
-  }
+  const size_t idx = inside ? static_cast<size_t>(yi) * f.W + static_cast<size_t>(xi) : size_t{0};
+  float v = f.data[idx];
   v = inside ? v : f.unknown_value;
   const double pz = static_cast<double>(v);
   return f.prob ? log(pz) : pz * pz * pz;
@@ -399,77 +392,19 @@ __device__ __forceinline__ double lf_cube_fetch(__amdgpu_buffer_rsrc_t rsrc, con
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, offset, 0, 0));
 }
 
-// Variant A — one wavefront per particle, lanes stride over the beams, scan staged in LDS.
-// A wave owns a tile of 64 particles: the 64 world->field transforms are computed lane-parallel, then
-// broadcast one at a time through SGPRs (v_readlane), so the per-beam math has scalar pose operands.
-template <bool kIdx32>
-__global__ __launch_bounds__(kBlock) void k_reweight_lf_wave(Particles p, uint64_t n, FieldView f, const double2* __restrict__ pts,
-                                                             uint32_t B) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double2* s_pts = reinterpret_cast<double2*>(smem);
-  for (uint32_t i = threadIdx.x; i < B; i += kBlock) s_pts[i] = pts[i];
-  __syncthreads();
-
-  const uint32_t lane = threadIdx.x & 63;
-  const uint64_t tile = static_cast<uint64_t>(blockIdx.x) * (kBlock / kWave) + (threadIdx.x >> 6);
-  const uint64_t base = tile * kWave;
-  if (base >= n) return;
-  const uint64_t i = base + lane;
-  Pose2 state = pose_identity();
-  if (i < n) state = load_pose(p, i);
-  const Pose2 T = pose_mul(f.world_to_field, state);
-  const uint32_t cnt = static_cast<uint32_t>(n - base < kWave ? n - base : kWave);
-  double mine = 0.0;
-  for (uint32_t q = 0; q < cnt; ++q) {
-    const double ct = readlane_f64(T.r.c, q), st = readlane_f64(T.r.s, q);
-    const double xt = readlane_f64(T.x, q), yt = readlane_f64(T.y, q);
-    double acc = 0.0;
-#pragma unroll 4
-    for (uint32_t b = lane; b < B; b += kWave) {
-      const double2 pt = s_pts[b];
-      acc += lf_beam<kIdx32>(f, pt.x, pt.y, ct, st, xt, yt);
-    }
-    const double total = wave_sum_f64(acc);
-    if (lane == q) mine = total;
-  }
-  if (i < n) p.w[i] = p.w[i] * (f.prob ? exp(mine) : 1.0 + mine);
-}
-
-// Variant B — one lane per particle, every lane walks the scan in order; the scan is read with scalar
-// loads (wave-uniform address), the sum `1 + sum pz^3` is added in the order of the reference's std::transform_reduce (sum4).
-template <bool kIdx32>
-__global__ __launch_bounds__(kBlock) void k_reweight_lf_lane(Particles p, uint64_t n, FieldView f, const double* __restrict__ pts,
-                                                             uint32_t B) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  Pose2 state = pose_identity();
-  if (i < n) state = load_pose(p, i);
-  const Pose2 T = pose_mul(f.world_to_field, state);
-  double acc = f.prob ? 0.0 : 1.0;
-  uint32_t b = 0;
-#pragma unroll 2
-  for (; b + 4 <= B; b += 4) {
-    double t[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = lf_beam<kIdx32>(f, pts[2 * (b + k)], pts[2 * (b + k) + 1], T.r.c, T.r.s, T.x, T.y);
-    acc += sum4(t[0], t[1], t[2], t[3]);
-  }
-  for (; b < B; ++b) acc += lf_beam<kIdx32>(f, pts[2 * b], pts[2 * b + 1], T.r.c, T.r.s, T.x, T.y);
-  if (i < n) p.w[i] = p.w[i] * (f.prob ? exp(acc) : acc);
-}
-
-// Variant C — variant B's lane-per-particle walk over particles that have been counting-sorted into
-// (heading, x, y) bins.  The 64 lanes of a wave then hold nearly the same pose, so for a given beam their
-// end-points fall into a handful of 128-byte field lines: the vector L1 sees ~10 tag look-ups per gather
-// instead of 64 and the working set of a CU stays in its 32 KB L1 (profiles/r01: variants A/B are bound by
-// the L1/L2 request rate, not by HBM).  The order in which particles are visited does not change any
-// result: each lane still accumulates `1 + sum pz^3` over the scan in the reference's order.
+// The fallback family (fields with too many distinct values for a palette - the cube table or the f32 field itself -, sets without
+// an order): one lane per particle, every lane walks the scan in order, the scan read with scalar loads, the sum `1 + sum pz^3`
+// added in the order of the reference's std::transform_reduce (sum4).  With `perm` the lanes are neighbours of the spatial order:
+// for a given beam their end-points fall into a handful of 128-byte lines, the vector L1 sees ~10 tag look-ups per gather instead
+// of 64 (profiles/r01: unordered lanes are bound by the L1/L2 request rate, not by HBM).  The order in which particles are
+// visited does not change any result.
 // `partial` == nullptr: the whole scan per lane, weights updated in place (the sum in the reference's order: sum4).
 // `partial` != nullptr (medium particle counts, where one lane per particle cannot fill 256 CUs): blockIdx.y selects a
 // contiguous segment of the scan; the segment's sum goes to partial[segment][t] and k_lf_combine adds the segments up in
 // order — same terms, fixed association, bit-reproducible, differs from the whole-scan sum only in rounding.
 // The pose of the particle at a position of the spatial order, moved into the table's frame.  A 32-byte record gather
 // per lane, once per kernel (the ordering passes move 8 bytes per particle, not the poses).
-__device__ __forceinline__ Pose2 ordered_pose(const Pose2& to_frame, const double4* __restrict__ pose, uint32_t i) {
+__device__ __forceinline__ Pose2 ordered_pose(const Pose2& to_frame, const double4* __restrict__ pose, uint64_t i) {
   const double4 q = pose[i];
   return pose_mul(to_frame, Pose2{Rot2{q.x, q.y}, q.z, q.w});
 }
@@ -481,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
                                                                double* __restrict__ partial, uint32_t beams_per_segment) {
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const uint64_t tt = t < n ? t : n - 1;
-  const uint32_t i = perm[tt];
+  const uint64_t i = perm ? perm[tt] : tt;  // (no order: small sets without a palette, sets beyond 2^32 particles)
   const Pose2 T = ordered_pose(f.world_to_field, pose, i);  // likelihood_field_model.hpp:70
   const double ct = T.r.c, st = T.r.s, xt = T.x, yt = T.y;
   const uint32_t b_begin = partial ? blockIdx.y * beams_per_segment : 0u;
@@ -527,10 +462,10 @@ __global__ __launch_bounds__(kBlock) void k_reweight_lf_sorted(double* __restric
     for (; b + 4 <= b_end; b += 4) {
       double t[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) t[k] = lf_beam<false>(f, pts[2 * (b + k)], pts[2 * (b + k) + 1], ct, st, xt, yt);
+      for (int k = 0; k < 4; ++k) t[k] = lf_beam(f, pts[2 * (b + k)], pts[2 * (b + k) + 1], ct, st, xt, yt);
       acc += sum4(t[0], t[1], t[2], t[3]);
     }
-    for (; b < b_end; ++b) acc += lf_beam<false>(f, pts[2 * b], pts[2 * b + 1], ct, st, xt, yt);
+    for (; b < b_end; ++b) acc += lf_beam(f, pts[2 * b], pts[2 * b + 1], ct, st, xt, yt);
   }
   if (t < n) {
     if (partial) {
@@ -849,19 +784,28 @@ __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, 
 // The palette kernel with the index table read through LDS patches.
 // A scattered 64-lane 2-byte gather costs the CU's texture-address pipe one cycle per quad of lanes per line (16+ per
 // instruction, profiles/r02_calib_gather_cost.txt): the floor of k_reweight_lf_palette.  An LDS read of the same shape costs
-// two.  A workgroup holds 448 neighbours of the spatial order (waves 0-6, one lane per particle) and a PRODUCER (wave 7, no
-// particles).  For a group of 8 consecutive beams the end-point of particle p differs from that of a reference pose in the
-// middle of the workgroup's particles by (t_p - t_ref) + (R_p - R_ref) q, at most
+// two.  A workgroup holds neighbours of the spatial order, one lane per particle.  For a group of 8 consecutive beams the
+// end-point of particle p differs from that of a reference pose in the middle of the workgroup's particles by
+// (t_p - t_ref) + (R_p - R_ref) q, at most
 //     (Dx, Dy) + |q| Drot      Dx, Dy = max |t_p - t_ref| per axis,  Drot = max |R_p - R_ref| = max 2 |sin(dtheta / 2)|
 // over the workgroup (one reduction in the prologue).  If the bounding box of the reference's 8 end-point cells, widened by
-// that margin (+2 cells for every rounding involved), fits into 64 x 64 cells, the group goes through a PATCH: the producer
-// copies that part of the index table into LDS - 512 coalesced 16-byte pieces (a tile column of the 8x8-tiled table = 8
-// cells in y), column-major, 144 bytes per column - and every look-up of the group is an LDS read at cx * 144 + cy * 2 + K,
-// with no test: the bound is the proof that it lies inside.  Otherwise (the cloud's fringe, a range discontinuity inside the
-// group) the group is gathered as in k_reweight_lf_palette.  Where a look-up comes from changes no result.
+// that margin (+2 cells for every rounding involved), fits into 64 x 64 cells, the group goes through a PATCH: that part of the
+// index table is copied into LDS - 512 coalesced 16-byte pieces (a tile column of the 8x8-tiled table = 8 cells in y),
+// column-major, 144 bytes per column - and every look-up of the group is an LDS read at cx * 144 + cy * 2 + K, with no test: the
+// bound is the proof that it lies inside.  Otherwise (the cloud's fringe, a range discontinuity inside the group) the group is
+// gathered as in k_reweight_lf_palette.  Where a look-up comes from changes no result.
 // The plan - origin and mode of every group - is made once, in the prologue, one thread per group.  Then one s_barrier per
-// group: behind barrier g the patch of group g is visible and the buffer of g - 1 is free; the consumers evaluate group g
-// while the producer fetches g + 1 (the only wave that ever waits for that fetch).
+// group: behind barrier g the patch of group g is visible and the buffer of g - 1 is free.
+//
+// Who copies the patches (template parameter kCoop):
+//   false  seven waves of particles (448) and a PRODUCER wave without particles, which fetches every patch through its registers
+//          two groups ahead (rounds 2 - 4).  The producer occupies one of a workgroup's eight wave slots: of the 24 slots of a CU
+//          (80 registers) three hold producers, and the SIMDs that hold none carry 6 waves of arithmetic against 21 / 4 on average -
+//          the kernel, bound by vector issue, runs at the pace of those SIMDs (0.875 of the CU by construction).
+//   true   all eight waves hold particles (512) and every wave copies ONE TILE ROW of each patch - a 16-byte piece per lane:
+//          one buffer_load_dwordx4 and one ds_write_b128 per wave and group, the piece of group g + 2 in flight (4 registers) while
+//          group g is evaluated.  Four SIMDs x 6 waves of arithmetic.  The plan leaves to the gathers what would need clamping at the
+//          table's border (a patch is fetched with scalar offsets here).
 //
 // End-points: v = the reference's separately rounded (p.cos - q.sin + t) / res, cell = floor(v).  Evaluated here as
 //     s = fma(p, c', fma(-q, s', t' + M)),   c' = cos / res, s' = sin / res, t' = t / res,   M = 1.5 * 2^20 + 2^-31
@@ -871,74 +815,25 @@ __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, 
 // either its integer part is I (high word = kFastBias + I, whatever the low word) or it carried and its low word is below 4.
 // A group with a low word below 4 (4 in 2^32 end-points) is added by the exact evaluation, beam by beam, and so is every
 // group of a wave holding a particle farther than 2^14 cells from the grid origin.  4 VALU operations per end-point.
-// Measurement builds only (tools/build_variant.sh, never the product library): -DMCL_ABLATE=<bits> removes one ingredient of
-// the patch kernel's main loop at a time to see what it costs (the results are then wrong): 1 = the barriers, 2 = the palette
-// value reads, 4 = the look-ups in the patch, 16 = the producer's fetches and stores.
-// -DMCL_LF_TIMING (tools/exp_lf_timing.py): cycles (s_memtime) the waves of k_reweight_lf_patch spend in total and waiting at
-// their workgroup barriers.  g_lf_timing: [0] consumer waves, [1] their cycles, [2] of which at barriers, [3] producer waves,
-// [4] their cycles, [5] of which at barriers, [6] consumer cycles before the main loop (planning), [7] producer cycles waiting for its loads.  Compiled out of the product.
-#ifdef MCL_LF_TIMING
-__device__ unsigned long long g_lf_timing[16];
-// per workgroup of k_reweight_lf_patch (tools/exp_lf_workgroups.py): {start, end (s_memrealtime, 100 MHz), groups | fitting << 16 | loose << 31, HW_ID}
-__device__ unsigned long long g_lf_wg[4 * 8192];
-#ifdef MCL_LF_TIMING_COARSE  // (no timer around the barriers of the main loop: they distort it 2x)
-#define MCL_LF_BARRIER(statement) statement
-#else
-#define MCL_LF_BARRIER(statement)                         \
-  do {                                                    \
-    const long long t_b = __builtin_readcyclecounter();   \
-    statement;                                            \
-    lf_barrier_cycles += __builtin_readcyclecounter() - t_b; \
-  } while (0)
-#endif
-#else
-#define MCL_LF_BARRIER(statement) statement
-#endif
-#ifndef MCL_ABLATE
-#define MCL_ABLATE 0
-#endif
-#ifndef MCL_PIPE_ABLATE  // timing-only builds of k_reweight_lf_pipe: 1 = no wait for the patches, 2 = no patch fetches, 4 = the side work in the
-#define MCL_PIPE_ABLATE 0  // block's last step only, 8 = no raised priority
-#endif
+// (The measurement builds of rounds 3 / 4 - ablations, barrier timers, the workgroup timeline - are built from that round's sources:
+// tools/build_variant.sh.)
 constexpr int kPatchW = 64, kPatchH = 64;  // cells
 // Bytes per patch column: the 128 of its cells + 16, so that the bank of a cell is (4 x + y / 2) mod 32 - neighbouring
 // columns on different banks (with 128, every column of a row pair would share one).
 constexpr uint32_t kPatchPitch = kPatchH * 2 + 16;
 constexpr uint32_t kPatchBytes = kPatchW * kPatchPitch;
-#ifndef MCL_PATCH_BLOCK
-#define MCL_PATCH_BLOCK 512
-#endif
-#ifndef MCL_PATCH_LDS_PAD  // measurement builds: unused workgroup memory, so that fewer workgroups share a CU
-#define MCL_PATCH_LDS_PAD 0
-#endif
-#ifndef MCL_PATCH_WAVES
-#define MCL_PATCH_WAVES 6
-#endif
-constexpr int kPatchBlock = MCL_PATCH_BLOCK;  // threads of k_reweight_lf_patch: the waves that hold particles and, without kShared, the producer
+constexpr int kPatchBlock = 512;                      // threads of k_reweight_lf_patch
 constexpr uint32_t kPatchParticles = kPatchBlock - 64;  // per workgroup, with a producer wave (k_reweight_lf_patch<false>)
 constexpr uint32_t kPatchParticlesAll = kPatchBlock;    // per workgroup when every wave holds particles (k_reweight_lf_patch<true>)
 constexpr uint32_t kPatchPlanned = 192;               // groups with a plan entry (scans of up to 1536 points); the ones beyond are gathered
-// Patch buffers: THREE with a producer wave, so that the consumers need no wait at a group's barrier - the look-ups of group g
-// (issued at the end of step g, used in step g + 1) have returned long before the buffer of group g is written again behind
-// barrier g + 2, whereas with two buffers every wave had to sit out its outstanding LDS reads in front of each barrier - ; two when
-// the fetches are shared by all waves.  Behind them: the two plans, the prologue's partial results, and (shared fetches) the lanes'
-// constant shares of a fetch.
-#ifndef MCL_PATCH_BUFFERS
-#define MCL_PATCH_BUFFERS 3
-#endif
-#ifndef MCL_BARE_BARRIER
-#define MCL_BARE_BARRIER 1
-#endif
-constexpr uint32_t patch_buffers(bool shared) { return shared ? 2u : MCL_PATCH_BUFFERS; }
-constexpr uint32_t patch_lds_bytes(bool shared) { return patch_buffers(shared) * kPatchBytes + kPatchPlanned * 32 + 48 * 4 + (shared ? kPatchBlock * 8 : 0u); }
+// THREE patch buffers, so that nobody waits for its own look-ups at a group's barrier - the look-ups of group g (issued at the end of
+// step g, used in step g + 1) have returned long before the buffer of group g is written again behind barrier g + 2, whereas with
+// two buffers every wave had to sit out its outstanding LDS reads in front of each barrier.  Behind them: the two plans and the
+// prologue's partial results.
+constexpr uint32_t kPatchBuffers = 3;
+constexpr uint32_t kPatchLdsBytes = kPatchBuffers * kPatchBytes + kPatchPlanned * 32 + 48 * 4;
+static_assert(kPatchPlanned * 8 * 16 <= kPatchBuffers * kPatchBytes, "the per-beam records of the plan live in the patch buffers");
 constexpr double kPatchMagic = 1572864.0 + 4.656612873077392578125e-10;     // 1.5 * 2^20 + 2^-31
-// kShared: no producer wave.  All eight waves hold particles, and each fetches an eighth of the next group's patch itself with
-// buffer_load_dwordx4 ... lds (global memory -> LDS without passing through registers: lane i's 16 bytes land at M0 + 16 i,
-// tools/calib_lds_direct.hip): the patch's 576 16-byte pieces (64 columns x 8 tile rows + one piece of padding per column) are
-// dealt out 72 to a wave, a full instruction and one of 8 lanes.  Every lane's share of the address is a constant (column x 16
-// + tile row x pitch), the group's share a scalar: no vector instruction and no register per fetch.  The seven-consumer form
-// leaves one wave in eight without arithmetic; this one has none idle.  (Half patches and patches that need clamping at the
-// table's border are left to the producer form: here such groups are gathered.)
 // 6 waves per SIMD = three workgroups per CU: at most 80 registers
 // exp() as a call: inlined into the queue's loop, its dozen polynomial coefficients are hoisted out of the loop into registers and from
 // there into scratch memory (likelihood_field_prob_model.hpp:89 - once per particle and launch, and not at all for the plain model).
@@ -959,29 +854,18 @@ struct PatchArgs {
   uint32_t nblocks;
   uint32_t ends_first;  // 1: the blocks are taken from both ends of the order inwards
 };
-template <bool kShared, bool kQueue = false>
-__global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL_PATCH_WAVES, MCL_PATCH_WAVES))) void k_reweight_lf_patch(PatchArgs args) {
+template <bool kCoop, bool kQueue = false>
+__global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reweight_lf_patch(PatchArgs args) {
   // The arguments are read from the kernel argument segment at the start of every block (scalar loads), its address through an empty asm
   // statement so that the loads are not hoisted out of the queue's loop (kQueue): held in registers from the kernel's entry on they would all
   // stay alive around that loop - 90 scalar registers spilled.
   typedef const __attribute__((address_space(4))) unsigned char* kernarg_bytes_t;
   const kernarg_bytes_t kernarg = (kernarg_bytes_t)(__builtin_amdgcn_kernarg_segment_ptr());
   const PatchArgs* ka = (const PatchArgs*)(kernarg);
-  [[maybe_unused]] double* const w = ka->w;  // (these two in front of the loop: a timing build only)
-  [[maybe_unused]] const uint64_t n = ka->n;
-  const FieldView& f = ka->f;  // (used once, in front of the loop)
   const uint32_t patch_base = ka->patch_base;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifdef MCL_LF_TIMING
-  const long long lf_t0 = __builtin_readcyclecounter();
-  unsigned long long lf_wall0 = __builtin_amdgcn_s_memrealtime();
-  long long lf_barrier_cycles = 0, lf_t_main = lf_t0, lf_load_wait = 0;
-#endif
-  if constexpr ((MCL_ABLATE & 512) != 0) {  // timing only: what launching the workgroups costs
-    if (n == 0xFFFFFFFFFFFFull) w[threadIdx.x] = smem[threadIdx.x];
-    return;
-  }
-  if constexpr (!(MCL_ABLATE & 64)) {
+  {
+    const FieldView& f = ka->f;  // (used once, in front of the loop)
     uint32_t* s_row = reinterpret_cast<uint32_t*>(smem);
     for (uint32_t j = threadIdx.x; j < f.H + 2; j += kPatchBlock)
       s_row[j] = palette_row_offset(static_cast<int32_t>(j) - 1, f.pal_pitch) - kFastBiasX;
@@ -992,23 +876,22 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
   // flags: 1 = the group goes through a patch, 2 = split into two halves side by side (32 x 64 cells each), 4 = split into two
   // halves one above the other (64 x 32 cells each).  A group whose 8 end-points straddle a range discontinuity fits no single
   // patch however tight the cloud (3 - 5 % of the groups of an indoor scan); its beams [0, k) and [k, 8) almost always fit two
-  // half patches, which share the buffer of one whole patch: the consumers' addressing does not change, only the constant K
+  // half patches, which share the buffer of one whole patch: the addressing of the look-ups does not change, only the constant K
   // differs between the two halves (a scalar select per beam).
-  // The consumers read a second entry per group: {KA', meta, KB', the group's fetch offset (kShared)}: the constants of the two halves' LDS addresses less the
+  // The look-ups read a second entry per group: {KA', meta, KB', 0}: the constants of the two halves' LDS addresses less the
   // buffer's base (cell (cx, cy) sits at cx * pitch + cy * 2 + K), meta = 0: gathered, 8: one whole patch, k = 1 .. 7: two halves,
   // the second one from beam k on.
-  constexpr uint32_t kBuffers = patch_buffers(kShared);
   auto buffer_of = [&](uint32_t g) -> uint32_t {  // LDS byte address of the buffer that holds the patch of group g (g uniform, < 2^16)
-    const uint32_t slot = kBuffers == 2 ? (g & 1u) : g - 3u * ((g * 0xAAABu) >> 17);
+    const uint32_t slot = g - 3u * ((g * 0xAAABu) >> 17);
     return patch_base + slot * kPatchBytes;
   };
-  int4* s_plan = reinterpret_cast<int4*>(smem + patch_base + kBuffers * kPatchBytes);
+  int4* s_plan = reinterpret_cast<int4*>(smem + patch_base + kPatchBuffers * kPatchBytes);
   int4* s_plan_k = s_plan + kPatchPlanned;
-  float* s_bound = reinterpret_cast<float*>(smem + patch_base + kBuffers * kPatchBytes + kPatchPlanned * 32);  // [7][6]
-  constexpr uint32_t kConsumers = kShared ? kPatchBlock / 64 : kPatchBlock / 64 - 1;  // waves that hold particles
+  float* s_bound = reinterpret_cast<float*>(smem + patch_base + kPatchBuffers * kPatchBytes + kPatchPlanned * 32);  // [8][6]
+  constexpr uint32_t kConsumers = kCoop ? kPatchBlock / 64 : kPatchBlock / 64 - 1;  // waves that hold particles
   constexpr uint32_t kParticles = kConsumers * 64;
-  const bool producer = !kShared && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPatchBlock / 64 - 1);  // a scalar branch: the roles
-                                                                                                              // run different loops
+  const uint32_t wave_id = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+  const bool producer = !kCoop && wave_id == (kPatchBlock / 64 - 1);  // a scalar branch: the roles run different loops
   // kQueue: the launch holds as many workgroups as the device keeps resident, and each takes blocks of the order from a counter until
   // none is left (stats.arrivals: nblocks + gridDim.x fetches per launch, the last of which wraps it to zero for the next one).  The
   // hardware deals the workgroups of a grid out to the XCDs in turn, the same number to each - at 1M particles 279 blocks for 96 slots,
@@ -1044,9 +927,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
     __syncthreads();
     block = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(*s_next));
     if (block >= nblocks) break;
-#ifdef MCL_LF_TIMING
-    lf_wall0 = __builtin_amdgcn_s_memrealtime();
-#endif
   }
   // The blocks are taken from both ends of the order inwards: 0, N - 1, 1, N - 2, ...  The ends of the heading-major order are the cloud's
   // fringe - the blocks that gather everything, twice as slow as the others, sit in its first and last tenth (tools/exp_lf_workgroups.py) -
@@ -1069,7 +949,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
 
   // ---- the reference pose: the middle of the workgroup's box in x and y, its mean heading (any pose would do: the bound
   // below is taken against whatever is chosen here; a central one makes it small).  In cells, like ixt, iyt.
-  float* s_part = s_bound;  // [7][6] partial results, then [7][4]
+  float* s_part = s_bound;  // [8][6] partial results, then [8][4]
   if (!producer) {
     float lo_x = static_cast<float>(ixt), hi_x = lo_x, lo_y = static_cast<float>(iyt), hi_y = lo_y;
     float sum_c = static_cast<float>(ct), sum_s = static_cast<float>(st);
@@ -1145,18 +1025,16 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
       mine[3] = db;
     }
   }
-  // ---- the scan through the reference pose, a beam per thread (every wave, the producer's too): end-point cell and reach per
+  // ---- the scan through the reference pose, a beam per thread (every wave, a producer's too): end-point cell and reach per
   // axis of each beam of the planned groups, 16 bytes per beam in the patch buffers (nothing else uses them before the main
   // loop).  The plan below then works on these records: the double precision arithmetic of a workgroup's 1080 beams runs once,
-  // 512 wide, instead of once per question a group's thread asks about its 8 beams, one beam after the other (the planner was
-  // 18 us of the kernel's 450, none of it hidden behind other workgroups: they all plan at the same time).
+  // 512 wide, instead of once per question a group's thread asks about its 8 beams, one beam after the other.
   const uint32_t planned = groups < kPatchPlanned ? groups : kPatchPlanned;
-  const bool beam_records = static_cast<size_t>(planned) * 8 * sizeof(int4) <= kBuffers * kPatchBytes;
   int4* s_beam = reinterpret_cast<int4*>(smem + patch_base);
-  if (beam_records) {
+  {
     const double2* scan = reinterpret_cast<const double2*>(pts) + b_begin;
 #pragma unroll
-    for (uint32_t pass = 0; pass < (kBuffers * kPatchBytes / sizeof(int4) + kPatchBlock - 1) / kPatchBlock; ++pass) {
+    for (uint32_t pass = 0; pass < (kPatchPlanned * 8 + kPatchBlock - 1) / kPatchBlock; ++pass) {
       const uint32_t b = pass * kPatchBlock + tid;
       if (b < planned * 8) {
         const double2 p = scan[b];
@@ -1171,10 +1049,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
   __syncthreads();
   // ---- the plan: thread g looks at group g through the reference pose
   bool mine_fits = false;
-#pragma unroll 1
-  for (int plan_rep = 0; plan_rep < ((MCL_ABLATE & 1024) ? 2 : 1); ++plan_rep) {  // (twice: timing only - is the plan's time hidden?)
-  if constexpr ((MCL_ABLATE & 1024) != 0) asm volatile("" ::: "memory");
-  if (tid < planned && beam_records) {
+  if (tid < planned) {
     float Dx = 0.f, Dy = 0.f, Da = 0.f, Db = 0.f;
     for (uint32_t k = 0; k < kConsumers; ++k) {
       Dx = fmaxf(Dx, s_bound[4 * k]);
@@ -1191,21 +1066,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
     struct Range {
       int lo_x, hi_x, lo_y, hi_y;
       float reach_x, reach_y;
-    };
-    auto range_of = [&](int from, int to) {  // beams [from, to) of this group
-      Range r{INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0.f, 0.f};
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (k >= from && k < to) {
-          r.lo_x = min(r.lo_x, rec[k].x);
-          r.hi_x = max(r.hi_x, rec[k].x);
-          r.lo_y = min(r.lo_y, rec[k].y);
-          r.hi_y = max(r.hi_y, rec[k].y);
-          r.reach_x = fmaxf(r.reach_x, __builtin_bit_cast(float, rec[k].z));
-          r.reach_y = fmaxf(r.reach_y, __builtin_bit_cast(float, rec[k].w));
-        }
-      }
-      return r;
     };
     // Does the range fit a patch of PW x PH cells?  -> its origin
     auto fits_patch = [&](const Range& r, int PW, int PH, int& x0, int& y0) -> bool {
@@ -1224,23 +1084,29 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
       y0 = (r.lo_y - margin_y) & ~7;
       return fits && r.hi_x + margin_x - x0 < PW && r.hi_y + margin_y - y0 < PH;
     };
+    // kCoop: are all PW x PH cells inside the bordered table (its border tiles hold the unknown entry: what a clamped fetch reads as
+    // well)?  Then the waves fetch with the group's scalar offsets and nothing clamps; a patch that reaches beyond is marked, and
+    // fetched by the clamping code (the grid's edges only).
+    auto inside_table = [&](int x0, int y0, int PW, int PH) -> bool {
+      const int xu = x0 - static_cast<int>(kFastBias), yu = y0 - static_cast<int>(kFastBias);
+      const int x_last = static_cast<int>((f.W + 7u) & ~7u) + 7, y_last_cell = static_cast<int>((f.H + 7u) & ~7u) + 7;
+      return xu >= -8 && xu + PW - 1 <= x_last && yu >= -8 && yu + PH - 1 <= y_last_cell;
+    };
+    Range whole{INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      whole.lo_x = min(whole.lo_x, rec[k].x);
+      whole.hi_x = max(whole.hi_x, rec[k].x);
+      whole.lo_y = min(whole.lo_y, rec[k].y);
+      whole.hi_y = max(whole.hi_y, rec[k].y);
+      whole.reach_x = fmaxf(whole.reach_x, __builtin_bit_cast(float, rec[k].z));
+      whole.reach_y = fmaxf(whole.reach_y, __builtin_bit_cast(float, rec[k].w));
+    }
     int x0a = 0, y0a = 0, x0b = 0, y0b = 0;
     uint32_t flags = 0u, first_b = 0u;
-    uint32_t fetch_offset = 0u;  // kShared: the group's share of every piece's byte offset in the table
-    if ((MCL_ABLATE & 256) != 0) {
-    } else if (fits_patch(range_of(0, 8), kPatchW, kPatchH, x0a, y0a)) {
+    if (fits_patch(whole, kPatchW, kPatchH, x0a, y0a)) {
       flags = 1u;
-      if constexpr (kShared) {
-        // all 64 x 64 cells inside the bordered table (its border tiles hold the unknown entry: what a clamped fetch would
-        // read as well); a patch that reaches beyond them is left to the gathers
-        const int xu = x0a - static_cast<int>(kFastBias), yu = y0a - static_cast<int>(kFastBias);
-        const int x_last = static_cast<int>((f.W + 7u) & ~7u) + 7, y_last_cell = static_cast<int>((f.H + 7u) & ~7u) + 7;
-        if (xu >= -8 && xu + kPatchW - 1 <= x_last && yu >= -8 && yu + kPatchH - 1 <= y_last_cell)
-          fetch_offset = (static_cast<uint32_t>(xu + 8) << 4) + (static_cast<uint32_t>(yu + 8) >> 3) * f.pal_pitch;
-        else
-          flags = 0u;
-      }
-    } else if (!kShared && stats.split_patches) {
+    } else if (stats.split_patches) {
       // split where the scan jumps: between the two consecutive beams whose end-points lie farthest apart (the first such pair)
       int widest_jump = -1, k_split = 4;
 #pragma unroll
@@ -1271,123 +1137,37 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
         x0b = xb;
         y0b = yb;
         first_b = static_cast<uint32_t>(k_split);
-      }
-    }
-    s_plan[tid] = int4{x0a, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
-    {
-      const uint32_t ka = 0u - (static_cast<uint32_t>(x0a) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0a) << 1);
-      // half B lives in columns 32 .. 63 (side by side) or in rows 32 .. 63 (stacked) of the same buffer
-      const uint32_t kb = ((flags & 2u) ? (kPatchW / 2) * kPatchPitch : static_cast<uint32_t>(kPatchH)) -
-                          (static_cast<uint32_t>(x0b) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0b) << 1);
-      const uint32_t meta = flags == 0u ? 0u : ((flags & 6u) ? first_b : 8u);
-      s_plan_k[tid] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), static_cast<int>(fetch_offset)};
-    }
-    mine_fits = flags != 0u;
-  } else if (tid < planned) {  // (a scan too long for the records: the plan straight from global memory, a beam after the other)
-    float Dx = 0.f, Dy = 0.f, Da = 0.f, Db = 0.f;
-    for (uint32_t k = 0; k < kConsumers; ++k) {
-      Dx = fmaxf(Dx, s_bound[4 * k]);
-      Dy = fmaxf(Dy, s_bound[4 * k + 1]);
-      Da = fmaxf(Da, s_bound[4 * k + 2]);
-      Db = fmaxf(Db, s_bound[4 * k + 3]);
-    }
-    // every float operation below may round down: scaled up by 1 + 2^-10 where it matters, and two cells of slack
-    Dx = Dx * 1.001f + 2.f;
-    Dy = Dy * 1.001f + 2.f;
-    const uint32_t q0 = b_begin + 8 * tid;
-    const double2* q = reinterpret_cast<const double2*>(pts) + q0;
-    // Do the beams [from, to) of this group fit a patch of PW x PH cells?  -> its origin.  (The end-points are evaluated anew
-    // for every question - a few hundred operations for the 1 thread in 4 that plans, once per workgroup - rather than held
-    // in registers: the kernel's 80 registers belong to the main loop.)
-    int widest_jump = 0, jump_at = 4;  // the largest step between the end-points of consecutive beams of the last range asked about
-    auto try_fit = [&](int from, int to, int PW, int PH, int& x0, int& y0) -> bool {
-      int lo_x = INT_MAX, hi_x = INT_MIN, lo_y = INT_MAX, hi_y = INT_MIN;
-      float reach_x = 0.f, reach_y = 0.f;  // of q' = M q / res (cells), per axis
-      int last_x = 0, last_y = 0;
-      widest_jump = -1;
-#pragma unroll 1
-      for (int k = from; k < to; ++k) {
-        const double2 p = q[k];
-        const double sx = __builtin_fma(p.x, rc, __builtin_fma(-p.y, rs, rxm));
-        const double sy = __builtin_fma(p.x, rs, __builtin_fma(p.y, rc, rym));
-        const int cx = static_cast<int>(__builtin_bit_cast(uint64_t, sx) >> 32), cy = static_cast<int>(__builtin_bit_cast(uint64_t, sy) >> 32);
-        lo_x = min(lo_x, cx);
-        hi_x = max(hi_x, cx);
-        lo_y = min(lo_y, cy);
-        hi_y = max(hi_y, cy);
-        reach_x = fmaxf(reach_x, static_cast<float>(fabs(p.x * rc - p.y * rs)));
-        reach_y = fmaxf(reach_y, static_cast<float>(fabs(p.x * rs + p.y * rc)));
-        const int jump = k > from ? max(abs(cx - last_x), abs(cy - last_y)) : -1;
-        if (jump > widest_jump) {
-          widest_jump = jump;
-          jump_at = k;
-        }
-        last_x = cx;
-        last_y = cy;
-      }
-      float turn_x, turn_y;  // cells
-      if (stats.isotropic_margin) {  // |q'| <= sqrt(max q'x^2 + max q'y^2)
-        turn_x = turn_y = sqrtf(reach_x * reach_x + reach_y * reach_y) * 1.002f * (Da * 1.001f);
       } else {
-        const float A = Da * 1.001f, Bv = Db * 1.001f, qx = reach_x * 1.001f, qy = reach_y * 1.001f;
-        turn_x = (A * qx + Bv * qy) * 1.001f;
-        turn_y = (Bv * qx + A * qy) * 1.001f;
+        x0a = y0a = 0;
       }
-      const float mx = ceilf(Dx + turn_x), my = ceilf(Dy + turn_y);
-      bool fits = mx < 64.f && my < 64.f;  // false for NaN and infinity
-      const int margin_x = fits ? static_cast<int>(mx) : 0, margin_y = fits ? static_cast<int>(my) : 0;
-      x0 = lo_x - margin_x;
-      y0 = (lo_y - margin_y) & ~7;
-      return fits && hi_x + margin_x - x0 < PW && hi_y + margin_y - y0 < PH;
-    };
-    int x0a = 0, y0a = 0, x0b = 0, y0b = 0;
-    uint32_t flags = 0u, first_b = 0u;
-    uint32_t fetch_offset = 0u;  // kShared: the group's share of every piece's byte offset in the table
-    if ((MCL_ABLATE & 256) != 0) {
-    } else if (try_fit(0, 8, kPatchW, kPatchH, x0a, y0a)) {
-      flags = 1u;
-      if constexpr (kShared) {
-        // all 64 x 64 cells inside the bordered table (its border tiles hold the unknown entry: what a clamped fetch would
-        // read as well); a patch that reaches beyond them is left to the gathers
-        const int xu = x0a - static_cast<int>(kFastBias), yu = y0a - static_cast<int>(kFastBias);
-        const int x_last = static_cast<int>((f.W + 7u) & ~7u) + 7, y_last_cell = static_cast<int>((f.H + 7u) & ~7u) + 7;
-        if (xu >= -8 && xu + kPatchW - 1 <= x_last && yu >= -8 && yu + kPatchH - 1 <= y_last_cell)
-          fetch_offset = (static_cast<uint32_t>(xu + 8) << 4) + (static_cast<uint32_t>(yu + 8) >> 3) * f.pal_pitch;
-        else
-          flags = 0u;
-      }
-    } else if (!kShared && stats.split_patches) {
-      // split where the scan jumps: between the two consecutive beams whose end-points lie farthest apart (the pass above found it)
-      const int k = jump_at;
-      int xa, ya, xb, yb;
-      if ((stats.split_patches & 1u) && try_fit(0, k, kPatchW / 2, kPatchH, xa, ya) && try_fit(k, 8, kPatchW / 2, kPatchH, xb, yb)) flags = 1u | 2u;
-      else if ((stats.split_patches & 2u) && try_fit(0, k, kPatchW, kPatchH / 2, xa, ya) && try_fit(k, 8, kPatchW, kPatchH / 2, xb, yb)) flags = 1u | 4u;
-      if (flags) {
-        x0a = xa;
-        y0a = ya;
-        x0b = xb;
-        y0b = yb;
-        first_b = static_cast<uint32_t>(k);
-      }
+    } else {
+      x0a = y0a = 0;
     }
-    s_plan[tid] = int4{x0a, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
+    int clamped = 0;  // kCoop: bit 31 of the first word (biased coordinates are 0x4138....: the bit is free)
+    if constexpr (kCoop) {
+      bool inside = true;
+      if (flags == 1u) inside = inside_table(x0a, y0a, kPatchW, kPatchH);
+      else if (flags & 2u) inside = inside_table(x0a, y0a, kPatchW / 2, kPatchH) && inside_table(x0b, y0b, kPatchW / 2, kPatchH);
+      else if (flags & 4u) inside = inside_table(x0a, y0a, kPatchW, kPatchH / 2) && inside_table(x0b, y0b, kPatchW, kPatchH / 2);
+      clamped = inside ? 0 : INT_MIN;
+    }
+    s_plan[tid] = int4{x0a | clamped, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
     {
       const uint32_t ka = 0u - (static_cast<uint32_t>(x0a) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0a) << 1);
       // half B lives in columns 32 .. 63 (side by side) or in rows 32 .. 63 (stacked) of the same buffer
       const uint32_t kb = ((flags & 2u) ? (kPatchW / 2) * kPatchPitch : static_cast<uint32_t>(kPatchH)) -
                           (static_cast<uint32_t>(x0b) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0b) << 1);
       const uint32_t meta = flags == 0u ? 0u : ((flags & 6u) ? first_b : 8u);
-      s_plan_k[tid] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), static_cast<int>(fetch_offset)};
+      s_plan_k[tid] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), 0};
     }
     mine_fits = flags != 0u;
   }
-  }
-  // A workgroup with too few of its groups through a patch drops the machinery: no producer, no barriers, every look-up a
+  // A workgroup with too few of its groups through a patch drops the machinery: no patches, no barriers, every look-up a
   // gather.  Not only dispersed sets: a gathered group INSIDE a patched workgroup costs 2.6x a patched one (the workgroup waits
   // for the gathers at its next barrier), one of an all-gathering workgroup 1.3x, so mixing pays only above ~2/3 fitting
   // (stats.loose_below, in 256ths: measured, profiles/r02_lf_series.txt).
   // (counted by hand: __syncthreads_count brings a static LDS variable with it, and this kernel addresses LDS from 0)
-  uint32_t* s_count = reinterpret_cast<uint32_t*>(s_bound) + 4 * kConsumers;  // behind the bound's [7 or 8][4]
+  uint32_t* s_count = reinterpret_cast<uint32_t*>(s_bound) + 4 * (kPatchBlock / 64);  // behind the bound's [8][4]
   {
     const uint32_t in_wave = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine_fits)));
     if (lane == 0) s_count[tid >> 6] = in_wave;
@@ -1407,45 +1187,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
     plan.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.x));
     plan.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
   };
-
-  // kShared: this wave's 72 pieces of a patch.  Piece c = 9 x + r (column x, tile row r; r = 8 is the column's padding, which
-  // nobody fetches) lies at byte 16 c of the buffer: lane i of the full instruction takes piece 72 wave + i, lanes 0 .. 7 of
-  // the second one piece 72 wave + 64 + i.  The lane's share of the table offset never changes.
-  // (kept in LDS, one 8-byte read per fetch: the main loop has no two registers to spare for them)
-  uint2* s_piece = reinterpret_cast<uint2*>(smem + patch_base + kBuffers * kPatchBytes + kPatchPlanned * 32 + 48 * 4);
-  if constexpr (kShared) {
-    const uint32_t wave = tid >> 6;
-    const uint32_t ca = 72u * wave + lane, cb = 72u * wave + 64u + lane;
-    uint32_t piece_a = 0xFFFFFFFFu, piece_b = 0xFFFFFFFFu;
-    if (ca % 9u != 8u) piece_a = (ca / 9u) * 16u + (ca % 9u) * f.pal_pitch;
-    if (lane < 8u && cb % 9u != 8u) piece_b = (cb / 9u) * 16u + (cb % 9u) * f.pal_pitch;
-    s_piece[tid] = uint2{piece_a, piece_b};  // (read back by the same thread only)
-  }
-  typedef int rsrc_words_t __attribute__((ext_vector_type(4)));
-  const rsrc_words_t rsrc_words = {static_cast<int>(reinterpret_cast<uintptr_t>(f.pal_idx) & 0xFFFFFFFFull),
-                                   static_cast<int>((reinterpret_cast<uintptr_t>(f.pal_idx) >> 32) & 0xFFFFull), static_cast<int>(f.pal_bytes), 0x00020000};
-  auto fetch_shared = [&](uint32_t g) {  // g uniform
-    if constexpr (kShared) {
-      if (g >= groups || g >= kPatchPlanned) return;
-      const int4 e = s_plan_k[g];
-      if (__builtin_amdgcn_readfirstlane(e.y) != 8) return;  // no patch for this group
-      const uint32_t offset = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.w));
-      const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-      const uint32_t to = buffer_of(g) + wave * (72u * 16u);
-      const uint2 mine = s_piece[tid];
-      const uint32_t piece_a = mine.x, piece_b = mine.y;
-      // In assembly rather than through __builtin_amdgcn_raw_ptr_buffer_load_lds: the compiler makes every LDS read behind such a
-      // load wait for it (it cannot tell the patch buffer from the tables), i.e. stalls the wave for a memory latency once per
-      // group.  These loads are waited for where their data is needed: s_waitcnt vmcnt(0) in front of the next group's barrier.
-      if (piece_a != 0xFFFFFFFFu)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(to), "v"(piece_a), "s"(rsrc_words), "s"(offset) : "memory");
-      if (piece_b != 0xFFFFFFFFu)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(to + 64u * 16u), "v"(piece_b), "s"(rsrc_words), "s"(offset) : "memory");
-    }
-  };
-  if constexpr (kShared) {
-    if (!loose) fetch_shared(0);  // lands before the first group's barrier (a workgroup barrier waits for the wave's own fetches)
-  }
 
   // The launch's statistics (what the host picks the next launch's kernel by): groups planned and groups through a
   // patch, summed over a sample of the workgroups - every 16th of a large launch: thousands of atomic operations on one
@@ -1468,10 +1209,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
         }
       }
   };
-  if constexpr ((MCL_ABLATE & 32) != 0) {  // timing only: the prologue (tables, poses, bound, plan) and nothing else
-    if (tid == 0 && fitting == 0xFFFFFFFFu) w[0] = ixm + iym;
-    return;
-  }
+  const uint32_t last_planned = (groups < kPatchPlanned ? groups : kPatchPlanned) - 1u;
   if (producer) {
     if (loose) {
       report();
@@ -1481,9 +1219,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
       }
       return;
     }
-#ifdef MCL_PRODUCER_PRIO
-    __builtin_amdgcn_s_setprio(MCL_PRODUCER_PRIO);
-#endif
     const int y_last = static_cast<int>((f.H + 7u) & ~7u);  // first row of the bottom border tiles
     // The patch of group g, clamped into the bordered table (whatever lies outside the grid reads the unknown entry, like
     // a clamped gather): this lane's column, tile row by tile row.  While the consumers work on group g the patch of g + 1
@@ -1491,7 +1226,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
     using Pieces = uint4[kPatchH / 8];
     // Fetches and stores are unconditional (a group without a patch, or past the last one, moves a patch nobody reads):
     // straight-line code lets the compiler count the loads in flight exactly, so that a store waits for ITS fetch only.
-    const uint32_t last_planned = (groups < kPatchPlanned ? groups : kPatchPlanned) - 1u;
     // A whole patch: this lane's column x0A + lane, tile rows from y0A.  Halves side by side (flags & 2): the lanes from 32 on
     // fetch columns x0B + lane - 32, rows from y0B.  Halves one above the other (flags & 4): the pieces from 4 on come from
     // rows y0B + 8 (r - 4).
@@ -1516,8 +1250,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
       const bool side_by_side = (ya & 2) != 0, stacked = (ya & 4) != 0;  // scalar
       const bool half_b = side_by_side && lane >= static_cast<uint32_t>(kPatchW / 2);
       const int xu = (half_b ? x0b + static_cast<int>(lane) - kPatchW / 2 : x0a + static_cast<int>(lane)) - static_cast<int>(kFastBias);
-      // + 8: the border tile's share of palette_row_offset goes here, so that the vector offset - the one the buffer's
-      // range check looks at - is never negative
       const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W)) + 8) << 4;
       // stacked halves: the lower half of the buffer (pieces 4 .. 7) holds the columns from x0B on
       const int xu_low = (stacked ? x0b : x0a) + static_cast<int>(lane) - static_cast<int>(kFastBias);
@@ -1534,13 +1266,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
     };
     auto store = [&](uint32_t g, const Pieces& piece) {
       unsigned char* dst = smem + buffer_of(g) + lane * kPatchPitch;
-#ifdef MCL_LF_TIMING
-      {  // the wait for this set's loads (the other set's eight, issued later, may still be out: vmcnt(8))
-        const long long t_w = __builtin_readcyclecounter();
-        __builtin_amdgcn_s_waitcnt(0x0F78);
-        lf_load_wait += __builtin_readcyclecounter() - t_w;
-      }
-#endif
 #pragma unroll
       for (int r = 0; r < kPatchH / 8; ++r) *reinterpret_cast<uint4*>(dst + r * 16) = piece[r];
     };
@@ -1553,27 +1278,14 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
     fetch(2, even);
     uint32_t g = 0;
     for (; g + 1 < groups; g += 2) {
-      if constexpr (!(MCL_ABLATE & 1)) MCL_LF_BARRIER(__syncthreads());  // the consumers are done with group g - 1: its buffer takes the patch of g + 1
-      if constexpr (!(MCL_ABLATE & 16)) {
-        store(g + 1, odd);
-        fetch(g + 3, odd);
-      }
-      if constexpr (!(MCL_ABLATE & 1)) MCL_LF_BARRIER(__syncthreads());
-      if constexpr (!(MCL_ABLATE & 16)) {
-        store(g + 2, even);
-        fetch(g + 4, even);
-      }
+      __syncthreads();  // the consumers are done with group g - 1: its buffer takes the patch of g + 1
+      store(g + 1, odd);
+      fetch(g + 3, odd);
+      __syncthreads();
+      store(g + 2, even);
+      fetch(g + 4, even);
     }
-    if constexpr (!(MCL_ABLATE & 1))
-      if (g < groups) MCL_LF_BARRIER(__syncthreads());
-#ifdef MCL_LF_TIMING
-    if (lane == 0) {
-      atomicAdd(&g_lf_timing[3], 1ull);
-      atomicAdd(&g_lf_timing[4], static_cast<unsigned long long>(__builtin_readcyclecounter() - lf_t0));
-      atomicAdd(&g_lf_timing[5], static_cast<unsigned long long>(lf_barrier_cycles));
-      atomicAdd(&g_lf_timing[7], static_cast<unsigned long long>(lf_load_wait));
-    }
-#endif
+    if (g < groups) __syncthreads();
     report();  // off the consumers' path: they are still at their last group
     if constexpr (kQueue) {
       if (stats.weight_sums) __syncthreads();  // (the consumers' barrier around the block's sum)
@@ -1582,10 +1294,51 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
     return;
   }
 
+  // kCoop: this wave's tile row of a patch, a 16-byte piece per lane (lane = the patch's column).  Where the plan found the patch
+  // inside the bordered table (all but the grid's edges) the offsets are the group's scalars plus the lane's 16 bytes; a group without
+  // a patch (or past the last one) fetches the table's first bytes, which nobody reads: one unconditional load per step lets the
+  // compiler count the loads in flight.
+  auto coop_fetch = [&](uint32_t g, uint4& piece) {  // g uniform
+    if constexpr (kCoop) {
+      const int4 e = s_plan[g < last_planned ? g : last_planned];
+      const int ya = __builtin_amdgcn_readfirstlane(e.y), xa_word = __builtin_amdgcn_readfirstlane(e.x);
+      const int yb = __builtin_amdgcn_readfirstlane(e.w), x0b = __builtin_amdgcn_readfirstlane(e.z);
+      const int x0a = xa_word & INT_MAX;
+      const int bias = static_cast<int>(kFastBias);
+      const int r = static_cast<int>(wave_id);
+      if (xa_word < 0) {  // a patch across the table's border: columns and rows clamped like a producer's fetch (scalar branch, rare)
+        const int y_last = static_cast<int>((f.H + 7u) & ~7u);  // first row of the bottom border tiles
+        const bool half_b = (ya & 2) != 0 && lane >= static_cast<uint32_t>(kPatchW / 2);
+        const bool low = (ya & 4) != 0 && r >= kPatchH / 16;
+        const int xu = (half_b ? x0b + static_cast<int>(lane) - kPatchW / 2 : (low ? x0b : x0a) + static_cast<int>(lane)) - bias;
+        const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W)) + 8) << 4;
+        const int yu_a = (low ? (yb & ~7) + 8 * (r - kPatchH / 16) : (ya & ~7) + 8 * r) - bias, yu_b = (yb & ~7) + 8 * r - bias;  // scalar
+        const uint32_t row_a = palette_row_offset(min(max(yu_a, -8), y_last), f.pal_pitch) - 128u;
+        const uint32_t row_b = palette_row_offset(min(max(yu_b, -8), y_last), f.pal_pitch) - 128u;
+        piece = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, column + (half_b ? row_b : row_a), 0, 0));
+        return;
+      }
+      // (x + 8) * 16 + ((y + 8) / 8) * pitch = palette_offset(x, y) of a row y that is a multiple of 8
+      auto piece_offset = [&](int x0, int y0) -> uint32_t {  // scalar
+        return (static_cast<uint32_t>(x0 - bias + 8) << 4) + (static_cast<uint32_t>(y0 - bias + 8) >> 3) * f.pal_pitch;
+      };
+      const bool stacked_low = (ya & 4) != 0 && r >= kPatchH / 16;
+      uint32_t base_a = stacked_low ? piece_offset(x0b, (yb & ~7) + 8 * (r - kPatchH / 16)) : piece_offset(x0a, (ya & ~7) + 8 * r);
+      base_a = (ya & 1) ? base_a : 0u;
+      uint32_t voffset = lane << 4;
+      if ((ya & 2) != 0) {  // halves side by side: the lanes from 32 on fetch columns x0B + lane - 32, rows from y0B (rare: a scalar branch)
+        const uint32_t base_b = piece_offset(x0b, (yb & ~7) + 8 * r) - ((kPatchW / 2) << 4);
+        voffset += lane >= static_cast<uint32_t>(kPatchW / 2) ? base_b : base_a;
+        base_a = 0u;
+      }
+      piece = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, base_a, 0));
+    }
+  };
+  auto coop_store = [&](uint32_t g, const uint4& piece) {  // g uniform
+    if constexpr (kCoop) *reinterpret_cast<uint4*>(smem + buffer_of(g) + lane * kPatchPitch + wave_id * 16u) = piece;
+  };
+
   double acc = (f.prob || partial) ? 0.0 : 1.0;
-#if (MCL_ABLATE & 8192)
-  float lf_dummy = static_cast<float>(tid);
-#endif
   const bool fast = __builtin_amdgcn_ballot_w64(!lane_small) == 0;  // per wave: a far particle sends its wave through the exact code
   const int c_lo = static_cast<int>(kFastBias) - 1, x_hi = static_cast<int>(kFastBias + f.W), y_hi = static_cast<int>(kFastBias + f.H);
   const uint32_t row_bias = 4u - (kFastBias << 2);  // LDS byte address of the row entry = (biased y << 2) + row_bias
@@ -1638,12 +1391,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
       add_exact(b0, 8);
       return;
     }
-    if constexpr (MCL_ABLATE & 2) {
-      auto fake = [](uint32_t a) { return __hiloint2double(0x3F000000, static_cast<int>(a)); };
-      acc += sum4(fake(e.e[0]), fake(e.e[1]), fake(e.e[2]), fake(e.e[3]));
-      acc += sum4(fake(e.e[4]), fake(e.e[5]), fake(e.e[6]), fake(e.e[7]));
-      return;
-    }
     {
       const double t0 = lf_palette_value(e.e[0]), t1 = lf_palette_value(e.e[1]), t2 = lf_palette_value(e.e[2]), t3 = lf_palette_value(e.e[3]);
       acc += sum4(t0, t1, t2, t3);
@@ -1655,28 +1402,27 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
   };
   // One step: the end-points of group g, then the sum of the group before it (its gathers, if any, had the end-point
   // arithmetic to arrive), then the look-ups of group g.  `redo`: 1 if the group has to be added by add_exact instead.
-  auto step = [&](auto is_loose, auto add_before, uint32_t g_any, Lookups& now, const Lookups& before) {
+  // kCoop: `piece` holds this wave's tile row of the patch of group g + 1; it goes to LDS behind the barrier, and the row of g + 2 is fetched.
+  auto step = [&](auto is_loose, auto add_before, uint32_t g_any, Lookups& now, const Lookups& before, uint4& piece) {
     const uint32_t g = __builtin_amdgcn_readfirstlane(g_any);  // uniform anyway; this keeps the scan reads on the scalar unit
     const uint32_t b0 = b_begin + 8 * g;
     Plan plan{0u, 0u};
     if constexpr (!decltype(is_loose)::value) plan_of(g, plan);
     const uint32_t buffer = buffer_of(g);
-    if constexpr (kShared && !decltype(is_loose)::value) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of group g's patch are in LDS
-    if constexpr (!decltype(is_loose)::value && !(MCL_ABLATE & 1)) {
-      if constexpr (kShared || !MCL_BARE_BARRIER) {
-        MCL_LF_BARRIER(__syncthreads());
-      } else {
-        // A bare barrier: no wait for this wave's outstanding LDS reads (see patch_buffers).  What it orders: the producer's stores
-        // of patch g (complete before ITS barrier: it keeps the fence) against the look-ups below.  The empty asm statements keep
-        // the compiler from moving memory operations across it.
+    if constexpr (!decltype(is_loose)::value) {
+      // A bare barrier: no wait for this wave's outstanding LDS reads (see kPatchBuffers).  What it orders: the stores of patch g
+      // (a producer's are complete before ITS barrier: it keeps the fence; a wave's own piece - kCoop - was stored at the start of the
+      // step before, in front of the plan entry's LDS read that coop_fetch waits for: LDS operations of a wave complete in order)
+      // against the look-ups below.  The empty asm statements keep the compiler from moving memory operations across it.
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if constexpr (kCoop) {
+        coop_store(g + 1, piece);  // every wave is done with the look-ups of group g - 2, whose buffer this is
         asm volatile("" ::: "memory");
-        MCL_LF_BARRIER(__builtin_amdgcn_s_barrier());
-        asm volatile("" ::: "memory");
+        coop_fetch(g + 2, piece);
       }
     }
-    // kShared: behind this barrier every wave is done with the buffer of group g - 1, which takes the patch of group g + 1; the
-    // fetch issued here lands before the next barrier (one group of arithmetic, ~3 us, against ~1 us of L2 latency)
-    if constexpr (kShared && !decltype(is_loose)::value) fetch_shared(g + 1);
     now.redo = 1u;
     if (!fast) {
       if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
@@ -1689,9 +1435,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const double px = q[2 * k], py = q[2 * k + 1];
-#if (MCL_ABLATE & 8192)  // timing only: two more vector instructions per beam (the kernel's sensitivity to their number)
-      asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %0, %0, %0, %0" : "+v"(lf_dummy));
-#endif
       const double sx = __builtin_fma(px, ict, __builtin_fma(-py, ist, ixm));
       const double sy = __builtin_fma(px, ist, __builtin_fma(py, ict, iym));
       const uint64_t bx = __builtin_bit_cast(uint64_t, sx), by = __builtin_bit_cast(uint64_t, sy);
@@ -1705,8 +1448,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t at = mad_u24(static_cast<uint32_t>(cx[k]), kPatchPitch, lshl_add_u32_uniform(static_cast<uint32_t>(cy[k]), 1, K));
-        if constexpr (MCL_ABLATE & 4) now.e[k] = f.pal_base + (at & 0x3F8u);
-        else now.e[k] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(static_cast<uintptr_t>(at)));
+        now.e[k] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(static_cast<uintptr_t>(at)));
       }
     } else if (plan.meta != 0u) {  // two halves: the beams from plan.meta on read the second one
       const uint32_t KA = buffer + plan.ka, KB = buffer + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_plan_k[g].z));
@@ -1728,48 +1470,35 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
   };
   auto run = [&](auto is_loose) {
     Lookups a, c;
+    uint4 piece{};
+    if constexpr (kCoop && !decltype(is_loose)::value) {
+      // the patches of groups 0 and 1: the first goes to LDS here (the plan's records, which lived in the buffers, were read in front of
+      // the barrier above), the second one behind barrier 0
+      uint4 piece0;
+      coop_fetch(0, piece0);
+      coop_fetch(1, piece);
+      coop_store(0, piece0);
+    }
     uint32_t g;
     if (groups & 1) {
-      step(is_loose, std::false_type{}, 0, a, a);
+      step(is_loose, std::false_type{}, 0, a, a, piece);
       g = 1;
     } else {
-      step(is_loose, std::false_type{}, 0, c, c);
-      step(is_loose, std::true_type{}, 1, a, c);
+      step(is_loose, std::false_type{}, 0, c, c, piece);
+      step(is_loose, std::true_type{}, 1, a, c, piece);
       g = 2;
     }
     for (; g < groups; g += 2) {  // `a` holds group g - 1
-      step(is_loose, std::true_type{}, g, c, a);
-      step(is_loose, std::true_type{}, g + 1, a, c);
+      step(is_loose, std::true_type{}, g, c, a, piece);
+      step(is_loose, std::true_type{}, g + 1, a, c, piece);
     }
     consume(a, b_begin + 8 * groups - 8);
   };
-#ifdef MCL_LF_TIMING
-  lf_t_main = __builtin_readcyclecounter();
-#endif
   if (groups) {
     if (loose) run(std::true_type{});
     else run(std::false_type{});
   }
   add_exact(b_begin + 8 * groups, b_end - (b_begin + 8 * groups));
-#if (MCL_ABLATE & 8192)
-  if (lf_dummy == 12345.f) acc += 1.0;
-#endif
-#ifdef MCL_LF_TIMING
-  if (lane == 0) {
-    atomicAdd(&g_lf_timing[0], 1ull);
-    atomicAdd(&g_lf_timing[1], static_cast<unsigned long long>(__builtin_readcyclecounter() - lf_t0));
-    atomicAdd(&g_lf_timing[2], static_cast<unsigned long long>(lf_barrier_cycles));
-    atomicAdd(&g_lf_timing[6], static_cast<unsigned long long>(lf_t_main - lf_t0));
-  }
-  if (tid == 0 && block < 8192 && blockIdx.y == 0) {
-    unsigned long long* rec = g_lf_wg + 4 * block;
-    rec[0] = lf_wall0;
-    rec[1] = __builtin_amdgcn_s_memrealtime();
-    rec[2] = groups | (loose ? 0u : fitting) << 16 | (loose ? 1u : 0u) << 31;
-    rec[3] = static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(4 /* HW_ID */ | (0 << 6) | (31 << 11))) |
-             static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(20 /* XCC_ID */ | (0 << 6) | (3 << 11))) << 32;
-  }
-#endif
   uint64_t t_end;
   const uint32_t i_end = particle_again(t_end);
   double new_weight = 0.0;
@@ -1795,682 +1524,11 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(MCL
       stats.weight_sums[block] = total;
     }
   }
-  if constexpr (kShared) {
-    if (__builtin_amdgcn_readfirstlane(tid >> 6) == kPatchBlock / 64 - 1) report();
+  if constexpr (kCoop) {
+    if (wave_id == kPatchBlock / 64 - 1) report();
   }
   if constexpr (!kQueue) break;
   }  // the next block of the queue
-}
-
-// ---- the patch kernel, persistent ---------------------------------------------------------------------------------------
-// (Option lf_pipe, off: measured slower.  Its premise - 2232 workgroups on 768 slots in three lock-step rounds, every workgroup of a
-// round planning at the same time, so that nothing hides a workgroup's prologue (tables -> perm -> pose -> reference pose -> bound ->
-// plan: ~14 us) or its epilogue (perm -> old weight -> product -> scattered store: ~7 us) - did not survive the launch's timeline
-// (tools/exp_lf_workgroups.py, profiles/r04_lf_workgroup_timeline.txt): the CU serves its oldest waves first, three workgroups that
-// start together end one after the other, and from then on the workgroups of a CU are out of step by themselves.)  Here a workgroup stays
-// resident and takes blocks b, b + gridDim.x, ...; what its producer wave does beside the patches, while the seven consumer
-// waves run the main loop of block k, is everything of the next block's prologue and of the previous block's epilogue that
-// WAITS FOR MEMORY:
-//   * block k + 1's 448 indices of the order and then their pose records go from global memory straight into LDS (buffer_load ...
-//     lds: no register holds them; lane i's bytes land at M0 + 4 i / 16 i, tools/calib_lds_direct.hip), where the consumers pick
-//     them up at the block's first barrier - no dependent global loads on their path -;
-//   * block k - 1's sums, which the consumers park in the same slots and go on: indices and old weights come the same way, the
-//     products are stored, and the block's sum of new weights is added in k_reweight_lf_patch's order.
-// The arithmetic of the prologue (frame change, reference pose, bound, per-beam records, plan: k_reweight_lf_patch's, a beam or a
-// group per thread) stays with all eight waves at the block's start, and the patches go through the producer's registers two
-// groups ahead as there.  [Built and measured first: ALL of the prologue on the producer wave and the patches fetched straight
-// into LDS - the producer's instruction stream is the workgroup's critical path (every consumer waits for it at each group's
-// barrier): 130 instructions per group made the kernel 2.6 x slower, 40 still 1.2 x, with three LDS buffers a patch has one
-// group's time to arrive, not three (profiles/r04_lf_pipe_study.txt).]
-// Side work is cut into slices of a few dozen instructions, one per group step, none of which waits for a load it has issued
-// itself (issue in one slice, use in a later one).  Only the first block's loads and the last block's epilogue are exposed.
-// Same plan rule, same look-ups, same order of additions as k_reweight_lf_patch: the weights are its weights bit for bit, and so
-// are the blocks' sums of new weights (tests/test_gpu_parity.py).
-// Workgroup memory: no row-offset table (a gathered look-up computes its row: + 4 instructions on the few per cent of the beams
-// that gather) - its 16 KB at 4000 rows hold the parked poses instead; the palette stays at f.pal_base (the table's entries ARE
-// LDS addresses); three patch buffers (the per-beam records of the plan live there before a block's main loop); one plan.
-// A slot = the 64 particles of consumer wave j: 2048 bytes at park + 2048 j, two halves of 16 bytes per lane:
-//   half 0 (+ 16 lane): {c, s} of the parked pose (as the set holds it); its first 8 bytes take the consumer's sum at the block's end
-//   half 1 (+ 1024 + 16 lane): {x, y}; behind barrier B it is four planes of 4 bytes per lane for the epilogue: the particle's
-//   index (+ 0), its old weight (+ 256, + 512), and the next block's index (+ 768).
-// Barriers of a workgroup, per block: A (the block's poses are in their slots; the producer is done with the slots' previous
-// contents), B (the consumers have taken their poses and parked the previous block's sums), the prologue's five, then one per
-// group (none in a block that gathers everything); A and B once more behind the last block, for its sums.  All eight waves
-// count the same.
-constexpr uint32_t kPipePlanned = 136;  // groups with a plan entry: scans of up to 1095 points
-constexpr uint32_t kPipeParkBytes = (kPalBlock - 64) * 32;
-constexpr int kPipeSlices = 23;
-struct PipeLds {  // absolute LDS byte addresses, 16-aligned
-  uint32_t patch, plan, park, total;
-};
-constexpr uint32_t kPipePlanBytes = kPipePlanned * 32 + 64 * 4;  // producer entries, consumer entries, the prologue's partial results
-// A gathered look-up without the row-offset table: the byte offset of the clamped, biased cell (xc, yc) less kFastBiasX's share
-__device__ __forceinline__ uint32_t pipe_gather_offset(uint32_t xc /* biased */, uint32_t yc /* biased */, uint32_t pitch) {
-  const uint32_t py = yc + (8u - kFastBias);  // the cell's row + 8 (the border tile), 0 .. H + 8
-  return (xc << 4) - kFastBiasX + (py >> 3) * pitch + ((py & 7u) << 1) + 128u;
-}
-
-__global__ __launch_bounds__(kPalBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reweight_lf_pipe(
-    double* __restrict__ w, uint64_t n, FieldView f, const double* __restrict__ pts, uint32_t B, const uint32_t* __restrict__ perm,
-    const double4* __restrict__ pose, PipeLds L, PatchStats stats, uint32_t nblocks) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  {
-    double* s_pal = reinterpret_cast<double*>(smem + f.pal_base);
-    for (uint32_t k = threadIdx.x; k < f.pal_count; k += kPalBlock) s_pal[k] = f.pal_val[k];
-  }
-  constexpr uint32_t kConsumers = kPalBlock / 64 - 1;
-  constexpr uint32_t kParticles = kPalBlock - 64;  // 448: seven waves of particles
-  const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == (kPalBlock / 64 - 1);
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t groups = B / 8;  // 1 .. kPipePlanned (the launcher's precondition)
-  const uint32_t my_blocks = (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x;  // blocks blockIdx.x + k gridDim.x, k < my_blocks (>= 1)
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(f.pal_idx), 0, static_cast<int>(f.pal_bytes), 0x00020000);
-  auto buffer_of = [&](uint32_t g) -> uint32_t { return L.patch + (g - 3u * ((g * 0xAAABu) >> 17)) * kPatchBytes; };  // (g < 2^16) mod 3
-  int4* s_plan = reinterpret_cast<int4*>(smem + L.plan);  // as in k_reweight_lf_patch: {x0A, y0A | flags, x0B, y0B | first beam of half B}
-  int4* s_plan_k = s_plan + kPipePlanned;                 // {KA', meta, KB', -}
-  float* s_bound = reinterpret_cast<float*>(smem + L.plan + kPipePlanned * 32);  // [7][6] partial results, then [7][4], then the counts
-  auto slot = [&](uint32_t j) -> uint32_t { return L.park + 2048u * j; };
-  auto lds_u32 = [&](uint32_t address) -> uint32_t& { return *reinterpret_cast<uint32_t*>(smem + address); };
-  auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-
-  // ---- the producer's side work (declared for every wave: its lambdas are only called by the producer)
-  typedef int rsrc_words_t __attribute__((ext_vector_type(4)));
-  auto words_of = [&](const void* base, uint64_t bytes) -> rsrc_words_t {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(base);
-    const uint32_t size = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(bytes);
-    return rsrc_words_t{__builtin_amdgcn_readfirstlane(static_cast<int>(a & 0xFFFFFFFFull)),
-                        __builtin_amdgcn_readfirstlane(static_cast<int>((a >> 32) & 0xFFFFull)), __builtin_amdgcn_readfirstlane(static_cast<int>(size)), 0x00020000};
-  };
-  auto to_lds_b32 = [&](uint32_t lds, uint32_t offset, const rsrc_words_t& words) __attribute__((always_inline)) {  // lane i's 4 bytes land at lds + 4 i
-    const uint32_t to = __builtin_amdgcn_readfirstlane(lds);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" : : "s"(to), "v"(offset), "s"(words) : "memory");
-  };
-  auto to_lds_b128 = [&](uint32_t lds, uint32_t offset, const rsrc_words_t& words) __attribute__((always_inline)) {  // lane i's 16 bytes land at lds + 16 i
-    const uint32_t to = __builtin_amdgcn_readfirstlane(lds);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(to), "v"(offset), "s"(words) : "memory");
-  };
-  auto position_of = [&](uint32_t blk, uint32_t j) -> uint64_t { return static_cast<uint64_t>(blk) * kParticles + 64u * j + lane; };
-  auto index_offset = [&](uint32_t blk, uint32_t j) -> uint32_t {  // byte offset of the particle's entry of perm (the last one's beyond the set)
-    const uint64_t t = position_of(blk, j);
-    return static_cast<uint32_t>(t < n ? t : n - 1) << 2;
-  };
-  uint32_t ep_blk = 0, st_blk = 0;
-  bool ep_on = false, st_on = false;
-  double ep_total = 0.0;
-  // slices 0 .. 6: epilogue indices, 7 .. 13: old weights, 14 .. 20: the products and their sum, 21: staging indices, 22: staging poses
-  // `paced`: called once per group step of a patched block, behind the step's patch fetch (8 loads): what an earlier slice has
-  // asked for is in LDS when all but the 8 youngest loads have returned (vmcnt counts them in order) - waiting for everything would
-  // drain the producer's fetches two groups ahead, a full memory latency in front of the next barrier (measured: + 20 us per block).
-  auto slice = [&](int s, bool paced) __attribute__((always_inline)) {
-    auto landed = [&]() {
-      if (paced) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    const rsrc_words_t perm_words = words_of(perm, n * 4), w_words = words_of(w, n * 8), pose_words = words_of(pose, n * 32);
-    if (s < 7) {
-      if (ep_on) to_lds_b32(slot(s) + 1024u, index_offset(ep_blk, s), perm_words);
-    } else if (s < 14) {
-      if (ep_on) {
-        const uint32_t j = static_cast<uint32_t>(s - 7);
-        landed();
-        const uint32_t at = lds_u32(slot(j) + 1024u + 4u * lane) << 3;
-        to_lds_b32(slot(j) + 1024u + 256u, at, w_words);
-        to_lds_b32(slot(j) + 1024u + 512u, at + 4u, w_words);
-      }
-    } else if (s < 21) {  // the new weights; their sum in the order of k_reweight_lf_patch (the lanes of a wave in wave_sum_f64's tree, then the waves)
-      if (ep_on) {
-        const uint32_t j = static_cast<uint32_t>(s - 14);
-        landed();
-        const uint64_t t = position_of(ep_blk, j);
-        const double acc = *reinterpret_cast<const double*>(smem + slot(j) + 16u * lane);
-        const uint32_t i = lds_u32(slot(j) + 1024u + 4u * lane);
-        const double old_weight = __hiloint2double(static_cast<int>(lds_u32(slot(j) + 1024u + 512u + 4u * lane)),
-                                                   static_cast<int>(lds_u32(slot(j) + 1024u + 256u + 4u * lane)));
-        double new_weight = 0.0;
-        if (t < n) {
-          new_weight = old_weight * (f.prob ? exp(acc) : acc);
-          w[i] = new_weight;
-        }
-        const double wave_total = wave_sum_f64(new_weight);
-        ep_total = j == 0 ? wave_total : ep_total + wave_total;
-        if (j == 6 && stats.weight_sums && lane == 0) stats.weight_sums[ep_blk] = ep_total;
-      }
-    } else if (s == 21) {  // staging: the particles' indices (the epilogue is done with the slots)
-      if (st_on) {
-#pragma unroll 1
-        for (uint32_t j = 0; j < 7; ++j) to_lds_b32(slot(j) + 1024u + 768u, index_offset(st_blk, j), perm_words);
-      }
-    } else if (s == 22) {  // their pose records (the two halves of a record overwrite the slot, the index plane - read first - included)
-      if (st_on) {
-        landed();
-#pragma unroll 1
-        for (uint32_t j = 0; j < 7; ++j) {
-          const uint32_t at = lds_u32(slot(j) + 1024u + 768u + 4u * lane) << 5;
-          to_lds_b128(slot(j), at, pose_words);
-          to_lds_b128(slot(j) + 1024u, at + 16u, pose_words);
-        }
-      }
-    }
-  };
-
-  if (producer) {  // the first block's poses, while the others wait at barrier A
-    st_on = true;
-    st_blk = blockIdx.x;
-    slice(21, false);
-    slice(22, false);
-    landed();
-  }
-  const uint32_t opaque_zero = f.pal_bytes >> 31;  // (see k_reweight_lf_patch: keeps the palette addresses 32 bits wide)
-  const int c_lo = static_cast<int>(kFastBias) - 1, x_hi = static_cast<int>(kFastBias + f.W), y_hi = static_cast<int>(kFastBias + f.H);
-  double acc = 0.0;
-#ifdef MCL_LF_TIMING
-  const long long lf_t0 = __builtin_readcyclecounter();
-  long long lf_barrier_cycles = 0, lf_block_start = 0, lf_slices = 0, lf_steps = 0;
-#endif
-#pragma unroll 1
-  for (uint32_t k = 0; k < my_blocks; ++k) {
-    const uint32_t blk = blockIdx.x + k * gridDim.x;
-#ifdef MCL_LF_TIMING
-    const long long lf_tb = __builtin_readcyclecounter();
-#endif
-    __syncthreads();  // A: this block's poses are in their slots
-    // the parked pose -> the table's frame (likelihood_field_model.hpp:70: the arithmetic of ordered_pose, as the gather kernel does it)
-    const uint32_t my_slot = L.park + 2048u * (threadIdx.x >> 6) + 16u * lane;
-    Pose2 T = pose_identity();
-    if (!producer) {
-      const double2 q_cs = *reinterpret_cast<const double2*>(smem + my_slot), q_xy = *reinterpret_cast<const double2*>(smem + my_slot + 1024u);
-      if (k > 0) *reinterpret_cast<double*>(smem + my_slot) = acc;  // the previous block's sum, for the producer's epilogue
-      T = pose_mul(f.world_to_field, Pose2{Rot2{q_cs.x, q_cs.y}, q_xy.x, q_xy.y});
-    }
-    __syncthreads();  // B
-    const double ct = T.r.c, st = T.r.s;
-    const double ict = ct * f.inv_resolution, ist = st * f.inv_resolution, ixt = T.x * f.inv_resolution, iyt = T.y * f.inv_resolution;
-    const double ixm = ixt + kPatchMagic, iym = iyt + kPatchMagic;
-    const bool lane_small = fabs(ixt) < 16384.0 && fabs(iyt) < 16384.0;  // false for NaN as well
-
-    // ---- the prologue's arithmetic, all eight waves (k_reweight_lf_patch: reference pose, bound, per-beam records, plan)
-    float* s_part = s_bound;
-    if (!producer) {
-      float lo_x = static_cast<float>(ixt), hi_x = lo_x, lo_y = static_cast<float>(iyt), hi_y = lo_y;
-      float sum_c = static_cast<float>(ct), sum_s = static_cast<float>(st);
-      for (int o = 32; o > 0; o >>= 1) {
-        lo_x = fminf(lo_x, __shfl_xor(lo_x, o));
-        hi_x = fmaxf(hi_x, __shfl_xor(hi_x, o));
-        lo_y = fminf(lo_y, __shfl_xor(lo_y, o));
-        hi_y = fmaxf(hi_y, __shfl_xor(hi_y, o));
-        sum_c += __shfl_xor(sum_c, o);
-        sum_s += __shfl_xor(sum_s, o);
-      }
-      if (lane == 0) {
-        float* mine = s_part + 6 * (threadIdx.x >> 6);
-        mine[0] = lo_x;
-        mine[1] = hi_x;
-        mine[2] = lo_y;
-        mine[3] = hi_y;
-        mine[4] = sum_c;
-        mine[5] = sum_s;
-      }
-    }
-    __syncthreads();
-    double ref_c, ref_s, ref_x, ref_y;
-    {
-      float lo_x = s_part[0], hi_x = s_part[1], lo_y = s_part[2], hi_y = s_part[3], sum_c = s_part[4], sum_s = s_part[5];
-      for (uint32_t q = 1; q < kConsumers; ++q) {
-        lo_x = fminf(lo_x, s_part[6 * q]);
-        hi_x = fmaxf(hi_x, s_part[6 * q + 1]);
-        lo_y = fminf(lo_y, s_part[6 * q + 2]);
-        hi_y = fmaxf(hi_y, s_part[6 * q + 3]);
-        sum_c += s_part[6 * q + 4];
-        sum_s += s_part[6 * q + 5];
-      }
-      const float len = sqrtf(sum_c * sum_c + sum_s * sum_s);
-      ref_c = len > 0.f ? static_cast<double>(sum_c / len) : 1.0;  // a NaN stays one, and switches the patches off below
-      ref_s = len > 0.f ? static_cast<double>(sum_s / len) : 0.0;
-      ref_x = static_cast<double>(0.5f * (lo_x + hi_x));
-      ref_y = static_cast<double>(0.5f * (lo_y + hi_y));
-    }
-    const double rc = ref_c * f.inv_resolution, rs = ref_s * f.inv_resolution;
-    const double rxm = ref_x + kPatchMagic, rym = ref_y + kPatchMagic;
-    __syncthreads();  // the partial results are read; their place takes the next ones
-    if (!producer) {
-      const double dc = ct - ref_c, ds = st - ref_s;
-      float dx = static_cast<float>(fabs(ixt - ref_x)), dy = static_cast<float>(fabs(iyt - ref_y));
-      float da, db;
-      if (stats.isotropic_margin) {
-        da = db = static_cast<float>(sqrt(dc * dc + ds * ds));
-      } else {
-        const double norm2 = ref_c * ref_c + ref_s * ref_s;
-        da = static_cast<float>(fabs((ct * ref_c + st * ref_s) / norm2 - 1.0));
-        db = static_cast<float>(fabs((st * ref_c - ct * ref_s) / norm2));
-      }
-      if (!(lane_small && dx < 1e6f && dy < 1e6f && da < 4.f && db < 4.f)) dx = dy = da = db = INFINITY;  // a far or non-finite particle: no patches
-      for (int o = 32; o > 0; o >>= 1) {
-        dx = fmaxf(dx, __shfl_xor(dx, o));
-        dy = fmaxf(dy, __shfl_xor(dy, o));
-        da = fmaxf(da, __shfl_xor(da, o));
-        db = fmaxf(db, __shfl_xor(db, o));
-      }
-      if (lane == 0) {
-        float* mine = s_bound + 4 * (threadIdx.x >> 6);
-        mine[0] = dx;
-        mine[1] = dy;
-        mine[2] = da;
-        mine[3] = db;
-      }
-    }
-    // the scan through the reference pose, a beam per thread: 16-byte records in the patch buffers (idle before the main loop)
-    int4* s_beam = reinterpret_cast<int4*>(smem + L.patch);
-    {
-      const double2* scan = reinterpret_cast<const double2*>(pts);
-#pragma unroll
-      for (uint32_t pass = 0; pass < (kPipePlanned * 8 + kPalBlock - 1) / kPalBlock; ++pass) {
-        const uint32_t b = pass * kPalBlock + threadIdx.x;
-        if (b < groups * 8) {
-          const double2 p = scan[b];
-          const double sx = __builtin_fma(p.x, rc, __builtin_fma(-p.y, rs, rxm));
-          const double sy = __builtin_fma(p.x, rs, __builtin_fma(p.y, rc, rym));
-          const int cx = static_cast<int>(__builtin_bit_cast(uint64_t, sx) >> 32), cy = static_cast<int>(__builtin_bit_cast(uint64_t, sy) >> 32);
-          const float reach_x = static_cast<float>(fabs(p.x * rc - p.y * rs)), reach_y = static_cast<float>(fabs(p.x * rs + p.y * rc));
-          s_beam[b] = int4{cx, cy, __builtin_bit_cast(int, reach_x), __builtin_bit_cast(int, reach_y)};
-        }
-      }
-    }
-    __syncthreads();
-    bool mine_fits = false;
-    if (threadIdx.x < groups) {  // the plan: thread g looks at group g through the reference pose
-      float Dx = 0.f, Dy = 0.f, Da = 0.f, Db = 0.f;
-      for (uint32_t q = 0; q < kConsumers; ++q) {
-        Dx = fmaxf(Dx, s_bound[4 * q]);
-        Dy = fmaxf(Dy, s_bound[4 * q + 1]);
-        Da = fmaxf(Da, s_bound[4 * q + 2]);
-        Db = fmaxf(Db, s_bound[4 * q + 3]);
-      }
-      // every float operation below may round down: scaled up by 1 + 2^-10 where it matters, and two cells of slack
-      Dx = Dx * 1.001f + 2.f;
-      Dy = Dy * 1.001f + 2.f;
-      int4 rec[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) rec[q] = s_beam[8 * threadIdx.x + q];
-      struct Range {
-        int lo_x, hi_x, lo_y, hi_y;
-        float reach_x, reach_y;
-      };
-      auto fits_patch = [&](const Range& r, int PW, int PH, int& x0, int& y0) -> bool {
-        float turn_x, turn_y;  // cells
-        if (stats.isotropic_margin) {  // |q'| <= sqrt(max q'x^2 + max q'y^2)
-          turn_x = turn_y = sqrtf(r.reach_x * r.reach_x + r.reach_y * r.reach_y) * 1.002f * (Da * 1.001f);
-        } else {
-          const float A = Da * 1.001f, Bv = Db * 1.001f, qx = r.reach_x * 1.001f, qy = r.reach_y * 1.001f;
-          turn_x = (A * qx + Bv * qy) * 1.001f;
-          turn_y = (Bv * qx + A * qy) * 1.001f;
-        }
-        const float mx = ceilf(Dx + turn_x), my = ceilf(Dy + turn_y);
-        const bool fits = mx < 64.f && my < 64.f;  // false for NaN and infinity
-        const int margin_x = fits ? static_cast<int>(mx) : 0, margin_y = fits ? static_cast<int>(my) : 0;
-        x0 = r.lo_x - margin_x;
-        y0 = (r.lo_y - margin_y) & ~7;
-        return fits && r.hi_x + margin_x - x0 < PW && r.hi_y + margin_y - y0 < PH;
-      };
-      Range all{INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        all.lo_x = min(all.lo_x, rec[q].x);
-        all.hi_x = max(all.hi_x, rec[q].x);
-        all.lo_y = min(all.lo_y, rec[q].y);
-        all.hi_y = max(all.hi_y, rec[q].y);
-        all.reach_x = fmaxf(all.reach_x, __builtin_bit_cast(float, rec[q].z));
-        all.reach_y = fmaxf(all.reach_y, __builtin_bit_cast(float, rec[q].w));
-      }
-      int x0a = 0, y0a = 0, x0b = 0, y0b = 0;
-      uint32_t flags = 0u, first_b = 0u;
-      if (fits_patch(all, kPatchW, kPatchH, x0a, y0a)) {
-        flags = 1u;
-      } else if (stats.split_patches) {
-        // split where the scan jumps: between the two consecutive beams whose end-points lie farthest apart (the first such pair)
-        int widest_jump = -1, k_split = 4;
-#pragma unroll
-        for (int q = 1; q < 8; ++q) {
-          const int jump = max(abs(rec[q].x - rec[q - 1].x), abs(rec[q].y - rec[q - 1].y));
-          if (jump > widest_jump) {
-            widest_jump = jump;
-            k_split = q;
-          }
-        }
-        Range ra{INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0.f, 0.f}, rb = ra;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {  // (k_split is a run-time value: both halves in one pass)
-          Range& r = q < k_split ? ra : rb;
-          r.lo_x = min(r.lo_x, rec[q].x);
-          r.hi_x = max(r.hi_x, rec[q].x);
-          r.lo_y = min(r.lo_y, rec[q].y);
-          r.hi_y = max(r.hi_y, rec[q].y);
-          r.reach_x = fmaxf(r.reach_x, __builtin_bit_cast(float, rec[q].z));
-          r.reach_y = fmaxf(r.reach_y, __builtin_bit_cast(float, rec[q].w));
-        }
-        int xa, ya, xb, yb;
-        if ((stats.split_patches & 1u) && fits_patch(ra, kPatchW / 2, kPatchH, xa, ya) && fits_patch(rb, kPatchW / 2, kPatchH, xb, yb)) flags = 1u | 2u;
-        else if ((stats.split_patches & 2u) && fits_patch(ra, kPatchW, kPatchH / 2, xa, ya) && fits_patch(rb, kPatchW, kPatchH / 2, xb, yb)) flags = 1u | 4u;
-        if (flags) {
-          x0a = xa;
-          y0a = ya;
-          x0b = xb;
-          y0b = yb;
-          first_b = static_cast<uint32_t>(k_split);
-        }
-      }
-      s_plan[threadIdx.x] = int4{x0a, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
-      {
-        const uint32_t ka = 0u - (static_cast<uint32_t>(x0a) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0a) << 1);
-        // half B lives in columns 32 .. 63 (side by side) or in rows 32 .. 63 (stacked) of the same buffer
-        const uint32_t kb = ((flags & 2u) ? (kPatchW / 2) * kPatchPitch : static_cast<uint32_t>(kPatchH)) -
-                            (static_cast<uint32_t>(x0b) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0b) << 1);
-        const uint32_t meta = flags == 0u ? 0u : ((flags & 6u) ? first_b : 8u);
-        s_plan_k[threadIdx.x] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), 0};
-      }
-      mine_fits = flags != 0u;
-    }
-    // a block with too few of its groups through a patch drops the machinery (see k_reweight_lf_patch)
-    uint32_t* s_count = reinterpret_cast<uint32_t*>(s_bound) + 4 * kConsumers;  // behind the bound's [7][4]
-    {
-      const uint32_t in_wave = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine_fits)));
-      if (lane == 0) s_count[threadIdx.x >> 6] = in_wave;
-    }
-    __syncthreads();
-    uint32_t fitting = 0;
-    for (uint32_t q = 0; q < kPalBlock / 64; ++q) fitting += s_count[q];
-    const bool loose = __builtin_amdgcn_readfirstlane(fitting) * 256u < groups * stats.loose_below;
-#ifdef MCL_LF_TIMING
-    lf_block_start += __builtin_readcyclecounter() - lf_tb;
-#endif
-
-    if (producer) {
-      // ============================================================== the producer's main loop ==========================
-      // the launch's statistics (what the host picks the next launch's kernel by), from a sample of the blocks
-      {
-        const uint32_t stride = nblocks >= 256 ? 16u : 1u;
-        if (stats.device && lane == 0 && blk % stride == 0) {
-          atomicAdd(stats.device + 0, static_cast<unsigned long long>(groups));
-          atomicAdd(stats.device + 1, static_cast<unsigned long long>(loose ? 0u : fitting));
-        }
-      }
-      ep_on = k > 0;
-      ep_blk = blk - gridDim.x;
-      st_on = k + 1 < my_blocks;
-      st_blk = blk + gridDim.x;
-      int next = 0;
-#if (MCL_PIPE_ABLATE & 16)
-      __builtin_amdgcn_s_setprio(3);
-#endif
-      if (!loose) {
-        const int y_last = static_cast<int>((f.H + 7u) & ~7u);  // first row of the bottom border tiles
-        using Pieces = uint4[kPatchH / 8];
-        const uint32_t last_planned = groups - 1u;
-        auto fetch = [&](uint32_t g, Pieces& piece) {  // (k_reweight_lf_patch)
-          const int4 e = s_plan[g < last_planned ? g : last_planned];
-          const int ya = __builtin_amdgcn_readfirstlane(e.y);
-          const int x0a = __builtin_amdgcn_readfirstlane(e.x), y0a = ya & ~7;
-          if ((ya & 6) == 0) {  // one whole patch (or none: then nobody reads it): this lane's column, scalar row offsets
-            const int xu = x0a + static_cast<int>(lane) - static_cast<int>(kFastBias);
-            const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W)) + 8) << 4;
-#pragma unroll
-            for (int r = 0; r < kPatchH / 8; ++r) {
-              const int yu = y0a + 8 * r - static_cast<int>(kFastBias);
-              const int yc = min(max(yu, -8), y_last);  // scalar
-              piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, column, palette_row_offset(yc, f.pal_pitch) - 128u, 0));
-            }
-            return;
-          }
-          const int yb = __builtin_amdgcn_readfirstlane(e.w), x0b = __builtin_amdgcn_readfirstlane(e.z), y0b = yb & ~7;
-          const bool side_by_side = (ya & 2) != 0, stacked = (ya & 4) != 0;  // scalar
-          const bool half_b = side_by_side && lane >= static_cast<uint32_t>(kPatchW / 2);
-          const int xu = (half_b ? x0b + static_cast<int>(lane) - kPatchW / 2 : x0a + static_cast<int>(lane)) - static_cast<int>(kFastBias);
-          const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W)) + 8) << 4;
-          const int xu_low = (stacked ? x0b : x0a) + static_cast<int>(lane) - static_cast<int>(kFastBias);
-          const uint32_t column_low = stacked ? static_cast<uint32_t>(min(max(xu_low, -1), static_cast<int>(f.W)) + 8) << 4 : column;
-#pragma unroll
-          for (int r = 0; r < kPatchH / 8; ++r) {
-            const bool low = r >= kPatchH / 16;
-            const int yu_a = ((stacked && low) ? y0b + 8 * (r - kPatchH / 16) : y0a + 8 * r) - static_cast<int>(kFastBias);
-            const int yu_b = y0b + 8 * r - static_cast<int>(kFastBias);
-            const uint32_t row_a = palette_row_offset(min(max(yu_a, -8), y_last), f.pal_pitch) - 128u;  // scalar
-            const uint32_t row_b = palette_row_offset(min(max(yu_b, -8), y_last), f.pal_pitch) - 128u;  // scalar
-            piece[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (low ? column_low : column) + (half_b ? row_b : row_a), 0, 0));
-          }
-        };
-        auto store = [&](uint32_t g, const Pieces& piece) {
-          unsigned char* dst = smem + buffer_of(g) + lane * kPatchPitch;
-#pragma unroll
-          for (int r = 0; r < kPatchH / 8; ++r) *reinterpret_cast<uint4*>(dst + r * 16) = piece[r];
-        };
-        Pieces even, odd;
-        fetch(0, even);
-        store(0, even);
-        fetch(1, odd);
-        fetch(2, even);
-        uint32_t g = 0;
-        for (; g + 1 < groups; g += 2) {
-          MCL_LF_BARRIER(__syncthreads());  // the consumers are done with group g - 1: its buffer takes the patch of g + 1
-          store(g + 1, odd);
-          fetch(g + 3, odd);
-#ifdef MCL_LF_TIMING
-          const long long lf_ts0 = __builtin_readcyclecounter();
-#endif
-#if !(MCL_PIPE_ABLATE & 4)
-          if (next < kPipeSlices) slice(next, true);
-          ++next;
-#endif
-#ifdef MCL_LF_TIMING
-          lf_slices += __builtin_readcyclecounter() - lf_ts0;
-          lf_steps += 2;
-#endif
-          MCL_LF_BARRIER(__syncthreads());
-          store(g + 2, even);
-          fetch(g + 4, even);
-#ifdef MCL_LF_TIMING
-          const long long lf_ts1 = __builtin_readcyclecounter();
-#endif
-#if !(MCL_PIPE_ABLATE & 4)
-          if (next < kPipeSlices) slice(next, true);
-          ++next;
-#endif
-#ifdef MCL_LF_TIMING
-          lf_slices += __builtin_readcyclecounter() - lf_ts1;
-#endif
-        }
-        if (g < groups) __syncthreads();
-      }
-#pragma unroll 1
-      for (; next < kPipeSlices; ++next) slice(next, false);  // whatever the block's steps have left (a short scan; a block that gathers everything)
-      landed();
-      continue;
-    }
-
-    // ================================================================ the consumers' main loop ============================
-    acc = f.prob ? 0.0 : 1.0;
-    const bool fast = __builtin_amdgcn_ballot_w64(!lane_small) == 0;  // per wave: a far particle sends its wave through the exact code
-    struct Plan {  // scalars
-      uint32_t ka;    // less the buffer's base
-      uint32_t meta;  // 0: gathered, 8: one whole patch, 1 .. 7: two halves, the second one from this beam on
-    };
-    struct Lookups {
-      uint32_t e[8];  // palette addresses (LDS byte addresses of the f64 terms)
-      uint32_t redo;  // 1: the group is added by add_exact instead
-    };
-    auto exact_fetch = [&](int xi, int yi) -> uint32_t {  // lf_palette_fetch without the row-offset table
-      const uint32_t xc = static_cast<uint32_t>(clamp_cell(xi, f.W)) + kFastBias, yc = static_cast<uint32_t>(clamp_cell(yi, f.H)) + kFastBias;
-      return static_cast<uint32_t>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, pipe_gather_offset(xc, yc, f.pal_pitch), 0, 0)));
-    };
-    // The separately rounded evaluation, beam by beam with plain gathers (4 in 2^32 end-points; the tail of the scan).  It needs
-    // the pose as the reference holds it (not pre-multiplied by 1 / res): fetched again here, from global memory, rather than kept.
-    auto add_exact = [&](uint32_t b0, uint32_t count) {
-      if (count == 0) return;
-      const uint64_t position = static_cast<uint64_t>(blk) * kParticles + threadIdx.x;
-      const Pose2 T_again = ordered_pose(f.world_to_field, pose, perm[position < n ? position : n - 1]);
-      const double ct = T_again.r.c, st = T_again.r.s, xt = T_again.x, yt = T_again.y;
-      auto term = [&](uint32_t at) {
-        const double px = pts[2 * at], py = pts[2 * at + 1];
-        double vx = (px * ct - py * st + xt) * f.inv_resolution, vy = (px * st + py * ct + yt) * f.inv_resolution;
-        floor_rd_2(vx, vy);
-        return lf_palette_value(exact_fetch(floor_rd_result(vx), floor_rd_result(vy)));
-      };
-      uint32_t b = b0;
-      const uint32_t end = b0 + count;
-#pragma unroll 1
-      for (; b + 4 <= end; b += 4) {  // (groups start at multiples of 8: the blocks of four are the scan's)
-        const double t0 = term(b), t1 = term(b + 1), t2 = term(b + 2), t3 = term(b + 3);
-        acc += sum4(t0, t1, t2, t3);
-      }
-#pragma unroll 1
-      for (; b < end; ++b) acc += term(b);
-    };
-    auto consume = [&](const Lookups& e, uint32_t b0) {
-      if (__builtin_amdgcn_readfirstlane(e.redo)) {
-        add_exact(b0, 8);
-        return;
-      }
-      {
-        const double t0 = lf_palette_value(e.e[0]), t1 = lf_palette_value(e.e[1]), t2 = lf_palette_value(e.e[2]), t3 = lf_palette_value(e.e[3]);
-        acc += sum4(t0, t1, t2, t3);
-      }
-      {
-        const double t4 = lf_palette_value(e.e[4]), t5 = lf_palette_value(e.e[5]), t6 = lf_palette_value(e.e[6]), t7 = lf_palette_value(e.e[7]);
-        acc += sum4(t4, t5, t6, t7);
-      }
-    };
-    // One step: the end-points of group g, then the sum of the group before it, then the look-ups of group g (k_reweight_lf_patch).
-    auto step = [&](auto is_loose, auto add_before, uint32_t g_any, Lookups& now, const Lookups& before) {
-      const uint32_t g = __builtin_amdgcn_readfirstlane(g_any);
-      const uint32_t b0 = 8 * g;
-      Plan plan{0u, 0u};
-      if constexpr (!decltype(is_loose)::value) {
-        const int2 e = *reinterpret_cast<const int2*>(s_plan_k + g);
-        plan.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.x));
-        plan.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
-      }
-      const uint32_t buffer = buffer_of(g);
-      if constexpr (!decltype(is_loose)::value) {  // a bare barrier, see k_reweight_lf_patch: the producer's side keeps the fence
-        asm volatile("" ::: "memory");
-        MCL_LF_BARRIER(__builtin_amdgcn_s_barrier());
-        asm volatile("" ::: "memory");
-      }
-      now.redo = 1u;
-      if (!fast) {
-        if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
-        return;
-      }
-      const double* q = pts + 2 * b0;
-      int cx[8], cy[8];
-      uint32_t lowest = 0xFFFFFFFFu;
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const double px = q[2 * kk], py = q[2 * kk + 1];
-        const double sx = __builtin_fma(px, ict, __builtin_fma(-py, ist, ixm));
-        const double sy = __builtin_fma(px, ist, __builtin_fma(py, ict, iym));
-        const uint64_t bx = __builtin_bit_cast(uint64_t, sx), by = __builtin_bit_cast(uint64_t, sy);
-        lowest = min3_u32(lowest, static_cast<uint32_t>(bx), static_cast<uint32_t>(by));
-        cx[kk] = static_cast<int>(bx >> 32);
-        cy[kk] = static_cast<int>(by >> 32);
-      }
-      if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
-      if (plan.meta == 8u) {  // one whole patch (19 groups in 20): one constant for the eight look-ups
-        const uint32_t K = buffer + plan.ka;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const uint32_t at = mad_u24(static_cast<uint32_t>(cx[kk]), kPatchPitch, lshl_add_u32_uniform(static_cast<uint32_t>(cy[kk]), 1, K));
-          now.e[kk] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(static_cast<uintptr_t>(at)));
-        }
-      } else if (plan.meta != 0u) {  // two halves: the beams from plan.meta on read the second one
-        const uint32_t KA = buffer + plan.ka, KB = buffer + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_plan_k[g].z));
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const uint32_t K = static_cast<uint32_t>(kk) < plan.meta ? KA : KB;  // scalar
-          now.e[kk] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(
-              static_cast<uintptr_t>(mad_u24(static_cast<uint32_t>(cx[kk]), kPatchPitch, lshl_add_u32_uniform(static_cast<uint32_t>(cy[kk]), 1, K)))));
-        }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const uint32_t xc = static_cast<uint32_t>(med3_i32(cx[kk], c_lo, x_hi)), yc = static_cast<uint32_t>(med3_i32(cy[kk], c_lo, y_hi));
-          now.e[kk] = static_cast<uint32_t>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, pipe_gather_offset(xc, yc, f.pal_pitch), 0, 0))) | opaque_zero;
-        }
-      }
-      now.redo = __builtin_amdgcn_ballot_w64(lowest < 4u) != 0 ? 1u : 0u;
-    };
-    auto run = [&](auto is_loose) {
-      Lookups a, c;
-      uint32_t g;
-      if (groups & 1) {
-        step(is_loose, std::false_type{}, 0, a, a);
-        g = 1;
-      } else {
-        step(is_loose, std::false_type{}, 0, c, c);
-        step(is_loose, std::true_type{}, 1, a, c);
-        g = 2;
-      }
-      for (; g < groups; g += 2) {  // `a` holds group g - 1
-        step(is_loose, std::true_type{}, g, c, a);
-        step(is_loose, std::true_type{}, g + 1, a, c);
-      }
-      consume(a, 8 * groups - 8);
-    };
-    if (loose) run(std::true_type{});
-    else run(std::false_type{});
-    add_exact(8 * groups, B - 8 * groups);
-  }
-#ifdef MCL_LF_TIMING
-  if (lane == 0) {
-    const int o = producer ? 3 : 0;
-    atomicAdd(&g_lf_timing[o], 1ull);
-    atomicAdd(&g_lf_timing[o + 1], static_cast<unsigned long long>(__builtin_readcyclecounter() - lf_t0));
-    atomicAdd(&g_lf_timing[o + 2], static_cast<unsigned long long>(lf_barrier_cycles));
-    if (producer) {
-      atomicAdd(&g_lf_timing[9], static_cast<unsigned long long>(lf_slices));
-      atomicAdd(&g_lf_timing[10], static_cast<unsigned long long>(lf_steps));
-      atomicAdd(&g_lf_timing[11], static_cast<unsigned long long>(lf_block_start));
-    } else {
-      atomicAdd(&g_lf_timing[6], static_cast<unsigned long long>(lf_block_start));
-    }
-  }
-#endif
-  // ---- behind the last block: its epilogue by the consumers themselves, all lanes at once (k_reweight_lf_patch's; on the producer
-  // alone it is seven dependent rounds of loads with nothing to hide them behind)
-  {
-    const uint32_t blk = blockIdx.x + (my_blocks - 1) * gridDim.x;
-    double new_weight = 0.0;
-    if (!producer) {
-      const uint64_t t = static_cast<uint64_t>(blk) * kParticles + threadIdx.x;
-      if (t < n) {
-        const uint32_t i = perm[t];
-        new_weight = w[i] * (f.prob ? exp(acc) : acc);
-        w[i] = new_weight;
-      }
-    }
-    __syncthreads();  // (the plan's memory is free: every wave is out of the main loop)
-    if (stats.weight_sums) {
-      double* s_sum = reinterpret_cast<double*>(smem + L.plan);
-      const double wave_total = wave_sum_f64(new_weight);
-      if (!producer && lane == 0) s_sum[threadIdx.x >> 6] = wave_total;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        double total = s_sum[0];
-        for (uint32_t q = 1; q < kConsumers; ++q) total += s_sum[q];
-        stats.weight_sums[blk] = total;
-      }
-    }
-  }
-  if (!producer) return;
-  // The last workgroup to get here copies the running totals of the launch's statistics to the host's mirror.
-  if (stats.device && lane == 0) {
-    __threadfence();
-    // the last workgroup of THIS launch to arrive (a counter that wraps at the grid's size: no state carried between launches)
-    if (atomicInc(stats.arrivals, gridDim.x - 1u) == gridDim.x - 1u && stats.mirror) {
-      const unsigned long long planned = atomicAdd(stats.device + 0, 0ull), through = atomicAdd(stats.device + 1, 0ull);
-      stats.mirror[0] = planned;
-      stats.mirror[1] = through;
-      stats.mirror[2] = (planned & 0xFFFFFFFFull) | (through << 32);  // the pair as ONE word: never torn
-    }
-  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_lf_combine(double* __restrict__ w, uint64_t n, const uint32_t* __restrict__ perm,
@@ -3145,21 +2203,6 @@ __device__ __forceinline__ int block_distance(const uint32_t* coarse_rows, int r
   return best;
 }
 
-// Measurement build (-DMCL_BEAM_STATS, tools/gpu_beam_stats.sh): how often a wave / a lane passes the stages of the walk.
-// g_beam_stats[2 i] counts waves, [2 i + 1] lanes.  Compiled out of the product.
-#ifdef MCL_BEAM_STATS
-__device__ unsigned long long g_beam_stats[32];
-__device__ __forceinline__ void beam_stat(int i) {
-  const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
-  if ((threadIdx.x & 63) == static_cast<unsigned>(__builtin_ctzll(m))) {
-    atomicAdd(&g_beam_stats[2 * i], 1ull);
-    atomicAdd(&g_beam_stats[2 * i + 1], static_cast<unsigned long long>(__builtin_popcountll(m)));
-  }
-}
-#define MCL_BEAM_STAT(i) beam_stat(i)
-#else
-#define MCL_BEAM_STAT(i)
-#endif
 template <bool kAdvance, bool kClamp = true>
 __device__ __forceinline__ int examine_cells(const BlockMaps& maps, int& lx, int& ly, int& error, int count, int dminor, int dmajor,
                                              bool steep, int major_step, int minor_step) {
@@ -3264,7 +2307,6 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   const bool steep = STEEP == kRuntimeStep ? r_steep : (STEEP != 0);
   const int major_step = MAJ == kRuntimeStep ? r_major_step : MAJ, minor_step = MIN == kRuntimeStep ? r_minor_step : MIN;
   if (k > upto) return;
-  MCL_BEAM_STAT(STEEP == kRuntimeStep ? 2 : 1);  // a walk (1: major axis shared by the wave, 2: not)
   // Up to 8 cells that stay inside one block column: with nothing in that block or around it (block distance >= 2) they are
   // free, and the state behind them has a closed form - error + j dminor brought back into (0, dmajor], one trip per dmajor
   // taken off (a float quotient and a +-1 correction: the operands are far below 2^24).
@@ -3278,7 +2320,6 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   };
 #define advance_free(j) walk_advance_free((j), dminor, dmajor, inv_dmajor, steep, major_step, minor_step, lx, ly, error)
   if (k_start > 0 && closed_forms) {
-    MCL_BEAM_STAT(10);  // a certified start
     const int j = min(k_start, upto - k + 1);
     advance_free(j);
     k += j;
@@ -3292,7 +2333,6 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
     if (clear_ahead(lx, ly)) {
       advance_free(j);
     } else {
-      MCL_BEAM_STAT(14);  // head cells examined
       const int first = examine_cells<true>(maps, lx, ly, error, j, dminor, dmajor, steep, major_step, minor_step);
       if (first >= 0) {
         hit_k = k + first;
@@ -3316,9 +2356,6 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   const uint32_t* bitmap = steep ? maps.rows : maps.columns;
   const int bitmap_words = steep ? maps.row_words : maps.column_words;
   int major = steep ? ly : lx, minor = steep ? lx : ly;
-#ifdef MCL_BEAM_STATS
-  bool stat_after_skip = k_start > 0;
-#endif
   while (k + 8 <= upto) {  // cells k .. k+7 and the cell behind them are inside
     {
       // Empty space in closed form: d = block distance from the block of cell k to the nearest block holding anything.  The next
@@ -3330,12 +2367,6 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
       if (d >= 2u && closed_forms) {
         const uint32_t room = static_cast<uint32_t>(upto - k) >> 3;  // >= 1
         const int s_columns = static_cast<int>(min(d - 1u, room));
-        MCL_BEAM_STAT(9);  // a skip
-#ifdef MCL_BEAM_STATS
-        if (stat_after_skip) beam_stat(11);  // ... straight behind another skip (or the certified start)
-        if (s_columns >= 15) beam_stat(12);  // ... of the longest kind (the distance map's cap)
-        stat_after_skip = true;
-#endif
         const int cells = 8 * s_columns;
         const int total = error + cells * dminor;  // <= 129 dmajor, far below 2^24
         int trips = static_cast<int>(static_cast<float>(total - 1) * inv_dmajor);
@@ -3357,12 +2388,7 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
     const uint32_t* row = bitmap + (major >> 3) * bitmap_words;
     const int b0 = minor >> 3, b1 = minor_next >> 3;
     const uint32_t occupied = ((row[b0 >> 5] >> (b0 & 31)) | (row[b1 >> 5] >> (b1 & 31))) & 1u;
-    MCL_BEAM_STAT(3);  // a whole block column
-#ifdef MCL_BEAM_STATS
-    stat_after_skip = false;
-#endif
     if (occupied) {
-      MCL_BEAM_STAT(4);  // ... examined cell by cell
       int first;
       if (STEEP == kRuntimeStep) {
         int fx = steep ? minor : major, fy = steep ? major : minor, fe = error;
@@ -3371,7 +2397,6 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
         first = examine_column<(STEEP != 0 && STEEP != kRuntimeStep)>(maps, major, minor, error, dminor, dmajor, major_step, minor_step);
       }
       if (first >= 0) {
-        MCL_BEAM_STAT(5);  // ... with a hit
         hit_k = k + first;
         return;
       }
@@ -3385,12 +2410,10 @@ __device__ __forceinline__ void walk_blocks(const BlockMaps& maps, int& lx, int&
   ly = steep ? major : minor;
   // 3. the last cells (fewer than a block column)
   while (k <= upto) {
-    MCL_BEAM_STAT(6);  // tail cells
     const int j = min(8, upto - k + 1);
     if (clear_ahead(lx, ly)) {
       advance_free(j);
     } else {
-      MCL_BEAM_STAT(15);  // ... examined
       const int first = examine_cells<true>(maps, lx, ly, error, j, dminor, dmajor, steep, major_step, minor_step);
       if (first >= 0) {
         hit_k = k + first;
@@ -3434,7 +2457,6 @@ __device__ __forceinline__ auto cast_ray_window(const GridView& g, const BitWind
     const uint32_t* rows = w.lds + kWin * kWinStride;
     const BlockMaps lds_maps{w.lds, kWinStride, kWin - 1, kWin - 1, rows, rows + kCoarse * kCoarseWords, kCoarseWords, kCoarseWords,
                              reinterpret_cast<const uint8_t*>(rows + 2 * kCoarse * kCoarseWords), kCoarse};
-    MCL_BEAM_STAT(7);  // a walk inside the LDS window
     // cell k of the trace lies k * |line| / major_span from the source (within a cell): the cells below free_ahead, less two for the roundings
     int k_start = 0;
     if (free_ahead > 0.f) {
@@ -3442,10 +2464,6 @@ __device__ __forceinline__ auto cast_ray_window(const GridView& g, const BitWind
       const float length = sqrtf(dxs * dxs + dys * dys);
       k_start = length > 0.f ? static_cast<int>(free_ahead * static_cast<float>(r.major_span) * __builtin_amdgcn_rcpf(length) * 0.999f) - 2 : 0;
     }
-#ifdef MCL_BEAM_ABLATE  // timing only (2: no walk - a hit half way to the window's edge): what everything but the walk costs
-    if (MCL_BEAM_ABLATE & 2) hit_k = upto >> 1;
-    else
-#endif
     walk_blocks_any(lds_maps, r, lx, ly, error, k, hit_k, upto, k_start);
     if (hit_k >= 0) {
       walk_seek(r, hit_k, 0);
@@ -3454,11 +2472,7 @@ __device__ __forceinline__ auto cast_ray_window(const GridView& g, const BitWind
   }
   // Cells beyond the window (long rays near its edge): the same walk over the whole-grid maps in global memory.
   r.last = walk_room_in_grid(g, r);
-#ifdef MCL_BEAM_ABLATE  // timing only (1: rays that leave the window end there): what the walks over the whole-grid maps cost
-  if (MCL_BEAM_ABLATE & 1) r.last = -1;
-#endif
   if (k <= r.last) {
-    MCL_BEAM_STAT(8);  // a walk over the whole-grid maps (the ray left the window)
     walk_seek(r, k, error);
     int gx = r.x, gy = r.y;
     walk_blocks_any(w.grid_maps, r, gx, gy, error, k, hit_k, r.last);
@@ -3818,7 +2832,6 @@ __global__ __launch_bounds__(kBeamBlock) void k_reweight_beam_sorted(double* __r
         if (!(entry & 0x8000u)) continue;
         free_ahead = static_cast<float>(entry & 0x7FFFu);
       }
-      MCL_BEAM_STAT(0);  // a beam
       acc += beam_term<kTable>(g, m, norm_hit, src, pts[b], table, sx, sy, [&](int fx, int fy) {
         return cast_ray_window<kTable>(g, bw, sx, sy, fx, fy, m.beam_max_range, steps, free_ahead);
       });
@@ -4329,13 +3342,10 @@ __device__ __forceinline__ bool intersperse_here(const RngWords& r, uint64_t j, 
 // way out — est_partials[k][workgroup] — so that the estimate needs no pass of its own over the particles it just wrote.
 // Workgroups of 1024 outputs share an LDS copy of the upper levels of the search tree (staged doubles from level
 // first_staged on; dynamic shared memory).
-#ifndef MCL_DRAW_WAVES
-#define MCL_DRAW_WAVES 8
-#endif
 constexpr int kDrawBlock = 1024;
 constexpr uint32_t kDrawStageMax = 4608;  // doubles (36 KB): two workgroups per CU (which also takes 8 waves per SIMD: 64 registers)
 template <bool kEstimate>
-__global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(MCL_DRAW_WAVES, MCL_DRAW_WAVES))) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
+__global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
                                                               Particles dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
                                                               unsigned long long* __restrict__ hashes, double pivot_x, double pivot_y,
                                                               double* __restrict__ est_partials, uint32_t est_stride, int first_staged,
@@ -4343,9 +3353,6 @@ __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(MCL_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* staged = reinterpret_cast<double*>(smem);
   __shared__ double scratch[kEstimate ? (kDrawBlock / 64) * 9 : 1];
-#ifdef MCL_DRAW_ABLATE
-  if (!(MCL_DRAW_ABLATE & 8))
-#endif
   if (first_staged < cdf.depth) {
     const double* from = cdf.levels + cdf.offset[first_staged];
     for (uint32_t k = threadIdx.x; k < staged_doubles; k += kDrawBlock) staged[k] = from[k];
@@ -4356,19 +3363,10 @@ __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(MCL_
   // The search reads global memory a wave at a time: every lane goes through it, the ones with nothing to draw (beyond
   // the count, or taking an injected random state) with a target of zero.
   const uint64_t j = a.first_candidate + t;
-#ifdef MCL_DRAW_ABLATE
-  const RngWords r = (MCL_DRAW_ABLATE & 4) ? RngWords{{static_cast<uint32_t>(j * 2654435761u), static_cast<uint32_t>(j), 1u << 31, 0u}} : rng_draw(a.seed, a.step, kRngResample, j);
-#else
   const RngWords r = rng_draw(a.seed, a.step, kRngResample, j);
-#endif
   const double p_random = a.d_random_state_probability ? *a.d_random_state_probability : a.random_state_probability;
   const bool intersperse = t < a.count && intersperse_here(r, j, p_random, fc.count);
   uint64_t idx = 0;
-#ifdef MCL_DRAW_ABLATE  // timing only (tools/build_variant.sh): 1 = no search, 2 = no estimate sums, 4 = no generator
-  if (MCL_DRAW_ABLATE & 1) {
-    idx = (static_cast<uint64_t>(r.w[0]) * a.n_in) >> 32;
-  } else
-#endif
   if (a.n_in >= 2) {
     const double target = (t < a.count && !intersperse) ? rng_uniform53(r.w[0], r.w[1]) * (*d_total) : 0.0;
     idx = cdf_tree_lower_bound_staged(cdf, staged, first_staged, target);
@@ -4397,11 +3395,6 @@ __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(MCL_
       v[8] = dy * dy;
     }
   }
-#ifdef MCL_DRAW_ABLATE
-  if (kEstimate && (MCL_DRAW_ABLATE & 2)) {
-    if (threadIdx.x == 0) for (int k = 0; k < 9; ++k) est_partials[static_cast<size_t>(k) * est_stride + blockIdx.x] = v[k];
-  } else
-#endif
   if (kEstimate) {
     block_reduce<9, kDrawBlock>(v, scratch);
     if (threadIdx.x == 0) {
@@ -5131,12 +4124,11 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
 
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
-                        bool dispersed, bool* far_tiles_used, uint32_t* weight_sums_written, bool* pipe_used, bool* queue_used) {
+                        bool dispersed, bool* far_tiles_used, uint32_t* weight_sums_written, bool* queue_used) {
   if (weight_sums_written) *weight_sums_written = 0;
   if (far_tiles_used) *far_tiles_used = false;
-  if (pipe_used) *pipe_used = false;
+  if (queue_used) *queue_used = false;
   if (n == 0) return;
-  const bool idx32 = static_cast<uint64_t>(f.W) * f.H < (1ull << 31);
   if (variant == kLfSortedLanes && sort && n < (1ull << 32)) {
     const uint64_t cells = static_cast<uint64_t>(f.W) * f.H;
     const bool cube_ok = f.cube != nullptr && f.W < (1u << 21) && (cells + 1) * 8 < (1ull << 31);
@@ -5159,62 +4151,26 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
       // fallback handles everything else inside the kernel); tuning.lf_fast = 0 forces the separately rounded arithmetic.
       const bool fast = tuning.lf_fast != 0 && scan_is_short && f.W < 16384 && f.H < 16384;
       const uint32_t patch_base = (static_cast<uint32_t>(pal_lds) + 15u) & ~15u;
-      const size_t patch_lds = patch_base + patch_lds_bytes(tuning.lf_producer == 0);
-      // The persistent, pipelined form of the patch kernel (k_reweight_lf_pipe) where it applies: a producer wave, the whole scan
-      // in one segment of 1 .. kPipePlanned groups, and workgroup memory for three workgroups per CU (its tables take the place
-      // of the row-offset table below the palette, as far as they fit there).
-      PipeLds pipe{};
-      bool pipe_ok = false;
-      if (fast && use_patches && tuning.lf_pipe != 0 && tuning.lf_producer != 0 && segments == 1 && B >= 8 && B / 8 <= kPipePlanned) {
-        uint32_t low = 0, high = (static_cast<uint32_t>(pal_lds) + 15u) & ~15u;  // free below the palette: [low, pal_base); above it: from high on
-        auto place = [&](uint32_t bytes) {
-          const uint32_t need = (bytes + 15u) & ~15u;
-          if (low + need <= f.pal_base) {
-            const uint32_t at = low;
-            low += need;
-            return at;
-          }
-          const uint32_t at = high;
-          high += need;
-          return at;
-        };
-        pipe.park = place(kPipeParkBytes);
-        pipe.patch = place(3 * kPatchBytes);
-        pipe.plan = place(kPipePlanBytes);
-        pipe.total = high;
-        pipe_ok = pipe.total <= 53248;  // three workgroups per CU (tools/calib_lds_residency.hip)
-      }
-      static int cus = 0;
-      if (cus == 0) {
-        int device = 0, count = 0;
-        if (hipGetDevice(&device) != hipSuccess || hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || count <= 0) count = 256;
-        cus = count;
-      }
-      if (pipe_ok) {
-        const uint32_t nblocks = static_cast<uint32_t>((n + (kPalBlock - 64u) - 1) / (kPalBlock - 64u));
-        const uint32_t resident = tuning.lf_pipe_grid > 0 ? static_cast<uint32_t>(tuning.lf_pipe_grid) : 3u * static_cast<uint32_t>(cus);
-        const unsigned grid_x = std::min(nblocks, resident);
-        hipLaunchKernelGGL(k_reweight_lf_pipe, dim3(grid_x), dim3(kPalBlock), pipe.total, st, p.w, n, f, d_points, B, sort->perm, p.pose, pipe,
-                           patch_stats, nblocks);
-        if (weight_sums_written && patch_stats.weight_sums) *weight_sums_written = nblocks;
-        if (pipe_used) *pipe_used = true;
-      } else if (fast && use_patches && patch_lds <= 65536) {
-        const uint32_t per_group = tuning.lf_producer == 0 ? kPatchParticlesAll : kPatchParticles;
+      const size_t patch_lds = patch_base + kPatchLdsBytes;
+      if (fast && use_patches && patch_lds <= 65536) {
+        const bool coop = tuning.lf_producer == 0;  // every wave holds particles and copies its tile row of the patches
+        const uint32_t per_group = coop ? kPatchParticlesAll : kPatchParticles;
         const unsigned groups_x = static_cast<unsigned>((n + per_group - 1) / per_group);
         if (segments > 1) patch_stats.weight_sums = nullptr;  // the segments' sums are combined by k_lf_combine
         // A queue of blocks and as many workgroups as stay resident (three per CU) instead of a workgroup per block, where the launch
         // has more blocks than that: see k_reweight_lf_patch.
-        const uint32_t resident = tuning.lf_pipe_grid > 0 ? static_cast<uint32_t>(tuning.lf_pipe_grid) : 3u * static_cast<uint32_t>(cus);
-        if (tuning.lf_producer == 0)
-          hipLaunchKernelGGL(k_reweight_lf_patch<true>, dim3(groups_x, segments), dim3(kPatchBlock), patch_lds, st, PatchArgs{p.w, n, f, d_points, B,
-                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x, tuning.lf_ends_first != 0 ? 1u : 0u});
-        else if (tuning.lf_queue != 0 && segments == 1 && patch_stats.arrivals != nullptr && groups_x > resident) {
+        const uint32_t cus = tuning.device_cus > 0 ? static_cast<uint32_t>(tuning.device_cus) : 256u;
+        const uint32_t resident = tuning.lf_queue_grid > 0 ? static_cast<uint32_t>(tuning.lf_queue_grid) : 3u * cus;
+        const PatchArgs args{p.w, n, f, d_points, B, sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x,
+                             tuning.lf_ends_first != 0 ? 1u : 0u};
+        if (tuning.lf_queue != 0 && segments == 1 && patch_stats.arrivals != nullptr && groups_x > resident) {
           if (queue_used) *queue_used = true;
-          hipLaunchKernelGGL((k_reweight_lf_patch<false, true>), dim3(resident), dim3(kPatchBlock), patch_lds + MCL_PATCH_LDS_PAD, st, PatchArgs{p.w, n, f, d_points, B,
-                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x, tuning.lf_ends_first != 0 ? 1u : 0u});
-        } else
-          hipLaunchKernelGGL(k_reweight_lf_patch<false>, dim3(groups_x, segments), dim3(kPatchBlock), patch_lds + MCL_PATCH_LDS_PAD, st, PatchArgs{p.w, n, f, d_points, B,
-                             sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x, tuning.lf_ends_first != 0 ? 1u : 0u});
+          if (coop) hipLaunchKernelGGL((k_reweight_lf_patch<true, true>), dim3(resident), dim3(kPatchBlock), patch_lds, st, args);
+          else hipLaunchKernelGGL((k_reweight_lf_patch<false, true>), dim3(resident), dim3(kPatchBlock), patch_lds, st, args);
+        } else {
+          if (coop) hipLaunchKernelGGL((k_reweight_lf_patch<true, false>), dim3(groups_x, segments), dim3(kPatchBlock), patch_lds, st, args);
+          else hipLaunchKernelGGL((k_reweight_lf_patch<false, false>), dim3(groups_x, segments), dim3(kPatchBlock), patch_lds, st, args);
+        }
         if (weight_sums_written && patch_stats.weight_sums) *weight_sums_written = groups_x;
       }
       else if (fast && dispersed && tuning.lf_far_tiles != 0 && f.far_bits != nullptr && patch_base + f.far_bytes <= 65536) {
@@ -5246,17 +4202,11 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
     const size_t pal_lds = static_cast<size_t>(f.pal_base) + static_cast<size_t>(f.pal_count) * sizeof(double);
     hipLaunchKernelGGL(k_reweight_lf_beams, grid, dim3(kBeamsBlock), pal_lds, st, p, n, f, reinterpret_cast<const double2*>(d_points), B,
                        per_wave);
-  } else if (variant == kLfLanePerParticle || variant == kLfSortedLanes || variant == kLfBeamLanes) {  // (kLfBeamLanes without a palette)
-    const dim3 grid(blocks_for(n));
-    if (idx32) hipLaunchKernelGGL(k_reweight_lf_lane<true>, grid, dim3(kBlock), 0, st, p, n, f, d_points, B);
-    else hipLaunchKernelGGL(k_reweight_lf_lane<false>, grid, dim3(kBlock), 0, st, p, n, f, d_points, B);
   } else {
-    const uint64_t tiles = (n + kWave - 1) / kWave;
-    const dim3 grid(static_cast<unsigned>((tiles + (kBlock / kWave) - 1) / (kBlock / kWave)));
-    const size_t lds = static_cast<size_t>(B) * sizeof(double2);
-    const double2* pts = reinterpret_cast<const double2*>(d_points);
-    if (idx32) hipLaunchKernelGGL(k_reweight_lf_wave<true>, grid, dim3(kBlock), lds, st, p, n, f, pts, B);
-    else hipLaunchKernelGGL(k_reweight_lf_wave<false>, grid, dim3(kBlock), lds, st, p, n, f, pts, B);
+    // no order (option lf_variant 0 / 1, small sets whose field has too many distinct values for a palette, sets beyond 2^32 particles):
+    // a lane per particle in index order over the f32 field
+    hipLaunchKernelGGL(k_reweight_lf_sorted<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, p.w, n, f, d_points, B,
+                       static_cast<const uint32_t*>(nullptr), p.pose, static_cast<double*>(nullptr), 0u);
   }
 }
 
@@ -5295,46 +4245,16 @@ void launch_pack_nonfree(hipStream_t st, const int8_t* cells, uint32_t W, uint32
 // Nonzero for a measurement build of the kernels (tools/build_variant.sh: ablations compute nonsense by design, timing builds
 // distort): beluga_amd/capi.py refuses to load one as the product library unless told so.
 extern "C" int mcl_measurement_build(void) {
-#if MCL_ABLATE || MCL_PIPE_ABLATE || MCL_PATCH_LDS_PAD || defined(MCL_LF_TIMING) || defined(MCL_BEAM_STATS) || defined(MCL_BEAM_ABLATE) || defined(MCL_DRAW_ABLATE)
+#ifdef MCL_MEASUREMENT_BUILD
   return 1;
 #else
   return 0;
 #endif
 }
 namespace mcl {
-#ifdef MCL_LF_TIMING
-}  // namespace mcl
-extern "C" int mcl_debug_lf_workgroups(unsigned long long* out, unsigned int workgroups) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mcl::g_lf_wg), 4 * sizeof(unsigned long long) * (workgroups < 8192u ? workgroups : 8192u)) != hipSuccess;
-}
-extern "C" int mcl_debug_lf_timing(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mcl::g_lf_timing), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
-  if (reset) {
-    static const unsigned long long zeros[16] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(mcl::g_lf_timing), zeros, sizeof(zeros)) != hipSuccess) return 1;
-  }
-  return 0;
-}
-namespace mcl {
-#endif
-#ifdef MCL_BEAM_STATS
-}  // namespace mcl
-extern "C" int mcl_debug_beam_stats(unsigned long long* out32, int reset) {
-  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(mcl::g_beam_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
-  if (reset) {
-    static const unsigned long long zeros[32] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(mcl::g_beam_stats), zeros, sizeof(zeros)) != hipSuccess) return 1;
-  }
-  return 0;
-}
-namespace mcl {
-#endif
 // hipFuncSetAttribute is per device: contexts on several GPUs of one process each opt in (mcl_create calls this).
 void configure_device_kernels() {
   const size_t lds = kBeamLds;
-#if MCL_PATCH_LDS_PAD
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_lf_patch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#endif
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_beam_sorted<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(lds));
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_beam_sorted<true>), hipFuncAttributeMaxDynamicSharedMemorySize,

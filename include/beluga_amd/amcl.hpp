@@ -448,6 +448,7 @@ class Amcl {
 
   /// Joins the communicator of a sharded filter (this instance was constructed with its `Shard`).  `transport`: the two
   /// collectives of the exchange over device buffers (MPI, threads of one process, ...); copied, its `user` must outlive this.
+  /// A COLLECTIVE call for world > 1 (the ranks exchange a word of their configuration): every rank attaches, concurrently.
   void attach(unsigned rank, unsigned world, const mcl_transport& transport) { check(mcl_comm_attach(ctx_, rank, world, &transport)); }
   /// The same over RCCL / xGMI (librccl.so is loaded at run time): rank 0 calls rccl_unique_id() and hands the 128 bytes to
   /// the other ranks by whatever means the host has.
@@ -487,7 +488,7 @@ class Amcl {
   }
 
   /// Makes update() return cluster_based_estimate, as beluga_ros::Amcl does (beluga_ros/src/amcl.cpp:125), instead of
-  /// beluga::estimate, as beluga::Amcl does (amcl_core.hpp:200).
+  /// beluga::estimate, as beluga::Amcl does (amcl_core.hpp:200).  On a sharded filter (attach) a COLLECTIVE call: every rank, concurrently, alike.
   void use_cluster_based_estimate(bool enable) { check(mcl_set_estimate_kind(ctx_, enable ? 1 : 0, nullptr)); }
 
   /// beluga_ros::Amcl::likelihood_field() (beluga_ros/include/beluga_ros/amcl.hpp:141-158;

@@ -282,7 +282,13 @@ typedef struct mcl_transport {
                         void* hip_stream);
 } mcl_transport;
 /* Attaches a communicator of `world` ranks to a context created with this rank's shard_offset / shard_capacity.  The transport
- * struct is copied; `user` must outlive the context.  world == 1 is allowed (the cycle then needs no exchange). */
+ * struct is copied; `user` must outlive the context.  world == 1 is allowed (the cycle then needs no exchange).
+ * COLLECTIVE for world > 1: the attach all-gathers a word of the configuration that selects a cycle's collectives (particle bounds,
+ * resampling policy, thresholds, recovery alphas, KLD parameters, models, seed, device_policy, estimate kind) and blocks until every
+ * rank has attached - the ranks attach CONCURRENTLY (one thread or process per rank; a host that attaches its ranks one after the
+ * other from one thread through a rendezvous transport deadlocks) - and every rank fails alike on a mismatch.  On an attached
+ * filter mcl_set_option("device_policy", ...) and mcl_set_estimate_kind are collective in the same way: every rank calls them, concurrently,
+ * with the same arguments, whatever its own previous value was; on a mismatch they return an error and leave the value unchanged. */
 mcl_status mcl_comm_attach(mcl_ctx* ctx, uint32_t rank, uint32_t world, const mcl_transport* transport);
 /* RCCL: rank 0 obtains an id (ncclGetUniqueId), hands its 128 bytes to the other ranks by any means, every rank attaches. */
 mcl_status mcl_comm_unique_id(uint8_t id[128]);
@@ -369,10 +375,10 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
 /* ---- Switches and hooks for A/B measurements and tests.  No option but field_build changes a result beyond the rounding of a
  * particle's sum over the scan: the likelihood-field kernels with a lane per particle add the beams as libstdc++'s
  * std::transform_reduce does (blocks of four; the reference's call, likelihood_field_model.hpp:76), the kernels with a wave per
- * particle (lf_variant 0 / 3, small sets, lf_dispersed) in a fixed tree - 1e-16 relative. ------------------------------------
+ * particle (lf_variant 3, small sets, lf_dispersed) in a fixed tree - 1e-16 relative. ------------------------------------
  * Options (defaults in parentheses; BELUGA_MCL_<NAME> in the environment sets the default at mcl_create):
- *   lf_variant (2)  likelihood-field kernel family: 2 = spatially ordered lanes (small sets: see lf_small_particles), 1 = lane
- *                   per particle, 0 = wave per particle over the f32 field, 3 = wave per particle over the palette table
+ *   lf_variant (2)  likelihood-field kernel family: 2 = spatially ordered lanes (small sets: see lf_small_particles), 1 (and 0) = a lane
+ *                   per particle in index order over the f32 field (no ordering pass), 3 = wave per particle over the palette table
  *   lf_fast (-1)    FMA variant with exact fallback: nonzero = whenever its preconditions hold, 0 = never
  *   lf_table (0)    1 = force the 8-byte table instead of the palette
  *   lf_patch (1)    index table through per-workgroup LDS patches (dense sets): 1 = where the last launch found them useful
@@ -409,18 +415,16 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                   same number of particles; 0 = equal width (round 2)
  *   key_bits_xy (0) bits of the x and of the y bins of that key (the heading gets the other 20 - 2 b): 0 = chosen every cycle from
  *                   the cloud's spread and the scan's reach (4 .. 6), 4 / 5 / 6 = forced (round 2: 6)
- *   lf_producer (1) LDS-patch kernel: 1 = seven waves of particles and a producer wave per workgroup, 0 = eight waves of particles,
- *                   each fetching its share of the patches straight into LDS (buffer_load ... lds; no half patches, no patches
- *                   clamped at the table's border: such groups are gathered)
- *   lf_queue (1)    LDS-patch kernel, launches with more blocks of 448 particles than the device keeps workgroups resident (three per
- *                   CU): 1 = that many workgroups, each taking blocks from a counter until none is left (an XCD that is ahead takes more:
+ *   lf_producer (1) LDS-patch kernel: 1 = seven waves of particles (448) and a producer wave per workgroup, which copies the patches;
+ *                   0 = eight waves of particles (512), each copying one tile row of every patch through its registers (no wave slot
+ *                   without arithmetic: all four SIMDs of a CU carry six waves of it)
+ *   lf_queue (1)    LDS-patch kernel, launches with more blocks than the device keeps workgroups resident (three per CU): 1 = that many
+ *                   workgroups, each taking blocks from a counter until none is left (an XCD that is ahead takes more:
  *                   2 - 4 % off the kernel at 1M particles), 0 = one workgroup per block.  Which workgroup computes a block changes
- *                   nothing in it.  lf_pipe_grid (0): the number of resident workgroups, 0 = three per CU (tests: a few workgroups)
+ *                   nothing in it.  lf_queue_grid (0): the number of resident workgroups, 0 = three per CU (tests: a few workgroups)
  *   lf_ends_first (1)  LDS-patch kernel: the blocks are taken from both ends of the spatial order inwards (0, N - 1, 1, N - 2, ...): the ends
  *                   are the cloud's fringe, whose blocks gather every look-up and take twice as long - taken first they are not the launch's
  *                   last; 0 = in order
- *   lf_pipe (0)     LDS-patch kernel: 1 = persistent workgroups whose producer wave also fetches the next block's poses straight into LDS
- *                   and writes the previous block's weights (bit-identical; measured slower: off)
  *   beam_sectors (1)  beam model, ordered kernel, scanners that reach beyond half the 1024-cell LDS window (448 .. 896 cells): the scan is taken
  *                   in four sectors, each with a window that holds its rays; 0 = one centred window, rays that leave it go on over the
  *                   whole-grid maps in global memory (same cells visited either way)
@@ -445,8 +449,8 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *   lf_far_launches = those of the gather kernel with the far-tile bitmap, lf_far_tiles = tiles in the bitmap (0 = none built);
  *   lf_fast_launches = launches of the FMA variant so far; lf_patch_launches = those of them sent to the LDS-patch
  *   kernel; lf_patch_groups_planned / lf_patch_groups_through = groups of 8 beams (per workgroup) that kernel has looked at /
- *   has read through a patch, running totals over a sample of the workgroups; lf_queue_launches / lf_pipe_launches = launches of the
- *   LDS-patch kernel with the queue of blocks / in its pipelined form; field_built_on_device, field_build_us = the last mcl_set_map;
+ *   has read through a patch, running totals over a sample of the workgroups; lf_queue_launches = launches of the
+ *   LDS-patch kernel with the queue of blocks; field_built_on_device, field_build_us = the last mcl_set_map;
  *   cluster_cells = occupied cells of the last cluster_based_estimate; comm_ranks_seen (ncclCommCount of the library's communicator, 0
  *   without one), comm_collectives, comm_bytes_out (running totals of this rank), comm_backend (0 = none, 1 = the caller's transport, 2 = RCCL inside the library). */
 mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value);

@@ -345,6 +345,45 @@ def test_beam_walk_closed_forms_on_adversarial_maps(kind):
     f.close()
 
 
+@pytest.mark.parametrize("sigma", [(0.05, 0.05, 0.01), (0.6, 0.6, 0.25)])
+def test_beam_kernel_options_visit_the_same_cells_and_leave_the_same_weights(sigma):
+    """The ordered beam kernel with and without its two workgroup-level shortcuts - the scan taken in four sector windows
+    (beam_sectors; engaged by scanners that reach 448 .. 896 cells: 30 m at 5 cm = 600) and the free-ahead certificate of the
+    workgroup's middle ray (beam_free_ahead; fires on a tight cloud) -, all four combinations on a tight and on a wide cloud:
+    the cells visited (the reference's count, an integer) are IDENTICAL, the weights agree within the rounding of a particle's sum
+    over the scan (with sectors the terms are added sector by sector, and which sector a beam falls into is decided by the
+    workgroup's middle particle: the order of the additions, not a term, depends on the neighbours - 1e-12), and every combination
+    agrees with the oracle."""
+    cells = synth.make_rooms_map(2000, 2000, seed=11, n_rooms=60)
+    res, origin = 0.05, se2_from_xytheta(-50.0, -50.0, 0.0)
+    grid = OccupancyGrid(cells=cells, resolution=res, origin=origin)
+    truth = synth.find_free_pose(cells, res, (-50.0, -50.0), seed=2, clearance_cells=12)
+    max_range = 30.0
+    pts = make_scan(grid, truth, 360, max_range=max_range, fov=270.0)
+    n = 40_000
+    states = synth.normal_particles(n, truth, sigma, seed=6)
+    beam = BeamModelParam(beam_max_range=max_range)
+    results = {}
+    for sectors in (1, 0):
+        for ahead in (1, 0):
+            f = new_filter(grid, n, sensor=beam)
+            f.set_option("beam_sectors", sectors)
+            f.set_option("beam_free_ahead", ahead)
+            f.set_particles(states, np.ones(n))
+            f.beam_cells_visited(reset=True)
+            f.reweight(pts)
+            results[(sectors, ahead)] = (f.particles()[1].copy(), f.beam_cells_visited())
+            f.close()
+    want, steps = orc.beam_weights(grid.cells, res, grid.origin, (0.5, 0.5, 0.05, 0.05, 0.2, 0.1, max_range), states, pts,
+                                   threads=orc.max_threads(), return_steps=True)
+    base_w, base_cells = results[(0, 0)]
+    assert base_cells == steps
+    for key, (w, visited) in results.items():
+        assert visited == steps, (key, visited, steps)
+        np.testing.assert_allclose(w, base_w, rtol=1e-12, atol=1e-300, err_msg=str(key))
+        np.testing.assert_allclose(w, want, rtol=1e-10, atol=1e-300, err_msg=str(key))
+
+
 def test_propagate_matches_oracle():
     grid = rooms_grid(64, 1)
     n = 10_000
@@ -1204,8 +1243,9 @@ def test_reweight_lf_fma_variant_is_bit_identical(fast):
     f.close()
 
 
+@pytest.mark.parametrize("producer", [1, 0])
 @pytest.mark.parametrize("n", [16_384, 66_667, 200_000, 300_000])
-def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n):
+def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n, producer):
     """The default LF kernel reads the index table through per-workgroup LDS patches wherever a bound on the workgroup's
     spread proves the look-ups inside one (k_reweight_lf_patch, forced by option lf_patch = 2); lf_patch = 0 gathers every look-up.
     Same cells, same sums: the weights are identical bit for bit - here on a small map, where a wide initial cloud puts
@@ -1214,14 +1254,14 @@ def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n):
     cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
     grid = OccupancyGrid(cells=cells, resolution=0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
     truth = synth.find_free_pose(cells, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
-    # 1300 and 1700 beams (200 000 particles: one segment): more groups than the per-beam records of the planner hold (its
-    # fallback walks global memory), and more than there are plan entries (the groups beyond them are gathered)
+    # 1300 and 1700 beams (200 000 particles: one segment): more groups than there are plan entries (the groups beyond them are gathered)
     for beams in (57, 360, 1080) + ((1300, 1700) if n == 200_000 else ()):
         pts = make_scan(grid, truth, beams, max_range=12.0)
         weights = []
         for patch in (2, 0):  # always / never
             f = new_filter(grid, n)
             f.set_option("lf_patch", patch)
+            f.set_option("lf_producer", producer)
             f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
             states, w0 = f.particles()
             f.reweight(pts)
@@ -1233,51 +1273,16 @@ def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n):
         assert np.array_equal(weights[0], weights[1]), (n, beams, int((weights[0] != weights[1]).sum()))
 
 
-@pytest.mark.parametrize("n,grid_wgs", [(300_000, 0), (300_000, 7), (300_000, 64), (1_000_003, 0), (1_000_003, 96)])
-def test_reweight_lf_pipelined_patch_kernel_equals_the_gather_kernel_bit_for_bit(n, grid_wgs):
-    """k_reweight_lf_pipe (option lf_pipe = 1): persistent workgroups whose producer wave fetches the next block's poses straight
-    into LDS and writes the previous block's weights beside the patches (from 262 144 particles on: one scan segment).  Same
-    cells, same sums as the gather kernel: the weights are identical bit for bit - with the
-    default grid (three workgroups per CU: one block each at 300 000 particles, two at a million) and with a few workgroups that
-    take dozens of blocks each (option lf_pipe_grid), over wide clouds (blocks that gather everything, patches clamped at the
-    grid's edges, half patches) and tight ones, scans with a tail of beams (57, 1095), the shortest scan with a group (8) and
-    the longest the plan holds (1095; one more beam goes to k_reweight_lf_patch); the launch's statistics reach the host."""
-    cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
-    grid = OccupancyGrid(cells=cells, resolution=0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
-    truth = synth.find_free_pose(cells, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
-    cases = [(1080, (0.5, 0.5, 0.2)), (1080, (0.1, 0.1, 0.03)), (57, (0.3, 0.3, 0.1)), (1095, (0.1, 0.1, 0.03)), (8, (0.1, 0.1, 0.03)),
-             (1096, (0.1, 0.1, 0.03))]
-    if n > 500_000:
-        cases = cases[:2]
-    for beams, sigma in cases:
-        pts = make_scan(grid, truth, beams, max_range=12.0)
-        weights = []
-        for patch in (2, 0):  # always / never
-            f = new_filter(grid, n)
-            f.set_option("lf_patch", patch)
-            f.set_option("lf_pipe", 1)  # (an option: measured slower than the block-per-workgroup form, profiles/r04_lf_pipe_study.txt)
-            f.set_option("lf_pipe_grid", grid_wgs)
-            f.initialize(truth, np.diag([s * s for s in sigma]))
-            f.reweight(pts)
-            weights.append(f.particles()[1].copy())
-            if patch == 2:
-                assert f.counter("lf_pipe_launches") == (1 if beams <= 1095 else 0), (beams, n)
-                planned, through = f.counter("lf_patch_groups_planned"), f.counter("lf_patch_groups_through")
-                assert planned > 0 and through <= planned
-                if sigma[0] <= 0.1 and beams >= 57:
-                    assert through > 0.8 * planned, (beams, sigma, through, planned)
-            f.close()
-        assert np.array_equal(weights[0], weights[1]), (n, beams, sigma, int((weights[0] != weights[1]).sum()))
-
-
+@pytest.mark.parametrize("producer", [1, 0])
 @pytest.mark.parametrize("n,grid_wgs", [(300_000, 7), (300_000, 64), (300_000, 669), (1_000_003, 0), (1_000_003, 96)])
-def test_reweight_lf_patch_kernel_with_a_queue_of_blocks_equals_the_gather_kernel_bit_for_bit(n, grid_wgs):
-    """k_reweight_lf_patch<false, true> (option lf_queue = 1, the default where a launch has more blocks than the device keeps workgroups
+def test_reweight_lf_patch_kernel_with_a_queue_of_blocks_equals_the_gather_kernel_bit_for_bit(n, grid_wgs, producer):
+    """k_reweight_lf_patch<*, true> (option lf_queue = 1, the default where a launch has more blocks than the device keeps workgroups
     resident): the workgroups of the launch take their blocks from a counter instead of one block each - which workgroup computes a
     block changes nothing in it.  Weights identical to the gather kernel's bit for bit, with the default number of workgroups (three
-    per CU) and with a few that take dozens of blocks each (option lf_pipe_grid; 669 = one block short of a workgroup per block),
-    over wide and tight clouds and scans with a tail of beams; launch after launch (the counter wraps to zero by itself); the blocks taken
-    in order or from both ends of the order inwards (option lf_ends_first)."""
+    per CU) and with a few that take dozens of blocks each (option lf_queue_grid; 669 = one block short of a workgroup per block with
+    a producer wave), over wide and tight clouds and scans with a tail of beams; launch after launch (the counter wraps to zero by
+    itself); the blocks taken in order or from both ends of the order inwards (option lf_ends_first); with a producer wave per
+    workgroup and with every wave copying its tile row of the patches (option lf_producer)."""
     cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
     grid = OccupancyGrid(cells=cells, resolution=0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
     truth = synth.find_free_pose(cells, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
@@ -1291,7 +1296,8 @@ def test_reweight_lf_patch_kernel_with_a_queue_of_blocks_equals_the_gather_kerne
             f = new_filter(grid, n)
             f.set_option("lf_patch", patch)
             f.set_option("lf_queue", 1)
-            f.set_option("lf_pipe_grid", grid_wgs)
+            f.set_option("lf_producer", producer)
+            f.set_option("lf_queue_grid", grid_wgs)
             f.set_option("lf_ends_first", 0 if grid_wgs == 64 else 1)  # the blocks in order / from both ends of the order inwards (the default)
             f.initialize(truth, np.diag([s * s for s in sigma]))
             f.reweight(pts)
@@ -1307,11 +1313,13 @@ def test_reweight_lf_patch_kernel_with_a_queue_of_blocks_equals_the_gather_kerne
         assert np.array_equal(weights[0], weights[1]), (n, beams, sigma, int((weights[0] != weights[1]).sum()))
 
 
-def test_queue_of_blocks_leaves_the_same_cycle_as_a_workgroup_per_block():
+@pytest.mark.parametrize("producer", [1, 0])
+def test_queue_of_blocks_leaves_the_same_cycle_as_a_workgroup_per_block(producer):
     """Whole cycles (the fused mcl_update: the LF kernel's per-block sums of the new weights feed the normalisation) with the queue of
     blocks and with a workgroup per block (option lf_queue = 0): estimates, weights and particle sets identical bit for bit."""
     import bench
-    cells, truth, odoms, scans, _poses = bench.make_workload(4)
+    cycles = 8
+    cells, truth, odoms, scans, _poses = bench.make_workload(cycles)
     grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
     n = 1_000_000
     outs = []
@@ -1319,37 +1327,13 @@ def test_queue_of_blocks_leaves_the_same_cycle_as_a_workgroup_per_block():
         f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF),
                  AmclParams(min_particles=n, max_particles=n), seed=42)
         f.set_option("lf_queue", queue)
+        f.set_option("lf_producer", producer)
         f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
         est = []
-        for c in range(4):
+        for c in range(cycles):
             e = f.update(se2_from_xytheta(*odoms[c]), scans[c])
             est.append(np.concatenate([e[0], e[1].ravel(), [f.last_info["weight_sum"]]]))
-        assert f.counter("lf_queue_launches") == (4 if queue else 0)
-        outs.append((np.asarray(est), f.particles()))
-        f.close()
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert np.array_equal(outs[0][1][0], outs[1][1][0]) and np.array_equal(outs[0][1][1], outs[1][1][1])
-
-
-def test_pipelined_patch_kernel_leaves_the_same_cycle_as_the_block_per_workgroup_form():
-    """Whole cycles (the fused mcl_update: the LF kernel's per-block sums of the new weights feed the normalisation) with
-    k_reweight_lf_pipe and with k_reweight_lf_patch (option lf_pipe = 0): estimates, weights and particle sets are identical
-    bit for bit - the blocks' sums are added in the same tree by either kernel.  A million particles: three blocks per workgroup."""
-    import bench
-    cells, truth, odoms, scans, _poses = bench.make_workload(4)
-    grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
-    n = 1_000_000
-    outs = []
-    for pipe in (1, 0):
-        f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF),
-                 AmclParams(min_particles=n, max_particles=n), seed=42)
-        f.set_option("lf_pipe", pipe)
-        f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
-        est = []
-        for c in range(4):
-            e = f.update(se2_from_xytheta(*odoms[c]), scans[c])
-            est.append(np.concatenate([e[0], e[1].ravel(), [f.last_info["weight_sum"]]]))
-        assert f.counter("lf_pipe_launches") == (4 if pipe else 0)
+        assert f.counter("lf_queue_launches") == (cycles if queue else 0)
         outs.append((np.asarray(est), f.particles()))
         f.close()
     assert np.array_equal(outs[0][0], outs[1][0])
@@ -1364,7 +1348,7 @@ def test_pipelined_patch_kernel_leaves_the_same_cycle_as_the_block_per_workgroup
 def test_reweight_lf_patch_planner_options_change_no_weight(options):
     """What the LDS-patch kernel's planner and the ordering decide - whole patches, half patches side by side / stacked for groups
     that straddle a range discontinuity, the per-axis or isotropic bound, Hilbert or Morton keys and their bit split, a producer
-    wave or fetches shared by all waves (buffer_load ... lds) - changes where a look-up is read from, never its value: the
+    wave or every wave copying its tile row of the patches - changes where a look-up is read from, never its value: the
     weights equal the gather kernel's bit for bit, on a cloud wide enough to put patches across the grid's edges, and on a
     tight one where nearly every group goes through a patch (and the planner's statistics say so)."""
     cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
@@ -1386,7 +1370,7 @@ def test_reweight_lf_patch_planner_options_change_no_weight(options):
                 shares.append(f.counter("lf_patch_groups_through") / max(f.counter("lf_patch_groups_planned"), 1))
             f.close()
         assert np.array_equal(weights[0], weights[1]), (options, sigma, int((weights[0] != weights[1]).sum()))
-        if sigma[0] < 0.2 and options.get("lf_producer", 1) == 1:
+        if sigma[0] < 0.2:
             assert shares[0] > 0.9, (options, shares)
 
 

@@ -28,7 +28,7 @@ for case in range(cases):
                 key_warp=int(rng.integers(0, 2)), key_bits_xy=int(rng.choice([0, 4, 5, 6])), lf_producer=int(rng.integers(0, 2)),
                 lf_loose_below=int(rng.choice([0, 128, 224, 257])),
                 # the queue of blocks, with few resident workgroups so that every one takes many blocks (0 = three per CU: a workgroup per block here)
-                lf_queue=int(rng.integers(0, 2)), lf_ends_first=int(rng.integers(0, 2)), lf_pipe_grid=int(rng.choice([0, 1, 5, 37, 200])))
+                lf_queue=int(rng.integers(0, 2)), lf_ends_first=int(rng.integers(0, 2)), lf_queue_grid=int(rng.choice([0, 1, 5, 37, 200])))
     ws = []
     for patch in (2, 0):
         f = Amcl(grid, DifferentialDriveModelParam(0.1, 0.05, 0.1, 0.05), LF, AmclParams(min_particles=n, max_particles=n), seed=11)
