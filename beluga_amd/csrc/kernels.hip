@@ -1158,7 +1158,22 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
       const uint32_t kb = ((flags & 2u) ? (kPatchW / 2) * kPatchPitch : static_cast<uint32_t>(kPatchH)) -
                           (static_cast<uint32_t>(x0b) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0b) << 1);
       const uint32_t meta = flags == 0u ? 0u : ((flags & 6u) ? first_b : 8u);
-      s_plan_k[tid] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), 0};
+      // kCoop: the entry's fourth word is the FETCH WORD of the group two steps ahead - what a wave needs to fetch its tile row of that
+      // group's patch while it evaluates this group: the table offset of the patch's first piece (a whole patch inside the bordered
+      // table: row r of it lies r * pitch further, lane l's piece 16 l further), 1 = ask the plan (halves, a patch across the table's
+      // border), 0 = no patch (the table's first bytes are fetched, and nobody reads them).  Thread g writes it into entry g - 2.
+      int* mine = reinterpret_cast<int*>(s_plan_k + tid);
+      mine[0] = static_cast<int>(ka);
+      mine[1] = static_cast<int>(meta);
+      mine[2] = static_cast<int>(kb);
+      if (!kCoop || tid + 2 >= planned) mine[3] = 0;
+      if constexpr (kCoop) {
+        uint32_t fetch_word = flags == 0u ? 0u : 1u;
+        if (flags == 1u && clamped == 0)
+          fetch_word = (static_cast<uint32_t>(x0a - static_cast<int>(kFastBias) + 8) << 4) +
+                       (static_cast<uint32_t>(y0a - static_cast<int>(kFastBias) + 8) >> 3) * f.pal_pitch;
+        if (tid >= 2) reinterpret_cast<int*>(s_plan_k + (tid - 2))[3] = static_cast<int>(fetch_word);
+      }
     }
     mine_fits = flags != 0u;
   }
@@ -1177,15 +1192,23 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   for (uint32_t k = 0; k < kPatchBlock / 64; ++k) fitting += s_count[k];
   const bool loose = __builtin_amdgcn_readfirstlane(fitting) * 256u < groups * stats.loose_below;
   struct Plan {  // scalars
-    uint32_t ka;    // less the buffer's base
-    uint32_t meta;  // 0: gathered, 8: one whole patch, 1 .. 7: two halves, the second one from this beam on
+    uint32_t ka;     // less the buffer's base
+    uint32_t meta;   // 0: gathered, 8: one whole patch, 1 .. 7: two halves, the second one from this beam on
+    uint32_t fetch;  // kCoop: the fetch word of group g + 2
   };
   auto plan_of = [&](uint32_t g, Plan& plan) {  // g uniform; scalar results
-    plan = Plan{0u, 0u};
+    plan = Plan{0u, 0u, 0u};
     if (g >= kPatchPlanned) return;
-    const int2 e = *reinterpret_cast<const int2*>(s_plan_k + g);
-    plan.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.x));
-    plan.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
+    if constexpr (kCoop) {
+      const int4 e = s_plan_k[g];
+      plan.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.x));
+      plan.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
+      plan.fetch = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.w));
+    } else {
+      const int2 e = *reinterpret_cast<const int2*>(s_plan_k + g);
+      plan.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.x));
+      plan.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
+    }
   };
 
   // The launch's statistics (what the host picks the next launch's kernel by): groups planned and groups through a
@@ -1334,9 +1357,10 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
       piece = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, base_a, 0));
     }
   };
-  auto coop_store = [&](uint32_t g, const uint4& piece) {  // g uniform
-    if constexpr (kCoop) *reinterpret_cast<uint4*>(smem + buffer_of(g) + lane * kPatchPitch + wave_id * 16u) = piece;
+  auto coop_store = [&](uint32_t buffer, const uint4& piece) {  // buffer: LDS byte address of the patch's buffer (uniform)
+    if constexpr (kCoop) *reinterpret_cast<uint4*>(smem + lane * kPatchPitch + (buffer + wave_id * 16u)) = piece;
   };
+  const uint32_t coop_row = wave_id * f.pal_pitch;  // this wave's tile row of a patch, as a table offset
 
   double acc = (f.prob || partial) ? 0.0 : 1.0;
   const bool fast = __builtin_amdgcn_ballot_w64(!lane_small) == 0;  // per wave: a far particle sends its wave through the exact code
@@ -1403,12 +1427,14 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   // One step: the end-points of group g, then the sum of the group before it (its gathers, if any, had the end-point
   // arithmetic to arrive), then the look-ups of group g.  `redo`: 1 if the group has to be added by add_exact instead.
   // kCoop: `piece` holds this wave's tile row of the patch of group g + 1; it goes to LDS behind the barrier, and the row of g + 2 is fetched.
-  auto step = [&](auto is_loose, auto add_before, uint32_t g_any, Lookups& now, const Lookups& before, uint4& piece) {
+  // `rotor`: the buffer of group g on entry, that of group g + 1 on exit (the three buffers in turn).
+  auto step = [&](auto is_loose, auto add_before, uint32_t g_any, Lookups& now, const Lookups& before, uint4& piece, uint32_t& rotor) {
     const uint32_t g = __builtin_amdgcn_readfirstlane(g_any);  // uniform anyway; this keeps the scan reads on the scalar unit
     const uint32_t b0 = b_begin + 8 * g;
-    Plan plan{0u, 0u};
+    Plan plan{0u, 0u, 0u};
     if constexpr (!decltype(is_loose)::value) plan_of(g, plan);
-    const uint32_t buffer = buffer_of(g);
+    const uint32_t buffer = rotor;
+    rotor = buffer + kPatchBytes == patch_base + kPatchBuffers * kPatchBytes ? patch_base : buffer + kPatchBytes;
     if constexpr (!decltype(is_loose)::value) {
       // A bare barrier: no wait for this wave's outstanding LDS reads (see kPatchBuffers).  What it orders: the stores of patch g
       // (a producer's are complete before ITS barrier: it keeps the fence; a wave's own piece - kCoop - was stored at the start of the
@@ -1418,9 +1444,14 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if constexpr (kCoop) {
-        coop_store(g + 1, piece);  // every wave is done with the look-ups of group g - 2, whose buffer this is
+        // (16 x the lane's number from the hardware, three instructions, rather than from a register held - or spilled - across the step)
+        uint32_t lane16;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(lane16));
+        // group g + 1's piece: every wave is done with the look-ups of group g - 2, whose buffer this was (lane l's column: 144 l = 9 x 16 l)
+        *reinterpret_cast<uint4*>(smem + (__umul24(lane16, 9u) + (rotor + wave_id * 16u))) = piece;
         asm volatile("" ::: "memory");
-        coop_fetch(g + 2, piece);
+        if (plan.fetch & 1u) coop_fetch(g + 2, piece);  // halves, a patch across the table's border: by the plan (a scalar branch, rare)
+        else piece = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, plan.fetch + coop_row, 0));
       }
     }
     now.redo = 1u;
@@ -1477,20 +1508,21 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
       uint4 piece0;
       coop_fetch(0, piece0);
       coop_fetch(1, piece);
-      coop_store(0, piece0);
+      coop_store(patch_base, piece0);
     }
+    uint32_t rotor = patch_base;  // (group 0's buffer)
     uint32_t g;
     if (groups & 1) {
-      step(is_loose, std::false_type{}, 0, a, a, piece);
+      step(is_loose, std::false_type{}, 0, a, a, piece, rotor);
       g = 1;
     } else {
-      step(is_loose, std::false_type{}, 0, c, c, piece);
-      step(is_loose, std::true_type{}, 1, a, c, piece);
+      step(is_loose, std::false_type{}, 0, c, c, piece, rotor);
+      step(is_loose, std::true_type{}, 1, a, c, piece, rotor);
       g = 2;
     }
     for (; g < groups; g += 2) {  // `a` holds group g - 1
-      step(is_loose, std::true_type{}, g, c, a, piece);
-      step(is_loose, std::true_type{}, g + 1, a, c, piece);
+      step(is_loose, std::true_type{}, g, c, a, piece, rotor);
+      step(is_loose, std::true_type{}, g + 1, a, c, piece, rotor);
     }
     consume(a, b_begin + 8 * groups - 8);
   };

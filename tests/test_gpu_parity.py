@@ -1297,7 +1297,8 @@ def test_reweight_lf_patch_kernel_with_a_queue_of_blocks_equals_the_gather_kerne
             f.set_option("lf_patch", patch)
             f.set_option("lf_queue", 1)
             f.set_option("lf_producer", producer)
-            f.set_option("lf_queue_grid", grid_wgs)
+            # (one block short of a workgroup per block: 670 blocks of 448 particles, 586 of 512)
+            f.set_option("lf_queue_grid", 585 if (grid_wgs == 669 and not producer) else grid_wgs)
             f.set_option("lf_ends_first", 0 if grid_wgs == 64 else 1)  # the blocks in order / from both ends of the order inwards (the default)
             f.initialize(truth, np.diag([s * s for s in sigma]))
             f.reweight(pts)
