@@ -517,6 +517,13 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b /* uniform */
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
   return r;
 }
+// cx * pitch + cy * 2 + K (K uniform) in two instructions.  ONE asm statement: between two of them the compiler's hazard recogniser, which
+// cannot look inside, puts an s_nop (8 per group of beams in the LF patch kernel's main loop).
+__device__ __forceinline__ uint32_t patch_address(uint32_t cx, uint32_t cy, uint32_t K /* uniform */) {
+  uint32_t r;
+  asm("v_lshl_add_u32 %0, %1, 1, %3\n\tv_mad_u32_u24 %0, %2, %4, %0" : "=&v"(r) : "v"(cy), "v"(cx), "s"(K), "s"(144u));
+  return r;
+}
 __device__ __forceinline__ uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t r;
   asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -821,6 +828,7 @@ constexpr int kPatchW = 64, kPatchH = 64;  // cells
 // Bytes per patch column: the 128 of its cells + 16, so that the bank of a cell is (4 x + y / 2) mod 32 - neighbouring
 // columns on different banks (with 128, every column of a row pair would share one).
 constexpr uint32_t kPatchPitch = kPatchH * 2 + 16;
+static_assert(kPatchPitch == 144, "patch_address() carries the pitch as a literal");
 constexpr uint32_t kPatchBytes = kPatchW * kPatchPitch;
 constexpr int kPatchBlock = 512;                      // threads of k_reweight_lf_patch
 constexpr uint32_t kPatchParticles = kPatchBlock - 64;  // per workgroup, with a producer wave (k_reweight_lf_patch<false>)
@@ -831,7 +839,7 @@ constexpr uint32_t kPatchPlanned = 192;               // groups with a plan entr
 // two buffers every wave had to sit out its outstanding LDS reads in front of each barrier.  Behind them: the two plans and the
 // prologue's partial results.
 constexpr uint32_t kPatchBuffers = 3;
-constexpr uint32_t kPatchLdsBytes = kPatchBuffers * kPatchBytes + kPatchPlanned * 32 + 48 * 4;
+constexpr uint32_t kPatchLdsBytes = kPatchBuffers * kPatchBytes + kPatchPlanned * 32 + 16 + 48 * 4;  // (+ 16: the zero entry behind the plan)
 static_assert(kPatchPlanned * 8 * 16 <= kPatchBuffers * kPatchBytes, "the per-beam records of the plan live in the patch buffers");
 constexpr double kPatchMagic = 1572864.0 + 4.656612873077392578125e-10;     // 1.5 * 2^20 + 2^-31
 // 6 waves per SIMD = three workgroups per CU: at most 80 registers
@@ -871,6 +879,8 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
       s_row[j] = palette_row_offset(static_cast<int32_t>(j) - 1, f.pal_pitch) - kFastBiasX;
     double* s_pal = reinterpret_cast<double*>(smem + f.pal_base);
     for (uint32_t k = threadIdx.x; k < f.pal_count; k += kPatchBlock) s_pal[k] = f.pal_val[k];
+    // the entry behind the plan, read by the groups beyond it (scans of more than 8 kPatchPlanned points): gathered, nothing to fetch
+    if (threadIdx.x == 0) *reinterpret_cast<int4*>(smem + patch_base + kPatchBuffers * kPatchBytes + kPatchPlanned * 32) = int4{0, 0, 0, 0};
   }
   // plan entry of group g: {x0A, y0A | flags, x0B, y0B | first beam of half B} - biased origins, y0 multiples of 8;
   // flags: 1 = the group goes through a patch, 2 = split into two halves side by side (32 x 64 cells each), 4 = split into two
@@ -887,7 +897,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   };
   int4* s_plan = reinterpret_cast<int4*>(smem + patch_base + kPatchBuffers * kPatchBytes);
   int4* s_plan_k = s_plan + kPatchPlanned;
-  float* s_bound = reinterpret_cast<float*>(smem + patch_base + kPatchBuffers * kPatchBytes + kPatchPlanned * 32);  // [8][6]
+  float* s_bound = reinterpret_cast<float*>(smem + patch_base + kPatchBuffers * kPatchBytes + kPatchPlanned * 32 + 16);  // [8][6]
   constexpr uint32_t kConsumers = kCoop ? kPatchBlock / 64 : kPatchBlock / 64 - 1;  // waves that hold particles
   constexpr uint32_t kParticles = kConsumers * 64;
   const uint32_t wave_id = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
@@ -1198,7 +1208,8 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   };
   auto plan_of = [&](uint32_t g, Plan& plan) {  // g uniform; scalar results
     plan = Plan{0u, 0u, 0u};
-    if (g >= kPatchPlanned) return;
+    // (the groups beyond the plan read the entry behind it: zeros - gathered, nothing to fetch)
+    g = g < kPatchPlanned ? g : kPatchPlanned;
     if constexpr (kCoop) {
       const int4 e = s_plan_k[g];
       plan.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.x));
@@ -1363,7 +1374,11 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   const uint32_t coop_row = wave_id * f.pal_pitch;  // this wave's tile row of a patch, as a table offset
 
   double acc = (f.prob || partial) ? 0.0 : 1.0;
-  const bool fast = __builtin_amdgcn_ballot_w64(!lane_small) == 0;  // per wave: a far particle sends its wave through the exact code
+  // A wave that holds a far particle goes through the exact evaluation group by group - by the main loop's own means: its end-point
+  // constants are replaced by ones that put every end-point ON a cell boundary (the guard word comes out zero), so that every group is
+  // marked for add_exact; what its look-ups read meanwhile (cell 0 of whatever patch, an address that may lie outside LDS: zero) is dropped.
+  const bool fast = __builtin_amdgcn_ballot_w64(!lane_small) == 0;
+  const double e_ct = fast ? ict : 0.0, e_st = fast ? ist : 0.0, e_xm = fast ? ixm : 1572864.0, e_ym = fast ? iym : 1572864.0;
   const int c_lo = static_cast<int>(kFastBias) - 1, x_hi = static_cast<int>(kFastBias + f.W), y_hi = static_cast<int>(kFastBias + f.H);
   const uint32_t row_bias = 4u - (kFastBias << 2);  // LDS byte address of the row entry = (biased y << 2) + row_bias
   // Palette addresses are kept 32 bits wide from the load on: ds_read_u16 / buffer_load_ushort zero-extend for free.  The
@@ -1372,7 +1387,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   const uint32_t opaque_zero = f.pal_bytes >> 31;
   struct Lookups {
     uint32_t e[8];  // palette addresses (LDS byte addresses of the f64 terms)
-    uint32_t redo;  // 1: the group is added by add_exact instead
+    uint64_t redo;  // nonzero (the lanes with an end-point on a cell boundary): the group is added by add_exact instead
   };
   // The separately rounded evaluation, beam by beam with plain gathers.  It needs the pose as the reference holds it (not
   // pre-multiplied by 1 / res); this path runs for 4 in 2^32 end-points, so the pose is fetched again here rather than kept
@@ -1411,7 +1426,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
     for (; b < end; ++b) acc += term(b);
   };
   auto consume = [&](const Lookups& e, uint32_t b0) {
-    if (__builtin_amdgcn_readfirstlane(e.redo)) {
+    if (e.redo != 0) {  // (a ballot: uniform)
       add_exact(b0, 8);
       return;
     }
@@ -1428,17 +1443,21 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   // arithmetic to arrive), then the look-ups of group g.  `redo`: 1 if the group has to be added by add_exact instead.
   // kCoop: `piece` holds this wave's tile row of the patch of group g + 1; it goes to LDS behind the barrier, and the row of g + 2 is fetched.
   // `rotor`: the buffer of group g on entry, that of group g + 1 on exit (the three buffers in turn).
-  auto step = [&](auto is_loose, auto add_before, uint32_t g_any, Lookups& now, const Lookups& before, uint4& piece, uint32_t& rotor) {
-    const uint32_t g = __builtin_amdgcn_readfirstlane(g_any);  // uniform anyway; this keeps the scan reads on the scalar unit
-    const uint32_t b0 = b_begin + 8 * g;
-    Plan plan{0u, 0u, 0u};
-    if constexpr (!decltype(is_loose)::value) plan_of(g, plan);
+  // `cursor`: the scan points of group g on entry, those of group g + 1 on exit (the constant address space: scalar loads - `pts` is no
+  // kernel argument any more, of which the compiler knows that nobody writes there).
+  typedef const __attribute__((address_space(4))) double* scan_ptr_t;
+  // `carried`: the plan entry of group g on entry, that of group g + 1 on exit - read in the middle of the step, in front of the group's
+  // look-ups: the wait for an LDS read is a wait for every LDS read issued before it, and a plan entry read at a step's start would
+  // make the wave sit out the look-ups it has just issued in front of the barrier instead of behind the next end-points.
+  auto step = [&](auto is_loose, auto add_before, uint32_t g, Lookups& now, const Lookups& before, uint4& piece, uint32_t& rotor, scan_ptr_t& cursor,
+                  Plan& carried) {
+    const Plan plan = carried;
     const uint32_t buffer = rotor;
     rotor = buffer + kPatchBytes == patch_base + kPatchBuffers * kPatchBytes ? patch_base : buffer + kPatchBytes;
     if constexpr (!decltype(is_loose)::value) {
       // A bare barrier: no wait for this wave's outstanding LDS reads (see kPatchBuffers).  What it orders: the stores of patch g
       // (a producer's are complete before ITS barrier: it keeps the fence; a wave's own piece - kCoop - was stored at the start of the
-      // step before, in front of the plan entry's LDS read that coop_fetch waits for: LDS operations of a wave complete in order)
+      // step before, in front of the plan entry's LDS read that the step waits for: LDS operations of a wave complete in order)
       // against the look-ups below.  The empty asm statements keep the compiler from moving memory operations across it.
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -1454,31 +1473,48 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
         else piece = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, plan.fetch + coop_row, 0));
       }
     }
-    now.redo = 1u;
-    if (!fast) {
-      if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
-      return;
-    }
-    // (the constant address space: scalar loads - `pts` is no kernel argument any more, of which the compiler knows that nobody writes there)
-    const __attribute__((address_space(4))) double* q = (const __attribute__((address_space(4))) double*)(pts + 2 * b0);
+    const scan_ptr_t q = cursor;
+    cursor = q + 16;
     int cx[8], cy[8];
-    uint32_t lowest = 0xFFFFFFFFu;
+    uint32_t lowest = 0u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const double px = q[2 * k], py = q[2 * k + 1];
-      const double sx = __builtin_fma(px, ict, __builtin_fma(-py, ist, ixm));
-      const double sy = __builtin_fma(px, ist, __builtin_fma(py, ict, iym));
+      const double sx = __builtin_fma(px, e_ct, __builtin_fma(-py, e_st, e_xm));
+      const double sy = __builtin_fma(px, e_st, __builtin_fma(py, e_ct, e_ym));
       const uint64_t bx = __builtin_bit_cast(uint64_t, sx), by = __builtin_bit_cast(uint64_t, sy);
-      lowest = min3_u32(lowest, static_cast<uint32_t>(bx), static_cast<uint32_t>(by));
+      if (k == 0) lowest = min(static_cast<uint32_t>(bx), static_cast<uint32_t>(by));
+      else lowest = min3_u32(lowest, static_cast<uint32_t>(bx), static_cast<uint32_t>(by));
       cx[k] = static_cast<int>(bx >> 32);
       cy[k] = static_cast<int>(by >> 32);
     }
-    if constexpr (decltype(add_before)::value) consume(before, b0 - 8);
-    if (plan.meta == 8u) {  // one whole patch (19 groups in 20): one constant for the eight look-ups
+#ifndef MCL_V_NO_PLAN_PREFETCH
+    int4 next_entry{0, 0, 0, 0};
+    if constexpr (!decltype(is_loose)::value) {
+      const uint32_t at = g + 1u < kPatchPlanned ? g + 1u : kPatchPlanned;  // (the groups beyond the plan read the zero entry behind it)
+      if constexpr (kCoop) next_entry = s_plan_k[at];
+      else {
+        const int2 e = *reinterpret_cast<const int2*>(s_plan_k + at);
+        next_entry.x = e.x;
+        next_entry.y = e.y;
+      }
+    }
+#endif
+    if constexpr (decltype(add_before)::value) consume(before, b_begin + 8 * g - 8);
+#ifndef MCL_V_NO_PLAN_PREFETCH
+    if constexpr (!decltype(is_loose)::value) {
+      carried.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(next_entry.x));
+      carried.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(next_entry.y));
+      if constexpr (kCoop) carried.fetch = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(next_entry.w));
+    }
+#else
+    if constexpr (!decltype(is_loose)::value) plan_of(g + 1, carried);
+#endif
+    if (__builtin_expect(plan.meta == 8u, 1)) {  // one whole patch (19 groups in 20): one constant for the eight look-ups
       const uint32_t K = buffer + plan.ka;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const uint32_t at = mad_u24(static_cast<uint32_t>(cx[k]), kPatchPitch, lshl_add_u32_uniform(static_cast<uint32_t>(cy[k]), 1, K));
+        const uint32_t at = patch_address(static_cast<uint32_t>(cx[k]), static_cast<uint32_t>(cy[k]), K);
         now.e[k] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(static_cast<uintptr_t>(at)));
       }
     } else if (plan.meta != 0u) {  // two halves: the beams from plan.meta on read the second one
@@ -1487,7 +1523,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
       for (int k = 0; k < 8; ++k) {
         const uint32_t K = static_cast<uint32_t>(k) < plan.meta ? KA : KB;  // scalar: goes into the add as a scalar operand
         now.e[k] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(
-            static_cast<uintptr_t>(mad_u24(static_cast<uint32_t>(cx[k]), kPatchPitch, lshl_add_u32_uniform(static_cast<uint32_t>(cy[k]), 1, K)))));
+            static_cast<uintptr_t>(patch_address(static_cast<uint32_t>(cx[k]), static_cast<uint32_t>(cy[k]), K))));
       }
     } else {
 #pragma unroll
@@ -1497,7 +1533,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
         now.e[k] = static_cast<uint32_t>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, (static_cast<uint32_t>(xc) << 4) + row, 0, 0))) | opaque_zero;
       }
     }
-    now.redo = __builtin_amdgcn_ballot_w64(lowest < 4u) != 0 ? 1u : 0u;
+    now.redo = __builtin_amdgcn_ballot_w64(lowest < 4u);
   };
   auto run = [&](auto is_loose) {
     Lookups a, c;
@@ -1511,18 +1547,21 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
       coop_store(patch_base, piece0);
     }
     uint32_t rotor = patch_base;  // (group 0's buffer)
+    scan_ptr_t cursor = (scan_ptr_t)(pts + 2 * b_begin);
+    Plan carried{0u, 0u, 0u};
+    if constexpr (!decltype(is_loose)::value) plan_of(0, carried);
     uint32_t g;
     if (groups & 1) {
-      step(is_loose, std::false_type{}, 0, a, a, piece, rotor);
+      step(is_loose, std::false_type{}, 0, a, a, piece, rotor, cursor, carried);
       g = 1;
     } else {
-      step(is_loose, std::false_type{}, 0, c, c, piece, rotor);
-      step(is_loose, std::true_type{}, 1, a, c, piece, rotor);
+      step(is_loose, std::false_type{}, 0, c, c, piece, rotor, cursor, carried);
+      step(is_loose, std::true_type{}, 1, a, c, piece, rotor, cursor, carried);
       g = 2;
     }
     for (; g < groups; g += 2) {  // `a` holds group g - 1
-      step(is_loose, std::true_type{}, g, c, a, piece, rotor);
-      step(is_loose, std::true_type{}, g + 1, a, c, piece, rotor);
+      step(is_loose, std::true_type{}, g, c, a, piece, rotor, cursor, carried);
+      step(is_loose, std::true_type{}, g + 1, a, c, piece, rotor, cursor, carried);
     }
     consume(a, b_begin + 8 * groups - 8);
   };

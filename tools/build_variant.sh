@@ -1,8 +1,9 @@
 #!/bin/bash
 # Builds a measurement variant of libbeluga_mcl.so with extra compiler flags into build/variants/<name>/ (never the product
-# library): tools/build_variant.sh <name> "<flags>" [r04];  use with BELUGA_MCL_LIB=build/variants/<name>/libbeluga_mcl.so
+# library): tools/build_variant.sh <name> "<flags>" [r04 | <git revision>];  use with BELUGA_MCL_LIB=build/variants/<name>/libbeluga_mcl.so
 #
-# Third argument "r04": the variant is built from ROUND 4's sources (git commit 83dc34d - kernels.hip, context.hip, kernels.h with the
+# Third argument: a git revision whose sources the variant is built from (A/B against an earlier tree on the same box).
+# "r04": the variant is built from ROUND 4's sources (git commit 83dc34d - kernels.hip, context.hip, kernels.h with the
 # ablation / timing / statistics blocks the measurement scripts of rounds 2 - 4 drive: -DMCL_ABLATE, -DMCL_LF_TIMING, -DMCL_PIPE_ABLATE,
 # -DMCL_DRAW_ABLATE, -DMCL_BEAM_STATS, -DMCL_BEAM_ABLATE, -DMCL_PATCH_LDS_PAD, k_reweight_lf_pipe, the LDS-direct lf_producer = 0 form).
 # Round 5 took those blocks out of the product's kernels.hip; the numbers in profiles/r0[2-4]_* were measured on that tree.
@@ -13,15 +14,16 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/build/variants/$name
 mkdir -p $out
 src=$root/beluga_amd/csrc
-if [ "$tree" = "r04" ]; then
-  src=$out/src_r04
+if [ -n "$tree" ]; then
+  rev=$tree; [ "$tree" = "r04" ] && rev=83dc34d
+  src=$out/src_$tree
   mkdir -p $src
-  for f in kernels.hip context.hip kernels.h se2.h rng.h map_build.h map_build.cpp; do git -C $root show 83dc34d:beluga_amd/csrc/$f > $src/$f; done
-  git -C $root show 83dc34d:include/beluga_mcl.h > $src/beluga_mcl.h
+  for f in kernels.hip context.hip kernels.h se2.h rng.h map_build.h map_build.cpp; do git -C $root show $rev:beluga_amd/csrc/$f > $src/$f; done
+  git -C $root show $rev:include/beluga_mcl.h > $src/beluga_mcl.h
 fi
 common="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -I$src -I$root/include -DMCL_MEASUREMENT_BUILD $flags"
 /opt/rocm/bin/hipcc $common -x hip -c $src/kernels.hip -o $out/kernels.o
-if [ "$tree" = "r04" ]; then
+if [ -n "$tree" ]; then
   /opt/rocm/bin/hipcc $common -x hip -c $src/context.hip -o $out/context.o
   /opt/rocm/bin/hipcc $common -c $src/map_build.cpp -o $out/map_build.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libbeluga_mcl.so $out/kernels.o $out/context.o $out/map_build.o
