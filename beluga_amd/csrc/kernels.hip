@@ -1381,10 +1381,12 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   const double e_ct = fast ? ict : 0.0, e_st = fast ? ist : 0.0, e_xm = fast ? ixm : 1572864.0, e_ym = fast ? iym : 1572864.0;
   const int c_lo = static_cast<int>(kFastBias) - 1, x_hi = static_cast<int>(kFastBias + f.W), y_hi = static_cast<int>(kFastBias + f.H);
   const uint32_t row_bias = 4u - (kFastBias << 2);  // LDS byte address of the row entry = (biased y << 2) + row_bias
-  // Palette addresses are kept 32 bits wide from the load on: ds_read_u16 / buffer_load_ushort zero-extend for free.  The
-  // gathered look-ups are OR-ed with a zero the compiler cannot see through (pal_bytes < 2^31): without it the two sources
-  // are merged as 16-bit values and every look-up pays a v_and_b32 to widen it again (8 per group on the LDS path).
-  const uint32_t opaque_zero = f.pal_bytes >> 31;
+  // Palette addresses are kept 32 bits wide from the load on: the LDS look-ups SIGN-extend (ds_read_i16), the gathered ones zero-extend
+  // (buffer_load_ushort) - the same value either way, as this kernel's palette lies below 32 KB of LDS (its workgroup memory is
+  // pal_lds + 34 KB <= 64 KB).  Were both zero extensions, the compiler would merge the two sources as 16-bit values and every look-up
+  // would pay a v_and_b32 to widen it again (8 per group on the LDS path); rounds 2 - 4 kept them apart by OR-ing the gathered value
+  // with an opaque zero - an instruction that USES the value where it is loaded, i.e. a wait for every gather right behind its issue
+  // instead of one step later: what made a gathered group cost 2.4 x a patched one.
   struct Lookups {
     uint32_t e[8];  // palette addresses (LDS byte addresses of the f64 terms)
     uint64_t redo;  // nonzero (the lanes with an end-point on a cell boundary): the group is added by add_exact instead
@@ -1449,8 +1451,13 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   // `carried`: the plan entry of group g on entry, that of group g + 1 on exit - read in the middle of the step, in front of the group's
   // look-ups: the wait for an LDS read is a wait for every LDS read issued before it, and a plan entry read at a step's start would
   // make the wave sit out the look-ups it has just issued in front of the barrier instead of behind the next end-points.
-  auto step = [&](auto is_loose, auto add_before, uint32_t g, Lookups& now, const Lookups& before, uint4& piece, uint32_t& rotor, scan_ptr_t& cursor,
-                  Plan& carried) {
+  // `in_loop`: the step is one of the main loop's, not one of the two in front of it - the gathered look-ups of the former extend with
+  // zeros, those of the latter with the sign (the same value: palette addresses are below 2^15).  A lane's look-up registers are
+  // loop-carried; while every value that flows into them is a ZERO extension of a 16-bit load - which is all an all-gathering workgroup
+  // has - the compiler carries them as 16-bit values and widens each behind its load: an instruction that uses the gather right where it
+  // is issued, i.e. a memory latency per step in the open instead of one hidden behind the next group's end-points.
+  auto step = [&](auto is_loose, auto add_before, auto in_loop, uint32_t g, Lookups& now, const Lookups& before, uint4& piece, uint32_t& rotor,
+                  scan_ptr_t& cursor, Plan& carried) {
     const Plan plan = carried;
     const uint32_t buffer = rotor;
     rotor = buffer + kPatchBytes == patch_base + kPatchBuffers * kPatchBytes ? patch_base : buffer + kPatchBytes;
@@ -1515,22 +1522,27 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t at = patch_address(static_cast<uint32_t>(cx[k]), static_cast<uint32_t>(cy[k]), K);
-        now.e[k] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(static_cast<uintptr_t>(at)));
-      }
-    } else if (plan.meta != 0u) {  // two halves: the beams from plan.meta on read the second one
-      const uint32_t KA = buffer + plan.ka, KB = buffer + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_plan_k[g].z));
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t K = static_cast<uint32_t>(k) < plan.meta ? KA : KB;  // scalar: goes into the add as a scalar operand
-        now.e[k] = static_cast<uint32_t>(*reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(
-            static_cast<uintptr_t>(patch_address(static_cast<uint32_t>(cx[k]), static_cast<uint32_t>(cy[k]), K))));
+        now.e[k] = static_cast<uint32_t>(static_cast<int32_t>(*reinterpret_cast<__attribute__((address_space(3))) const int16_t*>(static_cast<uintptr_t>(at))));
       }
     } else {
+      // (one `else` for the two rare forms: the common one falls through a single scalar branch)
+      if (plan.meta != 0u) {  // two halves: the beams from plan.meta on read the second one
+        const uint32_t KA = buffer + plan.ka, KB = buffer + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_plan_k[g].z));
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int xc = med3_i32(cx[k], c_lo, x_hi), yc = med3_i32(cy[k], c_lo, y_hi);
-        const uint32_t row = *reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>((static_cast<uint32_t>(yc) << 2) + row_bias));
-        now.e[k] = static_cast<uint32_t>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, (static_cast<uint32_t>(xc) << 4) + row, 0, 0))) | opaque_zero;
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t K = static_cast<uint32_t>(k) < plan.meta ? KA : KB;  // scalar: goes into the add as a scalar operand
+          now.e[k] = static_cast<uint32_t>(static_cast<int32_t>(*reinterpret_cast<__attribute__((address_space(3))) const int16_t*>(
+              static_cast<uintptr_t>(patch_address(static_cast<uint32_t>(cx[k]), static_cast<uint32_t>(cy[k]), K)))));
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int xc = med3_i32(cx[k], c_lo, x_hi), yc = med3_i32(cy[k], c_lo, y_hi);
+          const uint32_t row = *reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>((static_cast<uint32_t>(yc) << 2) + row_bias));
+          const auto raw = __builtin_amdgcn_raw_buffer_load_b16(rsrc, (static_cast<uint32_t>(xc) << 4) + row, 0, 0);
+          if constexpr (decltype(in_loop)::value) now.e[k] = static_cast<uint32_t>(static_cast<uint16_t>(raw));
+          else now.e[k] = static_cast<uint32_t>(static_cast<int32_t>(static_cast<int16_t>(raw)));
+        }
       }
     }
     now.redo = __builtin_amdgcn_ballot_w64(lowest < 4u);
@@ -1552,16 +1564,16 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
     if constexpr (!decltype(is_loose)::value) plan_of(0, carried);
     uint32_t g;
     if (groups & 1) {
-      step(is_loose, std::false_type{}, 0, a, a, piece, rotor, cursor, carried);
+      step(is_loose, std::false_type{}, std::false_type{}, 0, a, a, piece, rotor, cursor, carried);
       g = 1;
     } else {
-      step(is_loose, std::false_type{}, 0, c, c, piece, rotor, cursor, carried);
-      step(is_loose, std::true_type{}, 1, a, c, piece, rotor, cursor, carried);
+      step(is_loose, std::false_type{}, std::false_type{}, 0, c, c, piece, rotor, cursor, carried);
+      step(is_loose, std::true_type{}, std::false_type{}, 1, a, c, piece, rotor, cursor, carried);
       g = 2;
     }
     for (; g < groups; g += 2) {  // `a` holds group g - 1
-      step(is_loose, std::true_type{}, g, c, a, piece, rotor, cursor, carried);
-      step(is_loose, std::true_type{}, g + 1, a, c, piece, rotor, cursor, carried);
+      step(is_loose, std::true_type{}, std::true_type{}, g, c, a, piece, rotor, cursor, carried);
+      step(is_loose, std::true_type{}, std::true_type{}, g + 1, a, c, piece, rotor, cursor, carried);
     }
     consume(a, b_begin + 8 * groups - 8);
   };
