@@ -292,7 +292,7 @@ struct mcl_ctx {
   // d_scalars[24..27), mirrored to h_scalars[28..30)); a launch that found few sends the next ones to the gather kernel,
   // with a probe every 16th launch (option lf_patch = 1).
   uint64_t lf_patch_launches{0};
-  uint64_t lf_queue_launches{0};  // of which by resident workgroups that take their blocks from a queue (k_reweight_lf_patch<*, true>)
+  uint64_t lf_queue_launches{0};  // of which by resident workgroups that take their blocks from a queue (k_reweight_lf_patch<true>)
   uint64_t patch_seen_planned{0}, patch_seen_through{0};
   bool patch_useful{true};
   int patch_probe_in{0};
@@ -1981,7 +1981,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     }
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_producer", "lf_queue_grid", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2904,7 +2904,6 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "key_warp") t.key_warp = value ? 1 : 0;
   else if (key == "key_bits_xy") t.key_bits_xy = (value >= 4 && value <= 6) ? static_cast<int>(value) : 0;
   else if (key == "lf_margin") t.lf_margin = value ? 1 : 0;
-  else if (key == "lf_producer") t.lf_producer = value ? 1 : 0;
   else if (key == "lf_queue") t.lf_queue = value ? 1 : 0;
   else if (key == "lf_ends_first") t.lf_ends_first = value ? 1 : 0;
   else if (key == "beam_free_ahead") t.beam_free_ahead = value ? 1 : 0;

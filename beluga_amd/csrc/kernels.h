@@ -143,8 +143,6 @@ struct Tuning {
                                     // function) when the frame comes from an estimate of the set, 0 = bins of equal width
   int key_bits_xy = 0;              // bits of the x / y bins of that key: 0 = chosen per cycle from the cloud's spread and the scan's
                                     // reach (4 .. 6), otherwise forced; round 2: 6 (8 heading bits)
-  int lf_producer = 1;              // LDS-patch kernel: 1 = seven waves of particles + a producer wave that copies the patches, 0 = every wave
-                                    // holds particles and copies one tile row of each patch through its registers (k_reweight_lf_patch<true>)
   int cycle_spin = 0;               // fixed-size cycles: 1 = the host waits for the cycle's own completion word (written to mapped host memory
                                     // by the last kernel, Completion) instead of the stream's completion signal; 0 = hipStreamSynchronize.
                                     // Measured: nothing at 1M particles (1489 / 1492 vs 1482 / 1496 cycles/s), 4 us per cycle SLOWER at
@@ -166,7 +164,7 @@ struct Tuning {
   int beam_sectors = 1;             // beam model, ordered kernel, scanners that reach beyond half the LDS window: the scan in four sectors, each with
                                     // a window of its own that holds its rays (0 = one centred window; the rays that leave it go on in global memory)
   int lf_queue = 1;                 // LDS-patch kernel: 1 = as many workgroups as stay resident (lf_queue_grid) take the blocks from a queue where
-                                    // there are more blocks than that (k_reweight_lf_patch<*, true>), 0 = one workgroup per block.  Bit-identical.
+                                    // there are more blocks than that (k_reweight_lf_patch<true>), 0 = one workgroup per block.  Bit-identical.
 };
 
 // Spatial ordering of the particles (kLfSortedLanes, ordered beam kernel): the 64 lanes of a wave should hold neighbouring
@@ -277,7 +275,7 @@ struct PatchStats {
   uint32_t split_patches;      // 1: a group that fits no whole patch may go through two half patches (Tuning::lf_split)
   double* weight_sums;         // optional: [workgroups] sums of the new weights, one per workgroup of the patch kernel (the
                                // normalisation's input: launch_sum_and_normalize); only written by single-segment launches
-  unsigned int* arrivals;      // the queue of blocks (k_reweight_lf_patch<*, true>): the next block to take; wraps to 0 behind a launch's last fetch
+  unsigned int* arrivals;      // the queue of blocks (k_reweight_lf_patch<true>): the next block to take; wraps to 0 behind a launch's last fetch
 };
 // *weight_sums_written (optional): how many workgroup sums of the new weights the launch left in patch_stats.weight_sums (0: none -
 // another kernel ran, or the launch was segmented)

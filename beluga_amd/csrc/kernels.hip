@@ -507,11 +507,6 @@ __device__ __forceinline__ int med3_i32(int v, int lo /* in a VGPR: one scalar o
   asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "s"(hi));
   return r;
 }
-__device__ __forceinline__ uint32_t lshl_add_u32_uniform(uint32_t a, int shift /* constant */, uint32_t b /* uniform: a scalar register */) {
-  uint32_t r;
-  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(shift), "s"(b));
-  return r;
-}
 __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b /* uniform */, uint32_t c) {  // (a mod 2^24) * (b mod 2^24) + c
   uint32_t r;
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
@@ -804,15 +799,13 @@ __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, 
 // The plan - origin and mode of every group - is made once, in the prologue, one thread per group.  Then one s_barrier per
 // group: behind barrier g the patch of group g is visible and the buffer of g - 1 is free.
 //
-// Who copies the patches (template parameter kCoop):
-//   false  seven waves of particles (448) and a PRODUCER wave without particles, which fetches every patch through its registers
-//          two groups ahead (rounds 2 - 4).  The producer occupies one of a workgroup's eight wave slots: of the 24 slots of a CU
-//          (80 registers) three hold producers, and the SIMDs that hold none carry 6 waves of arithmetic against 21 / 4 on average -
-//          the kernel, bound by vector issue, runs at the pace of those SIMDs (0.875 of the CU by construction).
-//   true   all eight waves hold particles (512) and every wave copies ONE TILE ROW of each patch - a 16-byte piece per lane:
-//          one buffer_load_dwordx4 and one ds_write_b128 per wave and group, the piece of group g + 2 in flight (4 registers) while
-//          group g is evaluated.  Four SIMDs x 6 waves of arithmetic.  The plan leaves to the gathers what would need clamping at the
-//          table's border (a patch is fetched with scalar offsets here).
+// Who copies the patches: a workgroup is seven waves of particles (448) and a PRODUCER wave without particles, which fetches every
+// patch through its registers two groups ahead.  Round 5 built the alternative - all eight waves hold particles (512) and every wave
+// copies one tile row of each patch, a 16-byte piece per lane in flight across a step: no wave slot without arithmetic, bit-identical -
+// and measured it 5 % SLOWER (0.404 against 0.382 ms on a settled cloud; profiles/r05_lf_coop_v2_ab.txt, r05_lf_diet_ab.txt): what a
+// wave's instruction stream carries per step - 5 vector, 10 scalar and 2 memory instructions for its piece - costs more than the
+// producer's idle slot.  The first version, with 45 scalar instructions per step for the piece's offsets, was 23 % slower
+// (r05_lf_coop_v1_ab.txt): every instruction of the main loop, scalar ones included, costs about 2.7 us per step at 1M particles.
 //
 // End-points: v = the reference's separately rounded (p.cos - q.sin + t) / res, cell = floor(v).  Evaluated here as
 //     s = fma(p, c', fma(-q, s', t' + M)),   c' = cos / res, s' = sin / res, t' = t / res,   M = 1.5 * 2^20 + 2^-31
@@ -831,8 +824,7 @@ constexpr uint32_t kPatchPitch = kPatchH * 2 + 16;
 static_assert(kPatchPitch == 144, "patch_address() carries the pitch as a literal");
 constexpr uint32_t kPatchBytes = kPatchW * kPatchPitch;
 constexpr int kPatchBlock = 512;                      // threads of k_reweight_lf_patch
-constexpr uint32_t kPatchParticles = kPatchBlock - 64;  // per workgroup, with a producer wave (k_reweight_lf_patch<false>)
-constexpr uint32_t kPatchParticlesAll = kPatchBlock;    // per workgroup when every wave holds particles (k_reweight_lf_patch<true>)
+constexpr uint32_t kPatchParticles = kPatchBlock - 64;  // per workgroup: seven waves of particles and a producer wave
 constexpr uint32_t kPatchPlanned = 192;               // groups with a plan entry (scans of up to 1536 points); the ones beyond are gathered
 // THREE patch buffers, so that nobody waits for its own look-ups at a group's barrier - the look-ups of group g (issued at the end of
 // step g, used in step g + 1) have returned long before the buffer of group g is written again behind barrier g + 2, whereas with
@@ -862,7 +854,7 @@ struct PatchArgs {
   uint32_t nblocks;
   uint32_t ends_first;  // 1: the blocks are taken from both ends of the order inwards
 };
-template <bool kCoop, bool kQueue = false>
+template <bool kQueue>
 __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reweight_lf_patch(PatchArgs args) {
   // The arguments are read from the kernel argument segment at the start of every block (scalar loads), its address through an empty asm
   // statement so that the loads are not hoisted out of the queue's loop (kQueue): held in registers from the kernel's entry on they would all
@@ -898,10 +890,10 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   int4* s_plan = reinterpret_cast<int4*>(smem + patch_base + kPatchBuffers * kPatchBytes);
   int4* s_plan_k = s_plan + kPatchPlanned;
   float* s_bound = reinterpret_cast<float*>(smem + patch_base + kPatchBuffers * kPatchBytes + kPatchPlanned * 32 + 16);  // [8][6]
-  constexpr uint32_t kConsumers = kCoop ? kPatchBlock / 64 : kPatchBlock / 64 - 1;  // waves that hold particles
+  constexpr uint32_t kConsumers = kPatchBlock / 64 - 1;  // waves that hold particles
   constexpr uint32_t kParticles = kConsumers * 64;
   const uint32_t wave_id = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
-  const bool producer = !kCoop && wave_id == (kPatchBlock / 64 - 1);  // a scalar branch: the roles run different loops
+  const bool producer = wave_id == (kPatchBlock / 64 - 1);  // a scalar branch: the roles run different loops
   // kQueue: the launch holds as many workgroups as the device keeps resident, and each takes blocks of the order from a counter until
   // none is left (stats.arrivals: nblocks + gridDim.x fetches per launch, the last of which wraps it to zero for the next one).  The
   // hardware deals the workgroups of a grid out to the XCDs in turn, the same number to each - at 1M particles 279 blocks for 96 slots,
@@ -1094,14 +1086,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
       y0 = (r.lo_y - margin_y) & ~7;
       return fits && r.hi_x + margin_x - x0 < PW && r.hi_y + margin_y - y0 < PH;
     };
-    // kCoop: are all PW x PH cells inside the bordered table (its border tiles hold the unknown entry: what a clamped fetch reads as
-    // well)?  Then the waves fetch with the group's scalar offsets and nothing clamps; a patch that reaches beyond is marked, and
-    // fetched by the clamping code (the grid's edges only).
-    auto inside_table = [&](int x0, int y0, int PW, int PH) -> bool {
-      const int xu = x0 - static_cast<int>(kFastBias), yu = y0 - static_cast<int>(kFastBias);
-      const int x_last = static_cast<int>((f.W + 7u) & ~7u) + 7, y_last_cell = static_cast<int>((f.H + 7u) & ~7u) + 7;
-      return xu >= -8 && xu + PW - 1 <= x_last && yu >= -8 && yu + PH - 1 <= y_last_cell;
-    };
     Range whole{INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -1153,37 +1137,14 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
     } else {
       x0a = y0a = 0;
     }
-    int clamped = 0;  // kCoop: bit 31 of the first word (biased coordinates are 0x4138....: the bit is free)
-    if constexpr (kCoop) {
-      bool inside = true;
-      if (flags == 1u) inside = inside_table(x0a, y0a, kPatchW, kPatchH);
-      else if (flags & 2u) inside = inside_table(x0a, y0a, kPatchW / 2, kPatchH) && inside_table(x0b, y0b, kPatchW / 2, kPatchH);
-      else if (flags & 4u) inside = inside_table(x0a, y0a, kPatchW, kPatchH / 2) && inside_table(x0b, y0b, kPatchW, kPatchH / 2);
-      clamped = inside ? 0 : INT_MIN;
-    }
-    s_plan[tid] = int4{x0a | clamped, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
+    s_plan[tid] = int4{x0a, y0a | static_cast<int>(flags), x0b, y0b | static_cast<int>(first_b)};
     {
       const uint32_t ka = 0u - (static_cast<uint32_t>(x0a) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0a) << 1);
       // half B lives in columns 32 .. 63 (side by side) or in rows 32 .. 63 (stacked) of the same buffer
       const uint32_t kb = ((flags & 2u) ? (kPatchW / 2) * kPatchPitch : static_cast<uint32_t>(kPatchH)) -
                           (static_cast<uint32_t>(x0b) & 0xFFFFFFu) * kPatchPitch - (static_cast<uint32_t>(y0b) << 1);
       const uint32_t meta = flags == 0u ? 0u : ((flags & 6u) ? first_b : 8u);
-      // kCoop: the entry's fourth word is the FETCH WORD of the group two steps ahead - what a wave needs to fetch its tile row of that
-      // group's patch while it evaluates this group: the table offset of the patch's first piece (a whole patch inside the bordered
-      // table: row r of it lies r * pitch further, lane l's piece 16 l further), 1 = ask the plan (halves, a patch across the table's
-      // border), 0 = no patch (the table's first bytes are fetched, and nobody reads them).  Thread g writes it into entry g - 2.
-      int* mine = reinterpret_cast<int*>(s_plan_k + tid);
-      mine[0] = static_cast<int>(ka);
-      mine[1] = static_cast<int>(meta);
-      mine[2] = static_cast<int>(kb);
-      if (!kCoop || tid + 2 >= planned) mine[3] = 0;
-      if constexpr (kCoop) {
-        uint32_t fetch_word = flags == 0u ? 0u : 1u;
-        if (flags == 1u && clamped == 0)
-          fetch_word = (static_cast<uint32_t>(x0a - static_cast<int>(kFastBias) + 8) << 4) +
-                       (static_cast<uint32_t>(y0a - static_cast<int>(kFastBias) + 8) >> 3) * f.pal_pitch;
-        if (tid >= 2) reinterpret_cast<int*>(s_plan_k + (tid - 2))[3] = static_cast<int>(fetch_word);
-      }
+      s_plan_k[tid] = int4{static_cast<int>(ka), static_cast<int>(meta), static_cast<int>(kb), 0};
     }
     mine_fits = flags != 0u;
   }
@@ -1202,24 +1163,14 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   for (uint32_t k = 0; k < kPatchBlock / 64; ++k) fitting += s_count[k];
   const bool loose = __builtin_amdgcn_readfirstlane(fitting) * 256u < groups * stats.loose_below;
   struct Plan {  // scalars
-    uint32_t ka;     // less the buffer's base
-    uint32_t meta;   // 0: gathered, 8: one whole patch, 1 .. 7: two halves, the second one from this beam on
-    uint32_t fetch;  // kCoop: the fetch word of group g + 2
+    uint32_t ka;    // less the buffer's base
+    uint32_t meta;  // 0: gathered, 8: one whole patch, 1 .. 7: two halves, the second one from this beam on
   };
   auto plan_of = [&](uint32_t g, Plan& plan) {  // g uniform; scalar results
-    plan = Plan{0u, 0u, 0u};
-    // (the groups beyond the plan read the entry behind it: zeros - gathered, nothing to fetch)
-    g = g < kPatchPlanned ? g : kPatchPlanned;
-    if constexpr (kCoop) {
-      const int4 e = s_plan_k[g];
-      plan.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.x));
-      plan.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
-      plan.fetch = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.w));
-    } else {
-      const int2 e = *reinterpret_cast<const int2*>(s_plan_k + g);
-      plan.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.x));
-      plan.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
-    }
+    // (the groups beyond the plan read the entry behind it: zeros - gathered)
+    const int2 e = *reinterpret_cast<const int2*>(s_plan_k + (g < kPatchPlanned ? g : kPatchPlanned));
+    plan.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.x));
+    plan.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(e.y));
   };
 
   // The launch's statistics (what the host picks the next launch's kernel by): groups planned and groups through a
@@ -1328,51 +1279,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
     return;
   }
 
-  // kCoop: this wave's tile row of a patch, a 16-byte piece per lane (lane = the patch's column).  Where the plan found the patch
-  // inside the bordered table (all but the grid's edges) the offsets are the group's scalars plus the lane's 16 bytes; a group without
-  // a patch (or past the last one) fetches the table's first bytes, which nobody reads: one unconditional load per step lets the
-  // compiler count the loads in flight.
-  auto coop_fetch = [&](uint32_t g, uint4& piece) {  // g uniform
-    if constexpr (kCoop) {
-      const int4 e = s_plan[g < last_planned ? g : last_planned];
-      const int ya = __builtin_amdgcn_readfirstlane(e.y), xa_word = __builtin_amdgcn_readfirstlane(e.x);
-      const int yb = __builtin_amdgcn_readfirstlane(e.w), x0b = __builtin_amdgcn_readfirstlane(e.z);
-      const int x0a = xa_word & INT_MAX;
-      const int bias = static_cast<int>(kFastBias);
-      const int r = static_cast<int>(wave_id);
-      if (xa_word < 0) {  // a patch across the table's border: columns and rows clamped like a producer's fetch (scalar branch, rare)
-        const int y_last = static_cast<int>((f.H + 7u) & ~7u);  // first row of the bottom border tiles
-        const bool half_b = (ya & 2) != 0 && lane >= static_cast<uint32_t>(kPatchW / 2);
-        const bool low = (ya & 4) != 0 && r >= kPatchH / 16;
-        const int xu = (half_b ? x0b + static_cast<int>(lane) - kPatchW / 2 : (low ? x0b : x0a) + static_cast<int>(lane)) - bias;
-        const uint32_t column = static_cast<uint32_t>(min(max(xu, -1), static_cast<int>(f.W)) + 8) << 4;
-        const int yu_a = (low ? (yb & ~7) + 8 * (r - kPatchH / 16) : (ya & ~7) + 8 * r) - bias, yu_b = (yb & ~7) + 8 * r - bias;  // scalar
-        const uint32_t row_a = palette_row_offset(min(max(yu_a, -8), y_last), f.pal_pitch) - 128u;
-        const uint32_t row_b = palette_row_offset(min(max(yu_b, -8), y_last), f.pal_pitch) - 128u;
-        piece = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, column + (half_b ? row_b : row_a), 0, 0));
-        return;
-      }
-      // (x + 8) * 16 + ((y + 8) / 8) * pitch = palette_offset(x, y) of a row y that is a multiple of 8
-      auto piece_offset = [&](int x0, int y0) -> uint32_t {  // scalar
-        return (static_cast<uint32_t>(x0 - bias + 8) << 4) + (static_cast<uint32_t>(y0 - bias + 8) >> 3) * f.pal_pitch;
-      };
-      const bool stacked_low = (ya & 4) != 0 && r >= kPatchH / 16;
-      uint32_t base_a = stacked_low ? piece_offset(x0b, (yb & ~7) + 8 * (r - kPatchH / 16)) : piece_offset(x0a, (ya & ~7) + 8 * r);
-      base_a = (ya & 1) ? base_a : 0u;
-      uint32_t voffset = lane << 4;
-      if ((ya & 2) != 0) {  // halves side by side: the lanes from 32 on fetch columns x0B + lane - 32, rows from y0B (rare: a scalar branch)
-        const uint32_t base_b = piece_offset(x0b, (yb & ~7) + 8 * r) - ((kPatchW / 2) << 4);
-        voffset += lane >= static_cast<uint32_t>(kPatchW / 2) ? base_b : base_a;
-        base_a = 0u;
-      }
-      piece = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, base_a, 0));
-    }
-  };
-  auto coop_store = [&](uint32_t buffer, const uint4& piece) {  // buffer: LDS byte address of the patch's buffer (uniform)
-    if constexpr (kCoop) *reinterpret_cast<uint4*>(smem + lane * kPatchPitch + (buffer + wave_id * 16u)) = piece;
-  };
-  const uint32_t coop_row = wave_id * f.pal_pitch;  // this wave's tile row of a patch, as a table offset
-
   double acc = (f.prob || partial) ? 0.0 : 1.0;
   // A wave that holds a far particle goes through the exact evaluation group by group - by the main loop's own means: its end-point
   // constants are replaced by ones that put every end-point ON a cell boundary (the guard word comes out zero), so that every group is
@@ -1443,7 +1349,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   };
   // One step: the end-points of group g, then the sum of the group before it (its gathers, if any, had the end-point
   // arithmetic to arrive), then the look-ups of group g.  `redo`: 1 if the group has to be added by add_exact instead.
-  // kCoop: `piece` holds this wave's tile row of the patch of group g + 1; it goes to LDS behind the barrier, and the row of g + 2 is fetched.
   // `rotor`: the buffer of group g on entry, that of group g + 1 on exit (the three buffers in turn).
   // `cursor`: the scan points of group g on entry, those of group g + 1 on exit (the constant address space: scalar loads - `pts` is no
   // kernel argument any more, of which the compiler knows that nobody writes there).
@@ -1456,29 +1361,18 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   // loop-carried; while every value that flows into them is a ZERO extension of a 16-bit load - which is all an all-gathering workgroup
   // has - the compiler carries them as 16-bit values and widens each behind its load: an instruction that uses the gather right where it
   // is issued, i.e. a memory latency per step in the open instead of one hidden behind the next group's end-points.
-  auto step = [&](auto is_loose, auto add_before, auto in_loop, uint32_t g, Lookups& now, const Lookups& before, uint4& piece, uint32_t& rotor,
+  auto step = [&](auto is_loose, auto add_before, auto in_loop, uint32_t g, Lookups& now, const Lookups& before, uint32_t& rotor,
                   scan_ptr_t& cursor, Plan& carried) {
     const Plan plan = carried;
     const uint32_t buffer = rotor;
     rotor = buffer + kPatchBytes == patch_base + kPatchBuffers * kPatchBytes ? patch_base : buffer + kPatchBytes;
     if constexpr (!decltype(is_loose)::value) {
-      // A bare barrier: no wait for this wave's outstanding LDS reads (see kPatchBuffers).  What it orders: the stores of patch g
-      // (a producer's are complete before ITS barrier: it keeps the fence; a wave's own piece - kCoop - was stored at the start of the
-      // step before, in front of the plan entry's LDS read that the step waits for: LDS operations of a wave complete in order)
-      // against the look-ups below.  The empty asm statements keep the compiler from moving memory operations across it.
+      // A bare barrier: no wait for this wave's outstanding LDS reads (see kPatchBuffers).  What it orders: the producer's stores of
+      // patch g (complete before ITS barrier: it keeps the fence) against the look-ups below.  The empty asm statements keep the
+      // compiler from moving memory operations across it.
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if constexpr (kCoop) {
-        // (16 x the lane's number from the hardware, three instructions, rather than from a register held - or spilled - across the step)
-        uint32_t lane16;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(lane16));
-        // group g + 1's piece: every wave is done with the look-ups of group g - 2, whose buffer this was (lane l's column: 144 l = 9 x 16 l)
-        *reinterpret_cast<uint4*>(smem + (__umul24(lane16, 9u) + (rotor + wave_id * 16u))) = piece;
-        asm volatile("" ::: "memory");
-        if (plan.fetch & 1u) coop_fetch(g + 2, piece);  // halves, a patch across the table's border: by the plan (a scalar branch, rare)
-        else piece = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, plan.fetch + coop_row, 0));
-      }
     }
     const scan_ptr_t q = cursor;
     cursor = q + 16;
@@ -1495,28 +1389,14 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
       cx[k] = static_cast<int>(bx >> 32);
       cy[k] = static_cast<int>(by >> 32);
     }
-#ifndef MCL_V_NO_PLAN_PREFETCH
-    int4 next_entry{0, 0, 0, 0};
-    if constexpr (!decltype(is_loose)::value) {
-      const uint32_t at = g + 1u < kPatchPlanned ? g + 1u : kPatchPlanned;  // (the groups beyond the plan read the zero entry behind it)
-      if constexpr (kCoop) next_entry = s_plan_k[at];
-      else {
-        const int2 e = *reinterpret_cast<const int2*>(s_plan_k + at);
-        next_entry.x = e.x;
-        next_entry.y = e.y;
-      }
-    }
-#endif
+    int2 next_entry{0, 0};
+    if constexpr (!decltype(is_loose)::value)
+      next_entry = *reinterpret_cast<const int2*>(s_plan_k + (g + 1u < kPatchPlanned ? g + 1u : kPatchPlanned));  // (beyond the plan: the zero entry)
     if constexpr (decltype(add_before)::value) consume(before, b_begin + 8 * g - 8);
-#ifndef MCL_V_NO_PLAN_PREFETCH
     if constexpr (!decltype(is_loose)::value) {
       carried.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(next_entry.x));
       carried.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(next_entry.y));
-      if constexpr (kCoop) carried.fetch = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(next_entry.w));
     }
-#else
-    if constexpr (!decltype(is_loose)::value) plan_of(g + 1, carried);
-#endif
     if (__builtin_expect(plan.meta == 8u, 1)) {  // one whole patch (19 groups in 20): one constant for the eight look-ups
       const uint32_t K = buffer + plan.ka;
 #pragma unroll
@@ -1549,31 +1429,22 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   };
   auto run = [&](auto is_loose) {
     Lookups a, c;
-    uint4 piece{};
-    if constexpr (kCoop && !decltype(is_loose)::value) {
-      // the patches of groups 0 and 1: the first goes to LDS here (the plan's records, which lived in the buffers, were read in front of
-      // the barrier above), the second one behind barrier 0
-      uint4 piece0;
-      coop_fetch(0, piece0);
-      coop_fetch(1, piece);
-      coop_store(patch_base, piece0);
-    }
     uint32_t rotor = patch_base;  // (group 0's buffer)
     scan_ptr_t cursor = (scan_ptr_t)(pts + 2 * b_begin);
-    Plan carried{0u, 0u, 0u};
+    Plan carried{0u, 0u};
     if constexpr (!decltype(is_loose)::value) plan_of(0, carried);
     uint32_t g;
     if (groups & 1) {
-      step(is_loose, std::false_type{}, std::false_type{}, 0, a, a, piece, rotor, cursor, carried);
+      step(is_loose, std::false_type{}, std::false_type{}, 0, a, a, rotor, cursor, carried);
       g = 1;
     } else {
-      step(is_loose, std::false_type{}, std::false_type{}, 0, c, c, piece, rotor, cursor, carried);
-      step(is_loose, std::true_type{}, std::false_type{}, 1, a, c, piece, rotor, cursor, carried);
+      step(is_loose, std::false_type{}, std::false_type{}, 0, c, c, rotor, cursor, carried);
+      step(is_loose, std::true_type{}, std::false_type{}, 1, a, c, rotor, cursor, carried);
       g = 2;
     }
     for (; g < groups; g += 2) {  // `a` holds group g - 1
-      step(is_loose, std::true_type{}, std::true_type{}, g, c, a, piece, rotor, cursor, carried);
-      step(is_loose, std::true_type{}, std::true_type{}, g + 1, a, c, piece, rotor, cursor, carried);
+      step(is_loose, std::true_type{}, std::true_type{}, g, c, a, rotor, cursor, carried);
+      step(is_loose, std::true_type{}, std::true_type{}, g + 1, a, c, rotor, cursor, carried);
     }
     consume(a, b_begin + 8 * groups - 8);
   };
@@ -1606,9 +1477,6 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
       for (uint32_t k = 1; k < kConsumers; ++k) total += s_sum[k];
       stats.weight_sums[block] = total;
     }
-  }
-  if constexpr (kCoop) {
-    if (wave_id == kPatchBlock / 64 - 1) report();
   }
   if constexpr (!kQueue) break;
   }  // the next block of the queue
@@ -4236,8 +4104,7 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
       const uint32_t patch_base = (static_cast<uint32_t>(pal_lds) + 15u) & ~15u;
       const size_t patch_lds = patch_base + kPatchLdsBytes;
       if (fast && use_patches && patch_lds <= 65536) {
-        const bool coop = tuning.lf_producer == 0;  // every wave holds particles and copies its tile row of the patches
-        const uint32_t per_group = coop ? kPatchParticlesAll : kPatchParticles;
+        const uint32_t per_group = kPatchParticles;
         const unsigned groups_x = static_cast<unsigned>((n + per_group - 1) / per_group);
         if (segments > 1) patch_stats.weight_sums = nullptr;  // the segments' sums are combined by k_lf_combine
         // A queue of blocks and as many workgroups as stay resident (three per CU) instead of a workgroup per block, where the launch
@@ -4248,11 +4115,9 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
                              tuning.lf_ends_first != 0 ? 1u : 0u};
         if (tuning.lf_queue != 0 && segments == 1 && patch_stats.arrivals != nullptr && groups_x > resident) {
           if (queue_used) *queue_used = true;
-          if (coop) hipLaunchKernelGGL((k_reweight_lf_patch<true, true>), dim3(resident), dim3(kPatchBlock), patch_lds, st, args);
-          else hipLaunchKernelGGL((k_reweight_lf_patch<false, true>), dim3(resident), dim3(kPatchBlock), patch_lds, st, args);
+          hipLaunchKernelGGL(k_reweight_lf_patch<true>, dim3(resident), dim3(kPatchBlock), patch_lds, st, args);
         } else {
-          if (coop) hipLaunchKernelGGL((k_reweight_lf_patch<true, false>), dim3(groups_x, segments), dim3(kPatchBlock), patch_lds, st, args);
-          else hipLaunchKernelGGL((k_reweight_lf_patch<false, false>), dim3(groups_x, segments), dim3(kPatchBlock), patch_lds, st, args);
+          hipLaunchKernelGGL(k_reweight_lf_patch<false>, dim3(groups_x, segments), dim3(kPatchBlock), patch_lds, st, args);
         }
         if (weight_sums_written && patch_stats.weight_sums) *weight_sums_written = groups_x;
       }

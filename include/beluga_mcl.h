@@ -415,9 +415,6 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                   same number of particles; 0 = equal width (round 2)
  *   key_bits_xy (0) bits of the x and of the y bins of that key (the heading gets the other 20 - 2 b): 0 = chosen every cycle from
  *                   the cloud's spread and the scan's reach (4 .. 6), 4 / 5 / 6 = forced (round 2: 6)
- *   lf_producer (1) LDS-patch kernel: 1 = seven waves of particles (448) and a producer wave per workgroup, which copies the patches;
- *                   0 = eight waves of particles (512), each copying one tile row of every patch through its registers (no wave slot
- *                   without arithmetic: all four SIMDs of a CU carry six waves of it)
  *   lf_queue (1)    LDS-patch kernel, launches with more blocks than the device keeps workgroups resident (three per CU): 1 = that many
  *                   workgroups, each taking blocks from a counter until none is left (an XCD that is ahead takes more:
  *                   2 - 4 % off the kernel at 1M particles), 0 = one workgroup per block.  Which workgroup computes a block changes

@@ -57,18 +57,16 @@ def _check_cycle(c, g, o, gi, oi, n, differing_mass):
     np.testing.assert_allclose(g[1], o[1], rtol=1e-8, atol=1e-11 + 4.0 * slack, err_msg=f"cycle {c}: covariance")
 
 
-@pytest.mark.parametrize("producer", [1, 0])
-def test_headline_config_1m_x_1080_over_the_timed_window_against_the_oracle(producer):
+def test_headline_config_1m_x_1080_over_the_timed_window_against_the_oracle():
     """BASELINE configs[1] exactly as bench.py builds and times it: 1M particles, 1080 beams, 4000^2 map (seed 42), multinomial
     resample every cycle, device-side recovery estimator, the LDS-patch kernel with its queue of blocks.  25 cycles = the driver's
-    5 warm-up cycles and the 20 it times (with a producer wave per workgroup, and with every wave copying its tile row of the patches):
+    5 warm-up cycles and the 20 it times:
     the mix of patched, half-patched, gathered groups and of workgroups that gather everything changes over them as the cloud
     converges, and every cycle is compared - decisions, normaliser, estimate, the particle set."""
     cycles, n = 25, 1_000_000
     cells, truth, odoms, scans, _poses = bench.make_workload(cycles)
     params = AmclParams(min_particles=n, max_particles=n)
     grid, gpu, cpu = _filters(cells, params)
-    gpu.set_option("lf_producer", producer)
     cov = np.diag([0.25, 0.25, 0.04])
     gpu.initialize(truth, cov)
     cpu.initialize(truth, cov)

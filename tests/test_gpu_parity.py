@@ -1243,9 +1243,8 @@ def test_reweight_lf_fma_variant_is_bit_identical(fast):
     f.close()
 
 
-@pytest.mark.parametrize("producer", [1, 0])
 @pytest.mark.parametrize("n", [16_384, 66_667, 200_000, 300_000])
-def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n, producer):
+def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n):
     """The default LF kernel reads the index table through per-workgroup LDS patches wherever a bound on the workgroup's
     spread proves the look-ups inside one (k_reweight_lf_patch, forced by option lf_patch = 2); lf_patch = 0 gathers every look-up.
     Same cells, same sums: the weights are identical bit for bit - here on a small map, where a wide initial cloud puts
@@ -1261,7 +1260,6 @@ def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n, produc
         for patch in (2, 0):  # always / never
             f = new_filter(grid, n)
             f.set_option("lf_patch", patch)
-            f.set_option("lf_producer", producer)
             f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
             states, w0 = f.particles()
             f.reweight(pts)
@@ -1273,16 +1271,14 @@ def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n, produc
         assert np.array_equal(weights[0], weights[1]), (n, beams, int((weights[0] != weights[1]).sum()))
 
 
-@pytest.mark.parametrize("producer", [1, 0])
 @pytest.mark.parametrize("n,grid_wgs", [(300_000, 7), (300_000, 64), (300_000, 669), (1_000_003, 0), (1_000_003, 96)])
-def test_reweight_lf_patch_kernel_with_a_queue_of_blocks_equals_the_gather_kernel_bit_for_bit(n, grid_wgs, producer):
-    """k_reweight_lf_patch<*, true> (option lf_queue = 1, the default where a launch has more blocks than the device keeps workgroups
+def test_reweight_lf_patch_kernel_with_a_queue_of_blocks_equals_the_gather_kernel_bit_for_bit(n, grid_wgs):
+    """k_reweight_lf_patch<true> (option lf_queue = 1, the default where a launch has more blocks than the device keeps workgroups
     resident): the workgroups of the launch take their blocks from a counter instead of one block each - which workgroup computes a
     block changes nothing in it.  Weights identical to the gather kernel's bit for bit, with the default number of workgroups (three
-    per CU) and with a few that take dozens of blocks each (option lf_queue_grid; 669 = one block short of a workgroup per block with
-    a producer wave), over wide and tight clouds and scans with a tail of beams; launch after launch (the counter wraps to zero by
-    itself); the blocks taken in order or from both ends of the order inwards (option lf_ends_first); with a producer wave per
-    workgroup and with every wave copying its tile row of the patches (option lf_producer)."""
+    per CU) and with a few that take dozens of blocks each (option lf_queue_grid; 669 = one block short of a workgroup per block),
+    over wide and tight clouds and scans with a tail of beams; launch after launch (the counter wraps to zero by itself); the blocks
+    taken in order or from both ends of the order inwards (option lf_ends_first)."""
     cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
     grid = OccupancyGrid(cells=cells, resolution=0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
     truth = synth.find_free_pose(cells, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
@@ -1296,9 +1292,7 @@ def test_reweight_lf_patch_kernel_with_a_queue_of_blocks_equals_the_gather_kerne
             f = new_filter(grid, n)
             f.set_option("lf_patch", patch)
             f.set_option("lf_queue", 1)
-            f.set_option("lf_producer", producer)
-            # (one block short of a workgroup per block: 670 blocks of 448 particles, 586 of 512)
-            f.set_option("lf_queue_grid", 585 if (grid_wgs == 669 and not producer) else grid_wgs)
+            f.set_option("lf_queue_grid", grid_wgs)
             f.set_option("lf_ends_first", 0 if grid_wgs == 64 else 1)  # the blocks in order / from both ends of the order inwards (the default)
             f.initialize(truth, np.diag([s * s for s in sigma]))
             f.reweight(pts)
@@ -1314,8 +1308,7 @@ def test_reweight_lf_patch_kernel_with_a_queue_of_blocks_equals_the_gather_kerne
         assert np.array_equal(weights[0], weights[1]), (n, beams, sigma, int((weights[0] != weights[1]).sum()))
 
 
-@pytest.mark.parametrize("producer", [1, 0])
-def test_queue_of_blocks_leaves_the_same_cycle_as_a_workgroup_per_block(producer):
+def test_queue_of_blocks_leaves_the_same_cycle_as_a_workgroup_per_block():
     """Whole cycles (the fused mcl_update: the LF kernel's per-block sums of the new weights feed the normalisation) with the queue of
     blocks and with a workgroup per block (option lf_queue = 0): estimates, weights and particle sets identical bit for bit."""
     import bench
@@ -1328,7 +1321,6 @@ def test_queue_of_blocks_leaves_the_same_cycle_as_a_workgroup_per_block(producer
         f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF),
                  AmclParams(min_particles=n, max_particles=n), seed=42)
         f.set_option("lf_queue", queue)
-        f.set_option("lf_producer", producer)
         f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
         est = []
         for c in range(cycles):
@@ -1342,14 +1334,13 @@ def test_queue_of_blocks_leaves_the_same_cycle_as_a_workgroup_per_block(producer
 
 
 @pytest.mark.parametrize("options", [
-    dict(lf_producer=1, lf_split=3, lf_margin=1, key_curve=1),  # the defaults
-    dict(lf_producer=1, lf_split=1), dict(lf_producer=1, lf_split=2), dict(lf_producer=1, lf_split=0, lf_margin=0, key_curve=0, key_bits_xy=6),
-    dict(lf_producer=0), dict(lf_producer=0, lf_margin=0, key_bits_xy=4), dict(lf_producer=1, key_bits_xy=5),
+    dict(lf_split=3, lf_margin=1, key_curve=1),  # the defaults
+    dict(lf_split=1), dict(lf_split=2), dict(lf_split=0, lf_margin=0, key_curve=0, key_bits_xy=6),
+    dict(lf_margin=0, key_bits_xy=4), dict(key_bits_xy=5),
 ])
 def test_reweight_lf_patch_planner_options_change_no_weight(options):
     """What the LDS-patch kernel's planner and the ordering decide - whole patches, half patches side by side / stacked for groups
-    that straddle a range discontinuity, the per-axis or isotropic bound, Hilbert or Morton keys and their bit split, a producer
-    wave or every wave copying its tile row of the patches - changes where a look-up is read from, never its value: the
+    that straddle a range discontinuity, the per-axis or isotropic bound, Hilbert or Morton keys and their bit split, changes where a look-up is read from, never its value: the
     weights equal the gather kernel's bit for bit, on a cloud wide enough to put patches across the grid's edges, and on a
     tight one where nearly every group goes through a patch (and the planner's statistics say so)."""
     cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)

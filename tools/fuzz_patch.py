@@ -25,7 +25,7 @@ for case in range(cases):
     n = int(rng.choice([16_384, 20_000, 66_667, 131_072, 250_000, 300_000, 524_288]))  # (from 262 144 on: one scan segment, the queue applies)
     sig = (float(rng.choice([0.02, 0.1, 0.3, 0.8])), float(rng.choice([0.02, 0.1, 0.3, 0.8])), float(rng.choice([0.01, 0.05, 0.15, 0.5])))
     opts = dict(lf_split=int(rng.integers(0, 4)), lf_margin=int(rng.integers(0, 2)), key_curve=int(rng.integers(0, 2)),
-                key_warp=int(rng.integers(0, 2)), key_bits_xy=int(rng.choice([0, 4, 5, 6])), lf_producer=int(rng.integers(0, 2)),
+                key_warp=int(rng.integers(0, 2)), key_bits_xy=int(rng.choice([0, 4, 5, 6])), 
                 lf_loose_below=int(rng.choice([0, 128, 224, 257])),
                 # the queue of blocks, with few resident workgroups so that every one takes many blocks (0 = three per CU: a workgroup per block here)
                 lf_queue=int(rng.integers(0, 2)), lf_ends_first=int(rng.integers(0, 2)), lf_queue_grid=int(rng.choice([0, 1, 5, 37, 200])))
