@@ -303,7 +303,7 @@ struct mcl_ctx {
   uint64_t lf_far_launches{0};     // launches of the gather kernel with the far-tile bitmap (dispersed sets)
   // scratch of the spatial ordering
   DeviceBuffer<uint32_t> d_route_u32;           // scratch of mcl_route_targets
-  DeviceBuffer<uint32_t> d_sort_u32;            // keys[cap] perm[cap] table[1024 * nblocks] totals[1024]
+  DeviceBuffer<uint32_t> d_sort_u32;            // keys[cap] perm[cap] table[1024 * nblocks] totals[1024] bases[1024] flags[16]
   DeviceBuffer<unsigned long long> d_sort_u64;  // keyidx[cap]
   DeviceBuffer<double> d_sort_f64;              // frame[8] bbox[8 + 6*nblocks] partial[...]
 
@@ -459,7 +459,7 @@ mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
   {
     static_assert(sizeof(KeyFrame) <= 8 * sizeof(double), "the key frame sits in the first 8 doubles of d_sort_f64");
     const size_t table = static_cast<size_t>(kSortDigits) * num_chunks(cap);
-    MCL_HIP(ctx, ctx->d_sort_u32.ensure(2 * cap + table + kSortDigits));
+    MCL_HIP(ctx, ctx->d_sort_u32.ensure(2 * cap + table + 2 * kSortDigits + 16));
     MCL_HIP(ctx, ctx->d_sort_u64.ensure(cap));
     MCL_HIP(ctx, ctx->d_sort_f64.ensure(8 + 8 + 6 * static_cast<size_t>(chunks) + kLfMaxSegments * std::min<uint64_t>(cap, kLfSegmentedBelow)));
   }

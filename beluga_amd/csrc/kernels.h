@@ -241,7 +241,8 @@ struct SortScratch {
   uint32_t* keys;                // [n] key of particle i
   uint32_t* perm;                // [n] sorted position -> particle index
   uint32_t* table;               // [kSortDigits][nblocks] block histograms -> exclusive offsets (reused by both passes)
-  uint32_t* totals;              // [kSortDigits] digit totals
+  uint32_t* totals;              // [kSortDigits] digit totals, then [kSortDigits] their exclusive scan (the buckets' first positions) and
+                                 // [16] flags ([0]: some bucket is beyond kSortHugeBucket) - written by the first pass's first workgroup
   unsigned long long* keyidx;    // [n] (high digit << 32 | index) after the first pass
   double* bbox;                  // [8] min/max of x, y, relative heading (+ [6 * nblocks] partials behind it)
   KeyFrame* frame;               // key frame derived from the bounding box (device-resident fallback)

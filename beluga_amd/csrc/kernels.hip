@@ -76,13 +76,17 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], double* s_scratch /
     for (int k = 0; k < K; ++k) s_scratch[wave * K + k] = v[k];
   }
   __syncthreads();
+  // The waves' partial sums of value k are added by thread k, waves in order (one thread adding all K columns held K x waves values in
+  // registers at once: 60 bytes of scratch per lane in the draw kernel).  Thread k touches column k only.
+  if (threadIdx.x < K) {
+    double acc = s_scratch[threadIdx.x];
+    for (int w = 1; w < kThreads / 64; ++w) acc += s_scratch[w * K + threadIdx.x];
+    s_scratch[threadIdx.x] = acc;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      double acc = s_scratch[k];
-      for (int w = 1; w < kThreads / 64; ++w) acc += s_scratch[w * K + k];
-      v[k] = acc;
-    }
+    for (int k = 0; k < K; ++k) v[k] = s_scratch[k];
   }
   __syncthreads();
 }
@@ -1684,15 +1688,27 @@ __device__ __forceinline__ unsigned long long same_digit_lanes(uint32_t digit, b
 // cross-wave step until every wave has ranked its part.  Out: (low digit << 32 | particle) at the element's place in its
 // bucket - the buckets hold their particles in index order.
 constexpr int kStable = 512;  // 8 waves x 256 elements: 48 KB of LDS counters per workgroup
+constexpr uint32_t kSortHugeBucket = 65535;  // a bucket beyond this is not sorted by its low digit (k_sort_buckets)
 __global__ __launch_bounds__(kStable) void k_sort_scatter_high(const uint32_t* __restrict__ keys, uint64_t n,
                                                               const uint32_t* __restrict__ table, uint32_t nblocks,
-                                                              const uint32_t* __restrict__ totals, unsigned long long* __restrict__ out) {
+                                                              const uint32_t* __restrict__ totals, unsigned long long* __restrict__ out,
+                                                              uint32_t* __restrict__ bases_out) {
   constexpr int kWaves = kStable / 64, kRounds = kChunk / kStable;
   __shared__ uint16_t wave_count[kWaves][kSortDigits];
   __shared__ uint32_t wave_base[kWaves][kSortDigits];
   __shared__ uint32_t base_of[kSortDigits], wave_sums[kWaves];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   digit_bases<kStable>(totals, base_of, wave_sums);
+  if (blockIdx.x == 0) {  // for the second pass: every bucket's first position, and whether any bucket is beyond what one workgroup sorts
+    bool huge = false;
+    for (uint32_t d = threadIdx.x; d < kSortDigits; d += kStable) {
+      bases_out[d] = base_of[d];
+      huge = huge || totals[d] > kSortHugeBucket;
+    }
+    if (threadIdx.x == 0) bases_out[kSortDigits] = 0u;
+    __syncthreads();
+    if (huge) bases_out[kSortDigits] = 1u;
+  }
   for (uint32_t d = threadIdx.x; d < kWaves * kSortDigits; d += kStable) (&wave_count[0][0])[d] = 0;
   __syncthreads();
   volatile uint16_t* mine = wave_count[wave];
@@ -1735,69 +1751,85 @@ __global__ __launch_bounds__(kStable) void k_sort_scatter_high(const uint32_t* _
 // Second pass: one workgroup per bucket (= high digit) sorts the bucket's particles by the low digit, stable: the order is the
 // sort by (key, particle index), the same in every run.  Two walks over the bucket, each wave over a contiguous eighth of it:
 // the first counts the digits per wave (ballots, as above), a scan turns the counts into every wave's first destination per
-// digit, the second walk ranks again and writes.  Buckets of any size (a degenerate set is one bucket); an average one holds a
-// thousand particles.
+// digit, the second walk ranks again and writes.  A wave's share of an ordinary bucket (an average one holds a thousand particles:
+// 128 per wave) stays in REGISTERS between the two walks - up to four rounds of 64; round 4 read it from global memory twice and
+// had every workgroup scan the 1024 digit totals for its bucket's first position (now left by the first pass: `bases`), 18.9 us of
+// dependent latencies for 12 MB.  Buckets of any size (a degenerate set is one bucket): longer shares are walked from memory.
 __global__ __launch_bounds__(kStable) void k_sort_buckets(const unsigned long long* __restrict__ in, const uint32_t* __restrict__ totals,
-                                                         uint32_t* __restrict__ perm) {
-  constexpr int kWaves = kStable / 64;
-  __shared__ uint32_t run[kWaves][kSortDigits];
-  __shared__ uint32_t base_of[kSortDigits], wave_sums[kWaves];
+                                                         const uint32_t* __restrict__ bases, uint32_t* __restrict__ perm) {
+  constexpr int kWaves = kStable / 64, kHeld = 4;
+  __shared__ uint16_t run16[kWaves][kSortDigits];  // per wave and digit: counts, then (as offsets from the bucket's start) destinations
+  __shared__ uint32_t wave_sums[kWaves];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  digit_bases<kStable>(totals, base_of, wave_sums);
   // A bucket far beyond the average (a degenerate set: identical poses, a zero-covariance initialisation - all of a million
   // particles in ONE bucket, which one workgroup would walk twice on its own: milliseconds) is not sorted by its low digit at
   // all: it keeps the first pass's order (by particle index), and every workgroup of the launch copies a slice of it.  Only
   // locality depends on the order, never a result; the order stays a pure function of the keys (deterministic).
-  constexpr uint32_t kHugeBucket = 65536;
-  {
-    constexpr int kPer = kSortDigits / kStable;
-    bool huge = false;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) huge = huge || totals[threadIdx.x * kPer + k] > kHugeBucket;
-    if (__syncthreads_or(huge)) {
+  if (bases[kSortDigits] != 0u) {  // (uniform: the first pass's flag)
 #pragma unroll 1
-      for (uint32_t d = 0; d < kSortDigits; ++d) {
-        const uint32_t count = totals[d];
-        if (count <= kHugeBucket) continue;  // (uniform)
-        const uint32_t from = base_of[d];
-        for (uint32_t e = blockIdx.x * kStable + threadIdx.x; e < count; e += gridDim.x * kStable) perm[from + e] = static_cast<uint32_t>(in[from + e]);
+    for (uint32_t d = 0; d < kSortDigits; ++d) {
+      const uint32_t count = totals[d];
+      if (count <= kSortHugeBucket) continue;  // (uniform)
+      const uint32_t from = bases[d];
+      for (uint32_t e = blockIdx.x * kStable + threadIdx.x; e < count; e += gridDim.x * kStable) perm[from + e] = static_cast<uint32_t>(in[from + e]);
+    }
+  }
+  const uint32_t begin = bases[blockIdx.x], size = totals[blockIdx.x];
+  if (size == 0 || size > kSortHugeBucket) return;  // (uniform)
+  const uint32_t per_wave = ((size + kWaves - 1) / kWaves + 63u) & ~63u;
+  const uint32_t first = min(wave * per_wave, size), last = min(first + per_wave, size);
+  const bool held = per_wave <= 64u * kHeld;  // (uniform over the workgroup)
+  // the wave's share, as far as it is held (loads in flight together: a round by itself would wait out a memory latency for 64 elements)
+  unsigned long long mine_v[kHeld];
+#pragma unroll
+  for (int r = 0; r < kHeld; ++r) {
+    const uint32_t at = first + 64u * r + lane;
+    mine_v[r] = (held && at < last) ? in[begin + at] : 0ull;
+  }
+  {
+    uint32_t* zero = reinterpret_cast<uint32_t*>(&run16[0][0]);
+    for (uint32_t d = threadIdx.x; d < kWaves * kSortDigits / 2; d += kStable) zero[d] = 0u;
+  }
+  __syncthreads();
+  volatile uint16_t* mine = run16[wave];
+  auto count_round = [&](uint32_t digit, bool valid) {
+    const unsigned long long same = same_digit_lanes(digit, valid);
+    if (valid && (same & ((1ull << lane) - 1ull)) == 0) mine[digit] = static_cast<uint16_t>(mine[digit] + static_cast<uint32_t>(__popcll(same)));
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (held) {
+#pragma unroll
+    for (int r = 0; r < kHeld; ++r) {
+      const uint32_t at = first + 64u * r;
+      if (at >= last) break;  // (uniform)
+      count_round(static_cast<uint32_t>(mine_v[r] >> 32), at + lane < last);
+    }
+  } else {
+    for (uint32_t at0 = first; at0 < last; at0 += 256) {
+      uint32_t digit4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t at = at0 + 64u * r;
+        digit4[r] = at + lane < last ? static_cast<uint32_t>(in[begin + at + lane] >> 32) : 0u;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t at = at0 + 64u * r;
+        if (at >= last) break;  // (uniform)
+        count_round(digit4[r], at + lane < last);
       }
     }
   }
-  const uint32_t begin = base_of[blockIdx.x], size = totals[blockIdx.x];
-  if (size == 0 || size > kHugeBucket) return;  // (uniform)
-  for (uint32_t d = threadIdx.x; d < kWaves * kSortDigits; d += kStable) (&run[0][0])[d] = 0;
   __syncthreads();
-  const uint32_t per_wave = ((size + kWaves - 1) / kWaves + 63u) & ~63u;
-  const uint32_t first = min(wave * per_wave, size), last = min(first + per_wave, size);
-  volatile uint32_t* mine = run[wave];
-  // (four rounds' loads in flight at a time: a round by itself would wait out a memory latency for 64 elements)
-  for (uint32_t at0 = first; at0 < last; at0 += 256) {
-    uint32_t digit4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t at = at0 + 64u * r;
-      digit4[r] = at + lane < last ? static_cast<uint32_t>(in[begin + at + lane] >> 32) : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t at = at0 + 64u * r;
-      if (at >= last) break;  // (uniform)
-      const bool valid = at + lane < last;
-      const unsigned long long same = same_digit_lanes(digit4[r], valid);
-      if (valid && (same & ((1ull << lane) - 1ull)) == 0) mine[digit4[r]] = mine[digit4[r]] + static_cast<uint32_t>(__popcll(same));
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  __syncthreads();
-  // counts -> first destinations: digits in order, inside a digit the waves in order
+  // counts -> first destinations (offsets from the bucket's start; a bucket holds at most 65535): digits in order, inside a digit the
+  // waves in order
   {
     constexpr int kPer = kSortDigits / kStable;
     uint32_t total[kPer], sum = 0;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       total[k] = 0;
-      for (int q = 0; q < kWaves; ++q) total[k] += run[q][threadIdx.x * kPer + k];
+      for (int q = 0; q < kWaves; ++q) total[k] += run16[q][threadIdx.x * kPer + k];
       sum += total[k];
     }
     uint32_t incl = sum;
@@ -1806,43 +1838,53 @@ __global__ __launch_bounds__(kStable) void k_sort_buckets(const unsigned long lo
       const uint32_t up = __shfl_up(incl, o);
       if (lane >= static_cast<uint32_t>(o)) incl += up;
     }
-    __syncthreads();  // (wave_sums was read by digit_bases)
     if (lane == 63) wave_sums[wave] = incl;
     __syncthreads();
-    uint32_t prefix = begin + incl - sum;
+    uint32_t prefix = incl - sum;
     for (uint32_t q = 0; q < wave; ++q) prefix += wave_sums[q];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       uint32_t at = prefix;
       for (int q = 0; q < kWaves; ++q) {
-        const uint32_t c = run[q][threadIdx.x * kPer + k];
-        run[q][threadIdx.x * kPer + k] = at;
+        const uint32_t c = run16[q][threadIdx.x * kPer + k];
+        run16[q][threadIdx.x * kPer + k] = static_cast<uint16_t>(at);
         at += c;
       }
       prefix += total[k];
     }
   }
   __syncthreads();
-  for (uint32_t at0 = first; at0 < last; at0 += 256) {
-    unsigned long long v4[4];
+  auto place_round = [&](unsigned long long v, bool valid) {
+    const uint32_t digit = static_cast<uint32_t>(v >> 32);
+    const unsigned long long same = same_digit_lanes(digit, valid);
+    const uint32_t below = static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
+    const uint32_t to = valid ? mine[digit] : 0u;
+    if (valid) perm[begin + to + below] = static_cast<uint32_t>(v);
+    __builtin_amdgcn_wave_barrier();
+    if (valid && below == 0) mine[digit] = static_cast<uint16_t>(to + static_cast<uint32_t>(__popcll(same)));
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (held) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t at = at0 + 64u * r;
-      v4[r] = at + lane < last ? in[begin + at + lane] : 0ull;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t at = at0 + 64u * r;
+    for (int r = 0; r < kHeld; ++r) {
+      const uint32_t at = first + 64u * r;
       if (at >= last) break;  // (uniform)
-      const bool valid = at + lane < last;
-      const uint32_t digit = static_cast<uint32_t>(v4[r] >> 32);
-      const unsigned long long same = same_digit_lanes(digit, valid);
-      const uint32_t below = static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
-      const uint32_t to = valid ? mine[digit] : 0u;
-      if (valid) perm[to + below] = static_cast<uint32_t>(v4[r]);
-      __builtin_amdgcn_wave_barrier();
-      if (valid && below == 0) mine[digit] = to + static_cast<uint32_t>(__popcll(same));
-      __builtin_amdgcn_wave_barrier();
+      place_round(mine_v[r], at + lane < last);
+    }
+  } else {
+    for (uint32_t at0 = first; at0 < last; at0 += 256) {
+      unsigned long long v4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t at = at0 + 64u * r;
+        v4[r] = at + lane < last ? in[begin + at + lane] : 0ull;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t at = at0 + 64u * r;
+        if (at >= last) break;  // (uniform)
+        place_round(v4[r], at + lane < last);
+      }
     }
   }
 }
@@ -4069,8 +4111,9 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
   const dim3 rows(kSortDigits / (kBlock / 64));
   hipLaunchKernelGGL(k_row_scan, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
   hipLaunchKernelGGL(k_sort_scatter_high, dim3(nblocks), dim3(kStable), 0, st, sort->keys, n, sort->table, nblocks, sort->totals,
-                     sort->keyidx);
-  hipLaunchKernelGGL(k_sort_buckets, dim3(kSortDigits), dim3(kStable), 0, st, sort->keyidx, sort->totals, sort->perm);
+                     sort->keyidx, sort->totals + kSortDigits);
+  hipLaunchKernelGGL(k_sort_buckets, dim3(kSortDigits), dim3(kStable), 0, st, sort->keyidx, sort->totals, sort->totals + kSortDigits,
+                     sort->perm);
 }
 
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,

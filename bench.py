@@ -69,6 +69,7 @@ def calibrated_issue_cycles():
 
 
 IN_RUN_COUNTERS = {}  # filled by collect_in_run_counters(): {counter: per-launch average of the LF kernel}, measured by this very run
+IN_RUN_BY_KERNEL = {}  # {kernel: {counter: per-launch average, "avg_us": launch duration, "calls": launches}}: every kernel of the cycle
 
 
 def lf_kernel_counters(kernel="k_reweight_lf_patch"):
@@ -163,17 +164,56 @@ def collect_in_run_counters(timeout_s=150):
                     return f"rocprofv3 pass '{counters}' failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-200:]}"
                 db = sqlite3.connect(db_path)
                 rows = db.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name").fetchall()
+                try:  # launch durations of the same pass (its kernel trace): microseconds
+                    durations = db.execute("select name, total_calls, average from top_kernels").fetchall()
+                except sqlite3.Error:
+                    durations = []
                 db.close()
+
+                def short(name):
+                    return name.replace("mcl::(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace(", ", ",")
+
                 for kernel, counter, value, launches in rows:
+                    IN_RUN_BY_KERNEL.setdefault(short(kernel), {})[counter] = float(value)
                     if "k_reweight_lf_patch" in kernel:
                         got[counter] = float(value)
                         got["launches"] = int(launches)
+                for name, calls, average in durations:
+                    rec = IN_RUN_BY_KERNEL.setdefault(short(name), {})
+                    rec.setdefault("calls", int(calls))
+                    rec["avg_us"] = min(rec.get("avg_us", float("inf")), float(average))  # (the least perturbed of the three passes)
     except Exception as exc:  # a profiler that hangs or a database of another layout: the tracked profiles serve
         return f"in-run counters failed: {exc!r}"
     if "SQ_INSTS_VALU" not in got:
         return "no LF kernel rows in the profiler's database"
     IN_RUN_COUNTERS.update(got)
     return "ok"
+
+
+def roofline_by_kernel():
+    """Every kernel of the headline cycle against the two rooflines that can bind it, from the in-run counter passes (per launch):
+    HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB; gfx950 tallies a read at half its size) against 8.0 TB/s, and the issue time of its
+    vector instructions at the datasheet's rates (f64 classes 4 cycles per wave64 instruction, the rest 2; 1024 SIMDs at 2.4 GHz);
+    `bound` = the larger of the two floors, `frac` = that floor / the launch's duration (the counter passes' own kernel trace: the
+    first 13 cycles of the filter, cloud still wide).  Kernels that ran in the passes but not in a cycle (map set-up) are left out."""
+    out = {}
+    for name, rec in sorted(IN_RUN_BY_KERNEL.items()):
+        if "avg_us" not in rec or "SQ_INSTS_VALU" not in rec or rec.get("calls", 0) < 8:
+            continue
+        f64 = sum(rec.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
+        valu = rec["SQ_INSTS_VALU"]
+        valu_floor_us = (f64 * 4.0 + max(valu - f64, 0.0) * 2.0) / (SIMDS * CLOCK_HZ) * 1e6
+        entry = {"avg_launch_us": rec["avg_us"], "launches": rec["calls"], "valu_instructions": valu, "valu_floor_us": valu_floor_us}
+        hbm_floor_us = None
+        if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
+            hbm = (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0
+            hbm_floor_us = hbm / HBM_PEAK * 1e6
+            entry.update({"hbm_bytes": hbm, "hbm_floor_us": hbm_floor_us, "hbm_GBps": hbm / (rec["avg_us"] * 1e-6) / 1e9})
+        bound = "hbm" if (hbm_floor_us or 0.0) > valu_floor_us else "valu"
+        floor_us = max(hbm_floor_us or 0.0, valu_floor_us)
+        entry.update({"bound": bound, "frac": floor_us / rec["avg_us"] if rec["avg_us"] > 0 else None})
+        out[name] = entry
+    return out
 
 
 def pmc_child():
@@ -697,6 +737,7 @@ def main():
                                "median": float(np.median(window_rates)) if window_rates else None},
             "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in stage_prof.items()},
             "roofline": roofline,
+            "roofline_by_kernel": roofline_by_kernel() or None,
             "verified": verified,
         }
         if not args.no_other_configs and world == 1 and n_local == 1_000_000:
