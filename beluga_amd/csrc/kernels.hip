@@ -173,14 +173,17 @@ __device__ __forceinline__ void pull_scan(const double* __restrict__ src, double
   const double2* s2 = reinterpret_cast<const double2*>(src);
   double2* d2 = reinterpret_cast<double2*>(dst);
   const uint32_t pairs = doubles / 2;
-  for (uint32_t j = threadIdx.x; j < pairs; j += 4 * blockDim.x) {
-    double2 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (j + u * blockDim.x < pairs) v[u] = s2[j + u * blockDim.x];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (j + u * blockDim.x < pairs) d2[j + u * blockDim.x] = v[u];
+  // (four loads in flight per thread - the reads cross PCIe -, in four named registers with clamped addresses: as an array with
+  // conditional elements it was a private object of 64 bytes per thread, which the compiler promoted to workgroup memory - 64 KB per
+  // workgroup of k_propagate, for a copy its last workgroup alone makes)
+  const uint32_t stride = blockDim.x, last = pairs ? pairs - 1 : 0;
+  for (uint32_t j = threadIdx.x; j < pairs; j += 4 * stride) {
+    const uint32_t j1 = j + stride, j2 = j + 2 * stride, j3 = j + 3 * stride;
+    const double2 a = s2[j], b = s2[j1 < last ? j1 : last], c = s2[j2 < last ? j2 : last], d = s2[j3 < last ? j3 : last];
+    d2[j] = a;
+    if (j1 < pairs) d2[j1] = b;
+    if (j2 < pairs) d2[j2] = c;
+    if (j3 < pairs) d2[j3] = d;
   }
   if ((doubles & 1u) && threadIdx.x == 0) dst[doubles - 1] = src[doubles - 1];
 }
@@ -200,10 +203,14 @@ __global__ __launch_bounds__(kBlock) void k_pull_scan(const double* __restrict__
 //    inside the FMA; |theta| < 1e6, anything else - NaN included - goes to the library), fdlibm's kernel polynomials on
 //    [-pi/4, pi/4] (k_sin.c, k_cos.c: 1.1e-16 / 1.4e-16 absolute against long double, checked over 2M points);
 //  * z / |z| as z * rsqrt(|z|^2): v_rsq_f64 and two Newton steps instead of hypot and two divisions.
+// (out of line: inlined at its four call sites per particle, the library's argument reduction brought 64 bytes of workgroup memory per
+// thread - its private arrays, promoted - and its registers into a path that an angle beyond a million radians alone takes)
+__device__ __attribute__((noinline)) double2 sincos_library(double theta) { return double2{sin(theta), cos(theta)}; }
 __device__ __forceinline__ void sincos_fast(double theta, double& s, double& c) {
   if (!(fabs(theta) < 1.0e6)) {
-    s = sin(theta);
-    c = cos(theta);
+    const double2 sc = sincos_library(theta);
+    s = sc.x;
+    c = sc.y;
     return;
   }
   const double kd = __builtin_rint(theta * 0x1.45f306dc9c883p-1);  // theta * 2 / pi
@@ -307,21 +314,24 @@ __global__ __launch_bounds__(kBlock) void k_propagate_small(Particles p, uint64_
   if (i < n) store_pose(p, i, propagate_one(load_pose(p, i), smp, seed, step, index_offset + i));
 }
 
+// 512 threads, four particles each: at the kernel's 100 registers a CU holds 16 waves - one workgroup of 1024 threads (round 4: 489
+// workgroups at 1M particles on 256 slots, two rounds of which the second is nine tenths full) or two of 512 (489 on 512 slots: one round).
+constexpr int kPropBlock = 512;
 template <bool kKeys>
-__global__ __launch_bounds__(kWide) void k_propagate(Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
+__global__ __launch_bounds__(kPropBlock) void k_propagate(Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
                                                       uint64_t index_offset, const double* __restrict__ scan_src,
                                                       double* __restrict__ scan_dst, uint32_t scan_doubles, KeyFrame kf,
                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ table, uint32_t nblocks) {
   __shared__ uint32_t hist[kKeys ? kSortDigits : 1];
   if (kKeys) {
-    for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) hist[d] = 0;
+    for (uint32_t d = threadIdx.x; d < kSortDigits; d += kPropBlock) hist[d] = 0;
     __syncthreads();
   }
   if (scan_dst && blockIdx.x == gridDim.x - 1) pull_scan(scan_src, scan_dst, scan_doubles);
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
 #pragma unroll 1
-  for (int k = 0; k < kChunk / kWide; ++k) {
-    const uint64_t i = base + static_cast<uint64_t>(k) * kWide + threadIdx.x;
+  for (int k = 0; k < kChunk / kPropBlock; ++k) {
+    const uint64_t i = base + static_cast<uint64_t>(k) * kPropBlock + threadIdx.x;
     if (i >= n) break;
     const Pose2 out = propagate_one(load_pose(p, i), smp, seed, step, index_offset + i);
     store_pose(p, i, out);
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(kWide) void k_propagate(Particles p, uint64_t n, Di
   }
   if (kKeys) {
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
+    for (uint32_t d = threadIdx.x; d < kSortDigits; d += kPropBlock) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
   }
 }
 
@@ -4081,10 +4091,10 @@ void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler 
     return;
   }
   if (sort && frame && n < (1ull << 32))
-    hipLaunchKernelGGL(k_propagate<true>, dim3(nblocks), dim3(kWide), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
+    hipLaunchKernelGGL(k_propagate<true>, dim3(nblocks), dim3(kPropBlock), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
                        scan_doubles, *frame, sort->keys, sort->table, nblocks);
   else
-    hipLaunchKernelGGL(k_propagate<false>, dim3(nblocks), dim3(kWide), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
+    hipLaunchKernelGGL(k_propagate<false>, dim3(nblocks), dim3(kPropBlock), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
                        scan_doubles, KeyFrame{}, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), nblocks);
 }
 
