@@ -208,6 +208,8 @@ struct mcl_ctx {
   bool field_built_on_device{false};
   uint64_t comm_bytes_out{0};   // bytes this rank has handed to the transport (all-gather contributions + all-to-all sends), cumulative
   uint64_t comm_collectives{0}; // collectives called, cumulative
+  uint64_t comm_host_syncs{0};  // host synchronisations inside sharded update cycles, cumulative
+  uint64_t comm_overflows{0};   // cycles whose fixed-capacity exchange overflowed and ran again with exact counts
   uint64_t comm_ranks_seen{0};  // ranks the communicator reports (ncclCommCount), or the attached world size
   int comm_backend{0};          // 0 none, 1 caller's transport, 2 RCCL inside the library
   uint64_t cluster_cells{0};  // occupied cells of the last cluster_based_estimate on this context (before the merge over shards)
@@ -1064,13 +1066,15 @@ mcl_status do_estimate_sums(mcl_ctx* ctx, const double pivot[2], double sums[12]
 
 
 // ---- particle shards: the cycle over a communicator --------------------------------------------------------------------
-constexpr size_t kCommScalars = 16;  // d_comm_f64[0] local sum | [1] cdf total | [2] norm sum | [3] norm sumsq | [4] global sum | [5..14) estimate sums
+constexpr size_t kCommScalars = 20;  // d_comm_f64[0] local sum | [1] cdf total | [2] norm sum | [3] norm sumsq | [4] global sum | [5..14) estimate sums |
+                                     // [14] this rank's overflow flag of the fixed-capacity exchange (gathered with the sums) | [16..18) the shard plan
+constexpr size_t kEstRecord = 10;    // doubles a rank contributes to the estimate's all-gather: nine sums + the overflow flag
 
 mcl_status comm_scratch(mcl_ctx* ctx) {
   const size_t world = ctx->comm_world;
-  MCL_HIP(ctx, ctx->d_comm_f64.ensure(kCommScalars + world * (1 + 3 + 2 + 9)));
+  MCL_HIP(ctx, ctx->d_comm_f64.ensure(kCommScalars + world * (1 + 3 + 2 + kEstRecord)));
   MCL_HIP(ctx, ctx->d_comm_i64.ensure(world + world * world));
-  if (!ctx->h_comm) MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_comm), (kCommScalars + 64 * (1 + 3 + 2 + 9) + 64 * 64 + 64) * sizeof(double)));
+  if (!ctx->h_comm) MCL_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_comm), (kCommScalars + 64 * (1 + 3 + 2 + kEstRecord) + 64 * 64 + 64) * sizeof(double)));
   return MCL_OK;
 }
 mcl_status comm_gather(mcl_ctx* ctx, const void* d_send, void* d_recv, uint64_t bytes) {
@@ -1130,7 +1134,7 @@ mcl_status comm_agree(mcl_ctx* ctx, const char* where) {
   if (const mcl_status s = comm_scratch(ctx)) return s;
   const uint32_t world = ctx->comm_world;
   long long* d_words = ctx->d_comm_i64.ptr;
-  long long* h_words = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + 9));
+  long long* h_words = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + kEstRecord));
   const uint64_t mine = comm_path_word(ctx);
   std::memcpy(h_words, &mine, sizeof(mine));
   MCL_HIP(ctx, hipMemcpyAsync(d_words, h_words, sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
@@ -1154,7 +1158,7 @@ mcl_status sharded_estimate_sums(mcl_ctx* ctx, unsigned int* t_cluster, unsigned
   if (const mcl_status s = comm_scratch(ctx)) return s;
   const uint32_t world = ctx->comm_world;
   double* d = ctx->d_comm_f64.ptr;
-  double* d_gather_est = d + kCommScalars + world * (1 + 3 + 2);  // [world][9]
+  double* d_gather_est = d + kCommScalars + world * (1 + 3 + 2);  // [world][kEstRecord]
   if (ctx->n == 0) {
     MCL_HIP(ctx, hipMemsetAsync(d + 5, 0, 9 * sizeof(double), ctx->stream));
   } else if (t_cluster) {
@@ -1164,10 +1168,12 @@ mcl_status sharded_estimate_sums(mcl_ctx* ctx, unsigned int* t_cluster, unsigned
     launch_estimate_sums(ctx->stream, ctx->cur(), ctx->n, ctx->pivot[0], ctx->pivot[1], ctx->chunk_row(0), d + 5);
   }
   MCL_HIP(ctx, hipGetLastError());
-  if (const mcl_status s = comm_gather(ctx, d + 5, d_gather_est, 9 * sizeof(double))) return s;
-  launch_sum_rows(ctx->stream, d_gather_est, world, 9, ctx->d_scalars.ptr + 8, ctx->hd_scalars + 8);
+  // (with the nine sums travels d[14]: this rank's overflow flag of the cycle's fixed-capacity exchange - their sum lands in h_scalars[17])
+  if (const mcl_status s = comm_gather(ctx, d + 5, d_gather_est, kEstRecord * sizeof(double))) return s;
+  launch_sum_rows(ctx->stream, d_gather_est, world, kEstRecord, ctx->d_scalars.ptr + 8, ctx->hd_scalars + 8);
   MCL_HIP(ctx, hipGetLastError());
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->comm_host_syncs += 1;
   for (int k = 0; k < 9; ++k) sums[k] = ctx->h_scalars[8 + k];
   sums[9] = ctx->pivot[0];
   sums[10] = ctx->pivot[1];
@@ -1321,7 +1327,7 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
     const uint32_t world = ctx->comm_world;
     constexpr size_t kRecord = 7;  // doubles per cell: key (bit pattern), weight sum, count (bit pattern), state[4]
     long long* d_counts = ctx->d_comm_i64.ptr;
-    long long* h_counts = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + 9));
+    long long* h_counts = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + kEstRecord));
     h_counts[0] = local_failure ? -1 : static_cast<long long>(m);  // -1: this rank's compaction failed
     MCL_HIP(ctx, hipMemcpyAsync(d_counts, h_counts, sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
     if (const mcl_status s = comm_gather(ctx, d_counts, d_counts + world, sizeof(long long))) return s;
@@ -1497,6 +1503,56 @@ void shard_bounds(uint64_t n_total, uint32_t world, uint32_t rank, uint64_t* fir
 // slot's point of the global CDF goes to the shard that owns it, which answers with the state.  Leaves the targets in
 // d_targets, the replies (request order) in d_replies_in and the slot of every request in d_route_order.
 // d_plan (optional): {total, random state probability} on the device (launch_shard_plan) instead of the two values.
+// Entries per pair of ranks in the fixed-capacity exchange: what a shard's m output slots ask of one other shard - m / world on average,
+// the shards' weight sums being those of equal random samples of one set - plus `permille` / 1000 - 1 of it, eight standard deviations
+// of the binomial count and 64.  Every rank derives the same number from the same arguments.
+uint64_t padded_capacity(uint64_t n_total, uint32_t world, uint32_t permille) {
+  const uint64_t m_max = (n_total + world - 1) / world;
+  const double mean = static_cast<double>(m_max) / world;
+  const double cap = mean * (permille / 1000.0) + 8.0 * std::sqrt(mean) + 64.0;
+  return (static_cast<uint64_t>(cap) + 63u) & ~63ull;
+}
+
+// The same exchange without a host read in the middle of the cycle: every pair of ranks moves `cap` entries whatever the counts are
+// (requests: cap doubles, NaN = none; replies: cap states), so that the sizes of both all-to-alls are known before anything is
+// computed.  6 % more bytes than the exact form; a rank whose requests to one shard do not fit sets its
+// overflow flag (d_comm_f64[14]), which travels with the estimate sums: sharded_update then runs the resampling again, exactly.
+// Leaves targets, replies and slots as sharded_draw does, in lists of world * cap entries.
+mcl_status sharded_draw_padded(mcl_ctx* ctx, const double* d_intervals, uint64_t first_slot, uint64_t m, const double* d_plan, uint64_t cap,
+                               uint64_t* entries_out) {
+  const uint32_t world = ctx->comm_world, rank = ctx->comm_rank;
+  const uint64_t entries = cap * world;
+  MCL_REQUIRE(ctx, entries < (1ull << 32), "too many exchange entries");
+  long long* d_counts = ctx->d_comm_i64.ptr;  // [world] (not read by the host here)
+  MCL_HIP(ctx, ctx->d_targets.ensure(std::max<uint64_t>(m, 1)));
+  MCL_HIP(ctx, ctx->d_send_targets.ensure(entries));
+  MCL_HIP(ctx, ctx->d_route_order.ensure(entries));
+  MCL_HIP(ctx, ctx->d_replies_in.ensure(4 * entries));
+  MCL_HIP(ctx, ctx->d_requests_in.ensure(entries));
+  MCL_HIP(ctx, ctx->d_replies_out.ensure(4 * entries));
+  MCL_HIP(ctx, hipMemsetAsync(ctx->d_send_targets.ptr, 0xFF, entries * sizeof(double), ctx->stream));    // NaN: no request
+  MCL_HIP(ctx, hipMemsetAsync(ctx->d_route_order.ptr, 0xFF, entries * sizeof(uint32_t), ctx->stream));    // 0xFFFFFFFF: no slot
+  launch_resample_targets(ctx->stream, ctx->cfg.seed, ctx->step, 0.0, 0.0, first_slot, m, ctx->have_map ? ctx->n_free : 0, ctx->d_targets.ptr, d_plan);
+  MCL_HIP(ctx, hipGetLastError());
+  {
+    const size_t nblocks = num_chunks(m);
+    const size_t hist = static_cast<size_t>(world) * nblocks;
+    MCL_HIP(ctx, ctx->d_route_u32.ensure(hist + 2 * (hist / kChunk + 1) + (m + 3) / 4 + 4));
+    uint32_t* block_hist = ctx->d_route_u32.ptr;
+    uint32_t* chunk_sum = block_hist + hist;
+    uint32_t* chunk_off = chunk_sum + (hist / kChunk + 1);
+    uint8_t* dest = reinterpret_cast<uint8_t*>(chunk_off + (hist / kChunk + 1));
+    launch_route_targets(ctx->stream, ctx->d_targets.ptr, m, d_intervals, d_intervals + world, world, rank, dest, block_hist, chunk_sum, chunk_off,
+                         ctx->d_send_targets.ptr, ctx->d_route_order.ptr, d_counts, static_cast<uint32_t>(cap), ctx->d_comm_f64.ptr + 14);
+    MCL_HIP(ctx, hipGetLastError());
+  }
+  std::vector<uint64_t> request_bytes(world, cap * sizeof(double)), reply_bytes(world, cap * 4 * sizeof(double));
+  if (const mcl_status s = comm_exchange(ctx, ctx->d_send_targets.ptr, request_bytes.data(), ctx->d_requests_in.ptr, request_bytes.data())) return s;
+  if (const mcl_status s = mcl_serve_requests(ctx, ctx->d_requests_in.ptr, entries, ctx->d_replies_out.ptr)) return s;
+  *entries_out = entries;
+  return comm_exchange(ctx, ctx->d_replies_out.ptr, reply_bytes.data(), ctx->d_replies_in.ptr, reply_bytes.data());
+}
+
 mcl_status sharded_draw(mcl_ctx* ctx, double random_state_probability, double total, const double* d_intervals, uint64_t first_slot,
                         uint64_t m, const double* d_plan = nullptr) {
   const uint32_t world = ctx->comm_world, rank = ctx->comm_rank;
@@ -1512,9 +1568,10 @@ mcl_status sharded_draw(mcl_ctx* ctx, double random_state_probability, double to
   if (const mcl_status s = mcl_route_targets(ctx, ctx->d_targets.ptr, m, d_intervals, d_intervals + world, world, rank, ctx->d_send_targets.ptr,
                                              ctx->d_route_order.ptr, reinterpret_cast<int64_t*>(d_counts))) return s;
   if (const mcl_status s = comm_gather(ctx, d_counts, d_all_counts, world * sizeof(long long))) return s;  // counts[r][q]: r asks q
-  long long* h_counts = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + 9));
+  long long* h_counts = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + kEstRecord));
   MCL_HIP(ctx, hipMemcpyAsync(h_counts, d_all_counts, world * world * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->comm_host_syncs += 1;
   std::vector<uint64_t> send_requests(world), recv_requests(world), send_replies(world), recv_replies(world);
   uint64_t incoming = 0;
   for (uint32_t q = 0; q < world; ++q) {
@@ -1640,7 +1697,7 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
     MCL_HIP(ctx, hipMemcpyAsync(d_counts, &mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (mine is a local)
     if (const mcl_status s = comm_gather(ctx, d_counts, d_counts + world, sizeof(long long))) return s;
-    long long* h_counts = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + 9));
+    long long* h_counts = reinterpret_cast<long long*>(ctx->h_comm + kCommScalars + 64 * (1 + 3 + 2 + kEstRecord));
     MCL_HIP(ctx, hipMemcpyAsync(h_counts, d_counts + world, world * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t sum = 0, before = 0;
@@ -1669,6 +1726,7 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
   double* d_intervals = d_gather_stats + 3 * world;    // ends[world], offsets[world]; behind them [world][9] estimate sums
   double* h = ctx->h_comm;
 
+  MCL_HIP(ctx, hipMemsetAsync(d + 14, 0, sizeof(double), ctx->stream));  // this cycle's overflow flag (the fixed-capacity exchange)
   bool keys_ready = false;
   if (const mcl_status s = do_propagate(ctx, ctx->window0, ctx->window1, ctx->step, num_points, &keys_ready)) return s;  // :174-175
   if (const mcl_status s = do_reweight(ctx, points_xy, num_points, true, keys_ready)) return s;                         // :176
@@ -1696,15 +1754,33 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
   if (!adaptive && !ap.selective_resampling && ctx->tuning.device_policy != 0) {
     constexpr int kPolicySlot = 20;  // d_scalars[20..23) = {slow, fast, p}, as in the single-context cycle
     const RecoveryPolicy policy{ap.alpha_slow, ap.alpha_fast, fires ? 1 : 0, ctx->d_scalars.ptr + kPolicySlot, ctx->hd_scalars + kPolicySlot};
-    double* d_plan = d + 14;  // {total, p}
+    double* d_plan = d + 16;  // {total, p}
     launch_shard_plan(ctx->stream, d_gather_stats, world, n_total, ctx->d_scalars.ptr + 1, ctx->hd_scalars + 1, policy, d_intervals, d_plan);
     launch_sum_rows(ctx->stream, d + 4, 1, 1, ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0);  // the global weight sum, for the info
     MCL_HIP(ctx, hipGetLastError());
+    // The ancestor exchange: fixed capacity per pair of ranks (no host read before the cycle's end) where the plain estimate follows -
+    // its all-gather carries the overflow flags -, exact counts (one host read) otherwise.
+    const bool padded = fires && ctx->estimate_kind == 0 && ctx->tuning.shard_pad_permille > 0;
+    const uint64_t m = ctx->n, first_slot = ctx->cfg.shard_offset;
+    auto commit = [&](uint64_t entries) -> mcl_status {
+      launch_commit_routed(ctx->stream, ctx->other(), ctx->cfg.seed, ctx->step, first_slot, entries, ctx->d_replies_in.ptr, ctx->d_route_order.ptr,
+                           ctx->d_targets.ptr, ctx->grid_view(), FreeCells{ctx->d_free.ptr, ctx->have_map ? ctx->n_free : 0});
+      MCL_HIP(ctx, hipGetLastError());
+      ctx->live ^= 1;
+      ctx->n = m;
+      return MCL_OK;
+    };
     if (fires) {
       stage_begin(ctx, MCL_STAGE_RESAMPLE);
-      const uint64_t m = ctx->n, first_slot = ctx->cfg.shard_offset;
-      if (const mcl_status s = sharded_draw(ctx, 0.0, 0.0, d_intervals, first_slot, m, d_plan)) return s;
-      if (const mcl_status s = mcl_commit_routed(ctx, ctx->step, first_slot, m, ctx->d_replies_in.ptr, ctx->d_route_order.ptr, ctx->d_targets.ptr)) return s;
+      if (padded) {
+        uint64_t entries = 0;
+        if (const mcl_status s = sharded_draw_padded(ctx, d_intervals, first_slot, m, d_plan,
+                                                    padded_capacity(n_total, world, static_cast<uint32_t>(ctx->tuning.shard_pad_permille)), &entries)) return s;
+        if (const mcl_status s = commit(entries)) return s;
+      } else {
+        if (const mcl_status s = sharded_draw(ctx, 0.0, 0.0, d_intervals, first_slot, m, d_plan)) return s;
+        if (const mcl_status s = commit(m)) return s;
+      }
       stage_end(ctx, MCL_STAGE_RESAMPLE);
     }
     ctx->force_update = false;  // :199
@@ -1714,9 +1790,22 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
       if (const mcl_status s = do_cluster_estimate(ctx, ctx->cluster_params, &est)) return s;
       stage_end(ctx, MCL_STAGE_ESTIMATE);
       MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->comm_host_syncs += 1;
     } else {
       double sums[12];
       if (const mcl_status s = sharded_estimate_sums(ctx, nullptr, 0, sums)) return s;
+      if (padded && ctx->h_scalars[17] != 0.0) {
+        // Some rank's requests to one shard did not fit the fixed capacity (every rank reads the same sum of flags and gets here
+        // together): the new set is incomplete.  The old one and its CDF are untouched - the commit wrote the other buffer -: back to
+        // it, the exchange again with exact counts, the estimate again.
+        ctx->comm_overflows += 1;
+        ctx->live ^= 1;
+        stage_begin(ctx, MCL_STAGE_RESAMPLE);
+        if (const mcl_status s = sharded_draw(ctx, 0.0, 0.0, d_intervals, first_slot, m, d_plan)) return s;
+        if (const mcl_status s = commit(m)) return s;
+        stage_end(ctx, MCL_STAGE_RESAMPLE);
+        if (const mcl_status s = sharded_estimate_sums(ctx, nullptr, 0, sums)) return s;
+      }
       stage_end(ctx, MCL_STAGE_ESTIMATE);
       if (const mcl_status s = mcl_estimate_from_sums(sums, &est)) return s;
     }
@@ -1740,6 +1829,7 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
   MCL_HIP(ctx, hipMemcpyAsync(h, d + 4, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MCL_HIP(ctx, hipMemcpyAsync(h + 1, d_gather_stats, 3 * world * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->comm_host_syncs += 1;
   stage_collect(ctx);
   const double weight_sum = h[0];
   double norm_sum = 0.0, norm_sumsq = 0.0;
@@ -1981,7 +2071,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     }
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2908,6 +2998,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "lf_ends_first") t.lf_ends_first = value ? 1 : 0;
   else if (key == "beam_free_ahead") t.beam_free_ahead = value ? 1 : 0;
   else if (key == "beam_sectors") t.beam_sectors = value ? 1 : 0;
+  else if (key == "shard_pad_permille") t.shard_pad_permille = static_cast<int>(std::clamp<int64_t>(value, 0, 8000));
   else if (key == "lf_queue_grid") t.lf_queue_grid = static_cast<int>(std::clamp<int64_t>(value, 0, 1 << 20));
   else if (key == "cycle_spin") t.cycle_spin = value ? 1 : 0;
   else if (key == "beam_table") {
@@ -2953,6 +3044,8 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
   else if (key == "cluster_cells") *value = ctx->cluster_cells;
   else if (key == "comm_bytes_out") *value = ctx->comm_bytes_out;
   else if (key == "comm_collectives") *value = ctx->comm_collectives;
+  else if (key == "comm_host_syncs") *value = ctx->comm_host_syncs;
+  else if (key == "comm_overflows") *value = ctx->comm_overflows;
   else if (key == "comm_ranks_seen") *value = ctx->comm_ranks_seen;
   else if (key == "comm_backend") *value = static_cast<uint64_t>(ctx->comm_backend);
   else return fail(ctx, MCL_ERR_INVALID_ARGUMENT, "mcl_get_counter: unknown counter " + key);

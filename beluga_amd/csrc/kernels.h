@@ -160,6 +160,9 @@ struct Tuning {
   int lf_queue_grid = 0;            // workgroups of the queue form (lf_queue): 0 = three per CU, otherwise this many (tests: few workgroups, many
                                     // blocks each)
   int device_cus = 0;               // compute units of the context's device (filled in by mcl_create; 0 = assume 256)
+  int shard_pad_permille = 1063;    // sharded fixed-size cycle: the ancestor exchange moves a FIXED number of entries per pair of ranks - this many
+                                    // thousandths of a shard's share of another shard's draws, plus eight standard deviations - so that no count
+                                    // is read by the host before the cycle's end; 0 = exact counts (one more host synchronisation per cycle)
   int lf_ends_first = 1;            // LDS-patch kernel: the blocks are taken from both ends of the order inwards (the fringe's slow blocks first)
   int beam_sectors = 1;             // beam model, ordered kernel, scanners that reach beyond half the LDS window: the scan in four sectors, each with
                                     // a window of its own that holds its rays (0 = one centred window; the rays that leave it go on in global memory)
@@ -401,7 +404,8 @@ void launch_shard_plan(hipStream_t st, const double* d_stats, uint32_t world, ui
 // Counting sort of resample targets by owning shard; d_block_hist needs world * num_chunks(count) words.
 void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t count, const double* d_ends, const double* d_offsets,
                           uint32_t world, uint32_t self_rank, uint8_t* d_dest, uint32_t* d_block_hist, uint32_t* d_chunk_sum,
-                          uint32_t* d_chunk_off, double* d_send_targets, uint32_t* d_order, long long* d_counts);
+                          uint32_t* d_chunk_off, double* d_send_targets, uint32_t* d_order, long long* d_counts, uint32_t pad_capacity = 0,
+                          double* d_overflow = nullptr);
 void launch_gather_by_cdf_aos(hipStream_t st, Particles src, CdfTree cdf, const double* d_targets, uint64_t m,
                               double* d_out);
 void launch_commit_routed(hipStream_t st, Particles dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,

@@ -2288,6 +2288,9 @@ __device__ __forceinline__ int examine_column(const BlockMaps& maps, int major, 
 // float quotient and a +-1 correction: the operands are far below 2^24).
 __device__ __forceinline__ void walk_advance_free(int j, int dminor, int dmajor, float inv_dmajor, bool steep, int major_step, int minor_step,
                                                   int& lx, int& ly, int& error) {
+  // (values selected, not `if (steep) lx += ...; else ly += ...`: with a divergent `steep` the compiler turned those into ONE store through
+  // a selected address, and the walk's position lived in scratch memory - a store, a dependent load and their waits per beam)
+  int along_minor = 0;
   if (dmajor > 0) {
     const int total = error + j * dminor;
     int trips = static_cast<int>(static_cast<float>(total - 1) * inv_dmajor);
@@ -2296,11 +2299,12 @@ __device__ __forceinline__ void walk_advance_free(int j, int dminor, int dmajor,
     trips += up - down;
     rem -= (up - down) * dmajor;
     error = rem;
-    if (steep) lx += trips * minor_step;
-    else ly += trips * minor_step;
+    along_minor = trips * minor_step;
   }
-  if (steep) ly += j * major_step;
-  else lx += j * major_step;
+  const int along_major = j * major_step;
+  const int nx = lx + (steep ? along_minor : along_major), ny = ly + (steep ? along_major : along_minor);
+  lx = nx;
+  ly = ny;
 }
 // k_start: that many cells from the current one on are known to be free (the ordered beam kernel's per-beam certificate, see
 // k_reweight_beam_sorted): they are passed in one closed-form step.
@@ -3455,15 +3459,20 @@ __global__ __launch_bounds__(kBlock) void k_route_hist(const double* __restrict_
   if (threadIdx.x < world) block_hist[static_cast<size_t>(threadIdx.x) * nblocks + blockIdx.x] = hist[threadIdx.x];
 }
 
+// pad_capacity == 0: the requests of destination d follow those of d - 1 (compact; the counts go to the host, which sizes the exchange).
+// pad_capacity > 0 (the fixed-capacity exchange): destination d owns the entries [d * pad_capacity, (d + 1) * pad_capacity) of lists the
+// caller has filled with 0xFF bytes - a NaN target, slot 0xFFFFFFFF: "no request" -; a destination with more requests than that sets
+// *overflow and loses the ones beyond (the cycle's resampling is then run again with exact counts: sharded_update).
 __global__ __launch_bounds__(kBlock) void k_route_scatter(const double* __restrict__ targets, uint64_t count,
                                                           const double* __restrict__ shard_offsets, uint32_t world,
                                                           const uint8_t* __restrict__ dest, const uint32_t* __restrict__ block_offsets,
                                                           uint32_t nblocks, double* __restrict__ send_targets,
-                                                          uint32_t* __restrict__ order) {
+                                                          uint32_t* __restrict__ order, uint32_t pad_capacity, double* __restrict__ overflow) {
   __shared__ uint32_t cursor[kMaxRanks];
   __shared__ double s_off[kMaxRanks];
   if (threadIdx.x < world) {
-    cursor[threadIdx.x] = block_offsets[static_cast<size_t>(threadIdx.x) * nblocks + blockIdx.x];
+    const uint32_t compact = block_offsets[static_cast<size_t>(threadIdx.x) * nblocks + blockIdx.x];
+    cursor[threadIdx.x] = pad_capacity ? threadIdx.x * pad_capacity + (compact - block_offsets[static_cast<size_t>(threadIdx.x) * nblocks]) : compact;
     s_off[threadIdx.x] = shard_offsets[threadIdx.x];
   }
   __syncthreads();
@@ -3475,6 +3484,10 @@ __global__ __launch_bounds__(kBlock) void k_route_scatter(const double* __restri
       const uint32_t d = dest[i];
       const double t = targets[i];
       const uint32_t slot = atomicAdd(&cursor[d], 1u);
+      if (pad_capacity && slot >= (d + 1u) * pad_capacity) {
+        *overflow = 1.0;  // (every writer stores the same value)
+        continue;
+      }
       send_targets[slot] = t == t ? t - s_off[d] : 0.0;
       order[slot] = static_cast<uint32_t>(i);
     }
@@ -3495,7 +3508,12 @@ __global__ __launch_bounds__(kBlock) void k_gather_by_cdf_aos(Particles src, Cdf
                                                               const double* __restrict__ targets, uint64_t m, double4* __restrict__ out) {
   const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (t >= m) return;
-  const uint64_t idx = cdf_tree_lower_bound(cdf, targets[t]);
+  const double target = targets[t];
+  if (!(target == target)) {  // "no request" (an entry of the fixed-capacity exchange that nobody filled)
+    out[t] = double4{0.0, 0.0, 0.0, 0.0};
+    return;
+  }
+  const uint64_t idx = cdf_tree_lower_bound(cdf, target);
   const double4 v = src.pose[idx];
   out[t] = double4{v.z, v.w, v.x, v.y};
 }
@@ -3507,6 +3525,7 @@ __global__ __launch_bounds__(kBlock) void k_commit_routed(Particles dst, uint64_
   const uint64_t k = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (k >= count) return;
   const uint32_t t = order[k];  // reply k answers output slot t
+  if (t == 0xFFFFFFFFu) return;  // (an unused entry of the fixed-capacity exchange)
   Pose2 v;
   if (targets[t] != targets[t]) {
     v = random_free_state(seed, step, first_slot + t, g, fc);
@@ -4490,7 +4509,8 @@ void launch_shard_plan(hipStream_t st, const double* d_stats, uint32_t world, ui
 
 void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t count, const double* d_ends, const double* d_offsets,
                           uint32_t world, uint32_t self_rank, uint8_t* d_dest, uint32_t* d_block_hist, uint32_t* d_chunk_sum,
-                          uint32_t* d_chunk_off, double* d_send_targets, uint32_t* d_order, long long* d_counts) {
+                          uint32_t* d_chunk_off, double* d_send_targets, uint32_t* d_order, long long* d_counts, uint32_t pad_capacity,
+                          double* d_overflow) {
   const uint32_t nblocks = num_chunks(count);
   if (nblocks == 0) {
     (void)hipMemsetAsync(d_counts, 0, sizeof(long long) * world, st);
@@ -4506,7 +4526,7 @@ void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t coun
   hipLaunchKernelGGL(k_u32_exclusive_apply, dim3(mchunks), dim3(kBlock), 0, st, d_block_hist, m, d_chunk_off);
   hipLaunchKernelGGL(k_route_counts, dim3(1), dim3(kMaxRanks), 0, st, d_block_hist, nblocks, world, count, d_counts);
   hipLaunchKernelGGL(k_route_scatter, dim3(nblocks), dim3(kBlock), 0, st, d_targets, count, d_offsets, world, d_dest, d_block_hist,
-                     nblocks, d_send_targets, d_order);
+                     nblocks, d_send_targets, d_order, pad_capacity, d_overflow);
 }
 void launch_gather_by_cdf_aos(hipStream_t st, Particles src, CdfTree cdf, const double* d_targets, uint64_t m,
                               double* d_out) {

@@ -567,7 +567,7 @@ def main():
     sync_all()
     patch_before = (filt.counter("lf_patch_groups_planned"), filt.counter("lf_patch_groups_through")) if hasattr(filt, "counter") else None
     library_comm = use_sharded and type(filt).__name__ == "Amcl"  # (the torch.distributed driver is beluga_amd.sharded.ShardedAmcl)
-    comm_before = (filt.counter("comm_bytes_out"), filt.counter("comm_collectives")) if library_comm else None
+    comm_before = (filt.counter("comm_bytes_out"), filt.counter("comm_collectives"), filt.counter("comm_host_syncs")) if library_comm else None
     timed_estimates = []
     t0 = time.perf_counter()
     for c in range(args.warmup, args.warmup + args.steps):
@@ -589,7 +589,9 @@ def main():
         collective = {"backend": backend_name.get(filt.counter("comm_backend"), "?"), "ranks_seen": filt.counter("comm_ranks_seen"),
                       "bytes_out_per_rank_per_cycle": (filt.counter("comm_bytes_out") - comm_before[0]) / args.steps,
                       "collectives_per_cycle": (filt.counter("comm_collectives") - comm_before[1]) / args.steps,
-                      "host_synchronisations_per_cycle": 2 if world > 1 else 1}
+                      # counted by the library (comm_host_syncs): 1 with the fixed-capacity ancestor exchange, 2 with exact counts
+                      "host_synchronisations_per_cycle": ((filt.counter("comm_host_syncs") - comm_before[2]) / args.steps) if world > 1 else 1,
+                      "exchange_overflows": filt.counter("comm_overflows")}
     elif use_sharded:
         collective = {"backend": f"torch.distributed ({backend}) driver, beluga_amd/sharded.py", "ranks_seen": dist.get_world_size(),
                       "bytes_out_per_rank_per_cycle": None}

@@ -187,3 +187,98 @@ def test_facade_matches_python_facade(demo):
     bad = subprocess.run([demo, "bad-covariance"], capture_output=True, text=True)
     assert bad.returncode == 0 and "Invalid covariance matrix" in bad.stdout
     f.close()
+
+
+@pytest.fixture(scope="module")
+def sharded_procs(tmp_path_factory):
+    """tests/cpp/sharded_procs.cpp: ONE rank of a sharded filter per process, a POSIX shared-memory transport between them."""
+    mcl_build.build()
+    exe = tmp_path_factory.mktemp("cpp") / "sharded_procs"
+    lib_dir = os.path.join(ROOT, "beluga_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I",
+                           os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "sharded_procs.cpp"), "-L", lib_dir, "-lbeluga_mcl",
+                           f"-Wl,-rpath,{lib_dir}", "-L", "/opt/rocm/lib", "-lamdhip64", "-lpthread", "-lrt", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    return str(exe)
+
+
+def _padded_capacity(n_total, world, permille):
+    m_max = (n_total + world - 1) // world
+    mean = m_max / world
+    cap = int(mean * (permille / 1000.0) + 8.0 * math.sqrt(mean) + 64.0)
+    return (cap + 63) & ~63
+
+
+def _run_ranks(exe, tmp_path, world, particles, cycles, pad=None):
+    name = f"/beluga_mcl_test_{os.getpid()}_{world}_{particles}_{pad}"
+    procs = []
+    for r in range(world):
+        cmd = [exe, name, str(r), str(world), str(particles), str(cycles), str(tmp_path / f"w{world}_p{pad}_rank{r}.bin")]
+        if pad is not None:
+            cmd.append(str(pad))
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, out + err
+        outs.append(out)
+    runs = []
+    for r, out in enumerate(outs):
+        cyc = []
+        for line in out.splitlines():
+            f = line.split()
+            if f and f[0] == "cycle":
+                est = [float.fromhex(v) for v in f[3:16]]
+                kv = dict(zip(f[16::2], f[17::2]))
+                cyc.append((est, {k: int(v) for k, v in kv.items()}))
+        overflows = int([line for line in out.splitlines() if line.startswith("overflows")][0].split()[1])
+        states = np.fromfile(tmp_path / f"w{world}_p{pad}_rank{r}.bin", dtype=np.float64).reshape(-1, 4)
+        runs.append((cyc, overflows, states))
+    return runs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,particles", [(2, 60000), (3, 70001), (4, 131072)])
+def test_sharded_cycle_between_processes_and_its_collectives(sharded_procs, tmp_path, world, particles):
+    """The library's sharded cycle (mcl_update on an attached context) with the ranks as SEPARATE PROCESSES (one context each, a
+    shared-memory transport; all on the GPU at hand) against a single-context process on the same inputs, and what a cycle costs in
+    communication, asserted against DESIGN.md section 6 so that a collective or a host read that creeps in fails here:
+      * default (fixed-capacity ancestor exchange): 5 collectives per cycle - the shard weight sums, the shard statistics, requests
+        out, states back, the estimate sums (with the overflow flags) -, ONE host synchronisation, and exactly
+        8 + 24 + (world - 1) * cap * (8 + 32) + 80 bytes handed to the transport per rank, cap = the fixed capacity per pair of ranks;
+      * shard_pad_permille = 0 (exact counts): a sixth collective (the request counts, world * 8 bytes) and a second host
+        synchronisation (the host sizes the exchange), about 40 bytes per draw that crosses ranks;
+      * a capacity forced too small (500 permille): every cycle overflows, runs its resampling again with exact counts - three host
+        synchronisations - and leaves the same particles.
+    Every rank returns the same estimate bit for bit; it equals the single-context filter's within the rounding of the gathered sums;
+    the shards, concatenated in rank order, are the single-context set up to CDF-boundary draws."""
+    cycles = 5
+    single = _run_ranks(sharded_procs, tmp_path, 1, particles, cycles)[0]
+    for pad in (None, 0, 500):
+        runs = _run_ranks(sharded_procs, tmp_path, world, particles, cycles, pad)
+        cap = _padded_capacity(particles, world, 1063 if pad is None else pad)
+        for c in range(cycles):
+            for r in range(world):
+                assert runs[r][0][c][0] == runs[0][0][c][0], f"cycle {c}: rank {r} returns another estimate"
+            np.testing.assert_allclose(runs[0][0][c][0], single[0][c][0], rtol=0, atol=1e-9)
+            for r in range(world):
+                k = runs[r][0][c][1]
+                assert k["resampled"] == 1 and k["n"] == particles
+                if pad is None:
+                    assert k["collectives"] == 5 and k["syncs"] == 1, (c, r, k)
+                    assert k["bytes"] == 8 + 24 + (world - 1) * cap * 40 + 80, (c, r, k, cap)
+                elif pad == 0:
+                    assert k["collectives"] == 6 and k["syncs"] == 2, (c, r, k)
+                    crossing = 40.0 * (particles / world) * (world - 1) / world  # requests out (8 B) + states served (32 B), on average
+                    assert abs(k["bytes"] - (8 + 24 + 8 * world + 80) - crossing) < 0.1 * crossing, (c, r, k)
+                else:
+                    assert k["collectives"] == 5 + 4 and k["syncs"] == 3, (c, r, k)  # + counts, requests, states, the estimate again
+        assert all(run[1] == (cycles if pad == 500 else 0) for run in runs), [run[1] for run in runs]
+        whole = np.concatenate([run[2] for run in runs])
+        assert whole.shape == single[2].shape
+        differ = int(np.any(whole != single[2], axis=1).sum())
+        assert differ <= max(5, particles // 10000), (pad, differ)
