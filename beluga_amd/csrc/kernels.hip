@@ -1375,8 +1375,11 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   // loop-carried; while every value that flows into them is a ZERO extension of a 16-bit load - which is all an all-gathering workgroup
   // has - the compiler carries them as 16-bit values and widens each behind its load: an instruction that uses the gather right where it
   // is issued, i.e. a memory latency per step in the open instead of one hidden behind the next group's end-points.
-  auto step = [&](auto is_loose, auto add_before, auto in_loop, uint32_t g, Lookups& now, const Lookups& before, uint32_t& rotor,
-                  scan_ptr_t& cursor, Plan& carried) {
+  // `whole_patch`: the group is known to go through one whole patch (19 groups in 20).  The caller branches on the plan entry ONCE, in front
+  // of the step, between two instances of it: inside one instance the three-way choice (whole patch / two halves / gathered) cost the
+  // common group fourteen scalar instructions of predicate bookkeeping around its look-ups.
+  auto step_as = [&](auto is_loose, auto add_before, auto in_loop, auto whole_patch, uint32_t g, Lookups& now, const Lookups& before, uint32_t& rotor,
+                     scan_ptr_t& cursor, Plan& carried) {
     const Plan plan = carried;
     const uint32_t buffer = rotor;
     rotor = buffer + kPatchBytes == patch_base + kPatchBuffers * kPatchBytes ? patch_base : buffer + kPatchBytes;
@@ -1411,7 +1414,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
       carried.ka = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(next_entry.x));
       carried.meta = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(next_entry.y));
     }
-    if (__builtin_expect(plan.meta == 8u, 1)) {  // one whole patch (19 groups in 20): one constant for the eight look-ups
+    if constexpr (decltype(whole_patch)::value) {  // one constant for the eight look-ups
       const uint32_t K = buffer + plan.ka;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -1440,6 +1443,13 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
       }
     }
     now.redo = __builtin_amdgcn_ballot_w64(lowest < 4u);
+  };
+  auto step = [&](auto is_loose, auto add_before, auto in_loop, uint32_t g, Lookups& now, const Lookups& before, uint32_t& rotor,
+                  scan_ptr_t& cursor, Plan& carried) {
+    if (!decltype(is_loose)::value && __builtin_expect(carried.meta == 8u, 1))
+      step_as(is_loose, add_before, in_loop, std::true_type{}, g, now, before, rotor, cursor, carried);
+    else
+      step_as(is_loose, add_before, in_loop, std::false_type{}, g, now, before, rotor, cursor, carried);
   };
   auto run = [&](auto is_loose) {
     Lookups a, c;

@@ -190,6 +190,52 @@ def collect_in_run_counters(timeout_s=150):
     return "ok"
 
 
+def collect_beam_counters(timeout_s=120):
+    """One short run of configuration 5 (--pmc-child beam: 3 cycles) under `rocprofv3 --kernel-trace --pmc` with the SQ instruction
+    counters: the ordered beam kernel's per-launch averages -> the roofline entry of configs["5"] (vector issue: the walk is integer
+    and LDS work, its HBM traffic a rounding error).  Returns the entry, or a string saying why there is none."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if tool is None:
+        return "rocprofv3 not found"
+    counters = "SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_SALU"
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as out:
+            cmd = [tool, "--kernel-trace", "--pmc"] + counters.split() + ["-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "beam"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            db_path = None
+            for root, _dirs, files in os.walk(out):
+                for name in files:
+                    if name.endswith("_results.db"):
+                        db_path = os.path.join(root, name)
+            if r.returncode != 0 or db_path is None:
+                return f"rocprofv3 pass failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-200:]}"
+            db = sqlite3.connect(db_path)
+            rows = db.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection where kernel_name like '%k_reweight_beam_sorted%' group by kernel_name, counter_name").fetchall()
+            durations = db.execute("select name, total_calls, average from top_kernels where name like '%k_reweight_beam_sorted%'").fetchall()
+            db.close()
+    except Exception as exc:
+        return f"beam counters failed: {exc!r}"
+    rec = {counter: float(value) for _k, counter, value, _n in rows}
+    if "SQ_INSTS_VALU" not in rec or not durations:
+        return "no beam kernel rows in the profiler's database"
+    avg_us = float(durations[0][2])
+    f64 = sum(rec.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
+    valu = rec["SQ_INSTS_VALU"]
+    floor_us = (f64 * 4.0 + (valu - f64) * 2.0) / (SIMDS * CLOCK_HZ) * 1e6
+    wave_beams = 1_000_000 * BEAMS / 64
+    return {"kernel": "k_reweight_beam_sorted (Bresenham walks over an LDS bit window: integer and LDS work)", "bound": "valu",
+            "avg_launch_ms": avg_us * 1e-3, "launches": int(durations[0][1]), "valu_instructions_per_launch": valu,
+            "valu_per_wave_beam": valu / wave_beams, "salu_per_wave_beam": rec.get("SQ_INSTS_SALU", 0.0) / wave_beams,
+            "f64_per_wave_beam": f64 / wave_beams, "achieved": valu / (avg_us * 1e-6) / 1e9, "peak": SIMDS * CLOCK_HZ / 2.0 / 1e9,
+            "unit": "G wave64-instr/s", "issue_floor_ms_spec_rates": floor_us * 1e-3, "frac": floor_us / avg_us,
+            "pricing": "datasheet rates: 2 cycles per wave64 instruction, 4 for f64; 1024 SIMDs at 2.4 GHz",
+            "source": "in-run rocprofv3 --pmc pass of this bench.py (--pmc-child beam), per launch"}
+
+
 def roofline_by_kernel():
     """Every kernel of the headline cycle against the two rooflines that can bind it, from the in-run counter passes (per launch):
     HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB; gfx950 tallies a read at half its size) against 8.0 TB/s, and the issue time of its
@@ -216,12 +262,21 @@ def roofline_by_kernel():
     return out
 
 
-def pmc_child():
-    """What collect_in_run_counters profiles: the headline filter, 5 cycles of warm-up and 8 more (the same kernels as the timed region)."""
-    from beluga_amd.amcl import Amcl, AmclParams, DifferentialDriveModelParam, LikelihoodFieldModelParam, OccupancyGrid, se2_from_xytheta
-    cells, truth, odoms, scans, _poses = make_workload(13)
+def pmc_child(kind="lf"):
+    """What collect_in_run_counters profiles: the headline filter, 5 cycles of warm-up and 8 more (the same kernels as the timed region);
+    kind "beam": three cycles of configuration 5 (BeamSensorModel, 1M x 1080) for collect_beam_counters."""
+    from beluga_amd.amcl import Amcl, AmclParams, BeamModelParam, DifferentialDriveModelParam, LikelihoodFieldModelParam, OccupancyGrid, se2_from_xytheta
+    cells, truth, odoms, scans, _poses = make_workload(13 if kind == "lf" else 3)
     grid = OccupancyGrid(cells, RESOLUTION, origin=se2_from_xytheta(ORIGIN[0], ORIGIN[1], 0.0))
     n = 1_000_000
+    if kind == "beam":
+        b = Amcl(grid, DifferentialDriveModelParam(*ALPHAS), BeamModelParam(beam_max_range=MAX_RANGE), AmclParams(min_particles=n, max_particles=n), seed=42)
+        b.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+        for c in range(3):
+            assert b.update(se2_from_xytheta(*odoms[c]), scans[c]) is not None
+        b.sync()
+        b.close()
+        return
     f = Amcl(grid, DifferentialDriveModelParam(*ALPHAS), LikelihoodFieldModelParam(**LF), AmclParams(min_particles=n, max_particles=n), seed=42)
     f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
     for c in range(13):
@@ -452,10 +507,10 @@ def main():
     ap.add_argument("--stage-steps", type=int, default=6, help="cycles of the per-stage breakdown pass")
     ap.add_argument("--sharded", action="store_true", help="use the sharded driver even with one GPU (measures its overhead)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes behind the timed region (the line then quotes the tracked profiles)")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", nargs="?", const="lf", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
-        pmc_child()
+        pmc_child(args.pmc_child)
         return
 
     import torch
@@ -744,6 +799,8 @@ def main():
         }
         if not args.no_other_configs and world == 1 and n_local == 1_000_000:
             out["configs"] = other_configs(grid, cells, truth, controls, scans, filt, local_rank)
+            if not args.no_pmc and "5" in out["configs"]:
+                out["configs"]["5"]["roofline"] = collect_beam_counters()
         if config4 is not None:
             out["configs"] = {"4": config4}
         if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: the other ranks would sit in a barrier behind it)
