@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORICAL: ran on the round-2 tree (git history); some of the scripts and build flags it names are gone from the current one.
 # Round-2 profile artefacts: kernel trace + timeline of the default bench, HBM traffic of the LF kernel, PMC of the LF kernel,
 # gather / hand-off calibrations, traces of the other configurations.  Summaries land in gpurun_out/ (copied to profiles/).
 set -u

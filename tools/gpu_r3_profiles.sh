@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORICAL: ran on the round-3 tree (git history); some of the scripts and build flags it names are gone from the current one.
 # Round-3 profile artefacts (one GPU call): kernel trace + timeline of the default bench, PMC passes of the LF kernel
 # (instruction classes for the VALU-issue roofline, LDS / wait counters, cache counters, FETCH_SIZE / WRITE_SIZE), the full
 # bench line, traces of the other configurations.  Summaries land in gpurun_out/r03 (copied to profiles/r03_*).

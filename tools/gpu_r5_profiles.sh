@@ -1,12 +1,11 @@
 #!/bin/bash
-# HISTORICAL: ran on the round-4 tree (git history); some of the scripts and build flags it names are gone from the current one.
-# Round-4 profile artefacts (one GPU call): kernel trace + timeline of the default bench, PMC passes of the LF kernel
+# Round-5 profile artefacts (one GPU call): kernel trace + timeline of the default bench, PMC passes of the LF kernel
 # (instruction classes for the VALU-issue roofline, LDS / wait counters, cache counters, FETCH_SIZE / WRITE_SIZE), the full
-# bench line, traces of the other configurations.  Summaries land in gpurun_out/r04 (copied to profiles/r04_*).
+# bench line, traces of the other configurations.  Summaries land in gpurun_out/r05 (copied to profiles/r05_*).
 set -u
-mkdir -p gpurun_out/prof gpurun_out/r04
+mkdir -p gpurun_out/prof gpurun_out/r05
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r04
+O=$GRAFT_REPO_ROOT/gpurun_out/r05
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { tail -30 $O/build.log; exit 1; }
 SHA=$(python -c "import bench; print(bench.lf_kernel_source_sha(bench.KERNEL_SOURCE))")
 BENCH="python $GRAFT_REPO_ROOT/bench.py --windows 0 --stage-steps 0 --no-cpu-baseline --no-other-configs --no-pmc"
@@ -60,20 +59,10 @@ rm -rf gpurun_out/prof/tf
 python tools/exp_host_time.py 2>/dev/null | tail -n 1 > $O/host_time_per_cycle.txt
 python tools/exp_lf_converge.py 2>/dev/null > $O/lf_converge.txt
 timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench.err > $O/bench_1M.json
-python tools/exp_pipe_ab.py 45 2>/dev/null > $O/lf_pipe_ab.txt
 python tools/exp_small.py 2>/dev/null > $O/small_filters.txt
-# the queue of blocks: A/B on the bench's set (1M and 10M), and the launch's timeline workgroup by workgroup (timing build)
+# the queue of blocks: A/B on the bench's set (1M and 10M)
 { for q in 0 1 0 1; do echo "lf_queue=$q"; OPTIONS=lf_queue=$q python tools/exp_lf_variant.py 2>/dev/null; done
   for q in 0 1; do echo "lf_queue=$q, 10M particles"; N=10000000 OPTIONS=lf_queue=$q python tools/exp_lf_variant.py 2>/dev/null; done; } > $O/lf_queue_ab.txt
-export BELUGA_MCL_ALLOW_MEASUREMENT_BUILD=1
-{ echo "# workgroups per CU (timing builds with unused workgroup memory): 2 per CU, then 1 per CU; the product build is the first line of lf_queue_ab.txt"
-  for spec in "pad2:-DMCL_PATCH_LDS_PAD=2048" "pad1:-DMCL_PATCH_LDS_PAD=32768"; do
-    name=${spec%%:*}; flags=${spec#*:}
-    bash tools/build_variant.sh $name "$flags" > /dev/null 2>&1 && BELUGA_MCL_LIB=build/variants/$name/libbeluga_mcl.so OPTIONS=lf_queue=0 python tools/exp_lf_variant.py 2>/dev/null
-  done; } > $O/lf_workgroups_per_cu.txt
-bash tools/build_variant.sh lftw "-DMCL_LF_TIMING -DMCL_LF_TIMING_COARSE" > /dev/null 2>&1
-{ echo "# tools/exp_lf_workgroups.py, one workgroup per block (lf_queue = 0); times in ticks of s_memrealtime / 100"
-  OUT=/tmp BELUGA_MCL_LIB=build/variants/lftw/libbeluga_mcl.so AT=6,12,40 OPTIONS=lf_queue=0 python tools/exp_lf_workgroups.py 2>/dev/null
-  echo "# the same with the queue of blocks (lf_queue = 1): a record per BLOCK"
-  OUT=/tmp BELUGA_MCL_LIB=build/variants/lftw/libbeluga_mcl.so AT=12,40 OPTIONS=lf_queue=1 python tools/exp_lf_workgroups.py 2>/dev/null; } > $O/lf_workgroup_timeline.txt
+python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
 ls -la $O
