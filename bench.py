@@ -9,7 +9,8 @@ LikelihoodFieldModel reweight over a 1080-beam scan, normalisation + policies, m
 particles, SE2 estimate.  Workload = BASELINE.json configs[1]: 1M particles per GPU, 4000x4000 @ 5 cm grid
 (seed 42), resample every cycle.  Map, field and particles are resident in HBM before the timed region; each
 step uploads one 1080-point scan (17 KB) and downloads the estimate, as the reference's caller would.
-With --gpus N the particle set is sharded N ways (1M per rank, weak scaling) behind one logical filter.
+With --gpus N the particle set is sharded N ways (1M per rank, weak scaling) behind one logical filter; `value` is the whole
+job's rate in units of a 1M-particle cycle: N x that filter's cycle rate (`config.filter_cycles_per_s`).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the dominant kernel
 (likelihood-field reweight, HIP-event timed on the library's stream) and `cpu_baseline` (the oracle, a CPU
@@ -761,9 +762,10 @@ def main():
         }
         out = {
             "metric": "MCL update cycles/sec (motion+sensor+resample), N particles x 1080 beams",
-            # update cycles per second of the ONE logical filter the ranks run together (with N GPUs: N x particles_per_gpu
-            # particles behind it, weak scaling); config.particle_beam_evals_per_s is the aggregate work rate
-            "value": args.steps / elapsed,
+            # the whole job's rate in the metric's unit, a cycle of particles_per_gpu particles x 1080 beams: with N GPUs the ranks run ONE
+            # logical filter of N x particles_per_gpu particles together (weak scaling), every cycle of which is N such units -
+            # config.filter_cycles_per_s is that filter's own cycle rate (= value at N = 1)
+            "value": world * args.steps / elapsed,
             "unit": "cycles/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -786,6 +788,8 @@ def main():
                                                                     f"{driver_used[0] or 'inside libbeluga_mcl.so'})",
                 "collective": collective,
                 "particle_beam_evals_per_s": n_total * BEAMS * args.steps / elapsed,
+                "filter_cycles_per_s": args.steps / elapsed,
+                "value_counts": "cycles of particles_per_gpu particles: n_gpus x filter_cycles_per_s (one logical filter of particles_total particles)",
                 "units_of_1M_particle_cycles_per_s": world * args.steps / elapsed * (n_local / 1_000_000),
             },
             "timed_region_s": elapsed,

@@ -214,5 +214,7 @@ def test_bench_multi_rank_flow_dry_run_on_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 2 and line["unit"] == "cycles/s" and line["scaling"] == "weak"
     assert line["config"]["particles_total"] == 40000 and line["config"]["particles_per_gpu"] == 20000
     assert line["config"]["collective"]["ranks_seen"] == 2, line["config"]["collective"]  # (the field the driver's "did every rank take part" check reads)
-    assert line["value"] == pytest.approx(4 / line["timed_region_s"], rel=1e-9)  # cycles/s of the logical filter, not x ranks
+    # value = the whole job in the metric's unit (cycles of particles_per_gpu particles): ranks x the logical filter's own cycle rate
+    assert line["config"]["filter_cycles_per_s"] == pytest.approx(4 / line["timed_region_s"], rel=1e-9)
+    assert line["value"] == pytest.approx(2 * 4 / line["timed_region_s"], rel=1e-9)
     assert line["verified"]["estimate_vs_true_pose"]["ok"], line["verified"]
