@@ -14,8 +14,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libbeluga_mcl.so")
-SOURCES = ["kernels.hip", "context.hip", "map_build.cpp"]
-HEADERS = ["kernels.h", "se2.h", "rng.h", "map_build.h", os.path.join(ROOT, "include", "beluga_mcl.h")]
+SOURCES = ["kernels.hip", "beam_kernels.hip", "context.hip", "map_build.cpp"]
+HEADERS = ["kernels.h", "device_common.hpp", "se2.h", "rng.h", "map_build.h", os.path.join(ROOT, "include", "beluga_mcl.h")]
 # -ffp-contract=off: see the header comment of kernels.hip (floor() parity with the reference's arithmetic).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("BELUGA_MCL_EXTRA_CXXFLAGS", "").split()

@@ -292,10 +292,12 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
 // d_beam_points: scratch of kBeamPointDoubles * B doubles (per-beam terms shared by all particles; ordered variant only).
 constexpr uint32_t kBeamPointDoubles = 5;
 // d_beam_table (optional, ordered variant): launch_beam_table's output, beam_table_count entries of 4 doubles
+// w[perm[t]] *= the sum of a scan's segment sums partial[s][t] (mode 0: 1 + sum, 1: exp(sum), 2: sum - the beam model), segments in order
+void launch_lf_combine(hipStream_t st, double* w, uint64_t n, const uint32_t* perm, const double* partial, uint32_t segments, int mode);
 void launch_reweight_beam(hipStream_t st, Particles p, uint64_t n, GridView g, BeamModel m, const double* d_points, uint32_t B,
                           unsigned long long* d_steps, const SortScratch* sorted, const uint32_t* nonfree_bits, double* d_beam_points,
                           const double* d_beam_table = nullptr, uint32_t beam_table_count = 0, bool free_ahead = true, bool sectors = true);
-// The beam model's terms that depend on the expected range alone, tabulated over the squared cell distance of the hit (kernels.hip
+// The beam model's terms that depend on the expected range alone, tabulated over the squared cell distance of the hit (beam_kernels.hip
 // BeamTable): entries = beam_table_entries(...) (0: the range spans too many cells for a table), 4 doubles each.
 constexpr double kBeamTableMaxCells = 2046.0;
 uint32_t beam_table_entries(double beam_max_range, double resolution);

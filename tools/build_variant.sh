@@ -19,16 +19,19 @@ if [ -n "$tree" ]; then
   src=$out/src_$tree
   mkdir -p $src
   for f in kernels.hip context.hip kernels.h se2.h rng.h map_build.h map_build.cpp; do git -C $root show $rev:beluga_amd/csrc/$f > $src/$f; done
+  for f in beam_kernels.hip device_common.hpp; do git -C $root show $rev:beluga_amd/csrc/$f > $src/$f 2>/dev/null || rm -f $src/$f; done
   git -C $root show $rev:include/beluga_mcl.h > $src/beluga_mcl.h
 fi
 common="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -I$src -I$root/include -DMCL_MEASUREMENT_BUILD $flags"
 /opt/rocm/bin/hipcc $common -x hip -c $src/kernels.hip -o $out/kernels.o
+beam=""   # (the beam model's kernels are a translation unit of their own from round 5 on; older revisions have them inside kernels.hip)
+if [ -f $src/beam_kernels.hip ]; then /opt/rocm/bin/hipcc $common -x hip -c $src/beam_kernels.hip -o $out/beam_kernels.o; beam=$out/beam_kernels.o; fi
 if [ -n "$tree" ]; then
   /opt/rocm/bin/hipcc $common -x hip -c $src/context.hip -o $out/context.o
   /opt/rocm/bin/hipcc $common -c $src/map_build.cpp -o $out/map_build.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libbeluga_mcl.so $out/kernels.o $out/context.o $out/map_build.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libbeluga_mcl.so $out/kernels.o $beam $out/context.o $out/map_build.o
 else
   [ -f $root/beluga_amd/lib/context.o ] || python -m beluga_amd.build
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libbeluga_mcl.so $out/kernels.o $root/beluga_amd/lib/context.o $root/beluga_amd/lib/map_build.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libbeluga_mcl.so $out/kernels.o $beam $root/beluga_amd/lib/context.o $root/beluga_amd/lib/map_build.o
 fi
 echo built $out/libbeluga_mcl.so

@@ -1,4 +1,4 @@
-"""Registers, scratch and occupancy of every kernel of kernels.hip (hipcc -Rpass-analysis=kernel-resource-usage; CPU only).
+"""Registers, scratch and occupancy of every kernel of kernels.hip and beam_kernels.hip (hipcc -Rpass-analysis=kernel-resource-usage; CPU only).
 
     python tools/kernel_resources.py [--all] [--out profiles/r05_kernel_resources.txt]
 """
@@ -16,10 +16,12 @@ def main():
     ap.add_argument("--all", action="store_true")
     ap.add_argument("--out")
     args = ap.parse_args()
-    src = os.path.join(ROOT, "beluga_amd", "csrc", "kernels.hip")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
-           "-I" + os.path.dirname(src), "-x", "hip", "-c", src, "-o", "/tmp/kernel_resources.o", "-Rpass-analysis=kernel-resource-usage"]
-    t = subprocess.run(cmd, capture_output=True, text=True).stderr
+    t = ""
+    for name in ("kernels.hip", "beam_kernels.hip"):
+        src = os.path.join(ROOT, "beluga_amd", "csrc", name)
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+               "-I" + os.path.dirname(src), "-x", "hip", "-c", src, "-o", "/tmp/kernel_resources.o", "-Rpass-analysis=kernel-resource-usage"]
+        t += subprocess.run(cmd, capture_output=True, text=True).stderr
     blocks = re.split(r"remark: [^\n]*Function Name: ", t)[1:]
     lines = []
     for b in blocks:
