@@ -1116,6 +1116,7 @@ uint64_t comm_path_word(const mcl_ctx* ctx) {
   mix(ctx->cfg.seed);
   mix(static_cast<uint64_t>(ctx->tuning.device_policy != 0));
   mix(static_cast<uint64_t>(ctx->estimate_kind));
+  mix(static_cast<uint64_t>(ctx->tuning.shard_pad_permille));  // (the byte counts of the fixed-capacity exchange's two all-to-alls)
   // (the thresholds decide update / no update, the recovery alphas whether a cycle injects, the KLD parameters where a cut falls:
   // each of them changes which collectives a cycle reaches)
   for (const double v : {ap.update_min_d, ap.update_min_a, ap.alpha_slow, ap.alpha_fast, ap.kld_epsilon, ap.kld_z, ap.spatial_resolution_x,
@@ -1147,7 +1148,7 @@ mcl_status comm_agree(mcl_ctx* ctx, const char* where) {
     if (theirs != mine)
       return fail(ctx, MCL_ERR_INVALID_ARGUMENT,
                   std::string(where) + ": rank " + std::to_string(r) + " runs another configuration (particle bounds, resampling policy, models, seed, "
-                  "device_policy, estimate kind): every shard of a filter must be created and switched alike");
+                  "device_policy, estimate kind, shard_pad_permille): every shard of a filter must be created and switched alike");
   }
   return MCL_OK;
 }
@@ -2998,7 +2999,16 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "lf_ends_first") t.lf_ends_first = value ? 1 : 0;
   else if (key == "beam_free_ahead") t.beam_free_ahead = value ? 1 : 0;
   else if (key == "beam_sectors") t.beam_sectors = value ? 1 : 0;
-  else if (key == "shard_pad_permille") t.shard_pad_permille = static_cast<int>(std::clamp<int64_t>(value, 0, 8000));
+  else if (key == "shard_pad_permille") {
+    // The capacity every pair of ranks exchanges: on a sharded filter a COLLECTIVE call like device_policy (ranks with different
+    // capacities would post all-to-alls of different sizes); a mismatch leaves the option as it was.
+    const int before = t.shard_pad_permille;
+    t.shard_pad_permille = static_cast<int>(std::clamp<int64_t>(value, 0, 8000));
+    if (const mcl_status s = comm_agree(ctx, "mcl_set_option(shard_pad_permille)")) {
+      t.shard_pad_permille = before;
+      return s;
+    }
+  }
   else if (key == "lf_queue_grid") t.lf_queue_grid = static_cast<int>(std::clamp<int64_t>(value, 0, 1 << 20));
   else if (key == "cycle_spin") t.cycle_spin = value ? 1 : 0;
   else if (key == "beam_table") {

@@ -284,10 +284,10 @@ typedef struct mcl_transport {
 /* Attaches a communicator of `world` ranks to a context created with this rank's shard_offset / shard_capacity.  The transport
  * struct is copied; `user` must outlive the context.  world == 1 is allowed (the cycle then needs no exchange).
  * COLLECTIVE for world > 1: the attach all-gathers a word of the configuration that selects a cycle's collectives (particle bounds,
- * resampling policy, thresholds, recovery alphas, KLD parameters, models, seed, device_policy, estimate kind) and blocks until every
+ * resampling policy, thresholds, recovery alphas, KLD parameters, models, seed, device_policy, estimate kind, shard_pad_permille) and blocks until every
  * rank has attached - the ranks attach CONCURRENTLY (one thread or process per rank; a host that attaches its ranks one after the
  * other from one thread through a rendezvous transport deadlocks) - and every rank fails alike on a mismatch.  On an attached
- * filter mcl_set_option("device_policy", ...) and mcl_set_estimate_kind are collective in the same way: every rank calls them, concurrently,
+ * filter mcl_set_option("device_policy" | "shard_pad_permille", ...) and mcl_set_estimate_kind are collective in the same way: every rank calls them, concurrently,
  * with the same arguments, whatever its own previous value was; on a mismatch they return an error and leave the value unchanged. */
 mcl_status mcl_comm_attach(mcl_ctx* ctx, uint32_t rank, uint32_t world, const mcl_transport* transport);
 /* RCCL: rank 0 obtains an id (ncclGetUniqueId), hands its 128 bytes to the other ranks by any means, every rank attaches. */
@@ -419,6 +419,12 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                   workgroups, each taking blocks from a counter until none is left (an XCD that is ahead takes more:
  *                   2 - 4 % off the kernel at 1M particles), 0 = one workgroup per block.  Which workgroup computes a block changes
  *                   nothing in it.  lf_queue_grid (0): the number of resident workgroups, 0 = three per CU (tests: a few workgroups)
+ *   shard_pad_permille (1063)  sharded fixed-size cycle (mcl_comm_attach): the ancestor exchange moves a FIXED number of entries per pair of
+ *                   ranks - mean * permille / 1000 + 8 * sqrt(mean) + 64, mean = what a shard's output slots ask of one other shard on
+ *                   average - so that no count has to be read by the host in the middle of the cycle (one host synchronisation per cycle);
+ *                   a cycle whose requests do not fit runs the exchange again with exact counts (mcl_get_counter "comm_overflows").
+ *                   0 = always exact counts (two host synchronisations per cycle).  Part of the configuration the ranks compare at
+ *                   mcl_comm_attach; on an attached filter setting it is a COLLECTIVE call like device_policy (every rank, same value).
  *   lf_ends_first (1)  LDS-patch kernel: the blocks are taken from both ends of the spatial order inwards (0, N - 1, 1, N - 2, ...): the ends
  *                   are the cloud's fringe, whose blocks gather every look-up and take twice as long - taken first they are not the launch's
  *                   last; 0 = in order

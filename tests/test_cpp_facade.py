@@ -242,6 +242,25 @@ def _run_ranks(exe, tmp_path, world, particles, cycles, pad=None):
 
 
 @pytest.mark.gpu
+def test_ranks_with_different_exchange_capacities_are_refused_alike(sharded_procs, tmp_path):
+    """shard_pad_permille fixes the byte counts of the ancestor exchange's two all-to-alls: ranks that disagree on it (a stray
+    BELUGA_MCL_SHARD_PAD_PERMILLE in one process's environment) would post collectives of different sizes.  It is part of the word
+    the ranks compare in mcl_comm_attach: both processes are refused there, with the same message, instead of hanging in the first cycle."""
+    name = f"/beluga_mcl_test_{os.getpid()}_padmismatch"
+    procs = [subprocess.Popen([sharded_procs, name, str(r), "2", "60000", "2", str(tmp_path / f"mismatch_rank{r}.bin"), pad],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r, pad in ((0, "1063"), (1, "900"))]
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 5, (p.returncode, out, err)
+        assert "attach_error" in out and "another configuration" in out, out
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world,particles", [(2, 60000), (3, 70001), (4, 131072)])
 def test_sharded_cycle_between_processes_and_its_collectives(sharded_procs, tmp_path, world, particles):
     """The library's sharded cycle (mcl_update on an attached context) with the ranks as SEPARATE PROCESSES (one context each, a
