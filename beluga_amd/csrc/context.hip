@@ -833,9 +833,8 @@ mcl_status do_propagate(mcl_ctx* ctx, const Pose2& pose, const Pose2& prev, uint
 mcl_status reweight_preconditions(mcl_ctx* ctx, uint64_t B) {
   if (!ctx->have_map) return fail(ctx, MCL_ERR_NOT_READY, "mcl_reweight: no map set");
   MCL_REQUIRE(ctx, B <= 0x7FFFFFFFull, "too many points");
-  if (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM)
-    MCL_REQUIRE(ctx, B * sizeof(double2) <= 160 * 1024 || ctx->tuning.lf_variant != kLfWavePerParticle, "scan too large for LDS staging");
-  else if (!(ctx->n < (1ull << 32) && ctx->n >= static_cast<uint64_t>(ctx->tuning.beam_sort_min_particles)))
+  // (no likelihood-field kernel stages the whole scan in LDS any more: lf_variant 0 launches the lane-per-particle kernel of variant 1)
+  if (ctx->cfg.sensor_kind == MCL_SENSOR_BEAM && !(ctx->n < (1ull << 32) && ctx->n >= static_cast<uint64_t>(ctx->tuning.beam_sort_min_particles)))
     // the beam model's small-set kernel (a wave per particle) stages the scan in 64 KB of dynamic LDS
     MCL_REQUIRE(ctx, B * sizeof(double2) <= 64 * 1024, "scan too large for the beam model's small-set kernel (4096 points)");
   return MCL_OK;
@@ -1761,11 +1760,14 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
     MCL_HIP(ctx, hipGetLastError());
     // The ancestor exchange: fixed capacity per pair of ranks (no host read before the cycle's end) where the plain estimate follows -
     // its all-gather carries the overflow flags -, exact counts (one host read) otherwise.
-    const bool padded = fires && ctx->estimate_kind == 0 && ctx->tuning.shard_pad_permille > 0;
+    const bool padded = fires && ctx->estimate_kind == 0 && ctx->tuning.shard_pad_permille > 0 && world > 1;
     const uint64_t m = ctx->n, first_slot = ctx->cfg.shard_offset;
-    auto commit = [&](uint64_t entries) -> mcl_status {
+    auto commit = [&](uint64_t entries, bool injected_apart) -> mcl_status {
+      const FreeCells fc{ctx->d_free.ptr, ctx->have_map ? ctx->n_free : 0};
       launch_commit_routed(ctx->stream, ctx->other(), ctx->cfg.seed, ctx->step, first_slot, entries, ctx->d_replies_in.ptr, ctx->d_route_order.ptr,
-                           ctx->d_targets.ptr, ctx->grid_view(), FreeCells{ctx->d_free.ptr, ctx->have_map ? ctx->n_free : 0});
+                           ctx->d_targets.ptr, ctx->grid_view(), fc);
+      // (the fixed-capacity exchange routes no injected slot: sharded_draw_padded / k_route_hist)
+      if (injected_apart) launch_commit_injected(ctx->stream, ctx->other(), ctx->cfg.seed, ctx->step, first_slot, m, ctx->d_targets.ptr, ctx->grid_view(), fc);
       MCL_HIP(ctx, hipGetLastError());
       ctx->live ^= 1;
       ctx->n = m;
@@ -1777,10 +1779,10 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
         uint64_t entries = 0;
         if (const mcl_status s = sharded_draw_padded(ctx, d_intervals, first_slot, m, d_plan,
                                                     padded_capacity(n_total, world, static_cast<uint32_t>(ctx->tuning.shard_pad_permille)), &entries)) return s;
-        if (const mcl_status s = commit(entries)) return s;
+        if (const mcl_status s = commit(entries, true)) return s;
       } else {
         if (const mcl_status s = sharded_draw(ctx, 0.0, 0.0, d_intervals, first_slot, m, d_plan)) return s;
-        if (const mcl_status s = commit(m)) return s;
+        if (const mcl_status s = commit(m, false)) return s;
       }
       stage_end(ctx, MCL_STAGE_RESAMPLE);
     }
@@ -1801,11 +1803,17 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
         // it, the exchange again with exact counts, the estimate again.
         ctx->comm_overflows += 1;
         ctx->live ^= 1;
+        stage_end(ctx, MCL_STAGE_ESTIMATE);  // (one stage open at a time: the retry's resampling is timed as resampling)
         stage_begin(ctx, MCL_STAGE_RESAMPLE);
-        if (const mcl_status s = sharded_draw(ctx, 0.0, 0.0, d_intervals, first_slot, m, d_plan)) return s;
-        if (const mcl_status s = commit(m)) return s;
+        mcl_status retry = sharded_draw(ctx, 0.0, 0.0, d_intervals, first_slot, m, d_plan);
+        if (retry == MCL_OK) retry = commit(m, false);
         stage_end(ctx, MCL_STAGE_RESAMPLE);
-        if (const mcl_status s = sharded_estimate_sums(ctx, nullptr, 0, sums)) return s;
+        if (retry != MCL_OK) return retry;
+        stage_begin(ctx, MCL_STAGE_ESTIMATE);
+        if (const mcl_status s = sharded_estimate_sums(ctx, nullptr, 0, sums)) {
+          stage_end(ctx, MCL_STAGE_ESTIMATE);
+          return s;
+        }
       }
       stage_end(ctx, MCL_STAGE_ESTIMATE);
       if (const mcl_status s = mcl_estimate_from_sums(sums, &est)) return s;

@@ -412,6 +412,9 @@ void launch_gather_by_cdf_aos(hipStream_t st, Particles src, CdfTree cdf, const 
                               double* d_out);
 void launch_commit_routed(hipStream_t st, Particles dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
                           const double* d_replies, const uint32_t* d_order, const double* d_targets, GridView g, FreeCells fc);
+// The fixed-capacity exchange keeps injected slots (NaN targets) out of its request lists: their random states, straight from d_targets.
+void launch_commit_injected(hipStream_t st, Particles dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
+                            const double* d_targets, GridView g, FreeCells fc);
 // K7: exact parallel take_while_kld (take_while_kld.hpp:72-88).
 void launch_finish_candidates(hipStream_t st, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,
                               const uint32_t* d_order, const double* d_targets, GridView g, FreeCells fc, HashParams hp,

@@ -2390,9 +2390,12 @@ __global__ __launch_bounds__(kBlock) void k_resample_targets(uint64_t seed, uint
 
 // Routing of the resample targets to the shards that own them (counting sort by destination rank, <= 64 ranks).
 constexpr uint32_t kMaxRanks = 64;
+// skip_injected (the fixed-capacity exchange): an injected slot (NaN) gets no destination at all (dest 0xFF) - it would take an entry of
+// the self segment, whose capacity budgets the requests alone (with a recovery probability p the self segment would need m / world + p m
+// entries and overflow in every cycle of the recovery phase); k_commit_injected writes those slots straight from the targets.
 __global__ __launch_bounds__(kBlock) void k_route_hist(const double* __restrict__ targets, uint64_t count, const double* __restrict__ ends,
                                                        uint32_t world, uint32_t self_rank, uint8_t* __restrict__ dest,
-                                                       uint32_t* __restrict__ block_hist, uint32_t nblocks) {
+                                                       uint32_t* __restrict__ block_hist, uint32_t nblocks, int skip_injected) {
   __shared__ uint32_t hist[kMaxRanks];
   __shared__ double s_ends[kMaxRanks];
   if (threadIdx.x < kMaxRanks) {
@@ -2410,6 +2413,9 @@ __global__ __launch_bounds__(kBlock) void k_route_hist(const double* __restrict_
       if (t == t) {
         d = 0;
         while (d + 1 < world && s_ends[d] < t) ++d;  // std::lower_bound over the shard interval ends
+      } else if (skip_injected) {
+        dest[i] = 0xFFu;
+        continue;
       }
       dest[i] = static_cast<uint8_t>(d);
       atomicAdd(&hist[d], 1u);
@@ -2442,6 +2448,7 @@ __global__ __launch_bounds__(kBlock) void k_route_scatter(const double* __restri
     const uint64_t i = base + k * kBlock + threadIdx.x;
     if (i < count) {
       const uint32_t d = dest[i];
+      if (d == 0xFFu) continue;  // an injected slot of the fixed-capacity exchange: no request (k_route_hist)
       const double t = targets[i];
       const uint32_t slot = atomicAdd(&cursor[d], 1u);
       if (pad_capacity && slot >= (d + 1u) * pad_capacity) {
@@ -2494,6 +2501,16 @@ __global__ __launch_bounds__(kBlock) void k_commit_routed(Particles dst, uint64_
     v = Pose2{Rot2{r.z, r.w}, r.x, r.y};
   }
   store_pose(dst, t, v);
+  dst.w[t] = 1.0;
+}
+
+// The injected slots of the fixed-capacity exchange (their targets are NaN and they are in no request list: k_route_hist): the random
+// state of output slot first_slot + t, exactly as k_commit_routed writes it in the exact exchange.
+__global__ __launch_bounds__(kBlock) void k_commit_injected(Particles dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
+                                                            const double* __restrict__ targets, GridView g, FreeCells fc) {
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= count || targets[t] == targets[t]) return;
+  store_pose(dst, t, random_free_state(seed, step, first_slot + t, g, fc));
   dst.w[t] = 1.0;
 }
 
@@ -3394,7 +3411,7 @@ void launch_route_targets(hipStream_t st, const double* d_targets, uint64_t coun
     return;
   }
   hipLaunchKernelGGL(k_route_hist, dim3(nblocks), dim3(kBlock), 0, st, d_targets, count, d_ends, world, self_rank, d_dest, d_block_hist,
-                     nblocks);
+                     nblocks, pad_capacity != 0 ? 1 : 0);
   const uint32_t m = world * nblocks;
   const uint32_t mchunks = num_chunks(m);
   hipLaunchKernelGGL(k_u32_chunk_sum, dim3(mchunks), dim3(kBlock), 0, st, d_block_hist, m, d_chunk_sum);
@@ -3416,6 +3433,12 @@ void launch_commit_routed(hipStream_t st, Particles dst, uint64_t seed, uint32_t
   if (count == 0) return;
   hipLaunchKernelGGL(k_commit_routed, dim3(blocks_for(count)), dim3(kBlock), 0, st, dst, seed, step, first_slot, count,
                      reinterpret_cast<const double4*>(d_replies), d_order, d_targets, g, fc);
+}
+
+void launch_commit_injected(hipStream_t st, Particles dst, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count,
+                            const double* d_targets, GridView g, FreeCells fc) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_commit_injected, dim3(blocks_for(count)), dim3(kBlock), 0, st, dst, seed, step, first_slot, count, d_targets, g, fc);
 }
 
 void launch_finish_candidates(hipStream_t st, uint64_t seed, uint32_t step, uint64_t first_slot, uint64_t count, const double* d_replies,

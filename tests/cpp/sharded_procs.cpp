@@ -5,7 +5,9 @@
 // library's sharded cycle (sharded_update: the collectives, their sizes, the host synchronisations) runs between real processes on
 // a one-GPU box.  On a node with several GPUs: device_id = rank and mcl_comm_attach_rccl instead.
 //
-//   sharded_procs <shm name> <rank> <world> <particles> <cycles> <out file> [shard_pad_permille = library default]
+//   sharded_procs <shm name> <rank> <world> <particles> <cycles> <out file> [shard_pad_permille = library default (-1)]
+//                 [alpha_slow alpha_fast = library defaults; "recovery" scenario: the scans jump half way, the recovery estimator
+//                  (thrun_recovery_probability_estimator.hpp:69-89) answers with a random state probability > 0]
 //
 // Prints, per cycle: the estimate (13 doubles, hex floats) and what the cycle added to the library's communication counters
 // (collectives, bytes handed to the transport, host synchronisations); at the end the exchange's overflow count.  Writes the
@@ -17,6 +19,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -99,6 +102,8 @@ int main(int argc, char** argv) {
   const int cycles = std::atoi(argv[5]);
   const std::string out_path = argv[6];
   const long pad = argc > 7 ? std::atol(argv[7]) : -1;
+  const bool recovery = argc > 9;
+  const double alpha_slow = recovery ? std::atof(argv[8]) : 0.0, alpha_fast = recovery ? std::atof(argv[9]) : 0.0;
   if (world < 1 || world > 64 || rank < 0 || rank >= world) return 64;
 
   // the scenario of tests/cpp/sharded_demo.cpp: a 200 x 160 map with four walls, 120-beam scans, a gentle arc
@@ -111,7 +116,11 @@ int main(int argc, char** argv) {
   shared.rank = rank;
   size_t shm_bytes = 0;
   if (world > 1) {
-    const uint64_t box_bytes = 1 << 16, mail_bytes = ((n_total / world + 1) * 32 + 4095) & ~4095ull;  // a shard's every request to ONE peer fits
+    // a mail box holds what one rank sends ONE peer: a shard's every request to it where that is small, 2.5 x the average share of a
+    // shard's output slots (states of 32 bytes; the fixed capacity is 1.07 x) at the sizes where world^2 such boxes would not fit /dev/shm
+    const uint64_t per_shard = n_total / world + 1;
+    const uint64_t box_bytes = 1 << 16;
+    const uint64_t mail_bytes = (std::min<uint64_t>(per_shard, std::max<uint64_t>(1u << 17, 5 * (per_shard / world) / 2)) * 32 + 4095) & ~4095ull;
     shm_bytes = sizeof(Header) + world * box_bytes + static_cast<uint64_t>(world) * world * mail_bytes;
     int fd = -1;
     if (rank == 0) {
@@ -160,6 +169,10 @@ int main(int argc, char** argv) {
   cfg.amcl.min_particles = cfg.amcl.max_particles = n_total;
   cfg.motion = mcl_diffdrive_params{0.1, 0.05, 0.1, 0.05, 0.01};
   cfg.lf = mcl_lf_params{2.0, 100.0, 0.5, 0.5, 0.2, 1, 0};
+  if (recovery) {
+    cfg.amcl.alpha_slow = alpha_slow;
+    cfg.amcl.alpha_fast = alpha_fast;
+  }
   if (world > 1) {
     cfg.shard_offset = first;
     cfg.shard_capacity = mine;
@@ -188,7 +201,8 @@ int main(int argc, char** argv) {
     const double control[4] = {std::cos(ot), std::sin(ot), ox, oy};
     std::vector<double> scan;
     for (int b = 0; b < 120; ++b) {
-      const double a = -2.0 + b * (4.0 / 120), r = 2.0 + 0.5 * std::sin(0.3 * b + c);
+      // (recovery scenario: from the middle cycle on the scan no longer fits the walls - the average weight drops)
+      const double a = -2.0 + b * (4.0 / 120), r = (recovery && 2 * c >= cycles ? 0.7 : 2.0) + 0.5 * std::sin(0.3 * b + c);
       scan.push_back(r * std::cos(a));
       scan.push_back(r * std::sin(a));
     }
@@ -202,11 +216,12 @@ int main(int argc, char** argv) {
     std::printf("cycle %d est", c);
     for (int k = 0; k < 4; ++k) std::printf(" %a", est.pose[k]);
     for (int k = 0; k < 9; ++k) std::printf(" %a", est.covariance[k]);
-    std::printf(" collectives %llu bytes %llu syncs %llu resampled %d n %llu\n",
+    std::printf(" collectives %llu bytes %llu syncs %llu resampled %d n %llu p_permille %llu\n",
                 static_cast<unsigned long long>(counter(ctx, "comm_collectives") - collectives),
                 static_cast<unsigned long long>(counter(ctx, "comm_bytes_out") - bytes),
                 static_cast<unsigned long long>(counter(ctx, "comm_host_syncs") - syncs), info.resampled,
-                static_cast<unsigned long long>(info.num_particles));
+                static_cast<unsigned long long>(info.num_particles),
+                static_cast<unsigned long long>(info.random_state_probability * 1000.0));
   }
   std::printf("overflows %llu\n", static_cast<unsigned long long>(counter(ctx, "comm_overflows")));
   uint64_t held = 0, got = 0;

@@ -208,18 +208,20 @@ def _padded_capacity(n_total, world, permille):
     return (cap + 63) & ~63
 
 
-def _run_ranks(exe, tmp_path, world, particles, cycles, pad=None):
+def _run_ranks(exe, tmp_path, world, particles, cycles, pad=None, alphas=None, timeout=300):
     name = f"/beluga_mcl_test_{os.getpid()}_{world}_{particles}_{pad}"
     procs = []
     for r in range(world):
         cmd = [exe, name, str(r), str(world), str(particles), str(cycles), str(tmp_path / f"w{world}_p{pad}_rank{r}.bin")]
-        if pad is not None:
-            cmd.append(str(pad))
+        if pad is not None or alphas is not None:
+            cmd.append(str(-1 if pad is None else pad))
+        if alphas is not None:
+            cmd += [repr(float(alphas[0])), repr(float(alphas[1]))]
         procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
         try:
-            out, err = p.communicate(timeout=300)
+            out, err = p.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -301,3 +303,60 @@ def test_sharded_cycle_between_processes_and_its_collectives(sharded_procs, tmp_
         assert whole.shape == single[2].shape
         differ = int(np.any(whole != single[2], axis=1).sum())
         assert differ <= max(5, particles // 10000), (pad, differ)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_recovery_phase_does_not_overflow_the_fixed_capacity_exchange(sharded_procs, tmp_path, world):
+    """random_intersperse over shards (views/random_intersperse.hpp:90-115 behind views/sample.hpp:128-159): with a random state
+    probability p > 0 the injected output slots ask no shard for anything.  They must not take entries of the fixed-capacity
+    exchange either - its capacity budgets m / world requests per pair of ranks plus 6.3 %, and p m injected slots in the self
+    segment would overflow it in every cycle of the recovery phase.  Here the scans jump half way through, the
+    recovery estimator answers with p of several percent, and the exchange still never overflows: one host synchronisation and
+    five collectives in every cycle, and the same particles as the single-context filter."""
+    particles, cycles, alphas = 131072, 8, (0.05, 0.9)
+    single = _run_ranks(sharded_procs, tmp_path, 1, particles, cycles, alphas=alphas)[0]
+    runs = _run_ranks(sharded_procs, tmp_path, world, particles, cycles, alphas=alphas)
+    p_seen = [runs[0][0][c][1]["p_permille"] for c in range(cycles)]
+    assert max(p_seen) >= 1000.0 * 0.063 / world + 10, f"the scenario does not reach the recovery phase: p (permille) per cycle {p_seen}"
+    for c in range(cycles):
+        np.testing.assert_allclose(runs[0][0][c][0], single[0][c][0], rtol=0, atol=1e-9)
+        for r in range(world):
+            k = runs[r][0][c][1]
+            assert k["p_permille"] == single[0][c][1]["p_permille"]
+            assert k["collectives"] == 5 and k["syncs"] == 1, (c, r, k)
+    assert all(run[1] == 0 for run in runs), [run[1] for run in runs]
+    whole = np.concatenate([run[2] for run in runs])
+    differ = int(np.any(whole != single[2], axis=1).sum())
+    assert differ <= max(5, particles // 10000), differ
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_size_realistic_sharded_cycle_on_one_device(sharded_procs, tmp_path, world):
+    """BASELINE configs[3] at the size of ONE rank's share of it: 8M particles as 2 x 4M and 4 x 2M shards - one process per rank, all on
+    the GPU at hand, the shared-memory transport - against a single-context process with the same 8M.  What has only ever run at
+    40k - 200k particles runs here at the sizes it is meant for: the fixed capacity per pair of ranks (millions of entries; entries x 40
+    bytes and every offset beyond 2^31), zero overflows at the default shard_pad_permille, bytes per rank and cycle = the formula of
+    DESIGN.md section 6, one host synchronisation and five collectives per cycle, every rank the same estimate, and the shards in rank
+    order = the single-context set up to CDF-boundary draws."""
+    particles, cycles = 8_000_000, 3
+    single = _run_ranks(sharded_procs, tmp_path, 1, particles, cycles, timeout=900)[0]
+    runs = _run_ranks(sharded_procs, tmp_path, world, particles, cycles, timeout=900)
+    cap = _padded_capacity(particles, world, 1063)
+    assert cap * world < 2**32 and cap * 40 > 2**24
+    for c in range(cycles):
+        for r in range(world):
+            assert runs[r][0][c][0] == runs[0][0][c][0], f"cycle {c}: rank {r} returns another estimate"
+            k = runs[r][0][c][1]
+            assert k["resampled"] == 1 and k["n"] == particles
+            assert k["collectives"] == 5 and k["syncs"] == 1, (c, r, k)
+            assert k["bytes"] == 8 + 24 + (world - 1) * cap * 40 + 80, (c, r, k, cap)
+        np.testing.assert_allclose(runs[0][0][c][0], single[0][c][0], rtol=0, atol=1e-9)
+    assert all(run[1] == 0 for run in runs), [run[1] for run in runs]
+    sizes = [len(run[2]) for run in runs]
+    assert sizes == [particles // world] * world
+    whole = np.concatenate([run[2] for run in runs])
+    assert whole.shape == single[2].shape
+    differ = int(np.any(whole != single[2], axis=1).sum())
+    assert differ <= particles // 10000, differ

@@ -193,7 +193,8 @@ def test_library_rccl_transport_world_one():
     sharded.close()
 
 
-def test_bench_multi_rank_flow_dry_run_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("with_config4", [False, True])
+def test_bench_multi_rank_flow_dry_run_on_one_gpu(tmp_path, with_config4):
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), here with both ranks on the
     GPU at hand and gloo between them (BELUGA_BENCH_BACKEND=gloo: the timings mean nothing): the multi-rank flow - rendezvous,
     sharded filter, timed region with barriers, max over ranks, ONE JSON line from rank 0 - must not fall over unseen on the
@@ -205,7 +206,11 @@ def test_bench_multi_rank_flow_dry_run_on_one_gpu(tmp_path):
     env = dict(os.environ, BELUGA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
            "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--particles", "20000", "--windows", "1",
-           "--stage-steps", "2", "--no-cpu-baseline", "--no-other-configs"]
+           "--stage-steps", "2", "--no-cpu-baseline"]
+    # with_config4: the branch that several ranks add to the line - BASELINE configs[3], a second sharded filter behind the first - runs
+    # as well, at a reduced size (the default 8M per rank is the configuration itself; two of those on one device is the size-realistic
+    # test of tests/test_cpp_facade.py)
+    cmd += ["--config4-particles", "60000"] if with_config4 else ["--no-other-configs"]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -217,4 +222,10 @@ def test_bench_multi_rank_flow_dry_run_on_one_gpu(tmp_path):
     # value = the whole job in the metric's unit (cycles of particles_per_gpu particles): ranks x the logical filter's own cycle rate
     assert line["config"]["filter_cycles_per_s"] == pytest.approx(4 / line["timed_region_s"], rel=1e-9)
     assert line["value"] == pytest.approx(2 * 4 / line["timed_region_s"], rel=1e-9)
+    assert "aggregate over 2 GPUs" in line["metric"] and line["metric"].startswith("MCL update cycles/sec (motion+sensor+resample), N particles x 1080 beams")
     assert line["verified"]["estimate_vs_true_pose"]["ok"], line["verified"]
+    if with_config4:
+        c4 = line["configs"]["4"]
+        assert c4["particles_total"] == 120000 and c4["cycles_per_s"] > 0, c4
+    else:
+        assert "configs" not in line
