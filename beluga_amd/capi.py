@@ -166,6 +166,7 @@ _SIGNATURES = {
     "mcl_set_option": (C.c_int32, [_ctx, C.c_char_p, C.c_int64]),
     "mcl_get_counter": (C.c_int32, [_ctx, C.c_char_p, c_u64_p]),
     "mcl_debug_order": (C.c_int32, [_ctx, c_u32_p, c_u32_p]),
+    "mcl_debug_set_recovery_filters": (C.c_int32, [_ctx, C.c_double, C.c_double]),
     "mcl_debug_curve_index": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mcl_version": (C.c_char_p, []),
     "mcl_measurement_build": (C.c_int, []),

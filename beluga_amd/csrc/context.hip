@@ -247,8 +247,12 @@ struct mcl_ctx {
   uint64_t host_cycles{0};
   DeviceBuffer<double> d_cloud_w;
   DeviceBuffer<double> d_cdf_tree;  // sampled levels of the 16-ary search tree over d_cdf (CdfTree)
+  DeviceBuffer<unsigned long long> d_scan_state;  // k_normalize_cdf: ticket word + the chunk sums' granules (kScanStateWords, zeroed once)
+  uint32_t scan_epoch{0};           // of the last k_normalize_cdf launch on that state
   DeviceBuffer<double> d_lf_wsum;   // sums of the new weights per workgroup of the LF patch kernel (PatchStats::weight_sums)
   uint32_t lf_wsum_count{0};        // how many the last reweight left (0: none; consumed by the normalisation right behind it)
+  bool weights_unit{false};         // every weight of the live set is exactly 1.0: set by what writes them all (initialisation, resampling,
+                                    // particle_traits.hpp:105), cleared by whatever else touches a weight
   CdfTree cdf_tree() const { return make_cdf_tree(d_cdf.ptr, d_cdf_tree.ptr, n); }
 
   // KLD
@@ -457,6 +461,10 @@ mcl_status ensure_capacity(mcl_ctx* ctx, uint64_t cap) {
   MCL_HIP(ctx, ctx->d_cdf.ensure(cap));
   MCL_HIP(ctx, ctx->d_cdf_tree.ensure(cdf_tree_doubles(cap)));
   MCL_HIP(ctx, ctx->d_lf_wsum.ensure(cap / 448 + 2));
+  if (!ctx->d_scan_state.ptr) {
+    MCL_HIP(ctx, ctx->d_scan_state.ensure(kScanStateWords));
+    MCL_HIP(ctx, hipMemset(ctx->d_scan_state.ptr, 0, kScanStateWords * sizeof(unsigned long long)));
+  }
   ctx->capacity = cap;
   {
     static_assert(sizeof(KeyFrame) <= 8 * sizeof(double), "the key frame sits in the first 8 doubles of d_sort_f64");
@@ -847,6 +855,8 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
                        bool want_weight_sums = false) {
   ctx->lf_wsum_count = 0;
   if (const mcl_status s = reweight_preconditions(ctx, B)) return s;
+  const bool unit_weights = ctx->weights_unit && ctx->tuning.lf_unit_weights != 0;
+  ctx->weights_unit = false;
   if (!points_staged) {
     if (const mcl_status s = stage_points(ctx, pts, B)) return s;
     if (B) {
@@ -888,7 +898,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
                                   static_cast<uint32_t>(ctx->tuning.lf_split), want_weight_sums ? ctx->d_lf_wsum.ptr : nullptr,
                                   reinterpret_cast<unsigned int*>(ctx->d_scalars.ptr + 30)},
                        /*dispersed=*/!use_patches && (ctx->tuning.lf_far_tiles == 2 || (ctx->tuning.lf_patch == 1 && !ctx->patch_useful)),
-                       &far_tiles_used, &ctx->lf_wsum_count, &queue_used);
+                       &far_tiles_used, &ctx->lf_wsum_count, &queue_used, unit_weights);
     if (far_tiles_used) ctx->lf_far_launches += 1;
     if (queue_used) ctx->lf_queue_launches += 1;
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
@@ -934,6 +944,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
 // finalize == false (only with factor = NaN and read_back == false): the totals of the normalised weights in d_scalars[1..3)
 // are left to the next kernel (do_build_cdf with a policy, or launch_norm_finalize).
 mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats, bool read_back = true, bool finalize = true) {
+  ctx->weights_unit = false;
   stage_begin(ctx, MCL_STAGE_NORMALIZE);
   if (std::isnan(factor)) {  // by the set's own total
     launch_sum_and_normalize(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->chunk_row(1), ctx->chunk_row(2),
@@ -963,6 +974,24 @@ mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats, bo
   return MCL_OK;
 }
 
+// do_normalize(NaN, nullptr, false, false) + do_build_cdf(true, policy, true) in one launch where the set allows it (*done says whether it
+// did): the fixed-size cycle that resamples at once.  d_scalars[0..3) and [4] as the two leave them, the recovery estimator included.
+mcl_status do_normalize_cdf(mcl_ctx* ctx, const RecoveryPolicy& policy, bool* done) {
+  *done = false;
+  if (ctx->tuning.scan_fused == 0 || !ctx->d_scan_state.ptr || (ctx->tuning.scan_fused == 1 && ctx->n > 65536)) return MCL_OK;
+  ctx->weights_unit = false;
+  stage_begin(ctx, MCL_STAGE_NORMALIZE);
+  if (++ctx->scan_epoch == 0) ctx->scan_epoch = 1;
+  *done = launch_normalize_cdf(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->lf_wsum_count ? ctx->d_lf_wsum.ptr : nullptr,
+                               ctx->lf_wsum_count, ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0, ctx->chunk_row(1), ctx->chunk_row(2),
+                               /*write_weights=*/false, ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4, ctx->d_cdf_tree.ptr, &policy,
+                               ctx->d_scan_state.ptr, ctx->scan_epoch);
+  if (*done) ctx->lf_wsum_count = 0;
+  stage_end(ctx, MCL_STAGE_NORMALIZE);
+  MCL_HIP(ctx, hipGetLastError());
+  return MCL_OK;
+}
+
 // normalized_just_now: the chunk sums k_normalize left in chunk_row(1) are those of the current weights (same summation,
 // same bits as k_chunk_sum would produce) and are reused.  policy (needs normalized_just_now): the CDF kernel's first
 // workgroup also finishes the normalisation's totals (d_scalars[1..3)) and runs the recovery estimator.
@@ -980,13 +1009,14 @@ mcl_status do_build_cdf(mcl_ctx* ctx, bool normalized_just_now = false, const Re
 mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t step, uint64_t* n_out,
                        const double* d_random_state_probability = nullptr, bool normalized_just_now = false,
                        bool with_estimate = false, bool* estimate_enqueued = nullptr, const RecoveryPolicy* policy = nullptr,
-                       bool finalize_norm = false) {
+                       bool finalize_norm = false, bool cdf_ready = false) {
   const mcl_amcl_params& a = ctx->cfg.amcl;
   MCL_REQUIRE(ctx, ctx->n > 0, "mcl_resample: empty particle set");
   ctx->lf_wsum_count = 0;  // (the set changes: workgroup sums of an earlier reweight describe another one)
   const uint64_t max_p = std::min<uint64_t>(a.max_particles, ctx->capacity);
   stage_begin(ctx, MCL_STAGE_RESAMPLE);
-  if (const mcl_status s = do_build_cdf(ctx, normalized_just_now, policy, finalize_norm)) return s;
+  if (!cdf_ready)  // (cdf_ready: do_normalize_cdf left the CDF, the totals and the recovery probability)
+    if (const mcl_status s = do_build_cdf(ctx, normalized_just_now, policy, finalize_norm)) return s;
   ResampleArgs ra{};
   ra.seed = ctx->cfg.seed;
   ra.step = step;
@@ -1005,7 +1035,10 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
     if (with_estimate) {
       MCL_HIP(ctx, ctx->d_est_partials.ensure(static_cast<size_t>(9) * ((max_p + 1023) / 1024)));
       Completion done{};
-      ctx->done_armed = ctx->tuning.cycle_spin && !ctx->profile && estimate_enqueued;
+      // (cycle_spin -1: where the cycle is long enough for the stream's completion signal to be what the host waits for last - measured
+      // + 1 % at 1M particles in alternating runs, profiles/r06_ab_cycle_end.txt; small sets are bound by the host, which the spin costs)
+      const bool spin = ctx->tuning.cycle_spin > 0 || (ctx->tuning.cycle_spin < 0 && max_p >= 262144);
+      ctx->done_armed = spin && !ctx->profile && estimate_enqueued;
       if (ctx->done_armed) {
         done.d_ticket = reinterpret_cast<unsigned long long*>(ctx->d_scalars.ptr + 27);
         done.host_flag = reinterpret_cast<unsigned long long*>(ctx->hd_scalars + 31);
@@ -1013,7 +1046,10 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
       }
       launch_resample_draw_and_estimate(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp,
                                         ctx->pivot[0], ctx->pivot[1], ctx->d_est_partials.ptr, ctx->d_scalars.ptr + 8,
-                                        ctx->hd_scalars + 8, ctx->done_armed ? &done : nullptr);
+                                        ctx->hd_scalars + 8, ctx->done_armed ? &done : nullptr,
+                                        ((ctx->tuning.draw_fold == 2 || (ctx->tuning.draw_fold == 1 && max_p <= 65536)) && ctx->d_scan_state.ptr)
+                                            ? reinterpret_cast<unsigned int*>(ctx->d_scan_state.ptr + 4)
+                                            : nullptr);
       if (estimate_enqueued) *estimate_enqueued = true;
     } else {
       launch_resample_draw(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp, nullptr);
@@ -1045,6 +1081,7 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
   stage_end(ctx, MCL_STAGE_RESAMPLE);
   ctx->live ^= 1;
   ctx->n = result;
+  ctx->weights_unit = true;  // particle_traits.hpp:105: the draw kernel wrote 1.0 to every weight of the new set
   if (n_out) *n_out = result;
   return MCL_OK;
 }
@@ -1771,6 +1808,7 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
       MCL_HIP(ctx, hipGetLastError());
       ctx->live ^= 1;
       ctx->n = m;
+      ctx->weights_unit = true;  // (every output slot took a weight of 1.0: particle_traits.hpp:105)
       return MCL_OK;
     };
     if (fires) {
@@ -1803,6 +1841,7 @@ mcl_status sharded_update(mcl_ctx* ctx, const Pose2& pose, const double* points_
         // it, the exchange again with exact counts, the estimate again.
         ctx->comm_overflows += 1;
         ctx->live ^= 1;
+        ctx->weights_unit = false;  // (the old set again: normalised weights)
         stage_end(ctx, MCL_STAGE_ESTIMATE);  // (one stage open at a time: the retry's resampling is timed as resampling)
         stage_begin(ctx, MCL_STAGE_RESAMPLE);
         mcl_status retry = sharded_draw(ctx, 0.0, 0.0, d_intervals, first_slot, m, d_plan);
@@ -2080,7 +2119,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     }
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin", "scan_fused", "draw_fold", "lf_unit_weights"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2124,6 +2163,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_cdf.release();
   ctx->d_cdf_tree.release();
   ctx->d_lf_wsum.release();
+  ctx->d_scan_state.release();
   ctx->d_cloud.release();
   ctx->d_est_partials.release();
   ctx->d_cloud_w.release();
@@ -2271,8 +2311,10 @@ mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], con
   if (!covariance_to_transform(cov, T)) return fail(ctx, MCL_ERR_BAD_COVARIANCE, "Invalid covariance matrix");
   if (const mcl_status s = bind_device(ctx)) return s;
   const uint64_t n = std::min<uint64_t>(ctx->cfg.amcl.max_particles, ctx->capacity);  // take_exactly(max_particles)
+  ctx->weights_unit = false;
   launch_init_normal(ctx->stream, ctx->cur(), n, mean_xytheta, T, ctx->cfg.seed, ctx->cfg.shard_offset);
   MCL_HIP(ctx, hipGetLastError());
+  ctx->weights_unit = true;  // (k_init_normal writes 1.0 to every weight)
   ctx->n = n;
   ctx->global_n = 0;  // (shards: every rank holds its share of max_particles again)
   ctx->global_n_unknown = false;
@@ -2299,6 +2341,7 @@ mcl_status mcl_set_particles(mcl_ctx* ctx, const double* states, const double* w
     MCL_HIP(ctx, hipMemcpy(ctx->cur().pose, states, n * 4 * sizeof(double), hipMemcpyHostToDevice));  // same record layout
     MCL_HIP(ctx, hipMemcpy(ctx->cur().w, weights, n * sizeof(double), hipMemcpyHostToDevice));
   }
+  ctx->weights_unit = false;
   ctx->n = n;
   ctx->global_n_unknown = ctx->have_comm && ctx->comm_world > 1;  // a shard loaded by the caller: the ranks compare notes first
   ctx->force_update = true;
@@ -2510,14 +2553,18 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   constexpr int kPolicySlot = 20;  // d_scalars[20..23) = {slow, fast, p}
   if (device_policy) {
     // :177; the totals of the normalised weights and the recovery estimator (:179, :184-186) ride on the next kernel
-    if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), nullptr, false, false)) return s;
     ctx->every_n_current = (ctx->every_n_current + 1) % ap.resample_interval;  // :181
     do_resampling = ctx->every_n_current == 0;
     const RecoveryPolicy policy{ap.alpha_slow, ap.alpha_fast, do_resampling ? 1 : 0, ctx->d_scalars.ptr + kPolicySlot,
                                 ctx->hd_scalars + kPolicySlot};
+    bool fused = false;  // :177 and the CDF of :188 in one launch (the normalised weights of a set that is resampled at once are not stored)
+    if (do_resampling)
+      if (const mcl_status s = do_normalize_cdf(ctx, policy, &fused)) return s;
+    if (!fused)
+      if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), nullptr, false, false)) return s;
     if (do_resampling) {
       if (const mcl_status s = do_resample(ctx, 0.0, ctx->step, nullptr, ctx->d_scalars.ptr + kPolicySlot + 2, true,
-                                           ctx->estimate_kind == 0, &estimate_enqueued, &policy, true)) return s;  // :188-196
+                                           ctx->estimate_kind == 0, &estimate_enqueued, &policy, true, fused)) return s;  // :188-196
     } else {
       launch_norm_finalize(ctx->stream, ctx->chunk_row(1), ctx->chunk_row(2), ctx->n, ctx->d_scalars.ptr + 1, ctx->hd_scalars + 1, &policy);
       MCL_HIP(ctx, hipGetLastError());
@@ -2708,6 +2755,7 @@ mcl_status mcl_sample_particle_cloud(mcl_ctx* ctx, uint64_t size, uint32_t draw_
 mcl_status mcl_get_device_view(mcl_ctx* ctx, mcl_device_view* view) {
   if (!ctx || !view) return MCL_ERR_INVALID_ARGUMENT;
   const Particles p = ctx->cur();
+  ctx->weights_unit = false;  // (the caller gets writable pointers)
   view->states = reinterpret_cast<double*>(p.pose);
   view->w = p.w;
   view->cdf = ctx->d_cdf.ptr;
@@ -2721,6 +2769,7 @@ mcl_status mcl_set_num_particles(mcl_ctx* ctx, uint64_t n) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
   ctx->lf_wsum_count = 0;  // (workgroup sums of an earlier reweight describe another set)
   MCL_REQUIRE(ctx, n <= ctx->capacity, "n exceeds capacity");
+  if (n > ctx->n) ctx->weights_unit = false;  // (what lies beyond the set is whatever was there)
   ctx->n = n;
   return MCL_OK;
 }
@@ -2795,6 +2844,7 @@ mcl_status mcl_commit_routed(mcl_ctx* ctx, uint32_t step, uint64_t first_slot, u
   MCL_HIP(ctx, hipGetLastError());
   ctx->live ^= 1;
   ctx->n = count;
+  ctx->weights_unit = true;
   return MCL_OK;
 }
 
@@ -2842,8 +2892,10 @@ mcl_status mcl_load_shard(mcl_ctx* ctx, const double* d_states, uint64_t n, uint
   MCL_REQUIRE(ctx, n == 0 || d_states, "null states");
   if (const mcl_status s = bind_device(ctx)) return s;
   if (n) MCL_HIP(ctx, hipMemcpyAsync(ctx->cur().pose, d_states, n * sizeof(double4), hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->weights_unit = false;
   launch_fill(ctx->stream, ctx->cur().w, n, 1.0);  // particle_traits.hpp:105
   MCL_HIP(ctx, hipGetLastError());
+  ctx->weights_unit = true;
   ctx->n = n;
   ctx->cfg.shard_offset = shard_offset;
   ctx->have_cloud_estimate = false;
@@ -2861,6 +2913,7 @@ mcl_status mcl_weight_sum_device(mcl_ctx* ctx, double* d_sum) {
 mcl_status mcl_normalize_device(mcl_ctx* ctx, const double* d_factor, double* d_stats) {
   if (!ctx || !d_factor || !d_stats) return MCL_ERR_INVALID_ARGUMENT;
   if (const mcl_status s = bind_device(ctx)) return s;
+  ctx->weights_unit = false;
   stage_begin(ctx, MCL_STAGE_NORMALIZE);
   launch_normalize(ctx->stream, ctx->cur().w, ctx->n, d_factor, ctx->chunk_row(1), ctx->chunk_row(2), d_stats);
   stage_end(ctx, MCL_STAGE_NORMALIZE);
@@ -2897,9 +2950,11 @@ mcl_status mcl_initialize_from_map(mcl_ctx* ctx) {
   MCL_REQUIRE(ctx, ctx->n_free > 0, "mcl_initialize_from_map: the map has no free cell");  // the reference asserts (:136)
   if (const mcl_status s = bind_device(ctx)) return s;
   const uint64_t n = std::min<uint64_t>(ctx->cfg.amcl.max_particles, ctx->capacity);  // take_exactly(max_particles)
+  ctx->weights_unit = false;
   launch_init_from_map(ctx->stream, ctx->cur(), n, ctx->cfg.seed, ctx->cfg.shard_offset, ctx->grid_view(),
                        FreeCells{ctx->d_free.ptr, ctx->n_free});
   MCL_HIP(ctx, hipGetLastError());
+  ctx->weights_unit = true;  // (k_init_from_map writes 1.0 to every weight)
   ctx->n = n;
   ctx->global_n = 0;
   ctx->global_n_unknown = false;
@@ -3018,7 +3073,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
     }
   }
   else if (key == "lf_queue_grid") t.lf_queue_grid = static_cast<int>(std::clamp<int64_t>(value, 0, 1 << 20));
-  else if (key == "cycle_spin") t.cycle_spin = value ? 1 : 0;
+  else if (key == "cycle_spin") t.cycle_spin = value < 0 ? -1 : (value ? 1 : 0);
   else if (key == "beam_table") {
     t.beam_table = value ? 1 : 0;
     if (!t.beam_table && ctx->beam_table_ready) {  // its memory goes back at once
@@ -3029,6 +3084,9 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
     }
   }
   else if (key == "lf_weight_sums") t.lf_weight_sums = value ? 1 : 0;
+  else if (key == "scan_fused") t.scan_fused = static_cast<int>(std::clamp<int64_t>(value, 0, 2));
+  else if (key == "draw_fold") t.draw_fold = static_cast<int>(std::clamp<int64_t>(value, 0, 2));
+  else if (key == "lf_unit_weights") t.lf_unit_weights = value ? 1 : 0;
   else if (key == "lf_split") t.lf_split = static_cast<int>(value & 3);  // 1: side by side only, 2: stacked only, 3: both
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else if (key == "beam_sort_min_particles") t.beam_sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
@@ -3083,6 +3141,17 @@ mcl_status mcl_debug_order(mcl_ctx* ctx, uint32_t* perm, uint32_t* keys) {
   MCL_HIP(ctx, hipMemcpyAsync(perm, sort.perm, ctx->n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   MCL_HIP(ctx, hipMemcpyAsync(keys, sort.keys, ctx->n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MCL_OK;
+}
+
+mcl_status mcl_debug_set_recovery_filters(mcl_ctx* ctx, double slow, double fast) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  if (const mcl_status s = bind_device(ctx)) return s;
+  ctx->slow.output = slow;
+  ctx->fast.output = fast;
+  const double both[2] = {slow, fast};
+  MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MCL_HIP(ctx, hipMemcpy(ctx->d_scalars.ptr + 20, both, sizeof(both), hipMemcpyHostToDevice));  // d_scalars[20..23) = {slow, fast, p}
   return MCL_OK;
 }
 

@@ -143,10 +143,12 @@ struct Tuning {
                                     // function) when the frame comes from an estimate of the set, 0 = bins of equal width
   int key_bits_xy = 0;              // bits of the x / y bins of that key: 0 = chosen per cycle from the cloud's spread and the scan's
                                     // reach (4 .. 6), otherwise forced; round 2: 6 (8 heading bits)
-  int cycle_spin = 0;               // fixed-size cycles: 1 = the host waits for the cycle's own completion word (written to mapped host memory
-                                    // by the last kernel, Completion) instead of the stream's completion signal; 0 = hipStreamSynchronize.
-                                    // Measured: nothing at 1M particles (1489 / 1492 vs 1482 / 1496 cycles/s), 4 us per cycle SLOWER at
-                                    // 2000 particles (the launches behind an unsynchronised stream cost the host more) - off
+  int cycle_spin = -1;              // fixed-size cycles: 1 = the host waits for the cycle's own completion word (written to mapped host memory
+                                    // by the last kernel, Completion) instead of the stream's completion signal; 0 = hipStreamSynchronize;
+                                    // -1 = the word for sets of 256K particles and more.  Measured (round 6, three alternating runs of 65
+                                    // cycles each): 1749 against 1731 cycles/s in the driver's window at 1M particles, 1933 against 1901 once
+                                    // the cloud has settled; round 3 at 2000 particles: 4 us per cycle SLOWER (the launches behind an
+                                    // unsynchronised stream cost the host more) - hence the threshold.  The waiting thread spins.
   int beam_table = 1;               // beam model, ordered kernel: the terms that depend on the expected range alone from a table over the hit's
                                     // squared cell distance (built at mcl_set_map); 0 = evaluated per beam
   int lf_weight_sums = 1;           // fixed-size cycle: the normalisation factor is added up from the LF patch kernel's workgroup sums of the
@@ -168,6 +170,16 @@ struct Tuning {
                                     // a window of its own that holds its rays (0 = one centred window; the rays that leave it go on in global memory)
   int lf_queue = 1;                 // LDS-patch kernel: 1 = as many workgroups as stay resident (lf_queue_grid) take the blocks from a queue where
                                     // there are more blocks than that (k_reweight_lf_patch<true>), 0 = one workgroup per block.  Bit-identical.
+  int scan_fused = 1;               // fixed-size cycle that resamples: normalisation, totals, recovery estimator and CDF in ONE launch
+                                    // (k_normalize_cdf): 1 = for sets of up to 64K particles (where the cycle is bound by the host's launches:
+                                    // one less), 2 = wherever the kernel takes the set (up to 2M particles; measured at 1M: 18.6 us against
+                                    // 10.3 + 7.2 - a hand-off inside a launch costs what the kernel boundary did), 0 = k_normalize + k_cdf.
+                                    // Bit-identical.
+  int draw_fold = 1;                // the draw kernel's last workgroup to finish adds up the estimate sums (no k_final_rows launch behind it):
+                                    // 1 = for sets of up to 64K particles, 2 = up to 4M (measured at 1M: 56.2 us against 49.2 + 4.4 - every
+                                    // workgroup ends on the ticket's round trip), 0 = k_final_rows.  Bit-identical.
+  int lf_unit_weights = 1;          // LF patch kernel on a set whose weights are all 1.0 (fresh from a resampling or an initialisation):
+                                    // the old weight is not loaded (1.0 x = x: bit-identical); 0 = always loaded
 };
 
 // Spatial ordering of the particles (kLfSortedLanes, ordered beam kernel): the 64 lanes of a wave should hold neighbouring
@@ -286,7 +298,7 @@ struct PatchStats {
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
                         bool dispersed = false, bool* far_tiles_used = nullptr, uint32_t* weight_sums_written = nullptr,
-                        bool* queue_used = nullptr);
+                        bool* queue_used = nullptr, bool unit_weights = false);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_order_particles first).
 // d_beam_points: scratch of kBeamPointDoubles * B doubles (per-beam terms shared by all particles; ordered variant only).
@@ -388,12 +400,23 @@ inline CdfTree make_cdf_tree(const double* cdf, const double* levels, uint64_t n
 void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
                 double* d_total, double* tree_levels, const double* known_chunk_sum = nullptr, const double* finalize_sumsq = nullptr,
                 double* finalize_sums = nullptr, double* finalize_mirror = nullptr, const RecoveryPolicy* policy = nullptr);
+// Normalisation by the set's own total + totals of the normalised weights (+ recovery estimator) + CDF and its search tree in one launch
+// (k_normalize_cdf): what launch_sum_and_normalize(finalize = false) followed by launch_cdf(known chunk sums, finalize arguments) leave,
+// bit for bit.  known_partials as in launch_sum_and_normalize (nullptr: k_chunk_sum into d_partials first).  scan_state: kScanStateWords
+// words of 8 bytes, zero when allocated, owned by the context; epoch: nonzero, another one than the previous launch's on that state.
+// write_weights = false: the normalised weights themselves are not stored (a cycle that resamples at once never reads them).
+// Returns false, nothing launched, where the set is beyond what the kernel takes (more than 2M particles).
+constexpr size_t kScanStateWords = 8 + 4 * 1024;
+bool launch_normalize_cdf(hipStream_t st, double* w, uint64_t n, double* d_partials, const double* known_partials, uint32_t known_count,
+                          double* d_sums, double* sums_mirror, double* d_chunk_sum, double* d_chunk_sumsq, bool write_weights, double* cdf,
+                          double* d_total, double* tree_levels, const RecoveryPolicy* policy, unsigned long long* scan_state, uint32_t epoch);
 // K6: one thread per candidate (views/sample.hpp:102,133-135; random_intersperse.hpp:90-115; particle_traits.hpp:105).
 void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst,
                           ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes);
 void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst, ResampleArgs a,
                                        GridView g, FreeCells fc, HashParams hp, double pivot_x, double pivot_y, double* d_partials,
-                                       double* d_sums, double* host_mirror, const Completion* done = nullptr);
+                                       double* d_sums, double* host_mirror, const Completion* done = nullptr,
+                                       unsigned int* fold_ticket = nullptr);
 // Sharded variant: targets given, no RNG (mcl_gather_by_cdf).
 // Sharded resampling helpers (mcl_resample_targets / mcl_commit_resampled).
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,

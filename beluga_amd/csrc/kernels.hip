@@ -789,6 +789,9 @@ struct PatchArgs {
   PatchStats stats;
   uint32_t nblocks;
   uint32_t ends_first;  // 1: the blocks are taken from both ends of the order inwards
+  uint32_t unit_weights;  // 1: every weight of the set is 1.0 (a set fresh from a resampling or an initialisation - particle_traits.hpp:105 -:
+                          // the host knows): the new weight is the sensor term itself, 1.0 x = x, and the scattered load of the old weight -
+                          // the last dependent memory round trip of a block's end, 8 us of a 1M launch - is not made
 };
 template <bool kQueue>
 __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reweight_lf_patch(PatchArgs args) {
@@ -858,6 +861,7 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
   const PatchStats& stats = kb->stats;
   const uint32_t nblocks = kb->nblocks;
   const bool ends_first = kb->ends_first != 0u;
+  const uint32_t& unit_weights = kb->unit_weights;
   uint32_t block = blockIdx.x;
   if constexpr (kQueue) {
     __syncthreads();  // the block before is done with the workgroup's memory
@@ -1406,7 +1410,9 @@ __global__ __launch_bounds__(kPatchBlock) __attribute__((amdgpu_waves_per_eu(6, 
     if (partial) {
       partial[static_cast<size_t>(blockIdx.y) * n + t_end] = acc;
     } else {
-      new_weight = w[i_end] * (f.prob ? exp_out_of_line(acc) : acc);
+      double old_weight = 1.0;
+      if (unit_weights == 0u) old_weight = w[i_end];  // (uniform)
+      new_weight = old_weight * (f.prob ? exp_out_of_line(acc) : acc);
       w[i_end] = new_weight;
     }
   }
@@ -1884,8 +1890,9 @@ constexpr int kItems = kChunk / kBlock;  // 8
 // unchanged.  Elements beyond n read as 0.
 constexpr int kChunkPadded = kChunk + kChunk / kItems;
 __device__ __forceinline__ int chunk_slot(int e) { return e + (e >> 3); }
-__device__ __forceinline__ void chunk_items_load(const double* __restrict__ a, uint64_t n, double* lds, double (&x)[kItems]) {
-  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+__device__ __forceinline__ void chunk_items_load(const double* __restrict__ a, uint64_t n, double* lds, double (&x)[kItems],
+                                                 uint32_t chunk = blockIdx.x) {
+  const uint64_t base = static_cast<uint64_t>(chunk) * kChunk;
   if ((reinterpret_cast<uintptr_t>(a) & 15u) == 0) {
 #pragma unroll
     for (int k = 0; k < kChunk / 2 / kBlock; ++k) {
@@ -1910,8 +1917,9 @@ __device__ __forceinline__ void chunk_items_load(const double* __restrict__ a, u
 }
 // The way back: the threads' items to a[chunk] (elements below n only).  The LDS copy may be the one chunk_items_load filled: a
 // thread overwrites the slots it read itself.
-__device__ __forceinline__ void chunk_items_store(double* __restrict__ a, uint64_t n, double* lds, const double (&x)[kItems]) {
-  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+__device__ __forceinline__ void chunk_items_store(double* __restrict__ a, uint64_t n, double* lds, const double (&x)[kItems],
+                                                  uint32_t chunk = blockIdx.x) {
+  const uint64_t base = static_cast<uint64_t>(chunk) * kChunk;
 #pragma unroll
   for (int k = 0; k < kItems; ++k) lds[threadIdx.x * (kItems + 1) + k] = x[k];
   __syncthreads();
@@ -2188,6 +2196,204 @@ __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, ui
   }
 }
 
+// ---- K3 + K5 in one pass: normalise, totals, recovery estimator and CDF (sets of up to kScanFusedMaxChunks chunks) ----------------
+// k_normalize and k_cdf were two launches of a few microseconds of bandwidth each (16 MB apiece at 1M particles) and two ramps: one
+// kernel reads the weights ONCE and leaves w / total, the chunk sums, the totals of the normalised weights (+ one step of the recovery
+// estimator) and the CDF with its search tree.  What a workgroup needs from the others - the sums of the chunks before its own - travels
+// INSIDE the launch (cdna_hip_programming.md section 6, guideline 16, form R2: the data is the flag): a chunk's two sums are published as
+// four 8-byte granules {epoch : 32 | half of the double : 32}, each ONE relaxed agent-scope store (sc1: written through, no release
+// fence, no L2 write-back); a reader re-reads a granule (relaxed agent-scope loads) until its tag is this launch's epoch.  A workgroup
+// publishes before it waits for anything, and the chunk it works on is the TICKET it draws (atomicInc, wrapping to zero behind the
+// launch's last workgroup), not blockIdx: every chunk it waits for belongs to a workgroup that is already running - forward progress
+// holds for any dispatch order, resident or not.  Epochs never repeat within 2^32 launches of a context and the granules start at zero:
+// nothing is reset between launches.
+// Same threads, same elements, same order of additions as k_normalize + k_cdf (the replayed chunk offsets, norm_finalize's rows):
+// every bit of the weights, the sums, the recovery probability and the CDF is the two-kernel path's (tests compare them for equality).
+constexpr uint32_t kScanFusedMaxChunks = 4 * kBlock;  // = k_cdf's replay bound; beyond it a workgroup's look-back would be most of its time
+struct ScanState {
+  unsigned int* ticket;           // one word, zero between launches
+  unsigned long long* granules;   // [chunks][4]: sum lo, sum hi, sum of squares lo, hi
+  uint32_t epoch;                 // != 0
+};
+__device__ __forceinline__ void publish_f64(unsigned long long* g, uint32_t epoch, double v) {
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v), tag = static_cast<unsigned long long>(epoch) << 32;
+  __hip_atomic_store(g + 0, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(g + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double await_f64(unsigned long long* g, uint32_t epoch) {
+  for (;;) {
+    const unsigned long long lo = __hip_atomic_load(g + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (static_cast<uint32_t>(lo >> 32) == epoch && static_cast<uint32_t>(hi >> 32) == epoch)
+      return __builtin_bit_cast(double, (hi << 32) | (lo & 0xFFFFFFFFull));
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+// chunk_offset_replay on values the threads hold: v[t] = the sum of chunk t * kBlock + threadIdx.x (0 from chunk `me` on).
+__device__ __forceinline__ double chunk_offset_replay_held(const double (&held)[kScanFusedMaxChunks / kBlock], uint32_t me) {
+  __shared__ double h_wave[kBlock / 64];
+  __shared__ double h_carry, h_result;
+  if (threadIdx.x == 0) h_carry = 0.0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (uint32_t t = 0; t < kScanFusedMaxChunks / kBlock; ++t) {
+    const uint32_t start = t * kBlock;
+    if (start > me) break;  // (uniform)
+    const uint32_t i = start + threadIdx.x;
+    const double v = held[t];
+    double incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) h_wave[wave] = incl;
+    __syncthreads();
+    double wave_prefix = 0.0;
+    for (int q = 0; q < wave; ++q) wave_prefix += h_wave[q];
+    const double carry = h_carry;
+    if (i == me) h_result = carry + wave_prefix + (incl - v);
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) h_carry = carry + wave_prefix + incl;
+    __syncthreads();
+  }
+  return h_result;
+}
+__global__ __launch_bounds__(kBlock) void k_normalize_cdf(double* __restrict__ w, uint64_t n, const double* __restrict__ d_factor,
+                                                          const double* __restrict__ sum_partials, uint32_t sum_count,
+                                                          double* __restrict__ d_sum_out, double* __restrict__ sum_mirror,
+                                                          double* __restrict__ chunk_sum, double* __restrict__ chunk_sumsq,
+                                                          uint32_t chunk_count, int write_weights, double* __restrict__ cdf,
+                                                          double* __restrict__ total, CdfTree tree, double* __restrict__ levels,
+                                                          NormFinalize fin, ScanState state) {
+  __shared__ double scratch[(kBlock / 64) * 2];
+  __shared__ double s_factor, s_own[2];
+  __shared__ uint32_t s_chunk;
+  __shared__ double s_items[kChunkPadded];
+  if (threadIdx.x == 0) s_chunk = atomicInc(state.ticket, gridDim.x - 1u);
+  if (sum_partials) {  // the factor: the total of these sums, added up by every workgroup as k_final_rows does (k_normalize)
+    double t[1] = {0.0};
+    for (uint32_t b = threadIdx.x; b < sum_count; b += kBlock) t[0] += sum_partials[b];
+    block_reduce<1>(t, scratch);
+    if (threadIdx.x == 0) s_factor = t[0];
+  }
+  __syncthreads();
+  const uint32_t me = s_chunk;
+  const double factor = sum_partials ? s_factor : *d_factor;
+  if (sum_partials && me == 0 && threadIdx.x == 0) {
+    d_sum_out[0] = factor;
+    if (sum_mirror) sum_mirror[0] = factor;
+  }
+  const bool skip = fabs(factor - 1.0) < DBL_EPSILON;  // normalize.hpp:73
+  double x[kItems];
+  chunk_items_load(w, n, s_items, x, me);
+  double v[2] = {0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    if (!skip) x[k] = x[k] / factor;
+    v[0] += x[k];
+    v[1] += x[k] * x[k];
+  }
+  block_reduce<2>(v, scratch);
+  unsigned long long* mine = state.granules + 4ull * me;
+  if (threadIdx.x == 0) {  // published before this workgroup waits for anybody
+    publish_f64(mine + 0, state.epoch, v[0]);
+    publish_f64(mine + 2, state.epoch, v[1]);
+    chunk_sum[me] = v[0];
+    chunk_sumsq[me] = v[1];
+    s_own[0] = v[0];
+    s_own[1] = v[1];
+  }
+  if (!skip && write_weights) chunk_items_store(w, n, s_items, x, me);
+  // the chunk's own scan (k_cdf)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ double s_wave[kBlock / 64];
+  double run = 0.0;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    run += x[k];
+    x[k] = run;
+  }
+  double incl = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  // the sums of the chunks before this one
+  double held[kScanFusedMaxChunks / kBlock];
+#pragma unroll
+  for (uint32_t t = 0; t < kScanFusedMaxChunks / kBlock; ++t) {
+    const uint32_t i = t * kBlock + threadIdx.x;
+    held[t] = i < me ? await_f64(state.granules + 4ull * i, state.epoch) : 0.0;
+  }
+  __syncthreads();  // (s_wave, s_own)
+#pragma unroll
+  for (uint32_t t = 0; t < kScanFusedMaxChunks / kBlock; ++t)  // (the replay's scan runs over this chunk's own sum as well: same bits as k_cdf's)
+    if (t * kBlock + threadIdx.x == me) held[t] = s_own[0];
+  const double my_offset = chunk_offset_replay_held(held, me);
+  double prefix = my_offset;
+  for (int q = 0; q < wave; ++q) prefix += s_wave[q];
+  prefix += incl - run;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) x[k] = prefix + x[k];
+  __syncthreads();  // (s_items: chunk_items_store of the weights may still be read)
+  chunk_items_store(cdf, n, s_items, x, me);
+  const uint64_t base = static_cast<uint64_t>(me) * kChunk + threadIdx.x * kItems;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint64_t i = base + k;
+    if (i < n) {
+      const double c = x[k];
+      if (levels) {
+        uint64_t q = i + 1;
+        for (int l = 0; l < tree.depth && (q & 15) == 0; ++l) {
+          q >>= 4;
+          levels[tree.offset[l] + q - 1] = c;
+        }
+      }
+      if (i == n - 1) {
+        *total = c;
+        if (levels)
+          for (int l = 0; l < tree.depth; ++l) levels[tree.offset[l] + tree.size[l] - 1] = c;
+      }
+    }
+  }
+  // The last chunk's workgroup has every chunk's sum at hand: the totals of the normalised weights and the recovery estimator
+  // (norm_finalize: thread t adds the chunks t, t + kBlock, ... in order, then the block reduction).
+  if (fin.d_sums && me + 1 == chunk_count) {  // (uniform)
+    double sq[kScanFusedMaxChunks / kBlock];
+#pragma unroll
+    for (uint32_t t = 0; t < kScanFusedMaxChunks / kBlock; ++t) {
+      const uint32_t i = t * kBlock + threadIdx.x;
+      sq[t] = i < me ? await_f64(state.granules + 4ull * i + 2, state.epoch) : 0.0;
+      if (i == me) sq[t] = s_own[1];
+    }
+    double a[1] = {0.0}, b[1] = {0.0};
+#pragma unroll
+    for (uint32_t t = 0; t < kScanFusedMaxChunks / kBlock; ++t) {
+      if (t * kBlock + threadIdx.x < chunk_count) {
+        a[0] += held[t];
+        b[0] += sq[t];
+      }
+    }
+    __syncthreads();
+    block_reduce<1>(a, scratch);
+    block_reduce<1>(b, scratch);
+    if (threadIdx.x == 0) {
+      fin.d_sums[0] = a[0];
+      fin.d_sums[1] = b[0];
+      if (fin.sums_mirror) {
+        fin.sums_mirror[0] = a[0];
+        fin.sums_mirror[1] = b[0];
+      }
+      if (fin.policy) recovery_policy_step(a[0], fin);
+    }
+  }
+}
+
 // ---- K6 resample draw -----------------------------------------------------------------------------------
 // spatial_hash.hpp:45-75,87-94,190-193
 __device__ __forceinline__ unsigned long long floor_and_fibo_hash(double value, unsigned shift) {
@@ -2311,12 +2517,24 @@ __device__ __forceinline__ bool intersperse_here(const RngWords& r, uint64_t j, 
 // first_staged on; dynamic shared memory).
 constexpr int kDrawBlock = 1024;
 constexpr uint32_t kDrawStageMax = 4608;  // doubles (36 KB): two workgroups per CU (which also takes 8 waves per SIMD: 64 registers)
+// fold (kEstimate, optional): no k_final_rows launch behind this one - a workgroup stores its nine partial sums WRITTEN THROUGH (one
+// relaxed agent-scope store each: sc1), waits for them to land (s_waitcnt vmcnt(0)) and draws a ticket (atomicInc, wrapping to zero
+// behind the launch's last workgroup); the workgroup that draws the last ticket reads all partials back (relaxed agent-scope loads) and
+// adds every row up as k_final_rows does - 256 threads per row, thread t the workgroups t, t + 256, ... in order, wave sums, the four
+// waves in order: the same bits - four rows at a time on its sixteen waves (cdna_hip_programming.md section 6, guideline 16: written-through
+// payload + drained counter, no release fence and no L2 write-back).
+struct DrawFold {
+  unsigned int* ticket{nullptr};  // zero between launches; nullptr = k_final_rows follows
+  double* out{nullptr};           // [9] the sums
+  double* host_mirror{nullptr};   // optional
+  Completion done{};              // optional completion word (cycle_spin)
+};
 template <bool kEstimate>
 __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
                                                               Particles dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
                                                               unsigned long long* __restrict__ hashes, double pivot_x, double pivot_y,
                                                               double* __restrict__ est_partials, uint32_t est_stride, int first_staged,
-                                                              uint32_t staged_doubles) {
+                                                              uint32_t staged_doubles, DrawFold fold) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* staged = reinterpret_cast<double*>(smem);
   __shared__ double scratch[kEstimate ? (kDrawBlock / 64) * 9 : 1];
@@ -2364,9 +2582,48 @@ __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(8, 8
   }
   if (kEstimate) {
     block_reduce<9, kDrawBlock>(v, scratch);
+    if (fold.ticket == nullptr) {
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) est_partials[static_cast<size_t>(k) * est_stride + blockIdx.x] = v[k];
+      }
+      return;
+    }
+    __shared__ uint32_t s_last;
     if (threadIdx.x == 0) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) est_partials[static_cast<size_t>(k) * est_stride + blockIdx.x] = v[k];
+      for (int k = 0; k < 9; ++k)
+        __hip_atomic_store(est_partials + static_cast<size_t>(k) * est_stride + blockIdx.x, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the written-through partials have landed before the ticket counts
+      s_last = atomicInc(fold.ticket, gridDim.x - 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last == 0u) return;  // (uniform)
+    // the launch's last workgroup: rows k = group, group + 4, group + 8 on the 256 threads of wave group `group`
+    const uint32_t group = threadIdx.x >> 8, t = threadIdx.x & 255u, wave_in_group = t >> 6;
+    double* group_scratch = scratch + group * 4;  // (9 * 16 doubles: room for 4 x 4)
+#pragma unroll 1
+    for (uint32_t round = 0; round < 3; ++round) {
+      const uint32_t k = round * 4 + group;
+      double acc = 0.0;
+      if (k < 9)
+        for (uint32_t b = t; b < gridDim.x; b += 256u)
+          acc += __hip_atomic_load(est_partials + static_cast<size_t>(k) * est_stride + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc = wave_sum_f64(acc);
+      __syncthreads();
+      if ((t & 63u) == 0) group_scratch[wave_in_group] = acc;
+      __syncthreads();
+      if (t == 0 && k < 9) {
+        double total = group_scratch[0];
+        for (int w = 1; w < 4; ++w) total += group_scratch[w];
+        fold.out[k] = total;
+        if (fold.host_mirror) fold.host_mirror[k] = total;
+      }
+    }
+    if (fold.done.host_flag) {
+      __threadfence_system();  // every mirrored value is visible to the host before the completion word
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(fold.done.host_flag, fold.done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -3123,7 +3380,7 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
 
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
-                        bool dispersed, bool* far_tiles_used, uint32_t* weight_sums_written, bool* queue_used) {
+                        bool dispersed, bool* far_tiles_used, uint32_t* weight_sums_written, bool* queue_used, bool unit_weights) {
   if (weight_sums_written) *weight_sums_written = 0;
   if (far_tiles_used) *far_tiles_used = false;
   if (queue_used) *queue_used = false;
@@ -3160,7 +3417,7 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
         const uint32_t cus = tuning.device_cus > 0 ? static_cast<uint32_t>(tuning.device_cus) : 256u;
         const uint32_t resident = tuning.lf_queue_grid > 0 ? static_cast<uint32_t>(tuning.lf_queue_grid) : 3u * cus;
         const PatchArgs args{p.w, n, f, d_points, B, sort->perm, p.pose, partial, per_segment, patch_base, patch_stats, groups_x,
-                             tuning.lf_ends_first != 0 ? 1u : 0u};
+                             tuning.lf_ends_first != 0 ? 1u : 0u, (unit_weights && segments == 1) ? 1u : 0u};
         if (tuning.lf_queue != 0 && segments == 1 && patch_stats.arrivals != nullptr && groups_x > resident) {
           if (queue_used) *queue_used = true;
           hipLaunchKernelGGL(k_reweight_lf_patch<true>, dim3(resident), dim3(kPatchBlock), patch_lds, st, args);
@@ -3316,6 +3573,28 @@ void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum
                      make_cdf_tree(cdf, tree_levels, n), tree_levels, replay ? sums : static_cast<const double*>(nullptr), chunks, fin);
 }
 
+// launch_sum_and_normalize (known partial sums, the totals left to this kernel) + launch_cdf (with its finalize arguments) in ONE launch:
+// k_normalize_cdf.  scan_state: 8 + 4 * kScanFusedMaxChunks words of 8 bytes, zero when the context allocated them; epoch != 0 and different
+// from the previous launch's.  Returns false (nothing launched) where the set is beyond what the kernel takes.
+bool launch_normalize_cdf(hipStream_t st, double* w, uint64_t n, double* d_partials, const double* known_partials, uint32_t known_count,
+                          double* d_sums, double* sums_mirror, double* d_chunk_sum, double* d_chunk_sumsq, bool write_weights, double* cdf,
+                          double* d_total, double* tree_levels, const RecoveryPolicy* policy, unsigned long long* scan_state, uint32_t epoch) {
+  static_assert(kScanStateWords >= 8 + 4 * kScanFusedMaxChunks, "a granule quadruple per chunk behind the ticket's line");
+  const uint32_t chunks = num_chunks(n);
+  if (chunks == 0 || chunks > kScanFusedMaxChunks || (known_partials && known_count > 4096u)) return false;
+  if (!known_partials) {
+    hipLaunchKernelGGL(k_chunk_sum, dim3(chunks), dim3(kBlock), 0, st, w, n, d_partials);
+    known_partials = d_partials;
+    known_count = chunks;
+  }
+  const NormFinalize fin = make_norm_finalize(d_chunk_sum, d_chunk_sumsq, n, d_sums + 1, sums_mirror ? sums_mirror + 1 : nullptr, policy);
+  const ScanState state{reinterpret_cast<unsigned int*>(scan_state), scan_state + 8, epoch};
+  hipLaunchKernelGGL(k_normalize_cdf, dim3(chunks), dim3(kBlock), 0, st, w, n, static_cast<const double*>(nullptr), known_partials, known_count,
+                     d_sums, sums_mirror, d_chunk_sum, d_chunk_sumsq, chunks, write_weights ? 1 : 0, cdf, d_total,
+                     make_cdf_tree(cdf, tree_levels, n), tree_levels, fin, state);
+  return true;
+}
+
 namespace {
 // Which sampled levels of the search tree the draw kernel stages in LDS: all from `first` on, as many as fit.
 void draw_staging(const CdfTree& t, int& first, uint32_t& doubles) {
@@ -3336,21 +3615,28 @@ void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const doub
   draw_staging(cdf, first, doubles);
   const unsigned blocks = static_cast<unsigned>((a.count + kDrawBlock - 1) / kDrawBlock);
   hipLaunchKernelGGL(k_resample_draw<false>, dim3(blocks), dim3(kDrawBlock), doubles * sizeof(double), st, src, cdf, d_total, dst, a, g,
-                     fc, hp, d_hashes, 0.0, 0.0, static_cast<double*>(nullptr), 0u, first, doubles);
+                     fc, hp, d_hashes, 0.0, 0.0, static_cast<double*>(nullptr), 0u, first, doubles, DrawFold{});
 }
 
 // The draw plus the estimate sums of the set it produces: d_partials needs 9 * ceil(count / 1024) doubles.
 void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst, ResampleArgs a,
                                        GridView g, FreeCells fc, HashParams hp, double pivot_x, double pivot_y, double* d_partials,
-                                       double* d_sums, double* host_mirror, const Completion* done) {
+                                       double* d_sums, double* host_mirror, const Completion* done, unsigned int* fold_ticket) {
   int first;
   uint32_t doubles;
   draw_staging(cdf, first, doubles);
   const unsigned blocks = static_cast<unsigned>((a.count + kDrawBlock - 1) / kDrawBlock);
-  if (blocks)
+  // fold_ticket: the sums are added up by the draw's own last workgroup (k_resample_draw, DrawFold) while one workgroup reads them back in
+  // a few loads per thread (4096 workgroups = 4M particles: 36 loads); beyond that, and without a ticket word, k_final_rows follows.
+  const bool fold = fold_ticket != nullptr && blocks > 0 && blocks <= 4096u;
+  if (blocks) {
+    DrawFold f{};
+    if (fold) f = DrawFold{fold_ticket, d_sums, host_mirror, done ? *done : Completion{}};
     hipLaunchKernelGGL(k_resample_draw<true>, dim3(blocks), dim3(kDrawBlock), doubles * sizeof(double), st, src, cdf, d_total, dst, a, g,
-                       fc, hp, static_cast<unsigned long long*>(nullptr), pivot_x, pivot_y, d_partials, blocks, first, doubles);
-  hipLaunchKernelGGL(k_final_rows, dim3(9), dim3(kBlock), 0, st, d_partials, blocks, blocks, d_sums, host_mirror, done ? *done : Completion{});
+                       fc, hp, static_cast<unsigned long long*>(nullptr), pivot_x, pivot_y, d_partials, blocks, first, doubles, f);
+  }
+  if (!fold)
+    hipLaunchKernelGGL(k_final_rows, dim3(9), dim3(kBlock), 0, st, d_partials, blocks, blocks, d_sums, host_mirror, done ? *done : Completion{});
 }
 
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,

@@ -433,10 +433,19 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                   whole-grid maps in global memory (same cells visited either way)
  *   beam_free_ahead (1)  beam model, ordered kernel: per workgroup and beam, the cells the middle particle's ray clearance proves free for
  *                   every lane are passed in one closed-form step before a lane's own walk (same cells visited, same weights)
- *   cycle_spin (0)  fixed-size cycles (resample every cycle, mean / covariance estimate): 1 = the host waits for a completion word the
- *                   cycle's last kernel stores to mapped host memory instead of the stream's completion signal; 0 = hipStreamSynchronize.
- *                   Measured: no gain at 1M particles, 4 us per cycle slower at 2000 - off by default.  Never while stage
- *                   profiling is enabled.
+ *   cycle_spin (-1)  fixed-size cycles (resample every cycle, mean / covariance estimate): 1 = the host waits for a completion word the
+ *                   cycle's last kernel stores to mapped host memory instead of the stream's completion signal (the calling thread spins
+ *                   for the length of the cycle); 0 = hipStreamSynchronize; -1 = the word for sets of 256K particles and more.
+ *                   Measured: + 1 % at 1M particles, 4 us per cycle slower at 2000.  Never while stage profiling is enabled.
+ *   scan_fused (1)  fixed-size cycle that resamples: normalisation, totals of the normalised weights, recovery estimator and CDF in ONE
+ *                   launch (the chunk sums travel between the workgroups inside it): 1 = for sets of up to 64K particles, where the cycle
+ *                   is bound by the host's launches; 2 = up to 2M particles (measured at 1M: no faster than the two launches); 0 = never.
+ *                   Bit-identical.
+ *   draw_fold (1)   the draw kernel's last workgroup to finish adds up the estimate sums instead of a launch of its own behind it: 1 = for
+ *                   sets of up to 64K particles, 2 = up to 4M (measured at 1M: 2.6 us slower), 0 = never.  Bit-identical.
+ *   lf_unit_weights (1)  LDS-patch kernel on a set whose weights are all 1.0 - fresh from a resampling or an initialisation
+ *                   (particle_traits.hpp:105), which the library keeps track of -: the old weight is not loaded (1.0 x = x); 0 = always
+ *                   loaded.  Bit-identical; 9 us of a 1M-particle cycle.
  *   lf_split (3)    LDS-patch planner: a group of 8 beams that fits no whole 64 x 64-cell patch (its end-points straddle a range
  *                   discontinuity: 3 - 5 % of the groups of an indoor scan, whatever the cloud) goes through two half patches -
  *                   beams [0, k) and [k, 8), 32 x 64 (bit 0) or 64 x 32 (bit 1) cells each, in the buffer of one whole patch; 0 = such
@@ -461,6 +470,13 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value);
 /* Runs the spatial ordering on the current set and returns it: perm[t] = particle at position t, keys[i] = ordering key
  * of particle i (n entries each, host memory).  keys[perm[t]] is non-decreasing in t. */
 mcl_status mcl_debug_order(mcl_ctx* ctx, uint32_t* perm, uint32_t* keys);
+
+/* Test hook: sets the outputs of the two exponential filters of ThrunRecoveryProbabilityEstimator
+ * (thrun_recovery_probability_estimator.hpp:69-89, exponential_filter.hpp:32-44) on the host and on the device.  With a fixed particle
+ * count the estimator sees the average of NORMALISED weights - 1 / N in every cycle - and never leaves p = 0 by itself (amcl_core.hpp:177-179,
+ * as in the reference); a test that wants a cycle with injected random states (random_intersperse over shards) puts the filters apart first.
+ * On an attached filter every rank has to make the same call. */
+mcl_status mcl_debug_set_recovery_filters(mcl_ctx* ctx, double slow, double fast);
 
 /* Position of the cell (heading, y, x), `bits` bits each, along the 3-D Hilbert curve the heading-major ordering key follows
  * (kernels.h hilbert_index_3; pure host arithmetic, no device needed): consecutive positions are face neighbours. */

@@ -6,8 +6,9 @@
 // a one-GPU box.  On a node with several GPUs: device_id = rank and mcl_comm_attach_rccl instead.
 //
 //   sharded_procs <shm name> <rank> <world> <particles> <cycles> <out file> [shard_pad_permille = library default (-1)]
-//                 [alpha_slow alpha_fast = library defaults; "recovery" scenario: the scans jump half way, the recovery estimator
-//                  (thrun_recovery_probability_estimator.hpp:69-89) answers with a random state probability > 0]
+//                 [alpha_slow alpha_fast = library defaults; "recovery" scenario: before the middle cycle the two filters of the recovery
+//                  estimator are put apart (mcl_debug_set_recovery_filters: slow = 2 / N, fast = 1 / N - with a fixed particle count the
+//                  estimator never leaves p = 0 by itself), and that cycle resamples with a random state probability of several tenths]
 //
 // Prints, per cycle: the estimate (13 doubles, hex floats) and what the cycle added to the library's communication counters
 // (collectives, bytes handed to the transport, host synchronisations); at the end the exchange's overflow count.  Writes the
@@ -201,11 +202,12 @@ int main(int argc, char** argv) {
     const double control[4] = {std::cos(ot), std::sin(ot), ox, oy};
     std::vector<double> scan;
     for (int b = 0; b < 120; ++b) {
-      // (recovery scenario: from the middle cycle on the scan no longer fits the walls - the average weight drops)
-      const double a = -2.0 + b * (4.0 / 120), r = (recovery && 2 * c >= cycles ? 0.7 : 2.0) + 0.5 * std::sin(0.3 * b + c);
+      const double a = -2.0 + b * (4.0 / 120), r = 2.0 + 0.5 * std::sin(0.3 * b + c);
       scan.push_back(r * std::cos(a));
       scan.push_back(r * std::sin(a));
     }
+    if (recovery && c == cycles / 2 &&
+        mcl_debug_set_recovery_filters(ctx, 2.0 / static_cast<double>(n_total), 1.0 / static_cast<double>(n_total)) != MCL_OK) return 7;
     const uint64_t collectives = counter(ctx, "comm_collectives"), bytes = counter(ctx, "comm_bytes_out"), syncs = counter(ctx, "comm_host_syncs");
     mcl_estimate est;
     mcl_update_info info;

@@ -1333,6 +1333,66 @@ def test_queue_of_blocks_leaves_the_same_cycle_as_a_workgroup_per_block():
     assert np.array_equal(outs[0][1][0], outs[1][1][0]) and np.array_equal(outs[0][1][1], outs[1][1][1])
 
 
+@pytest.mark.parametrize("n,beams", [(1_000_000, 1080), (300_001, 360), (70_000, 180), (2_000, 180), (2_097_152, 90)])
+def test_one_launch_scan_and_folded_estimate_sums_leave_the_same_cycle(n, beams):
+    """Round 6 took two launches out of the fixed-size cycle: k_normalize_cdf (option scan_fused: normalisation, totals of the normalised
+    weights, recovery estimator and CDF in one pass, the chunk sums handed from workgroup to workgroup inside the launch) instead of
+    k_normalize + k_cdf, and the estimate sums added up by the draw kernel's last workgroup (option draw_fold) instead of k_final_rows.
+    Same threads, same elements, same order of additions (actions/normalize.hpp:54-85, views/sample.hpp:128-159,
+    effective_sample_size.hpp:46-59): estimates, weight sums, recovery probabilities and the resampled sets are identical bit for bit,
+    launch after launch (the tickets wrap to zero, the epochs move on), on sets of one chunk, of a ragged last chunk, of the largest size
+    the fused kernel takes (1024 chunks) - with the LF patch kernel's workgroup sums (1M) and with chunk sums of the weights (the others)."""
+    import bench
+    cycles = 6
+    cells, truth, odoms, scans, _poses = bench.make_workload(cycles)
+    grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
+    keep = np.linspace(0, bench.BEAMS - 1, beams).astype(int)
+    outs = []
+    for fused, fold in ((1, 1), (0, 0), (1, 0), (0, 1)):
+        f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF),
+                 AmclParams(min_particles=n, max_particles=n), seed=42)
+        f.set_option("scan_fused", 2 * fused)  # (2: wherever the kernel takes the set; the default takes it for small sets only)
+        f.set_option("draw_fold", 2 * fold)
+        f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+        est = []
+        for c in range(cycles):
+            e = f.update(se2_from_xytheta(*odoms[c]), scans[c][keep])
+            est.append(np.concatenate([e[0], e[1].ravel(), [f.last_info["weight_sum"], f.last_info["random_state_probability"]]]))
+        outs.append((np.asarray(est), f.particles()))
+        f.close()
+    for other in outs[1:]:
+        assert np.array_equal(outs[0][0], other[0]), np.abs(outs[0][0] - other[0]).max()
+        assert np.array_equal(outs[0][1][0], other[1][0]) and np.array_equal(outs[0][1][1], other[1][1])
+
+
+@pytest.mark.parametrize("interval", [1, 2])
+def test_unit_weights_skip_the_old_weights_load_and_change_nothing(interval):
+    """A set fresh from a resampling or an initialisation holds weights of exactly 1.0 (particle_traits.hpp:105), and the host knows: the
+    LF patch kernel then takes the sensor term as the new weight without loading the old one (option lf_unit_weights; 1.0 x = x).  Whole
+    cycles with and without: identical bit for bit - resampling every cycle (every reweight sees unit weights) and every second cycle
+    (resample_interval 2: the reweights in between multiply into normalised weights, which must still be loaded)."""
+    import bench
+    cycles, n = 7, 1_000_000
+    cells, truth, odoms, scans, _poses = bench.make_workload(cycles)
+    grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
+    outs = []
+    for unit in (1, 0):
+        f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF),
+                 AmclParams(min_particles=n, max_particles=n, resample_interval=interval), seed=42)
+        f.set_option("lf_unit_weights", unit)
+        f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+        est = []
+        for c in range(cycles):
+            e = f.update(se2_from_xytheta(*odoms[c]), scans[c])
+            est.append(np.concatenate([e[0], e[1].ravel(), [f.last_info["weight_sum"], float(f.last_info["resampled"])]]))
+        outs.append((np.asarray(est), f.particles()))
+        f.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1][0], outs[1][1][0]) and np.array_equal(outs[0][1][1], outs[1][1][1])
+    if interval == 2:
+        assert set(outs[0][0][:, -1]) == {0.0, 1.0}
+
+
 @pytest.mark.parametrize("options", [
     dict(lf_split=3, lf_margin=1, key_curve=1),  # the defaults
     dict(lf_split=1), dict(lf_split=2), dict(lf_split=0, lf_margin=0, key_curve=0, key_bits_xy=6),
