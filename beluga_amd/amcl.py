@@ -197,7 +197,32 @@ class Amcl:
                                           traits))
         self._shape = (H, W)
 
+    def update_map_async(self, grid: OccupancyGrid):
+        """Extension (mcl_set_map_async): the new map's likelihood field is built on a worker thread while the filter keeps running on
+        the map it has; the swap happens at the start of the first update() after the build is done, or in map_commit()."""
+        cells = np.ascontiguousarray(grid.cells, dtype=np.int8)
+        H, W = cells.shape
+        origin = np.ascontiguousarray(grid.origin, dtype=np.float64)
+        traits = (C.c_int8 * 3)(*grid.value_traits)
+        self._check(self._lib.mcl_set_map_async(self._ctx, cells.ctypes.data_as(capi.c_i8_p), W, H, float(grid.resolution), _dp(origin),
+                                                traits))
+        self._pending_shape = (H, W)
+
+    def map_pending(self) -> int:
+        """0: no map on its way, 1: its field is being built, 2: built, waiting for the swap."""
+        v = C.c_int32(0)
+        self._check(self._lib.mcl_map_pending(self._ctx, C.byref(v)))
+        if v.value == 0 and getattr(self, "_pending_shape", None) is not None:
+            self._shape, self._pending_shape = self._pending_shape, None
+        return v.value
+
+    def map_commit(self, wait: bool = True):
+        """Swaps to the map given to update_map_async now (wait: for its build first; otherwise only if it is done)."""
+        self._check(self._lib.mcl_map_commit(self._ctx, 1 if wait else 0))
+        self.map_pending()
+
     def likelihood_field(self) -> np.ndarray:
+        self.map_pending()  # (a swap inside update() may have changed the map's shape)
         """LikelihoodFieldModelBase::likelihood_field() (likelihood_field_model_base.hpp:102)."""
         out = np.zeros(self._shape, dtype=np.float32)
         self._check(self._lib.mcl_get_likelihood_field(self._ctx, out.ctypes.data_as(capi.c_float_p)))

@@ -115,6 +115,9 @@ _SIGNATURES = {
     "mcl_destroy": (None, [_ctx]),
     "mcl_last_error": (C.c_char_p, [_ctx]),
     "mcl_set_map": (C.c_int32, [_ctx, c_i8_p, C.c_uint32, C.c_uint32, C.c_double, c_double_p, c_i8_p]),
+    "mcl_set_map_async": (C.c_int32, [_ctx, c_i8_p, C.c_uint32, C.c_uint32, C.c_double, c_double_p, c_i8_p]),
+    "mcl_map_pending": (C.c_int32, [_ctx, C.POINTER(C.c_int32)]),
+    "mcl_map_commit": (C.c_int32, [_ctx, C.c_int32]),
     "mcl_get_likelihood_field": (C.c_int32, [_ctx, c_float_p]),
     "mcl_set_likelihood_field": (C.c_int32, [_ctx, c_float_p]),
     "mcl_initialize_normal": (C.c_int32, [_ctx, c_double_p, c_double_p]),

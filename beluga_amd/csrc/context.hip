@@ -254,6 +254,17 @@ struct mcl_ctx {
   bool weights_unit{false};         // every weight of the live set is exactly 1.0: set by what writes them all (initialisation, resampling,
                                     // particle_traits.hpp:105), cleared by whatever else touches a weight
   CdfTree cdf_tree() const { return make_cdf_tree(d_cdf.ptr, d_cdf_tree.ptr, n); }
+  // mcl_set_map_async: the next map, its likelihood field being built on a worker thread (state 1) or built and waiting for its swap (2)
+  struct PendingMap {
+    std::vector<int8_t> cells;
+    uint32_t W{0}, H{0};
+    double resolution{0.0}, origin[4]{1.0, 0.0, 0.0, 0.0};
+    int8_t traits[3]{0, -1, 100};
+    std::vector<float> field;  // (likelihood-field models with the host build; empty otherwise: nothing to build ahead)
+    std::thread worker;
+    std::atomic<int> state{0};
+  };
+  PendingMap* pending_map{nullptr};
 
   // KLD
   DeviceBuffer<unsigned long long> d_hashes;
@@ -2032,6 +2043,10 @@ int32_t rccl_all_to_all(void* user, const void* d_send, const uint64_t* send_byt
   return rc ? rc : end;
 }
 
+// (mcl_set_map_async: defined beside mcl_set_map)
+void drop_pending_map(mcl_ctx* ctx);
+mcl_status apply_pending_map(mcl_ctx* ctx, bool wait);
+
 }  // namespace
 
 extern "C" {
@@ -2140,6 +2155,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
 }
 
 void mcl_destroy(mcl_ctx* ctx) {
+  if (ctx) drop_pending_map(ctx);
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -2209,11 +2225,89 @@ void mcl_destroy(mcl_ctx* ctx) {
   delete ctx;
 }
 
+}  // extern "C"
+namespace {
+void drop_pending_map(mcl_ctx* ctx) {
+  if (!ctx->pending_map) return;
+  if (ctx->pending_map->worker.joinable()) ctx->pending_map->worker.join();
+  delete ctx->pending_map;
+  ctx->pending_map = nullptr;
+}
+// prebuilt_field (mcl_set_map_async): the likelihood field of exactly these cells and the context's parameters, built ahead by the worker
+mcl_status set_map_impl(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32_t height, double resolution, const double origin[4],
+                        const int8_t value_traits[3], std::vector<float>* prebuilt_field);
+// The swap of a map built ahead, where one is ready (the start of mcl_update; mcl_map_commit).
+mcl_status apply_pending_map(mcl_ctx* ctx, bool wait) {
+  mcl_ctx::PendingMap* p = ctx->pending_map;
+  if (!p) return MCL_OK;
+  if (p->state.load(std::memory_order_acquire) != 2 && !wait) return MCL_OK;
+  if (p->worker.joinable()) p->worker.join();
+  const mcl_status s = set_map_impl(ctx, p->cells.data(), p->W, p->H, p->resolution, p->origin, p->traits, p->field.empty() ? nullptr : &p->field);
+  drop_pending_map(ctx);
+  return s;
+}
+}  // namespace
+extern "C" {
+
 mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32_t height, double resolution,
                        const double origin[4], const int8_t value_traits[3]) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
   MCL_REQUIRE(ctx, cells && origin && value_traits && width > 0 && height > 0 && resolution > 0, "mcl_set_map: bad argument");
   MCL_REQUIRE(ctx, static_cast<uint64_t>(width) * height < 0xFFFFFFFFull, "mcl_set_map: grid too large");
+  drop_pending_map(ctx);  // (a map given now replaces one that is still on its way)
+  return set_map_impl(ctx, cells, width, height, resolution, origin, value_traits, nullptr);
+}
+
+mcl_status mcl_set_map_async(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32_t height, double resolution,
+                             const double origin[4], const int8_t value_traits[3]) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  MCL_REQUIRE(ctx, cells && origin && value_traits && width > 0 && height > 0 && resolution > 0, "mcl_set_map_async: bad argument");
+  MCL_REQUIRE(ctx, static_cast<uint64_t>(width) * height < 0xFFFFFFFFull, "mcl_set_map_async: grid too large");
+  if (ctx->have_comm && ctx->comm_world > 1)
+    return fail(ctx, MCL_ERR_UNSUPPORTED, "mcl_set_map_async: not on a sharded filter (the ranks would swap maps in different cycles)");
+  drop_pending_map(ctx);
+  auto* p = new (std::nothrow) mcl_ctx::PendingMap();
+  if (!p) return fail(ctx, MCL_ERR_OUT_OF_MEMORY, "mcl_set_map_async: out of memory");
+  try {
+    p->cells.assign(cells, cells + static_cast<size_t>(width) * height);
+  } catch (const std::bad_alloc&) {
+    delete p;
+    return fail(ctx, MCL_ERR_OUT_OF_MEMORY, "mcl_set_map_async: out of memory");
+  }
+  p->W = width;
+  p->H = height;
+  p->resolution = resolution;
+  std::memcpy(p->origin, origin, sizeof p->origin);
+  std::memcpy(p->traits, value_traits, sizeof p->traits);
+  ctx->pending_map = p;
+  if (ctx->cfg.sensor_kind != MCL_SENSOR_BEAM && ctx->tuning.field_build == 0) {
+    p->state.store(1, std::memory_order_release);
+    const mcl_lf_params lf = ctx->cfg.lf;
+    p->worker = std::thread([p, lf] {
+      build_likelihood_field(p->cells.data(), p->W, p->H, p->resolution, OccupancyTraits{p->traits[0], p->traits[1], p->traits[2]}, lf, p->field);
+      p->state.store(2, std::memory_order_release);
+    });
+  } else {
+    p->state.store(2, std::memory_order_release);  // (nothing to build on the host: the swap does it all)
+  }
+  return MCL_OK;
+}
+
+mcl_status mcl_map_pending(mcl_ctx* ctx, int32_t* state) {
+  if (!ctx || !state) return MCL_ERR_INVALID_ARGUMENT;
+  *state = ctx->pending_map ? ctx->pending_map->state.load(std::memory_order_acquire) : 0;
+  return MCL_OK;
+}
+
+mcl_status mcl_map_commit(mcl_ctx* ctx, int32_t wait) {
+  if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
+  return apply_pending_map(ctx, wait != 0);
+}
+
+}  // extern "C"
+namespace {
+mcl_status set_map_impl(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32_t height, double resolution, const double origin[4],
+                        const int8_t value_traits[3], std::vector<float>* prebuilt_field) {
   if (const mcl_status s = bind_device(ctx)) return s;
   const size_t n = static_cast<size_t>(width) * height;
   ctx->W = width;
@@ -2271,7 +2365,8 @@ mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32
       }
     }
     if (!on_device) {
-      build_likelihood_field(cells, width, height, resolution, ctx->traits, ctx->cfg.lf, ctx->h_field);
+      if (prebuilt_field) ctx->h_field.swap(*prebuilt_field);
+      else build_likelihood_field(cells, width, height, resolution, ctx->traits, ctx->cfg.lf, ctx->h_field);
       MCL_HIP(ctx, hipMemcpy(ctx->d_field.ptr, ctx->h_field.data(), n * sizeof(float), hipMemcpyHostToDevice));
     }
     ctx->field_built_on_device = on_device;
@@ -2280,6 +2375,8 @@ mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32
   ctx->have_map = true;
   return MCL_OK;
 }
+}  // namespace
+extern "C" {
 
 mcl_status mcl_get_likelihood_field(mcl_ctx* ctx, float* out) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
@@ -2481,6 +2578,8 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
     info->effective_sample_size = -1.0;
     info->num_particles = ctx->n;
   }
+  if (ctx->pending_map)  // a map built ahead (mcl_set_map_async) takes over where its field is done
+    if (const mcl_status s = apply_pending_map(ctx, false)) return s;
   if (ctx->n == 0) return MCL_OK;  // amcl_core.hpp:166-168 -> nullopt
   const Pose2 pose = pose_from(control_pose);
   // update_policy_ = on_motion (policies/on_motion.hpp:63-67,121-133); evaluated even when forced (:170)

@@ -396,6 +396,33 @@ class Amcl {
     field_.reset();
   }
 
+  /// Extension (mcl_set_map_async): the new map's likelihood field is built on a worker thread - the reference's update_map blocks the
+  /// caller for the build, seconds at 16 M cells - while the filter keeps running on the map it has; the swap happens at the start of the
+  /// first update() after the build is done, or in map_commit().  `map` is copied before the call returns.
+  void update_map_async(const OccupancyGridView& map) {
+    const std::int8_t traits[3] = {map.free_value, map.unknown_value, map.occupied_value};
+    check(mcl_set_map_async(ctx_, map.cells, map.width, map.height, map.resolution, map.origin.data(), traits));
+    pending_ = {map.width, map.height, map.resolution};
+    have_pending_ = true;
+  }
+  /// 0: no map on its way, 1: its field is being built, 2: built, waiting for the swap.
+  int map_pending() {
+    std::int32_t state = 0;
+    check(mcl_map_pending(ctx_, &state));
+    if (state == 0 && have_pending_) {  // the swap has happened (inside an update, or in map_commit)
+      width_ = pending_.width;
+      height_ = pending_.height;
+      resolution_ = pending_.resolution;
+      have_pending_ = false;
+      field_.reset();
+    }
+    return state;
+  }
+  void map_commit(bool wait = true) {
+    check(mcl_map_commit(ctx_, wait ? 1 : 0));
+    (void)map_pending();
+  }
+
   /// The C ABI writes points as a flat double[2 m]; the measurement type is a vector of pairs (no aliasing between the two).
   static measurement_type pairs_from(const std::vector<double>& flat, std::size_t m) {
     measurement_type points;
@@ -413,6 +440,7 @@ class Amcl {
     check(mcl_update(ctx_, control_action.data(), measurement.empty() ? nullptr : &measurement.front().first, measurement.size(),
                      &est, &info));
     last_info_ = info;
+    if (have_pending_) (void)map_pending();  // (a map given to update_map_async may have taken over inside this call)
     if (!info.updated) return std::nullopt;
     dirty_ = true;
     estimation_type out;
@@ -542,6 +570,12 @@ class Amcl {
     if (st != MCL_OK) throw std::runtime_error(std::string("beluga_amd::Amcl: ") + mcl_last_error(ctx_));
   }
   mcl_ctx* ctx_{nullptr};
+  struct PendingShape {
+    std::uint32_t width{0}, height{0};
+    double resolution{0.0};
+  };
+  PendingShape pending_{};  ///< of the map given to update_map_async, until its swap
+  bool have_pending_{false};
   std::uint32_t width_{0}, height_{0};
   std::size_t max_particles_{0};
   double resolution_{0.0};

@@ -128,6 +128,18 @@ const char* mcl_last_error(const mcl_ctx* ctx); /* ctx may be NULL: error of the
  * free-cell list used by the random-state generator (random/multivariate_uniform_distribution.hpp:126-161). */
 mcl_status mcl_set_map(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32_t height, double resolution,
                        const double origin[4], const int8_t value_traits[3]);
+/* Extension beside mcl_set_map (the reference has no such call: Amcl::update_map, amcl_core.hpp:150, builds the new sensor model on the
+ * caller's thread, which at 16 M cells is 1 - 3 s of priority-queue wavefront, distance_map.hpp:55-98, during which no update runs):
+ * the arguments are copied, the likelihood field of the new grid is built on a WORKER thread - the same host wavefront, the same bits -
+ * while the filter keeps running on the map it has, and the swap (uploads, derived tables: a few milliseconds) happens at the start of
+ * the first mcl_update after the build is done, or in mcl_map_commit.  A second call, or mcl_set_map, replaces a pending one.
+ * mcl_map_pending: *state = 0 nothing pending, 1 building, 2 built and waiting for its swap.
+ * mcl_map_commit: swaps now if the build is done (wait = 0: otherwise returns with nothing changed; wait = 1: waits for it first).
+ * Not on a filter with a communicator of several ranks (MCL_ERR_UNSUPPORTED): the ranks would swap in different cycles. */
+mcl_status mcl_set_map_async(mcl_ctx* ctx, const int8_t* cells, uint32_t width, uint32_t height, double resolution,
+                             const double origin[4], const int8_t value_traits[3]);
+mcl_status mcl_map_pending(mcl_ctx* ctx, int32_t* state);
+mcl_status mcl_map_commit(mcl_ctx* ctx, int32_t wait);
 /* LikelihoodFieldModelBase::likelihood_field() (likelihood_field_model_base.hpp:102). out: H*W floats. */
 mcl_status mcl_get_likelihood_field(mcl_ctx* ctx, float* out);
 /* beluga_ros::Amcl::has_likelihood_field() (beluga_ros/include/beluga_ros/amcl.hpp:181-188): 1 for the two likelihood-field

@@ -1365,6 +1365,64 @@ def test_one_launch_scan_and_folded_estimate_sums_leave_the_same_cycle(n, beams)
         assert np.array_equal(outs[0][1][0], other[1][0]) and np.array_equal(outs[0][1][1], other[1][1])
 
 
+def test_map_built_ahead_on_a_worker_thread_swaps_in_between_two_updates():
+    """mcl_set_map_async (an extension beside Amcl::update_map, amcl_core.hpp:150): the likelihood field of the next map is built on a
+    worker thread - the reference's wavefront (distance_map.hpp:55-98), the same bits - while the filter keeps updating on the map it
+    has; the swap happens at the start of the first update after the build is done.  Against a twin filter that is given the same map
+    with the synchronous update_map at the cycle where the first one swaps: identical estimates and particles in every cycle, identical
+    likelihood fields afterwards; before the swap both run on the old map."""
+    import time
+    cells_a = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
+    cells_b = synth.make_rooms_map(640, 480, seed=8, n_rooms=16)  # another shape as well
+    origin = se2_from_xytheta(-10.0, -10.0, 0.0)
+    grid_a, grid_b = OccupancyGrid(cells_a, 0.05, origin=origin), OccupancyGrid(cells_b, 0.05, origin=origin)
+    truth = synth.find_free_pose(cells_a, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
+    n = 50_000
+    filters = [new_filter(grid_a, n) for _ in range(2)]
+    cov = np.diag([0.25, 0.25, 0.04])
+    for f in filters:
+        f.initialize(truth, cov)
+    first, twin = filters
+    angles = synth.lidar_angles(360, 270.0)
+    pose, odom = truth, (0.0, 0.0, 0.0)
+    swapped_at = None
+    for c in range(8):
+        pose = synth.odometry_step(pose, 0.3, 0.05)
+        odom = synth.odometry_step(odom, 0.3, 0.05)
+        pts = synth.scan_points(synth.cast_scan(cells_a, 0.05, (-10.0, -10.0), pose, angles, 12.0, 0.01, seed=c), angles)
+        if c == 2:
+            first.update_map_async(grid_b)
+            assert first.map_pending() in (1, 2)
+            assert first.likelihood_field().shape == cells_a.shape  # still the old map
+        if c == 4:  # by now the build is to be done: wait for it without swapping (the swap is the next update's)
+            t0 = time.time()
+            while first.map_pending() == 1 and time.time() - t0 < 60:
+                time.sleep(0.01)
+            assert first.map_pending() == 2
+            twin.update_map(grid_b)
+            swapped_at = c
+        a = first.update(se2_from_xytheta(*odom), pts)
+        b = twin.update(se2_from_xytheta(*odom), pts)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), c
+        if swapped_at is not None:
+            assert first.map_pending() == 0
+    assert swapped_at == 4
+    assert first.likelihood_field().shape == cells_b.shape
+    assert np.array_equal(first.likelihood_field(), twin.likelihood_field())
+    sa, wa = first.particles()
+    sb, wb = twin.particles()
+    assert np.array_equal(sa, sb) and np.array_equal(wa, wb)
+    # a synchronous update_map replaces a map that is still on its way; map_commit(wait) swaps at once
+    first.update_map_async(grid_a)
+    first.update_map(grid_b)
+    assert first.map_pending() == 0 and first.likelihood_field().shape == cells_b.shape
+    first.update_map_async(grid_a)
+    first.map_commit(wait=True)
+    assert first.map_pending() == 0 and first.likelihood_field().shape == cells_a.shape
+    for f in filters:
+        f.close()
+
+
 @pytest.mark.parametrize("interval", [1, 2])
 def test_unit_weights_skip_the_old_weights_load_and_change_nothing(interval):
     """A set fresh from a resampling or an initialisation holds weights of exactly 1.0 (particle_traits.hpp:105), and the host knows: the
