@@ -196,6 +196,7 @@ class Amcl:
         self._check(self._lib.mcl_set_map(self._ctx, cells.ctypes.data_as(capi.c_i8_p), W, H, float(grid.resolution), _dp(origin),
                                           traits))
         self._shape = (H, W)
+        self._pending_shape = None  # (a map given now replaces one that was still on its way)
 
     def update_map_async(self, grid: OccupancyGrid):
         """Extension (mcl_set_map_async): the new map's likelihood field is built on a worker thread while the filter keeps running on

@@ -387,6 +387,7 @@ class Amcl {
   void update_map(const OccupancyGridView& map) {
     const std::int8_t traits[3] = {map.free_value, map.unknown_value, map.occupied_value};
     check(mcl_set_map(ctx_, map.cells, map.width, map.height, map.resolution, map.origin.data(), traits));
+    have_pending_ = false;  // (a map given now replaces one that was still on its way)
     width_ = map.width;
     height_ = map.height;
     resolution_ = map.resolution;
