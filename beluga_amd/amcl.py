@@ -477,6 +477,10 @@ class Amcl:
         beyond the rounding of a particle's sum over the scan."""
         self._check(self._lib.mcl_set_option(self._ctx, name.encode(), int(value)))
 
+    def debug_set_recovery_filters(self, slow: float, fast: float):
+        """Test hook (mcl_debug_set_recovery_filters): the outputs of the recovery estimator's two exponential filters."""
+        self._check(self._lib.mcl_debug_set_recovery_filters(self._ctx, float(slow), float(fast)))
+
     def counter(self, name: str) -> int:
         v = C.c_uint64(0)
         self._check(self._lib.mcl_get_counter(self._ctx, name.encode(), C.byref(v)))

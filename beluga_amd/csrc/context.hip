@@ -2134,7 +2134,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     }
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin", "scan_fused", "draw_fold", "lf_unit_weights"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin", "scan_fused", "draw_fold", "lf_unit_weights", "small_fused"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2644,6 +2644,77 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
                              ctx->tuning.device_policy != 0;
   // (the normalisation follows at once: the LF kernel leaves the sums it is built on)
   if (const mcl_status s = do_reweight(ctx, points_xy, num_points, true, keys_ready, /*want_weight_sums=*/ctx->tuning.lf_weight_sums != 0)) return s;  // :176
+  // Small sets (the reference's own sizes): everything behind the reweight in ONE launch of one workgroup and one synchronisation
+  // (k_small_tail) - the policies are evaluated on the device, the host keeps the recovery filters' state.
+  if (ctx->tuning.small_fused != 0 && ctx->estimate_kind == 0 && ctx->n <= 4096 && std::min<uint64_t>(ap.max_particles, ctx->capacity) <= 4096) {
+    ctx->every_n_current = (ctx->every_n_current + 1) % ap.resample_interval;  // :181
+    SmallTail t{};
+    t.src = ctx->cur();
+    t.dst = ctx->other();
+    t.n = static_cast<uint32_t>(ctx->n);
+    t.max_particles = static_cast<uint32_t>(std::min<uint64_t>(ap.max_particles, ctx->capacity));
+    t.min_particles = static_cast<uint32_t>(std::min<uint64_t>(ap.min_particles, t.max_particles));
+    t.seed = ctx->cfg.seed;
+    t.step = ctx->step;
+    t.fires = ctx->every_n_current == 0;
+    t.selective = ap.selective_resampling != 0;
+    t.alpha_slow = ap.alpha_slow;
+    t.alpha_fast = ap.alpha_fast;
+    t.slow = ctx->slow.output;
+    t.fast = ctx->fast.output;
+    t.kld_epsilon = ap.kld_epsilon;
+    t.kld_z = ap.kld_z;
+    t.hp = HashParams{ap.spatial_resolution_x, ap.spatial_resolution_y, ap.spatial_resolution_theta};
+    t.g = ctx->grid_view();
+    t.fc = FreeCells{ctx->d_free.ptr, ctx->have_map ? ctx->n_free : 0};
+    t.pivot_x = ctx->pivot[0];
+    t.pivot_y = ctx->pivot[1];
+    t.mirror = ctx->hd_scalars;
+    t.d_scalars = ctx->d_scalars.ptr;
+    stage_begin(ctx, MCL_STAGE_RESAMPLE);
+    const bool launched = launch_small_tail(ctx->stream, t);
+    stage_end(ctx, MCL_STAGE_RESAMPLE);
+    if (launched) {
+      MCL_HIP(ctx, hipGetLastError());
+      ctx->lf_wsum_count = 0;
+      ctx->weights_unit = false;
+      MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      stage_collect(ctx);
+      const double* h = ctx->h_scalars;
+      const bool resampled = h[5] != 0.0;
+      if (resampled) {
+        ctx->live ^= 1;
+        ctx->n = static_cast<uint64_t>(h[6]);
+        ctx->weights_unit = true;  // particle_traits.hpp:105
+      }
+      ctx->slow.output = h[18];
+      ctx->fast.output = h[19];
+      ctx->force_update = false;  // :199
+      double sums[12];
+      for (int k = 0; k < 9; ++k) sums[k] = h[8 + k];
+      sums[9] = ctx->pivot[0];
+      sums[10] = ctx->pivot[1];
+      sums[11] = 0.0;
+      mcl_estimate est{};
+      if (const mcl_status s = mcl_estimate_from_sums(sums, &est)) return s;  // :200
+      if (std::isfinite(est.pose[2]) && std::isfinite(est.pose[3])) {
+        ctx->pivot[0] = est.pose[2];
+        ctx->pivot[1] = est.pose[3];
+      }
+      remember_cloud_estimate(ctx, est);
+      if (estimate) *estimate = est;
+      if (info) {
+        info->updated = 1;
+        info->resampled = resampled ? 1 : 0;
+        info->num_particles = ctx->n;
+        info->weight_sum = h[0];
+        info->effective_sample_size = h[7];
+        info->random_state_probability = h[22];
+      }
+      return MCL_OK;
+    }
+    ctx->every_n_current = (ctx->every_n_current + ap.resample_interval - 1) % ap.resample_interval;  // (not launched: the large path counts)
+  }
   mcl_weight_stats stats{};
   double random_state_probability = 0.0;
   double ess = -1.0;
@@ -3186,6 +3257,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "scan_fused") t.scan_fused = static_cast<int>(std::clamp<int64_t>(value, 0, 2));
   else if (key == "draw_fold") t.draw_fold = static_cast<int>(std::clamp<int64_t>(value, 0, 2));
   else if (key == "lf_unit_weights") t.lf_unit_weights = value ? 1 : 0;
+  else if (key == "small_fused") t.small_fused = value ? 1 : 0;
   else if (key == "lf_split") t.lf_split = static_cast<int>(value & 3);  // 1: side by side only, 2: stacked only, 3: both
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else if (key == "beam_sort_min_particles") t.beam_sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));

@@ -178,6 +178,9 @@ struct Tuning {
   int draw_fold = 1;                // the draw kernel's last workgroup to finish adds up the estimate sums (no k_final_rows launch behind it):
                                     // 1 = for sets of up to 64K particles, 2 = up to 4M (measured at 1M: 56.2 us against 49.2 + 4.4 - every
                                     // workgroup ends on the ticket's round trip), 0 = k_final_rows.  Bit-identical.
+  int small_fused = 1;              // sets of up to 4096 particles (plain estimate, one context): everything behind the reweight - normalise,
+                                    // policies, fixed-size or KLD resampling, estimate sums - in one launch of one workgroup and one host
+                                    // synchronisation (k_small_tail); 0 = the kernels of the large path
   int lf_unit_weights = 1;          // LF patch kernel on a set whose weights are all 1.0 (fresh from a resampling or an initialisation):
                                     // the old weight is not loaded (1.0 x = x: bit-identical); 0 = always loaded
 };
@@ -410,6 +413,26 @@ constexpr size_t kScanStateWords = 8 + 4 * 1024;
 bool launch_normalize_cdf(hipStream_t st, double* w, uint64_t n, double* d_partials, const double* known_partials, uint32_t known_count,
                           double* d_sums, double* sums_mirror, double* d_chunk_sum, double* d_chunk_sumsq, bool write_weights, double* cdf,
                           double* d_total, double* tree_levels, const RecoveryPolicy* policy, unsigned long long* scan_state, uint32_t epoch);
+// The whole tail of a small set's cycle - normalise, policies, resample (fixed size or KLD-adaptive), estimate sums - in one launch of one
+// workgroup (k_small_tail; sets and candidate streams of up to 4096 particles).  Results through `mirror` (32 doubles of mapped host memory)
+// and d_scalars: [0] weight sum, [1] [2] sum and sum of squares of the normalised weights, [5] resampled (0 / 1), [6] particles after the
+// cycle, [7] effective sample size (-1: not evaluated), [8..17) the estimate's sums, [18] [19] the recovery filters' new outputs, [22] the
+// random state probability.  Returns false, nothing launched, where the set does not fit.
+struct SmallTail {
+  Particles src, dst;
+  uint32_t n, min_particles, max_particles;
+  uint64_t seed;
+  uint32_t step;
+  bool fires, selective;
+  double alpha_slow, alpha_fast, slow, fast, kld_epsilon, kld_z;
+  HashParams hp;
+  GridView g;
+  FreeCells fc;
+  double pivot_x, pivot_y;
+  double* mirror;
+  double* d_scalars;
+};
+bool launch_small_tail(hipStream_t st, const SmallTail& t);
 // K6: one thread per candidate (views/sample.hpp:102,133-135; random_intersperse.hpp:90-115; particle_traits.hpp:105).
 void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst,
                           ResampleArgs a, GridView g, FreeCells fc, HashParams hp, unsigned long long* d_hashes);

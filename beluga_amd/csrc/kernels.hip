@@ -2952,6 +2952,281 @@ __global__ __launch_bounds__(kBlock) void k_estimate_partials(Particles p, uint6
   }
 }
 
+// ---- the whole tail of the cycle in ONE workgroup (small sets: the reference's own sizes, amcl_core.hpp:44-46: 500 .. 2000) --------------
+// Behind the reweight, a cycle of a few thousand particles was seven launches when its size is fixed and a dozen with three host
+// synchronisations when it is KLD-adaptive - the reference's default configuration - every one of them a few microseconds of launch and
+// dependency latency around nanoseconds of work (profiles/r04_small_filters.txt: 0.05 / 0.11 ms per update).  Here one workgroup of 1024
+// threads does, for a set and a candidate stream of up to kSmallMax particles:
+//   actions::normalize (normalize.hpp:54-85), the totals of the normalised weights, ThrunRecoveryProbabilityEstimator on them
+//   (thrun_recovery_probability_estimator.hpp:69-89, exponential_filter.hpp:32-44; reset rule amcl_core.hpp:184-186), the resampling policy
+//   every_n [&& on_effective_size_drop] (every_n.hpp:47-50, on_effective_size_drop.hpp:45-49, effective_sample_size.hpp:46-59), and, where it
+//   fires, views::sample | random_intersperse | take_while_kld | take(max) | assign (sample.hpp:128-159, random_intersperse.hpp:90-115,
+//   take_while_kld.hpp:72-88 over spatial_hash.hpp:45-94,190-193) - the CDF in workgroup memory, std::lower_bound per candidate, the KLD cut
+//   order-exact: k(j) = distinct hashes among candidates 0 .. j through a table that keeps the smallest candidate index per hash - and the sums
+//   of beluga::estimate (estimation.hpp:436-475) over the set it leaves.
+// Everything the host needs comes back through the mirror in mapped host memory behind ONE synchronisation.  Same Philox stream, same
+// expressions as the kernels of the large path; its sums are added in this kernel's own fixed order (results within the rounding of a sum:
+// the parity tests' tolerances, the KLD cut and the particle counts exact).
+constexpr uint32_t kSmallMax = 4096, kSmallBlock = 1024, kSmallItems = kSmallMax / kSmallBlock, kSmallSlots = 2 * kSmallMax;
+constexpr size_t kSmallLdsBytes = kSmallMax * 8 /* cdf */ + kSmallMax * 8 /* hashes */ + kSmallSlots * 4 /* table */ + 16 * 9 * 8 + 128;
+struct SmallTailArgs {
+  Particles src, dst;
+  uint32_t n;               // live particles
+  uint32_t min_particles, max_particles;
+  uint64_t seed;
+  uint32_t step;
+  int fires;                // every_n says so
+  int selective;            // && on_effective_size_drop
+  int adaptive;             // min < max: take_while_kld
+  double alpha_slow, alpha_fast, slow, fast;  // the recovery estimator's filters (the host keeps their state)
+  double two_epsilon, z;
+  HashParams hp;
+  GridView g;
+  FreeCells fc;
+  double pivot_x, pivot_y;
+  double* out;              // [32] mirror in mapped host memory (the context's h_scalars): see the stores below
+  double* d_out;            // the same values in device memory (d_scalars)
+};
+__device__ __forceinline__ double small_block_sum(double v, double* s_wave /* [16] */) {  // every thread gets the total; fixed order
+  v = wave_sum_f64(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double total = s_wave[0];
+  for (uint32_t q = 1; q < kSmallBlock / 64; ++q) total += s_wave[q];
+  return total;
+}
+__global__ __launch_bounds__(kSmallBlock) void k_small_tail(SmallTailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* s_cdf = reinterpret_cast<double*>(smem);
+  unsigned long long* s_hash = reinterpret_cast<unsigned long long*>(smem + kSmallMax * 8);
+  uint32_t* s_table = reinterpret_cast<uint32_t*>(smem + 2 * kSmallMax * 8);
+  double* s_wave = reinterpret_cast<double*>(smem + 2 * kSmallMax * 8 + kSmallSlots * 4);  // [16][9]
+  uint32_t* s_word = reinterpret_cast<uint32_t*>(s_wave + 16 * 9);                          // [16]
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t n = a.n;
+  // ---- normalise (thread t holds the elements 4 t .. 4 t + 3)
+  double x[kSmallItems];
+  double local = 0.0;
+#pragma unroll
+  for (uint32_t k = 0; k < kSmallItems; ++k) {
+    const uint32_t i = tid * kSmallItems + k;
+    x[k] = i < n ? a.src.w[i] : 0.0;
+    local += x[k];
+  }
+  const double total = small_block_sum(local, s_wave);
+  const bool skip = fabs(total - 1.0) < DBL_EPSILON;  // normalize.hpp:73
+  double l1 = 0.0, l2 = 0.0;
+#pragma unroll
+  for (uint32_t k = 0; k < kSmallItems; ++k) {
+    if (!skip) x[k] = x[k] / total;
+    l1 += x[k];
+    l2 += x[k] * x[k];
+  }
+  const double norm_sum = small_block_sum(l1, s_wave), norm_sumsq = small_block_sum(l2, s_wave);
+  // ---- recovery estimator, resampling policy (uniform: every thread computes the same)
+  double slow = a.slow, fast = a.fast, p = 0.0;
+  {
+    const double average = norm_sum / static_cast<double>(n);
+    fast += (fast == 0.) ? average : a.alpha_fast * (average - fast);
+    slow += (slow == 0.) ? average : a.alpha_slow * (average - slow);
+    if (fabs(slow) >= 2.220446049250313e-16) p = fmin(fmax(1.0 - fast / slow, 0.0), 1.0);
+  }
+  bool resample = a.fires != 0;
+  double ess = -1.0;
+  if (resample && a.selective) {
+    ess = norm_sum == 0.0 ? 0.0 : (norm_sum * norm_sum) / norm_sumsq;
+    resample = ess < static_cast<double>(n) * 0.5;
+  }
+  if (resample && p > 0.0) slow = fast = 0.0;  // amcl_core.hpp:184-186
+  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t n_out = n;
+  if (!resample) {
+    // the set stays: its normalised weights, and the estimate over them
+#pragma unroll
+    for (uint32_t k = 0; k < kSmallItems; ++k) {
+      const uint32_t i = tid * kSmallItems + k;
+      if (i < n) {
+        if (!skip) a.src.w[i] = x[k];
+        const double w = x[k];
+        const double4 q = a.src.pose[i];
+        const double dx = q.z - a.pivot_x, dy = q.w - a.pivot_y;
+        v[0] += w;
+        v[1] += w * w;
+        v[2] += w * q.x;
+        v[3] += w * q.y;
+        v[4] += w * dx;
+        v[5] += w * dy;
+        v[6] += w * dx * dx;
+        v[7] += w * dx * dy;
+        v[8] += w * dy * dy;
+      }
+    }
+  } else {
+    // ---- CDF: inclusive scan of the normalised weights, in workgroup memory
+    double run = 0.0;
+#pragma unroll
+    for (uint32_t k = 0; k < kSmallItems; ++k) {
+      run += x[k];
+      x[k] = run;
+    }
+    double incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double up = __shfl_up(incl, o);
+      if (lane >= static_cast<uint32_t>(o)) incl += up;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    double prefix = incl - run;
+    for (uint32_t q = 0; q < wave; ++q) prefix += s_wave[q];
+#pragma unroll
+    for (uint32_t k = 0; k < kSmallItems; ++k) {
+      const uint32_t i = tid * kSmallItems + k;
+      if (i < n) s_cdf[i] = prefix + x[k];
+    }
+    for (uint32_t s = tid; s < kSmallSlots; s += kSmallBlock) s_table[s] = 0xFFFFFFFFu;
+    if (tid == 0) s_word[0] = 0xFFFFFFFFu;  // first candidate that fails kld_condition
+    __syncthreads();
+    const double cdf_total = s_cdf[n - 1];
+    // ---- the candidates (candidate j = output slot j), thread t takes j = t, t + 1024, ...
+    const uint32_t candidates = a.max_particles;
+    Pose2 state[kSmallItems];
+#pragma unroll
+    for (uint32_t k = 0; k < kSmallItems; ++k) {
+      const uint32_t j = k * kSmallBlock + tid;
+      if (j < candidates) {
+        const RngWords r = rng_draw(a.seed, a.step, kRngResample, j);
+        if (intersperse_here(r, j, p, a.fc.count)) {
+          state[k] = random_free_state(a.seed, a.step, j, a.g, a.fc);
+        } else {
+          const double target = rng_uniform53(r.w[0], r.w[1]) * cdf_total;
+          uint32_t lo = 0, len = n;  // std::lower_bound, clamped to n - 1 (discrete_distribution forces the last cumulative probability to one)
+          while (len > 0) {
+            const uint32_t half = len >> 1;
+            if (s_cdf[lo + half] < target) {
+              lo += half + 1;
+              len -= half + 1;
+            } else {
+              len = half;
+            }
+          }
+          state[k] = load_pose(a.src, lo < n ? lo : n - 1);
+        }
+        store_pose(a.dst, j, state[k]);
+        a.dst.w[j] = 1.0;  // particle_traits.hpp:105
+        if (a.adaptive) s_hash[j] = kld_key(spatial_hash(state[k], a.hp));
+      }
+    }
+    n_out = candidates;
+    if (a.adaptive) {
+      __syncthreads();
+      // the smallest candidate index per hash
+#pragma unroll
+      for (uint32_t k = 0; k < kSmallItems; ++k) {
+        const uint32_t j = k * kSmallBlock + tid;
+        if (j < candidates) {
+          const unsigned long long key = s_hash[j];
+          uint32_t slot = static_cast<uint32_t>(kld_slot(key, kSmallSlots - 1));
+          for (;;) {
+            const uint32_t holder = atomicCAS(&s_table[slot], 0xFFFFFFFFu, j);
+            if (holder == 0xFFFFFFFFu) break;  // this candidate represents its hash (until a smaller index of the same hash comes)
+            if (s_hash[holder] == key) {       // (a slot's holders all carry one hash)
+              atomicMin(&s_table[slot], j);
+              break;
+            }
+            slot = (slot + 1) & (kSmallSlots - 1);
+          }
+        }
+      }
+      __syncthreads();
+      // first occurrences in candidate order: thread t looks at the candidates 4 t .. 4 t + 3 now (a blocked scan), k(j) = their inclusive count
+      uint32_t f[kSmallItems], count_run = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kSmallItems; ++k) {
+        const uint32_t j = tid * kSmallItems + k;
+        f[k] = 0;
+        if (j < candidates) {
+          const unsigned long long key = s_hash[j];
+          uint32_t slot = static_cast<uint32_t>(kld_slot(key, kSmallSlots - 1));
+          while (s_hash[s_table[slot]] != key) slot = (slot + 1) & (kSmallSlots - 1);
+          f[k] = s_table[slot] == j ? 1u : 0u;
+        }
+        count_run += f[k];
+        f[k] = count_run;
+      }
+      uint32_t incl_u = count_run;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl_u, o);
+        if (lane >= static_cast<uint32_t>(o)) incl_u += up;
+      }
+      if (lane == 63) s_word[1 + wave] = incl_u;  // (s_word[0] is the failing candidate's index)
+      __syncthreads();
+      uint32_t before = incl_u - count_run;
+      for (uint32_t q = 0; q < wave; ++q) before += s_word[1 + q];
+      uint32_t fail = 0xFFFFFFFFu;
+#pragma unroll
+      for (uint32_t k = 0; k < kSmallItems; ++k) {
+        const uint32_t j = tid * kSmallItems + k;
+        if (j < candidates) {
+          const unsigned long long cnt = static_cast<unsigned long long>(j) + 1ull;  // kld_condition's count after this element
+          const bool keep = cnt <= a.min_particles || cnt <= kld_target_size(before + f[k], a.two_epsilon, a.z);
+          if (!keep && fail == 0xFFFFFFFFu) fail = j;
+        }
+      }
+      if (fail != 0xFFFFFFFFu) atomicMin(&s_word[0], fail);
+      __syncthreads();
+      const uint32_t first_fail = s_word[0];
+      n_out = first_fail < candidates ? first_fail : candidates;  // the first element failing the predicate is dropped (take_while) | take(max)
+    }
+    // ---- the estimate's sums over the new set (weights 1)
+#pragma unroll
+    for (uint32_t k = 0; k < kSmallItems; ++k) {
+      const uint32_t j = k * kSmallBlock + tid;
+      if (j < n_out) {
+        const double dx = state[k].x - a.pivot_x, dy = state[k].y - a.pivot_y;
+        v[0] += 1.0;
+        v[1] += 1.0;
+        v[2] += state[k].r.c;
+        v[3] += state[k].r.s;
+        v[4] += dx;
+        v[5] += dy;
+        v[6] += dx * dx;
+        v[7] += dx * dy;
+        v[8] += dy * dy;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) v[k] = wave_sum_f64(v[k]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s_wave[wave * 9 + k] = v[k];
+  }
+  __syncthreads();
+  if (tid < 9) {
+    double acc = s_wave[tid];
+    for (uint32_t q = 1; q < kSmallBlock / 64; ++q) acc += s_wave[q * 9 + tid];
+    a.out[8 + tid] = acc;
+    a.d_out[8 + tid] = acc;
+  }
+  if (tid == 0) {
+    const double scalars[10] = {total, norm_sum, norm_sumsq, 0.0, 0.0, resample ? 1.0 : 0.0, static_cast<double>(n_out), ess, slow, fast};
+    for (int k = 0; k < 3; ++k) a.out[k] = a.d_out[k] = scalars[k];
+    a.out[5] = a.d_out[5] = scalars[5];
+    a.out[6] = a.d_out[6] = scalars[6];
+    a.out[7] = a.d_out[7] = scalars[7];
+    a.out[18] = a.d_out[18] = slow;
+    a.out[19] = a.d_out[19] = fast;
+    a.out[20] = a.d_out[20] = slow;  // (the device-side policy slot of the large path: {slow, fast, p})
+    a.out[21] = a.d_out[21] = fast;
+    a.out[22] = a.d_out[22] = p;
+  }
+}
+
 // ---- cluster_based_estimate (algorithm/cluster_based_estimation.hpp) ---------------------------------------------
 // Device side: spatial hash of every particle, per-cell aggregation (weight sum, count, first particle), compaction of
 // the occupied cells for the host, and the masked estimate of the winning cluster.  The cluster assignment itself is
@@ -3751,6 +4026,42 @@ void launch_kld_scan(hipStream_t st, const unsigned long long* d_hashes, uint64_
                      d_k_base);
   hipLaunchKernelGGL(k_kld_check, dim3(chunks), dim3(kBlock), 0, st, first, count, d_flags_scan, d_chunk_offset, min_particles,
                      2 * epsilon, z, d_first_fail);
+}
+
+bool launch_small_tail(hipStream_t st, const SmallTail& t) {
+  if (t.n == 0 || t.n > kSmallMax || t.max_particles == 0 || t.max_particles > kSmallMax) return false;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_tail), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSmallLdsBytes)) != hipSuccess)
+      return false;
+    configured = true;
+  }
+  SmallTailArgs a{};
+  a.src = t.src;
+  a.dst = t.dst;
+  a.n = t.n;
+  a.min_particles = t.min_particles;
+  a.max_particles = t.max_particles;
+  a.seed = t.seed;
+  a.step = t.step;
+  a.fires = t.fires ? 1 : 0;
+  a.selective = t.selective ? 1 : 0;
+  a.adaptive = t.min_particles < t.max_particles ? 1 : 0;
+  a.alpha_slow = t.alpha_slow;
+  a.alpha_fast = t.alpha_fast;
+  a.slow = t.slow;
+  a.fast = t.fast;
+  a.two_epsilon = 2.0 * t.kld_epsilon;
+  a.z = t.kld_z;
+  a.hp = t.hp;
+  a.g = t.g;
+  a.fc = t.fc;
+  a.pivot_x = t.pivot_x;
+  a.pivot_y = t.pivot_y;
+  a.out = t.mirror;
+  a.d_out = t.d_scalars;
+  hipLaunchKernelGGL(k_small_tail, dim3(1), dim3(kSmallBlock), kSmallLdsBytes, st, a);
+  return true;
 }
 
 void launch_estimate_sums(hipStream_t st, Particles p, uint64_t n, double pivot_x, double pivot_y, double* d_partials,

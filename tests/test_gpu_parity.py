@@ -1365,6 +1365,63 @@ def test_one_launch_scan_and_folded_estimate_sums_leave_the_same_cycle(n, beams)
         assert np.array_equal(outs[0][1][0], other[1][0]) and np.array_equal(outs[0][1][1], other[1][1])
 
 
+@pytest.mark.parametrize("lo,hi,selective,interval,beams", [
+    (2000, 2000, False, 1, 180), (500, 2000, False, 1, 180), (500, 2000, True, 1, 360), (4096, 4096, False, 2, 90),
+    (100, 4096, True, 1, 180), (1, 1, False, 1, 8), (700, 700, True, 1, 180)])
+def test_small_sets_one_launch_tail_matches_the_kernels_of_the_large_path(lo, hi, selective, interval, beams):
+    """Sets of up to 4096 particles - the reference's own sizes (amcl_core.hpp:44-46) - run everything behind the reweight in ONE launch of
+    one workgroup (k_small_tail, option small_fused): normalisation, the recovery estimator, every_n [&& on_effective_size_drop], the
+    fixed-size or KLD-adaptive resampling with random_intersperse, the estimate's sums; one host synchronisation per cycle instead of up
+    to three.  Against the same filter on the kernels of the large path (small_fused = 0), cycle by cycle: the same decisions and particle
+    counts (integers: exact - the KLD cut among them), weight sums / effective sample sizes / recovery probabilities within 1e-12,
+    estimates within 1e-9, and the same particles up to draws that sit on a CDF rounding boundary.  One cycle runs with the recovery
+    filters put apart (a random state probability of about a half: injected states)."""
+    cells = synth.make_rooms_map(400, 400, seed=3, n_rooms=12)
+    grid = OccupancyGrid(cells, 0.05, origin=se2_from_xytheta(-10.0, -10.0, 0.0))
+    truth = synth.find_free_pose(cells, 0.05, (-10.0, -10.0), seed=4, clearance_cells=8)
+    angles = synth.lidar_angles(beams, 270.0)
+    outs = []
+    for fused in (1, 0):
+        f = Amcl(grid, MOTION, LF, AmclParams(min_particles=lo, max_particles=hi, selective_resampling=selective, resample_interval=interval), seed=11)
+        f.set_option("small_fused", fused)
+        f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+        pose, odom, rows = truth, (0.0, 0.0, 0.0), []
+        for c in range(9):
+            pose = synth.odometry_step(pose, 0.3, 0.05)
+            odom = synth.odometry_step(odom, 0.3, 0.05)
+            pts = synth.scan_points(synth.cast_scan(cells, 0.05, (-10.0, -10.0), pose, angles, 12.0, 0.01, seed=c), angles)
+            if c == 5:
+                n_now = f.num_particles()
+                f.debug_set_recovery_filters(2.0 / n_now, 1.0 / n_now)
+            e = f.update(se2_from_xytheta(*odom), pts)
+            i = f.last_info
+            rows.append((e, dict(i), f.particles()))
+        outs.append(rows)
+        f.close()
+    flips = 0
+    for c, (a, b) in enumerate(zip(*outs)):
+        ia, ib = a[1], b[1]
+        assert ia["resampled"] == ib["resampled"] and ia["num_particles"] == ib["num_particles"], (c, ia, ib)
+        np.testing.assert_allclose(ia["weight_sum"], ib["weight_sum"], rtol=1e-12)
+        np.testing.assert_allclose(ia["random_state_probability"], ib["random_state_probability"], rtol=0, atol=1e-12)
+        if ib["ess"] >= 0:
+            np.testing.assert_allclose(ia["ess"], ib["ess"], rtol=1e-12)
+        sa, wa = a[2]
+        sb, wb = b[2]
+        assert sa.shape == sb.shape
+        differ = int(np.any(sa != sb, axis=1).sum())
+        flips = max(flips, differ)
+        # (a draw on a CDF rounding boundary picks the neighbour: a particle differs from there on, the estimate by its share)
+        tol = 1e-9 + 2.0 * differ / max(len(wa), 1)
+        np.testing.assert_allclose(a[0][0], b[0][0], rtol=0, atol=tol)
+        np.testing.assert_allclose(a[0][1], b[0][1], rtol=1e-7, atol=1e-9 + 4.0 * differ / max(len(wa), 1))
+        if differ == 0:
+            np.testing.assert_allclose(wa, wb, rtol=1e-12)
+    assert flips <= 3, flips
+    if lo == 500 and hi == 2000:
+        assert any(r[1]["random_state_probability"] > 0.3 for r in outs[0]), [r[1]["random_state_probability"] for r in outs[0]]
+
+
 def test_map_built_ahead_on_a_worker_thread_swaps_in_between_two_updates():
     """mcl_set_map_async (an extension beside Amcl::update_map, amcl_core.hpp:150): the likelihood field of the next map is built on a
     worker thread - the reference's wavefront (distance_map.hpp:55-98), the same bits - while the filter keeps updating on the map it
