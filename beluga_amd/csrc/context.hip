@@ -1301,7 +1301,17 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
   const HashParams hp{cp.linear_hash_resolution, cp.linear_hash_resolution, cp.angular_hash_resolution};
   unsigned int m = 0;
   bool local_failure = false;  // (sharded: reported to the peers with the count, so that every rank leaves together)
-  if (n) {
+  // a small set on one context: one workgroup writes the cells straight into the mapped list (k_small_cluster_cells), another one adds the
+  // winning cluster's particles up (k_small_cluster_sums) - two launches instead of eight
+  bool small = false;
+  if (n && !sharded && ctx->tuning.small_fused != 0 && n <= 4096)
+    small = launch_small_cluster_cells(ctx->stream, ctx->cur(), n, hp, dk, df, dc, dsl, dw, ds, c_size, dsize);
+  if (small) {
+    MCL_HIP(ctx, hipGetLastError());
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m = *hsize;
+    if (!(m >= 1 && m <= m_cap)) return fail(ctx, MCL_ERR_HIP, "cell compaction failed");
+  } else if (n) {
     launch_cluster_cells(ctx->stream, ctx->cur(), n, hp, ctx->d_hashes.ptr, ctx->d_table_keys.ptr, ctx->d_table_first.ptr, t_wsum,
                          t_count, t_cluster, slots, dk, df, dc, dsl, dw, ds, c_size, kHostCells);
     MCL_HIP(ctx, hipGetLastError());
@@ -1521,6 +1531,17 @@ mcl_status do_cluster_estimate(mcl_ctx* ctx, const mcl_cluster_params& cp, mcl_e
   } else {
     MCL_HIP(ctx, hipMemcpyAsync(c_cluster, cluster_of.data(), m * sizeof(unsigned int), hipMemcpyHostToDevice, ctx->stream));
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (cluster_of is pageable host memory of this call)
+  }
+  if (small) {  // (the cells' keys and their cluster ids are in the mapped list: hk / hcl)
+    launch_small_cluster_sums(ctx->stream, ctx->cur(), n, hp, dk, dcl, m, static_cast<unsigned int>(best), ctx->pivot[0], ctx->pivot[1],
+                              ctx->d_scalars.ptr + 8, ctx->hd_scalars + 8);
+    MCL_HIP(ctx, hipGetLastError());
+    MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 9; ++k) sums[k] = ctx->h_scalars[8 + k];
+    sums[9] = ctx->pivot[0];
+    sums[10] = ctx->pivot[1];
+    sums[11] = 0.0;
+    return mcl_estimate_from_sums(sums, out);
   }
   if (m) launch_cell_set_cluster(ctx->stream, slot_list, cluster_list, m, t_cluster);
   if (sharded) return [&] {
@@ -2646,7 +2667,7 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
   if (const mcl_status s = do_reweight(ctx, points_xy, num_points, true, keys_ready, /*want_weight_sums=*/ctx->tuning.lf_weight_sums != 0)) return s;  // :176
   // Small sets (the reference's own sizes): everything behind the reweight in ONE launch of one workgroup and one synchronisation
   // (k_small_tail) - the policies are evaluated on the device, the host keeps the recovery filters' state.
-  if (ctx->tuning.small_fused != 0 && ctx->estimate_kind == 0 && ctx->n <= 4096 && std::min<uint64_t>(ap.max_particles, ctx->capacity) <= 4096) {
+  if (ctx->tuning.small_fused != 0 && ctx->n <= 4096 && std::min<uint64_t>(ap.max_particles, ctx->capacity) <= 4096) {
     ctx->every_n_current = (ctx->every_n_current + 1) % ap.resample_interval;  // :181
     SmallTail t{};
     t.src = ctx->cur();
@@ -2671,6 +2692,12 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
     t.pivot_y = ctx->pivot[1];
     t.mirror = ctx->hd_scalars;
     t.d_scalars = ctx->d_scalars.ptr;
+    // (the completion word only where asked for: measured 10 us per cycle SLOWER than the stream's signal at 2000 particles, round 6)
+    ctx->done_armed = ctx->tuning.cycle_spin > 0 && !ctx->profile;
+    if (ctx->done_armed) {
+      t.done_flag = reinterpret_cast<unsigned long long*>(ctx->hd_scalars + 31);
+      t.done_seq = ++ctx->done_seq;
+    }
     stage_begin(ctx, MCL_STAGE_RESAMPLE);
     const bool launched = launch_small_tail(ctx->stream, t);
     stage_end(ctx, MCL_STAGE_RESAMPLE);
@@ -2678,7 +2705,7 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
       MCL_HIP(ctx, hipGetLastError());
       ctx->lf_wsum_count = 0;
       ctx->weights_unit = false;
-      MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (const mcl_status s = wait_for_cycle(ctx)) return s;
       stage_collect(ctx);
       const double* h = ctx->h_scalars;
       const bool resampled = h[5] != 0.0;
@@ -2690,13 +2717,19 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
       ctx->slow.output = h[18];
       ctx->fast.output = h[19];
       ctx->force_update = false;  // :199
-      double sums[12];
-      for (int k = 0; k < 9; ++k) sums[k] = h[8 + k];
-      sums[9] = ctx->pivot[0];
-      sums[10] = ctx->pivot[1];
-      sums[11] = 0.0;
+      // (what the info reports, before another kernel's mirrored values take their place)
+      const double weight_sum = h[0], ess_seen = h[7], p_seen = h[22];
       mcl_estimate est{};
-      if (const mcl_status s = mcl_estimate_from_sums(sums, &est)) return s;  // :200
+      if (ctx->estimate_kind == 1) {  // beluga_ros::Amcl returns cluster_based_estimate (beluga_ros/src/amcl.cpp:125): its own kernels
+        if (const mcl_status s = mcl_cluster_based_estimate(ctx, &ctx->cluster_params, &est)) return s;
+      } else {
+        double sums[12];
+        for (int k = 0; k < 9; ++k) sums[k] = h[8 + k];
+        sums[9] = ctx->pivot[0];
+        sums[10] = ctx->pivot[1];
+        sums[11] = 0.0;
+        if (const mcl_status s = mcl_estimate_from_sums(sums, &est)) return s;  // :200
+      }
       if (std::isfinite(est.pose[2]) && std::isfinite(est.pose[3])) {
         ctx->pivot[0] = est.pose[2];
         ctx->pivot[1] = est.pose[3];
@@ -2707,12 +2740,13 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
         info->updated = 1;
         info->resampled = resampled ? 1 : 0;
         info->num_particles = ctx->n;
-        info->weight_sum = h[0];
-        info->effective_sample_size = h[7];
-        info->random_state_probability = h[22];
+        info->weight_sum = weight_sum;
+        info->effective_sample_size = ess_seen;
+        info->random_state_probability = p_seen;
       }
       return MCL_OK;
     }
+    ctx->done_armed = false;
     ctx->every_n_current = (ctx->every_n_current + ap.resample_interval - 1) % ap.resample_interval;  // (not launched: the large path counts)
   }
   mcl_weight_stats stats{};

@@ -431,6 +431,8 @@ struct SmallTail {
   double pivot_x, pivot_y;
   double* mirror;
   double* d_scalars;
+  unsigned long long* done_flag{nullptr};  // completion word in mapped host memory (optional) and the value it takes
+  unsigned long long done_seq{0};
 };
 bool launch_small_tail(hipStream_t st, const SmallTail& t);
 // K6: one thread per candidate (views/sample.hpp:102,133-135; random_intersperse.hpp:90-115; particle_traits.hpp:105).
@@ -486,6 +488,15 @@ void launch_cluster_cells(hipStream_t st, Particles p, uint64_t n, HashParams hp
                           unsigned int* t_cluster, uint64_t capacity, unsigned long long* c_key, unsigned int* c_first,
                           unsigned int* c_count, unsigned int* c_slot, double* c_wsum, double* c_state, unsigned int* c_size,
                           unsigned int list_capacity, bool table_ready = false);
+// The same for a set of up to 4096 particles: one workgroup each (k_small_cluster_cells: straight into the caller's list - the mapped host
+// list - and its size into size_mirror as well; false = the set does not fit; k_small_cluster_sums: the cells' keys and cluster ids back
+// in, the sums of the particles of cluster `wanted` out).
+bool launch_small_cluster_cells(hipStream_t st, Particles p, uint64_t n, HashParams hp, unsigned long long* c_key, unsigned int* c_first,
+                                unsigned int* c_count, unsigned int* c_slot, double* c_wsum, double* c_state, unsigned int* c_size,
+                                unsigned int* size_mirror);
+void launch_small_cluster_sums(hipStream_t st, Particles p, uint64_t n, HashParams hp, const unsigned long long* d_keys,
+                               const unsigned int* d_cluster, uint32_t cells, unsigned int wanted, double pivot_x, double pivot_y, double* d_out,
+                               double* host_mirror);
 void launch_cell_set_cluster(hipStream_t st, const unsigned int* d_slot, const unsigned int* d_cluster, uint32_t m,
                              unsigned int* t_cluster);
 void launch_estimate_sums_cluster(hipStream_t st, Particles p, uint64_t n, const unsigned long long* d_hashes,

@@ -2986,6 +2986,8 @@ struct SmallTailArgs {
   double pivot_x, pivot_y;
   double* out;              // [32] mirror in mapped host memory (the context's h_scalars): see the stores below
   double* d_out;            // the same values in device memory (d_scalars)
+  unsigned long long* done_flag;  // optional: a word of mapped host memory that takes done_seq behind everything mirrored (cycle_spin)
+  unsigned long long done_seq;
 };
 __device__ __forceinline__ double small_block_sum(double v, double* s_wave /* [16] */) {  // every thread gets the total; fixed order
   v = wave_sum_f64(v);
@@ -3225,6 +3227,11 @@ __global__ __launch_bounds__(kSmallBlock) void k_small_tail(SmallTailArgs a) {
     a.out[21] = a.d_out[21] = fast;
     a.out[22] = a.d_out[22] = p;
   }
+  if (a.done_flag) {  // (uniform) the host may be watching this word instead of the stream
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---- cluster_based_estimate (algorithm/cluster_based_estimation.hpp) ---------------------------------------------
@@ -3373,6 +3380,130 @@ __global__ __launch_bounds__(kBlock) void k_estimate_partials_cluster(Particles 
     for (int k = 0; k < kEstK; ++k) partials[static_cast<size_t>(k) * stride + blockIdx.x] = v[k];
   }
 }
+
+// ---- cluster_based_estimate of a small set (up to kSmallMax particles): two launches of one workgroup each around the host's pass --------
+// The large path is five launches and two synchronisations (clear, hash, aggregate, compact | set clusters, masked sums, final rows): a
+// tenth of a millisecond on a set of 2000 particles, twice the rest of its cycle - and cluster_based_estimate is what beluga_ros::Amcl
+// returns on every update (beluga_ros/src/amcl.cpp:125).  k_small_cluster_cells: hash of every particle (spatial_hash.hpp:190-193 at the
+// clustering's resolutions), a table in workgroup memory that keeps the smallest particle index per hash, counts and weight sums per cell,
+// the occupied cells straight into the mapped host list (make_cluster_map, cluster_based_estimation.hpp:137-157: key, weight, count, first
+// particle and its state).  k_small_cluster_sums: the host's cluster ids per cell back into a table, the estimate's sums over the particles
+// of the winning cluster (estimate_clusters :345-411 over estimation.hpp:436-475).
+constexpr size_t kSmallClusterLdsBytes = kSmallMax * 8 /* hashes */ + kSmallSlots * 4 /* table */ + kSmallMax * 4 /* counts */ + kSmallMax * 8 /* sums */ + 64;
+__global__ __launch_bounds__(kSmallBlock) void k_small_cluster_cells(Particles p, uint32_t n, HashParams hp, CellList out, unsigned int* size_mirror) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* s_hash = reinterpret_cast<unsigned long long*>(smem);
+  uint32_t* s_table = reinterpret_cast<uint32_t*>(smem + kSmallMax * 8);
+  uint32_t* s_count = s_table + kSmallSlots;
+  double* s_sum = reinterpret_cast<double*>(s_count + kSmallMax);
+  uint32_t* s_size = reinterpret_cast<uint32_t*>(s_sum + kSmallMax);
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t s = tid; s < kSmallSlots; s += kSmallBlock) s_table[s] = 0xFFFFFFFFu;
+  for (uint32_t i = tid; i < kSmallMax; i += kSmallBlock) {
+    s_count[i] = 0u;
+    s_sum[i] = 0.0;
+    if (i < n) s_hash[i] = kld_key(spatial_hash(load_pose(p, i), hp));
+  }
+  if (tid == 0) *s_size = 0u;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += kSmallBlock) {  // the smallest particle index per hash
+    const unsigned long long key = s_hash[i];
+    uint32_t slot = static_cast<uint32_t>(kld_slot(key, kSmallSlots - 1));
+    for (;;) {
+      const uint32_t holder = atomicCAS(&s_table[slot], 0xFFFFFFFFu, i);
+      if (holder == 0xFFFFFFFFu) break;
+      if (s_hash[holder] == key) {
+        atomicMin(&s_table[slot], i);
+        break;
+      }
+      slot = (slot + 1) & (kSmallSlots - 1);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += kSmallBlock) {  // counts and weight sums, kept with the cell's first particle
+    const unsigned long long key = s_hash[i];
+    uint32_t slot = static_cast<uint32_t>(kld_slot(key, kSmallSlots - 1));
+    while (s_hash[s_table[slot]] != key) slot = (slot + 1) & (kSmallSlots - 1);
+    const uint32_t first = s_table[slot];
+    atomicAdd(&s_count[first], 1u);
+    atomicAdd(&s_sum[first], p.w[i]);
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += kSmallBlock) {
+    if (s_count[i] == 0u) continue;  // (not a cell's first particle)
+    const uint32_t k = atomicAdd(s_size, 1u);
+    out.key[k] = s_hash[i];
+    out.first[k] = i;
+    out.count[k] = s_count[i];
+    out.slot[k] = 0u;
+    out.wsum[k] = s_sum[i];
+    out.state[k] = p.pose[i];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    *out.size = *s_size;
+    *size_mirror = *s_size;
+  }
+}
+__global__ __launch_bounds__(kSmallBlock) void k_small_cluster_sums(Particles p, uint32_t n, HashParams hp, const unsigned long long* __restrict__ keys,
+                                                                    const unsigned int* __restrict__ cluster, uint32_t cells, unsigned int wanted,
+                                                                    double pivot_x, double pivot_y, double* __restrict__ d_out,
+                                                                    double* __restrict__ mirror) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(smem);  // [kSmallMax] the cells' keys
+  uint32_t* s_table = reinterpret_cast<uint32_t*>(smem + kSmallMax * 8);   // [kSmallSlots] -> cell
+  uint32_t* s_cluster = s_table + kSmallSlots;                             // [kSmallMax]
+  double* s_wave = reinterpret_cast<double*>(s_cluster + kSmallMax);       // [16][9] (behind: kSmallMax * 8 of sums' room)
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (uint32_t s = tid; s < kSmallSlots; s += kSmallBlock) s_table[s] = 0xFFFFFFFFu;
+  for (uint32_t j = tid; j < cells; j += kSmallBlock) {
+    s_key[j] = keys[j];
+    s_cluster[j] = cluster[j];
+  }
+  __syncthreads();
+  for (uint32_t j = tid; j < cells; j += kSmallBlock) {  // (the keys are distinct)
+    uint32_t slot = static_cast<uint32_t>(kld_slot(s_key[j], kSmallSlots - 1));
+    while (atomicCAS(&s_table[slot], 0xFFFFFFFFu, j) != 0xFFFFFFFFu) slot = (slot + 1) & (kSmallSlots - 1);
+  }
+  __syncthreads();
+  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t i = tid; i < n; i += kSmallBlock) {
+    const double4 q = p.pose[i];
+    const unsigned long long key = kld_key(spatial_hash(Pose2{Rot2{q.x, q.y}, q.z, q.w}, hp));
+    uint32_t slot = static_cast<uint32_t>(kld_slot(key, kSmallSlots - 1));
+    uint32_t cell = s_table[slot];
+    while (cell != 0xFFFFFFFFu && s_key[cell] != key) {
+      slot = (slot + 1) & (kSmallSlots - 1);
+      cell = s_table[slot];
+    }
+    if (cell == 0xFFFFFFFFu || s_cluster[cell] != wanted) continue;
+    const double w = p.w[i];
+    const double dx = q.z - pivot_x, dy = q.w - pivot_y;
+    v[0] += w;
+    v[1] += w * w;
+    v[2] += w * q.x;
+    v[3] += w * q.y;
+    v[4] += w * dx;
+    v[5] += w * dy;
+    v[6] += w * dx * dx;
+    v[7] += w * dx * dy;
+    v[8] += w * dy * dy;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) v[k] = wave_sum_f64(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s_wave[wave * 9 + k] = v[k];
+  }
+  __syncthreads();
+  if (tid < 9) {
+    double acc = s_wave[tid];
+    for (uint32_t q = 1; q < kSmallBlock / 64; ++q) acc += s_wave[q * 9 + tid];
+    d_out[tid] = acc;
+    mirror[tid] = acc;
+  }
+}
+
 
 // ---- misc -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_init_normal(Particles p, uint64_t n, double m0, double m1, double m2, double t00,
@@ -4060,6 +4191,8 @@ bool launch_small_tail(hipStream_t st, const SmallTail& t) {
   a.pivot_y = t.pivot_y;
   a.out = t.mirror;
   a.d_out = t.d_scalars;
+  a.done_flag = t.done_flag;
+  a.done_seq = t.done_seq;
   hipLaunchKernelGGL(k_small_tail, dim3(1), dim3(kSmallBlock), kSmallLdsBytes, st, a);
   return true;
 }
@@ -4085,6 +4218,29 @@ void launch_cluster_cells(hipStream_t st, Particles p, uint64_t n, HashParams hp
   }
   const CellList out{c_key, c_first, c_count, c_slot, c_wsum, reinterpret_cast<double4*>(c_state), c_size};
   hipLaunchKernelGGL(k_cell_compact, dim3(blocks_for(capacity)), dim3(kBlock), 0, st, t, p, out, list_capacity);
+}
+bool launch_small_cluster_cells(hipStream_t st, Particles p, uint64_t n, HashParams hp, unsigned long long* c_key, unsigned int* c_first,
+                                unsigned int* c_count, unsigned int* c_slot, double* c_wsum, double* c_state, unsigned int* c_size,
+                                unsigned int* size_mirror) {
+  if (n == 0 || n > kSmallMax) return false;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_cluster_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kSmallClusterLdsBytes)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_cluster_sums), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kSmallClusterLdsBytes)) != hipSuccess)
+      return false;
+    configured = true;
+  }
+  const CellList out{c_key, c_first, c_count, c_slot, c_wsum, reinterpret_cast<double4*>(c_state), c_size};
+  hipLaunchKernelGGL(k_small_cluster_cells, dim3(1), dim3(kSmallBlock), kSmallClusterLdsBytes, st, p, static_cast<uint32_t>(n), hp, out, size_mirror);
+  return true;
+}
+void launch_small_cluster_sums(hipStream_t st, Particles p, uint64_t n, HashParams hp, const unsigned long long* d_keys,
+                               const unsigned int* d_cluster, uint32_t cells, unsigned int wanted, double pivot_x, double pivot_y, double* d_out,
+                               double* host_mirror) {
+  hipLaunchKernelGGL(k_small_cluster_sums, dim3(1), dim3(kSmallBlock), kSmallClusterLdsBytes, st, p, static_cast<uint32_t>(n), hp, d_keys, d_cluster,
+                     cells, wanted, pivot_x, pivot_y, d_out, host_mirror);
 }
 void launch_cell_set_cluster(hipStream_t st, const unsigned int* d_slot, const unsigned int* d_cluster, uint32_t m,
                              unsigned int* t_cluster) {

@@ -1365,10 +1365,10 @@ def test_one_launch_scan_and_folded_estimate_sums_leave_the_same_cycle(n, beams)
         assert np.array_equal(outs[0][1][0], other[1][0]) and np.array_equal(outs[0][1][1], other[1][1])
 
 
-@pytest.mark.parametrize("lo,hi,selective,interval,beams", [
-    (2000, 2000, False, 1, 180), (500, 2000, False, 1, 180), (500, 2000, True, 1, 360), (4096, 4096, False, 2, 90),
-    (100, 4096, True, 1, 180), (1, 1, False, 1, 8), (700, 700, True, 1, 180)])
-def test_small_sets_one_launch_tail_matches_the_kernels_of_the_large_path(lo, hi, selective, interval, beams):
+@pytest.mark.parametrize("lo,hi,selective,interval,beams,cluster", [
+    (2000, 2000, False, 1, 180, False), (500, 2000, False, 1, 180, False), (500, 2000, True, 1, 360, False), (4096, 4096, False, 2, 90, False),
+    (100, 4096, True, 1, 180, False), (1, 1, False, 1, 8, False), (700, 700, True, 1, 180, False), (500, 2000, False, 1, 180, True)])
+def test_small_sets_one_launch_tail_matches_the_kernels_of_the_large_path(lo, hi, selective, interval, beams, cluster):
     """Sets of up to 4096 particles - the reference's own sizes (amcl_core.hpp:44-46) - run everything behind the reweight in ONE launch of
     one workgroup (k_small_tail, option small_fused): normalisation, the recovery estimator, every_n [&& on_effective_size_drop], the
     fixed-size or KLD-adaptive resampling with random_intersperse, the estimate's sums; one host synchronisation per cycle instead of up
@@ -1384,6 +1384,8 @@ def test_small_sets_one_launch_tail_matches_the_kernels_of_the_large_path(lo, hi
     for fused in (1, 0):
         f = Amcl(grid, MOTION, LF, AmclParams(min_particles=lo, max_particles=hi, selective_resampling=selective, resample_interval=interval), seed=11)
         f.set_option("small_fused", fused)
+        if cluster:  # what beluga_ros::Amcl returns (beluga_ros/src/amcl.cpp:125): cluster_based_estimate, behind the same tail
+            f.set_estimate_kind(True)
         f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
         pose, odom, rows = truth, (0.0, 0.0, 0.0), []
         for c in range(9):
