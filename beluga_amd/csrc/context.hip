@@ -251,6 +251,7 @@ struct mcl_ctx {
   uint32_t scan_epoch{0};           // of the last k_normalize_cdf launch on that state
   DeviceBuffer<double> d_lf_wsum;   // sums of the new weights per workgroup of the LF patch kernel (PatchStats::weight_sums)
   uint32_t lf_wsum_count{0};        // how many the last reweight left (0: none; consumed by the normalisation right behind it)
+  bool cdf_divides{false};          // the last normalisation left the weights undivided: the CDF kernel right behind it divides (do_normalize)
   bool weights_unit{false};         // every weight of the live set is exactly 1.0: set by what writes them all (initialisation, resampling,
                                     // particle_traits.hpp:105), cleared by whatever else touches a weight
   CdfTree cdf_tree() const { return make_cdf_tree(d_cdf.ptr, d_cdf_tree.ptr, n); }
@@ -954,13 +955,18 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
 // d_scalars layout: [0] weight sum, [1] norm_sum, [2] norm_sumsq, [3] factor override, [4] cdf total, [8..16] estimate sums
 // finalize == false (only with factor = NaN and read_back == false): the totals of the normalised weights in d_scalars[1..3)
 // are left to the next kernel (do_build_cdf with a policy, or launch_norm_finalize).
-mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats, bool read_back = true, bool finalize = true) {
+// store_weights == false (mcl_update, a resampling follows at once): the normalised weights are not stored; do_build_cdf has to divide
+// (ctx->cdf_divides tells it).
+mcl_status do_normalize(mcl_ctx* ctx, double factor, mcl_weight_stats* stats, bool read_back = true, bool finalize = true,
+                        bool store_weights = true) {
   ctx->weights_unit = false;
+  ctx->cdf_divides = false;
   stage_begin(ctx, MCL_STAGE_NORMALIZE);
   if (std::isnan(factor)) {  // by the set's own total
     launch_sum_and_normalize(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->chunk_row(1), ctx->chunk_row(2),
                              ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0, finalize, ctx->lf_wsum_count ? ctx->d_lf_wsum.ptr : nullptr,
-                             ctx->lf_wsum_count);
+                             ctx->lf_wsum_count, store_weights);
+    ctx->cdf_divides = !store_weights;
     ctx->lf_wsum_count = 0;  // (they described the weights as the reweight left them)
   } else {
     launch_weight_sum(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(0), ctx->d_scalars.ptr + 0, ctx->hd_scalars + 0);
@@ -1010,7 +1016,9 @@ mcl_status do_build_cdf(mcl_ctx* ctx, bool normalized_just_now = false, const Re
                         bool finalize_norm = false) {
   launch_cdf(ctx->stream, ctx->cur().w, ctx->n, ctx->chunk_row(3), ctx->chunk_row(4), ctx->d_cdf.ptr, ctx->d_scalars.ptr + 4,
              ctx->d_cdf_tree.ptr, normalized_just_now ? ctx->chunk_row(1) : nullptr, finalize_norm ? ctx->chunk_row(2) : nullptr,
-             finalize_norm ? ctx->d_scalars.ptr + 1 : nullptr, finalize_norm ? ctx->hd_scalars + 1 : nullptr, policy);
+             finalize_norm ? ctx->d_scalars.ptr + 1 : nullptr, finalize_norm ? ctx->hd_scalars + 1 : nullptr, policy,
+             (normalized_just_now && ctx->cdf_divides) ? ctx->d_scalars.ptr + 0 : nullptr);
+  ctx->cdf_divides = false;
   MCL_HIP(ctx, hipGetLastError());
   return MCL_OK;
 }
@@ -2155,7 +2163,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     }
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin", "scan_fused", "draw_fold", "lf_unit_weights", "small_fused"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin", "scan_fused", "draw_fold", "lf_unit_weights", "small_fused", "norm_store"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2765,7 +2773,8 @@ mcl_status mcl_update(mcl_ctx* ctx, const double control_pose[4], const double* 
     if (do_resampling)
       if (const mcl_status s = do_normalize_cdf(ctx, policy, &fused)) return s;
     if (!fused)
-      if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), nullptr, false, false)) return s;
+      if (const mcl_status s = do_normalize(ctx, std::numeric_limits<double>::quiet_NaN(), nullptr, false, false,
+                                            /*store_weights=*/!do_resampling || ctx->tuning.norm_store != 0)) return s;
     if (do_resampling) {
       if (const mcl_status s = do_resample(ctx, 0.0, ctx->step, nullptr, ctx->d_scalars.ptr + kPolicySlot + 2, true,
                                            ctx->estimate_kind == 0, &estimate_enqueued, &policy, true, fused)) return s;  // :188-196
@@ -3292,6 +3301,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "draw_fold") t.draw_fold = static_cast<int>(std::clamp<int64_t>(value, 0, 2));
   else if (key == "lf_unit_weights") t.lf_unit_weights = value ? 1 : 0;
   else if (key == "small_fused") t.small_fused = value ? 1 : 0;
+  else if (key == "norm_store") t.norm_store = value ? 1 : 0;
   else if (key == "lf_split") t.lf_split = static_cast<int>(value & 3);  // 1: side by side only, 2: stacked only, 3: both
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else if (key == "beam_sort_min_particles") t.beam_sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));

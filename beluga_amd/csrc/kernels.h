@@ -178,6 +178,9 @@ struct Tuning {
   int draw_fold = 1;                // the draw kernel's last workgroup to finish adds up the estimate sums (no k_final_rows launch behind it):
                                     // 1 = for sets of up to 64K particles, 2 = up to 4M (measured at 1M: 56.2 us against 49.2 + 4.4 - every
                                     // workgroup ends on the ticket's round trip), 0 = k_final_rows.  Bit-identical.
+  int norm_store = 0;               // fixed-size cycle that resamples at once: 0 = k_normalize leaves the chunk sums of the normalised weights
+                                    // but does not store them - the CDF kernel divides again (same division, same bits), nothing else reads them;
+                                    // 1 = stored
   int small_fused = 1;              // sets of up to 4096 particles (plain estimate, one context): everything behind the reweight - normalise,
                                     // policies, fixed-size or KLD resampling, estimate sums - in one launch of one workgroup and one host
                                     // synchronisation (k_small_tail); 0 = the kernels of the large path
@@ -348,7 +351,7 @@ void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_fac
 // known_partials (optional): `known_count` sums whose total is the normalisation factor (PatchStats::weight_sums) - k_chunk_sum is skipped
 void launch_sum_and_normalize(hipStream_t st, double* w, uint64_t n, double* d_partials, double* d_chunk_sum, double* d_chunk_sumsq,
                               double* d_sums, double* host_mirror, bool finalize = true, const double* known_partials = nullptr,
-                              uint32_t known_count = 0);
+                              uint32_t known_count = 0, bool store_weights = true);
 // ThrunRecoveryProbabilityEstimator (thrun_recovery_probability_estimator.hpp:69-89, exponential_filter.hpp:32-44) evaluated
 // on the device so that a cycle without host-side decisions needs no mid-cycle read-back: d_policy = {slow, fast, p}.
 // It rides on the workgroup that adds up the totals of the normalised weights (launch_cdf / launch_norm_finalize).
@@ -402,7 +405,8 @@ inline CdfTree make_cdf_tree(const double* cdf, const double* levels, uint64_t n
 // the recovery estimator (see launch_norm_finalize) — for the cycle that goes straight from k_normalize into a resample.
 void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
                 double* d_total, double* tree_levels, const double* known_chunk_sum = nullptr, const double* finalize_sumsq = nullptr,
-                double* finalize_sums = nullptr, double* finalize_mirror = nullptr, const RecoveryPolicy* policy = nullptr);
+                double* finalize_sums = nullptr, double* finalize_mirror = nullptr, const RecoveryPolicy* policy = nullptr,
+                const double* d_factor = nullptr);
 // Normalisation by the set's own total + totals of the normalised weights (+ recovery estimator) + CDF and its search tree in one launch
 // (k_normalize_cdf): what launch_sum_and_normalize(finalize = false) followed by launch_cdf(known chunk sums, finalize arguments) leave,
 // bit for bit.  known_partials as in launch_sum_and_normalize (nullptr: k_chunk_sum into d_partials first).  scan_state: kScanStateWords

@@ -1989,7 +1989,7 @@ __global__ __launch_bounds__(kBlock) void k_final_rows(const double* __restrict_
 __global__ __launch_bounds__(kBlock) void k_normalize(double* __restrict__ w, uint64_t n, const double* __restrict__ d_factor,
                                                       double* __restrict__ chunk_sum, double* __restrict__ chunk_sumsq,
                                                       const double* __restrict__ sum_partials, uint32_t sum_count,
-                                                      double* __restrict__ d_sum_out, double* __restrict__ sum_mirror) {
+                                                      double* __restrict__ d_sum_out, double* __restrict__ sum_mirror, int store_weights) {
   __shared__ double scratch[(kBlock / 64) * 2];
   __shared__ double s_factor;
   if (sum_partials) {
@@ -2017,7 +2017,9 @@ __global__ __launch_bounds__(kBlock) void k_normalize(double* __restrict__ w, ui
     v[0] += x[k];
     v[1] += x[k] * x[k];
   }
-  if (!skip) chunk_items_store(w, n, s_items, x);
+  // store_weights == 0 (a cycle that resamples at once): the normalised weights themselves are not written - the CDF kernel that follows
+  // divides again (k_cdf, d_factor: the same division, the same bits), nothing else reads them
+  if (!skip && store_weights) chunk_items_store(w, n, s_items, x);
   block_reduce<2>(v, scratch);
   if (threadIdx.x == 0) {
     chunk_sum[blockIdx.x] = v[0];
@@ -2143,7 +2145,7 @@ __global__ __launch_bounds__(kBlock) void k_norm_finalize(NormFinalize f) {
 __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, uint64_t n, const double* __restrict__ chunk_offset,
                                                 double* __restrict__ cdf, double* __restrict__ total, CdfTree tree,
                                                 double* __restrict__ levels, const double* __restrict__ chunk_sum_to_scan,
-                                                uint32_t chunk_count, NormFinalize fin) {
+                                                uint32_t chunk_count, NormFinalize fin, const double* __restrict__ d_factor) {
   __shared__ double s_wave[kBlock / 64];
   if (fin.d_sums && blockIdx.x == 0) {  // the totals (and the recovery estimator) ride on the first workgroup
     norm_finalize(fin, s_wave);
@@ -2155,6 +2157,13 @@ __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, ui
   __shared__ double s_items[kChunkPadded];
   double loc[kItems];
   chunk_items_load(w, n, s_items, loc);
+  if (d_factor) {  // w holds the weights as the reweight left them: actions::normalize's division here (k_normalize did not store it)
+    const double factor = *d_factor;
+    if (!(fabs(factor - 1.0) < DBL_EPSILON)) {  // normalize.hpp:73
+#pragma unroll
+      for (int k = 0; k < kItems; ++k) loc[k] = loc[k] / factor;
+    }
+  }
   double run = 0.0;
 #pragma unroll
   for (int k = 0; k < kItems; ++k) {
@@ -3892,10 +3901,11 @@ void launch_weight_sum(hipStream_t st, const double* w, uint64_t n, double* d_pa
 
 void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_factor, double* d_chunk_sum, double* d_chunk_sumsq,
                       double* d_out, double* host_mirror) {
+  constexpr bool store_weights = true;
   const uint32_t chunks = num_chunks(n);
   if (chunks)
     hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, d_factor, d_chunk_sum, d_chunk_sumsq,
-                       static_cast<const double*>(nullptr), 0u, static_cast<double*>(nullptr), static_cast<double*>(nullptr));
+                       static_cast<const double*>(nullptr), 0u, static_cast<double*>(nullptr), static_cast<double*>(nullptr), store_weights ? 1 : 0);
   // d_chunk_sum and d_chunk_sumsq are adjacent rows of one [2][stride] buffer (see context.hip)
   hipLaunchKernelGGL(k_final_rows, dim3(2), dim3(kBlock), 0, st, d_chunk_sum, chunks, static_cast<uint32_t>(d_chunk_sumsq - d_chunk_sum),
                      d_out, host_mirror, Completion{});
@@ -3906,7 +3916,8 @@ void launch_normalize(hipStream_t st, double* w, uint64_t n, const double* d_fac
 // finalize == false: the totals after (and the recovery estimator) are left to the kernel that follows — launch_cdf with its
 // finalize arguments, or launch_norm_finalize.
 void launch_sum_and_normalize(hipStream_t st, double* w, uint64_t n, double* d_partials, double* d_chunk_sum, double* d_chunk_sumsq,
-                              double* d_sums, double* host_mirror, bool finalize, const double* known_partials, uint32_t known_count) {
+                              double* d_sums, double* host_mirror, bool finalize, const double* known_partials, uint32_t known_count,
+                              bool store_weights) {
   const uint32_t chunks = num_chunks(n);
   if (chunks) {
     // known_partials: sums whose total is the factor already exist (the LF kernel's workgroup sums): no pass to add the weights up
@@ -3918,10 +3929,10 @@ void launch_sum_and_normalize(hipStream_t st, double* w, uint64_t n, double* d_p
     if (count > 4096u) {
       hipLaunchKernelGGL(k_final_rows, dim3(1), dim3(kBlock), 0, st, partials, count, count, d_sums, host_mirror, Completion{});
       hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, static_cast<const double*>(d_sums), d_chunk_sum, d_chunk_sumsq,
-                         static_cast<const double*>(nullptr), 0u, static_cast<double*>(nullptr), static_cast<double*>(nullptr));
+                         static_cast<const double*>(nullptr), 0u, static_cast<double*>(nullptr), static_cast<double*>(nullptr), store_weights ? 1 : 0);
     } else {
       hipLaunchKernelGGL(k_normalize, dim3(chunks), dim3(kBlock), 0, st, w, n, static_cast<const double*>(nullptr), d_chunk_sum,
-                         d_chunk_sumsq, partials, count, d_sums, host_mirror);
+                         d_chunk_sumsq, partials, count, d_sums, host_mirror, store_weights ? 1 : 0);
     }
   } else {
     hipLaunchKernelGGL(k_final_rows, dim3(1), dim3(kBlock), 0, st, d_partials, chunks, chunks, d_sums, host_mirror, Completion{});
@@ -3961,7 +3972,7 @@ void launch_norm_finalize(hipStream_t st, const double* d_chunk_sum, const doubl
 
 void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum, double* d_chunk_offset, double* cdf,
                 double* d_total, double* tree_levels, const double* known_chunk_sum, const double* finalize_sumsq, double* finalize_sums,
-                double* finalize_mirror, const RecoveryPolicy* policy) {
+                double* finalize_mirror, const RecoveryPolicy* policy, const double* d_factor) {
   const uint32_t chunks = num_chunks(n);
   if (!chunks) return;
   const double* sums = known_chunk_sum;
@@ -3976,7 +3987,7 @@ void launch_cdf(hipStream_t st, const double* w, uint64_t n, double* d_chunk_sum
   NormFinalize fin{};
   if (finalize_sums) fin = make_norm_finalize(sums, finalize_sumsq, n, finalize_sums, finalize_mirror, policy);
   hipLaunchKernelGGL(k_cdf, dim3(chunks), dim3(kBlock), 0, st, w, n, d_chunk_offset, cdf, d_total,
-                     make_cdf_tree(cdf, tree_levels, n), tree_levels, replay ? sums : static_cast<const double*>(nullptr), chunks, fin);
+                     make_cdf_tree(cdf, tree_levels, n), tree_levels, replay ? sums : static_cast<const double*>(nullptr), chunks, fin, d_factor);
 }
 
 // launch_sum_and_normalize (known partial sums, the totals left to this kernel) + launch_cdf (with its finalize arguments) in ONE launch:

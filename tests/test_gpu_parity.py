@@ -1348,11 +1348,13 @@ def test_one_launch_scan_and_folded_estimate_sums_leave_the_same_cycle(n, beams)
     grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
     keep = np.linspace(0, bench.BEAMS - 1, beams).astype(int)
     outs = []
-    for fused, fold in ((1, 1), (0, 0), (1, 0), (0, 1)):
+    for fused, fold, store in ((1, 1, 0), (0, 0, 0), (0, 0, 1), (1, 0, 0), (0, 1, 1)):
         f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF),
                  AmclParams(min_particles=n, max_particles=n), seed=42)
+        f.set_option("small_fused", 0)         # (the 2000-particle case: these are the large path's kernels)
         f.set_option("scan_fused", 2 * fused)  # (2: wherever the kernel takes the set; the default takes it for small sets only)
         f.set_option("draw_fold", 2 * fold)
+        f.set_option("norm_store", store)      # (0: k_normalize does not store the normalised weights, k_cdf divides again)
         f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
         est = []
         for c in range(cycles):
