@@ -37,8 +37,8 @@ KERNEL_SOURCE = os.path.join(ROOT, "beluga_amd", "csrc", "kernels.hip")
 PROFILES = os.path.join(ROOT, "profiles")
 # per-launch counters of the LF kernel (rocprofv3 --pmc passes of the default bench, tools/gpu_r3_profiles.sh) and the measured
 # issue cost of the instruction classes on this part (tools/calib_f64_rate.hip): what the VALU-issue roofline is computed from
-PMC_FILES = [os.path.join(PROFILES, "r05_pmc_bench_1M.txt"), os.path.join(PROFILES, "r04_pmc_bench_1M.txt"), os.path.join(PROFILES, "r03_pmc_bench_1M.txt"), os.path.join(PROFILES, "r02_pmc_bench_1M.txt")]
-TRAFFIC_FILES = [os.path.join(PROFILES, "r05_lf_kernel_traffic.json"), os.path.join(PROFILES, "r04_lf_kernel_traffic.json"), os.path.join(PROFILES, "r03_lf_kernel_traffic.json")]
+PMC_FILES = [os.path.join(PROFILES, "r06_pmc_bench_1M.txt"), os.path.join(PROFILES, "r05_pmc_bench_1M.txt"), os.path.join(PROFILES, "r04_pmc_bench_1M.txt"), os.path.join(PROFILES, "r03_pmc_bench_1M.txt"), os.path.join(PROFILES, "r02_pmc_bench_1M.txt")]
+TRAFFIC_FILES = [os.path.join(PROFILES, "r06_lf_kernel_traffic.json"), os.path.join(PROFILES, "r05_lf_kernel_traffic.json"), os.path.join(PROFILES, "r04_lf_kernel_traffic.json"), os.path.join(PROFILES, "r03_lf_kernel_traffic.json")]
 CALIB_FILE = os.path.join(PROFILES, "r01_calib_f64_issue_rate.txt")
 # the datasheet's issue rates (MI355X_MICROARCH.md, "Wave scheduling"): a wave64 instruction takes 2 passes of a SIMD-32, f64 at half rate 4
 SPEC_CYCLES = {"fma_f64": 4.0, "mul_f64": 4.0, "add_f64": 4.0, "other": 2.0}

@@ -1335,9 +1335,11 @@ def test_queue_of_blocks_leaves_the_same_cycle_as_a_workgroup_per_block():
 
 @pytest.mark.parametrize("n,beams", [(1_000_000, 1080), (300_001, 360), (70_000, 180), (2_000, 180), (2_097_152, 90)])
 def test_one_launch_scan_and_folded_estimate_sums_leave_the_same_cycle(n, beams):
-    """Round 6 took two launches out of the fixed-size cycle: k_normalize_cdf (option scan_fused: normalisation, totals of the normalised
+    """Round 6 built two fusions of the fixed-size cycle's tail: k_normalize_cdf (option scan_fused: normalisation, totals of the normalised
     weights, recovery estimator and CDF in one pass, the chunk sums handed from workgroup to workgroup inside the launch) instead of
-    k_normalize + k_cdf, and the estimate sums added up by the draw kernel's last workgroup (option draw_fold) instead of k_final_rows.
+    k_normalize + k_cdf, and the estimate sums added up by the draw kernel's last workgroup (option draw_fold) instead of k_final_rows -
+    measured no faster at 1M particles, so by default they serve sets of up to 64K particles, where a cycle is bound by the host's launches;
+    here they are forced on at every size (value 2) - and k_normalize without its store, the division repeated by k_cdf (option norm_store).
     Same threads, same elements, same order of additions (actions/normalize.hpp:54-85, views/sample.hpp:128-159,
     effective_sample_size.hpp:46-59): estimates, weight sums, recovery probabilities and the resampled sets are identical bit for bit,
     launch after launch (the tickets wrap to zero, the epochs move on), on sets of one chunk, of a ragged last chunk, of the largest size
