@@ -245,12 +245,18 @@ struct mcl_ctx {
   // kernel enqueued, -> last kernel enqueued, the wait for the cycle, the rest until the return; host_cycles counts them.
   uint64_t host_ns[4]{0, 0, 0, 0};
   uint64_t host_cycles{0};
+  uint64_t noise_ahead_used{0};  // launches of k_propagate that found their normals drawn ahead (mcl_get_counter)
   DeviceBuffer<double> d_cloud_w;
   DeviceBuffer<double> d_cdf_tree;  // sampled levels of the 16-ary search tree over d_cdf (CdfTree)
   DeviceBuffer<unsigned long long> d_scan_state;  // k_normalize_cdf: ticket word + the chunk sums' granules (kScanStateWords, zeroed once)
   uint32_t scan_epoch{0};           // of the last k_normalize_cdf launch on that state
   DeviceBuffer<double> d_lf_wsum;   // sums of the new weights per workgroup of the LF patch kernel (PatchStats::weight_sums)
   uint32_t lf_wsum_count{0};        // how many the last reweight left (0: none; consumed by the normalisation right behind it)
+  // k_noise_ahead: the propagation normals of step `noise_step` for the particles [noise_offset, noise_offset + noise_n) of the global index
+  // space, drawn behind the previous cycle (they depend on nothing else: any set of that size at that step may use them)
+  DeviceBuffer<double> d_noise;
+  uint32_t noise_step{0};
+  uint64_t noise_n{0}, noise_offset{0}, noise_seed{0};
   bool cdf_divides{false};          // the last normalisation left the weights undivided: the CDF kernel right behind it divides (do_normalize)
   bool weights_unit{false};         // every weight of the live set is exactly 1.0: set by what writes them all (initialisation, resampling,
                                     // particle_traits.hpp:105), cleared by whatever else touches a weight
@@ -840,9 +846,13 @@ mcl_status do_propagate(mcl_ctx* ctx, const Pose2& pose, const Pose2& prev, uint
   const SortScratch sort = ctx->sort_scratch();
   if (keys_emitted) decide_lf_mode(ctx);  // the fused cycle: the reweight follows, and the keys depend on its kernel
   const bool keys = keys_emitted && wants_ordering(ctx) && predict_key_frame(ctx, &sampler, &frame);
+  // (the normals of this step, if the previous cycle left them: k_noise_ahead)
+  const bool ahead = ctx->d_noise.ptr && ctx->noise_n >= ctx->n && ctx->n > 65536 && ctx->noise_step == step && ctx->noise_seed == ctx->cfg.seed &&
+                     ctx->noise_offset == ctx->cfg.shard_offset;
   launch_propagate(ctx->stream, ctx->cur(), ctx->n, sampler, ctx->cfg.seed, step, ctx->cfg.shard_offset,
                    scan_points ? ctx->hd_points : nullptr, scan_points ? ctx->d_points.ptr : nullptr, static_cast<uint32_t>(2 * scan_points),
-                   keys ? &sort : nullptr, keys ? &frame : nullptr);
+                   keys ? &sort : nullptr, keys ? &frame : nullptr, ahead ? ctx->d_noise.ptr : nullptr);
+  if (ahead) ctx->noise_ahead_used += 1;
   if (scan_points) points_pulled(ctx, false);
   if (keys_emitted) *keys_emitted = keys;
   stage_end(ctx, MCL_STAGE_PROPAGATE);
@@ -1063,12 +1073,22 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
         done.host_flag = reinterpret_cast<unsigned long long*>(ctx->hd_scalars + 31);
         done.seq = ++ctx->done_seq;
       }
+      // (behind the draw and its sums - the completion word is theirs -: the next cycle's propagation normals, while the host is away)
+      const bool noise_ahead = ctx->done_armed && ctx->tuning.noise_ahead != 0 && max_p > 65536 && max_p <= 2000000 &&
+                               ctx->d_noise.ensure(4 * static_cast<size_t>(max_p)) == hipSuccess;
       launch_resample_draw_and_estimate(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp,
                                         ctx->pivot[0], ctx->pivot[1], ctx->d_est_partials.ptr, ctx->d_scalars.ptr + 8,
                                         ctx->hd_scalars + 8, ctx->done_armed ? &done : nullptr,
                                         ((ctx->tuning.draw_fold == 2 || (ctx->tuning.draw_fold == 1 && max_p <= 65536)) && ctx->d_scan_state.ptr)
                                             ? reinterpret_cast<unsigned int*>(ctx->d_scan_state.ptr + 4)
                                             : nullptr);
+      if (noise_ahead) {
+        launch_noise_ahead(ctx->stream, ctx->cfg.seed, step + 1, ctx->cfg.shard_offset, max_p, ctx->d_noise.ptr);
+        ctx->noise_step = step + 1;
+        ctx->noise_n = max_p;
+        ctx->noise_offset = ctx->cfg.shard_offset;
+        ctx->noise_seed = ctx->cfg.seed;
+      }
       if (estimate_enqueued) *estimate_enqueued = true;
     } else {
       launch_resample_draw(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp, nullptr);
@@ -2163,7 +2183,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     }
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin", "scan_fused", "draw_fold", "lf_unit_weights", "small_fused", "norm_store"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin", "scan_fused", "draw_fold", "lf_unit_weights", "small_fused", "norm_store", "noise_ahead"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2209,6 +2229,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_cdf_tree.release();
   ctx->d_lf_wsum.release();
   ctx->d_scan_state.release();
+  ctx->d_noise.release();
   ctx->d_cloud.release();
   ctx->d_est_partials.release();
   ctx->d_cloud_w.release();
@@ -3302,6 +3323,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "lf_unit_weights") t.lf_unit_weights = value ? 1 : 0;
   else if (key == "small_fused") t.small_fused = value ? 1 : 0;
   else if (key == "norm_store") t.norm_store = value ? 1 : 0;
+  else if (key == "noise_ahead") t.noise_ahead = value ? 1 : 0;
   else if (key == "lf_split") t.lf_split = static_cast<int>(value & 3);  // 1: side by side only, 2: stacked only, 3: both
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else if (key == "beam_sort_min_particles") t.beam_sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
@@ -3318,6 +3340,7 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
   else if (key == "lf_beams_launches") *value = ctx->lf_beams_launches;
   else if (key == "lf_far_launches") *value = ctx->lf_far_launches;
   else if (key == "lf_far_tiles") *value = ctx->far_tiles;
+  else if (key == "noise_ahead_used") *value = ctx->noise_ahead_used;
   else if (key == "lf_patch_groups_planned" || key == "lf_patch_groups_through") {
     if (const mcl_status s = bind_device(ctx)) return s;
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -178,6 +178,9 @@ struct Tuning {
   int draw_fold = 1;                // the draw kernel's last workgroup to finish adds up the estimate sums (no k_final_rows launch behind it):
                                     // 1 = for sets of up to 64K particles, 2 = up to 4M (measured at 1M: 56.2 us against 49.2 + 4.4 - every
                                     // workgroup ends on the ticket's round trip), 0 = k_final_rows.  Bit-identical.
+  int noise_ahead = 1;              // fixed-size cycles that end on the completion word (cycle_spin), sets of 64K .. 2M particles: the next cycle's
+                                    // propagation normals are drawn behind the cycle's last kernel, while the host is away (k_noise_ahead);
+                                    // 0 = drawn by k_propagate itself.  Bit-identical.
   int norm_store = 0;               // fixed-size cycle that resamples at once: 0 = k_normalize leaves the chunk sums of the normalised weights
                                     // but does not store them - the CDF kernel divides again (same division, same bits), nothing else reads them;
                                     // 1 = stored
@@ -278,7 +281,10 @@ constexpr uint64_t kLfSegmentedBelow = 262144;  // particles
 // pass's block histograms (launch_order_particles then skips its own key pass).
 void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
                       uint64_t index_offset, const double* scan_src = nullptr, double* scan_dst = nullptr, uint32_t scan_doubles = 0,
-                      const SortScratch* sort = nullptr, const KeyFrame* frame = nullptr);
+                      const SortScratch* sort = nullptr, const KeyFrame* frame = nullptr, const double* normals_ahead = nullptr);
+// The propagation's four standard normals per particle for `step`, drawn ahead of the cycle that uses them (k_noise_ahead; 4 doubles per
+// particle): launch_propagate(..., normals_ahead) then reads them instead of drawing (not the small-set kernel).  Same bits.
+void launch_noise_ahead(hipStream_t st, uint64_t seed, uint32_t step, uint64_t index_offset, uint64_t n, double* d_normals);
 void launch_pull_scan(hipStream_t st, const double* scan_src, double* scan_dst, uint32_t scan_doubles);
 // Full sort of the particles by the ordering key -> sort->perm.  frame == nullptr: bounding-box pass + device-resident frame.
 // keys_ready: launch_propagate already wrote sort->keys and the first pass's block histograms.

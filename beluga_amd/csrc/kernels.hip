@@ -200,12 +200,21 @@ __device__ __forceinline__ void box_muller_fast(double u1, double u2, double& z0
   z0 = r * cs;
   z1 = r * sn;
 }
-__device__ __forceinline__ Pose2 propagate_one(const Pose2& state, const DiffDriveSampler& smp, uint64_t seed, uint32_t step, uint64_t index) {
+// The four standard normals of particle `index` at `step`: the two Philox draws and Box-Muller pairs of the propagation (rng.h) - a function of
+// (seed, step, index) alone, which is why they can be drawn AHEAD of the control action they will be scaled by (k_noise_ahead).
+__device__ __forceinline__ double4 propagation_normals(uint64_t seed, uint32_t step, uint64_t index) {
   const RngWords a = rng_draw(seed, step, kRngPropagateA, index);
   const RngWords b = rng_draw(seed, step, kRngPropagateB, index);
   double z0, z1, z2, z3;
   box_muller_fast(rng_uniform53(a.w[0], a.w[1]), rng_uniform53(a.w[2], a.w[3]), z0, z1);
   box_muller_fast(rng_uniform53(b.w[0], b.w[1]), rng_uniform53(b.w[2], b.w[3]), z2, z3);
+  return double4{z0, z1, z2, z3};
+}
+__device__ __forceinline__ Pose2 propagate_one(const Pose2& state, const DiffDriveSampler& smp, uint64_t seed, uint32_t step, uint64_t index,
+                                               const double4* __restrict__ normals_ahead = nullptr, uint64_t local = 0) {
+  // normals_ahead: drawn by k_noise_ahead behind the previous cycle (the same expressions: the same bits)
+  const double4 z = normals_ahead ? normals_ahead[local] : propagation_normals(seed, step, index);
+  const double z0 = z.x, z1 = z.y, z2 = z.z;
   if (smp.kind == 1) {
     // omnidirectional_drive_model.hpp:133-144 — draws in source order: rotation, translation, strafe
     const Rot2 first{smp.first_c, smp.first_s};
@@ -243,7 +252,8 @@ template <bool kKeys>
 __global__ __launch_bounds__(kPropBlock) void k_propagate(Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
                                                       uint64_t index_offset, const double* __restrict__ scan_src,
                                                       double* __restrict__ scan_dst, uint32_t scan_doubles, KeyFrame kf,
-                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ table, uint32_t nblocks) {
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ table, uint32_t nblocks,
+                                                      const double4* __restrict__ normals_ahead) {
   __shared__ uint32_t hist[kKeys ? kSortDigits : 1];
   if (kKeys) {
     for (uint32_t d = threadIdx.x; d < kSortDigits; d += kPropBlock) hist[d] = 0;
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(kPropBlock) void k_propagate(Particles p, uint64_t 
   for (int k = 0; k < kChunk / kPropBlock; ++k) {
     const uint64_t i = base + static_cast<uint64_t>(k) * kPropBlock + threadIdx.x;
     if (i >= n) break;
-    const Pose2 out = propagate_one(load_pose(p, i), smp, seed, step, index_offset + i);
+    const Pose2 out = propagate_one(load_pose(p, i), smp, seed, step, index_offset + i, normals_ahead, i);
     store_pose(p, i, out);
     if (kKeys) {
       const uint32_t key = order_key(double4{out.r.c, out.r.s, out.x, out.y}, kf);
@@ -267,6 +277,17 @@ __global__ __launch_bounds__(kPropBlock) void k_propagate(Particles p, uint64_t 
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < kSortDigits; d += kPropBlock) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
   }
+}
+
+// The propagation's random numbers, a cycle AHEAD: they depend on (seed, step, particle index) alone, not on the control action that scales them
+// (differential_drive_model.hpp:156-163 draws standard normals and scales them afterwards; so do the other two models) nor on the states.
+// Launched behind the last kernel of a fixed-size cycle whose end the host takes from the completion word (cycle_spin): it runs while the host
+// returns the estimate and comes back with the next control action - the 20 us the device used to idle between two cycles -, and the next
+// k_propagate finds 60 % of its instructions (two Philox draws, two logarithms, square roots and sine / cosine pairs per particle) done.
+// Same expressions as k_propagate's own: the same bits.
+__global__ __launch_bounds__(kBlock) void k_noise_ahead(uint64_t seed, uint32_t step, uint64_t index_offset, uint64_t n, double4* __restrict__ out) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) out[i] = propagation_normals(seed, step, index_offset + i);
 }
 
 // [lf-kernels-begin] (the HBM-traffic record of the LF kernel, profiles/lf_kernel_traffic.json, is keyed by the SHA-256 of
@@ -3746,7 +3767,7 @@ __global__ __launch_bounds__(kBlock) void k_fill(double* p, uint64_t n, double v
 // =====================================================================================================
 void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
                       uint64_t index_offset, const double* scan_src, double* scan_dst, uint32_t scan_doubles, const SortScratch* sort,
-                      const KeyFrame* frame) {
+                      const KeyFrame* frame, const double* normals_ahead) {
   if (n == 0) {
     if (scan_dst && scan_doubles) launch_pull_scan(st, scan_src, scan_dst, scan_doubles);
     return;
@@ -3759,10 +3780,16 @@ void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler 
   }
   if (sort && frame && n < (1ull << 32))
     hipLaunchKernelGGL(k_propagate<true>, dim3(nblocks), dim3(kPropBlock), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
-                       scan_doubles, *frame, sort->keys, sort->table, nblocks);
+                       scan_doubles, *frame, sort->keys, sort->table, nblocks, reinterpret_cast<const double4*>(normals_ahead));
   else
     hipLaunchKernelGGL(k_propagate<false>, dim3(nblocks), dim3(kPropBlock), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
-                       scan_doubles, KeyFrame{}, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), nblocks);
+                       scan_doubles, KeyFrame{}, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), nblocks,
+                       reinterpret_cast<const double4*>(normals_ahead));
+}
+
+void launch_noise_ahead(hipStream_t st, uint64_t seed, uint32_t step, uint64_t index_offset, uint64_t n, double* d_normals) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_noise_ahead, dim3(blocks_for(n)), dim3(kBlock), 0, st, seed, step, index_offset, n, reinterpret_cast<double4*>(d_normals));
 }
 
 void launch_pull_scan(hipStream_t st, const double* scan_src, double* scan_dst, uint32_t scan_doubles) {

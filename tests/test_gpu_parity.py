@@ -1428,6 +1428,36 @@ def test_small_sets_one_launch_tail_matches_the_kernels_of_the_large_path(lo, hi
         assert any(r[1]["random_state_probability"] > 0.3 for r in outs[0]), [r[1]["random_state_probability"] for r in outs[0]]
 
 
+@pytest.mark.parametrize("n", [1_000_000, 300_001])
+def test_propagation_normals_drawn_ahead_change_nothing(n):
+    """The propagation's standard normals depend on (seed, step, particle index) alone - differential_drive_model.hpp:156-163 scales them by
+    the control action afterwards -, so a fixed-size cycle that ends on the completion word draws the NEXT cycle's behind its last kernel,
+    while the host is away (k_noise_ahead, option noise_ahead), and k_propagate reads them.  Same expressions, same bits: whole cycles with
+    and without are identical, and the counter says the normals drawn ahead were used from the second cycle on - also across a cycle in
+    which the robot does not move (no update: the normals wait for the step they belong to)."""
+    import bench
+    cycles = 7
+    cells, truth, odoms, scans, _poses = bench.make_workload(cycles)
+    grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
+    outs = []
+    for ahead in (1, 0):
+        f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF),
+                 AmclParams(min_particles=n, max_particles=n), seed=42)
+        f.set_option("noise_ahead", ahead)
+        f.initialize(truth, np.diag([0.25, 0.25, 0.04]))
+        est = []
+        for c in range(cycles):
+            e = f.update(se2_from_xytheta(*odoms[c]), scans[c])
+            est.append(np.concatenate([e[0], e[1].ravel(), [f.last_info["weight_sum"]]]))
+            if c == 3:
+                assert f.update(se2_from_xytheta(*odoms[c]), scans[c]) is None  # the same odometry again: on_motion says no
+        assert f.counter("noise_ahead_used") == (cycles - 1 if ahead else 0)
+        outs.append((np.asarray(est), f.particles()))
+        f.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1][0], outs[1][1][0]) and np.array_equal(outs[0][1][1], outs[1][1][1])
+
+
 def test_map_built_ahead_on_a_worker_thread_swaps_in_between_two_updates():
     """mcl_set_map_async (an extension beside Amcl::update_map, amcl_core.hpp:150): the likelihood field of the next map is built on a
     worker thread - the reference's wavefront (distance_map.hpp:55-98), the same bits - while the filter keeps updating on the map it
