@@ -1067,7 +1067,9 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
       // (cycle_spin -1: where the cycle is long enough for the stream's completion signal to be what the host waits for last - measured
       // + 1 % at 1M particles in alternating runs, profiles/r06_ab_cycle_end.txt; small sets are bound by the host, which the spin costs)
       const bool spin = ctx->tuning.cycle_spin > 0 || (ctx->tuning.cycle_spin < 0 && max_p >= 262144);
-      ctx->done_armed = spin && !ctx->profile && estimate_enqueued;
+      // (profile 1 times the sensor kernel alone: its events are complete long before the cycle's last kernel stores the word; the per-stage
+      // events of profile 2 include stages behind it, which need the stream's own completion)
+      ctx->done_armed = spin && ctx->profile <= 1 && estimate_enqueued;
       if (ctx->done_armed) {
         done.d_ticket = reinterpret_cast<unsigned long long*>(ctx->d_scalars.ptr + 27);
         done.host_flag = reinterpret_cast<unsigned long long*>(ctx->hd_scalars + 31);
