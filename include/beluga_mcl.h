@@ -458,6 +458,14 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *   lf_unit_weights (1)  LDS-patch kernel on a set whose weights are all 1.0 - fresh from a resampling or an initialisation
  *                   (particle_traits.hpp:105), which the library keeps track of -: the old weight is not loaded (1.0 x = x); 0 = always
  *                   loaded.  Bit-identical; 9 us of a 1M-particle cycle.
+ *   noise_ahead (1)  fixed-size cycles that end on the completion word (cycle_spin), sets of 64K .. 2M particles: the NEXT cycle's propagation
+ *                   normals - a function of (seed, step, particle index) alone - are drawn behind the cycle's last kernel, while the host is away;
+ *                   0 = drawn by the propagation kernel itself.  Bit-identical; counter noise_ahead_used.
+ *   norm_store (0)  fixed-size cycle that resamples at once: 0 = the normalisation kernel does not store the normalised weights (nothing reads
+ *                   them), the CDF kernel divides again; 1 = stored.  Bit-identical.
+ *   small_fused (1)  sets of up to 4096 particles: everything behind the reweight - normalise, policies, fixed-size or KLD resampling, estimate
+ *                   sums - in one launch of one workgroup and one host synchronisation (and two one-workgroup kernels around the host's pass of
+ *                   cluster_based_estimate); 0 = the kernels of the large path
  *   lf_split (3)    LDS-patch planner: a group of 8 beams that fits no whole 64 x 64-cell patch (its end-points straddle a range
  *                   discontinuity: 3 - 5 % of the groups of an indoor scan, whatever the cloud) goes through two half patches -
  *                   beams [0, k) and [k, 8), 32 x 64 (bit 0) or 64 x 32 (bit 1) cells each, in the buffer of one whole patch; 0 = such
