@@ -851,7 +851,7 @@ mcl_status do_propagate(mcl_ctx* ctx, const Pose2& pose, const Pose2& prev, uint
                      ctx->noise_offset == ctx->cfg.shard_offset;
   launch_propagate(ctx->stream, ctx->cur(), ctx->n, sampler, ctx->cfg.seed, step, ctx->cfg.shard_offset,
                    scan_points ? ctx->hd_points : nullptr, scan_points ? ctx->d_points.ptr : nullptr, static_cast<uint32_t>(2 * scan_points),
-                   keys ? &sort : nullptr, keys ? &frame : nullptr, ahead ? ctx->d_noise.ptr : nullptr);
+                   keys ? &sort : nullptr, keys ? &frame : nullptr, ahead ? ctx->d_noise.ptr : nullptr, ctx->noise_n);
   if (ahead) ctx->noise_ahead_used += 1;
   if (scan_points) points_pulled(ctx, false);
   if (keys_emitted) *keys_emitted = keys;
@@ -1077,7 +1077,7 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
       }
       // (behind the draw and its sums - the completion word is theirs -: the next cycle's propagation normals, while the host is away)
       const bool noise_ahead = ctx->done_armed && ctx->tuning.noise_ahead != 0 && max_p > 65536 && max_p <= 2000000 &&
-                               ctx->d_noise.ensure(4 * static_cast<size_t>(max_p)) == hipSuccess;
+                               ctx->d_noise.ensure(3 * static_cast<size_t>(max_p)) == hipSuccess;
       launch_resample_draw_and_estimate(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp,
                                         ctx->pivot[0], ctx->pivot[1], ctx->d_est_partials.ptr, ctx->d_scalars.ptr + 8,
                                         ctx->hd_scalars + 8, ctx->done_armed ? &done : nullptr,

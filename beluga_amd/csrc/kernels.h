@@ -281,9 +281,11 @@ constexpr uint64_t kLfSegmentedBelow = 262144;  // particles
 // pass's block histograms (launch_order_particles then skips its own key pass).
 void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
                       uint64_t index_offset, const double* scan_src = nullptr, double* scan_dst = nullptr, uint32_t scan_doubles = 0,
-                      const SortScratch* sort = nullptr, const KeyFrame* frame = nullptr, const double* normals_ahead = nullptr);
-// The propagation's four standard normals per particle for `step`, drawn ahead of the cycle that uses them (k_noise_ahead; 4 doubles per
-// particle): launch_propagate(..., normals_ahead) then reads them instead of drawing (not the small-set kernel).  Same bits.
+                      const SortScratch* sort = nullptr, const KeyFrame* frame = nullptr, const double* normals_ahead = nullptr,
+                      uint64_t normals_stride = 0);
+// The propagation's standard normals per particle for `step`, drawn ahead of the cycle that uses them (k_noise_ahead: the three the motion
+// models use, as three arrays of n doubles): launch_propagate(..., normals_ahead, stride = that n) then reads them instead of drawing (not the
+// small-set kernel).  Same bits.
 void launch_noise_ahead(hipStream_t st, uint64_t seed, uint32_t step, uint64_t index_offset, uint64_t n, double* d_normals);
 void launch_pull_scan(hipStream_t st, const double* scan_src, double* scan_dst, uint32_t scan_doubles);
 // Full sort of the particles by the ordering key -> sort->perm.  frame == nullptr: bounding-box pass + device-resident frame.

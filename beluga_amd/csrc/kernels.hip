@@ -210,11 +210,21 @@ __device__ __forceinline__ double4 propagation_normals(uint64_t seed, uint32_t s
   box_muller_fast(rng_uniform53(b.w[0], b.w[1]), rng_uniform53(b.w[2], b.w[3]), z2, z3);
   return double4{z0, z1, z2, z3};
 }
+// normals_ahead: the first three normals of every particle, drawn by k_noise_ahead behind the previous cycle - three arrays of `stride` doubles
+// (the fourth is used by no motion model) -; the same expressions: the same bits
 __device__ __forceinline__ Pose2 propagate_one(const Pose2& state, const DiffDriveSampler& smp, uint64_t seed, uint32_t step, uint64_t index,
-                                               const double4* __restrict__ normals_ahead = nullptr, uint64_t local = 0) {
-  // normals_ahead: drawn by k_noise_ahead behind the previous cycle (the same expressions: the same bits)
-  const double4 z = normals_ahead ? normals_ahead[local] : propagation_normals(seed, step, index);
-  const double z0 = z.x, z1 = z.y, z2 = z.z;
+                                               const double* __restrict__ normals_ahead = nullptr, uint64_t local = 0, uint64_t stride = 0) {
+  double z0, z1, z2;
+  if (normals_ahead) {  // (uniform)
+    z0 = normals_ahead[local];
+    z1 = normals_ahead[stride + local];
+    z2 = normals_ahead[2 * stride + local];
+  } else {
+    const double4 z = propagation_normals(seed, step, index);
+    z0 = z.x;
+    z1 = z.y;
+    z2 = z.z;
+  }
   if (smp.kind == 1) {
     // omnidirectional_drive_model.hpp:133-144 — draws in source order: rotation, translation, strafe
     const Rot2 first{smp.first_c, smp.first_s};
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(kPropBlock) void k_propagate(Particles p, uint64_t 
                                                       uint64_t index_offset, const double* __restrict__ scan_src,
                                                       double* __restrict__ scan_dst, uint32_t scan_doubles, KeyFrame kf,
                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ table, uint32_t nblocks,
-                                                      const double4* __restrict__ normals_ahead) {
+                                                      const double* __restrict__ normals_ahead, uint64_t normals_stride) {
   __shared__ uint32_t hist[kKeys ? kSortDigits : 1];
   if (kKeys) {
     for (uint32_t d = threadIdx.x; d < kSortDigits; d += kPropBlock) hist[d] = 0;
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(kPropBlock) void k_propagate(Particles p, uint64_t 
   for (int k = 0; k < kChunk / kPropBlock; ++k) {
     const uint64_t i = base + static_cast<uint64_t>(k) * kPropBlock + threadIdx.x;
     if (i >= n) break;
-    const Pose2 out = propagate_one(load_pose(p, i), smp, seed, step, index_offset + i, normals_ahead, i);
+    const Pose2 out = propagate_one(load_pose(p, i), smp, seed, step, index_offset + i, normals_ahead, i, normals_stride);
     store_pose(p, i, out);
     if (kKeys) {
       const uint32_t key = order_key(double4{out.r.c, out.r.s, out.x, out.y}, kf);
@@ -285,9 +295,13 @@ __global__ __launch_bounds__(kPropBlock) void k_propagate(Particles p, uint64_t 
 // returns the estimate and comes back with the next control action - the 20 us the device used to idle between two cycles -, and the next
 // k_propagate finds 60 % of its instructions (two Philox draws, two logarithms, square roots and sine / cosine pairs per particle) done.
 // Same expressions as k_propagate's own: the same bits.
-__global__ __launch_bounds__(kBlock) void k_noise_ahead(uint64_t seed, uint32_t step, uint64_t index_offset, uint64_t n, double4* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_noise_ahead(uint64_t seed, uint32_t step, uint64_t index_offset, uint64_t n, double* __restrict__ out) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i < n) out[i] = propagation_normals(seed, step, index_offset + i);
+  if (i >= n) return;
+  const double4 z = propagation_normals(seed, step, index_offset + i);
+  out[i] = z.x;
+  out[n + i] = z.y;
+  out[2 * n + i] = z.z;
 }
 
 // [lf-kernels-begin] (the HBM-traffic record of the LF kernel, profiles/lf_kernel_traffic.json, is keyed by the SHA-256 of
@@ -3767,7 +3781,7 @@ __global__ __launch_bounds__(kBlock) void k_fill(double* p, uint64_t n, double v
 // =====================================================================================================
 void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler smp, uint64_t seed, uint32_t step,
                       uint64_t index_offset, const double* scan_src, double* scan_dst, uint32_t scan_doubles, const SortScratch* sort,
-                      const KeyFrame* frame, const double* normals_ahead) {
+                      const KeyFrame* frame, const double* normals_ahead, uint64_t normals_stride) {
   if (n == 0) {
     if (scan_dst && scan_doubles) launch_pull_scan(st, scan_src, scan_dst, scan_doubles);
     return;
@@ -3780,16 +3794,16 @@ void launch_propagate(hipStream_t st, Particles p, uint64_t n, DiffDriveSampler 
   }
   if (sort && frame && n < (1ull << 32))
     hipLaunchKernelGGL(k_propagate<true>, dim3(nblocks), dim3(kPropBlock), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
-                       scan_doubles, *frame, sort->keys, sort->table, nblocks, reinterpret_cast<const double4*>(normals_ahead));
+                       scan_doubles, *frame, sort->keys, sort->table, nblocks, normals_ahead, normals_stride);
   else
     hipLaunchKernelGGL(k_propagate<false>, dim3(nblocks), dim3(kPropBlock), 0, st, p, n, smp, seed, step, index_offset, scan_src, scan_dst,
-                       scan_doubles, KeyFrame{}, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), nblocks,
-                       reinterpret_cast<const double4*>(normals_ahead));
+                       scan_doubles, KeyFrame{}, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), nblocks, normals_ahead,
+                       normals_stride);
 }
 
 void launch_noise_ahead(hipStream_t st, uint64_t seed, uint32_t step, uint64_t index_offset, uint64_t n, double* d_normals) {
   if (n == 0) return;
-  hipLaunchKernelGGL(k_noise_ahead, dim3(blocks_for(n)), dim3(kBlock), 0, st, seed, step, index_offset, n, reinterpret_cast<double4*>(d_normals));
+  hipLaunchKernelGGL(k_noise_ahead, dim3(blocks_for(n)), dim3(kBlock), 0, st, seed, step, index_offset, n, d_normals);
 }
 
 void launch_pull_scan(hipStream_t st, const double* scan_src, double* scan_dst, uint32_t scan_doubles) {

@@ -61,6 +61,6 @@ python tools/exp_lf_converge.py 2>/dev/null > $O/lf_converge.txt
 timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench.err > $O/bench_1M.json
 python tools/exp_small.py 2>/dev/null > $O/small_filters.txt
 python tools/exp_cluster.py 2>/dev/null > $O/cluster_estimate.txt
-python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/pytest_gpu.log
+python -m pytest tests -m gpu -q 2>&1 | grep -a "passed\|failed\|error" | tail -3 > $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
 ls -la $O
