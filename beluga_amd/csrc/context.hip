@@ -1076,16 +1076,22 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
         done.seq = ++ctx->done_seq;
       }
       // (behind the draw and its sums - the completion word is theirs -: the next cycle's propagation normals, while the host is away)
-      const bool noise_ahead = ctx->done_armed && ctx->tuning.noise_ahead != 0 && max_p > 65536 && max_p <= 2000000 &&
+      // noise_ahead 1: inside the draw kernel (its vector units wait for the fabric); 2: a kernel of its own behind the cycle's last one
+      // (both up to 2M particles: at 10M the draw sits at 0.85 of the HBM peak and the normals' stores cost it more than k_propagate saves -
+      // 214.4 against 215.8 cycles/s measured)
+      const bool noise_in_draw = ctx->tuning.noise_ahead == 1 && max_p > 65536 && max_p <= 2000000 &&
+                                 ctx->d_noise.ensure(3 * static_cast<size_t>(max_p)) == hipSuccess;
+      const bool noise_ahead = ctx->done_armed && ctx->tuning.noise_ahead == 2 && max_p > 65536 && max_p <= 2000000 &&
                                ctx->d_noise.ensure(3 * static_cast<size_t>(max_p)) == hipSuccess;
       launch_resample_draw_and_estimate(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp,
                                         ctx->pivot[0], ctx->pivot[1], ctx->d_est_partials.ptr, ctx->d_scalars.ptr + 8,
                                         ctx->hd_scalars + 8, ctx->done_armed ? &done : nullptr,
                                         ((ctx->tuning.draw_fold == 2 || (ctx->tuning.draw_fold == 1 && max_p <= 65536)) && ctx->d_scan_state.ptr)
                                             ? reinterpret_cast<unsigned int*>(ctx->d_scan_state.ptr + 4)
-                                            : nullptr);
-      if (noise_ahead) {
-        launch_noise_ahead(ctx->stream, ctx->cfg.seed, step + 1, ctx->cfg.shard_offset, max_p, ctx->d_noise.ptr);
+                                            : nullptr,
+                                        noise_in_draw ? ctx->d_noise.ptr : nullptr, max_p, ctx->cfg.shard_offset, step + 1);
+      if (noise_ahead) launch_noise_ahead(ctx->stream, ctx->cfg.seed, step + 1, ctx->cfg.shard_offset, max_p, ctx->d_noise.ptr);
+      if (noise_ahead || noise_in_draw) {
         ctx->noise_step = step + 1;
         ctx->noise_n = max_p;
         ctx->noise_offset = ctx->cfg.shard_offset;
@@ -3325,7 +3331,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "lf_unit_weights") t.lf_unit_weights = value ? 1 : 0;
   else if (key == "small_fused") t.small_fused = value ? 1 : 0;
   else if (key == "norm_store") t.norm_store = value ? 1 : 0;
-  else if (key == "noise_ahead") t.noise_ahead = value ? 1 : 0;
+  else if (key == "noise_ahead") t.noise_ahead = static_cast<int>(std::clamp<int64_t>(value, 0, 2));
   else if (key == "lf_split") t.lf_split = static_cast<int>(value & 3);  // 1: side by side only, 2: stacked only, 3: both
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
   else if (key == "beam_sort_min_particles") t.beam_sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));

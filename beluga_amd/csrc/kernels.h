@@ -178,9 +178,11 @@ struct Tuning {
   int draw_fold = 1;                // the draw kernel's last workgroup to finish adds up the estimate sums (no k_final_rows launch behind it):
                                     // 1 = for sets of up to 64K particles, 2 = up to 4M (measured at 1M: 56.2 us against 49.2 + 4.4 - every
                                     // workgroup ends on the ticket's round trip), 0 = k_final_rows.  Bit-identical.
-  int noise_ahead = 1;              // fixed-size cycles that end on the completion word (cycle_spin), sets of 64K .. 2M particles: the next cycle's
-                                    // propagation normals are drawn behind the cycle's last kernel, while the host is away (k_noise_ahead);
-                                    // 0 = drawn by k_propagate itself.  Bit-identical.
+  int noise_ahead = 1;              // fixed-size cycles, sets of more than 64K particles: the next cycle's propagation normals are drawn a cycle AHEAD:
+                                    // 1 = by the draw kernel, whose vector units wait for the fabric (draw + 7.4 us, k_propagate - 12 at 1M); 2 = by a
+                                    // kernel of its own behind the cycle's last one, while the host is away (k_noise_ahead, 17 us: cycles that end
+                                    // on the completion word); both up to 2M particles (at 10M the draw is at the HBM's limit: measured a loss);
+                                    // 0 = by k_propagate itself.  Bit-identical.
   int norm_store = 0;               // fixed-size cycle that resamples at once: 0 = k_normalize leaves the chunk sums of the normalised weights
                                     // but does not store them - the CDF kernel divides again (same division, same bits), nothing else reads them;
                                     // 1 = stored
@@ -453,7 +455,8 @@ void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const doub
 void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst, ResampleArgs a,
                                        GridView g, FreeCells fc, HashParams hp, double pivot_x, double pivot_y, double* d_partials,
                                        double* d_sums, double* host_mirror, const Completion* done = nullptr,
-                                       unsigned int* fold_ticket = nullptr);
+                                       unsigned int* fold_ticket = nullptr, double* normals_ahead = nullptr, uint64_t normals_stride = 0,
+                                       uint64_t normals_index_offset = 0, uint32_t normals_step = 0);
 // Sharded variant: targets given, no RNG (mcl_gather_by_cdf).
 // Sharded resampling helpers (mcl_resample_targets / mcl_commit_resampled).
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,

@@ -2573,12 +2573,21 @@ struct DrawFold {
   double* host_mirror{nullptr};   // optional
   Completion done{};              // optional completion word (cycle_spin)
 };
+// The NEXT cycle's propagation normals of the particle an output slot becomes (k_noise_ahead's work, inside this kernel): the draw waits for
+// the fabric - random 128-byte lines of CDF groups and pose records - with its vector units a quarter busy, and the normals are pure arithmetic on
+// (seed, step + 1, global particle index).  normals == nullptr: not drawn here.
+struct DrawNormals {
+  double* normals{nullptr};  // three arrays of `stride` doubles
+  uint64_t stride{0};
+  uint64_t index_offset{0};  // global index of output slot 0's particle less a.out_offset (the shard's offset)
+  uint32_t step{0};          // the step they are for
+};
 template <bool kEstimate>
 __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
                                                               Particles dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
                                                               unsigned long long* __restrict__ hashes, double pivot_x, double pivot_y,
                                                               double* __restrict__ est_partials, uint32_t est_stride, int first_staged,
-                                                              uint32_t staged_doubles, DrawFold fold) {
+                                                              uint32_t staged_doubles, DrawFold fold, DrawNormals ahead) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* staged = reinterpret_cast<double*>(smem);
   __shared__ double scratch[kEstimate ? (kDrawBlock / 64) * 9 : 1];
@@ -2611,6 +2620,12 @@ __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     store_pose(dst, o, s);
     dst.w[o] = 1.0;  // particle_traits.hpp:105
     if (hashes) hashes[o] = spatial_hash(s, hp);
+    if (ahead.normals) {  // (uniform) behind the slot's own stores: nothing of the search is alive any more
+      const double4 z = propagation_normals(a.seed, ahead.step, ahead.index_offset + o);
+      ahead.normals[o] = z.x;
+      ahead.normals[ahead.stride + o] = z.y;
+      ahead.normals[2 * ahead.stride + o] = z.z;
+    }
     if (kEstimate) {
       const double dx = s.x - pivot_x, dy = s.y - pivot_y;
       v[0] = 1.0;
@@ -4073,13 +4088,14 @@ void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const doub
   draw_staging(cdf, first, doubles);
   const unsigned blocks = static_cast<unsigned>((a.count + kDrawBlock - 1) / kDrawBlock);
   hipLaunchKernelGGL(k_resample_draw<false>, dim3(blocks), dim3(kDrawBlock), doubles * sizeof(double), st, src, cdf, d_total, dst, a, g,
-                     fc, hp, d_hashes, 0.0, 0.0, static_cast<double*>(nullptr), 0u, first, doubles, DrawFold{});
+                     fc, hp, d_hashes, 0.0, 0.0, static_cast<double*>(nullptr), 0u, first, doubles, DrawFold{}, DrawNormals{});
 }
 
 // The draw plus the estimate sums of the set it produces: d_partials needs 9 * ceil(count / 1024) doubles.
 void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst, ResampleArgs a,
                                        GridView g, FreeCells fc, HashParams hp, double pivot_x, double pivot_y, double* d_partials,
-                                       double* d_sums, double* host_mirror, const Completion* done, unsigned int* fold_ticket) {
+                                       double* d_sums, double* host_mirror, const Completion* done, unsigned int* fold_ticket,
+                                       double* normals_ahead, uint64_t normals_stride, uint64_t normals_index_offset, uint32_t normals_step) {
   int first;
   uint32_t doubles;
   draw_staging(cdf, first, doubles);
@@ -4091,7 +4107,8 @@ void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cd
     DrawFold f{};
     if (fold) f = DrawFold{fold_ticket, d_sums, host_mirror, done ? *done : Completion{}};
     hipLaunchKernelGGL(k_resample_draw<true>, dim3(blocks), dim3(kDrawBlock), doubles * sizeof(double), st, src, cdf, d_total, dst, a, g,
-                       fc, hp, static_cast<unsigned long long*>(nullptr), pivot_x, pivot_y, d_partials, blocks, first, doubles, f);
+                       fc, hp, static_cast<unsigned long long*>(nullptr), pivot_x, pivot_y, d_partials, blocks, first, doubles, f,
+                       DrawNormals{normals_ahead, normals_stride, normals_index_offset, normals_step});
   }
   if (!fold)
     hipLaunchKernelGGL(k_final_rows, dim3(9), dim3(kBlock), 0, st, d_partials, blocks, blocks, d_sums, host_mirror, done ? *done : Completion{});

@@ -458,9 +458,10 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *   lf_unit_weights (1)  LDS-patch kernel on a set whose weights are all 1.0 - fresh from a resampling or an initialisation
  *                   (particle_traits.hpp:105), which the library keeps track of -: the old weight is not loaded (1.0 x = x); 0 = always
  *                   loaded.  Bit-identical; 9 us of a 1M-particle cycle.
- *   noise_ahead (1)  fixed-size cycles that end on the completion word (cycle_spin), sets of 64K .. 2M particles: the NEXT cycle's propagation
- *                   normals - a function of (seed, step, particle index) alone - are drawn behind the cycle's last kernel, while the host is away;
- *                   0 = drawn by the propagation kernel itself.  Bit-identical; counter noise_ahead_used.
+ *   noise_ahead (1)  fixed-size cycles, sets of 64K .. 2M particles: the NEXT cycle's propagation normals - a function of (seed, step, particle
+ *                   index) alone - are drawn a cycle ahead: 1 = by the draw kernel (whose vector units wait for memory), 2 = by a kernel of its
+ *                   own behind the cycle's last one, while the host is away (cycles that end on the completion word); 0 = by the propagation
+ *                   kernel itself.  Bit-identical; counter noise_ahead_used.
  *   norm_store (0)  fixed-size cycle that resamples at once: 0 = the normalisation kernel does not store the normalised weights (nothing reads
  *                   them), the CDF kernel divides again; 1 = stored.  Bit-identical.
  *   small_fused (1)  sets of up to 4096 particles: everything behind the reweight - normalise, policies, fixed-size or KLD resampling, estimate

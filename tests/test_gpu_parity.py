@@ -1431,8 +1431,9 @@ def test_small_sets_one_launch_tail_matches_the_kernels_of_the_large_path(lo, hi
 @pytest.mark.parametrize("n", [1_000_000, 300_001])
 def test_propagation_normals_drawn_ahead_change_nothing(n):
     """The propagation's standard normals depend on (seed, step, particle index) alone - differential_drive_model.hpp:156-163 scales them by
-    the control action afterwards -, so a fixed-size cycle that ends on the completion word draws the NEXT cycle's behind its last kernel,
-    while the host is away (k_noise_ahead, option noise_ahead), and k_propagate reads them.  Same expressions, same bits: whole cycles with
+    the control action afterwards -, so a fixed-size cycle draws the NEXT cycle's a cycle ahead - inside the draw kernel, whose vector units
+    wait for the fabric (option noise_ahead = 1), or by a kernel of its own behind the cycle's last one while the host is away
+    (k_noise_ahead, 2) -, and k_propagate reads them.  Same expressions, same bits: whole cycles with
     and without are identical, and the counter says the normals drawn ahead were used from the second cycle on - also across a cycle in
     which the robot does not move (no update: the normals wait for the step they belong to)."""
     import bench
@@ -1440,7 +1441,7 @@ def test_propagation_normals_drawn_ahead_change_nothing(n):
     cells, truth, odoms, scans, _poses = bench.make_workload(cycles)
     grid = OccupancyGrid(cells, bench.RESOLUTION, origin=se2_from_xytheta(bench.ORIGIN[0], bench.ORIGIN[1], 0.0))
     outs = []
-    for ahead in (1, 0):
+    for ahead in (1, 0, 2):  # by the draw kernel (the default) / by k_propagate itself / by k_noise_ahead behind the cycle's last kernel
         f = Amcl(grid, DifferentialDriveModelParam(*bench.ALPHAS), LikelihoodFieldModelParam(**bench.LF),
                  AmclParams(min_particles=n, max_particles=n), seed=42)
         f.set_option("noise_ahead", ahead)
@@ -1454,8 +1455,9 @@ def test_propagation_normals_drawn_ahead_change_nothing(n):
         assert f.counter("noise_ahead_used") == (cycles - 1 if ahead else 0)
         outs.append((np.asarray(est), f.particles()))
         f.close()
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert np.array_equal(outs[0][1][0], outs[1][1][0]) and np.array_equal(outs[0][1][1], outs[1][1][1])
+    for other in outs[1:]:
+        assert np.array_equal(outs[0][0], other[0])
+        assert np.array_equal(outs[0][1][0], other[1][0]) and np.array_equal(outs[0][1][1], other[1][1])
 
 
 def test_map_built_ahead_on_a_worker_thread_swaps_in_between_two_updates():
