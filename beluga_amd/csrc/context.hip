@@ -257,6 +257,16 @@ struct mcl_ctx {
   DeviceBuffer<double> d_noise;
   uint32_t noise_step{0};
   uint64_t noise_n{0}, noise_offset{0}, noise_seed{0};
+  // launch_order_ahead: the spatial order (sort_scratch().perm) of the particles as the propagation of step `order_step` will leave them, if the
+  // control action of that step is the predicted one (order_sampler); the frame it was computed in
+  bool order_valid{false};
+  uint32_t order_step{0};
+  uint64_t order_n{0};
+  DiffDriveSampler order_sampler{};
+  uint32_t order_layout{0};
+  bool order_ready{false};      // this cycle's propagation found it usable: do_reweight skips the ordering passes
+  uint64_t order_ahead_used{0}, order_ahead_missed{0};
+  DiffDriveSampler last_sampler{};  // of the last propagation (the prediction for the next one)
   bool cdf_divides{false};          // the last normalisation left the weights undivided: the CDF kernel right behind it divides (do_normalize)
   bool weights_unit{false};         // every weight of the live set is exactly 1.0: set by what writes them all (initialisation, resampling,
                                     // particle_traits.hpp:105), cleared by whatever else touches a weight
@@ -685,12 +695,20 @@ uint32_t key_layout(const mcl_ctx* ctx) {
               : 0u) |
          curve;
 }
-bool predict_key_frame(const mcl_ctx* ctx, const DiffDriveSampler* motion, KeyFrame* out) {
+// moves: how often the set's centre is moved by `motion` (2: the frame of the cycle AFTER the one that is running - launch_order_ahead -, whose
+// set is the remembered one moved twice; its spread grows once: the resampling in between takes it back to where it was).
+bool predict_key_frame(const mcl_ctx* ctx, const DiffDriveSampler* motion, KeyFrame* out, int moves = 1) {
   out->layout = key_layout(ctx);
   if (!ctx->have_cloud_estimate) return false;
   double x = ctx->cloud_mean[0], y = ctx->cloud_mean[1], t = ctx->cloud_mean[2];
   double sx = ctx->cloud_sigma[0], sy = ctx->cloud_sigma[1], st = ctx->cloud_sigma[2];
   if (motion && motion->kind != MCL_MOTION_STATIONARY) {
+    for (int move = 1; move < moves; ++move) {  // (the centre alone)
+      const double heading = t + (motion->kind == MCL_MOTION_DIFFERENTIAL ? motion->m1 : std::atan2(motion->first_s, motion->first_c));
+      x += motion->mt * std::exp(-0.5 * st * st) * std::cos(heading);
+      y += motion->mt * std::exp(-0.5 * st * st) * std::sin(heading);
+      t += motion->kind == MCL_MOTION_DIFFERENTIAL ? motion->m1 + motion->m2 : motion->m1;
+    }
     const double heading = t + (motion->kind == MCL_MOTION_DIFFERENTIAL ? motion->m1 : std::atan2(motion->first_s, motion->first_c));
     // every pose moves along ITS heading: the set's mean moves by the translation times the mean resultant length of the headings
     // (next to nothing for a set that points everywhere), and a heading error turns into a lateral one over the translation -
@@ -836,6 +854,24 @@ bool wants_ordering(const mcl_ctx* ctx) {
   return ctx->tuning.lf_variant == kLfSortedLanes && !(lf_set_is_small(ctx) && ctx->pal_count != 0 && ctx->tuning.lf_table == 0);
 }
 
+// Is the control action that came close enough to the one the order was predicted with (launch_order_ahead)?  What matters is that the
+// particles end up in the same ARRANGEMENT: a common shift does not change it, different noise scales or a translation along another
+// heading do.  Generous bounds: a miss costs look-ups that fit no LDS patch, a fallback costs the ordering passes on the critical path.
+bool samplers_close(const DiffDriveSampler& now, const DiffDriveSampler& predicted) {
+  if (now.kind != predicted.kind) return false;
+  auto ratio_ok = [](double a, double b) { return a <= 1.5 * b + 1e-3 && b <= 1.5 * a + 1e-3; };
+  if (!ratio_ok(now.s1, predicted.s1) || !ratio_ok(now.st, predicted.st) || !ratio_ok(now.s2, predicted.s2)) return false;
+  if (std::abs(now.mt - predicted.mt) > 0.3 * std::max(std::abs(predicted.mt), 0.02)) return false;
+  const double turn_now = now.kind == MCL_MOTION_DIFFERENTIAL ? now.m1 + now.m2 : now.m1;
+  const double turn_predicted = predicted.kind == MCL_MOTION_DIFFERENTIAL ? predicted.m1 + predicted.m2 : predicted.m1;
+  if (std::abs(turn_now - turn_predicted) > 0.15) return false;
+  // the direction of the translation in the robot's frame (differential: the first rotation; omnidirectional: `first`)
+  const double heading_now = now.kind == MCL_MOTION_DIFFERENTIAL ? now.m1 : std::atan2(now.first_s, now.first_c);
+  const double heading_predicted = predicted.kind == MCL_MOTION_DIFFERENTIAL ? predicted.m1 : std::atan2(predicted.first_s, predicted.first_c);
+  const double apart = std::abs(std::remainder(heading_now - heading_predicted, 2.0 * kPi));
+  return apart * std::max(std::abs(now.mt), std::abs(predicted.mt)) <= 0.05;  // (metres of lateral disagreement)
+}
+
 // fused (mcl_update): the scan staged by stage_points is pulled by the same kernel, and the ordering keys of the new poses
 // come out of it when the host knows where the set is (*keys_emitted).
 mcl_status do_propagate(mcl_ctx* ctx, const Pose2& pose, const Pose2& prev, uint32_t step, uint64_t scan_points = 0,
@@ -845,7 +881,19 @@ mcl_status do_propagate(mcl_ctx* ctx, const Pose2& pose, const Pose2& prev, uint
   KeyFrame frame{};
   const SortScratch sort = ctx->sort_scratch();
   if (keys_emitted) decide_lf_mode(ctx);  // the fused cycle: the reweight follows, and the keys depend on its kernel
-  const bool keys = keys_emitted && wants_ordering(ctx) && predict_key_frame(ctx, &sampler, &frame);
+  // The order the previous cycle computed AHEAD for this step (launch_order_ahead) serves if the control action it predicted is close to the
+  // one that came: then no keys, no ordering passes - the reweight follows the propagation at once.  Only locality depends on it.
+  ctx->order_ready = false;
+  bool use_ahead = false;
+  if (keys_emitted && ctx->order_valid) {
+    ctx->order_valid = false;
+    use_ahead = ctx->tuning.order_ahead != 0 && ctx->order_step == step && ctx->order_n == ctx->n && wants_ordering(ctx) &&
+                ctx->order_layout == key_layout(ctx) && samplers_close(sampler, ctx->order_sampler);
+    if (use_ahead) ctx->order_ahead_used += 1;
+    else ctx->order_ahead_missed += 1;
+  }
+  ctx->last_sampler = sampler;
+  const bool keys = !use_ahead && keys_emitted && wants_ordering(ctx) && predict_key_frame(ctx, &sampler, &frame);
   // (the normals of this step, if the previous cycle left them: k_noise_ahead)
   const bool ahead = ctx->d_noise.ptr && ctx->noise_n >= ctx->n && ctx->n > 65536 && ctx->noise_step == step && ctx->noise_seed == ctx->cfg.seed &&
                      ctx->noise_offset == ctx->cfg.shard_offset;
@@ -855,6 +903,7 @@ mcl_status do_propagate(mcl_ctx* ctx, const Pose2& pose, const Pose2& prev, uint
   if (ahead) ctx->noise_ahead_used += 1;
   if (scan_points) points_pulled(ctx, false);
   if (keys_emitted) *keys_emitted = keys;
+  ctx->order_ready = use_ahead;
   stage_end(ctx, MCL_STAGE_PROPAGATE);
   MCL_HIP(ctx, hipGetLastError());
   return MCL_OK;
@@ -892,7 +941,9 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
   ctx->lf_mode.decided = false;  // the next cycle decides again
   const SortScratch sort = ctx->sort_scratch();
   const bool ordered = wants_ordering(ctx) && !mode.beams;
-  if (ordered) {
+  const bool order_ready = ctx->order_ready;  // (launch_order_ahead's, accepted by this cycle's propagation)
+  ctx->order_ready = false;
+  if (ordered && !order_ready) {
     KeyFrame frame{};
     // The ordering also serves the beam model: both kernels gather the pose records through sort.perm.
     const bool have_frame = !keys_ready && predict_key_frame(ctx, nullptr, &frame);
@@ -1083,19 +1134,35 @@ mcl_status do_resample(mcl_ctx* ctx, double random_state_probability, uint32_t s
                                  ctx->d_noise.ensure(3 * static_cast<size_t>(max_p)) == hipSuccess;
       const bool noise_ahead = ctx->done_armed && ctx->tuning.noise_ahead == 2 && max_p > 65536 && max_p <= 2000000 &&
                                ctx->d_noise.ensure(3 * static_cast<size_t>(max_p)) == hipSuccess;
+      // Option order_ahead (cycles that end on the completion word): the draw kernel also leaves the ordering keys of where its particles will be
+      // after the NEXT propagation - through the predicted control action (this cycle's) and the frame of that set as the host predicts it
+      // from the last estimate it has, moved twice -, and the ordering passes run behind the cycle's last kernel, while the host is away.
+      KeyFrame ahead_frame{};
+      const bool order_keys = noise_in_draw && ctx->done_armed && ctx->tuning.order_ahead != 0 && max_p < (1ull << 32) && wants_ordering(ctx) &&
+                              predict_key_frame(ctx, &ctx->last_sampler, &ahead_frame, 2);
       launch_resample_draw_and_estimate(ctx->stream, ctx->cur(), ctx->cdf_tree(), ctx->d_scalars.ptr + 4, ctx->other(), ra, gv, fc, hp,
                                         ctx->pivot[0], ctx->pivot[1], ctx->d_est_partials.ptr, ctx->d_scalars.ptr + 8,
                                         ctx->hd_scalars + 8, ctx->done_armed ? &done : nullptr,
                                         ((ctx->tuning.draw_fold == 2 || (ctx->tuning.draw_fold == 1 && max_p <= 65536)) && ctx->d_scan_state.ptr)
                                             ? reinterpret_cast<unsigned int*>(ctx->d_scan_state.ptr + 4)
                                             : nullptr,
-                                        noise_in_draw ? ctx->d_noise.ptr : nullptr, max_p, ctx->cfg.shard_offset, step + 1);
+                                        noise_in_draw ? ctx->d_noise.ptr : nullptr, max_p, ctx->cfg.shard_offset, step + 1,
+                                        order_keys ? ctx->sort_scratch().keys : nullptr, &ctx->last_sampler, &ahead_frame);
       if (noise_ahead) launch_noise_ahead(ctx->stream, ctx->cfg.seed, step + 1, ctx->cfg.shard_offset, max_p, ctx->d_noise.ptr);
       if (noise_ahead || noise_in_draw) {
         ctx->noise_step = step + 1;
         ctx->noise_n = max_p;
         ctx->noise_offset = ctx->cfg.shard_offset;
         ctx->noise_seed = ctx->cfg.seed;
+      }
+      if (order_keys) {
+        const SortScratch sort = ctx->sort_scratch();
+        launch_order_ahead(ctx->stream, max_p, &sort);
+        ctx->order_valid = true;
+        ctx->order_step = step + 1;
+        ctx->order_n = max_p;
+        ctx->order_sampler = ctx->last_sampler;
+        ctx->order_layout = key_layout(ctx);
       }
       if (estimate_enqueued) *estimate_enqueued = true;
     } else {
@@ -2191,7 +2258,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     }
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin", "scan_fused", "draw_fold", "lf_unit_weights", "small_fused", "norm_store", "noise_ahead"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin", "scan_fused", "draw_fold", "lf_unit_weights", "small_fused", "norm_store", "noise_ahead", "order_ahead"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2461,6 +2528,7 @@ mcl_status mcl_set_likelihood_field(mcl_ctx* ctx, const float* field) {
 mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], const double cov[9]) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
   ctx->lf_wsum_count = 0;  // (workgroup sums of an earlier reweight describe another set)
+  ctx->order_valid = false;  // (and an order computed ahead describes the particles of another one)
   MCL_REQUIRE(ctx, mean_xytheta && cov, "null argument");
   double T[9];
   if (!covariance_to_transform(cov, T)) return fail(ctx, MCL_ERR_BAD_COVARIANCE, "Invalid covariance matrix");
@@ -2488,6 +2556,7 @@ mcl_status mcl_initialize_normal(mcl_ctx* ctx, const double mean_xytheta[3], con
 mcl_status mcl_set_particles(mcl_ctx* ctx, const double* states, const double* weights, uint64_t n) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
   ctx->lf_wsum_count = 0;  // (workgroup sums of an earlier reweight describe another set)
+  ctx->order_valid = false;  // (and an order computed ahead describes the particles of another one)
   MCL_REQUIRE(ctx, n == 0 || (states && weights), "null argument");
   MCL_REQUIRE(ctx, n <= ctx->capacity, "mcl_set_particles: n exceeds capacity");
   if (const mcl_status s = bind_device(ctx)) return s;
@@ -3010,6 +3079,7 @@ mcl_status mcl_get_device_view(mcl_ctx* ctx, mcl_device_view* view) {
 mcl_status mcl_set_num_particles(mcl_ctx* ctx, uint64_t n) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
   ctx->lf_wsum_count = 0;  // (workgroup sums of an earlier reweight describe another set)
+  ctx->order_valid = false;  // (and an order computed ahead describes the particles of another one)
   MCL_REQUIRE(ctx, n <= ctx->capacity, "n exceeds capacity");
   if (n > ctx->n) ctx->weights_unit = false;  // (what lies beyond the set is whatever was there)
   ctx->n = n;
@@ -3130,6 +3200,7 @@ mcl_status mcl_kld_feed(mcl_ctx* ctx, const uint64_t* d_hashes, uint64_t count, 
 mcl_status mcl_load_shard(mcl_ctx* ctx, const double* d_states, uint64_t n, uint64_t shard_offset) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
   ctx->lf_wsum_count = 0;
+  ctx->order_valid = false;
   MCL_REQUIRE(ctx, n <= ctx->capacity, "n exceeds shard capacity");
   MCL_REQUIRE(ctx, n == 0 || d_states, "null states");
   if (const mcl_status s = bind_device(ctx)) return s;
@@ -3188,6 +3259,7 @@ mcl_status mcl_estimate_sums_device(mcl_ctx* ctx, const double pivot_xy[2], doub
 mcl_status mcl_initialize_from_map(mcl_ctx* ctx) {
   if (!ctx) return MCL_ERR_INVALID_ARGUMENT;
   ctx->lf_wsum_count = 0;  // (workgroup sums of an earlier reweight describe another set)
+  ctx->order_valid = false;  // (and an order computed ahead describes the particles of another one)
   if (!ctx->have_map) return fail(ctx, MCL_ERR_NOT_READY, "mcl_initialize_from_map: no map set");
   MCL_REQUIRE(ctx, ctx->n_free > 0, "mcl_initialize_from_map: the map has no free cell");  // the reference asserts (:136)
   if (const mcl_status s = bind_device(ctx)) return s;
@@ -3331,6 +3403,7 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   else if (key == "lf_unit_weights") t.lf_unit_weights = value ? 1 : 0;
   else if (key == "small_fused") t.small_fused = value ? 1 : 0;
   else if (key == "norm_store") t.norm_store = value ? 1 : 0;
+  else if (key == "order_ahead") t.order_ahead = value ? 1 : 0;
   else if (key == "noise_ahead") t.noise_ahead = static_cast<int>(std::clamp<int64_t>(value, 0, 2));
   else if (key == "lf_split") t.lf_split = static_cast<int>(value & 3);  // 1: side by side only, 2: stacked only, 3: both
   else if (key == "sort_min_particles") t.sort_min_particles = static_cast<int>(std::clamp<int64_t>(value, 0, 1ll << 30));
@@ -3349,6 +3422,8 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
   else if (key == "lf_far_launches") *value = ctx->lf_far_launches;
   else if (key == "lf_far_tiles") *value = ctx->far_tiles;
   else if (key == "noise_ahead_used") *value = ctx->noise_ahead_used;
+  else if (key == "order_ahead_used") *value = ctx->order_ahead_used;
+  else if (key == "order_ahead_missed") *value = ctx->order_ahead_missed;
   else if (key == "lf_patch_groups_planned" || key == "lf_patch_groups_through") {
     if (const mcl_status s = bind_device(ctx)) return s;
     MCL_HIP(ctx, hipStreamSynchronize(ctx->stream));

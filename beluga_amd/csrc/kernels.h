@@ -183,6 +183,9 @@ struct Tuning {
                                     // kernel of its own behind the cycle's last one, while the host is away (k_noise_ahead, 17 us: cycles that end
                                     // on the completion word); both up to 2M particles (at 10M the draw is at the HBM's limit: measured a loss);
                                     // 0 = by k_propagate itself.  Bit-identical.
+  int order_ahead = 1;              // with noise_ahead = 1: the NEXT cycle's spatial order is computed behind a cycle's last kernel, while the host is
+                                    // away, from the predicted control action (the one of the cycle that ends); the next cycle uses it if the action it
+                                    // gets is close to the prediction, else it orders by the real poses as before.  Only locality depends on the order.
   int norm_store = 0;               // fixed-size cycle that resamples at once: 0 = k_normalize leaves the chunk sums of the normalised weights
                                     // but does not store them - the CDF kernel divides again (same division, same bits), nothing else reads them;
                                     // 1 = stored
@@ -295,6 +298,9 @@ void launch_pull_scan(hipStream_t st, const double* scan_src, double* scan_dst, 
 // layout: KeyFrame::layout of the device-resident frame (a host frame carries its own).
 void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortScratch* sort, const KeyFrame* frame, bool keys_ready,
                             uint32_t layout = 0);
+// The same order a cycle AHEAD: sort->keys hold the keys the draw kernel predicted for the next cycle (launch_resample_draw_and_estimate,
+// keys_ahead) - their block histograms and the three ordering kernels -> sort->perm.
+void launch_order_ahead(hipStream_t st, uint64_t n, const SortScratch* sort);
 // K2  actions/reweight.hpp:53-60 + likelihood_field_model.hpp:68-91 (kLfSortedLanes needs launch_order_particles first)
 // scan_is_short: every scan point lies within 8192 cells of the sensor (precondition of the kernel's FMA variant)
 // use_patches: the LDS-patch kernel where its preconditions hold (dense sets); patch_stats: running totals it reports
@@ -456,7 +462,8 @@ void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cd
                                        GridView g, FreeCells fc, HashParams hp, double pivot_x, double pivot_y, double* d_partials,
                                        double* d_sums, double* host_mirror, const Completion* done = nullptr,
                                        unsigned int* fold_ticket = nullptr, double* normals_ahead = nullptr, uint64_t normals_stride = 0,
-                                       uint64_t normals_index_offset = 0, uint32_t normals_step = 0);
+                                       uint64_t normals_index_offset = 0, uint32_t normals_step = 0, uint32_t* keys_ahead = nullptr,
+                                       const DiffDriveSampler* predicted = nullptr, const KeyFrame* frame_ahead = nullptr);
 // Sharded variant: targets given, no RNG (mcl_gather_by_cdf).
 // Sharded resampling helpers (mcl_resample_targets / mcl_commit_resampled).
 void launch_resample_targets(hipStream_t st, uint64_t seed, uint32_t step, double p, double total, uint64_t first_slot,

@@ -210,21 +210,8 @@ __device__ __forceinline__ double4 propagation_normals(uint64_t seed, uint32_t s
   box_muller_fast(rng_uniform53(b.w[0], b.w[1]), rng_uniform53(b.w[2], b.w[3]), z2, z3);
   return double4{z0, z1, z2, z3};
 }
-// normals_ahead: the first three normals of every particle, drawn by k_noise_ahead behind the previous cycle - three arrays of `stride` doubles
-// (the fourth is used by no motion model) -; the same expressions: the same bits
-__device__ __forceinline__ Pose2 propagate_one(const Pose2& state, const DiffDriveSampler& smp, uint64_t seed, uint32_t step, uint64_t index,
-                                               const double* __restrict__ normals_ahead = nullptr, uint64_t local = 0, uint64_t stride = 0) {
-  double z0, z1, z2;
-  if (normals_ahead) {  // (uniform)
-    z0 = normals_ahead[local];
-    z1 = normals_ahead[stride + local];
-    z2 = normals_ahead[2 * stride + local];
-  } else {
-    const double4 z = propagation_normals(seed, step, index);
-    z0 = z.x;
-    z1 = z.y;
-    z2 = z.z;
-  }
+// One particle through the motion model, given its three standard normals (the body of actions::propagate for the three models).
+__device__ __forceinline__ Pose2 propagate_with_normals(const Pose2& state, const DiffDriveSampler& smp, double z0, double z1, double z2) {
   if (smp.kind == 1) {
     // omnidirectional_drive_model.hpp:133-144 — draws in source order: rotation, translation, strafe
     const Rot2 first{smp.first_c, smp.first_s};
@@ -242,6 +229,24 @@ __device__ __forceinline__ Pose2 propagate_one(const Pose2& state, const DiffDri
   const double t = z1 * smp.st + smp.mt;
   const double r2 = z2 * smp.s2 + smp.m2;
   return pose_mul_fast(pose_mul_fast(state, Pose2{rot_exp_fast(r1), 0.0, 0.0}), Pose2{rot_exp_fast(r2), t, 0.0});
+}
+
+// normals_ahead: the first three normals of every particle, drawn a cycle ahead (k_resample_draw / k_noise_ahead) - three arrays of `stride`
+// doubles (the fourth is used by no motion model) -; the same expressions: the same bits
+__device__ __forceinline__ Pose2 propagate_one(const Pose2& state, const DiffDriveSampler& smp, uint64_t seed, uint32_t step, uint64_t index,
+                                               const double* __restrict__ normals_ahead = nullptr, uint64_t local = 0, uint64_t stride = 0) {
+  double z0, z1, z2;
+  if (normals_ahead) {  // (uniform)
+    z0 = normals_ahead[local];
+    z1 = normals_ahead[stride + local];
+    z2 = normals_ahead[2 * stride + local];
+  } else {
+    const double4 z = propagation_normals(seed, step, index);
+    z0 = z.x;
+    z1 = z.y;
+    z2 = z.z;
+  }
+  return propagate_with_normals(state, smp, z0, z1, z2);
 }
 
 // Small sets (no ordering keys): one particle per lane, 256 per workgroup - 2000 particles are 8 workgroups on 8 CUs, a wave
@@ -1601,6 +1606,22 @@ __global__ __launch_bounds__(kWide) void k_order_keys(Particles p, uint64_t n, K
   for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
 }
 
+// The block histograms of keys that exist already (the ones the draw kernel predicted for the next cycle: DrawNormals::keys), for the ordering's
+// first pass: k_order_keys without the keys.
+__global__ __launch_bounds__(kWide) void k_key_hist(const uint32_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ table, uint32_t nblocks) {
+  __shared__ uint32_t hist[kSortDigits];
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) hist[d] = 0;
+  __syncthreads();
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kChunk;
+#pragma unroll
+  for (int k = 0; k < kChunk / kWide; ++k) {
+    const uint64_t i = base + k * kWide + threadIdx.x;
+    if (i < n) atomicAdd(&hist[keys[i] >> kDigitBits], 1u);
+  }
+  __syncthreads();
+  for (uint32_t d = threadIdx.x; d < kSortDigits; d += kWide) table[static_cast<size_t>(d) * nblocks + blockIdx.x] = hist[d];
+}
+
 // totals[d] = sum of row d of the [digit][block] table; one wave per digit.
 // Row d of the table (block histograms of digit d) becomes its exclusive scan; totals[d] = the row's sum.  The scatter
 // kernels add the sum of all smaller digits themselves (digit_bases): one launch less per pass.
@@ -2581,7 +2602,42 @@ struct DrawNormals {
   uint64_t stride{0};
   uint64_t index_offset{0};  // global index of output slot 0's particle less a.out_offset (the shard's offset)
   uint32_t step{0};          // the step they are for
+  // Option order_ahead: the ordering key of where the slot's particle will be after the NEXT propagation - its normals are at hand, the
+  // control action is the predicted one, the frame the host's prediction of that set's - in single precision and to first order (only
+  // locality depends on a key).  keys == nullptr: none.
+  uint32_t* keys{nullptr};
+  DiffDriveSampler predicted{};
+  KeyFrame frame{};
 };
+// Where a pose goes under the motion model with the given normals, to first order and in single precision: (c, s, x, y).
+__device__ __forceinline__ double4 predicted_pose_f32(const Pose2& p, const DiffDriveSampler& m, float z0, float z1, float z2) {
+  const float c = static_cast<float>(p.r.c), s = static_cast<float>(p.r.s);
+  float turn, ahead, left, dir_c, dir_s;  // heading change; translation along / across the direction (dir_c, dir_s) in the robot's frame
+  if (m.kind == 1) {  // omnidirectional: rotation z0, translation z1 along `first`, strafe z2
+    turn = z0 * static_cast<float>(m.s1) + static_cast<float>(m.m1);
+    ahead = z1 * static_cast<float>(m.st) + static_cast<float>(m.mt);
+    left = -(z2 * static_cast<float>(m.s2));
+    dir_c = static_cast<float>(m.first_c);
+    dir_s = static_cast<float>(m.first_s);
+  } else if (m.kind == 2) {  // stationary
+    turn = z0 * 0.02f;
+    ahead = z1 * 0.02f;
+    left = z2 * 0.02f;
+    dir_c = 1.f;
+    dir_s = 0.f;
+  } else {  // differential: first rotation, translation along the new heading, second rotation
+    const float r1 = z0 * static_cast<float>(m.s1) + static_cast<float>(m.m1);
+    turn = r1 + z2 * static_cast<float>(m.s2) + static_cast<float>(m.m2);
+    ahead = z1 * static_cast<float>(m.st) + static_cast<float>(m.mt);
+    left = 0.f;
+    dir_c = __cosf(r1);
+    dir_s = __sinf(r1);
+  }
+  const float hc = c * dir_c - s * dir_s, hs = s * dir_c + c * dir_s;  // the direction of the translation in the world
+  const float tc = __cosf(turn), ts = __sinf(turn);
+  return double4{static_cast<double>(c * tc - s * ts), static_cast<double>(s * tc + c * ts),
+                 p.x + static_cast<double>(ahead * hc - left * hs), p.y + static_cast<double>(ahead * hs + left * hc)};
+}
 template <bool kEstimate>
 __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_resample_draw(Particles src, CdfTree cdf, const double* __restrict__ d_total,
                                                               Particles dst, ResampleArgs a, GridView g, FreeCells fc, HashParams hp,
@@ -2625,6 +2681,9 @@ __global__ __launch_bounds__(kDrawBlock) __attribute__((amdgpu_waves_per_eu(8, 8
       ahead.normals[o] = z.x;
       ahead.normals[ahead.stride + o] = z.y;
       ahead.normals[2 * ahead.stride + o] = z.z;
+      if (ahead.keys)  // (uniform)
+        ahead.keys[o] = order_key(predicted_pose_f32(s, ahead.predicted, static_cast<float>(z.x), static_cast<float>(z.y), static_cast<float>(z.z)),
+                                  ahead.frame);
     }
     if (kEstimate) {
       const double dx = s.x - pivot_x, dy = s.y - pivot_y;
@@ -3849,6 +3908,18 @@ void launch_order_particles(hipStream_t st, Particles p, uint64_t n, const SortS
                      sort->perm);
 }
 
+void launch_order_ahead(hipStream_t st, uint64_t n, const SortScratch* sort) {
+  if (n == 0 || !sort || n >= (1ull << 32)) return;
+  const uint32_t nblocks = num_chunks(n);
+  hipLaunchKernelGGL(k_key_hist, dim3(nblocks), dim3(kWide), 0, st, sort->keys, n, sort->table, nblocks);
+  const dim3 rows(kSortDigits / (kBlock / 64));
+  hipLaunchKernelGGL(k_row_scan, rows, dim3(kBlock), 0, st, sort->table, nblocks, sort->totals);
+  hipLaunchKernelGGL(k_sort_scatter_high, dim3(nblocks), dim3(kStable), 0, st, sort->keys, n, sort->table, nblocks, sort->totals,
+                     sort->keyidx, sort->totals + kSortDigits);
+  hipLaunchKernelGGL(k_sort_buckets, dim3(kSortDigits), dim3(kStable), 0, st, sort->keyidx, sort->totals, sort->totals + kSortDigits,
+                     sort->perm);
+}
+
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
                         bool dispersed, bool* far_tiles_used, uint32_t* weight_sums_written, bool* queue_used, bool unit_weights) {
@@ -4095,7 +4166,8 @@ void launch_resample_draw(hipStream_t st, Particles src, CdfTree cdf, const doub
 void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cdf, const double* d_total, Particles dst, ResampleArgs a,
                                        GridView g, FreeCells fc, HashParams hp, double pivot_x, double pivot_y, double* d_partials,
                                        double* d_sums, double* host_mirror, const Completion* done, unsigned int* fold_ticket,
-                                       double* normals_ahead, uint64_t normals_stride, uint64_t normals_index_offset, uint32_t normals_step) {
+                                       double* normals_ahead, uint64_t normals_stride, uint64_t normals_index_offset, uint32_t normals_step,
+                                       uint32_t* keys_ahead, const DiffDriveSampler* predicted, const KeyFrame* frame_ahead) {
   int first;
   uint32_t doubles;
   draw_staging(cdf, first, doubles);
@@ -4108,7 +4180,9 @@ void launch_resample_draw_and_estimate(hipStream_t st, Particles src, CdfTree cd
     if (fold) f = DrawFold{fold_ticket, d_sums, host_mirror, done ? *done : Completion{}};
     hipLaunchKernelGGL(k_resample_draw<true>, dim3(blocks), dim3(kDrawBlock), doubles * sizeof(double), st, src, cdf, d_total, dst, a, g,
                        fc, hp, static_cast<unsigned long long*>(nullptr), pivot_x, pivot_y, d_partials, blocks, first, doubles, f,
-                       DrawNormals{normals_ahead, normals_stride, normals_index_offset, normals_step});
+                       DrawNormals{normals_ahead, normals_stride, normals_index_offset, normals_step,
+                                   (normals_ahead && predicted && frame_ahead) ? keys_ahead : nullptr,
+                                   predicted ? *predicted : DiffDriveSampler{}, frame_ahead ? *frame_ahead : KeyFrame{}});
   }
   if (!fold)
     hipLaunchKernelGGL(k_final_rows, dim3(9), dim3(kBlock), 0, st, d_partials, blocks, blocks, d_sums, host_mirror, done ? *done : Completion{});
