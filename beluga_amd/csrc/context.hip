@@ -198,6 +198,8 @@ struct mcl_ctx {
   DeviceBuffer<uint8_t> d_far_bits;   // FieldView::far_bits: tiles of d_pal_idx uniformly equal to the table's most common entry
   DeviceBuffer<uint32_t> d_far_votes;
   uint32_t far_row_bytes{0}, far_bytes{0}, far_entry{0};
+  DeviceBuffer<uint8_t> d_far_linear;  // FieldView::far_linear: the same bits by the tiles' linear index
+  uint32_t far_linear_bytes{0};
   uint64_t far_tiles{0};  // number of set bits' worth of tiles voted for far_entry (0 = no bitmap)
   DeviceBuffer<int8_t> d_cells;
   DeviceBuffer<uint32_t> d_nonfree_bits;  // beam model: 1 bit per cell
@@ -335,6 +337,7 @@ struct mcl_ctx {
   struct LfMode { bool decided, patches, beams; } lf_mode{false, false, false};
   uint64_t lf_beams_launches{0};   // launches of k_reweight_lf_beams (mcl_get_counter)
   uint64_t lf_far_launches{0};     // launches of the gather kernel with the far-tile bitmap (dispersed sets)
+  uint64_t lf_far_beams_launches{0};  // those of them that were k_reweight_lf_far_beams (lf_dispersed = 2)
   // scratch of the spatial ordering
   DeviceBuffer<uint32_t> d_route_u32;           // scratch of mcl_route_targets
   DeviceBuffer<uint32_t> d_sort_u32;            // keys[cap] perm[cap] table[1024 * nblocks] totals[1024] bases[1024] flags[16]
@@ -375,7 +378,8 @@ struct mcl_ctx {
     return FieldView{d_field.ptr, W, H, 1. / resolution, origin_inverse, static_cast<float>(1. / cfg.lf.max_laser_distance),
                      d_cube.ptr, cfg.sensor_kind == MCL_SENSOR_LIKELIHOOD_FIELD_PROB ? 1 : 0,
                      pal_count ? d_pal_idx.ptr : nullptr, d_pal_val.ptr, pal_count, pal_pitch, pal_base, pal_bytes,
-                     pal_count && far_tiles ? d_far_bits.ptr : nullptr, far_row_bytes, far_bytes, far_entry};
+                     pal_count && far_tiles ? d_far_bits.ptr : nullptr, far_row_bytes, far_bytes, far_entry,
+                     pal_count && far_tiles && far_linear_bytes ? d_far_linear.ptr : nullptr, far_linear_bytes};
   }
   SortScratch sort_scratch() {
     SortScratch s{};
@@ -632,6 +636,10 @@ mcl_status rebuild_cube(mcl_ctx* ctx, const float* h_field) {
           ctx->far_bytes = far_bytes;
           launch_far_tile_bits(ctx->stream, ctx->d_pal_idx.ptr, static_cast<uint32_t>(tiles_x), static_cast<uint32_t>(tiles_y), ctx->far_entry,
                                row_bytes, far_bytes, ctx->d_far_bits.ptr);
+          ctx->far_linear_bytes = static_cast<uint32_t>(((tiles_x * tiles_y + 7) / 8 + 15) & ~15ull);
+          MCL_HIP(ctx, ctx->d_far_linear.ensure(ctx->far_linear_bytes));
+          launch_far_tile_bits_linear(ctx->stream, ctx->d_pal_idx.ptr, static_cast<uint32_t>(tiles_x * tiles_y), ctx->far_entry,
+                                      ctx->far_linear_bytes, ctx->d_far_linear.ptr);
           MCL_HIP(ctx, hipGetLastError());
           ctx->far_tiles = votes[best];
         }
@@ -842,7 +850,7 @@ void decide_lf_mode(mcl_ctx* ctx) {
   }
   if (ctx->tuning.lf_variant != kLfSortedLanes) return;
   ctx->lf_mode.patches = wants_patches(ctx);
-  ctx->lf_mode.beams = !ctx->lf_mode.patches && ctx->tuning.lf_patch == 1 && ctx->tuning.lf_dispersed != 0 && !ctx->patch_useful && palette &&
+  ctx->lf_mode.beams = !ctx->lf_mode.patches && ctx->tuning.lf_patch == 1 && ctx->tuning.lf_dispersed == 1 && !ctx->patch_useful && palette &&
                        !lf_set_is_small(ctx);
 }
 
@@ -961,7 +969,7 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
     const bool scan_is_short = ctx->scan_extent / ctx->resolution < 8192.0;
     stage_begin(ctx, MCL_STAGE_SENSOR_KERNEL);
     const bool use_patches = mode.patches;
-    bool far_tiles_used = false, queue_used = false;
+    bool far_tiles_used = false, queue_used = false, far_beams_used = false;
     if (mode.beams) ctx->lf_beams_launches += 1;
     launch_reweight_lf(ctx->stream, ctx->cur(), ctx->n, ctx->field_view(), ctx->d_points.ptr, static_cast<uint32_t>(B), variant, &sort,
                        scan_is_short, ctx->tuning, use_patches,
@@ -971,8 +979,9 @@ mcl_status do_reweight(mcl_ctx* ctx, const double* pts, uint64_t B, bool points_
                                   static_cast<uint32_t>(ctx->tuning.lf_split), want_weight_sums ? ctx->d_lf_wsum.ptr : nullptr,
                                   reinterpret_cast<unsigned int*>(ctx->d_scalars.ptr + 30)},
                        /*dispersed=*/!use_patches && (ctx->tuning.lf_far_tiles == 2 || (ctx->tuning.lf_patch == 1 && !ctx->patch_useful)),
-                       &far_tiles_used, &ctx->lf_wsum_count, &queue_used, unit_weights);
+                       &far_tiles_used, &ctx->lf_wsum_count, &queue_used, unit_weights, &far_beams_used);
     if (far_tiles_used) ctx->lf_far_launches += 1;
+    if (far_beams_used) ctx->lf_far_beams_launches += 1;
     if (queue_used) ctx->lf_queue_launches += 1;
     stage_end(ctx, MCL_STAGE_SENSOR_KERNEL);
     if (variant == kLfSortedLanes && ctx->tuning.lf_fast != 0 && scan_is_short && ctx->W < 16384 && ctx->H < 16384 && ctx->pal_count &&
@@ -2258,7 +2267,7 @@ mcl_status mcl_create(const mcl_config* cfg, mcl_ctx** out) {
     }
     // Environment defaults of the per-context switches (mcl_set_option changes them at run time).
     for (const char* name : {"lf_variant", "lf_fast", "lf_table", "lf_patch", "lf_dispersed", "lf_far_tiles", "key_layout", "lf_loose_below", "lf_small_particles", "device_policy",
-                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin", "scan_fused", "draw_fold", "lf_unit_weights", "small_fused", "norm_store", "noise_ahead", "order_ahead"}) {
+                             "sort_min_particles", "beam_sort_min_particles", "field_build", "key_curve", "key_warp", "key_bits_xy", "lf_margin", "lf_split", "lf_queue_grid", "shard_pad_permille", "lf_queue", "lf_ends_first", "beam_free_ahead", "beam_sectors", "lf_weight_sums", "beam_table", "cycle_spin", "scan_fused", "draw_fold", "lf_unit_weights", "small_fused", "norm_store", "noise_ahead", "order_ahead", "lf_far_beams_per_wave"}) {
       std::string env = "BELUGA_MCL_";
       for (const char* c = name; *c; ++c) env += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
       if (const char* v = std::getenv(env.c_str())) {
@@ -2289,6 +2298,7 @@ void mcl_destroy(mcl_ctx* ctx) {
   ctx->d_cube.release();
   ctx->d_pal_idx.release();
   ctx->d_far_bits.release();
+  ctx->d_far_linear.release();
   ctx->d_far_votes.release();
   ctx->d_pal_val.release();
   ctx->d_pal_keys.release();
@@ -3348,7 +3358,8 @@ mcl_status mcl_set_option(mcl_ctx* ctx, const char* name, int64_t value) {
   const std::string key(name);
   Tuning& t = ctx->tuning;
   if (key == "lf_variant") t.lf_variant = value == 0 ? kLfWavePerParticle : (value == 1 ? kLfLanePerParticle : (value == 3 ? kLfBeamLanes : kLfSortedLanes));
-  else if (key == "lf_dispersed") t.lf_dispersed = value ? 1 : 0;
+  else if (key == "lf_dispersed") t.lf_dispersed = value < 0 ? 0 : static_cast<int>(std::min<int64_t>(value, 2));
+  else if (key == "lf_far_beams_per_wave") t.lf_far_beams_per_wave = value < 0 ? 0 : static_cast<int>(std::min<int64_t>(value, 4096));
   else if (key == "key_layout") t.key_layout = value < 0 ? -1 : (value ? 1 : 0);
   else if (key == "lf_far_tiles") t.lf_far_tiles = value < 0 ? 0 : static_cast<int>(std::min<int64_t>(value, 2));
   else if (key == "lf_loose_below") t.lf_loose_below = static_cast<int>(std::clamp<int64_t>(value, 0, 257));
@@ -3420,6 +3431,7 @@ mcl_status mcl_get_counter(mcl_ctx* ctx, const char* name, uint64_t* value) {
   else if (key == "lf_queue_launches") *value = ctx->lf_queue_launches;
   else if (key == "lf_beams_launches") *value = ctx->lf_beams_launches;
   else if (key == "lf_far_launches") *value = ctx->lf_far_launches;
+  else if (key == "lf_far_beams_launches") *value = ctx->lf_far_beams_launches;
   else if (key == "lf_far_tiles") *value = ctx->far_tiles;
   else if (key == "noise_ahead_used") *value = ctx->noise_ahead_used;
   else if (key == "order_ahead_used") *value = ctx->order_ahead_used;

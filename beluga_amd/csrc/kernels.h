@@ -52,6 +52,10 @@ struct FieldView {
   uint32_t far_row_bytes;
   uint32_t far_bytes;  // size of far_bits, a multiple of 16
   uint32_t far_entry;  // LDS byte address of the common entry (as stored in pal_idx)
+  // The same bits by the tile's LINEAR index (ty * tiles_x + tx = a cell's byte offset in pal_idx >> 7): bit (index & 7) of byte
+  // index >> 3 - the test then starts from the offset a look-up has computed anyway (k_reweight_lf_far_beams).  nullptr = none.
+  const uint8_t* far_linear;
+  uint32_t far_linear_bytes;  // a multiple of 16
 };
 
 constexpr uint32_t kMaxPalette = 2048;
@@ -125,9 +129,11 @@ struct Tuning {
                                     // 0 = never (per-lane gathers only), 2 = always
   int lf_loose_below = 224;         // LF patch kernel: a workgroup with fewer than this many 256ths of its beam groups fitting a patch
                                     // drops the patches (no producer, no barriers) and gathers every look-up
-  int lf_dispersed = 0;             // a set the patch kernel reports as dispersed (lf_patch = 1): 0 = the ordered-lanes gather kernel,
-                                    // 1 = wave per particle / lane per beam (k_reweight_lf_beams, no ordering pass; measured
-                                    // 20 % slower at 1M x 1080: profiles/r02_dispersed_study.txt)
+  int lf_dispersed = 2;             // a set the patch kernel reports as dispersed (lf_patch = 1): 2 = lanes over the beams of a pose, the poses
+                                    // in the position-major order, far-tile bitmap (k_reweight_lf_far_beams; where its tables fit LDS, else
+                                    // as 0), 0 = the ordered-lanes gather kernel (a lane per particle; rounds 2 - 5), 1 = wave per particle /
+                                    // lane per beam without any order (k_reweight_lf_beams; 20 % slower than 0: profiles/r02_dispersed_study.txt)
+  int lf_far_beams_per_wave = 0;    // particles a wave of k_reweight_lf_far_beams takes (0 = 32)
   int device_policy = 1;            // recovery estimator on the device when the cycle has no host-side decision
   int sort_min_particles = 16384;   // below this the ordering passes cost more than they save (likelihood-field models)
   int beam_sort_min_particles = 16384;  // beam model: the ordered kernel (LDS bit window, scan segments) from here on; below, a wave per
@@ -320,7 +326,7 @@ struct PatchStats {
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
                         bool dispersed = false, bool* far_tiles_used = nullptr, uint32_t* weight_sums_written = nullptr,
-                        bool* queue_used = nullptr, bool unit_weights = false);
+                        bool* queue_used = nullptr, bool unit_weights = false, bool* far_beams_used = nullptr);
 // K2' beam_model.hpp:104-150 + raycasting.hpp:62-107 + bresenham.hpp:84-160
 // `sorted` != nullptr: lane-per-ordered-particle variant (needs launch_order_particles first).
 // d_beam_points: scratch of kBeamPointDoubles * B doubles (per-beam terms shared by all particles; ordered variant only).
@@ -551,6 +557,7 @@ void launch_palette_table(hipStream_t st, const float* field, uint32_t W, uint32
 // Far tiles of a palette table (FieldView::far_bits).  votes[k] (count entries, zeroed here) = number of tiles uniformly equal
 // to entry k; the caller picks the entry and has launch_far_tile_bits write the bitmap (far_bytes bytes).
 void launch_far_tile_votes(hipStream_t st, const uint16_t* idx, uint32_t tiles, uint32_t pal_base, uint32_t count, uint32_t* votes);
+void launch_far_tile_bits_linear(hipStream_t st, const uint16_t* idx, uint32_t tiles, uint32_t entry, uint32_t bytes, uint8_t* bits);
 void launch_far_tile_bits(hipStream_t st, const uint16_t* idx, uint32_t tiles_x, uint32_t tiles_y, uint32_t entry, uint32_t row_bytes,
                           uint32_t far_bytes, uint8_t* bits);
 // AoS (c,s,x,y) host layout <-> SoA device layout

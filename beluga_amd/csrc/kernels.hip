@@ -759,6 +759,204 @@ __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, 
   if (lane < cnt) p.w[i] = p.w[i] * (f.prob ? exp(mine) : 1.0 + mine);
 }
 
+// Variant D for large DISPERSED sets, round 6 (option lf_dispersed = 2): the lanes over the beams of a pose as above, but with everything
+// that made the ordered-lanes gather kernel of such sets fast (k_reweight_lf_palette<true, true>) - the FMA end-points on biased cell
+// coordinates with their exact fallback, the far-tile bitmap in LDS, the particles taken in the position-major order with XCD k walking the
+// k-th contiguous eighth of it (98 % L2 hits) - and without what bounds that kernel: there every lane's look-up is a cache line of its
+// own (the L1 takes a cycle per quad of lanes and line: 573 M of them per launch at 1M x 1080, 0.93 ms), here the four lanes of a quad hold
+// four consecutive beams of one pose, whose end-points lie cells apart along the wall the scan saw - one tile or two -, and a quad whose
+// four end-points fall into far tiles costs nothing.  The scan sits in LDS; a lane reads its beam of a round once for kFarBeamsPoses poses,
+// which go through SGPRs (register blocking: 4 independent look-ups per point read, the next round's issued before this round's are
+// consumed).  The far test starts from the byte offset the look-up has anyway (FieldView::far_linear: offset >> 7 is the tile's linear
+// index).  A lane adds its beams in scan order, the 64 lane sums are added in a fixed tree: the weight differs from the lane-per-particle
+// kernels' in rounding only (as k_reweight_lf_beams').
+// Workgroup memory: the bitmap at 0 (the byte of a tile is at offset >> 10: no base to add), the row offsets (less kFastBiasX) behind it, the
+// palette kFarBeamsPalShift bytes above its place in the other kernels (the table's entries are LDS addresses from pal_base on; the
+// shift is a constant and rides in the DS instruction's offset field), then the scan (16 bytes per beam, whole rounds of 64).  The
+// bitmap may take up to kFarBeamsPalShift bytes (maps of up to ~4000^2 cells); the rows then fit below the palette whatever H is.
+#ifndef MCL_FB_BLOCK
+#define MCL_FB_BLOCK 768
+#define MCL_FB_WAVES 6
+#define MCL_FB_POSES 2
+#endif
+#ifndef MCL_FB_ABLATE
+#define MCL_FB_ABLATE 0
+#endif
+constexpr int kFarBeamsBlock = MCL_FB_BLOCK;
+constexpr int kFarBeamsPoses = MCL_FB_POSES;
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f64x2_t lds_f64x2_t;
+constexpr uint32_t kFarBeamsPalShift = 32768;
+constexpr uint32_t kFarBeamsChunk = 16;  // poses a wave transforms at a time (<= 64, a multiple of kFarBeamsPoses)
+// (kProb: the weight is exp(sum) - likelihood_field_prob_model.hpp:77-90; an instance of its own because the exponential's constants, hoisted
+// out of every loop, would otherwise cost the likelihood-field model's instance twenty registers)
+template <bool kProb>
+__global__ __launch_bounds__(kFarBeamsBlock) __attribute__((amdgpu_waves_per_eu(MCL_FB_WAVES, MCL_FB_WAVES))) void k_reweight_lf_far_beams(double* __restrict__ w, uint64_t n, FieldView f,
+                                                                          const double2* __restrict__ pts, uint32_t B,
+                                                                          const uint32_t* __restrict__ perm, const double4* __restrict__ pose,
+                                                                          uint32_t pts_at, uint32_t per_wave, uint32_t unit_weights) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int J = kFarBeamsPoses;
+  const uint32_t rows_at = f.far_linear_bytes;  // (a multiple of 16)
+  const uint32_t rounds = (B + 63u) >> 6;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(f.far_linear);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (uint32_t j = threadIdx.x; j < f.far_linear_bytes / 16; j += kFarBeamsBlock) dst[j] = src[j];
+    uint32_t* s_row = reinterpret_cast<uint32_t*>(smem + rows_at);
+    for (uint32_t j = threadIdx.x; j < f.H + 2; j += kFarBeamsBlock)
+      s_row[j] = palette_row_offset(static_cast<int32_t>(j) - 1, f.pal_pitch) - kFastBiasX;
+    double* s_pal = reinterpret_cast<double*>(smem + kFarBeamsPalShift + f.pal_base);
+    for (uint32_t k = threadIdx.x; k < f.pal_count; k += kFarBeamsBlock) s_pal[k] = f.pal_val[k];
+    double2* s_pts = reinterpret_cast<double2*>(smem + pts_at);
+    for (uint32_t b = threadIdx.x; b < rounds * 64u; b += kFarBeamsBlock) s_pts[b] = b < B ? pts[b] : double2{0.0, 0.0};
+  }
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t first = (static_cast<uint64_t>(far_block(blockIdx.x, gridDim.x)) * (kFarBeamsBlock / kWave) + wave) * per_wave;
+  if (first >= n) return;  // (no barrier below)
+  const uint32_t cnt = static_cast<uint32_t>(n - first < per_wave ? n - first : per_wave);
+  const bool dead_last = ((rounds - 1u) << 6) + lane >= B;  // no such beam in the last round
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(f.pal_idx), 0, static_cast<int>(f.pal_bytes), 0x00020000);
+  const int c_lo = static_cast<int>(kFastBias) - 1, x_hi = static_cast<int>(kFastBias + f.W), y_hi = static_cast<int>(kFastBias + f.H);
+  const uint32_t row_bias = rows_at + 4u - (kFastBias << 2);  // LDS byte address of the row entry = (biased y << 2) + row_bias
+  const uint32_t my_point = pts_at + (lane << 4);
+  // The poses of a wave, kFarBeamsChunk at a time: lane q of the wave transforms pose q and leaves (cos, sin, x, y) / resolution in the wave's
+  // 32-byte slots of LDS; the scan loop reads a pose back as a broadcast - every lane holds it in VECTOR registers (an FMA takes one
+  // scalar operand: from SGPRs the translations would have to be moved to vector registers in every round).
+  const uint32_t slots_at = pts_at + (rounds << 10) + wave * (kFarBeamsChunk * 32u);
+#pragma unroll 1
+  for (uint32_t c0 = 0; c0 < cnt; c0 += kFarBeamsChunk) {
+    const uint32_t m = cnt - c0 < kFarBeamsChunk ? cnt - c0 : kFarBeamsChunk;
+    uint32_t i = 0;
+    Pose2 T = pose_identity();
+    if (lane < m) {
+      i = perm[first + c0 + lane];
+      T = ordered_pose(f.world_to_field, pose, i);  // likelihood_field_model.hpp:70
+    }
+    unsigned long long large;
+    {
+      const double l_ict = T.r.c * f.inv_resolution, l_ist = T.r.s * f.inv_resolution, l_ixt = T.x * f.inv_resolution,
+                   l_iyt = T.y * f.inv_resolution;
+      large = __builtin_amdgcn_ballot_w64(!(fabs(l_ixt) < 16384.0 && fabs(l_iyt) < 16384.0));  // NaN as well
+      if (lane < kFarBeamsChunk) {
+        f64x2_t* slot = reinterpret_cast<f64x2_t*>(smem + slots_at + (lane << 5));
+        slot[0] = f64x2_t{l_ict, l_ist};
+        slot[1] = f64x2_t{l_ixt, l_iyt};
+      }
+    }
+    double mine = 0.0;
+#pragma unroll 1
+    for (uint32_t q0 = 0; q0 < m; q0 += J) {  // poses q0 .. q0 + J - 1 (beyond m: the identity's, computed and dropped)
+      double ict[J], ist[J], ixt[J], iyt[J], acc[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const uint32_t at = slots_at + ((q0 + j) << 5);  // (q0 + j < kFarBeamsChunk: J divides it)
+        const f64x2_t rot = *reinterpret_cast<lds_f64x2_t*>(static_cast<uintptr_t>(at));
+        const f64x2_t tr = *reinterpret_cast<lds_f64x2_t*>(static_cast<uintptr_t>(at + 16u));
+        ict[j] = rot.x;
+        ist[j] = rot.y;
+        ixt[j] = tr.x;
+        iyt[j] = tr.y;
+        acc[j] = 0.0;
+      }
+      bool exact = ((large >> q0) & ((1ull << J) - 1ull)) != 0;  // (uniform)
+      if (!exact) {
+        uint32_t near_integer = 0xFFFFFFFFu;
+        auto issue = [&](uint32_t (&e)[J], uint32_t k) {
+          const f64x2_t pt = *reinterpret_cast<lds_f64x2_t*>(static_cast<uintptr_t>(my_point + (k << 10)));
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            const double sx = __builtin_fma(pt.x, ict[j], __builtin_fma(-pt.y, ist[j], ixt[j])) + kFastMagic;
+            const double sy = __builtin_fma(pt.x, ist[j], __builtin_fma(pt.y, ict[j], iyt[j])) + kFastMagic;
+            const uint64_t bx = __builtin_bit_cast(uint64_t, sx), by = __builtin_bit_cast(uint64_t, sy);
+            near_integer = min3_u32(near_integer, static_cast<uint32_t>(bx), static_cast<uint32_t>(by));
+            const int xc = med3_i32(static_cast<int>(bx >> 32), c_lo, x_hi), yc = med3_i32(static_cast<int>(by >> 32), c_lo, y_hi);
+            const uint32_t row = *reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>((static_cast<uint32_t>(yc) << 2) + row_bias));
+            const uint32_t offset = (static_cast<uint32_t>(xc) << 4) + row;
+            const uint32_t byte = *reinterpret_cast<lds_u8_t*>(static_cast<uintptr_t>(offset >> 10));
+            uint32_t far = __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(offset, 7, 3), 1);
+            if (MCL_FB_ABLATE & 1) far |= 1u;  // (measurement builds: no look-up reaches memory)
+            // a far look-up's offset is pushed out of range (the load returns 0 and moves nothing); its entry is the common one
+            const uint32_t loaded = (MCL_FB_ABLATE & 2) ? (offset & 8u) : static_cast<uint32_t>(
+                static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, offset | (far << 31), 0, 0)));
+            e[j] = mad_u24(far, f.far_entry, loaded);
+          }
+        };
+        // (a lane without a beam in the scan's last round looked up the pose's own cell: not added)
+        auto consume = [&](const uint32_t (&e)[J], bool last) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            double v = (MCL_FB_ABLATE & 8) ? __hiloint2double(static_cast<int>(e[j]), 0) : lf_palette_value(e[j] + kFarBeamsPalShift);
+            if (last) v = dead_last ? 0.0 : v;  // (uniform branch)
+            acc[j] += v;
+          }
+        };
+        // two rounds in flight alternately; the scan's last round (its dead lanes) outside the loop
+        uint32_t ea[J], eb[J];
+        if (rounds > 1) {
+          issue(ea, 0);
+          uint32_t k = 1;
+          while (k + 2 < rounds) {
+            issue(eb, k);
+            consume(ea, false);
+            issue(ea, k + 1);
+            consume(eb, false);
+            k += 2;
+          }
+          if (k + 1 < rounds) {
+            issue(eb, k);
+            consume(ea, false);
+            issue(ea, k + 1);
+            consume(eb, false);
+            consume(ea, true);
+          } else {
+            issue(eb, k);
+            consume(ea, false);
+            consume(eb, true);
+          }
+        } else {
+          issue(ea, 0);
+          consume(ea, true);
+        }
+        exact = __builtin_amdgcn_ballot_w64(near_integer == 0) != 0;  // an end-point on a cell boundary: these poses again, exactly
+      }
+      if (exact) {  // the reference's separately rounded arithmetic (rare: a pose 2^14 cells from the origin, an end-point on a boundary)
+#pragma unroll 1
+        for (int j = 0; j < J; ++j) {
+          const uint32_t iq = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(i), static_cast<int>(q0) + j));
+          const Pose2 Tq = ordered_pose(f.world_to_field, pose, iq);
+          double sum = 0.0;
+#pragma unroll 1
+          for (uint32_t k = 0; k < rounds; ++k) {
+            if (64u * k + lane < B) {
+              const double2 pt = pts[64u * k + lane];
+              double vx = (pt.x * Tq.r.c - pt.y * Tq.r.s + Tq.x) * f.inv_resolution, vy = (pt.x * Tq.r.s + pt.y * Tq.r.c + Tq.y) * f.inv_resolution;
+              floor_rd_2(vx, vy);
+              const int xc = clamp_cell(floor_rd_result(vx), f.W), yc = clamp_cell(floor_rd_result(vy), f.H);
+              const uint32_t row = *reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>(rows_at + (static_cast<uint32_t>(yc + 1) << 2)));
+              const uint32_t at = (static_cast<uint32_t>(xc) << 4) + kFastBiasX + row;
+              sum += lf_palette_value(static_cast<uint32_t>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, at, 0, 0))) +
+                                      kFarBeamsPalShift);
+            }
+          }
+          // (acc[j] with a runtime j would go through scratch)
+#pragma unroll
+          for (int jj = 0; jj < J; ++jj)
+            if (j == jj) acc[jj] = sum;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const double total = wave_sum_f64(acc[j]);
+        if (lane == q0 + j) mine = total;
+      }
+    }
+    if (lane < m) w[i] = (unit_weights != 0u ? 1.0 : w[i]) * (kProb ? exp(mine) : 1.0 + mine);
+  }
+}
+
 // The palette kernel with the index table read through LDS patches.
 // A scattered 64-lane 2-byte gather costs the CU's texture-address pipe one cycle per quad of lanes per line (16+ per
 // instruction, profiles/r02_calib_gather_cost.txt): the floor of k_reweight_lf_palette.  An LDS read of the same shape costs
@@ -3845,6 +4043,18 @@ __global__ __launch_bounds__(kBlock) void k_far_tile_bits(const uint16_t* __rest
   }
   bits[at] = static_cast<uint8_t>(byte);
 }
+__global__ __launch_bounds__(kBlock) void k_far_tile_bits_linear(const uint16_t* __restrict__ idx, uint32_t tiles, uint32_t entry, uint32_t bytes,
+                                                                 uint8_t* __restrict__ bits) {
+  const uint32_t at = blockIdx.x * kBlock + threadIdx.x;
+  if (at >= bytes) return;
+  uint32_t byte = 0;
+  for (uint32_t k = 0; k < 8; ++k) {
+    const uint64_t tile = static_cast<uint64_t>(at) * 8 + k;
+    uint32_t found;
+    if (tile < tiles && tile_is_uniform(idx, tile, &found) && found == entry) byte |= 1u << k;
+  }
+  bits[at] = static_cast<uint8_t>(byte);
+}
 __global__ __launch_bounds__(kBlock) void k_fill(double* p, uint64_t n, double v) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i < n) p[i] = v;
@@ -3920,9 +4130,36 @@ void launch_order_ahead(hipStream_t st, uint64_t n, const SortScratch* sort) {
                      sort->perm);
 }
 
+namespace {
+constexpr uint32_t kFarBeamsMaxLds = 80 * 1024;  // two workgroups per CU
+uint32_t far_beams_points_at(const FieldView& f) {  // the scan's place in the workgroup memory of k_reweight_lf_far_beams
+  return (kFarBeamsPalShift + f.pal_base + f.pal_count * 8u + 15u) & ~15u;
+}
+uint32_t far_beams_lds(const FieldView& f, uint32_t B) {
+  return far_beams_points_at(f) + ((B + 63u) & ~63u) * 16u + (kFarBeamsBlock / kWave) * kFarBeamsChunk * 32u;
+}
+// (hipFuncSetAttribute is per device)
+bool far_beams_configured() {
+  static bool done[64] = {};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return false;
+  if (!done[device]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_lf_far_beams<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kFarBeamsMaxLds)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_reweight_lf_far_beams<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kFarBeamsMaxLds)) != hipSuccess)
+      return false;
+    done[device] = true;
+  }
+  return true;
+}
+}  // namespace
+
 void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, const double* d_points, uint32_t B, int variant,
                         const SortScratch* sort, bool scan_is_short, const Tuning& tuning, bool use_patches, PatchStats patch_stats,
-                        bool dispersed, bool* far_tiles_used, uint32_t* weight_sums_written, bool* queue_used, bool unit_weights) {
+                        bool dispersed, bool* far_tiles_used, uint32_t* weight_sums_written, bool* queue_used, bool unit_weights,
+                        bool* far_beams_used) {
+  if (far_beams_used) *far_beams_used = false;
   if (weight_sums_written) *weight_sums_written = 0;
   if (far_tiles_used) *far_tiles_used = false;
   if (queue_used) *queue_used = false;
@@ -3967,6 +4204,27 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
           hipLaunchKernelGGL(k_reweight_lf_patch<false>, dim3(groups_x, segments), dim3(kPatchBlock), patch_lds, st, args);
         }
         if (weight_sums_written && patch_stats.weight_sums) *weight_sums_written = groups_x;
+      }
+      else if (fast && dispersed && tuning.lf_far_tiles != 0 && tuning.lf_dispersed == 2 && f.far_linear != nullptr && B > 0 &&
+               f.far_linear_bytes <= kFarBeamsPalShift && far_beams_lds(f, B) <= kFarBeamsMaxLds && far_beams_configured()) {
+        // lanes over the beams of one pose, the poses in the position-major order (k_reweight_lf_far_beams); a small set needs no
+        // segments of the scan to fill the chip: fewer poses per wave
+        segments = 1;
+        const uint64_t waves_wanted = 256ull * 4 * MCL_FB_WAVES;
+        const uint32_t per_wave_auto = static_cast<uint32_t>(std::min<uint64_t>(32, std::max<uint64_t>(kFarBeamsPoses, n / waves_wanted)));
+        const uint32_t per_wave = tuning.lf_far_beams_per_wave > 0 ? static_cast<uint32_t>(tuning.lf_far_beams_per_wave) : per_wave_auto;
+        const uint64_t per_block = static_cast<uint64_t>(per_wave) * (kFarBeamsBlock / kWave);
+        const unsigned blocks = (static_cast<unsigned>((n + per_block - 1) / per_block) + 7u) & ~7u;
+        if (f.prob)
+          hipLaunchKernelGGL(k_reweight_lf_far_beams<true>, dim3(blocks), dim3(kFarBeamsBlock), far_beams_lds(f, B), st, p.w, n, f,
+                             reinterpret_cast<const double2*>(d_points), B, sort->perm, p.pose, far_beams_points_at(f), per_wave,
+                             unit_weights ? 1u : 0u);
+        else
+          hipLaunchKernelGGL(k_reweight_lf_far_beams<false>, dim3(blocks), dim3(kFarBeamsBlock), far_beams_lds(f, B), st, p.w, n, f,
+                             reinterpret_cast<const double2*>(d_points), B, sort->perm, p.pose, far_beams_points_at(f), per_wave,
+                             unit_weights ? 1u : 0u);
+        if (far_tiles_used) *far_tiles_used = true;
+        if (far_beams_used) *far_beams_used = true;
       }
       else if (fast && dispersed && tuning.lf_far_tiles != 0 && f.far_bits != nullptr && patch_base + f.far_bytes <= 65536) {
         const dim3 fgrid((pgrid.x + 7u) & ~7u, segments);
@@ -4459,6 +4717,9 @@ void launch_palette_table(hipStream_t st, const float* field, uint32_t W, uint32
 void launch_far_tile_votes(hipStream_t st, const uint16_t* idx, uint32_t tiles, uint32_t pal_base, uint32_t count, uint32_t* votes) {
   (void)hipMemsetAsync(votes, 0, count * sizeof(uint32_t), st);
   hipLaunchKernelGGL(k_far_tile_votes, dim3(blocks_for(tiles)), dim3(kBlock), 0, st, idx, tiles, pal_base, count, votes);
+}
+void launch_far_tile_bits_linear(hipStream_t st, const uint16_t* idx, uint32_t tiles, uint32_t entry, uint32_t bytes, uint8_t* bits) {
+  hipLaunchKernelGGL(k_far_tile_bits_linear, dim3(blocks_for(bytes)), dim3(kBlock), 0, st, idx, tiles, entry, bytes, bits);
 }
 void launch_far_tile_bits(hipStream_t st, const uint16_t* idx, uint32_t tiles_x, uint32_t tiles_y, uint32_t entry, uint32_t row_bytes,
                           uint32_t far_bytes, uint8_t* bits) {

@@ -189,6 +189,7 @@ def test_far_tile_bitmap_changes_no_weight(case):
     f = new_filter(grid, n, sensor=sensor)
     f.set_option("lf_patch", 0)
     f.set_option("lf_far_tiles", 0)
+    f.set_option("lf_dispersed", 0)  # the lane-per-particle gather kernel, with and without the bitmap: bit for bit
     f.set_particles(states, np.ones(n))
     f.reweight(pts)
     plain = f.particles()[1]
@@ -208,6 +209,22 @@ def test_far_tile_bitmap_changes_no_weight(case):
     want = orc.lf_weights(f.likelihood_field(), grid.resolution, grid.origin, sensor.max_laser_distance, states, pts,
                           threads=orc.max_threads())
     np.testing.assert_allclose(plain, want, rtol=RTOL)
+    # the default for dispersed sets (lf_dispersed = 2): the lanes over the beams of a pose (k_reweight_lf_far_beams; 363 beams: five full
+    # rounds of 64 and one of 43), the bitmap by the tiles' linear index, the poses in either order - a lane adds its beams in scan
+    # order and the lane sums are added in a tree: the same weights up to rounding, whatever the order of the poses (bit for bit)
+    f.set_option("lf_dispersed", 2)
+    got = []
+    for layout, per_wave in ((1, 0), (0, 0), (1, 5)):
+        f.set_option("key_layout", layout)
+        f.set_option("lf_far_beams_per_wave", per_wave)
+        before = f.counter("lf_far_beams_launches")
+        f.set_particles(states, np.ones(n))
+        f.reweight(pts)
+        assert f.counter("lf_far_beams_launches") == before + 1
+        got.append(f.particles()[1])
+        np.testing.assert_allclose(got[-1], plain, rtol=1e-13)
+        np.testing.assert_allclose(got[-1], want, rtol=RTOL)
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
     f.close()
 
 
@@ -1243,6 +1260,45 @@ def test_reweight_lf_fma_variant_is_bit_identical(fast):
     f.close()
 
 
+def test_reweight_lf_far_beams_kernel_falls_back_to_the_exact_end_points():
+    """k_reweight_lf_far_beams (dispersed sets: lanes over the beams of a pose) evaluates end-points with FMAs like the other kernels and
+    runs a group of poses again with the separately rounded arithmetic when one of their end-points lies within 2^-33 of a cell boundary
+    or a pose is too far away for the error bound: a power-of-two resolution, poses on the cell lattice with heading 0 and scan points on
+    multiples of the resolution (many end-points exactly on boundaries), poses 10^6 cells away, beams that end far outside the map; prior
+    weights that are not 1.  Against the oracle, and against the lane-per-particle gather kernel up to the rounding of the sum."""
+    cells = synth.make_rooms_map(1024, 1024, seed=5, n_rooms=10)
+    res = 0.0625
+    grid = OccupancyGrid(cells=cells, resolution=res, origin=se2_from_xytheta(-32.0, -32.0, 0.0))
+    truth = synth.find_free_pose(cells, res, (-32.0, -32.0), seed=2, clearance_cells=6)
+    pts = make_scan(grid, truth, 200, max_range=12.0)
+    on_boundary = np.array([[k * res, (k % 7) * res] for k in range(1, 40)])  # multiples of the resolution
+    pts = np.concatenate([pts, on_boundary, [[300.0, -200.0]]])
+    n = 40_003
+    rng = np.random.Generator(np.random.MT19937(11))
+    th = rng.uniform(-np.pi, np.pi, n)
+    states = np.stack([np.cos(th), np.sin(th), rng.uniform(-34.0, 34.0, n), rng.uniform(-34.0, 34.0, n)], axis=1)
+    states[:2000, 0], states[:2000, 1] = 1.0, 0.0                     # heading exactly 0
+    states[:2000, 2:] = np.round(states[:2000, 2:] / res) * res       # positions on the cell lattice
+    states[2000:2004, 2] += 1e5                                        # beyond the fast path's range
+    w0 = rng.uniform(0.5, 1.5, n)
+    f = new_filter(grid, n)
+    f.set_option("lf_patch", 0)
+    f.set_option("lf_far_tiles", 2)
+    weights = {}
+    for mode in (2, 0):
+        f.set_option("lf_dispersed", mode)
+        before = f.counter("lf_far_beams_launches")
+        f.set_particles(states, w0)
+        f.reweight(pts)
+        assert f.counter("lf_far_tiles") > 0 and f.counter("lf_far_beams_launches") == before + (1 if mode == 2 else 0)
+        weights[mode] = f.particles()[1]
+    want = w0 * orc.lf_weights(f.likelihood_field(), res, grid.origin, LF.max_laser_distance, states, pts, threads=orc.max_threads())
+    np.testing.assert_allclose(weights[0], want, rtol=RTOL, atol=0)
+    np.testing.assert_allclose(weights[2], want, rtol=RTOL, atol=0)
+    np.testing.assert_allclose(weights[2], weights[0], rtol=1e-13, atol=0)
+    f.close()
+
+
 @pytest.mark.parametrize("n", [16_384, 66_667, 200_000, 300_000])
 def test_reweight_lf_patch_kernel_equals_the_gather_kernel_bit_for_bit(n):
     """The default LF kernel reads the index table through per-workgroup LDS patches wherever a bound on the workgroup's
@@ -1788,6 +1844,7 @@ def test_dispersed_cloud_1m_sampled_against_oracle():
     pts = make_scan(grid, truth, 1080, max_range=30.0)
     n = 1_000_000
     f = Amcl(grid, MOTION, LF, AmclParams(min_particles=n, max_particles=n), seed=3)
+    f.set_option("lf_dispersed", 0)  # (the lane-per-particle form first; the default, 2, below)
     f.initialize_from_map()
     states, w0 = f.particles()
     assert np.all(w0 == 1.0)
@@ -1824,4 +1881,13 @@ def test_dispersed_cloud_1m_sampled_against_oracle():
     f.reweight(pts)
     assert f.counter("lf_patch_launches") == 1 and f.counter("lf_beams_launches") == 1
     np.testing.assert_allclose(f.particles()[1], w, rtol=1e-13)
+    # the default, lf_dispersed = 2: the lanes over the beams of a pose, the poses in the position-major order, the bitmap by the
+    # tiles' linear index (k_reweight_lf_far_beams; 1080 beams: 16 full rounds and one of 56)
+    f.set_option("lf_dispersed", 2)
+    f.initialize_from_map()
+    f.reweight(pts)
+    assert f.counter("lf_far_beams_launches") == 1 and f.counter("lf_beams_launches") == 1 and f.counter("lf_patch_launches") == 1
+    got = f.particles()[1]
+    np.testing.assert_allclose(got, w, rtol=1e-13)
+    np.testing.assert_allclose(got[sample], want, rtol=RTOL)
     f.close()
