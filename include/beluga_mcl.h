@@ -398,8 +398,11 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                   16th launch), 0 = never, 2 = always
  *   lf_loose_below (224)  LDS-patch kernel: a workgroup with fewer than this many 256ths of its beam groups fitting a patch
  *                   gathers every look-up (a gathered group inside a patched workgroup costs twice one of an all-gathering one)
- *   lf_dispersed (0)  a set reported as dispersed: 0 = the ordered-lanes gather kernel, 1 = a wave per particle, lanes over the
- *                   beams, no ordering pass (measured slower at 1M x 1080)
+ *   lf_dispersed (2)  a set reported as dispersed: 2 = the lanes of a wave over the beams of one pose, the poses in the position-major
+ *                   order, the far-tile bitmap in LDS (where the bitmap takes at most 32 KB and the scan fits beside it, else as 0),
+ *                   0 = the ordered-lanes gather kernel (a lane per particle; 15 % slower at 1M x 1080), 1 = a wave per particle, lanes
+ *                   over the beams, no ordering pass (slower still).  2 and 1 add a pose's terms as a tree over 64 lane sums: the
+ *                   weights of 0 up to rounding (1e-13 relative).  lf_far_beams_per_wave (0 = 32): poses per wave of 2.
  *   lf_far_tiles (1)  the per-lane gather kernel keeps a bitmap of the table's far tiles in LDS (8x8 cells uniformly at the
  *                   field's most common value: free space beyond max_obstacle_distance of anything) and skips the memory access
  *                   of a look-up into one: 1 = for sets reported as dispersed, 0 = never, 2 = whenever that kernel runs.  Same
@@ -462,6 +465,12 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                   index) alone - are drawn a cycle ahead: 1 = by the draw kernel (whose vector units wait for memory), 2 = by a kernel of its
  *                   own behind the cycle's last one, while the host is away (cycles that end on the completion word); 0 = by the propagation
  *                   kernel itself.  Bit-identical; counter noise_ahead_used.
+ *   order_ahead (1)  fixed-size cycles that end on the completion word (cycle_spin), sets of 64K .. 2M particles: the draw kernel also leaves the
+ *                   ordering key of where each particle will be after the NEXT propagation - with the control action of this cycle as the
+ *                   prediction, first order, single precision -, the ordering passes run behind the cycle's last kernel while the host is
+ *                   away, and the next cycle goes from its propagation straight into the reweight if the action it gets is close to the
+ *                   predicted one (else it orders as before).  Only locality depends on the order.  0 = the ordering inside the cycle.
+ *                   Counters order_ahead_used / order_ahead_missed.
  *   norm_store (0)  fixed-size cycle that resamples at once: 0 = the normalisation kernel does not store the normalised weights (nothing reads
  *                   them), the CDF kernel divides again; 1 = stored.  Bit-identical.
  *   small_fused (1)  sets of up to 4096 particles: everything behind the reweight - normalise, policies, fixed-size or KLD resampling, estimate
@@ -479,7 +488,8 @@ mcl_status mcl_beam_cells_visited(mcl_ctx* ctx, uint64_t* cells, int32_t reset);
  *                    never farther from the truth; falls back to 0 when max_obstacle_distance spans more than 1024 cells).
  *                    This one DOES change the field where the two algorithms differ; everything downstream follows the field.
  * Counters: lf_beams_launches = launches of the wave-per-particle LF kernel (small sets, lf_dispersed, lf_variant 3);
- *   lf_far_launches = those of the gather kernel with the far-tile bitmap, lf_far_tiles = tiles in the bitmap (0 = none built);
+ *   lf_far_launches = those of the gather kernels with the far-tile bitmap (lf_far_beams_launches of them: the lanes-over-beams form,
+ *   lf_dispersed 2), lf_far_tiles = tiles in the bitmap (0 = none built);
  *   lf_fast_launches = launches of the FMA variant so far; lf_patch_launches = those of them sent to the LDS-patch
  *   kernel; lf_patch_groups_planned / lf_patch_groups_through = groups of 8 beams (per workgroup) that kernel has looked at /
  *   has read through a patch, running totals over a sample of the workgroups; lf_queue_launches = launches of the
