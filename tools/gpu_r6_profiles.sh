@@ -60,6 +60,8 @@ python tools/exp_host_time.py 2>/dev/null | tail -n 1 > $O/host_time_per_cycle.t
 python tools/exp_lf_converge.py 2>/dev/null > $O/lf_converge.txt
 timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench.err > $O/bench_1M.json
 python tools/exp_small.py 2>/dev/null > $O/small_filters.txt
+python tools/exp_dispersed.py 32 2>/dev/null > $O/dispersed.txt
+python tools/exp_order_ahead.py 2>/dev/null > $O/order_ahead_counters.txt
 python tools/exp_cluster.py 2>/dev/null > $O/cluster_estimate.txt
 python -m pytest tests -m gpu -q 2>&1 | grep -a "passed\|failed\|error" | tail -3 > $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
