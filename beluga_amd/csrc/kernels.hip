@@ -774,16 +774,9 @@ __global__ __launch_bounds__(kBeamsBlock) void k_reweight_lf_beams(Particles p, 
 // palette kFarBeamsPalShift bytes above its place in the other kernels (the table's entries are LDS addresses from pal_base on; the
 // shift is a constant and rides in the DS instruction's offset field), then the scan (16 bytes per beam, whole rounds of 64).  The
 // bitmap may take up to kFarBeamsPalShift bytes (maps of up to ~4000^2 cells); the rows then fit below the palette whatever H is.
-#ifndef MCL_FB_BLOCK
-#define MCL_FB_BLOCK 768
-#define MCL_FB_WAVES 6
-#define MCL_FB_POSES 2
-#endif
-#ifndef MCL_FB_ABLATE
-#define MCL_FB_ABLATE 0
-#endif
-constexpr int kFarBeamsBlock = MCL_FB_BLOCK;
-constexpr int kFarBeamsPoses = MCL_FB_POSES;
+constexpr int kFarBeamsBlock = 768;  // 12 waves; two workgroups per CU: six waves per SIMD at <= 80 registers
+constexpr int kFarBeamsWaves = 6;
+constexpr int kFarBeamsPoses = 2;    // poses per point read (measured: 1 -> + 5 - 35 %, 4 -> + 25 - 50 %: registers)
 typedef double f64x2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const f64x2_t lds_f64x2_t;
 constexpr uint32_t kFarBeamsPalShift = 32768;
@@ -791,7 +784,7 @@ constexpr uint32_t kFarBeamsChunk = 16;  // poses a wave transforms at a time (<
 // (kProb: the weight is exp(sum) - likelihood_field_prob_model.hpp:77-90; an instance of its own because the exponential's constants, hoisted
 // out of every loop, would otherwise cost the likelihood-field model's instance twenty registers)
 template <bool kProb>
-__global__ __launch_bounds__(kFarBeamsBlock) __attribute__((amdgpu_waves_per_eu(MCL_FB_WAVES, MCL_FB_WAVES))) void k_reweight_lf_far_beams(double* __restrict__ w, uint64_t n, FieldView f,
+__global__ __launch_bounds__(kFarBeamsBlock) __attribute__((amdgpu_waves_per_eu(kFarBeamsWaves, kFarBeamsWaves))) void k_reweight_lf_far_beams(double* __restrict__ w, uint64_t n, FieldView f,
                                                                           const double2* __restrict__ pts, uint32_t B,
                                                                           const uint32_t* __restrict__ perm, const double4* __restrict__ pose,
                                                                           uint32_t pts_at, uint32_t per_wave, uint32_t unit_weights) {
@@ -876,10 +869,9 @@ __global__ __launch_bounds__(kFarBeamsBlock) __attribute__((amdgpu_waves_per_eu(
             const uint32_t row = *reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>((static_cast<uint32_t>(yc) << 2) + row_bias));
             const uint32_t offset = (static_cast<uint32_t>(xc) << 4) + row;
             const uint32_t byte = *reinterpret_cast<lds_u8_t*>(static_cast<uintptr_t>(offset >> 10));
-            uint32_t far = __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(offset, 7, 3), 1);
-            if (MCL_FB_ABLATE & 1) far |= 1u;  // (measurement builds: no look-up reaches memory)
+            const uint32_t far = __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(offset, 7, 3), 1);
             // a far look-up's offset is pushed out of range (the load returns 0 and moves nothing); its entry is the common one
-            const uint32_t loaded = (MCL_FB_ABLATE & 2) ? (offset & 8u) : static_cast<uint32_t>(
+            const uint32_t loaded = static_cast<uint32_t>(
                 static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, offset | (far << 31), 0, 0)));
             e[j] = mad_u24(far, f.far_entry, loaded);
           }
@@ -888,7 +880,7 @@ __global__ __launch_bounds__(kFarBeamsBlock) __attribute__((amdgpu_waves_per_eu(
         auto consume = [&](const uint32_t (&e)[J], bool last) {
 #pragma unroll
           for (int j = 0; j < J; ++j) {
-            double v = (MCL_FB_ABLATE & 8) ? __hiloint2double(static_cast<int>(e[j]), 0) : lf_palette_value(e[j] + kFarBeamsPalShift);
+            double v = lf_palette_value(e[j] + kFarBeamsPalShift);
             if (last) v = dead_last ? 0.0 : v;  // (uniform branch)
             acc[j] += v;
           }
@@ -4210,7 +4202,7 @@ void launch_reweight_lf(hipStream_t st, Particles p, uint64_t n, FieldView f, co
         // lanes over the beams of one pose, the poses in the position-major order (k_reweight_lf_far_beams); a small set needs no
         // segments of the scan to fill the chip: fewer poses per wave
         segments = 1;
-        const uint64_t waves_wanted = 256ull * 4 * MCL_FB_WAVES;
+        const uint64_t waves_wanted = 256ull * 4 * kFarBeamsWaves;
         const uint32_t per_wave_auto = static_cast<uint32_t>(std::min<uint64_t>(32, std::max<uint64_t>(kFarBeamsPoses, n / waves_wanted)));
         const uint32_t per_wave = tuning.lf_far_beams_per_wave > 0 ? static_cast<uint32_t>(tuning.lf_far_beams_per_wave) : per_wave_auto;
         const uint64_t per_block = static_cast<uint64_t>(per_wave) * (kFarBeamsBlock / kWave);

@@ -1297,6 +1297,25 @@ def test_reweight_lf_far_beams_kernel_falls_back_to_the_exact_end_points():
     np.testing.assert_allclose(weights[2], want, rtol=RTOL, atol=0)
     np.testing.assert_allclose(weights[2], weights[0], rtol=1e-13, atol=0)
     f.close()
+    # LikelihoodFieldProbModel (likelihood_field_prob_model.hpp:77-90: the weight is the exponential of the sum of logs): the kernel's other instance
+    from beluga_amd.amcl import LikelihoodFieldProbModelParam
+    g = new_filter(grid, n, sensor=LikelihoodFieldProbModelParam(2.0, 100.0, 0.5, 0.5, 0.2, True))
+    g.set_option("lf_patch", 0)
+    g.set_option("lf_far_tiles", 2)
+    inside = states.copy()
+    inside[2000:2004, 2] -= 1e5
+    got = {}
+    for mode in (2, 0):
+        g.set_option("lf_dispersed", mode)
+        before = g.counter("lf_far_beams_launches")
+        g.set_particles(inside, np.ones(n))
+        g.reweight(pts[:200])
+        assert g.counter("lf_far_beams_launches") == before + (1 if mode == 2 and g.counter("lf_far_tiles") > 0 else 0)
+        got[mode] = g.particles()[1]
+    want = orc.lf_prob_weights(g.likelihood_field(), res, grid.origin, 100.0, inside, pts[:200])
+    np.testing.assert_allclose(got[2], want, rtol=1e-11, atol=0)
+    np.testing.assert_allclose(got[2], got[0], rtol=1e-12, atol=0)
+    g.close()
 
 
 @pytest.mark.parametrize("n", [16_384, 66_667, 200_000, 300_000])
